@@ -1,0 +1,312 @@
+"""TEST INFRASTRUCTURE ONLY — CPU oracle, part 2: restatement of HARP's render-and-compare path.
+
+Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may import this.
+Each function cites the reference file:line it follows (paths relative to /root/reference).
+Same structure as the reference: materialised (B,S,S,K) fragments (oracle.p3d_like), torch autograd
+for the backward pass, torch.optim.Adam for the update.
+
+Pinning status:
+  * mano_forward / batch_rodrigues, kps_loss, arap_loss, albedo_reg / normal_reg are PINNED against
+    the reference itself (imported in the build container by tests/golden/make_golden.py; vectors in
+    tests/golden/*.npz; checked by tests/test_oracle_golden.py).
+  * everything that goes through PyTorch3D (rasteriser, blending, texture sampling, shading, shadow,
+    laplacian, normal consistency) is PARITY UNPINNED (see oracle/p3d_like.py header).
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+from . import p3d_like as P
+
+
+# ----------------------------------------------------------------------------------------------
+# MANO layer  (manopth/manolayer.py:108-296, rodrigues_layer.py:15-54, tensutils.py:6-42)
+# ----------------------------------------------------------------------------------------------
+def quat2mat(quat):
+    """rodrigues_layer.py:15-40"""
+    nq = quat / quat.norm(p=2, dim=1, keepdim=True)
+    w, x, y, z = nq[:, 0], nq[:, 1], nq[:, 2], nq[:, 3]
+    w2, x2, y2, z2 = w.pow(2), x.pow(2), y.pow(2), z.pow(2)
+    wx, wy, wz = w * x, w * y, w * z
+    xy, xz, yz = x * y, x * z, y * z
+    return torch.stack([w2 + x2 - y2 - z2, 2 * xy - 2 * wz, 2 * wy + 2 * xz,
+                        2 * wz + 2 * xy, w2 - x2 + y2 - z2, 2 * yz - 2 * wx,
+                        2 * xz - 2 * wy, 2 * wx + 2 * yz, w2 - x2 - y2 + z2], dim=1).view(-1, 3, 3)
+
+
+def batch_rodrigues(axisang):
+    """rodrigues_layer.py:43-54 (note norm(axisang + 1e-8))."""
+    n = torch.norm(axisang + 1e-8, p=2, dim=1)
+    ang = n.unsqueeze(-1)
+    axis = axisang / ang
+    ang = ang * 0.5
+    quat = torch.cat([torch.cos(ang), torch.sin(ang) * axis], dim=1)
+    return quat2mat(quat).view(-1, 9)
+
+
+MANO_TIPS_RIGHT = [745, 317, 444, 556, 673]                              # manolayer.py:270
+MANO_JOINT_REORDER = [0, 13, 14, 15, 16, 1, 2, 3, 17, 4, 5, 6, 18, 10, 11, 12, 19, 7, 8, 9, 20]  # :279
+
+
+def _with_zeros(t):
+    pad = t.new_tensor([0.0, 0.0, 0.0, 1.0]).view(1, 1, 4).repeat(t.shape[0], 1, 1)
+    return torch.cat([t, pad], 1)
+
+
+def mano_forward(model, pose_coeffs, betas, trans):
+    """ManoLayer(use_pca=False, flat_hand_mean=False, side='right').forward (manolayer.py:108-296).
+    model: dict of v_template (778,3), shapedirs (778,3,10), posedirs (778,3,135), J_regressor (16,778),
+    weights (778,16), hands_mean (45,).  Returns verts (B,778,3) mm, joints (B,21,3) mm."""
+    B = pose_coeffs.shape[0]
+    full_pose = torch.cat([pose_coeffs[:, :3], model["hands_mean"][None] + pose_coeffs[:, 3:48]], 1)  # :139-143
+    rot_map = batch_rodrigues(full_pose.contiguous().view(-1, 3)).view(B, 16 * 9)                   # tensutils.py:6-12
+    pose_map = rot_map - torch.eye(3, dtype=rot_map.dtype).view(1, 9).repeat(B, 16)
+    root_rot = rot_map[:, :9].view(B, 3, 3)                                                          # :150-153
+    rot_map, pose_map = rot_map[:, 9:], pose_map[:, 9:]
+    v_shaped = torch.matmul(model["shapedirs"], betas.transpose(1, 0)).permute(2, 0, 1) + model["v_template"][None]  # :185-187
+    th_j = torch.matmul(model["J_regressor"], v_shaped)                                              # :188
+    v_posed = v_shaped + torch.matmul(model["posedirs"], pose_map.transpose(0, 1)).permute(2, 0, 1)  # :191-192
+    root_j = th_j[:, 0, :].contiguous().view(B, 3, 1)
+    root_trans = _with_zeros(torch.cat([root_rot, root_j], 2))                                       # :202
+    all_rots = rot_map.view(B, 15, 3, 3)
+    l1, l2, l3 = [1, 4, 7, 10, 13], [2, 5, 8, 11, 14], [3, 6, 9, 12, 15]
+    r1, r2, r3 = all_rots[:, [i - 1 for i in l1]], all_rots[:, [i - 1 for i in l2]], all_rots[:, [i - 1 for i in l3]]
+    j1, j2, j3 = th_j[:, l1], th_j[:, l2], th_j[:, l3]
+    transforms = [root_trans.unsqueeze(1)]
+    j1_rel = j1 - root_j.transpose(1, 2)
+    t1 = _with_zeros(torch.cat([r1, j1_rel.unsqueeze(3)], 3).view(-1, 3, 4))
+    root_flt = root_trans.unsqueeze(1).repeat(1, 5, 1, 1).view(B * 5, 4, 4)
+    lev1 = torch.matmul(root_flt, t1)
+    transforms.append(lev1.view(B, 5, 4, 4))
+    t2 = _with_zeros(torch.cat([r2, (j2 - j1).unsqueeze(3)], 3).view(-1, 3, 4))
+    lev2 = torch.matmul(lev1, t2)
+    transforms.append(lev2.view(B, 5, 4, 4))
+    t3 = _with_zeros(torch.cat([r3, (j3 - j2).unsqueeze(3)], 3).view(-1, 3, 4))
+    lev3 = torch.matmul(lev2, t3)
+    transforms.append(lev3.view(B, 5, 4, 4))
+    reorder = [0, 1, 6, 11, 2, 7, 12, 3, 8, 13, 4, 9, 14, 5, 10, 15]                                  # :241
+    results = torch.cat(transforms, 1)[:, reorder]
+    joint_js = torch.cat([th_j, th_j.new_zeros(B, 16, 1)], 2)
+    tmp2 = torch.matmul(results, joint_js.unsqueeze(3))
+    results2 = (results - torch.cat([tmp2.new_zeros(B, 16, 4, 3), tmp2], 3)).permute(0, 2, 3, 1)    # :247
+    th_T = torch.matmul(results2, model["weights"].transpose(0, 1))                                  # :251
+    rest_h = torch.cat([v_posed.transpose(2, 1), v_posed.new_ones(B, 1, v_posed.shape[1])], 1)
+    verts = (th_T * rest_h.unsqueeze(1)).sum(2).transpose(2, 1)[:, :, :3]                            # :260-261
+    jtr = results[:, :, :3, 3]
+    jtr = torch.cat([jtr, verts[:, MANO_TIPS_RIGHT]], 1)[:, MANO_JOINT_REORDER]
+    if not bool(torch.norm(trans) == 0):                                                             # :281
+        jtr = jtr + trans.unsqueeze(1)
+        verts = verts + trans.unsqueeze(1)
+    return verts * 1000, jtr * 1000
+
+
+# ----------------------------------------------------------------------------------------------
+# Scene assembly (utils/visualize.py:16-108)
+# ----------------------------------------------------------------------------------------------
+def prepare_mesh(params, fid, model, topo):
+    """utils/visualize.py:16-88, MANO branch, with subdivision + normal displacement.
+    topo: dict with edges0 (E0,2), faces (F,3) long (subdivided). Returns joints (B,21,3) m, verts (B,V,3) m."""
+    B = fid.shape[0]
+    pose_b, rot_b = params["pose"][fid], params["rot"][fid]                                          # :26-27
+    verts, joints = mano_forward(model, torch.cat((rot_b, pose_b), 1), params["shape"].repeat([B, 1]),
+                                 params["trans"][fid])                                               # :42-44
+    verts, joints = verts / 1000.0, joints / 1000.0                                                  # :45-46
+    e = topo["edges0"]
+    verts = torch.cat([verts, verts[:, e].mean(2)], 1)                                               # SubdivideMeshes (:52)
+    n = P.verts_normals(verts, topo["faces"])
+    verts = verts + n * params["verts_disps"].repeat(B, 1, 1)                                        # :58-64
+    return joints, verts
+
+
+def camera_RT(cam, S, focal):
+    """utils/visualize.py:268-271 / renderer_helper.py:455-459."""
+    T = torch.stack([-cam[:, 1], -cam[:, 2], 2 * focal / (S * cam[:, 0] + 1e-9)], dim=1)
+    R = torch.tensor([[-1., 0., 0.], [0., -1., 0.], [0., 0., 1.]], dtype=cam.dtype).repeat(cam.shape[0], 1, 1)
+    return R, T
+
+
+def render_silhouette(verts, faces, cam, S, focal, sigma=1e-7, K=50):
+    """render_image(..., silhouette=True) (utils/visualize.py:258-285) with the silhouette renderer of
+    renderer_helper.py:33-58. Returns alpha (B,S,S)."""
+    R, T = camera_RT(cam, S, focal)
+    _, ndc = P.world_to_ndc(verts, R, T, focal, (S / 2.0, S / 2.0), S)
+    blur = math.log(1.0 / 1e-4 - 1.0) * sigma
+    p2f, zbuf, bary, dists = P.rasterize_meshes(ndc, faces, S, blur, K)
+    return P.sigmoid_alpha_blend(p2f, dists, sigma)
+
+
+def process_info_for_shadow(cam, light_positions, center, S, focal):
+    """renderer_helper.py:454-468."""
+    cam_R, cam_T = camera_RT(cam, S, focal)
+    radius = 1.5
+    d = light_positions - center
+    pos = center + d * (radius / torch.linalg.norm(d, dim=1, keepdim=True))
+    up = torch.tensor([[0.0, 1.0, 0.0]], dtype=cam.dtype)
+    light_R = P.look_at_rotation(pos, center, up)
+    light_T = -torch.bmm(light_R.transpose(1, 2), pos[:, :, None])[:, :, 0]
+    return light_R, light_T, cam_R, cam_T
+
+
+def compute_tangent(normals):
+    """pbr_materials.py:58-77."""
+    x, y, z = normals[..., 0], normals[..., 1], normals[..., 2]
+    s = (2 * (z >= 0)) - 1.0
+    a = -1 / (s + z)
+    b = x * y * a
+    uv = torch.stack((1 + s * x * x * a, s * b, -s * x, b, s + y * y * a, -y), dim=-1)
+    return uv.view(uv.shape[:-1] + (2, 3))
+
+
+def apply_normal_map(pixel_normals, nm):
+    """pbr_materials.py:82-124; nm = sampled normal-map texels (N,H,W,K,3)."""
+    tangent = compute_tangent(pixel_normals)
+    TBN = torch.cat([-tangent, pixel_normals.unsqueeze(4)], dim=4)
+    out = torch.matmul(TBN.transpose(-1, -2).reshape(-1, 3, 3), nm.reshape(-1, 3, 1)).reshape(pixel_normals.shape)
+    return F.normalize(out, dim=-1)
+
+
+def render_rgb(verts, topo, params, cam, S, focal, self_shadow=True, light_positions=None, return_aux=False):
+    """RGB pass. self_shadow=True: render_image_with_RT + MeshRendererShadow.forward + SoftPhongShaderShadow
+    (utils/visualize.py:288-319, renderer_helper.py:331-412, 472-523, 565-592). self_shadow=False: render_image
+    with the phong renderer (renderer_helper.py:60-81, 106-190). Returns (B,S,S,3)."""
+    B = verts.shape[0]
+    dt = verts.dtype
+    faces = topo["faces"]
+    Fn = faces.shape[0]
+    pp = (S / 2.0, S / 2.0)
+    if light_positions is None:
+        light_positions = params["light_positions"][0].repeat(B, 1)                                 # optimize_sequence.py:453-454
+    texture = params["texture"][None, 0].repeat(B, 1, 1, 1)                                          # visualize.py:81
+    nmap = F.normalize(params["normal_map"][None, 0].repeat(B, 1, 1, 1), dim=-1)                     # visualize.py:94-99
+    vn = P.verts_normals(verts, faces)                                                               # renderer_helper.py:495
+    fverts = verts[:, faces].reshape(B * Fn, 3, 3)
+    fnorm = vn[:, faces].reshape(B * Fn, 3, 3)
+    if self_shadow:
+        light_R, light_T, cam_R, cam_T = process_info_for_shadow(cam, light_positions, verts.mean(1), S, focal)
+        _, ndc_l = P.world_to_ndc(verts, light_R, light_T, focal, pp, S)
+        _, zbuf_l, _, _ = P.rasterize_meshes(ndc_l, faces, S, 0.0, 1)                                # :344
+        amb = torch.sigmoid(params["amb_ratio"])                                                     # optimize_sequence.py:480
+        ambient = amb * torch.ones(1, 3, dtype=dt)                                                   # :435-441
+        diffuse_c = 1.0 - ambient
+        specular = torch.zeros(1, 3, dtype=dt)
+    else:
+        cam_R, cam_T = camera_RT(cam, S, focal)
+        ambient = torch.full((1, 3), 0.5, dtype=dt)                                                  # :70-73
+        diffuse_c = torch.full((1, 3), 0.4, dtype=dt)
+        specular = torch.full((1, 3), 0.1, dtype=dt)   # shininess=0 -> pow(.,0)=1 -> constant
+    _, ndc = P.world_to_ndc(verts, cam_R, cam_T, focal, pp, S)
+    p2f, zbuf, bary, dists = P.rasterize_meshes(ndc, faces, S, 0.0, 1)                               # :353
+    pix_pos = P.interpolate_face_attributes(p2f, bary, fverts)                                       # :364 / :498
+    if self_shadow:
+        N_, H, W, Kk, _ = pix_pos.shape
+        flat = pix_pos.reshape(N_, H * W * Kk, 3)
+        in_light = torch.bmm(flat, light_R) + light_T[:, None, :]                                   # :379-380
+        xs, ys = P.view_to_screen_xy(in_light, focal, pp, S)                                         # :382
+        xk = xs.round().long().reshape(-1)                                                           # :385
+        yk = ys.round().long().reshape(-1)
+        bk = torch.arange(B).repeat_interleave(H * W * Kk)
+        vis = torch.zeros_like(zbuf_l)
+        for ii in (-1, 0, 1):                                                                        # :394-406
+            for jj in (-1, 0, 1):
+                d_at = zbuf_l[bk, (yk + ii).clamp(0, S - 1), (xk + jj).clamp(0, S - 1), 0].reshape(N_, H, W, Kk)
+                aa = in_light.reshape(N_, H, W, Kk, 3)[..., 2] - 0.008
+                vis = vis + torch.sigmoid((d_at - aa) * 1000.0)
+        vis = vis / 9.0                                                                              # :408
+    texels = P.sample_textures_uv(texture, params["verts_uvs"], params["faces_uvs"], p2f, bary, Fn)  # :572
+    pix_n = P.interpolate_face_attributes(p2f, bary, fnorm)                                          # :501-503
+    nm = P.sample_textures_uv(nmap, params["verts_uvs"], params["faces_uvs"], p2f, bary, Fn)         # pbr_materials.py:110
+    pix_n = apply_normal_map(pix_n, nm)                                                              # :505-511
+    diff = P.point_light_diffuse(pix_pos, pix_n, light_positions[:, None, None, None, :], diffuse_c[:, None, None, None, :])
+    amb_b = ambient[:, None, None, None, :]
+    if self_shadow:
+        colors = (amb_b + diff * vis[..., None]) * texels + specular[:, None, None, None, :]        # :517-518
+    else:
+        colors = (amb_b + diff) * texels + specular[:, None, None, None, :]                          # :188
+    img = P.softmax_rgb_blend(colors, p2f, zbuf, dists)                                              # :589-591
+    if return_aux:
+        aux = {"pix_to_face": p2f, "zbuf": zbuf, "bary": bary}
+        if self_shadow:
+            aux.update(zbuf_light=zbuf_l, vis=vis, light_R=light_R, light_T=light_T)
+        return img[..., :3], aux
+    return img[..., :3]
+
+
+# ----------------------------------------------------------------------------------------------
+# Losses (loss/*.py, optimize_sequence.py:517-553)
+# ----------------------------------------------------------------------------------------------
+def kps_loss(gt_kps, pred_kps, use_arm=False):
+    """loss/kps_loss.py:4-17."""
+    if use_arm:
+        pred_kps = pred_kps[:, :21, :]
+    gt = gt_kps - gt_kps[:, 0, None, :]
+    pr = (pred_kps - pred_kps[:, 0, None, :]) * 1000.0
+    return torch.mean((torch.norm(gt - pr, dim=2) / 100.0) ** 2.0)
+
+
+def arap_loss(verts, ref_verts, edges):
+    """loss/arap.py:4-57 on (B,V,3) verts, (1,V,3) reference verts, (E,2) edges."""
+    N = verts.shape[0]
+    e = edges.long()
+    v0, v1 = verts[:, e[:, 0]], verts[:, e[:, 1]]
+    r0, r1 = ref_verts[:, e[:, 0]], ref_verts[:, e[:, 1]]
+    loss = ((v0 - v1).norm(dim=-1, p=2) * 1000.0 - (r0 - r1).norm(dim=-1, p=2) * 1000.0) ** 2.0
+    return (loss * (1.0 / e.shape[0])).sum() / N
+
+
+def _smooth_reg(tex, dist, uv_mask):
+    """loss/texture_reg.py:11-30 / 48-66 with the random integer offsets passed in."""
+    t = tex.squeeze(0)
+    H, W = t.shape[:2]
+    gx, gy = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
+    tx = torch.clamp(gx + dist[:, :, 0], 0, H - 1)
+    ty = torch.clamp(gy + dist[:, :, 1], 0, W - 1)
+    diff = torch.norm(t - t[tx, ty], p=1, dim=2) / 3.0
+    if uv_mask is not None:
+        diff = diff * uv_mask.to(diff.dtype)
+    return diff.mean()
+
+
+def albedo_reg(uv_texture, dist, uv_mask=None):
+    """loss/texture_reg.py:5-30; dist = torch.normal(0,std,(H,W,2)).to(torch.int)."""
+    return _smooth_reg(uv_texture, dist, uv_mask)
+
+
+def close_to_z_reg(normal_map):
+    """loss/texture_reg.py:40-45 (norm over dim=2 of the un-squeezed (1,H,W,3) tensor: SURVEY Appendix C.2)."""
+    diff = torch.norm(normal_map - torch.tensor([0.0, 0.0, 1.0], dtype=normal_map.dtype), p=2, dim=2) / 3.0
+    return diff.mean()
+
+
+def normal_reg(normal_map, dist, uv_mask=None):
+    """loss/texture_reg.py:33-37."""
+    return 0.2 * close_to_z_reg(normal_map) + _smooth_reg(normal_map, dist, uv_mask)
+
+
+LOSS_WEIGHTS = {"silhouette": 7.0, "kps_anchor": 10.0, "vert_disp_reg": 2.0, "normal": 0.1, "laplacian": 4.0,
+                "arap": 0.2, "photo": 1.0, "albedo": 0.5, "normal_reg": 0.1}       # optimize_sequence.py:411-422 (vgg excluded)
+
+
+def step_losses(params, fid, model, topo, targets, S, focal, ref_verts, dist_albedo, dist_normal,
+                coarse=True, app=True, self_shadow=True):
+    """Loop body optimize_sequence.py:446-558 (VGG term excluded: SURVEY §8(f)). Returns (dict, weighted sum,
+    aux dict with images)."""
+    y_true, y_sil_true, y_sil_col = targets["y_true"][fid], targets["y_sil"][fid], targets["y_sil_col"][fid]
+    joints, verts = prepare_mesh(params, fid, model, topo)
+    cam = params["cam"][fid]
+    y_sil_pred = render_silhouette(verts, topo["faces"], cam, S, focal)
+    y_pred = render_rgb(verts, topo, params, cam, S, focal, self_shadow=self_shadow)
+    loss = {}
+    if coarse:
+        loss["silhouette"] = F.l1_loss(y_sil_true, y_sil_pred)                                      # :519
+        loss["kps_anchor"] = kps_loss(params["init_joints"][fid], joints)                           # :524
+        loss["vert_disp_reg"] = torch.sum(params["verts_disps"] ** 2.0)                             # :533
+        loss["laplacian"] = P.mesh_laplacian_smoothing_uniform(verts, topo["nbr_off"], topo["nbr_idx"])   # :536
+        loss["normal"] = P.mesh_normal_consistency(verts, topo["nc_pairs"])                         # :537
+        loss["arap"] = arap_loss(verts, ref_verts, topo["edges"])                                   # :539
+    if app:
+        loss["photo"] = F.l1_loss(y_true * y_sil_col.unsqueeze(-1), y_pred * y_sil_col.unsqueeze(-1))  # :543
+        loss["albedo"] = albedo_reg(params["texture"], dist_albedo, params["uv_mask"])              # :552
+        loss["normal_reg"] = normal_reg(params["normal_map"], dist_normal, params["uv_mask"])       # :553
+    total = sum(l * LOSS_WEIGHTS[k] for k, l in loss.items())                                        # :556-558
+    return loss, total, {"y_sil_pred": y_sil_pred, "y_pred": y_pred, "verts": verts, "joints": joints}
