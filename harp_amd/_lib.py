@@ -1,0 +1,54 @@
+"""ctypes binding of the C-ABI library (include/harp_hip.h).  No CPU fallback: if the library is missing
+or a call fails, raise — the product path must never silently run anything else."""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libharp_hip.so")
+
+_vp, _i, _f, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
+
+# name -> (restype, argtypes); must list every symbol include/harp_hip.h declares (tests/test_abi.py checks)
+SIGNATURES = {
+    "harp_rasterize_ws_bytes": (_sz, [_i, _i, _i]),
+    "harp_rasterize_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _vp]),
+    "harp_silhouette_bwd": (_i, [_vp, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _vp]),
+}
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"HIP library not built: {LIB_PATH} (run `python -m harp_amd.build`); "
+                               "harp_amd has no CPU fallback")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = L
+    return _lib
+
+
+def ptr(t):
+    """Raw device pointer of a contiguous CUDA(HIP) tensor, or NULL for None."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("harp_amd ops need HIP device tensors (no CPU path)")
+    if not t.is_contiguous():
+        raise RuntimeError("harp_amd ops need contiguous tensors")
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def check(code, what):
+    if code != 0:
+        raise RuntimeError(f"{what} failed with status {code}")

@@ -1,0 +1,57 @@
+// Shared device helpers for the gfx950 (CDNA4, wave64) kernels of the HARP render-and-compare path.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define HARP_OK 0
+#define HARP_ERR_ARG 1
+#define HARP_ERR_LAUNCH 2
+
+#define HARP_CHECK_LAUNCH()                                   \
+  do {                                                        \
+    hipError_t e__ = hipGetLastError();                       \
+    if (e__ != hipSuccess) return HARP_ERR_LAUNCH + (int)e__; \
+  } while (0)
+
+constexpr float kEps = 1e-8f;      // PyTorch3D kEpsilon
+constexpr int kWave = 64;          // gfx950 wavefront
+
+// Screen tiling shared by the binning and raster kernels: 64x64-px super-tiles hold the coarse face
+// lists; a workgroup of 4 waves owns a 16x16 tile, each wave a 16x4 strip (64-B output rows).
+constexpr int kSuper = 64;
+constexpr int kTile = 16;
+
+// Per-face setup record (64 B, one float4-aligned struct per (frame, face)).
+struct FaceRec {
+  float4 a;   // x0 y0 z0 x1
+  float4 b;   // y1 z1 x2 y2
+  float4 c;   // z2 face_area - -
+  float4 bb;  // xmin-r xmax+r ymin-r ymax+r   (empty box => culled face)
+};
+
+__device__ __forceinline__ float pix_to_ndc(int i, int S) {
+  // pixel index -> NDC of its centre; PyTorch3D flips both axes: pixel 0 is at +1-1/S.
+  return -1.0f + (2.0f * (float)(S - 1 - i) + 1.0f) / (float)S;
+}
+
+__device__ __forceinline__ float edge_fn(float px, float py, float ax, float ay, float bx, float by) {
+  return (px - ax) * (by - ay) - (py - ay) * (bx - ax);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// Block-wide sum for blockDim.x == 256 (4 waves); result valid in thread 0.
+__device__ __forceinline__ float block_sum_256(float v, float* lds4) {
+  v = wave_sum(v);
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) lds4[w] = v;
+  __syncthreads();
+  float r = 0.f;
+  if (threadIdx.x == 0) r = lds4[0] + lds4[1] + lds4[2] + lds4[3];
+  __syncthreads();
+  return r;
+}

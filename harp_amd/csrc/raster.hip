@@ -1,0 +1,330 @@
+// Tile rasteriser for gfx950: replaces PyTorch3D's rasterize_meshes (coarse+fine) and, fused into the same
+// per-pixel face walk, SoftSilhouetteShader/sigmoid_alpha_blend.
+//   reference call sites: renderer/renderer_helper.py:52-58 (K=50 soft silhouette), :76-79 / :444-447 (K=1),
+//   :344, :353 (light view, camera view).  Semantics: SURVEY.md Appendix A.2/A.3.
+//
+// Design (not PyTorch3D's): nothing of shape (B,S,S,K) is ever materialised.
+//   1. face_setup   one thread per (frame, face): gather 3 NDC vertices, write a 64-B FaceRec with the
+//                   blur-dilated bbox; culled faces get an empty box.
+//   2. bin_faces    one workgroup per (frame, 64x64 super-tile): scan the frame's bboxes (coalesced float4),
+//                   wave-ballot compaction -> ascending face-id list in HBM/L2 (deterministic, no atomics).
+//   3. raster       one workgroup (4 waves) per 16x16 tile, one pixel per lane (wave = 16x4 strip).
+//                   Stages the tile's faces into LDS (SoA float4, broadcast reads), each wave ballots the
+//                   staged faces against its own strip and walks only the hits.  Per pixel, in registers:
+//                   nearest-z face (K=1 semantics, ties -> lower face id like PyTorch3D) and the running
+//                   silhouette product prod_f (1 - sigmoid(-d_f/sigma)).
+//   4. sil_bwd      same walk, rim pixels only: dL/dalpha -> dL/d(ndc xy) of the face vertices (atomics).
+#include "harp_common.h"
+
+namespace {
+
+constexpr int kStage = 256;   // faces staged in LDS per round (17 KB)
+
+struct Tri {
+  float x0, y0, z0, x1, y1, z1, x2, y2, z2;
+};
+
+__device__ __forceinline__ Tri tri_from(const float4 a, const float4 b, const float4 c) {
+  Tri t;
+  t.x0 = a.x; t.y0 = a.y; t.z0 = a.z; t.x1 = a.w;
+  t.y1 = b.x; t.z1 = b.y; t.x2 = b.z; t.y2 = b.w;
+  t.z2 = c.x;
+  return t;
+}
+
+// BarycentricCoordsForward + BarycentricPerspectiveCorrectionForward; returns "inside" (all bary > 0).
+__device__ __forceinline__ bool tri_bary(const Tri& t, float px, float py, float& b0, float& b1, float& b2) {
+  const float area = edge_fn(t.x2, t.y2, t.x0, t.y0, t.x1, t.y1) + kEps;
+  const float w0 = edge_fn(px, py, t.x1, t.y1, t.x2, t.y2) / area;
+  const float w1 = edge_fn(px, py, t.x2, t.y2, t.x0, t.y0) / area;
+  const float w2 = edge_fn(px, py, t.x0, t.y0, t.x1, t.y1) / area;
+  const float t0 = w0 * t.z1 * t.z2, t1 = t.z0 * w1 * t.z2, t2 = t.z0 * t.z1 * w2;
+  const float den = fmaxf(t0 + t1 + t2, kEps);
+  b0 = t0 / den; b1 = t1 / den; b2 = t2 / den;
+  return b0 > 0.f && b1 > 0.f && b2 > 0.f;
+}
+
+// PointLineDistanceForward: squared distance to segment (a,b); also returns the clamped parameter t.
+__device__ __forceinline__ float seg_dist2(float px, float py, float ax, float ay, float bx, float by, float& tt) {
+  const float bax = bx - ax, bay = by - ay;
+  const float l2 = bax * bax + bay * bay;
+  if (l2 <= kEps) { tt = 1.f; return (px - bx) * (px - bx) + (py - by) * (py - by); }
+  float t = (bax * (px - ax) + bay * (py - ay)) / l2;
+  t = fminf(fmaxf(t, 0.f), 1.f);
+  tt = t;
+  const float qx = ax + t * bax, qy = ay + t * bay;
+  return (px - qx) * (px - qx) + (py - qy) * (py - qy);
+}
+
+__global__ void __launch_bounds__(256) face_setup_kernel(const float* __restrict__ ndc, const int32_t* __restrict__ faces,
+                                                         int V, int F, float r, FaceRec* __restrict__ recs) {
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  const int b = blockIdx.y;
+  if (f >= F) return;
+  const int i0 = faces[3 * f], i1 = faces[3 * f + 1], i2 = faces[3 * f + 2];
+  const float* vb = ndc + (size_t)b * V * 3;
+  Tri t;
+  t.x0 = vb[3 * i0]; t.y0 = vb[3 * i0 + 1]; t.z0 = vb[3 * i0 + 2];
+  t.x1 = vb[3 * i1]; t.y1 = vb[3 * i1 + 1]; t.z1 = vb[3 * i1 + 2];
+  t.x2 = vb[3 * i2]; t.y2 = vb[3 * i2 + 1]; t.z2 = vb[3 * i2 + 2];
+  const float area = edge_fn(t.x0, t.y0, t.x1, t.y1, t.x2, t.y2);
+  const float zmax = fmaxf(t.z0, fmaxf(t.z1, t.z2)), zmin = fminf(t.z0, fminf(t.z1, t.z2));
+  // skipped for every pixel: behind camera, |area| <= eps, any vertex with z < eps (z_invalid), non-finite
+  const bool cull = (zmax < 0.f) || (area <= kEps && area >= -kEps) || (zmin < kEps) || !(area == area);
+  FaceRec rec;
+  rec.a = make_float4(t.x0, t.y0, t.z0, t.x1);
+  rec.b = make_float4(t.y1, t.z1, t.x2, t.y2);
+  rec.c = make_float4(t.z2, area, 0.f, 0.f);
+  if (cull) {
+    rec.bb = make_float4(3.0e38f, -3.0e38f, 3.0e38f, -3.0e38f);
+  } else {
+    rec.bb = make_float4(fminf(t.x0, fminf(t.x1, t.x2)) - r, fmaxf(t.x0, fmaxf(t.x1, t.x2)) + r,
+                         fminf(t.y0, fminf(t.y1, t.y2)) - r, fmaxf(t.y0, fmaxf(t.y1, t.y2)) + r);
+  }
+  recs[(size_t)b * F + f] = rec;
+}
+
+// Ascending-order compaction of `pred` across a 256-thread block. Returns this thread's slot (or -1) and
+// advances *running (uniform). lds_cnt: 4 ints.
+__device__ __forceinline__ int block_compact(bool pred, int running, int* lds_cnt, int& total) {
+  const unsigned long long m = __ballot(pred);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) lds_cnt[w] = __popcll(m);
+  __syncthreads();
+  int base = running;
+  for (int i = 0; i < w; ++i) base += lds_cnt[i];
+  total = lds_cnt[0] + lds_cnt[1] + lds_cnt[2] + lds_cnt[3];
+  const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+  __syncthreads();
+  return pred ? pos : -1;
+}
+
+__global__ void __launch_bounds__(256) bin_faces_kernel(const FaceRec* __restrict__ recs, int F, int S, int nsx,
+                                                        int32_t* __restrict__ bins, int32_t* __restrict__ bin_count) {
+  __shared__ int lds_cnt[4];
+  const int st = blockIdx.x, b = blockIdx.y;
+  const int sx = st % nsx, sy = st / nsx;
+  const int x_lo = sx * kSuper, x_hi = min(x_lo + kSuper, S) - 1;
+  const int y_lo = sy * kSuper, y_hi = min(y_lo + kSuper, S) - 1;
+  // NDC decreases with pixel index
+  const float nx_hi = pix_to_ndc(x_lo, S), nx_lo = pix_to_ndc(x_hi, S);
+  const float ny_hi = pix_to_ndc(y_lo, S), ny_lo = pix_to_ndc(y_hi, S);
+  const FaceRec* rb = recs + (size_t)b * F;
+  int32_t* out = bins + ((size_t)b * gridDim.x + st) * F;
+  int running = 0;
+  for (int base = 0; base < F; base += 256) {
+    const int f = base + threadIdx.x;
+    bool hit = false;
+    if (f < F) {
+      const float4 bb = rb[f].bb;
+      hit = !(nx_lo > bb.y || nx_hi < bb.x || ny_lo > bb.w || ny_hi < bb.z);
+    }
+    int total;
+    const int pos = block_compact(hit, running, lds_cnt, total);
+    if (pos >= 0) out[pos] = f;
+    running += total;
+  }
+  if (threadIdx.x == 0) bin_count[b * gridDim.x + st] = running;
+}
+
+// MODE 0: depth only (light view).  MODE 1: nearest face + silhouette product (camera view).
+// MODE 2: silhouette backward (rim pixels): scatter dL/d(ndc xy).
+template <int MODE>
+__global__ void __launch_bounds__(256) raster_kernel(const FaceRec* __restrict__ recs, const int32_t* __restrict__ bins,
+                                                     const int32_t* __restrict__ bin_count, int F, int S, int nsx,
+                                                     float blur, float sigma, int32_t* __restrict__ face_id,
+                                                     float* __restrict__ zbuf, float* __restrict__ alpha,
+                                                     const float* __restrict__ g_alpha, const int32_t* __restrict__ faces,
+                                                     int V, float* __restrict__ g_ndc) {
+  __shared__ float4 s_a[kStage], s_b[kStage], s_bb[kStage];
+  __shared__ float s_z2[kStage];
+  __shared__ int32_t s_id[kStage];
+  __shared__ int lds_cnt[4];
+
+  const int b = blockIdx.z;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int tx0 = blockIdx.x * kTile, ty0 = blockIdx.y * kTile;
+  const int xi = tx0 + (lane & 15), yi = ty0 + w * 4 + (lane >> 4);
+  const bool in_img = (xi < S) && (yi < S);
+  const float px = pix_to_ndc(xi, S), py = pix_to_ndc(yi, S);
+  const int st = (ty0 / kSuper) * nsx + (tx0 / kSuper);
+  const int nst = nsx * nsx;
+  const int n = bin_count[b * nst + st];
+  const int32_t* list = bins + ((size_t)b * nst + st) * F;
+  const FaceRec* rb = recs + (size_t)b * F;
+
+  // tile and wave-strip bounds in NDC (conservative supersets of the per-pixel bbox test)
+  const float t_xhi = pix_to_ndc(tx0, S), t_xlo = pix_to_ndc(min(tx0 + kTile, S) - 1, S);
+  const float t_yhi = pix_to_ndc(ty0, S), t_ylo = pix_to_ndc(min(ty0 + kTile, S) - 1, S);
+  const float w_yhi = pix_to_ndc(ty0 + w * 4, S), w_ylo = pix_to_ndc(ty0 + w * 4 + 3, S);
+
+  float best_z = 3.0e38f;
+  int best_f = -1;
+  float prod = 1.0f;
+  float P = 0.f, ga = 0.f;
+  bool need = in_img;
+  if (MODE == 2) {
+    if (in_img) {
+      const size_t o = ((size_t)b * S + yi) * S + xi;
+      P = 1.0f - alpha[o];
+      ga = g_alpha[o];
+    }
+    need = in_img && (P != 0.f) && (ga != 0.f);
+    // whole tile saturated / no upstream gradient -> nothing to do
+    if (__syncthreads_or(need ? 1 : 0) == 0) return;
+  }
+
+  for (int base = 0; base < n; base += kStage) {
+    // ---- stage: filter this round's list entries against the 16x16 tile, compact into LDS
+    const int e = base + threadIdx.x;
+    bool hit = false;
+    int id = 0;
+    float4 bb;
+    if (e < n) {
+      id = list[e];
+      bb = rb[id].bb;
+      hit = !(t_xlo > bb.y || t_xhi < bb.x || t_ylo > bb.w || t_yhi < bb.z);
+    }
+    int nl;
+    const int pos = block_compact(hit, 0, lds_cnt, nl);
+    if (pos >= 0) {
+      const FaceRec r = rb[id];
+      s_a[pos] = r.a; s_b[pos] = r.b; s_z2[pos] = r.c.x; s_bb[pos] = bb; s_id[pos] = id;
+    }
+    __syncthreads();
+    // ---- walk: each wave ballots the staged faces against its 16x4 strip
+    for (int g = 0; g < nl; g += 64) {
+      const int i = g + lane;
+      bool whit = false;
+      if (i < nl) {
+        const float4 q = s_bb[i];
+        whit = !(t_xlo > q.y || t_xhi < q.x || w_ylo > q.w || w_yhi < q.z);
+      }
+      unsigned long long m = __ballot(whit);
+      while (m) {
+        const int j = g + __ffsll((unsigned long long)m) - 1;
+        m &= m - 1;
+        const float4 q = s_bb[j];
+        const bool inbox = !(px > q.y || px < q.x || py > q.w || py < q.z);
+        if (!__any(inbox && need)) continue;
+        const float4 fa = s_a[j], fb = s_b[j];
+        Tri t = tri_from(fa, fb, make_float4(s_z2[j], 0.f, 0.f, 0.f));
+        float b0, b1, b2;
+        const bool inside = tri_bary(t, px, py, b0, b1, b2);
+        if (MODE != 2) {
+          if (inside && inbox && in_img) {
+            const float pz = b0 * t.z0 + b1 * t.z1 + b2 * t.z2;
+            if (pz >= 0.f && pz < best_z) { best_z = pz; best_f = s_id[j]; }
+          }
+        }
+        if (MODE >= 1) {
+          const bool active = (MODE == 1) ? (inbox && in_img && prod != 0.f) : (inbox && need);
+          if (active) {
+            float ta, tb, tc;
+            const float d01 = seg_dist2(px, py, t.x0, t.y0, t.x1, t.y1, ta);
+            const float d02 = seg_dist2(px, py, t.x0, t.y0, t.x2, t.y2, tb);
+            const float d12 = seg_dist2(px, py, t.x1, t.y1, t.x2, t.y2, tc);
+            const float dist = fminf(d01, fminf(d02, d12));
+            if (inside || dist < blur) {
+              const float sd = inside ? -dist : dist;
+              const float p = 1.0f / (1.0f + expf(sd / sigma));   // sigmoid(-sd/sigma)
+              if (MODE == 1) {
+                prod *= (1.0f - p);
+              } else {
+                // d alpha / d sd = -P * p / sigma  (P = prod over all faces)
+                const float g_sd = ga * (-P * p / sigma);
+                const float gd = inside ? -g_sd : g_sd;     // d/d(dist^2)
+                // PointLineDistanceBackward on the argmin edge (t treated as constant)
+                int ia, ib; float ax, ay, bx, by, tt;
+                if (d01 <= d02 && d01 <= d12) { ia = 0; ib = 1; ax = t.x0; ay = t.y0; bx = t.x1; by = t.y1; tt = ta; }
+                else if (d02 <= d12)          { ia = 0; ib = 2; ax = t.x0; ay = t.y0; bx = t.x2; by = t.y2; tt = tb; }
+                else                          { ia = 1; ib = 2; ax = t.x1; ay = t.y1; bx = t.x2; by = t.y2; tt = tc; }
+                const float qx = ax + tt * (bx - ax), qy = ay + tt * (by - ay);
+                const float cx = gd * 2.f * (qx - px), cy = gd * 2.f * (qy - py);
+                const int fid = s_id[j];
+                const int va = faces[3 * fid + ia], vb2 = faces[3 * fid + ib];
+                float* gb = g_ndc + (size_t)b * V * 3;
+                atomicAdd(gb + 3 * va, (1.f - tt) * cx);
+                atomicAdd(gb + 3 * va + 1, (1.f - tt) * cy);
+                atomicAdd(gb + 3 * vb2, tt * cx);
+                atomicAdd(gb + 3 * vb2 + 1, tt * cy);
+              }
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  if (MODE != 2 && in_img) {
+    const size_t o = ((size_t)b * S + yi) * S + xi;
+    face_id[o] = best_f;
+    if (zbuf) zbuf[o] = (best_f >= 0) ? best_z : -1.0f;
+    if (MODE == 1) alpha[o] = 1.0f - prod;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t harp_rasterize_ws_bytes(int B, int F, int S) {
+  const int nsx = (S + kSuper - 1) / kSuper;
+  size_t recs = (size_t)B * F * sizeof(FaceRec);
+  size_t bins = (size_t)B * nsx * nsx * F * sizeof(int32_t);
+  size_t cnt = (((size_t)B * nsx * nsx * sizeof(int32_t)) + 255) / 256 * 256;
+  return recs + bins + cnt;
+}
+
+static void ws_split(void* ws, int B, int F, int S, FaceRec** recs, int32_t** bins, int32_t** cnt) {
+  const int nsx = (S + kSuper - 1) / kSuper;
+  char* p = (char*)ws;
+  *recs = (FaceRec*)p;
+  p += (size_t)B * F * sizeof(FaceRec);
+  *bins = (int32_t*)p;
+  p += (size_t)B * nsx * nsx * F * sizeof(int32_t);
+  *cnt = (int32_t*)p;
+}
+
+// Forward rasterisation of B frames sharing one face table.
+//   ndc (B,V,3) f32 [x_ndc, y_ndc, z_view]; faces (F,3) i32.
+//   soft != 0: also accumulate the soft-silhouette alpha (blur_radius, sigma as in renderer_helper.py:44-58).
+//   Outputs (B,S,S): face_id i32 (frame-local, -1 empty), zbuf f32 or NULL (-1 empty), alpha f32 (soft only).
+//   ws: harp_rasterize_ws_bytes() bytes, 256-B aligned; must stay untouched until the matching backward ran.
+int harp_rasterize_fwd(const float* ndc, const int32_t* faces, int B, int V, int F, int S, int soft, float blur_radius,
+                       float sigma, void* ws, int32_t* face_id, float* zbuf, float* alpha, hipStream_t stream) {
+  if (!ndc || !faces || !ws || !face_id || B <= 0 || F <= 0 || S <= 0 || (soft && !alpha)) return HARP_ERR_ARG;
+  FaceRec* recs; int32_t *bins, *cnt;
+  ws_split(ws, B, F, S, &recs, &bins, &cnt);
+  const int nsx = (S + kSuper - 1) / kSuper;
+  const float r = soft ? sqrtf(blur_radius) : 0.f;
+  hipLaunchKernelGGL(face_setup_kernel, dim3((F + 255) / 256, B), dim3(256), 0, stream, ndc, faces, V, F, r, recs);
+  hipLaunchKernelGGL(bin_faces_kernel, dim3(nsx * nsx, B), dim3(256), 0, stream, recs, F, S, nsx, bins, cnt);
+  const dim3 grid((S + kTile - 1) / kTile, (S + kTile - 1) / kTile, B);
+  if (soft)
+    hipLaunchKernelGGL(raster_kernel<1>, grid, dim3(256), 0, stream, recs, bins, cnt, F, S, nsx, blur_radius, sigma,
+                       face_id, zbuf, alpha, nullptr, nullptr, 0, nullptr);
+  else
+    hipLaunchKernelGGL(raster_kernel<0>, grid, dim3(256), 0, stream, recs, bins, cnt, F, S, nsx, 0.f, 1.f, face_id, zbuf,
+                       nullptr, nullptr, nullptr, 0, nullptr);
+  HARP_CHECK_LAUNCH();
+  return HARP_OK;
+}
+
+// Soft-silhouette backward: g_alpha (B,S,S) -> accumulates (atomicAdd) into g_ndc (B,V,3) (x,y components).
+// ws must be the workspace of the matching harp_rasterize_fwd(soft=1); alpha its output.
+int harp_silhouette_bwd(const int32_t* faces, int B, int V, int F, int S, float blur_radius, float sigma, const void* ws,
+                        const float* alpha, const float* g_alpha, float* g_ndc, hipStream_t stream) {
+  if (!faces || !ws || !alpha || !g_alpha || !g_ndc) return HARP_ERR_ARG;
+  FaceRec* recs; int32_t *bins, *cnt;
+  ws_split((void*)ws, B, F, S, &recs, &bins, &cnt);
+  const int nsx = (S + kSuper - 1) / kSuper;
+  const dim3 grid((S + kTile - 1) / kTile, (S + kTile - 1) / kTile, B);
+  hipLaunchKernelGGL(raster_kernel<2>, grid, dim3(256), 0, stream, recs, bins, cnt, F, S, nsx, blur_radius, sigma, nullptr,
+                     nullptr, (float*)alpha, g_alpha, faces, V, g_ndc);
+  HARP_CHECK_LAUNCH();
+  return HARP_OK;
+}
+
+}  // extern "C"
