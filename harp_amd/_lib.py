@@ -52,3 +52,28 @@ def stream():
 def check(code, what):
     if code != 0:
         raise RuntimeError(f"{what} failed with status {code}")
+
+
+class ShadeArgs(ctypes.Structure):
+    """mirror of `harp_shade_args` (include/harp_hip.h)"""
+    _fields_ = ([(n, _vp) for n in ("face_id", "recs", "faces", "faces_uvs", "verts_uvs", "verts", "vnormals", "tex", "nmap",
+                                    "light_pos", "colors", "zl", "light_R", "light_T")] +
+                [(n, _i) for n in ("B", "V", "F", "S", "Ht", "Wt")] +
+                [(n, _f) for n in ("focal", "ppx", "ppy")] + [("bg", _f * 3)] +
+                [(n, _vp) for n in ("rgb", "g_rgb", "g_tex", "g_nmap", "g_verts", "g_vnormals", "g_ndc", "g_zl", "g_light_pos",
+                                    "g_colors", "g_light_R", "g_light_T")])
+
+
+SIGNATURES.update({
+    "harp_depth_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "harp_shade_fwd": (_i, [ctypes.POINTER(ShadeArgs), _vp]),
+    "harp_shade_bwd": (_i, [ctypes.POINTER(ShadeArgs), _vp]),
+    "harp_subdivide_fwd": (_i, [_vp, _vp, _i, _i, _i, _f, _vp, _vp]),
+    "harp_subdivide_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _vp, _vp]),
+    "harp_vertex_normals_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "harp_vertex_normals_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "harp_displace_bwd": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
+    "harp_project_fwd": (_i, [_vp, _vp, _vp, _i, _i, _f, _f, _f, _i, _vp, _vp]),
+    "harp_project_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _i, _vp, _vp, _vp, _vp]),
+    "harp_centroid": (_i, [_vp, _i, _i, _vp, _vp]),
+})

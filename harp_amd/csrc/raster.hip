@@ -15,6 +15,7 @@
 //                   silhouette product prod_f (1 - sigmoid(-d_f/sigma)).
 //   4. sil_bwd      same walk, rim pixels only: dL/dalpha -> dL/d(ndc xy) of the face vertices (atomics).
 #include "harp_common.h"
+#include "harp_hip.h"
 
 namespace {
 

@@ -1,0 +1,400 @@
+// Fused per-pixel shader + its backward for gfx950.  Replaces, for the K=1 RGB passes of HARP, the ~40 torch /
+// PyTorch3D ops of SoftPhongShaderShadow / SoftPhongShaderPBR:
+//   interpolate_face_attributes x3 (positions, normals, uvs)       renderer_helper.py:173-178, 364, 498-503
+//   TexturesUV.sample_textures x2 (albedo, normal map; grid_sample) renderer_helper.py:127, 572; pbr_materials.py:110
+//   PBRMaterials.apply_normal_map / compute_tangent                 pbr_materials.py:58-124
+//   _apply_lighting (PointLights diffuse, shininess-0 specular)     renderer_helper.py:186, 513-515
+//   shadow-map test (3x3 taps of sigmoid(1000 (z_light - z_hit + 0.008)))  renderer_helper.py:360-408
+//   colour composition + softmax_rgb_blend (K=1)                    renderer_helper.py:188, 517-518, 589-591
+// One lane = one pixel; fragments (bary, position, normal, uv, texels) live only in registers: the barycentrics are
+// recomputed from the 64-B face record of the hit face instead of being stored as (B,S,S,K,3) tensors.
+// Backward recomputes the forward per pixel and scatters with float atomics (HW global_atomic_add_f32).
+#include "harp_common.h"
+#include "harp_hip.h"
+
+namespace {
+
+struct V3 { float x, y, z; };
+__device__ __forceinline__ V3 mk(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ V3 ld(const float* p) { return mk(p[0], p[1], p[2]); }
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ V3 operator*(V3 a, float s) { return mk(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+
+struct Tri { float x0, y0, z0, x1, y1, z1, x2, y2, z2; };
+
+__device__ __forceinline__ Tri load_tri(const FaceRec* r) {
+  const float4 a = r->a, b = r->b;
+  Tri t;
+  t.x0 = a.x; t.y0 = a.y; t.z0 = a.z; t.x1 = a.w; t.y1 = b.x; t.z1 = b.y; t.x2 = b.z; t.y2 = b.w; t.z2 = r->c.x;
+  return t;
+}
+
+struct Bary { float b0, b1, b2, w0, w1, w2, area, den; bool den_clamped; };
+
+__device__ __forceinline__ Bary bary_fwd(const Tri& t, float px, float py) {
+  Bary r;
+  r.area = edge_fn(t.x2, t.y2, t.x0, t.y0, t.x1, t.y1) + kEps;
+  r.w0 = edge_fn(px, py, t.x1, t.y1, t.x2, t.y2) / r.area;
+  r.w1 = edge_fn(px, py, t.x2, t.y2, t.x0, t.y0) / r.area;
+  r.w2 = edge_fn(px, py, t.x0, t.y0, t.x1, t.y1) / r.area;
+  const float t0 = r.w0 * t.z1 * t.z2, t1 = t.z0 * r.w1 * t.z2, t2 = t.z0 * t.z1 * r.w2;
+  const float s = t0 + t1 + t2;
+  r.den_clamped = !(s > kEps);
+  r.den = fmaxf(s, kEps);
+  r.b0 = t0 / r.den; r.b1 = t1 / r.den; r.b2 = t2 / r.den;
+  return r;
+}
+
+// d(edge(p,a,b)) for a, b
+__device__ __forceinline__ void edge_bwd(float g, float px, float py, float ax, float ay, float bx, float by, float& gax,
+                                         float& gay, float& gbx, float& gby) {
+  gax += g * (py - by); gay += g * (bx - px); gbx += g * -(py - ay); gby += g * (px - ax);
+}
+
+// BarycentricPerspectiveCorrectionBackward + BarycentricCoordsBackward: g_b -> g on the 9 face-vertex NDC comps.
+// out[9] = g x0 y0 z0 x1 y1 z1 x2 y2 z2 (accumulated into).
+__device__ __forceinline__ void bary_bwd(const Tri& t, float px, float py, const Bary& r, float gb0, float gb1, float gb2,
+                                         float* out) {
+  const float t0 = r.w0 * t.z1 * t.z2, t1 = t.z0 * r.w1 * t.z2, t2 = t.z0 * t.z1 * r.w2;
+  float gt0 = gb0 / r.den, gt1 = gb1 / r.den, gt2 = gb2 / r.den;
+  if (!r.den_clamped) {
+    const float c = (gb0 * t0 + gb1 * t1 + gb2 * t2) / (r.den * r.den);
+    gt0 -= c; gt1 -= c; gt2 -= c;
+  }
+  const float gw0 = gt0 * t.z1 * t.z2, gw1 = gt1 * t.z0 * t.z2, gw2 = gt2 * t.z0 * t.z1;
+  out[2] += gt1 * r.w1 * t.z2 + gt2 * r.w2 * t.z1;                // z0
+  out[5] += gt0 * r.w0 * t.z2 + gt2 * r.w2 * t.z0;                // z1
+  out[8] += gt0 * r.w0 * t.z1 + gt1 * r.w1 * t.z0;                // z2
+  const float ge0 = gw0 / r.area, ge1 = gw1 / r.area, ge2 = gw2 / r.area;
+  const float garea = -(gw0 * r.w0 + gw1 * r.w1 + gw2 * r.w2) / r.area;
+  // e0 = edge(p, v1, v2); e1 = edge(p, v2, v0); e2 = edge(p, v0, v1); area = edge(v2, v0, v1)
+  edge_bwd(ge0, px, py, t.x1, t.y1, t.x2, t.y2, out[3], out[4], out[6], out[7]);
+  edge_bwd(ge1, px, py, t.x2, t.y2, t.x0, t.y0, out[6], out[7], out[0], out[1]);
+  edge_bwd(ge2, px, py, t.x0, t.y0, t.x1, t.y1, out[0], out[1], out[3], out[4]);
+  edge_bwd(garea, t.x2, t.y2, t.x0, t.y0, t.x1, t.y1, out[0], out[1], out[3], out[4]);
+  out[6] += garea * (t.y1 - t.y0);
+  out[7] += garea * -(t.x1 - t.x0);
+}
+
+// bilinear, align_corners=True, border padding, v flipped
+struct Bil { int x0, y0; float wx, wy; float gxm, gym; };
+__device__ __forceinline__ Bil bil_setup(float u, float v, int W, int H) {
+  Bil s;
+  float x = u * (float)(W - 1), y = (1.0f - v) * (float)(H - 1);   // grid = (2u-1, 1-2v); ix = (g+1)/2*(W-1)
+  s.gxm = (x > 0.f && x < (float)(W - 1)) ? 1.f : 0.f;
+  s.gym = (y > 0.f && y < (float)(H - 1)) ? 1.f : 0.f;
+  x = fminf(fmaxf(x, 0.f), (float)(W - 1));
+  y = fminf(fmaxf(y, 0.f), (float)(H - 1));
+  const float fx = floorf(x), fy = floorf(y);
+  s.x0 = (int)fx; s.y0 = (int)fy; s.wx = x - fx; s.wy = y - fy;
+  return s;
+}
+__device__ __forceinline__ V3 texel(const float* m, int x, int y, int W, int H) {
+  if (x >= W || y >= H) return mk(0.f, 0.f, 0.f);
+  return ld(m + ((size_t)y * W + x) * 3);
+}
+__device__ __forceinline__ V3 bil_sample(const float* m, const Bil& s, int W, int H, V3* ddx, V3* ddy) {
+  const V3 t00 = texel(m, s.x0, s.y0, W, H), t10 = texel(m, s.x0 + 1, s.y0, W, H);
+  const V3 t01 = texel(m, s.x0, s.y0 + 1, W, H), t11 = texel(m, s.x0 + 1, s.y0 + 1, W, H);
+  const float ax = 1.f - s.wx, ay = 1.f - s.wy;
+  if (ddx) {
+    *ddx = ((t10 - t00) * ay + (t11 - t01) * s.wy) * s.gxm;
+    *ddy = ((t01 - t00) * ax + (t11 - t10) * s.wx) * s.gym;
+  }
+  return t00 * (ax * ay) + t10 * (s.wx * ay) + t01 * (ax * s.wy) + t11 * (s.wx * s.wy);
+}
+__device__ __forceinline__ void bil_scatter(float* g, const Bil& s, int W, int H, V3 v) {
+  const float ax = 1.f - s.wx, ay = 1.f - s.wy;
+  const float w[4] = {ax * ay, s.wx * ay, ax * s.wy, s.wx * s.wy};
+  const int xs[4] = {s.x0, s.x0 + 1, s.x0, s.x0 + 1}, ys[4] = {s.y0, s.y0, s.y0 + 1, s.y0 + 1};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (xs[k] < W && ys[k] < H && w[k] != 0.f) {
+      float* p = g + ((size_t)ys[k] * W + xs[k]) * 3;
+      atomicAdd(p, v.x * w[k]); atomicAdd(p + 1, v.y * w[k]); atomicAdd(p + 2, v.z * w[k]);
+    }
+  }
+}
+
+__device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// Everything the forward computes for one covered pixel (recomputed by the backward).
+struct Frag {
+  Tri t; Bary br; int i0, i1, i2, u0, u1, u2;
+  V3 p, n, texel, m, nprime, nhat, nn, lhat, ldir; float lnp, lnh, llen;
+  float u, v, cosr, vis, zq; int ix, iy; V3 q; Bil bs;
+  V3 tu, tv;   // tangent frame
+  float s, a;
+};
+
+template <bool BWD>
+__global__ void __launch_bounds__(256) shade_kernel(const harp_shade_args A) {
+  __shared__ float s_red[32];
+  const int b = blockIdx.z;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int xi = blockIdx.x * kTile + (lane & 15), yi = blockIdx.y * kTile + w * 4 + (lane >> 4);
+  const int S = A.S, V = A.V;
+  const bool in_img = xi < S && yi < S;
+  const size_t o = ((size_t)b * S + (in_img ? yi : 0)) * S + (in_img ? xi : 0);
+  const int f = in_img ? A.face_id[o] : -1;
+  V3 gc = mk(0.f, 0.f, 0.f);
+  bool act = f >= 0;
+  if (BWD) {
+    if (act) gc = ld(A.g_rgb + o * 3);
+    act = act && (gc.x != 0.f || gc.y != 0.f || gc.z != 0.f);
+    if (threadIdx.x < 32) s_red[threadIdx.x] = 0.f;
+    if (__syncthreads_or(act ? 1 : 0) == 0) return;
+  } else if (!act) {
+    if (in_img) { float* r = A.rgb + o * 3; r[0] = A.bg[0]; r[1] = A.bg[1]; r[2] = A.bg[2]; }
+    return;
+  }
+  float racc[20];
+#pragma unroll
+  for (int k = 0; k < 20; ++k) racc[k] = 0.f;
+
+  if (act) {
+    const float px = pix_to_ndc(xi, S), py = pix_to_ndc(yi, S);
+    const float* col = A.colors;               // amb(3) diff(3) spec(3)
+    Frag g;
+    g.t = load_tri(((const FaceRec*)A.recs) + (size_t)b * A.F + f);
+    g.br = bary_fwd(g.t, px, py);
+    const float b0 = g.br.b0, b1 = g.br.b1, b2 = g.br.b2;
+    g.i0 = A.faces[3 * f]; g.i1 = A.faces[3 * f + 1]; g.i2 = A.faces[3 * f + 2];
+    g.u0 = A.faces_uvs[3 * f]; g.u1 = A.faces_uvs[3 * f + 1]; g.u2 = A.faces_uvs[3 * f + 2];
+    const float* vb = A.verts + (size_t)b * V * 3;
+    const float* nb = A.vnormals + (size_t)b * V * 3;
+    const V3 v0 = ld(vb + 3 * g.i0), v1 = ld(vb + 3 * g.i1), v2 = ld(vb + 3 * g.i2);
+    const V3 n0 = ld(nb + 3 * g.i0), n1 = ld(nb + 3 * g.i1), n2 = ld(nb + 3 * g.i2);
+    const float uv0x = A.verts_uvs[2 * g.u0], uv0y = A.verts_uvs[2 * g.u0 + 1];
+    const float uv1x = A.verts_uvs[2 * g.u1], uv1y = A.verts_uvs[2 * g.u1 + 1];
+    const float uv2x = A.verts_uvs[2 * g.u2], uv2y = A.verts_uvs[2 * g.u2 + 1];
+    g.p = v0 * b0 + v1 * b1 + v2 * b2;
+    g.n = n0 * b0 + n1 * b1 + n2 * b2;
+    g.u = uv0x * b0 + uv1x * b1 + uv2x * b2;
+    g.v = uv0y * b0 + uv1y * b1 + uv2y * b2;
+    g.bs = bil_setup(g.u, g.v, A.Wt, A.Ht);
+    V3 tdx, tdy, mdx, mdy;
+    g.texel = bil_sample(A.tex, g.bs, A.Wt, A.Ht, BWD ? &tdx : nullptr, &tdy);
+    // normal map (pbr_materials.py:58-124): n' = normalize(-u m.x - v m.y + n m.z)
+    V3 nfin = g.n;
+    if (A.nmap) {
+      g.m = bil_sample(A.nmap, g.bs, A.Wt, A.Ht, BWD ? &mdx : nullptr, &mdy);
+      g.s = (g.n.z >= 0.f) ? 1.f : -1.f;
+      g.a = -1.0f / (g.s + g.n.z);
+      const float bb = g.n.x * g.n.y * g.a;
+      g.tu = mk(1.f + g.s * g.n.x * g.n.x * g.a, g.s * bb, -g.s * g.n.x);
+      g.tv = mk(bb, g.s + g.n.y * g.n.y * g.a, -g.n.y);
+      g.nprime = g.tu * (-g.m.x) + g.tv * (-g.m.y) + g.n * g.m.z;
+      g.lnp = sqrtf(dot(g.nprime, g.nprime));
+      g.nhat = g.nprime * (1.0f / fmaxf(g.lnp, 1e-12f));
+      nfin = g.nhat;
+    }
+    // PointLights.diffuse: normalize(n, eps 1e-6) . normalize(L - p, eps 1e-6)
+    g.lnh = sqrtf(dot(nfin, nfin));
+    g.nn = nfin * (1.0f / fmaxf(g.lnh, 1e-6f));
+    g.ldir = ld(A.light_pos + 3 * b) - g.p;
+    g.llen = sqrtf(dot(g.ldir, g.ldir));
+    g.lhat = g.ldir * (1.0f / fmaxf(g.llen, 1e-6f));
+    g.cosr = dot(g.nn, g.lhat);
+    const float cosang = fmaxf(g.cosr, 0.f);
+    // shadow (renderer_helper.py:379-408)
+    g.vis = 1.f;
+    float sg[9];
+    int tapo[9];
+    const float half = 0.5f * (float)S;
+    if (A.zl) {
+      const float* R = A.light_R + 9 * b;
+      const float* T = A.light_T + 3 * b;
+      g.q = mk(g.p.x * R[0] + g.p.y * R[3] + g.p.z * R[6] + T[0], g.p.x * R[1] + g.p.y * R[4] + g.p.z * R[7] + T[1],
+               g.p.x * R[2] + g.p.y * R[5] + g.p.z * R[8] + T[2]);
+      const float xn = (A.focal * g.q.x / g.q.z - A.ppx + half) / half, yn = (A.focal * g.q.y / g.q.z - A.ppy + half) / half;
+      const float xs = half - half * xn, ys = half - half * yn;
+      // torch .round().long(): half-to-even; non-finite -> clamp below makes it harmless
+      g.ix = (int)rintf(fminf(fmaxf(xs, -1.0e6f), 1.0e6f));
+      g.iy = (int)rintf(fminf(fmaxf(ys, -1.0e6f), 1.0e6f));
+      const float aa = g.q.z - 0.008f;
+      float acc = 0.f;
+      int k = 0;
+      for (int ii = -1; ii <= 1; ++ii)
+        for (int jj = -1; jj <= 1; ++jj, ++k) {
+          const int yy = min(max(g.iy + ii, 0), S - 1), xx = min(max(g.ix + jj, 0), S - 1);
+          tapo[k] = yy * S + xx;
+          sg[k] = sigmoidf((A.zl[(size_t)b * S * S + tapo[k]] - aa) * 1000.0f);
+          acc += sg[k];
+        }
+      g.vis = acc / 9.0f;
+    }
+    const V3 amb = ld(col), dfc = ld(col + 3), spc = ld(col + 6);
+    const V3 lightc = mk(amb.x + dfc.x * cosang * g.vis, amb.y + dfc.y * cosang * g.vis, amb.z + dfc.z * cosang * g.vis);
+    const V3 c = mk(lightc.x * g.texel.x + spc.x, lightc.y * g.texel.y + spc.y, lightc.z * g.texel.z + spc.z);
+    // softmax_rgb_blend, K=1, blur=0 (Appendix A.4); prob in (0.5,1] is taken as 1 (error <= 2e-10)
+    const float zpix = b0 * g.t.z0 + b1 * g.t.z1 + b2 * g.t.z2;
+    const float zinv = (100.0f - zpix) / 99.0f;
+    const float zmax = fmaxf(zinv, 1e-10f);
+    const float wnum = expf((zinv - zmax) / 1e-4f);
+    const float delta = fmaxf(expf((1e-10f - zmax) / 1e-4f), 1e-10f);
+    const float denom = wnum + delta;
+    if (!BWD) {
+      float* r = A.rgb + o * 3;
+      r[0] = (wnum * c.x + delta * A.bg[0]) / denom;
+      r[1] = (wnum * c.y + delta * A.bg[1]) / denom;
+      r[2] = (wnum * c.z + delta * A.bg[2]) / denom;
+    } else {
+      const float wk = wnum / denom;
+      const V3 g_c = gc * wk;
+      // c = lightc * texel + spec
+      const V3 g_tex = mk(g_c.x * lightc.x, g_c.y * lightc.y, g_c.z * lightc.z);
+      const V3 g_lc = mk(g_c.x * g.texel.x, g_c.y * g.texel.y, g_c.z * g.texel.z);
+      racc[0] = g_lc.x; racc[1] = g_lc.y; racc[2] = g_lc.z;                               // amb
+      racc[3] = g_lc.x * cosang * g.vis; racc[4] = g_lc.y * cosang * g.vis; racc[5] = g_lc.z * cosang * g.vis;  // diff
+      racc[6] = g_c.x; racc[7] = g_c.y; racc[8] = g_c.z;                                  // spec
+      const float g_dv = g_lc.x * dfc.x + g_lc.y * dfc.y + g_lc.z * dfc.z;               // d/d(cosang*vis)
+      const float g_vis = g_dv * cosang;
+      const float g_cos = (g.cosr > 0.f) ? g_dv * g.vis : 0.f;
+      float gu = 0.f, gv = 0.f;                     // d/d(u,v)
+      if (A.g_tex) bil_scatter(A.g_tex, g.bs, A.Wt, A.Ht, g_tex);
+      gu += dot(g_tex, tdx) * (float)(A.Wt - 1);
+      gv += dot(g_tex, tdy) * -(float)(A.Ht - 1);
+      V3 g_p = mk(0.f, 0.f, 0.f);
+      // cos = nn . lhat
+      const V3 g_nn = g.lhat * g_cos, g_lhat = g.nn * g_cos;
+      V3 g_ldir = (g.llen > 1e-6f) ? (g_lhat - g.lhat * dot(g.lhat, g_lhat)) * (1.0f / g.llen) : g_lhat * 1e6f;
+      racc[9] = g_ldir.x; racc[10] = g_ldir.y; racc[11] = g_ldir.z;                       // light_pos
+      g_p = g_p - g_ldir;
+      V3 g_nfin = (g.lnh > 1e-6f) ? (g_nn - g.nn * dot(g.nn, g_nn)) * (1.0f / g.lnh) : g_nn * 1e6f;
+      V3 g_n = g_nfin;
+      if (A.nmap) {
+        const V3 g_np = (g.lnp > 1e-12f) ? (g_nfin - g.nhat * dot(g.nhat, g_nfin)) * (1.0f / g.lnp) : g_nfin * 1e12f;
+        const V3 g_m = mk(-dot(g.tu, g_np), -dot(g.tv, g_np), dot(g.n, g_np));
+        if (A.g_nmap) bil_scatter(A.g_nmap, g.bs, A.Wt, A.Ht, g_m);
+        gu += dot(g_m, mdx) * (float)(A.Wt - 1);
+        gv += dot(g_m, mdy) * -(float)(A.Ht - 1);
+        const V3 g_tu = g_np * (-g.m.x), g_tv = g_np * (-g.m.y);
+        g_n = g_np * g.m.z;
+        const float x = g.n.x, y = g.n.y, s = g.s, a = g.a;
+        // tu = (1 + s x^2 a, s b, -s x), tv = (b, s + y^2 a, -y), b = x y a, a = -1/(s+z)
+        const float g_b = s * g_tu.y + g_tv.x;
+        const float g_a = s * x * x * g_tu.x + y * y * g_tv.y + g_b * x * y;
+        g_n.x += 2.f * s * x * a * g_tu.x - s * g_tu.z + g_b * y * a;
+        g_n.y += 2.f * y * a * g_tv.y - g_tv.z + g_b * x * a;
+        g_n.z += g_a * a * a;
+      }
+      // shadow
+      if (A.zl) {
+        float g_zq = 0.f;
+        for (int k = 0; k < 9; ++k) {
+          const float d = g_vis * (1.0f / 9.0f) * sg[k] * (1.0f - sg[k]) * 1000.0f;
+          if (d != 0.f) {
+            if (A.g_zl) atomicAdd(A.g_zl + (size_t)b * S * S + tapo[k], d);
+            g_zq -= d;
+          }
+        }
+        const float* R = A.light_R + 9 * b;
+        g_p = g_p + mk(R[2], R[5], R[8]) * g_zq;
+        racc[12] = g.p.x * g_zq; racc[13] = g.p.y * g_zq; racc[14] = g.p.z * g_zq;        // light_R[:,2]
+        racc[15] = g_zq;                                                                   // light_T.z
+      }
+      // interpolation backward
+      float gb0 = dot(v0, g_p) + dot(n0, g_n) + uv0x * gu + uv0y * gv;
+      float gb1 = dot(v1, g_p) + dot(n1, g_n) + uv1x * gu + uv1y * gv;
+      float gb2 = dot(v2, g_p) + dot(n2, g_n) + uv2x * gu + uv2y * gv;
+      float* gvb = A.g_verts + (size_t)b * V * 3;
+      float* gnb = A.g_vnormals + (size_t)b * V * 3;
+      const int vi[3] = {g.i0, g.i1, g.i2};
+      const float bw[3] = {b0, b1, b2};
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        atomicAdd(gvb + 3 * vi[k], g_p.x * bw[k]); atomicAdd(gvb + 3 * vi[k] + 1, g_p.y * bw[k]); atomicAdd(gvb + 3 * vi[k] + 2, g_p.z * bw[k]);
+        atomicAdd(gnb + 3 * vi[k], g_n.x * bw[k]); atomicAdd(gnb + 3 * vi[k] + 1, g_n.y * bw[k]); atomicAdd(gnb + 3 * vi[k] + 2, g_n.z * bw[k]);
+      }
+      float gnd[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      bary_bwd(g.t, px, py, g.br, gb0, gb1, gb2, gnd);
+      float* gdb = A.g_ndc + (size_t)b * V * 3;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        atomicAdd(gdb + 3 * vi[k], gnd[3 * k]); atomicAdd(gdb + 3 * vi[k] + 1, gnd[3 * k + 1]); atomicAdd(gdb + 3 * vi[k] + 2, gnd[3 * k + 2]);
+      }
+    }
+  }
+  if (BWD) {
+    // block-level reduction of the 16 per-frame / global scalars, then one atomic each
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const float s = wave_sum(racc[k]);
+      if (lane == 0 && s != 0.f) atomicAdd(&s_red[k], s);
+    }
+    __syncthreads();
+    if (threadIdx.x < 16) {
+      const float s = s_red[threadIdx.x];
+      const int k = threadIdx.x;
+      if (s != 0.f) {
+        if (k < 9) { if (A.g_colors) atomicAdd(A.g_colors + k, s); }
+        else if (k < 12) { if (A.g_light_pos) atomicAdd(A.g_light_pos + 3 * b + (k - 9), s); }
+        else if (k < 15) { if (A.g_light_R) atomicAdd(A.g_light_R + 9 * b + 3 * (k - 12) + 2, s); }
+        else if (A.g_light_T) atomicAdd(A.g_light_T + 3 * b + 2, s);
+      }
+    }
+  }
+}
+
+// zbuf backward of a K=1 pass (used for the light-view depth map the shadow test gathers from):
+// zbuf = sum_i bary_i z_i  ->  g on the face's NDC vertices (rasterize_meshes_backward, grad_zbuf path).
+__global__ void __launch_bounds__(256) depth_bwd_kernel(const int32_t* __restrict__ face_id, const FaceRec* __restrict__ recs,
+                                                        const int32_t* __restrict__ faces, const float* __restrict__ g_z,
+                                                        int V, int F, int S, float* __restrict__ g_ndc) {
+  const int b = blockIdx.z;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int xi = blockIdx.x * kTile + (lane & 15), yi = blockIdx.y * kTile + w * 4 + (lane >> 4);
+  if (xi >= S || yi >= S) return;
+  const size_t o = ((size_t)b * S + yi) * S + xi;
+  const float g = g_z[o];
+  const int f = face_id[o];
+  if (f < 0 || g == 0.f) return;
+  const Tri t = load_tri(recs + (size_t)b * F + f);
+  const float px = pix_to_ndc(xi, S), py = pix_to_ndc(yi, S);
+  const Bary br = bary_fwd(t, px, py);
+  float gnd[9] = {0.f, 0.f, g * br.b0, 0.f, 0.f, g * br.b1, 0.f, 0.f, g * br.b2};
+  bary_bwd(t, px, py, br, g * t.z0, g * t.z1, g * t.z2, gnd);
+  float* gdb = g_ndc + (size_t)b * V * 3;
+  const int vi[3] = {faces[3 * f], faces[3 * f + 1], faces[3 * f + 2]};
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    atomicAdd(gdb + 3 * vi[k], gnd[3 * k]); atomicAdd(gdb + 3 * vi[k] + 1, gnd[3 * k + 1]); atomicAdd(gdb + 3 * vi[k] + 2, gnd[3 * k + 2]);
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int harp_shade_fwd(const harp_shade_args* a, hipStream_t stream) {
+  if (!a || !a->face_id || !a->recs || !a->faces || !a->faces_uvs || !a->verts_uvs || !a->verts || !a->vnormals || !a->tex ||
+      !a->light_pos || !a->colors || !a->rgb || (a->zl && (!a->light_R || !a->light_T)))
+    return HARP_ERR_ARG;
+  const dim3 grid((a->S + kTile - 1) / kTile, (a->S + kTile - 1) / kTile, a->B);
+  hipLaunchKernelGGL(shade_kernel<false>, grid, dim3(256), 0, stream, *a);
+  HARP_CHECK_LAUNCH();
+  return HARP_OK;
+}
+
+int harp_shade_bwd(const harp_shade_args* a, hipStream_t stream) {
+  if (!a || !a->face_id || !a->recs || !a->g_rgb || !a->g_verts || !a->g_vnormals || !a->g_ndc) return HARP_ERR_ARG;
+  const dim3 grid((a->S + kTile - 1) / kTile, (a->S + kTile - 1) / kTile, a->B);
+  hipLaunchKernelGGL(shade_kernel<true>, grid, dim3(256), 0, stream, *a);
+  HARP_CHECK_LAUNCH();
+  return HARP_OK;
+}
+
+// g_z (B,S,S) -> g_ndc (B,V,3) += ; ws = workspace of the harp_rasterize_fwd call that produced face_id
+int harp_depth_bwd(const int32_t* face_id, const void* ws, const int32_t* faces, const float* g_z, int B, int V, int F, int S,
+                   float* g_ndc, hipStream_t stream) {
+  if (!face_id || !ws || !faces || !g_z || !g_ndc) return HARP_ERR_ARG;
+  const dim3 grid((S + kTile - 1) / kTile, (S + kTile - 1) / kTile, B);
+  hipLaunchKernelGGL(depth_bwd_kernel, grid, dim3(256), 0, stream, face_id, (const FaceRec*)ws, faces, g_z, V, F, S, g_ndc);
+  HARP_CHECK_LAUNCH();
+  return HARP_OK;
+}
+
+}  // extern "C"

@@ -63,3 +63,218 @@ class _SoftSilhouette(torch.autograd.Function):
 
 def soft_silhouette(ndc, faces, S, blur_radius=SIL_BLUR, sigma=SIL_SIGMA):
     return _SoftSilhouette.apply(ndc, faces, S, blur_radius, sigma)
+
+
+# ------------------------------------------------------------------------------------------------------
+# static topology on the device
+# ------------------------------------------------------------------------------------------------------
+class DeviceTopology:
+    """int32 HBM copies of the host tables of harp_amd.synth.build_topology / topology.py."""
+
+    def __init__(self, topo, verts_uvs, faces_uvs, device):
+        i32 = lambda a: torch.as_tensor(a, dtype=torch.int32).contiguous().to(device)
+        self.V0, self.V = int(topo["n_verts0"]), int(topo["n_verts"])
+        for k in ("faces0", "edges0", "faces", "edges", "nbr_off", "nbr_idx", "vf_off", "vf_idx", "nc_pairs", "sub_off", "sub_idx"):
+            setattr(self, k, i32(topo[k]))
+        self.E0, self.F, self.E = self.edges0.shape[0], self.faces.shape[0], self.edges.shape[0]
+        self.verts_uvs = torch.as_tensor(verts_uvs, dtype=torch.float32).reshape(-1, 2).contiguous().to(device)
+        self.faces_uvs = i32(faces_uvs).reshape(-1, 3)
+        self.device = device
+
+
+def _f32(t):
+    return t.contiguous().float()
+
+
+class _Subdivide(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, v0, topo, scale):
+        v0 = _f32(v0)
+        B = v0.shape[0]
+        vs = torch.empty(B, topo.V, 3, dtype=torch.float32, device=v0.device)
+        _lib.check(_lib.lib().harp_subdivide_fwd(_lib.ptr(v0), _lib.ptr(topo.edges0), B, topo.V0, topo.E0, scale, _lib.ptr(vs),
+                                                 _lib.stream()), "harp_subdivide_fwd")
+        ctx.topo, ctx.scale = topo, scale
+        return vs
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _f32(g)
+        topo, B = ctx.topo, g.shape[0]
+        g0 = torch.empty(B, topo.V0, 3, dtype=torch.float32, device=g.device)
+        _lib.check(_lib.lib().harp_subdivide_bwd(_lib.ptr(g), _lib.ptr(topo.sub_off), _lib.ptr(topo.sub_idx), B, topo.V0, topo.V,
+                                                 ctx.scale, _lib.ptr(g0), _lib.stream()), "harp_subdivide_bwd")
+        return g0, None, None
+
+
+def subdivide(v0, topo, scale=1.0):
+    """[scale*v0 ; edge midpoints] (SubdivideMeshes, utils/visualize.py:45-52)."""
+    return _Subdivide.apply(v0, topo, scale)
+
+
+class _NormalsDisplace(torch.autograd.Function):
+    """n = unit vertex normals of v; optionally vd = v + n * disp (utils/visualize.py:58-64)."""
+
+    @staticmethod
+    def forward(ctx, v, disp, topo):
+        v = _f32(v)
+        B = v.shape[0]
+        n = torch.empty_like(v)
+        inv_len = torch.empty(B, topo.V, dtype=torch.float32, device=v.device)
+        d = _f32(disp.reshape(-1)) if disp is not None else None
+        vd = torch.empty_like(v) if disp is not None else None
+        _lib.check(_lib.lib().harp_vertex_normals_fwd(_lib.ptr(v), _lib.ptr(topo.faces), _lib.ptr(topo.vf_off), _lib.ptr(topo.vf_idx),
+                                                      B, topo.V, _lib.ptr(n), _lib.ptr(inv_len), _lib.ptr(d), _lib.ptr(vd),
+                                                      _lib.stream()), "harp_vertex_normals_fwd")
+        ctx.topo, ctx.has_disp = topo, disp is not None
+        ctx.disp_shape = disp.shape if disp is not None else None
+        ctx.save_for_backward(v, n, inv_len, d)
+        return (n, vd) if disp is not None else (n, None)
+
+    @staticmethod
+    def backward(ctx, g_n, g_vd):
+        v, n, inv_len, d = ctx.saved_tensors
+        topo, B = ctx.topo, v.shape[0]
+        L = _lib.lib()
+        g_v = torch.zeros_like(v)
+        g_disp = None
+        g_n_tot = _f32(g_n) if g_n is not None else torch.zeros_like(v)
+        if ctx.has_disp and g_vd is not None:
+            g_vd = _f32(g_vd)
+            g_v = g_vd.clone()
+            g_nd = torch.empty_like(v)
+            g_disp = torch.zeros(topo.V, dtype=torch.float32, device=v.device)
+            _lib.check(L.harp_displace_bwd(_lib.ptr(g_vd), _lib.ptr(n), _lib.ptr(d), B, topo.V, _lib.ptr(g_nd), _lib.ptr(g_disp),
+                                           _lib.stream()), "harp_displace_bwd")
+            g_n_tot = g_n_tot + g_nd
+            g_disp = g_disp.reshape(ctx.disp_shape)
+        tmp = torch.empty_like(v)
+        _lib.check(L.harp_vertex_normals_bwd(_lib.ptr(v), _lib.ptr(topo.faces), _lib.ptr(topo.vf_off), _lib.ptr(topo.vf_idx), B, topo.V,
+                                             _lib.ptr(n), _lib.ptr(inv_len), _lib.ptr(g_n_tot.contiguous()), _lib.ptr(tmp), _lib.ptr(g_v),
+                                             _lib.stream()), "harp_vertex_normals_bwd")
+        return g_v, g_disp, None
+
+
+def vertex_normals(v, topo):
+    return _NormalsDisplace.apply(v, None, topo)[0]
+
+
+def normals_displace(v, disp, topo):
+    return _NormalsDisplace.apply(v, disp, topo)
+
+
+class _Project(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, v, R, T, focal, ppx, ppy, S):
+        v, R, T = _f32(v), _f32(R).reshape(-1, 9), _f32(T)
+        B, V, _ = v.shape
+        ndc = torch.empty_like(v)
+        _lib.check(_lib.lib().harp_project_fwd(_lib.ptr(v), _lib.ptr(R), _lib.ptr(T), B, V, focal, ppx, ppy, S, _lib.ptr(ndc),
+                                               _lib.stream()), "harp_project_fwd")
+        ctx.save_for_backward(v, R, T)
+        ctx.meta = (focal, S)
+        return ndc
+
+    @staticmethod
+    def backward(ctx, g):
+        v, R, T = ctx.saved_tensors
+        focal, S = ctx.meta
+        B, V, _ = v.shape
+        g_v = torch.zeros_like(v)
+        g_R = torch.zeros(B, 9, dtype=torch.float32, device=v.device)
+        g_T = torch.zeros(B, 3, dtype=torch.float32, device=v.device)
+        _lib.check(_lib.lib().harp_project_bwd(_lib.ptr(v), _lib.ptr(R), _lib.ptr(T), _lib.ptr(_f32(g)), B, V, focal, S, _lib.ptr(g_v),
+                                               _lib.ptr(g_R), _lib.ptr(g_T), _lib.stream()), "harp_project_bwd")
+        return g_v, g_R.view(B, 3, 3), g_T, None, None, None, None
+
+
+def project(v, R, T, focal, S, pp=None):
+    """world -> (x_ndc, y_ndc, z_view), MeshRasterizer.transform for PerspectiveCameras(in_ndc=False)."""
+    ppx, ppy = (S / 2.0, S / 2.0) if pp is None else pp
+    return _Project.apply(v, R, T, float(focal), float(ppx), float(ppy), int(S))
+
+
+class _DepthRaster(torch.autograd.Function):
+    """K=1 hard rasterisation returning (zbuf, face_id, ws); differentiable through zbuf."""
+
+    @staticmethod
+    def forward(ctx, ndc, faces, S):
+        ndc = _f32(ndc)
+        face_id, zbuf, _, ws = rasterize_fwd(ndc, faces, S, soft=False, want_zbuf=True)
+        ctx.save_for_backward(face_id, ws, faces)
+        ctx.meta = (ndc.shape, S)
+        ctx.mark_non_differentiable(face_id, ws)
+        return zbuf, face_id, ws
+
+    @staticmethod
+    def backward(ctx, g_z, _a, _b):
+        face_id, ws, faces = ctx.saved_tensors
+        shape, S = ctx.meta
+        g_ndc = torch.zeros(shape, dtype=torch.float32, device=face_id.device)
+        _lib.check(_lib.lib().harp_depth_bwd(_lib.ptr(face_id), _lib.ptr(ws), _lib.ptr(faces), _lib.ptr(_f32(g_z)), shape[0], shape[1],
+                                             faces.shape[0], S, _lib.ptr(g_ndc), _lib.stream()), "harp_depth_bwd")
+        return g_ndc, None, None
+
+
+def depth_raster(ndc, faces, S):
+    return _DepthRaster.apply(ndc, faces, S)
+
+
+def _shade_args(face_id, ws, topo, verts, vnormals, tex, nmap, light_pos, colors, zl, light_R, light_T, S, focal, pp, bg):
+    a = _lib.ShadeArgs()
+    B, V, _ = verts.shape
+    for k, t in (("face_id", face_id), ("recs", ws), ("faces", topo.faces), ("faces_uvs", topo.faces_uvs), ("verts_uvs", topo.verts_uvs),
+                 ("verts", verts), ("vnormals", vnormals), ("tex", tex), ("nmap", nmap), ("light_pos", light_pos), ("colors", colors),
+                 ("zl", zl), ("light_R", light_R), ("light_T", light_T)):
+        setattr(a, k, _lib.ptr(t))
+    a.B, a.V, a.F, a.S, a.Ht, a.Wt = B, V, topo.F, S, tex.shape[-3], tex.shape[-2]
+    a.focal, a.ppx, a.ppy = focal, pp[0], pp[1]
+    a.bg[0], a.bg[1], a.bg[2] = bg
+    return a
+
+
+class _Shade(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, ndc, verts, vnormals, tex, nmap, light_pos, colors, zl, light_R, light_T, face_id, ws, topo, S, focal, pp, bg):
+        verts, vnormals, tex = _f32(verts), _f32(vnormals), _f32(tex)
+        nmap = _f32(nmap) if nmap is not None else None
+        light_pos, colors = _f32(light_pos), _f32(colors).reshape(9)
+        if zl is not None:
+            zl, light_R, light_T = _f32(zl), _f32(light_R).reshape(-1, 9), _f32(light_T)
+        B = verts.shape[0]
+        rgb = torch.empty(B, S, S, 3, dtype=torch.float32, device=verts.device)
+        a = _shade_args(face_id, ws, topo, verts, vnormals, tex, nmap, light_pos, colors, zl, light_R, light_T, S, focal, pp, bg)
+        a.rgb = _lib.ptr(rgb)
+        _lib.check(_lib.lib().harp_shade_fwd(a, _lib.stream()), "harp_shade_fwd")
+        ctx.save_for_backward(verts, vnormals, tex, nmap, light_pos, colors, zl, light_R, light_T, face_id, ws)
+        ctx.meta = (topo, S, focal, pp, bg)
+        return rgb
+
+    @staticmethod
+    def backward(ctx, g_rgb):
+        verts, vnormals, tex, nmap, light_pos, colors, zl, light_R, light_T, face_id, ws = ctx.saved_tensors
+        topo, S, focal, pp, bg = ctx.meta
+        a = _shade_args(face_id, ws, topo, verts, vnormals, tex, nmap, light_pos, colors, zl, light_R, light_T, S, focal, pp, bg)
+        g_rgb = _f32(g_rgb)
+        z = torch.zeros_like
+        g_ndc, g_verts, g_vn, g_tex = z(verts), z(verts), z(verts), z(tex)
+        g_nmap = z(nmap) if nmap is not None else None
+        g_lp, g_col = z(light_pos), z(colors)
+        g_zl = z(zl) if zl is not None else None
+        g_lR = z(light_R) if zl is not None else None
+        g_lT = z(light_T) if zl is not None else None
+        for k, t in (("g_rgb", g_rgb), ("g_tex", g_tex), ("g_nmap", g_nmap), ("g_verts", g_verts), ("g_vnormals", g_vn), ("g_ndc", g_ndc),
+                     ("g_zl", g_zl), ("g_light_pos", g_lp), ("g_colors", g_col), ("g_light_R", g_lR), ("g_light_T", g_lT)):
+            setattr(a, k, _lib.ptr(t))
+        _lib.check(_lib.lib().harp_shade_bwd(a, _lib.stream()), "harp_shade_bwd")
+        B = verts.shape[0]
+        return (g_ndc, g_verts, g_vn, g_tex, g_nmap, g_lp, g_col, g_zl, g_lR.view(B, 3, 3) if g_lR is not None else None, g_lT,
+                None, None, None, None, None, None, None)
+
+
+def shade(ndc, verts, vnormals, tex, nmap, light_pos, colors, face_id, ws, topo, S, focal, zl=None, light_R=None, light_T=None,
+          pp=None, bg=(1.0, 1.0, 1.0)):
+    """Fused K=1 shader (see csrc/shade.hip). `ndc` is only used to route the barycentric gradient."""
+    pp = (S / 2.0, S / 2.0) if pp is None else pp
+    return _Shade.apply(ndc, verts, vnormals, tex, nmap, light_pos, colors, zl, light_R, light_T, face_id, ws, topo, int(S), float(focal),
+                        (float(pp[0]), float(pp[1])), tuple(float(x) for x in bg))
