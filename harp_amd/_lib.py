@@ -77,3 +77,46 @@ SIGNATURES.update({
     "harp_project_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _i, _vp, _vp, _vp, _vp]),
     "harp_centroid": (_i, [_vp, _i, _i, _vp, _vp]),
 })
+
+
+class ManoModel(ctypes.Structure):
+    """mirror of `harp_mano_model` (include/harp_hip.h)"""
+    _fields_ = [(n, _vp) for n in ("v_template", "shapedirs_T", "posedirs_T", "posedirs", "J_template", "J_dirs", "weights", "hands_mean")]
+
+
+_mp = ctypes.POINTER(ManoModel)
+SIGNATURES.update({
+    "harp_lbs_mano_ws_floats": (_sz, [_i]),
+    "harp_lbs_mano_fwd": (_i, [_mp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
+    "harp_lbs_mano_bwd": (_i, [_mp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "harp_image_l1": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "harp_kps_loss": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
+    "harp_mesh_regularizers": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "harp_sum_squares": (_i, [_vp, _i, _vp, _vp, _vp, _vp]),
+    "harp_texture_smooth_reg": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
+    "harp_close_to_z_reg": (_i, [_vp, _i, _i, _f, _vp, _vp, _vp, _vp]),
+    "harp_normalize3_fwd": (_i, [_vp, _i, _vp, _vp]),
+    "harp_normalize3_bwd": (_i, [_vp, _vp, _i, _vp, _vp]),
+    "harp_adam_step": (_i, [_vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _i, _f, _vp]),
+})
+
+
+class FrameTables(ctypes.Structure):
+    """mirror of `harp_frame_tables` (include/harp_hip.h)"""
+    _fields_ = ([(n, _vp) for n in ("pose", "rot", "trans", "cam", "shape", "light_positions", "amb_ratio", "g_pose", "g_rot", "g_trans",
+                                    "g_cam", "g_shape", "g_light_positions", "g_amb_ratio")] + [("share_light", _i)])
+
+
+_tp = ctypes.POINTER(FrameTables)
+SIGNATURES.update({
+    "harp_frame_setup_fwd": (_i, [_tp, _vp, _i, _i, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "harp_frame_setup_bwd": (_i, [_tp, _vp, _i, _i, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "harp_light_setup_fwd": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
+    "harp_light_setup_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
+    "harp_scale": (_i, [_vp, _f, _i, _vp, _vp]),
+})
+
+SIGNATURES.update({
+    "harp_adam_tick": (_i, [_vp, _vp]),
+    "harp_adam_apply": (_i, [_vp, _vp, _vp, _vp, _sz, _vp, _vp]),
+})

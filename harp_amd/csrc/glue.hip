@@ -1,0 +1,197 @@
+// Per-frame "glue" of the fitting loop for gfx950: everything the reference does with dozens of tiny torch ops between
+// the parameter dict and the renderers — row gathers params[k][fid] (utils/visualize.py:26-27,38-39), the camera
+// convention (utils/visualize.py:268-271), shared light + ambient ratio (optimize_sequence.py:453-456, 478-480;
+// renderer_helper.py:435-441) and the light camera of process_info_for_shadow (renderer_helper.py:454-468, with
+// PyTorch3D look_at_rotation) — as one forward and one backward kernel each, one lane per frame.  The backward scatters
+// straight into the flat gradient arena of the parameter tables (dense-Adam semantics: untouched rows keep zero grad).
+#include "harp_common.h"
+#include "harp_hip.h"
+
+namespace {
+
+struct V3 { float x, y, z; };
+__device__ __forceinline__ V3 mk(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ V3 ld(const float* p) { return mk(p[0], p[1], p[2]); }
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ V3 operator*(V3 a, float s) { return mk(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ V3 cross(V3 a, V3 b) { return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+__device__ __forceinline__ V3 normz(V3 a, float eps, float& len) { len = sqrtf(dot(a, a)); return a * (1.0f / fmaxf(len, eps)); }
+__device__ __forceinline__ V3 normz_bwd(V3 n, float len, float eps, V3 g) {
+  return (len > eps) ? (g - n * dot(n, g)) * (1.0f / len) : g * (1.0f / eps);
+}
+
+__global__ void frame_setup_fwd_kernel(const harp_frame_tables t, const int32_t* __restrict__ fid, int B, int S, float focal,
+                                       int self_shadow, float* __restrict__ pose48, float* __restrict__ betas,
+                                       float* __restrict__ trans_b, float* __restrict__ cam_R, float* __restrict__ cam_T,
+                                       float* __restrict__ light_pos, float* __restrict__ colors) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b == 0) {
+    if (self_shadow) {
+      const float amb = 1.0f / (1.0f + expf(-t.amb_ratio[0]));            // nn.Sigmoid()(params['amb_ratio'])
+      for (int c = 0; c < 3; ++c) { colors[c] = amb; colors[3 + c] = 1.0f - amb; colors[6 + c] = 0.f; }
+    } else {
+      for (int c = 0; c < 3; ++c) { colors[c] = 0.5f; colors[3 + c] = 0.4f; colors[6 + c] = 0.1f; }   // renderer_helper.py:70-73
+    }
+  }
+  if (b >= B) return;
+  const int f = fid[b];
+  for (int k = 0; k < 3; ++k) pose48[b * 48 + k] = t.rot[f * 3 + k];
+  for (int k = 0; k < 45; ++k) pose48[b * 48 + 3 + k] = t.pose[f * 45 + k];
+  for (int k = 0; k < 10; ++k) betas[b * 10 + k] = t.shape[k];
+  for (int k = 0; k < 3; ++k) trans_b[b * 3 + k] = t.trans[f * 3 + k];
+  const float c0 = t.cam[f * 3], c1 = t.cam[f * 3 + 1], c2 = t.cam[f * 3 + 2];
+  cam_T[b * 3] = -c1; cam_T[b * 3 + 1] = -c2; cam_T[b * 3 + 2] = 2.0f * focal / ((float)S * c0 + 1e-9f);
+  const float R[9] = {-1.f, 0.f, 0.f, 0.f, -1.f, 0.f, 0.f, 0.f, 1.f};
+  for (int k = 0; k < 9; ++k) cam_R[b * 9 + k] = R[k];
+  const int lf = t.share_light ? 0 : f;
+  for (int k = 0; k < 3; ++k) light_pos[b * 3 + k] = t.light_positions[lf * 3 + k];
+}
+
+__global__ void frame_setup_bwd_kernel(const harp_frame_tables t, const int32_t* __restrict__ fid, int B, int S, float focal,
+                                       int self_shadow, const float* __restrict__ g_pose48, const float* __restrict__ g_betas,
+                                       const float* __restrict__ g_trans_b, const float* __restrict__ g_cam_T,
+                                       const float* __restrict__ g_light_pos, const float* __restrict__ g_colors) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b == 0 && self_shadow && g_colors && t.g_amb_ratio) {
+    const float amb = 1.0f / (1.0f + expf(-t.amb_ratio[0]));
+    const float g_amb = (g_colors[0] + g_colors[1] + g_colors[2]) - (g_colors[3] + g_colors[4] + g_colors[5]);
+    atomicAdd(t.g_amb_ratio, g_amb * amb * (1.0f - amb));
+  }
+  if (b >= B) return;
+  const int f = fid[b];
+  // duplicates of a frame inside one batch are legal -> atomics
+  if (g_pose48) {
+    if (t.g_rot) for (int k = 0; k < 3; ++k) atomicAdd(t.g_rot + f * 3 + k, g_pose48[b * 48 + k]);
+    if (t.g_pose) for (int k = 0; k < 45; ++k) atomicAdd(t.g_pose + f * 45 + k, g_pose48[b * 48 + 3 + k]);
+  }
+  if (g_betas && t.g_shape) for (int k = 0; k < 10; ++k) atomicAdd(t.g_shape + k, g_betas[b * 10 + k]);
+  if (g_trans_b && t.g_trans) for (int k = 0; k < 3; ++k) atomicAdd(t.g_trans + f * 3 + k, g_trans_b[b * 3 + k]);
+  if (g_cam_T && t.g_cam) {
+    const float c0 = t.cam[f * 3];
+    const float den = (float)S * c0 + 1e-9f;
+    atomicAdd(t.g_cam + f * 3, g_cam_T[b * 3 + 2] * (-2.0f * focal * (float)S / (den * den)));
+    atomicAdd(t.g_cam + f * 3 + 1, -g_cam_T[b * 3]);
+    atomicAdd(t.g_cam + f * 3 + 2, -g_cam_T[b * 3 + 1]);
+  }
+  if (g_light_pos && t.g_light_positions) {
+    const int lf = t.share_light ? 0 : f;
+    for (int k = 0; k < 3; ++k) atomicAdd(t.g_light_positions + lf * 3 + k, g_light_pos[b * 3 + k]);
+  }
+}
+
+// process_info_for_shadow (renderer_helper.py:461-467) + look_at_rotation
+template <bool BWD>
+__global__ void light_setup_kernel(const float* __restrict__ centroid, const float* __restrict__ light_pos, int B,
+                                   float* __restrict__ light_R, float* __restrict__ light_T, const float* __restrict__ g_R,
+                                   const float* __restrict__ g_T, float* __restrict__ g_light_pos, float* __restrict__ g_centroid) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const V3 c = ld(centroid + 3 * b), L = ld(light_pos + 3 * b);
+  const V3 d = L - c;
+  const float dl = sqrtf(dot(d, d));
+  const float s = 1.5f / dl;
+  const V3 pos = c + d * s;
+  const V3 up = mk(0.f, 1.f, 0.f);
+  float lz, lx, ly;
+  const V3 zr = c - pos;
+  const V3 z = normz(zr, 1e-5f, lz);
+  const V3 xr = cross(up, z);
+  const V3 x = normz(xr, 1e-5f, lx);
+  const V3 yr = cross(z, x);
+  const V3 y = normz(yr, 1e-5f, ly);
+  if (!BWD) {
+    float* R = light_R + 9 * b;
+    R[0] = x.x; R[1] = y.x; R[2] = z.x; R[3] = x.y; R[4] = y.y; R[5] = z.y; R[6] = x.z; R[7] = y.z; R[8] = z.z;
+    light_T[3 * b] = -dot(x, pos); light_T[3 * b + 1] = -dot(y, pos); light_T[3 * b + 2] = -dot(z, pos);
+  } else {
+    const float* gR = g_R + 9 * b;
+    const float* gT = g_T + 3 * b;
+    V3 gx = mk(gR[0], gR[3], gR[6]) - pos * gT[0];
+    V3 gy = mk(gR[1], gR[4], gR[7]) - pos * gT[1];
+    V3 gz = mk(gR[2], gR[5], gR[8]) - pos * gT[2];
+    V3 gpos = (x * gT[0] + y * gT[1] + z * gT[2]) * -1.0f;
+    const V3 gyr = normz_bwd(y, ly, 1e-5f, gy);
+    gz = gz + cross(x, gyr);
+    gx = gx + cross(gyr, z);
+    const V3 gxr = normz_bwd(x, lx, 1e-5f, gx);
+    gz = gz + cross(gxr, up);
+    const V3 gzr = normz_bwd(z, lz, 1e-5f, gz);
+    V3 gc = gzr;
+    gpos = gpos - gzr;
+    gc = gc + gpos;
+    const V3 gd = gpos * s - d * (1.5f * dot(d, gpos) / (dl * dl * dl));
+    gc = gc - gd;
+    float* gl = g_light_pos + 3 * b;
+    gl[0] += gd.x; gl[1] += gd.y; gl[2] += gd.z;
+    float* gco = g_centroid + 3 * b;
+    gco[0] = gc.x; gco[1] = gc.y; gco[2] = gc.z;
+  }
+}
+
+// centroid = mean_v verts  ->  g_verts[b, v, :] += g_centroid[b] / V
+__global__ void centroid_bwd_kernel(const float* __restrict__ g_c, int V, float* __restrict__ g_v) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+  if (i >= V) return;
+  const float inv = 1.0f / (float)V;
+  float* o = g_v + ((size_t)b * V + i) * 3;
+  o[0] += g_c[3 * b] * inv; o[1] += g_c[3 * b + 1] * inv; o[2] += g_c[3 * b + 2] * inv;
+}
+
+__global__ void scale_kernel(const float* __restrict__ x, float s, int n, float* __restrict__ y) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) y[i] = x[i] * s;
+}
+
+}  // namespace
+
+extern "C" {
+
+int harp_frame_setup_fwd(const harp_frame_tables* t, const int32_t* fid, int B, int S, float focal, int self_shadow, float* pose48,
+                         float* betas, float* trans_b, float* cam_R, float* cam_T, float* light_pos, float* colors,
+                         hipStream_t stream) {
+  if (!t || !fid || !pose48 || !betas || !trans_b || !cam_R || !cam_T || !light_pos || !colors) return HARP_ERR_ARG;
+  hipLaunchKernelGGL(frame_setup_fwd_kernel, dim3((B + 63) / 64), dim3(64), 0, stream, *t, fid, B, S, focal, self_shadow, pose48, betas,
+                     trans_b, cam_R, cam_T, light_pos, colors);
+  HARP_CHECK_LAUNCH();
+  return HARP_OK;
+}
+
+int harp_frame_setup_bwd(const harp_frame_tables* t, const int32_t* fid, int B, int S, float focal, int self_shadow,
+                         const float* g_pose48, const float* g_betas, const float* g_trans_b, const float* g_cam_T,
+                         const float* g_light_pos, const float* g_colors, hipStream_t stream) {
+  if (!t || !fid) return HARP_ERR_ARG;
+  hipLaunchKernelGGL(frame_setup_bwd_kernel, dim3((B + 63) / 64), dim3(64), 0, stream, *t, fid, B, S, focal, self_shadow, g_pose48,
+                     g_betas, g_trans_b, g_cam_T, g_light_pos, g_colors);
+  HARP_CHECK_LAUNCH();
+  return HARP_OK;
+}
+
+int harp_light_setup_fwd(const float* centroid, const float* light_pos, int B, float* light_R, float* light_T, hipStream_t stream) {
+  if (!centroid || !light_pos || !light_R || !light_T) return HARP_ERR_ARG;
+  hipLaunchKernelGGL(light_setup_kernel<false>, dim3((B + 63) / 64), dim3(64), 0, stream, centroid, light_pos, B, light_R, light_T,
+                     nullptr, nullptr, nullptr, nullptr);
+  HARP_CHECK_LAUNCH();
+  return HARP_OK;
+}
+
+// g_light_pos (B,3) (+=); g_centroid (B,3) overwritten; then g_verts (B,V,3) (+=) g_centroid / V if g_verts != NULL
+int harp_light_setup_bwd(const float* centroid, const float* light_pos, const float* g_light_R, const float* g_light_T, int B, int V,
+                         float* g_light_pos, float* g_centroid, float* g_verts, hipStream_t stream) {
+  if (!centroid || !light_pos || !g_light_R || !g_light_T || !g_light_pos || !g_centroid) return HARP_ERR_ARG;
+  hipLaunchKernelGGL(light_setup_kernel<true>, dim3((B + 63) / 64), dim3(64), 0, stream, centroid, light_pos, B, nullptr, nullptr,
+                     g_light_R, g_light_T, g_light_pos, g_centroid);
+  if (g_verts) hipLaunchKernelGGL(centroid_bwd_kernel, dim3((V + 255) / 256, B), dim3(256), 0, stream, g_centroid, V, g_verts);
+  HARP_CHECK_LAUNCH();
+  return HARP_OK;
+}
+
+int harp_scale(const float* x, float s, int n, float* y, hipStream_t stream) {
+  if (!x || !y) return HARP_ERR_ARG;
+  hipLaunchKernelGGL(scale_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, x, s, n, y);
+  HARP_CHECK_LAUNCH();
+  return HARP_OK;
+}
+
+}  // extern "C"

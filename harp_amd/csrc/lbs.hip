@@ -1,0 +1,371 @@
+// MANO linear-blend skinning for gfx950, forward and hand-written backward.
+// Replaces ManoLayer.forward (manopth/manolayer.py:108-296; batch_rodrigues rodrigues_layer.py:43-54, quat2mat :15-40,
+// th_posemap_axisang tensutils.py:6-12) for the configuration HARP builds (use_pca=False, flat_hand_mean=False,
+// axis-angle root, right hand: utils/hand_model_utils.py:74) — ~35 tiny torch kernels per call in the reference.
+//
+//   joints kernel   one wave per frame: Rodrigues (via quaternion, with the reference's norm(aa + 1e-8)) for the 16
+//                   joints in 16 lanes, J = J_template + J_dirs . beta (J_regressor folded into the shape basis on the
+//                   host), the 3-level kinematic chain, A_j = [R_j | t_j - R_j J_j]; writes pose_map (B,135), A (B,16,12)
+//                   and the 16 joint positions.
+//   skin kernel     one lane per vertex, 8 frames per workgroup sharing every blend-shape read:
+//                   v_posed = v_t + S beta + P pose_map (the (B,135)x(135,2334) contraction, transposed bases so that
+//                   lanes read consecutive floats), T = sum_j w_j A_j, out = (T [v_posed;1] + trans) * 1000.
+//   backward        skin_bwd (per vertex: g_v_posed, M = g_out (x) [v_posed;1]) -> two small reductions over vertices
+//                   (g_A = W^T M, g_pose_map = P^T g_vp, g_beta) -> chain_bwd (one wave per frame: chain, Rodrigues).
+#include "harp_common.h"
+#include "harp_hip.h"
+
+namespace {
+
+constexpr int NJ = 16;
+constexpr int NV = 778;
+constexpr int NB = 10;
+constexpr int NP = 135;
+constexpr int FRAMES_PER_BLOCK = 8;
+
+__device__ __forceinline__ int parent_of(int j) { return (j % 3 == 1) ? 0 : j - 1; }   // manolayer.py:209-239
+
+// full_pose joint j axis-angle -> R (row-major 9)   [rodrigues_layer.py:43-54 + quat2mat :15-40]
+__device__ __forceinline__ void rodrigues_fwd(const float aa[3], float R[9]) {
+  const float e0 = aa[0] + 1e-8f, e1 = aa[1] + 1e-8f, e2 = aa[2] + 1e-8f;
+  const float n = sqrtf(e0 * e0 + e1 * e1 + e2 * e2);
+  const float ax = aa[0] / n, ay = aa[1] / n, az = aa[2] / n;
+  const float h = n * 0.5f, c = cosf(h), s = sinf(h);
+  float q0 = c, q1 = s * ax, q2 = s * ay, q3 = s * az;
+  const float qn = sqrtf(q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3);
+  const float w = q0 / qn, x = q1 / qn, y = q2 / qn, z = q3 / qn;
+  const float w2 = w * w, x2 = x * x, y2 = y * y, z2 = z * z;
+  const float wx = w * x, wy = w * y, wz = w * z, xy = x * y, xz = x * z, yz = y * z;
+  R[0] = w2 + x2 - y2 - z2; R[1] = 2 * xy - 2 * wz;    R[2] = 2 * wy + 2 * xz;
+  R[3] = 2 * wz + 2 * xy;    R[4] = w2 - x2 + y2 - z2; R[5] = 2 * yz - 2 * wx;
+  R[6] = 2 * xz - 2 * wy;    R[7] = 2 * wx + 2 * yz;    R[8] = w2 - x2 - y2 + z2;
+}
+
+__device__ __forceinline__ void rodrigues_bwd(const float aa[3], const float g[9], float gaa[3]) {
+  const float e0 = aa[0] + 1e-8f, e1 = aa[1] + 1e-8f, e2 = aa[2] + 1e-8f;
+  const float n = sqrtf(e0 * e0 + e1 * e1 + e2 * e2);
+  const float a[3] = {aa[0] / n, aa[1] / n, aa[2] / n};
+  const float h = n * 0.5f, c = cosf(h), s = sinf(h);
+  const float q[4] = {c, s * a[0], s * a[1], s * a[2]};
+  const float qn = sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  const float w = q[0] / qn, x = q[1] / qn, y = q[2] / qn, z = q[3] / qn;
+  float gn4[4];
+  gn4[0] = 2 * w * (g[0] + g[4] + g[8]) + 2 * (-z * g[1] + y * g[2] + z * g[3] - x * g[5] - y * g[6] + x * g[7]);
+  gn4[1] = 2 * x * (g[0] - g[4] - g[8]) + 2 * (y * g[1] + z * g[2] + y * g[3] - w * g[5] + z * g[6] + w * g[7]);
+  gn4[2] = 2 * y * (-g[0] + g[4] - g[8]) + 2 * (x * g[1] + w * g[2] + x * g[3] + z * g[5] - w * g[6] + z * g[7]);
+  gn4[3] = 2 * z * (-g[0] - g[4] + g[8]) + 2 * (-w * g[1] + x * g[2] + w * g[3] + y * g[5] + x * g[6] + y * g[7]);
+  const float nq[4] = {w, x, y, z};
+  const float d = nq[0] * gn4[0] + nq[1] * gn4[1] + nq[2] * gn4[2] + nq[3] * gn4[3];
+  float gq[4];
+  for (int k = 0; k < 4; ++k) gq[k] = (gn4[k] - nq[k] * d) / qn;
+  const float g_h = -s * gq[0] + c * (a[0] * gq[1] + a[1] * gq[2] + a[2] * gq[3]);
+  const float ga[3] = {s * gq[1], s * gq[2], s * gq[3]};
+  const float g_n = -(a[0] * ga[0] + a[1] * ga[1] + a[2] * ga[2]) / n + 0.5f * g_h;
+  gaa[0] = ga[0] / n + g_n * e0 / n;
+  gaa[1] = ga[1] / n + g_n * e1 / n;
+  gaa[2] = ga[2] / n + g_n * e2 / n;
+}
+
+// one wave per frame
+__global__ void __launch_bounds__(64) lbs_joints_kernel(const harp_mano_model M, const float* __restrict__ pose,
+                                                        const float* __restrict__ betas, float* __restrict__ pose_map,
+                                                        float* __restrict__ A, float* __restrict__ j16,
+                                                        float* __restrict__ Jrest, float* __restrict__ Rloc,
+                                                        float* __restrict__ G) {
+  __shared__ float sR[NJ][9], sJ[NJ][3], sG[NJ][12];
+  const int b = blockIdx.x, l = threadIdx.x;
+  if (l < NJ) {
+    float aa[3];
+    for (int c = 0; c < 3; ++c) {
+      const float p = pose[b * 48 + 3 * l + c];
+      aa[c] = (l == 0) ? p : (M.hands_mean[3 * (l - 1) + c] + p);       // manolayer.py:139-143
+    }
+    float R[9];
+    rodrigues_fwd(aa, R);
+    for (int k = 0; k < 9; ++k) { sR[l][k] = R[k]; Rloc[(b * NJ + l) * 9 + k] = R[k]; }
+    if (l > 0)
+      for (int k = 0; k < 9; ++k) pose_map[b * NP + (l - 1) * 9 + k] = R[k] - ((k == 0 || k == 4 || k == 8) ? 1.f : 0.f);
+  }
+  if (l < NJ * 3) {
+    float acc = M.J_template[l];
+    for (int k = 0; k < NB; ++k) acc += M.J_dirs[l * NB + k] * betas[b * NB + k];
+    sJ[l / 3][l % 3] = acc;
+    Jrest[b * NJ * 3 + l] = acc;
+  }
+  __syncthreads();
+  // kinematic chain: lanes 0..4 own one finger each (after the root, lane 0)
+  if (l == 0) {
+    for (int k = 0; k < 9; ++k) sG[0][(k / 3) * 4 + (k % 3)] = sR[0][k];
+    for (int r = 0; r < 3; ++r) sG[0][r * 4 + 3] = sJ[0][r];
+  }
+  __syncthreads();
+  if (l < 5) {
+    for (int lev = 0; lev < 3; ++lev) {
+      const int j = 3 * l + 1 + lev, p = parent_of(j);
+      float rel[3] = {sJ[j][0] - sJ[p][0], sJ[j][1] - sJ[p][1], sJ[j][2] - sJ[p][2]};
+      for (int r = 0; r < 3; ++r) {
+        for (int c = 0; c < 3; ++c)
+          sG[j][r * 4 + c] = sG[p][r * 4] * sR[j][c] + sG[p][r * 4 + 1] * sR[j][3 + c] + sG[p][r * 4 + 2] * sR[j][6 + c];
+        sG[j][r * 4 + 3] = sG[p][r * 4] * rel[0] + sG[p][r * 4 + 1] * rel[1] + sG[p][r * 4 + 2] * rel[2] + sG[p][r * 4 + 3];
+      }
+    }
+  }
+  __syncthreads();
+  if (l < NJ) {
+    float* Ao = A + (b * NJ + l) * 12;
+    float* Go = G + (b * NJ + l) * 12;
+    for (int r = 0; r < 3; ++r) {
+      for (int c = 0; c < 3; ++c) { Ao[r * 4 + c] = sG[l][r * 4 + c]; Go[r * 4 + c] = sG[l][r * 4 + c]; }
+      Go[r * 4 + 3] = sG[l][r * 4 + 3];
+      Ao[r * 4 + 3] = sG[l][r * 4 + 3] - (sG[l][r * 4] * sJ[l][0] + sG[l][r * 4 + 1] * sJ[l][1] + sG[l][r * 4 + 2] * sJ[l][2]);  // :241-247
+      j16[(b * NJ + l) * 3 + r] = sG[l][r * 4 + 3];
+    }
+  }
+}
+
+// blockIdx.x: vertex chunk (256), blockIdx.y: frame chunk (8)
+template <bool BWD>
+__global__ void __launch_bounds__(256) lbs_skin_kernel(const harp_mano_model M, const float* __restrict__ betas,
+                                                       const float* __restrict__ trans, const float* __restrict__ pose_map,
+                                                       const float* __restrict__ A, int B, float* __restrict__ verts,
+                                                       const float* __restrict__ g_verts, float* __restrict__ g_vp,
+                                                       float* __restrict__ Mo) {
+  __shared__ float s_pm[FRAMES_PER_BLOCK][NP], s_beta[FRAMES_PER_BLOCK][NB], s_A[FRAMES_PER_BLOCK][NJ * 12];
+  const int v = blockIdx.x * 256 + threadIdx.x;
+  const int b0 = blockIdx.y * FRAMES_PER_BLOCK;
+  const int nb = min(FRAMES_PER_BLOCK, B - b0);
+  for (int i = threadIdx.x; i < nb * NP; i += 256) s_pm[i / NP][i % NP] = pose_map[b0 * NP + i];
+  for (int i = threadIdx.x; i < nb * NB; i += 256) s_beta[i / NB][i % NB] = betas[b0 * NB + i];
+  for (int i = threadIdx.x; i < nb * NJ * 12; i += 256) s_A[i / (NJ * 12)][i % (NJ * 12)] = A[b0 * NJ * 12 + i];
+  __syncthreads();
+  if (v >= NV) return;
+  float vp[FRAMES_PER_BLOCK][3];
+  const float t0 = M.v_template[3 * v], t1 = M.v_template[3 * v + 1], t2 = M.v_template[3 * v + 2];
+#pragma unroll
+  for (int f = 0; f < FRAMES_PER_BLOCK; ++f) { vp[f][0] = t0; vp[f][1] = t1; vp[f][2] = t2; }
+  for (int k = 0; k < NB; ++k) {
+    const float s0 = M.shapedirs_T[k * NV * 3 + 3 * v], s1 = M.shapedirs_T[k * NV * 3 + 3 * v + 1], s2 = M.shapedirs_T[k * NV * 3 + 3 * v + 2];
+#pragma unroll
+    for (int f = 0; f < FRAMES_PER_BLOCK; ++f) { const float c = s_beta[f][k]; vp[f][0] += s0 * c; vp[f][1] += s1 * c; vp[f][2] += s2 * c; }
+  }
+  for (int k = 0; k < NP; ++k) {
+    const float p0 = M.posedirs_T[k * NV * 3 + 3 * v], p1 = M.posedirs_T[k * NV * 3 + 3 * v + 1], p2 = M.posedirs_T[k * NV * 3 + 3 * v + 2];
+#pragma unroll
+    for (int f = 0; f < FRAMES_PER_BLOCK; ++f) { const float c = s_pm[f][k]; vp[f][0] += p0 * c; vp[f][1] += p1 * c; vp[f][2] += p2 * c; }
+  }
+  float w[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) w[j] = M.weights[v * NJ + j];
+  for (int f = 0; f < nb; ++f) {
+    float T[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) T[k] = 0.f;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int k = 0; k < 12; ++k) T[k] += w[j] * s_A[f][j * 12 + k];
+    const int b = b0 + f;
+    if (!BWD) {
+      for (int r = 0; r < 3; ++r) {
+        const float o = T[r * 4] * vp[f][0] + T[r * 4 + 1] * vp[f][1] + T[r * 4 + 2] * vp[f][2] + T[r * 4 + 3];
+        verts[((size_t)b * NV + v) * 3 + r] = (o + trans[3 * b + r]) * 1000.0f;
+      }
+    } else {
+      float g[3];
+      for (int r = 0; r < 3; ++r) g[r] = g_verts[((size_t)b * NV + v) * 3 + r] * 1000.0f;
+      for (int c = 0; c < 3; ++c) g_vp[((size_t)b * NV + v) * 3 + c] = T[c] * g[0] + T[4 + c] * g[1] + T[8 + c] * g[2];
+      float* mo = Mo + ((size_t)b * NV + v) * 12;
+      for (int r = 0; r < 3; ++r) {
+        mo[r * 4] = g[r] * vp[f][0]; mo[r * 4 + 1] = g[r] * vp[f][1]; mo[r * 4 + 2] = g[r] * vp[f][2]; mo[r * 4 + 3] = g[r];
+      }
+    }
+  }
+}
+
+// g_A[b][j][k] = sum_v w[v][j] M[b][v][k]   (192 lanes per frame)
+__global__ void __launch_bounds__(192) lbs_gA_kernel(const float* __restrict__ weights, const float* __restrict__ Mo,
+                                                     float* __restrict__ g_A) {
+  const int b = blockIdx.x, j = threadIdx.x / 12, k = threadIdx.x % 12;
+  float acc = 0.f;
+  for (int v = 0; v < NV; ++v) acc += weights[v * NJ + j] * Mo[((size_t)b * NV + v) * 12 + k];
+  g_A[(b * NJ + j) * 12 + k] = acc;
+}
+
+// g_pose_map[b][k] = sum_{vc} posedirs[vc][k] g_vp[b][vc];  g_beta_part[b][k] likewise with shapedirs (k<10)
+__global__ void __launch_bounds__(192) lbs_gpm_kernel(const harp_mano_model M, const float* __restrict__ g_vp,
+                                                      float* __restrict__ g_pm, float* __restrict__ g_beta_b) {
+  const int b = blockIdx.x, k = threadIdx.x;
+  const float* g = g_vp + (size_t)b * NV * 3;
+  if (k < NP) {
+    float acc = 0.f;
+    for (int i = 0; i < NV * 3; ++i) acc += M.posedirs[i * NP + k] * g[i];
+    g_pm[b * NP + k] = acc;
+  } else if (k < NP + NB) {
+    const int kk = k - NP;
+    float acc = 0.f;
+    for (int i = 0; i < NV * 3; ++i) acc += M.shapedirs_T[kk * NV * 3 + i] * g[i];
+    g_beta_b[b * NB + kk] = acc;
+  }
+}
+
+// one wave per frame: chain + Rodrigues backward. g_j16 (B,16,3): gradient on the 16 chain joint positions (metres).
+__global__ void __launch_bounds__(64) lbs_chain_bwd_kernel(const harp_mano_model M, const float* __restrict__ pose,
+                                                           const float* __restrict__ Rloc, const float* __restrict__ G,
+                                                           const float* __restrict__ Jrest, const float* __restrict__ g_A,
+                                                           const float* __restrict__ g_pm, const float* __restrict__ g_j16,
+                                                           float* __restrict__ g_pose, float* __restrict__ g_beta_b) {
+  __shared__ float gRG[NJ][9], gtG[NJ][3], gRl[NJ][9], gJ[NJ][3];
+  const int b = blockIdx.x, l = threadIdx.x;
+  const float* Gb = G + b * NJ * 12;
+  const float* Rb = Rloc + b * NJ * 9;
+  const float* Jb = Jrest + b * NJ * 3;
+  if (l < NJ) {
+    const float* ga = g_A + (b * NJ + l) * 12;
+    for (int r = 0; r < 3; ++r) {
+      const float gt = ga[r * 4 + 3];
+      for (int c = 0; c < 3; ++c) gRG[l][r * 3 + c] = ga[r * 4 + c] - gt * Jb[l * 3 + c];
+      gtG[l][r] = gt + g_j16[(b * NJ + l) * 3 + r];
+    }
+    for (int c = 0; c < 3; ++c) {
+      float acc = 0.f;
+      for (int r = 0; r < 3; ++r) acc -= Gb[l * 12 + r * 4 + c] * ga[r * 4 + 3];
+      gJ[l][c] = acc;
+    }
+    for (int k = 0; k < 9; ++k) gRl[l][k] = (l > 0) ? g_pm[b * NP + (l - 1) * 9 + k] : 0.f;
+  }
+  __syncthreads();
+  // leaves -> root, one finger per lane; the root accumulators are touched by 5 lanes -> LDS float atomics
+  if (l < 5) {
+    for (int lev = 2; lev >= 0; --lev) {
+      const int j = 3 * l + 1 + lev, p = parent_of(j);
+      const float rel[3] = {Jb[j * 3] - Jb[p * 3], Jb[j * 3 + 1] - Jb[p * 3 + 1], Jb[j * 3 + 2] - Jb[p * 3 + 2]};
+      float gl[3];
+      for (int c = 0; c < 3; ++c) {
+        gl[c] = Gb[p * 12 + 0 * 4 + c] * gtG[j][0] + Gb[p * 12 + 1 * 4 + c] * gtG[j][1] + Gb[p * 12 + 2 * 4 + c] * gtG[j][2];
+      }
+      for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) {
+          // g_Rloc_j = RG_p^T g_RG_j
+          gRl[j][r * 3 + c] += Gb[p * 12 + 0 * 4 + r] * gRG[j][0 * 3 + c] + Gb[p * 12 + 1 * 4 + r] * gRG[j][1 * 3 + c] +
+                               Gb[p * 12 + 2 * 4 + r] * gRG[j][2 * 3 + c];
+          // g_RG_p += g_RG_j R_j^T + g_tG_j (x) rel
+          const float add = gRG[j][r * 3] * Rb[j * 9 + c * 3] + gRG[j][r * 3 + 1] * Rb[j * 9 + c * 3 + 1] +
+                            gRG[j][r * 3 + 2] * Rb[j * 9 + c * 3 + 2] + gtG[j][r] * rel[c];
+          if (p == 0) atomicAdd(&gRG[0][r * 3 + c], add); else gRG[p][r * 3 + c] += add;
+        }
+      for (int c = 0; c < 3; ++c) {
+        if (p == 0) { atomicAdd(&gtG[0][c], gtG[j][c]); atomicAdd(&gJ[0][c], -gl[c]); }
+        else { gtG[p][c] += gtG[j][c]; gJ[p][c] -= gl[c]; }
+        gJ[j][c] += gl[c];
+      }
+    }
+  }
+  __syncthreads();
+  if (l == 0) {
+    for (int k = 0; k < 9; ++k) gRl[0][k] += gRG[0][k];
+    for (int c = 0; c < 3; ++c) gJ[0][c] += gtG[0][c];
+  }
+  __syncthreads();
+  if (l < NJ) {
+    float aa[3];
+    for (int c = 0; c < 3; ++c) {
+      const float p = pose[b * 48 + 3 * l + c];
+      aa[c] = (l == 0) ? p : (M.hands_mean[3 * (l - 1) + c] + p);
+    }
+    float gaa[3];
+    rodrigues_bwd(aa, gRl[l], gaa);
+    for (int c = 0; c < 3; ++c) g_pose[b * 48 + 3 * l + c] = gaa[c];
+  }
+  if (l < NB) {
+    float acc = g_beta_b[b * NB + l];
+    for (int i = 0; i < NJ * 3; ++i) acc += M.J_dirs[i * NB + l] * gJ[i / 3][i % 3];
+    g_beta_b[b * NB + l] = acc;
+  }
+}
+
+__constant__ int c_tips[5] = {745, 317, 444, 556, 673};                                                  // manolayer.py:270
+__constant__ int c_reorder[21] = {0, 13, 14, 15, 16, 1, 2, 3, 17, 4, 5, 6, 18, 10, 11, 12, 19, 7, 8, 9, 20};  // :279
+
+// joints (B,21,3) mm from chain joints (m, no trans) and tip vertices (already mm, trans included)
+__global__ void lbs_joints_out_kernel(const float* __restrict__ j16, const float* __restrict__ verts, const float* __restrict__ trans,
+                                      int B, float* __restrict__ joints) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * 21 * 3) return;
+  const int b = i / 63, k = (i % 63) / 3, c = i % 3, src = c_reorder[k];
+  joints[i] = (src < NJ) ? (j16[(b * NJ + src) * 3 + c] + trans[3 * b + c]) * 1000.0f
+                         : verts[((size_t)b * NV + c_tips[src - NJ]) * 3 + c];
+}
+
+// split g_joints (B,21,3) into g_j16 (B,16,3) [metres] and adds the tip part into g_verts (B,778,3)
+__global__ void lbs_joints_bwd_kernel(const float* __restrict__ g_joints, int B, float* __restrict__ g_j16, float* __restrict__ g_verts) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * 21 * 3) return;
+  const int b = i / 63, k = (i % 63) / 3, c = i % 3, src = c_reorder[k];
+  if (src < NJ) g_j16[(b * NJ + src) * 3 + c] = g_joints[i] * 1000.0f;
+  else g_verts[((size_t)b * NV + c_tips[src - NJ]) * 3 + c] += g_joints[i];
+}
+
+// g_trans[b] = 1000 * (sum_v g_verts + sum_{chain joints} g_joints)
+__global__ void __launch_bounds__(256) lbs_gtrans_kernel(const float* __restrict__ g_verts, const float* __restrict__ g_j16,
+                                                         float* __restrict__ g_trans) {
+  __shared__ float red[4];
+  const int b = blockIdx.x;
+  float a[3] = {0.f, 0.f, 0.f};
+  for (int v = threadIdx.x; v < NV; v += 256)
+    for (int c = 0; c < 3; ++c) a[c] += g_verts[((size_t)b * NV + v) * 3 + c] * 1000.0f;
+  for (int j = threadIdx.x; j < NJ; j += 256)
+    for (int c = 0; c < 3; ++c) a[c] += g_j16[(b * NJ + j) * 3 + c];
+  for (int c = 0; c < 3; ++c) {
+    const float s = block_sum_256(a[c], red);
+    if (threadIdx.x == 0) g_trans[3 * b + c] = s;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t harp_lbs_mano_ws_floats(int B) {
+  // pose_map 135 | A 192 | j16 48 | Jrest 48 | Rloc 144 | G 192 | g_vp 2334 | M 9336 | g_A 192 | g_pm 135 | g_j16 48
+  return (size_t)B * (135 + 192 + 48 + 48 + 144 + 192 + 2334 + 9336 + 192 + 135 + 48);
+}
+
+struct LbsWs { float *pm, *A, *j16, *Jrest, *Rloc, *G, *g_vp, *Mo, *g_A, *g_pm, *g_j16; };
+static LbsWs lbs_ws(float* ws, int B) {
+  LbsWs w; float* p = ws;
+  w.pm = p; p += (size_t)B * 135; w.A = p; p += (size_t)B * 192; w.j16 = p; p += (size_t)B * 48; w.Jrest = p; p += (size_t)B * 48;
+  w.Rloc = p; p += (size_t)B * 144; w.G = p; p += (size_t)B * 192; w.g_vp = p; p += (size_t)B * 2334; w.Mo = p; p += (size_t)B * 9336;
+  w.g_A = p; p += (size_t)B * 192; w.g_pm = p; p += (size_t)B * 135; w.g_j16 = p;
+  return w;
+}
+
+int harp_lbs_mano_fwd(const harp_mano_model* m, const float* pose, const float* betas, const float* trans, int B, float* ws,
+                      float* verts, float* joints, hipStream_t stream) {
+  if (!m || !pose || !betas || !trans || !ws || !verts || !joints || B <= 0) return HARP_ERR_ARG;
+  const LbsWs w = lbs_ws(ws, B);
+  hipLaunchKernelGGL(lbs_joints_kernel, dim3(B), dim3(64), 0, stream, *m, pose, betas, w.pm, w.A, w.j16, w.Jrest, w.Rloc, w.G);
+  hipLaunchKernelGGL(lbs_skin_kernel<false>, dim3((NV + 255) / 256, (B + FRAMES_PER_BLOCK - 1) / FRAMES_PER_BLOCK), dim3(256), 0, stream,
+                     *m, betas, trans, w.pm, w.A, B, verts, nullptr, nullptr, nullptr);
+  hipLaunchKernelGGL(lbs_joints_out_kernel, dim3((B * 63 + 255) / 256), dim3(256), 0, stream, w.j16, verts, trans, B, joints);
+  HARP_CHECK_LAUNCH();
+  return HARP_OK;
+}
+
+// g_verts (B,778,3) is MODIFIED (tip-joint gradients are folded in). Outputs: g_pose (B,48), g_betas (B,10), g_trans (B,3).
+int harp_lbs_mano_bwd(const harp_mano_model* m, const float* pose, const float* betas, const float* trans, int B, float* ws,
+                      float* g_verts, const float* g_joints, float* g_pose, float* g_betas, float* g_trans, hipStream_t stream) {
+  if (!m || !pose || !betas || !ws || !g_verts || !g_joints || !g_pose || !g_betas || !g_trans) return HARP_ERR_ARG;
+  const LbsWs w = lbs_ws(ws, B);
+  hipLaunchKernelGGL(lbs_joints_bwd_kernel, dim3((B * 63 + 255) / 256), dim3(256), 0, stream, g_joints, B, w.g_j16, g_verts);
+  hipLaunchKernelGGL(lbs_gtrans_kernel, dim3(B), dim3(256), 0, stream, g_verts, w.g_j16, g_trans);
+  hipLaunchKernelGGL(lbs_skin_kernel<true>, dim3((NV + 255) / 256, (B + FRAMES_PER_BLOCK - 1) / FRAMES_PER_BLOCK), dim3(256), 0, stream,
+                     *m, betas, trans, w.pm, w.A, B, nullptr, g_verts, w.g_vp, w.Mo);
+  hipLaunchKernelGGL(lbs_gA_kernel, dim3(B), dim3(192), 0, stream, m->weights, w.Mo, w.g_A);
+  hipLaunchKernelGGL(lbs_gpm_kernel, dim3(B), dim3(192), 0, stream, *m, w.g_vp, w.g_pm, g_betas);
+  hipLaunchKernelGGL(lbs_chain_bwd_kernel, dim3(B), dim3(64), 0, stream, *m, pose, w.Rloc, w.G, w.Jrest, w.g_A, w.g_pm, w.g_j16,
+                     g_pose, g_betas);
+  HARP_CHECK_LAUNCH();
+  return HARP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,373 @@
+// Loss terms of the HARP fitting loop (optimize_sequence.py:517-553) with their gradients, texture-map helpers and
+// the fused Adam update, for gfx950.  Each kernel evaluates a term AND, when a device weight array is given, its
+// gradient (weight = d total / d term, i.e. the loss weight of optimize_sequence.py:411-422 in the fused engine or
+// the autograd upstream scalar in the op-level API), so forward and backward share one pass over the data.
+#include "harp_common.h"
+#include "harp_hip.h"
+
+namespace {
+
+__device__ __forceinline__ float sgn(float x) { return (x > 0.f) - (x < 0.f); }
+
+// L1Loss(mean) between pred*mask and target*mask, C channels, mask broadcast over channels (optimize_sequence.py:519,543).
+// frame b of pred pairs with frame fid[b] of target/mask (fid NULL => identity).  n_per_frame = S*S*C.
+__global__ void __launch_bounds__(256) image_l1_kernel(const float* __restrict__ pred, const float* __restrict__ target,
+                                                       const float* __restrict__ mask, const int32_t* __restrict__ fid,
+                                                       int n_per_frame, int C, float inv_count, const float* __restrict__ w,
+                                                       float* __restrict__ loss, float* __restrict__ g_pred) {
+  __shared__ float red[4];
+  const int b = blockIdx.y;
+  const int tb = fid ? fid[b] : b;
+  const float* p = pred + (size_t)b * n_per_frame;
+  const float* t = target + (size_t)tb * n_per_frame;
+  const float* m = mask ? mask + (size_t)tb * (n_per_frame / C) : nullptr;
+  const float wk = w ? w[0] * inv_count : 0.f;
+  float acc = 0.f;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n_per_frame; i += gridDim.x * 256) {
+    const float mm = m ? m[i / C] : 1.f;
+    const float d = p[i] * mm - t[i] * mm;
+    acc += fabsf(d);
+    if (g_pred) g_pred[(size_t)b * n_per_frame + i] = wk * sgn(d) * mm;
+  }
+  const float s = block_sum_256(acc, red);
+  if (threadIdx.x == 0) atomicAdd(loss, s * inv_count);
+}
+
+// kps_loss (loss/kps_loss.py:4-17): mean_{b,j} (|| (gt-gt0) - 1000 (pred-pred0) ||/100)^2 over the first 21 joints.
+__global__ void __launch_bounds__(64) kps_kernel(const float* __restrict__ gt, const int32_t* __restrict__ fid,
+                                                 const float* __restrict__ pred, int B, int NJp, const float* __restrict__ w,
+                                                 float* __restrict__ loss, float* __restrict__ g_pred) {
+  const int b = blockIdx.x, j = threadIdx.x;
+  const float* g = gt + (size_t)(fid ? fid[b] : b) * 63;
+  const float* p = pred + (size_t)b * NJp * 3;
+  float d[3] = {0.f, 0.f, 0.f}, l = 0.f;
+  if (j < 21) {
+    for (int c = 0; c < 3; ++c) {
+      d[c] = (g[3 * j + c] - g[c]) - (p[3 * j + c] - p[c]) * 1000.0f;
+      l += d[c] * d[c];
+    }
+    l = sqrtf(l) / 100.0f;
+    l = l * l;
+  }
+  const float inv = 1.0f / (float)(B * 21);
+  const float s = wave_sum(l);
+  if (j == 0) atomicAdd(loss, s * inv);
+  if (w && g_pred) {
+    const float k = w[0] * inv * -2000.0f / 10000.0f;
+    float c3[3];
+    for (int c = 0; c < 3; ++c) {
+      c3[c] = (j < 21) ? k * d[c] : 0.f;
+      const float tot = wave_sum(c3[c]);
+      if (j > 0 && j < 21) g_pred[((size_t)b * NJp + j) * 3 + c] += c3[c];
+      if (j == 0) g_pred[((size_t)b * NJp) * 3 + c] += c3[c] - tot;
+    }
+  }
+}
+
+// laplacian (uniform, Appendix A.11) | normal consistency (A.12) | ARAP (loss/arap.py:45-57); blockIdx.y = frame
+// w[0..2] = weights of (laplacian, normal, arap); loss[0..2] accumulate.
+__global__ void __launch_bounds__(256) mesh_reg_kernel(const float* __restrict__ verts, const float* __restrict__ ref_verts,
+                                                       const int32_t* __restrict__ nbr_off, const int32_t* __restrict__ nbr_idx,
+                                                       const int32_t* __restrict__ pairs, const int32_t* __restrict__ edges, int B,
+                                                       int V, int P, int E, const float* __restrict__ w, float* __restrict__ loss,
+                                                       float* __restrict__ g_verts) {
+  __shared__ float red[4];
+  const int b = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+  const float* vb = verts + (size_t)b * V * 3;
+  float* gb = g_verts ? g_verts + (size_t)b * V * 3 : nullptr;
+  float l_lap = 0.f, l_nc = 0.f, l_ar = 0.f;
+  const bool grad = (w != nullptr) && (gb != nullptr);
+  if (i < V) {
+    const int s = nbr_off[i], e = nbr_off[i + 1];
+    float a[3] = {0.f, 0.f, 0.f};
+    for (int k = s; k < e; ++k) for (int c = 0; c < 3; ++c) a[c] += vb[3 * nbr_idx[k] + c];
+    const float invd = 1.0f / (float)(e - s);
+    float lv[3], n2 = 0.f;
+    for (int c = 0; c < 3; ++c) { lv[c] = a[c] * invd - vb[3 * i + c]; n2 += lv[c] * lv[c]; }
+    const float n = sqrtf(n2);
+    const float sc = 1.0f / ((float)V * (float)B);
+    l_lap = n * sc;
+    if (grad && n > 0.f) {
+      const float k = w[0] * sc / n;
+      for (int c = 0; c < 3; ++c) {
+        const float g = k * lv[c];
+        atomicAdd(gb + 3 * i + c, -g);
+        for (int q = s; q < e; ++q) atomicAdd(gb + 3 * nbr_idx[q] + c, g * invd);
+      }
+    }
+  }
+  if (i < P) {
+    const int i0 = pairs[4 * i], i1 = pairs[4 * i + 1], ia = pairs[4 * i + 2], ib = pairs[4 * i + 3];
+    float e[3], da[3], db[3];
+    for (int c = 0; c < 3; ++c) { e[c] = vb[3 * i1 + c] - vb[3 * i0 + c]; da[c] = vb[3 * ia + c] - vb[3 * i0 + c]; db[c] = vb[3 * ib + c] - vb[3 * i0 + c]; }
+    const float n0[3] = {e[1] * da[2] - e[2] * da[1], e[2] * da[0] - e[0] * da[2], e[0] * da[1] - e[1] * da[0]};
+    const float n1[3] = {-(e[1] * db[2] - e[2] * db[1]), -(e[2] * db[0] - e[0] * db[2]), -(e[0] * db[1] - e[1] * db[0])};
+    const float l0 = sqrtf(n0[0] * n0[0] + n0[1] * n0[1] + n0[2] * n0[2]), l1 = sqrtf(n1[0] * n1[0] + n1[1] * n1[1] + n1[2] * n1[2]);
+    const float dp = n0[0] * n1[0] + n0[1] * n1[1] + n0[2] * n1[2];
+    const float den = fmaxf(l0 * l1, 1e-8f);
+    const float cs = dp / den;
+    const float sc = 1.0f / ((float)P * (float)B);
+    l_nc = (1.0f - cs) * sc;
+    if (grad) {
+      const float k = -w[1] * sc;                       // d/d cos
+      float g0[3], g1[3];
+      // torch 1.11 cosine_similarity: w12 / sqrt(clamp_min(w1*w2, eps^2)); the clamp is ACTIVE for mm-sized triangles
+      // (|n0||n1| ~ 1e-11 < 1e-8), where cos = w12 / eps and only the numerator carries gradient.
+      const bool clamped = !(l0 * l1 > 1e-8f);
+      for (int c = 0; c < 3; ++c) {
+        g0[c] = k * (n1[c] / den - (clamped ? 0.f : cs * n0[c] / (l0 * l0)));
+        g1[c] = k * (n0[c] / den - (clamped ? 0.f : cs * n1[c] / (l1 * l1)));
+      }
+      // n0 = e x da : g_e = da x g0, g_da = g0 x e ;  n1 = -(e x db): g_e += -(db x g1), g_db = -(g1 x e)
+      const float ge[3] = {da[1] * g0[2] - da[2] * g0[1] - (db[1] * g1[2] - db[2] * g1[1]),
+                           da[2] * g0[0] - da[0] * g0[2] - (db[2] * g1[0] - db[0] * g1[2]),
+                           da[0] * g0[1] - da[1] * g0[0] - (db[0] * g1[1] - db[1] * g1[0])};
+      const float gda[3] = {g0[1] * e[2] - g0[2] * e[1], g0[2] * e[0] - g0[0] * e[2], g0[0] * e[1] - g0[1] * e[0]};
+      const float gdb[3] = {-(g1[1] * e[2] - g1[2] * e[1]), -(g1[2] * e[0] - g1[0] * e[2]), -(g1[0] * e[1] - g1[1] * e[0])};
+      for (int c = 0; c < 3; ++c) {
+        atomicAdd(gb + 3 * i1 + c, ge[c]);
+        atomicAdd(gb + 3 * ia + c, gda[c]);
+        atomicAdd(gb + 3 * ib + c, gdb[c]);
+        atomicAdd(gb + 3 * i0 + c, -ge[c] - gda[c] - gdb[c]);
+      }
+    }
+  }
+  if (i < E && ref_verts) {
+    const int i0 = edges[2 * i], i1 = edges[2 * i + 1];
+    float d[3], l2 = 0.f, r2 = 0.f;
+    for (int c = 0; c < 3; ++c) {
+      d[c] = vb[3 * i0 + c] - vb[3 * i1 + c];
+      l2 += d[c] * d[c];
+      const float r = ref_verts[3 * i0 + c] - ref_verts[3 * i1 + c];
+      r2 += r * r;
+    }
+    const float l = sqrtf(l2);
+    const float diff = l * 1000.0f - sqrtf(r2) * 1000.0f;
+    const float sc = 1.0f / ((float)E * (float)B);
+    l_ar = diff * diff * sc;
+    if (grad && l > 0.f) {
+      const float k = w[2] * sc * 2.0f * diff * 1000.0f / l;
+      for (int c = 0; c < 3; ++c) { atomicAdd(gb + 3 * i0 + c, k * d[c]); atomicAdd(gb + 3 * i1 + c, -k * d[c]); }
+    }
+  }
+  const float s0 = block_sum_256(l_lap, red), s1 = block_sum_256(l_nc, red), s2 = block_sum_256(l_ar, red);
+  if (threadIdx.x == 0) {
+    if (s0 != 0.f) atomicAdd(loss, s0);
+    if (s1 != 0.f) atomicAdd(loss + 1, s1);
+    if (s2 != 0.f) atomicAdd(loss + 2, s2);
+  }
+}
+
+// sum(d^2) (optimize_sequence.py:533)
+__global__ void __launch_bounds__(256) sumsq_kernel(const float* __restrict__ d, int n, const float* __restrict__ w,
+                                                    float* __restrict__ loss, float* __restrict__ g) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    acc += d[i] * d[i];
+    if (w && g) g[i] += 2.0f * w[0] * d[i];
+  }
+  const float s = block_sum_256(acc, red);
+  if (threadIdx.x == 0) atomicAdd(loss, s);
+}
+
+// albedo_reg / smooth_texture_reg (loss/texture_reg.py:5-30, 48-66): mean_xy( ||t[x,y]-t[x+dx,y+dy]||_1 / 3 * mask )
+__global__ void __launch_bounds__(256) tex_smooth_kernel(const float* __restrict__ t, const int32_t* __restrict__ dist,
+                                                         const float* __restrict__ mask, int H, int W, const float* __restrict__ w,
+                                                         float* __restrict__ loss, float* __restrict__ g) {
+  __shared__ float red[4];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  float acc = 0.f;
+  if (i < H * W) {
+    const int x = i / W, y = i % W;                    // reference names: x = row, y = column
+    const int tx = min(max(x + dist[2 * i], 0), H - 1), ty = min(max(y + dist[2 * i + 1], 0), W - 1);
+    const int j = tx * W + ty;
+    const float m = mask ? mask[i] : 1.f;
+    const float k = (w ? w[0] : 0.f) * m / (3.0f * (float)(H * W));
+    for (int c = 0; c < 3; ++c) {
+      const float d = t[3 * i + c] - t[3 * j + c];
+      acc += fabsf(d);
+      if (w && g && d != 0.f) { atomicAdd(g + 3 * i + c, k * sgn(d)); atomicAdd(g + 3 * j + c, -k * sgn(d)); }
+    }
+    acc = acc / 3.0f * m;
+  }
+  const float s = block_sum_256(acc, red);
+  if (threadIdx.x == 0) atomicAdd(loss, s / (float)(H * W));
+}
+
+// close_to_z_reg (loss/texture_reg.py:40-45) as the reference computes it: L2 norm over the WIDTH axis of
+// (nm - (0,0,1)) for every (row, channel), /3, mean over rows x channels. One block per row.
+__global__ void __launch_bounds__(256) close_to_z_kernel(const float* __restrict__ nm, int H, int W, const float* __restrict__ w,
+                                                         float scale, float* __restrict__ loss, float* __restrict__ g) {
+  __shared__ float red[4];
+  __shared__ float s_norm[3];
+  const int h = blockIdx.x;
+  float a[3] = {0.f, 0.f, 0.f};
+  for (int x = threadIdx.x; x < W; x += 256)
+    for (int c = 0; c < 3; ++c) { const float d = nm[((size_t)h * W + x) * 3 + c] - (c == 2 ? 1.f : 0.f); a[c] += d * d; }
+  for (int c = 0; c < 3; ++c) {
+    const float s = block_sum_256(a[c], red);
+    if (threadIdx.x == 0) s_norm[c] = sqrtf(s);
+  }
+  __syncthreads();
+  const float inv = 1.0f / (3.0f * (float)(H * 3));
+  if (threadIdx.x == 0) atomicAdd(loss, scale * (s_norm[0] + s_norm[1] + s_norm[2]) * inv);
+  if (w && g) {
+    const float k = w[0] * scale * inv;
+    for (int x = threadIdx.x; x < W; x += 256)
+      for (int c = 0; c < 3; ++c)
+        if (s_norm[c] > 0.f) g[((size_t)h * W + x) * 3 + c] += k * (nm[((size_t)h * W + x) * 3 + c] - (c == 2 ? 1.f : 0.f)) / s_norm[c];
+  }
+}
+
+// F.normalize(normal_map, dim=-1) per texel (utils/visualize.py:99), eps 1e-12
+__global__ void normalize3_fwd_kernel(const float* __restrict__ x, int n, float* __restrict__ y) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float a = x[3 * i], b = x[3 * i + 1], c = x[3 * i + 2];
+  const float inv = 1.0f / fmaxf(sqrtf(a * a + b * b + c * c), 1e-12f);
+  y[3 * i] = a * inv; y[3 * i + 1] = b * inv; y[3 * i + 2] = c * inv;
+}
+__global__ void normalize3_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gy, int n, float* __restrict__ gx) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float a = x[3 * i], b = x[3 * i + 1], c = x[3 * i + 2];
+  const float l = sqrtf(a * a + b * b + c * c);
+  const float g0 = gy[3 * i], g1 = gy[3 * i + 1], g2 = gy[3 * i + 2];
+  if (l > 1e-12f) {
+    const float inv = 1.0f / l, na = a * inv, nb = b * inv, nc = c * inv, d = na * g0 + nb * g1 + nc * g2;
+    gx[3 * i] += (g0 - na * d) * inv; gx[3 * i + 1] += (g1 - nb * d) * inv; gx[3 * i + 2] += (g2 - nc * d) * inv;
+  } else {
+    gx[3 * i] += g0 * 1e12f; gx[3 * i + 1] += g1 * 1e12f; gx[3 * i + 2] += g2 * 1e12f;
+  }
+}
+
+// torch.optim.Adam (betas, eps, no weight decay, no amsgrad) on a flat segment; bias corrections computed on the host.
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, size_t n,
+                            float step_size, float beta1, float beta2, float eps, float inv_sqrt_bc2, float gscale) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float gi = g[i] * gscale;
+    const float mi = m[i] + (gi - m[i]) * (1.0f - beta1);        // exp_avg.lerp_(grad, 1-beta1)
+    const float vi = v[i] * beta2 + (1.0f - beta2) * gi * gi;    // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1-beta2)
+    m[i] = mi; v[i] = vi;
+    p[i] -= step_size * (mi / (sqrtf(vi) * inv_sqrt_bc2 + eps));
+  }
+}
+
+// device-resident hyper-parameters so that a captured hipGraph can be replayed while step / lr change
+__global__ void adam_tick_kernel(harp_adam_hyper* h) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    h->step += 1;
+    const double bc1 = 1.0 - pow((double)h->beta1, (double)h->step), bc2 = 1.0 - pow((double)h->beta2, (double)h->step);
+    h->step_size = (float)((double)h->lr / bc1);
+    h->inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+  }
+}
+__global__ void adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                size_t n, const harp_adam_hyper* __restrict__ h) {
+  const float step_size = h->step_size, beta1 = h->beta1, beta2 = h->beta2, eps = h->eps, isb = h->inv_sqrt_bc2, gs = h->grad_scale;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float gi = g[i] * gs;
+    const float mi = m[i] + (gi - m[i]) * (1.0f - beta1);
+    const float vi = v[i] * beta2 + (1.0f - beta2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    p[i] -= step_size * (mi / (sqrtf(vi) * isb + eps));
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int harp_adam_tick(harp_adam_hyper* h, hipStream_t stream) {
+  if (!h) return HARP_ERR_ARG;
+  hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(64), 0, stream, h);
+  HARP_CHECK_LAUNCH();
+  return HARP_OK;
+}
+
+int harp_adam_apply(float* p, const float* g, float* m, float* v, size_t n, const harp_adam_hyper* h, hipStream_t stream) {
+  if (!p || !g || !m || !v || !h) return HARP_ERR_ARG;
+  const int blocks = (int)min((size_t)2048, (n + 255) / 256);
+  hipLaunchKernelGGL(adam_dev_kernel, dim3(blocks), dim3(256), 0, stream, p, g, m, v, n, h);
+  HARP_CHECK_LAUNCH();
+  return HARP_OK;
+}
+
+int harp_image_l1(const float* pred, const float* target, const float* mask, const int32_t* fid, int B, int n_per_frame, int C,
+                  const float* w, float* loss, float* g_pred, hipStream_t stream) {
+  if (!pred || !target || !loss || B <= 0) return HARP_ERR_ARG;
+  const float inv = 1.0f / ((float)B * (float)n_per_frame);
+  const int gx = min((n_per_frame + 255) / 256, 64);
+  hipLaunchKernelGGL(image_l1_kernel, dim3(gx, B), dim3(256), 0, stream, pred, target, mask, fid, n_per_frame, C, inv, w, loss, g_pred);
+  HARP_CHECK_LAUNCH();
+  return HARP_OK;
+}
+
+int harp_kps_loss(const float* gt, const int32_t* fid, const float* pred, int B, int n_joints_pred, const float* w, float* loss,
+                  float* g_pred, hipStream_t stream) {
+  if (!gt || !pred || !loss || n_joints_pred < 21) return HARP_ERR_ARG;
+  hipLaunchKernelGGL(kps_kernel, dim3(B), dim3(64), 0, stream, gt, fid, pred, B, n_joints_pred, w, loss, g_pred);
+  HARP_CHECK_LAUNCH();
+  return HARP_OK;
+}
+
+int harp_mesh_regularizers(const float* verts, const float* ref_verts, const int32_t* nbr_off, const int32_t* nbr_idx,
+                           const int32_t* nc_pairs, const int32_t* edges, int B, int V, int P, int E, const float* w, float* loss,
+                           float* g_verts, hipStream_t stream) {
+  if (!verts || !nbr_off || !nbr_idx || !nc_pairs || !edges || !loss) return HARP_ERR_ARG;
+  const int n = max(V, max(P, E));
+  hipLaunchKernelGGL(mesh_reg_kernel, dim3((n + 255) / 256, B), dim3(256), 0, stream, verts, ref_verts, nbr_off, nbr_idx, nc_pairs, edges,
+                     B, V, P, E, w, loss, g_verts);
+  HARP_CHECK_LAUNCH();
+  return HARP_OK;
+}
+
+int harp_sum_squares(const float* x, int n, const float* w, float* loss, float* g, hipStream_t stream) {
+  if (!x || !loss) return HARP_ERR_ARG;
+  hipLaunchKernelGGL(sumsq_kernel, dim3(min((n + 255) / 256, 64)), dim3(256), 0, stream, x, n, w, loss, g);
+  HARP_CHECK_LAUNCH();
+  return HARP_OK;
+}
+
+int harp_texture_smooth_reg(const float* tex, const int32_t* dist, const float* mask, int H, int W, const float* w, float* loss,
+                            float* g_tex, hipStream_t stream) {
+  if (!tex || !dist || !loss) return HARP_ERR_ARG;
+  hipLaunchKernelGGL(tex_smooth_kernel, dim3((H * W + 255) / 256), dim3(256), 0, stream, tex, dist, mask, H, W, w, loss, g_tex);
+  HARP_CHECK_LAUNCH();
+  return HARP_OK;
+}
+
+int harp_close_to_z_reg(const float* nm, int H, int W, float scale, const float* w, float* loss, float* g_nm, hipStream_t stream) {
+  if (!nm || !loss) return HARP_ERR_ARG;
+  hipLaunchKernelGGL(close_to_z_kernel, dim3(H), dim3(256), 0, stream, nm, H, W, w, scale, loss, g_nm);
+  HARP_CHECK_LAUNCH();
+  return HARP_OK;
+}
+
+int harp_normalize3_fwd(const float* x, int n, float* y, hipStream_t stream) {
+  if (!x || !y) return HARP_ERR_ARG;
+  hipLaunchKernelGGL(normalize3_fwd_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, x, n, y);
+  HARP_CHECK_LAUNCH();
+  return HARP_OK;
+}
+
+int harp_normalize3_bwd(const float* x, const float* gy, int n, float* gx, hipStream_t stream) {
+  if (!x || !gy || !gx) return HARP_ERR_ARG;
+  hipLaunchKernelGGL(normalize3_bwd_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, x, gy, n, gx);
+  HARP_CHECK_LAUNCH();
+  return HARP_OK;
+}
+
+int harp_adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps, int step,
+                   float grad_scale, hipStream_t stream) {
+  if (!p || !g || !m || !v || step < 1) return HARP_ERR_ARG;
+  const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+  const float step_size = (float)((double)lr / bc1), inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+  const int blocks = (int)min((size_t)2048, (n + 255) / 256);
+  hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, stream, p, g, m, v, n, step_size, beta1, beta2, eps, inv_sqrt_bc2, grad_scale);
+  HARP_CHECK_LAUNCH();
+  return HARP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,357 @@
+"""Fused render-and-compare step: the loop body of the reference's `optimize_hand_sequence`
+(optimize_sequence.py:446-579) as one pre-planned sequence of HIP kernel launches over pre-allocated HBM buffers,
+replayable as a hipGraph, with one RCCL all-reduce of the flat gradient arena between backward and Adam.
+
+What the reference does per step with ~600 torch/PyTorch3D kernel launches, >= 8 host syncs and CPU-resident
+parameters, this does with ~45 launches, no host sync and everything resident:
+
+  frame_setup -> LBS -> subdivide -> normals+displace -> normals -> project(cam) -> centroid -> light_setup ->
+  project(light) -> raster(light, K=1) -> raster(cam, K=1 + soft silhouette) -> normalize(normal map) -> shade ->
+  losses(+their gradients) -> shade_bwd -> silhouette_bwd -> depth_bwd -> project_bwd x2 -> light_setup_bwd ->
+  normals_bwd x2 -> displace_bwd -> subdivide_bwd -> LBS_bwd -> frame_setup_bwd -> [all-reduce] -> Adam x2
+
+Parameters live in ONE flat fp32 arena (and one gradient / exp_avg / exp_avg_sq arena of the same layout); the
+reference's parameter dict (optimize_sequence.py:181-250) is exposed as views into it (`params`).
+Multi-GPU: frames are sharded over ranks, every rank holds the full arena; gradients are summed with one all_reduce
+and scaled by 1/world inside the Adam kernel (SURVEY.md §5 "Data-parallel semantics").
+"""
+import ctypes
+import math
+
+import numpy as np
+import torch
+
+from . import _lib, ops
+from .manopth.manolayer import ManoDeviceModel
+
+LOSS_NAMES = ["silhouette", "kps_anchor", "vert_disp_reg", "laplacian", "normal", "arap", "photo", "albedo", "normal_reg"]
+LOSS_WEIGHTS = {"silhouette": 7.0, "kps_anchor": 10.0, "vert_disp_reg": 2.0, "laplacian": 4.0, "normal": 0.1, "arap": 0.2,
+                "photo": 1.0, "albedo": 0.5, "normal_reg": 0.1}                     # optimize_sequence.py:411-422 (vgg: §8f "next")
+COARSE_TERMS = LOSS_NAMES[:6]
+APP_TERMS = LOSS_NAMES[6:]
+
+
+class _Arena:
+    """Flat fp32 buffer with named, 64-float aligned segments."""
+
+    def __init__(self, spec, device):
+        self.offsets, off = {}, 0
+        for name, shape in spec:
+            n = int(np.prod(shape)) if len(shape) else 1
+            self.offsets[name] = (off, n, tuple(shape))
+            off += (n + 63) // 64 * 64
+        self.size = off
+        self.device = device
+
+    def alloc(self):
+        return torch.zeros(self.size, dtype=torch.float32, device=self.device)
+
+    def view(self, buf, name):
+        off, n, shape = self.offsets[name]
+        return buf[off:off + n].view(shape)
+
+    def span(self, first, last):
+        o0 = self.offsets[first][0]
+        o1, n1, _ = self.offsets[last]
+        return o0, (o1 + n1 + 63) // 64 * 64 - o0
+
+
+class FitEngine:
+    """One rank's share of a HARP fitting job.
+
+    model: MANO-shaped dict (numpy) — v_template, shapedirs, posedirs, J_regressor, weights, hands_mean.
+    topo: harp_amd.synth.build_topology(...) dict; verts_uvs/faces_uvs/uv_mask: template UV data.
+    input_params: dict of (T,.) tensors as `init_params` consumes (pose, rot, trans, shape, cam, joints).
+    """
+
+    def __init__(self, model, topo, verts_uvs, faces_uvs, uv_mask, input_params, img_size, focal_length, batch_size,
+                 device="cuda", self_shadow=True, share_light_position=True, tex_size=512, rank=0, world_size=1, seed=0):
+        self.dev = torch.device(device)
+        self.S, self.focal, self.B = int(img_size), float(focal_length), int(batch_size)
+        self.self_shadow, self.share_light = bool(self_shadow), bool(share_light_position)
+        self.rank, self.world = rank, world_size
+        self.topo = ops.DeviceTopology(topo, verts_uvs, faces_uvs, self.dev)
+        self.dm = ManoDeviceModel(model, self.dev)
+        T = input_params["pose"].shape[0]
+        self.T, V = T, self.topo.V
+        self.Ht = self.Wt = tex_size
+        # ---- parameter arena: [coarse group | appearance group | not optimised]  (optimize_sequence.py:253-310)
+        spec = [("pose", (T, 45)), ("cam", (T, 3)), ("verts_disps", (V, 1)), ("shape", (10,)),
+                ("light_positions", (T, 3)), ("amb_ratio", ()), ("texture", (1, tex_size, tex_size, 3)), ("normal_map", (1, tex_size, tex_size, 3)),
+                ("rot", (T, 3)), ("trans", (T, 3)), ("wrist_pose", (T, 3))]
+        self.arena = _Arena(spec, self.dev)
+        self.p_buf, self.g_buf, self.m_buf, self.v_buf = (self.arena.alloc() for _ in range(4))
+        self.params = {k: self.arena.view(self.p_buf, k) for k, _ in spec}
+        self.grads = {k: self.arena.view(self.g_buf, k) for k, _ in spec}
+        self.coarse_span = self.arena.span("pose", "shape")
+        self.app_span = self.arena.span("light_positions", "normal_map")
+        self.opt_span = (self.coarse_span[0], self.app_span[0] + self.app_span[1] - self.coarse_span[0])
+        with torch.no_grad():                                                         # init_params (optimize_sequence.py:181-250)
+            for k in ("pose", "rot", "trans", "cam"):
+                self.params[k].copy_(input_params[k].to(self.dev))
+            self.params["shape"].copy_(input_params["shape"].mean(0).to(self.dev))
+            self.params["texture"].copy_((torch.tensor([232, 190, 172]).repeat(1, tex_size, tex_size, 1) / 255.).to(self.dev))
+            self.params["normal_map"].copy_(torch.tensor([0.0, 0.0, 1.0]).repeat(1, tex_size, tex_size, 1).to(self.dev))
+            self.params["light_positions"].copy_(torch.tensor(((-0.5, -0.5, -0.5),)).repeat(T, 1).to(self.dev))
+            self.params["amb_ratio"].fill_(0.4)
+        self.uv_mask = torch.as_tensor(np.asarray(uv_mask), dtype=torch.float32).to(self.dev).contiguous() if uv_mask is not None else None
+        self.init_joints = input_params["joints"].to(self.dev).float().contiguous() if "joints" in input_params else None
+        # ---- frame tables struct
+        t = _lib.FrameTables()
+        for k in ("pose", "rot", "trans", "cam", "shape", "light_positions", "amb_ratio"):
+            setattr(t, k, _lib.ptr(self.params[k]))
+            setattr(t, "g_" + k, _lib.ptr(self.grads[k]))
+        t.share_light = int(self.share_light)
+        self.tables = t
+        # ---- Adam hyper-parameters on the device (coarse lr 1e-3, appearance lr 1e-2; torch defaults otherwise)
+        self.hyper_np = np.zeros(2, dtype=[("lr", "f4"), ("beta1", "f4"), ("beta2", "f4"), ("eps", "f4"), ("grad_scale", "f4"),
+                                           ("step", "i4"), ("step_size", "f4"), ("inv_sqrt_bc2", "f4")])
+        self.hyper_np["lr"] = [1e-3, 1e-2]
+        self.hyper_np["beta1"], self.hyper_np["beta2"], self.hyper_np["eps"] = 0.9, 0.999, 1e-8
+        self.hyper_np["grad_scale"] = 1.0 / world_size
+        self.hyper = torch.from_numpy(self.hyper_np.view(np.uint8).copy()).to(self.dev)
+        self._hyper_stride = self.hyper_np.dtype.itemsize
+        # ---- targets (set by set_targets) and per-step scratch
+        self.y_true = self.y_sil = self.y_sil_col = None
+        self.target_offset = 0
+        self._alloc_scratch(self.B)
+        self.loss_vec = torch.zeros(16, dtype=torch.float32, device=self.dev)
+        self.w_vec = torch.zeros(16, dtype=torch.float32, device=self.dev)
+        self.fid = torch.zeros(self.B, dtype=torch.int32, device=self.dev)
+        self.tfid = torch.zeros(self.B, dtype=torch.int32, device=self.dev)
+        self.dist_albedo = torch.zeros(tex_size, tex_size, 2, dtype=torch.int32, device=self.dev)
+        self.dist_normal = torch.zeros(tex_size, tex_size, 2, dtype=torch.int32, device=self.dev)
+        self.gen = torch.Generator(device=self.dev)
+        self.gen.manual_seed(seed)                      # SAME seed on every rank
+        self.ref_verts = None
+        self._graphs = {}
+        self.compute_reference_mesh()
+
+    # ------------------------------------------------------------------------------------------------
+    def _alloc_scratch(self, B):
+        dev, V, S = self.dev, self.topo.V, self.S
+        f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+        z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
+        L = _lib.lib()
+        self.s = s = {}
+        s["pose48"], s["betas"], s["trans_b"] = f(B, 48), f(B, 10), f(B, 3)
+        s["cam_R"], s["cam_T"], s["light_pos"], s["colors"] = f(B, 9), f(B, 3), f(B, 3), f(9)
+        s["lbs_ws"] = f(L.harp_lbs_mano_ws_floats(B))
+        s["verts_mm"], s["joints_mm"], s["joints_m"] = f(B, 778, 3), f(B, 21, 3), f(B, 21, 3)
+        s["vs"], s["n1"], s["il1"], s["vd"], s["n2"], s["il2"] = f(B, V, 3), f(B, V, 3), f(B, V), f(B, V, 3), f(B, V, 3), f(B, V)
+        s["ndc_c"], s["ndc_l"], s["centroid"], s["light_R"], s["light_T"] = f(B, V, 3), f(B, V, 3), f(B, 3), f(B, 9), f(B, 3)
+        s["ws_c"] = ops.rasterize_workspace(B, self.topo.F, S, dev)
+        s["ws_l"] = ops.rasterize_workspace(B, self.topo.F, S, dev)
+        s["face_c"] = torch.empty(B, S, S, dtype=torch.int32, device=dev)
+        s["face_l"] = torch.empty(B, S, S, dtype=torch.int32, device=dev)
+        s["alpha"], s["zl"], s["rgb"] = f(B, S, S), f(B, S, S), f(B, S, S, 3)
+        s["nmap_n"] = f(self.Ht, self.Wt, 3)
+        # gradients (zeroed every step in ONE memset: they are carved from one flat buffer)
+        gspec = [("g_alpha", (B, S, S)), ("g_rgb", (B, S, S, 3)), ("g_zl", (B, S, S)), ("g_vd", (B, V, 3)), ("g_n2", (B, V, 3)),
+                 ("g_ndc_c", (B, V, 3)), ("g_ndc_l", (B, V, 3)), ("g_n1", (B, V, 3)), ("g_vs", (B, V, 3)), ("g_tmp", (B, V, 3)),
+                 ("g_v0", (B, 778, 3)), ("g_joints_m", (B, 21, 3)), ("g_joints_mm", (B, 21, 3)), ("g_light_pos", (B, 3)), ("g_colors", (9,)),
+                 ("g_light_R", (B, 9)), ("g_light_T", (B, 3)), ("g_cam_R", (B, 9)), ("g_cam_T", (B, 3)), ("g_centroid", (B, 3)),
+                 ("g_pose48", (B, 48)), ("g_betas", (B, 10)), ("g_trans_b", (B, 3)), ("g_nmap_n", (self.Ht, self.Wt, 3))]
+        self.garena = _Arena(gspec, dev)
+        self.gs_buf = self.garena.alloc()
+        for k, _ in gspec:
+            s[k] = self.garena.view(self.gs_buf, k)
+        self._shade_args = None
+
+    def set_targets(self, y_true, y_sil, y_sil_col, frame_offset=0):
+        """(Tl,S,S,3), (Tl,S,S), (Tl,S,S) fp32 for this rank's frames [frame_offset, frame_offset+Tl): kept resident in HBM
+        (the reference re-reads them from 20 DataLoader workers + H2D every step, optimize_sequence.py:446-450)."""
+        self.y_true = y_true.to(self.dev).float().contiguous()
+        self.y_sil = y_sil.to(self.dev).float().contiguous()
+        self.y_sil_col = y_sil_col.to(self.dev).float().contiguous()
+        self.target_offset = int(frame_offset)
+
+    # ------------------------------------------------------------------------------------------------
+    def _ck(self, rc, what):
+        if rc != 0:
+            raise RuntimeError(f"{what} failed with status {rc}")
+
+    def _mesh_forward(self, fid, B):
+        """frame_setup .. normals: fills the scratch geometry for the B frames in `fid` (int32 device tensor)."""
+        L, s, p, st, tp = _lib.lib(), self.s, _lib.ptr, _lib.stream(), self.topo
+        self._ck(L.harp_frame_setup_fwd(ctypes.byref(self.tables), p(fid), B, self.S, self.focal, int(self.self_shadow), p(s["pose48"]),
+                                        p(s["betas"]), p(s["trans_b"]), p(s["cam_R"]), p(s["cam_T"]), p(s["light_pos"]), p(s["colors"]), st),
+                 "frame_setup_fwd")
+        self._ck(L.harp_lbs_mano_fwd(ctypes.byref(self.dm.struct), p(s["pose48"]), p(s["betas"]), p(s["trans_b"]), B, p(s["lbs_ws"]),
+                                     p(s["verts_mm"]), p(s["joints_mm"]), st), "lbs_fwd")
+        self._ck(L.harp_scale(p(s["joints_mm"]), 1e-3, B * 63, p(s["joints_m"]), st), "scale")          # visualize.py:46
+        self._ck(L.harp_subdivide_fwd(p(s["verts_mm"]), p(tp.edges0), B, tp.V0, tp.E0, 1e-3, p(s["vs"]), st), "subdivide_fwd")
+        self._ck(L.harp_vertex_normals_fwd(p(s["vs"]), p(tp.faces), p(tp.vf_off), p(tp.vf_idx), B, tp.V, p(s["n1"]), p(s["il1"]),
+                                           p(self.params["verts_disps"]), p(s["vd"]), st), "normals_displace_fwd")
+        self._ck(L.harp_vertex_normals_fwd(p(s["vd"]), p(tp.faces), p(tp.vf_off), p(tp.vf_idx), B, tp.V, p(s["n2"]), p(s["il2"]),
+                                           None, None, st), "normals_fwd")
+
+    @torch.no_grad()
+    def compute_reference_mesh(self):
+        """ARAP reference = frame-0 mesh under the initial parameters (optimize_sequence.py:429-435)."""
+        fid0 = torch.zeros(1, dtype=torch.int32, device=self.dev)
+        self._mesh_forward(fid0, 1)
+        self.ref_verts = self.s["vd"][0].clone()
+
+    def _shade_struct(self, B, app):
+        s, tp = self.s, self.topo
+        a = ops._shade_args(s["face_c"], s["ws_c"], tp, s["vd"][:B], s["n2"][:B], self.params["texture"][0], s["nmap_n"], s["light_pos"],
+                            s["colors"], s["zl"] if self.self_shadow else None, s["light_R"] if self.self_shadow else None,
+                            s["light_T"] if self.self_shadow else None, self.S, self.focal, (self.S / 2.0, self.S / 2.0), (1.0, 1.0, 1.0))
+        a.B = B
+        a.rgb = _lib.ptr(s["rgb"])
+        for k, t in (("g_rgb", s["g_rgb"]), ("g_tex", self.grads["texture"]), ("g_nmap", s["g_nmap_n"]), ("g_verts", s["g_vd"]),
+                     ("g_vnormals", s["g_n2"]), ("g_ndc", s["g_ndc_c"]), ("g_zl", s["g_zl"] if self.self_shadow else None),
+                     ("g_light_pos", s["g_light_pos"]), ("g_colors", s["g_colors"]),
+                     ("g_light_R", s["g_light_R"] if self.self_shadow else None), ("g_light_T", s["g_light_T"] if self.self_shadow else None)):
+            setattr(a, k, _lib.ptr(t))
+        return a
+
+    def forward_backward(self, coarse=True, app=True):
+        """Enqueue forward + losses + backward for the frames in self.fid; gradients land in self.g_buf, loss terms
+        in self.loss_vec[:9] (unweighted, order LOSS_NAMES)."""
+        L, s, p, st, tp, B, S = _lib.lib(), self.s, _lib.ptr, _lib.stream(), self.topo, self.B, self.S
+        V, F = tp.V, tp.F
+        w = self.w_vec
+        wp = lambda i: w.data_ptr() + 4 * i
+        lp = lambda i: self.loss_vec.data_ptr() + 4 * i
+        self.g_buf.zero_()
+        self.gs_buf.zero_()
+        self.loss_vec.zero_()
+        self._mesh_forward(self.fid, B)
+        # ---- camera view: projection + fused K=1 / soft-silhouette raster
+        self._ck(L.harp_project_fwd(p(s["vd"]), p(s["cam_R"]), p(s["cam_T"]), B, V, self.focal, S / 2.0, S / 2.0, S, p(s["ndc_c"]), st), "project")
+        self._ck(L.harp_rasterize_fwd(p(s["ndc_c"]), p(tp.faces), B, V, F, S, 1, ops.SIL_BLUR, ops.SIL_SIGMA, p(s["ws_c"]), p(s["face_c"]),
+                                      None, p(s["alpha"]), st), "raster_cam")
+        if app:
+            if self.self_shadow:
+                self._ck(L.harp_centroid(p(s["vd"]), B, V, p(s["centroid"]), st), "centroid")
+                self._ck(L.harp_light_setup_fwd(p(s["centroid"]), p(s["light_pos"]), B, p(s["light_R"]), p(s["light_T"]), st), "light_setup")
+                self._ck(L.harp_project_fwd(p(s["vd"]), p(s["light_R"]), p(s["light_T"]), B, V, self.focal, S / 2.0, S / 2.0, S, p(s["ndc_l"]), st), "project_l")
+                self._ck(L.harp_rasterize_fwd(p(s["ndc_l"]), p(tp.faces), B, V, F, S, 0, 0.0, 1.0, p(s["ws_l"]), p(s["face_l"]), p(s["zl"]), None, st),
+                         "raster_light")
+            self._ck(L.harp_normalize3_fwd(p(self.params["normal_map"]), self.Ht * self.Wt, p(s["nmap_n"]), st), "normalize3")
+            a = self._shade_struct(B, app)
+            self._ck(L.harp_shade_fwd(ctypes.byref(a), st), "shade_fwd")
+        # ---- losses and their gradients
+        if coarse:
+            self._ck(L.harp_image_l1(p(s["alpha"]), p(self.y_sil), None, p(self.tfid), B, S * S, 1, wp(0), lp(0), p(s["g_alpha"]), st), "l1_sil")
+            self._ck(L.harp_kps_loss(p(self.init_joints), p(self.fid), p(s["joints_m"]), B, 21, wp(1), lp(1), p(s["g_joints_m"]), st), "kps")
+            self._ck(L.harp_sum_squares(p(self.params["verts_disps"]), V, wp(2), lp(2), p(self.grads["verts_disps"]), st), "disp_reg")
+            self._ck(L.harp_mesh_regularizers(p(s["vd"]), p(self.ref_verts), p(tp.nbr_off), p(tp.nbr_idx), p(tp.nc_pairs), p(tp.edges), B, V,
+                                              tp.nc_pairs.shape[0], tp.E, wp(3), lp(3), p(s["g_vd"]), st), "mesh_reg")
+        if app:
+            self._ck(L.harp_image_l1(p(s["rgb"]), p(self.y_true), p(self.y_sil_col), p(self.tfid), B, S * S * 3, 3, wp(6), lp(6), p(s["g_rgb"]), st),
+                     "l1_photo")
+            self._ck(L.harp_texture_smooth_reg(p(self.params["texture"]), p(self.dist_albedo), p(self.uv_mask), self.Ht, self.Wt, wp(7), lp(7),
+                                               p(self.grads["texture"]), st), "albedo_reg")
+            self._ck(L.harp_close_to_z_reg(p(self.params["normal_map"]), self.Ht, self.Wt, 0.2, wp(8), lp(8), p(self.grads["normal_map"]), st), "close_z")
+            self._ck(L.harp_texture_smooth_reg(p(self.params["normal_map"]), p(self.dist_normal), p(self.uv_mask), self.Ht, self.Wt, wp(8), lp(8),
+                                               p(self.grads["normal_map"]), st), "normal_smooth")
+        # ---- backward
+        if app:
+            self._ck(L.harp_shade_bwd(ctypes.byref(a), st), "shade_bwd")
+            self._ck(L.harp_normalize3_bwd(p(self.params["normal_map"]), p(s["g_nmap_n"]), self.Ht * self.Wt, p(self.grads["normal_map"]), st), "normalize3_bwd")
+            if self.self_shadow:
+                self._ck(L.harp_depth_bwd(p(s["face_l"]), p(s["ws_l"]), p(tp.faces), p(s["g_zl"]), B, V, F, S, p(s["g_ndc_l"]), st), "depth_bwd")
+                self._ck(L.harp_project_bwd(p(s["vd"]), p(s["light_R"]), p(s["light_T"]), p(s["g_ndc_l"]), B, V, self.focal, S, p(s["g_vd"]),
+                                            p(s["g_light_R"]), p(s["g_light_T"]), st), "project_bwd_l")
+                self._ck(L.harp_light_setup_bwd(p(s["centroid"]), p(s["light_pos"]), p(s["g_light_R"]), p(s["g_light_T"]), B, V, p(s["g_light_pos"]),
+                                                p(s["g_centroid"]), p(s["g_vd"]), st), "light_setup_bwd")
+        if coarse:
+            self._ck(L.harp_silhouette_bwd(p(tp.faces), B, V, F, S, ops.SIL_BLUR, ops.SIL_SIGMA, p(s["ws_c"]), p(s["alpha"]), p(s["g_alpha"]),
+                                           p(s["g_ndc_c"]), st), "silhouette_bwd")
+        self._ck(L.harp_project_bwd(p(s["vd"]), p(s["cam_R"]), p(s["cam_T"]), p(s["g_ndc_c"]), B, V, self.focal, S, p(s["g_vd"]), None,
+                                    p(s["g_cam_T"]), st), "project_bwd_c")
+        if app:
+            self._ck(L.harp_vertex_normals_bwd(p(s["vd"]), p(tp.faces), p(tp.vf_off), p(tp.vf_idx), B, V, p(s["n2"]), p(s["il2"]), p(s["g_n2"]),
+                                               p(s["g_tmp"]), p(s["g_vd"]), st), "normals_bwd2")
+        self._ck(L.harp_displace_bwd(p(s["g_vd"]), p(s["n1"]), p(self.params["verts_disps"]), B, V, p(s["g_n1"]), p(self.grads["verts_disps"]), st),
+                 "displace_bwd")
+        self._ck(L.harp_vertex_normals_bwd(p(s["vs"]), p(tp.faces), p(tp.vf_off), p(tp.vf_idx), B, V, p(s["n1"]), p(s["il1"]), p(s["g_n1"]),
+                                           p(s["g_tmp"]), p(s["g_vd"]), st), "normals_bwd1")        # g_vs aliases g_vd (vd = vs + n d)
+        self._ck(L.harp_subdivide_bwd(p(s["g_vd"]), p(tp.sub_off), p(tp.sub_idx), B, tp.V0, V, 1e-3, p(s["g_v0"]), st), "subdivide_bwd")
+        self._ck(L.harp_scale(p(s["g_joints_m"]), 1e-3, B * 63, p(s["g_joints_mm"]), st), "scale_bwd")
+        self._ck(L.harp_lbs_mano_bwd(ctypes.byref(self.dm.struct), p(s["pose48"]), p(s["betas"]), p(s["trans_b"]), B, p(s["lbs_ws"]),
+                                     p(s["g_v0"]), p(s["g_joints_mm"]), p(s["g_pose48"]), p(s["g_betas"]), p(s["g_trans_b"]), st), "lbs_bwd")
+        self._ck(L.harp_frame_setup_bwd(ctypes.byref(self.tables), p(self.fid), B, S, self.focal, int(self.self_shadow), p(s["g_pose48"]),
+                                        p(s["g_betas"]), p(s["g_trans_b"]), p(s["g_cam_T"]), p(s["g_light_pos"]) if app else None,
+                                        p(s["g_colors"]) if app else None, st), "frame_setup_bwd")
+
+    def allreduce(self):
+        if self.world > 1:
+            import torch.distributed as dist
+            o, n = self.opt_span
+            dist.all_reduce(self.g_buf[o:o + n])          # one flat bucket (sum); 1/world is applied in the Adam kernel
+
+    def adam(self, coarse=True, app=True):
+        L, p, st = _lib.lib(), _lib.ptr, _lib.stream()
+        for on, idx, (o, n) in ((coarse, 0, self.coarse_span), (app, 1, self.app_span)):
+            if not on:
+                continue
+            h = self.hyper.data_ptr() + idx * self._hyper_stride
+            self._ck(L.harp_adam_tick(h, st), "adam_tick")
+            self._ck(L.harp_adam_apply(self.p_buf.data_ptr() + 4 * o, self.g_buf.data_ptr() + 4 * o, self.m_buf.data_ptr() + 4 * o,
+                                       self.v_buf.data_ptr() + 4 * o, n, h, st), "adam_apply")
+
+    # ------------------------------------------------------------------------------------------------
+    def set_stage(self, coarse, app):
+        w = torch.zeros(16)
+        for i, k in enumerate(LOSS_NAMES):
+            if (coarse and k in COARSE_TERMS) or (app and k in APP_TERMS):
+                w[i] = LOSS_WEIGHTS[k]
+        self.w_vec.copy_(w.to(self.dev))
+
+    def set_lr(self, lr_coarse=None, lr_app=None):
+        """host -> device hyper block (ReduceLROnPlateau lives on the host, optimize_sequence.py:309, 581-582)"""
+        h = self.hyper.cpu().numpy().view(self.hyper_np.dtype)
+        if lr_coarse is not None:
+            h["lr"][0] = lr_coarse
+        if lr_app is not None:
+            h["lr"][1] = lr_app
+        self.hyper.copy_(torch.from_numpy(h.view(np.uint8)).to(self.dev))
+
+    def draw_texture_offsets(self):
+        """the random neighbour offsets of albedo_reg (std 1) / smooth_texture_reg (std 2), loss/texture_reg.py:15, 51 — drawn on the
+        device from a generator seeded identically on every rank."""
+        n = self.Ht
+        self.dist_albedo.copy_(torch.normal(0.0, 1.0, (n, n, 2), generator=self.gen, device=self.dev).to(torch.int32))
+        self.dist_normal.copy_(torch.normal(0.0, 2.0, (n, n, 2), generator=self.gen, device=self.dev).to(torch.int32))
+
+    def step(self, fid, coarse=True, app=True, use_graph=True):
+        """One optimisation step on the frames `fid` (global frame ids, length == batch_size)."""
+        fid = torch.as_tensor(fid, dtype=torch.int32)
+        self.fid.copy_(fid.to(self.dev), non_blocking=True)
+        self.tfid.copy_((fid - self.target_offset).to(self.dev), non_blocking=True)
+        if app:
+            self.draw_texture_offsets()
+        key = (coarse, app)
+        if getattr(self, "_stage", None) != key:
+            self.set_stage(coarse, app)
+            self._stage = key
+        if not use_graph or self.world > 1:
+            self.forward_backward(coarse, app)
+            self.allreduce()
+            self.adam(coarse, app)
+            return
+        g = self._graphs.get(key)
+        if g is None:
+            # warm-up on a side stream, then capture (torch's documented recipe)
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                self.forward_backward(coarse, app)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self.forward_backward(coarse, app)
+                self.adam(coarse, app)
+            self._graphs[key] = g
+            # the capture itself does not execute; fall through to the first replay
+        g.replay()
+
+    def losses(self):
+        """dict of the last step's unweighted loss terms (one D2H copy; call sparingly)."""
+        v = self.loss_vec.cpu().tolist()
+        return {k: v[i] for i, k in enumerate(LOSS_NAMES)}

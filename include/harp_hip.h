@@ -104,6 +104,90 @@ int harp_project_bwd(const float* v, const float* R, const float* T, const float
 /* hand_verts.mean(1) (optimize_sequence.py:476) */
 int harp_centroid(const float* v, int B, int V, float* c, hipStream_t stream);
 
+/* ---- MANO linear-blend skinning ----------------------------------------------------------------------------------
+ * replaces ManoLayer.forward (manopth/manolayer.py:108-296, rodrigues_layer.py:15-54, tensutils.py:6-42) as built by
+ * utils/hand_model_utils.py:74 (use_pca=False, flat_hand_mean=False, axis-angle root, right hand); call site
+ * utils/visualize.py:42-44.  Model arrays are device pointers prepared once by harp_amd/manopth/manolayer.py. */
+typedef struct harp_mano_model {
+  const float* v_template;   /* (778,3) */
+  const float* shapedirs_T;  /* (10, 778*3)  th_shapedirs transposed */
+  const float* posedirs_T;   /* (135, 778*3) th_posedirs transposed */
+  const float* posedirs;     /* (778*3, 135) */
+  const float* J_template;   /* (16,3)  = J_regressor @ v_template */
+  const float* J_dirs;       /* (16*3,10) = J_regressor @ shapedirs */
+  const float* weights;      /* (778,16) */
+  const float* hands_mean;   /* (45,) */
+} harp_mano_model;
+size_t harp_lbs_mano_ws_floats(int B);
+/* pose (B,48) = [root axis-angle, 45 hand pose], betas (B,10), trans (B,3) -> verts (B,778,3) mm, joints (B,21,3) mm */
+int harp_lbs_mano_fwd(const harp_mano_model* m, const float* pose, const float* betas, const float* trans, int B, float* ws,
+                      float* verts, float* joints, hipStream_t stream);
+/* ws must be the workspace of the forward call; g_verts is modified in place (tip-joint gradients folded in) */
+int harp_lbs_mano_bwd(const harp_mano_model* m, const float* pose, const float* betas, const float* trans, int B, float* ws,
+                      float* g_verts, const float* g_joints, float* g_pose, float* g_betas, float* g_trans, hipStream_t stream);
+
+/* ---- losses, texture helpers, optimiser ---------------------------------------------------------------------------
+ * Every loss call accumulates (+=) its value into `loss` and, if `w` (device pointer to the weight(s) = d total/d term)
+ * and the gradient output are non-NULL, its weighted gradient (+= unless noted). */
+/* torch.nn.L1Loss between pred*mask and target[fid]*mask[fid] (optimize_sequence.py:519, 543); g_pred is overwritten */
+int harp_image_l1(const float* pred, const float* target, const float* mask, const int32_t* fid, int B, int n_per_frame, int C,
+                  const float* w, float* loss, float* g_pred, hipStream_t stream);
+/* kps_loss (loss/kps_loss.py:4-17); gt (T,21,3) mm indexed by fid, pred (B,n_joints_pred,3) m */
+int harp_kps_loss(const float* gt, const int32_t* fid, const float* pred, int B, int n_joints_pred, const float* w, float* loss,
+                  float* g_pred, hipStream_t stream);
+/* loss[0..2], w[0..2] = mesh_laplacian_smoothing, mesh_normal_consistency (optimize_sequence.py:536-537),
+ * arap_loss (loss/arap.py:4-57; ref_verts (V,3), NULL skips it) */
+int harp_mesh_regularizers(const float* verts, const float* ref_verts, const int32_t* nbr_off, const int32_t* nbr_idx,
+                           const int32_t* nc_pairs, const int32_t* edges, int B, int V, int P, int E, const float* w, float* loss,
+                           float* g_verts, hipStream_t stream);
+/* torch.sum(verts_disps ** 2) (optimize_sequence.py:533) */
+int harp_sum_squares(const float* x, int n, const float* w, float* loss, float* g, hipStream_t stream);
+/* albedo_reg / smooth_texture_reg (loss/texture_reg.py:5-30, 48-66) with the drawn integer offsets dist (H,W,2) */
+int harp_texture_smooth_reg(const float* tex, const int32_t* dist, const float* mask, int H, int W, const float* w, float* loss,
+                            float* g_tex, hipStream_t stream);
+/* scale * close_to_z_reg (loss/texture_reg.py:40-45) */
+int harp_close_to_z_reg(const float* nm, int H, int W, float scale, const float* w, float* loss, float* g_nm, hipStream_t stream);
+/* F.normalize(normal_map, dim=-1) (utils/visualize.py:99); n = number of texels */
+int harp_normalize3_fwd(const float* x, int n, float* y, hipStream_t stream);
+int harp_normalize3_bwd(const float* x, const float* gy, int n, float* gx, hipStream_t stream);
+/* torch.optim.Adam step on a flat fp32 segment (optimize_sequence.py:265-310, 567-573); grad is read as g*grad_scale */
+int harp_adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps, int step,
+                   float grad_scale, hipStream_t stream);
+
+/* graph-replayable variant: hyper-parameters live in device memory (the host updates lr between epochs, e.g. for
+ * ReduceLROnPlateau, optimize_sequence.py:309, 581-582); harp_adam_tick advances `step` and the bias corrections. */
+typedef struct harp_adam_hyper {
+  float lr, beta1, beta2, eps, grad_scale;
+  int step;
+  float step_size, inv_sqrt_bc2;   /* derived by harp_adam_tick */
+} harp_adam_hyper;
+int harp_adam_tick(harp_adam_hyper* h_dev, hipStream_t stream);
+int harp_adam_apply(float* p, const float* g, float* m, float* v, size_t n, const harp_adam_hyper* h_dev, hipStream_t stream);
+
+/* ---- per-frame glue of the fitting loop ---------------------------------------------------------------------------
+ * replaces the row gathers params[k][fid] of utils/visualize.py:26-27,38-39 / optimize_sequence.py:464, the camera
+ * convention of utils/visualize.py:268-271, optimize_sequence.py:453-456 (shared light), :478-480 + renderer_helper.py:
+ * 435-441 (ambient ratio -> light colours) and process_info_for_shadow (renderer_helper.py:454-468).
+ * The tables are the reference's parameter dict (optimize_sequence.py:181-250) laid out in one flat fp32 arena. */
+typedef struct harp_frame_tables {
+  const float *pose, *rot, *trans, *cam;   /* (T,45) (T,3) (T,3) (T,3) */
+  const float *shape;                      /* (10,) */
+  const float *light_positions;            /* (T,3) */
+  const float *amb_ratio;                  /* (1,) pre-sigmoid */
+  float *g_pose, *g_rot, *g_trans, *g_cam, *g_shape, *g_light_positions, *g_amb_ratio;   /* gradient arena (+=), NULL = skip */
+  int share_light;                         /* configs["share_light_position"] */
+} harp_frame_tables;
+int harp_frame_setup_fwd(const harp_frame_tables* t, const int32_t* fid, int B, int S, float focal, int self_shadow, float* pose48,
+                         float* betas, float* trans_b, float* cam_R, float* cam_T, float* light_pos, float* colors,
+                         hipStream_t stream);
+int harp_frame_setup_bwd(const harp_frame_tables* t, const int32_t* fid, int B, int S, float focal, int self_shadow,
+                         const float* g_pose48, const float* g_betas, const float* g_trans_b, const float* g_cam_T,
+                         const float* g_light_pos, const float* g_colors, hipStream_t stream);
+int harp_light_setup_fwd(const float* centroid, const float* light_pos, int B, float* light_R, float* light_T, hipStream_t stream);
+int harp_light_setup_bwd(const float* centroid, const float* light_pos, const float* g_light_R, const float* g_light_T, int B, int V,
+                         float* g_light_pos, float* g_centroid, float* g_verts, hipStream_t stream);
+int harp_scale(const float* x, float s, int n, float* y, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -298,5 +298,10 @@ def mesh_normal_consistency(verts, pairs):
     v0, v1, a, b = verts[:, p[:, 0]], verts[:, p[:, 1]], verts[:, p[:, 2]], verts[:, p[:, 3]]
     n0 = torch.cross(v1 - v0, a - v0, dim=-1)
     n1 = -torch.cross(v1 - v0, b - v0, dim=-1)
-    loss = 1.0 - F.cosine_similarity(n0, n1, dim=-1)
+    # torch 1.11 (the reference's pinned version, requirements.txt:81) cosine_similarity:
+    #   w12 / sqrt(clamp_min(w1 * w2, eps^2)), eps = 1e-8 — the PRODUCT of the squared norms is clamped, which is active
+    #   for millimetre-sized triangles in metre units (|n0||n1| ~ 1e-11): the term is then ~1 with a tiny gradient.
+    #   (torch >= 1.12 clamps each norm separately; restating 1.11 keeps the reference's behaviour.)
+    w12, w1, w2 = (n0 * n1).sum(-1), (n0 * n0).sum(-1), (n1 * n1).sum(-1)
+    loss = 1.0 - w12 / (w1 * w2).clamp_min(1e-8 * 1e-8).sqrt()
     return (loss / p.shape[0]).sum() / B
