@@ -1,0 +1,265 @@
+"""bench.py — frames/s of HARP's render + loss + backward + Adam inner step on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]          (N>1: launched by torch.distributed.run, one rank per GPU)
+
+Workload (BASELINE.json configs[2]/[3], SURVEY.md §8d "C3/C4"): 256-frame synthetic sequence, 512x512, subdivided MANO
+hand mesh (3093 v / 6152 f / 3327 uv), self-shadow on, per-vertex displacement + texture/normal-map optimisation stage
+(coarse AND appearance terms active: silhouette, keypoint, displacement reg, laplacian, normal consistency, ARAP,
+photometric, albedo reg, normal-map reg; VGG excluded per SURVEY.md §8f), 32 frames per GPU per step (weak scaling),
+one flat all-reduce of the parameter gradients over RCCL before the replicated dense Adam step.
+A "step" = LBS -> mesh prep -> 3 rasterisations -> shade -> losses -> backward -> [all-reduce] -> 2x Adam on 32 frames/GPU.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from harp_amd import synth  # noqa: E402
+from harp_amd.engine import FitEngine  # noqa: E402
+
+T_FRAMES, S, B_PER_GPU = 256, 512, 32
+HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def erode(mask, iters=2):
+    """3x3 erosion x2 (utils/data_util.py:17-20) on the device."""
+    m = mask[:, None]
+    for _ in range(iters):
+        m = -torch.nn.functional.max_pool2d(-m, 3, stride=1, padding=1)
+    return m[:, 0]
+
+
+def build_engine(rank, world, device, T=T_FRAMES, img=S, B=B_PER_GPU, seed=0):
+    tpl = synth.load_template("hand")
+    topo = synth.build_topology(tpl["faces0"], 778)
+    model = synth.make_mano_model(tpl, seed=seed)
+    seq, focal = synth.make_sequence(model, T, img, seed=seed)
+    seq["joints"] = torch.zeros(T, 21, 3)
+    eng = FitEngine(model, topo, tpl["verts_uvs"], tpl["faces_uvs"], tpl["uv_mask"].astype(np.float32) / 255.0, seq, img, focal, B,
+                    device=device, rank=rank, world_size=world, seed=seed)
+    # ---- synthetic targets: render a perturbed "ground-truth" parameter set with the engine itself
+    Tl = T // world
+    lo = rank * Tl
+    g = torch.Generator().manual_seed(seed + 7)
+    saved = {k: eng.params[k].clone() for k in ("pose", "cam", "texture", "normal_map", "verts_disps", "shape")}
+    with torch.no_grad():
+        eng.params["pose"].add_((torch.randn(T, 45, generator=g) * 0.05).to(device))
+        eng.params["cam"][:, 1:].add_((torch.randn(T, 2, generator=g) * 0.004).to(device))
+        eng.params["shape"].add_((torch.randn(10, generator=g) * 0.3).to(device))
+        eng.params["verts_disps"].copy_((torch.randn(eng.topo.V, 1, generator=g) * 0.0008).to(device))
+        tex = torch.nn.functional.interpolate(torch.rand(1, 3, 32, 32, generator=g), size=512, mode="bilinear")[0].permute(1, 2, 0)
+        eng.params["texture"].copy_((0.35 + 0.5 * tex)[None].to(device))
+    y_true = torch.empty(Tl, img, img, 3, device=device)
+    y_sil = torch.empty(Tl, img, img, device=device)
+    joints = torch.empty(T, 21, 3, device=device)
+    eng.set_stage(False, True)
+    eng.y_true, eng.y_sil, eng.y_sil_col = y_true, y_sil, y_sil      # placeholders (losses are ignored here)
+    for s0 in range(0, T, B):
+        fid = torch.arange(s0, s0 + B, dtype=torch.int32)
+        eng.fid.copy_(fid.to(device))
+        eng.tfid.zero_()
+        eng.forward_backward(coarse=True, app=True)
+        joints[s0:s0 + B] = eng.s["joints_mm"]
+        if lo <= s0 < lo + Tl:
+            y_true[s0 - lo:s0 - lo + B] = eng.s["rgb"]
+            y_sil[s0 - lo:s0 - lo + B] = (eng.s["alpha"] > 0.5).float()
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        for k, v in saved.items():
+            eng.params[k].copy_(v)
+    eng.init_joints = (joints + torch.randn(T, 21, 3, generator=g).to(device) * 2.0).contiguous()    # METRO-like noisy anchors (mm)
+    eng.set_targets(y_true, y_sil, erode(y_sil), frame_offset=lo)
+    eng.compute_reference_mesh()
+    eng.g_buf.zero_()
+    return eng, focal
+
+
+def algorithmic_bytes(eng):
+    """A_frame and A_step for this workload (fp32, int32 indices, shadow on)."""
+    V, F, VT = eng.topo.V, eng.topo.F, eng.topo.verts_uvs.shape[0]
+    S2, T2 = eng.S * eng.S, eng.Ht * eng.Wt
+    geom = V * 12 + F * 12 + VT * 8 + F * 12
+    targets, outs, depth = S2 * 20, S2 * 16, S2 * 4
+    a_frame = 2 * geom + 2 * targets + 2 * outs + 3 * depth + V * 12
+    n_param = 2 * T2 * 3 + V + 14
+    a_step = 4 * T2 * 12 + 28 * n_param
+    return a_frame, a_step, dict(geom=geom, S2=S2, V=V, F=F)
+
+
+def kernel_roofline(eng, steps):
+    """Duration of the dominant kernel, measured with HIP events on the launch stream in an eager (non-graph) re-run of the
+    same steps right after the timed region; algorithmic bytes per launch from SURVEY.md §8(d)."""
+    from harp_amd import _lib
+    L = _lib.lib()
+    names = ["harp_rasterize_fwd", "harp_shade_fwd", "harp_shade_bwd", "harp_silhouette_bwd", "harp_image_l1", "harp_depth_bwd"]
+    rec = {n: [] for n in names}
+    orig = {}
+
+    class Timed:
+        def __init__(self, name, fn):
+            self.name, self.fn = name, fn
+
+        def __call__(self, *a):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = self.fn(*a)
+            e1.record()
+            rec[self.name].append((e0, e1))
+            return r
+
+    for n in names:
+        orig[n] = getattr(L, n)
+        setattr(L, n, Timed(n, orig[n]))
+    try:
+        for i in range(steps):
+            fid = (torch.arange(eng.B) + i * eng.B) % (eng.T // eng.world) + eng.target_offset
+            eng.step(fid, True, True, use_graph=False)
+        torch.cuda.synchronize()
+    finally:
+        for n in names:
+            setattr(L, n, orig[n])
+    ms = {n: [a.elapsed_time(b) for a, b in v] for n, v in rec.items()}
+    # harp_rasterize_fwd is called twice per step: even calls = camera (soft, K=1 + silhouette), odd = light (K=1)
+    cam = ms["harp_rasterize_fwd"][0::2]
+    light = ms["harp_rasterize_fwd"][1::2]
+    out = {"raster_cam_fwd(setup+bin+raster)": float(np.mean(cam)), "raster_light_fwd(setup+bin+raster)": float(np.mean(light))}
+    for n in names[1:]:
+        if ms[n]:
+            out[n] = float(np.mean(ms[n]))
+    return out
+
+
+def cpu_baseline(seed=0):
+    """The CPU oracle (a restatement of the reference path: materialised (B,S,S,K) fragments, torch autograd,
+    torch.optim.Adam) timed on this box's host cores on a bounded sample: 1 frame of the same workload per step."""
+    from oracle import harp_ref as H
+    # many-core hosts oversubscribe badly on these small ops (256 threads: 306 s/step vs 3.9 s with 8) -> cap at 16
+    cores = min(os.cpu_count() or 1, 16)
+    torch.set_num_threads(cores)
+    tpl = synth.load_template("hand")
+    topo_np = synth.build_topology(tpl["faces0"], 778)
+    model_np = synth.make_mano_model(tpl, seed=seed)
+    model = {k: torch.from_numpy(v) for k, v in model_np.items()}
+    topo = {k: torch.from_numpy(np.asarray(v)).long() if isinstance(v, np.ndarray) else v for k, v in topo_np.items()}
+    T = 2
+    seq, focal = synth.make_sequence(model_np, T, S, seed=seed)
+    P = dict(pose=seq["pose"], cam=seq["cam"], verts_disps=torch.zeros(3093, 1), shape=seq["shape"].mean(0),
+             light_positions=torch.tensor(((-0.5, -0.5, -0.5),)).repeat(T, 1), amb_ratio=torch.tensor(0.4),
+             texture=torch.tensor([232, 190, 172]).repeat(1, 512, 512, 1) / 255., normal_map=torch.tensor([0., 0., 1.]).repeat(1, 512, 512, 1),
+             rot=seq["rot"], trans=seq["trans"])
+    P = {k: v.clone().requires_grad_() for k, v in P.items()}
+    P.update(verts_uvs=torch.from_numpy(tpl["verts_uvs"]), faces_uvs=torch.from_numpy(tpl["faces_uvs"]).long(),
+             uv_mask=torch.from_numpy(tpl["uv_mask"]).double() / 255, init_joints=torch.zeros(T, 21, 3))
+    tg = dict(y_true=torch.rand(T, S, S, 3), y_sil=(torch.rand(T, S, S) > 0.5).float(), y_sil_col=(torch.rand(T, S, S) > 0.5).float())
+    opt_c = torch.optim.Adam([{"params": [P["pose"], P["cam"]], "lr": 1e-3}, {"params": [P["verts_disps"], P["shape"]], "lr": 1e-3}])
+    opt_a = torch.optim.Adam([P["light_positions"], P["amb_ratio"], P["texture"], P["normal_map"]], lr=1e-2)
+    with torch.no_grad():
+        _, rv = H.prepare_mesh(P, torch.tensor([0]), model, topo)
+    times = []
+    for it in range(3):
+        t0 = time.time()
+        fid = torch.tensor([it % T])
+        da = torch.normal(0, 1.0, (512, 512, 2)).to(torch.int).long()
+        dn = torch.normal(0, 2.0, (512, 512, 2)).to(torch.int).long()
+        _, total, _ = H.step_losses(P, fid, model, topo, tg, S, focal, rv, da, dn)
+        opt_c.zero_grad(); opt_a.zero_grad()
+        total.backward()
+        opt_c.step(); opt_a.step()
+        times.append(time.time() - t0)
+    sec = float(np.median(times[1:]))
+    return {"value": 1.0 / sec, "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"oracle/harp_ref.step_losses + autograd + torch.optim.Adam, 1 frame/step at {S}x{S} (K=50 silhouette fragments "
+                      f"materialised), median of 2 steps after 1 warm-up, torch.set_num_threads({cores})"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
+    args = ap.parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 bench.py --gpus N")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=device)
+    eng, focal = build_engine(rank, world, device)
+    Tl = eng.T // world
+
+    def batch(i):
+        return (torch.arange(eng.B) + i * eng.B) % Tl + eng.target_offset
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        eng.step(batch(i), True, True, use_graph=not args.no_graph)
+    sync()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        eng.step(batch(args.warmup + i), True, True, use_graph=not args.no_graph)
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    losses = eng.losses()
+    finite = all(np.isfinite(v) for v in losses.values())
+    frames = world * eng.B * args.steps
+    out = {"metric": "render+loss+backward+Adam frames/sec, 512x512 MANO hand mesh", "value": frames / dt, "unit": "frames/s",
+           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "C3/C4: 256-frame 512x512 sequence, subdivided MANO hand 3093v/6152f/3327uv, self-shadow, "
+                                  "coarse+appearance terms (displacement+texture stage, VGG excluded), dense Adam",
+                      "frames_per_gpu_per_step": eng.B, "global_batch": world * eng.B, "sequence_frames": eng.T,
+                      "parallelism": f"dp{world} (frames sharded, 1 flat all-reduce of {eng.opt_span[1] * 4} B)",
+                      "hipgraph": (not args.no_graph) and world == 1},
+           "losses_finite": finite}
+    if rank == 0 and world == 1:
+        a_frame, a_step, parts = algorithmic_bytes(eng)
+        kt = kernel_roofline(eng, 4)
+        # dominant kernel: the fused camera-view rasteriser (K=1 + soft silhouette); its algorithmic bytes per frame are the
+        # rasteriser sub-figure of SURVEY.md §8(d): geom_pos + S^2*(4+4+12+4) for the K=1 fragment set + S^2*4 for alpha
+        dom = max(kt, key=kt.get)
+        geom_pos = parts["V"] * 12 + parts["F"] * 12
+        alg = {"raster_cam_fwd(setup+bin+raster)": (geom_pos + parts["S2"] * 24 + parts["S2"] * 4) * eng.B,
+               "raster_light_fwd(setup+bin+raster)": (geom_pos + parts["S2"] * 24) * eng.B,
+               "harp_shade_fwd": (parts["geom"] + parts["S2"] * (4 + 12 + 4)) * eng.B,
+               "harp_shade_bwd": (parts["geom"] + parts["V"] * 36 + parts["S2"] * (4 + 12 + 4 + 4)) * eng.B + 2 * eng.Ht * eng.Wt * 12,
+               "harp_silhouette_bwd": (geom_pos + parts["S2"] * 8 + parts["V"] * 12) * eng.B,
+               "harp_image_l1": parts["S2"] * (12 + 12 + 4 + 12) * eng.B,
+               "harp_depth_bwd": (geom_pos + parts["S2"] * 8 + parts["V"] * 12) * eng.B}
+        ach = alg[dom] / (kt[dom] * 1e-3) / 1e9
+        out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                           "traffic": None, "algorithmic_bytes_per_launch": alg[dom], "avg_ms": kt[dom],
+                           "kernel_ms": kt, "step_algorithmic_bytes": a_frame * eng.B + a_step,
+                           "step_frac_of_hbm_roofline": (a_frame * eng.B + a_step) / (dt / args.steps) / 1e9 / HBM_PEAK_GBS}
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

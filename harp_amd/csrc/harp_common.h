@@ -55,3 +55,33 @@ __device__ __forceinline__ float block_sum_256(float v, float* lds4) {
   __syncthreads();
   return r;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Workgroup-local gradient accumulator keyed by vertex id: an open-addressing hash table in LDS (NV floats per key).
+// Pixels of one screen tile touch only a few dozen distinct vertices, so gradients are first summed with LDS float
+// atomics (ds_add_f32) and each (vertex, component) is then flushed with ONE global atomic per workgroup instead of one
+// per pixel.  A full table (probe limit hit) falls back to direct global atomics, so it is always correct.
+template <int SLOTS, int NV>
+struct VertexAccum {
+  int key[SLOTS];
+  float val[SLOTS][NV];
+
+  __device__ __forceinline__ void clear() {
+    for (int i = threadIdx.x; i < SLOTS; i += blockDim.x) {
+      key[i] = -1;
+#pragma unroll
+      for (int c = 0; c < NV; ++c) val[i][c] = 0.f;
+    }
+  }
+  // returns slot or -1 (table full)
+  __device__ __forceinline__ int find(int v) {
+    unsigned h = ((unsigned)v * 2654435761u) & (SLOTS - 1);
+    for (int probe = 0; probe < 32; ++probe) {
+      const int k = atomicCAS(&key[h], -1, v);
+      if (k == -1 || k == v) return (int)h;
+      h = (h + 1) & (SLOTS - 1);
+    }
+    return -1;
+  }
+  __device__ __forceinline__ void add(int slot, int c, float x) { atomicAdd(&val[slot][c], x); }
+};

@@ -141,6 +141,7 @@ __global__ void __launch_bounds__(256) raster_kernel(const FaceRec* __restrict__
   __shared__ float s_z2[kStage];
   __shared__ int32_t s_id[kStage];
   __shared__ int lds_cnt[4];
+  __shared__ float s_g[MODE == 2 ? kStage : 1][6];   // MODE 2: per-staged-face gradient accumulators (x,y of 3 verts)
 
   const int b = blockIdx.z;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -192,6 +193,10 @@ __global__ void __launch_bounds__(256) raster_kernel(const FaceRec* __restrict__
       const FaceRec r = rb[id];
       s_a[pos] = r.a; s_b[pos] = r.b; s_z2[pos] = r.c.x; s_bb[pos] = bb; s_id[pos] = id;
     }
+    if (MODE == 2) {
+#pragma unroll
+      for (int c = 0; c < 6; ++c) s_g[threadIdx.x][c] = 0.f;
+    }
     __syncthreads();
     // ---- walk: each wave ballots the staged faces against its 16x4 strip
     for (int g = 0; g < nl; g += 64) {
@@ -242,16 +247,28 @@ __global__ void __launch_bounds__(256) raster_kernel(const FaceRec* __restrict__
                 else                          { ia = 1; ib = 2; ax = t.x1; ay = t.y1; bx = t.x2; by = t.y2; tt = tc; }
                 const float qx = ax + tt * (bx - ax), qy = ay + tt * (by - ay);
                 const float cx = gd * 2.f * (qx - px), cy = gd * 2.f * (qy - py);
-                const int fid = s_id[j];
-                const int va = faces[3 * fid + ia], vb2 = faces[3 * fid + ib];
-                float* gb = g_ndc + (size_t)b * V * 3;
-                atomicAdd(gb + 3 * va, (1.f - tt) * cx);
-                atomicAdd(gb + 3 * va + 1, (1.f - tt) * cy);
-                atomicAdd(gb + 3 * vb2, tt * cx);
-                atomicAdd(gb + 3 * vb2 + 1, tt * cy);
+                atomicAdd(&s_g[j][2 * ia], (1.f - tt) * cx);
+                atomicAdd(&s_g[j][2 * ia + 1], (1.f - tt) * cy);
+                atomicAdd(&s_g[j][2 * ib], tt * cx);
+                atomicAdd(&s_g[j][2 * ib + 1], tt * cy);
               }
             }
           }
+        }
+      }
+    }
+    __syncthreads();
+    if (MODE == 2 && (int)threadIdx.x < nl) {
+      // flush: one global atomic per (staged face, vertex, component) per workgroup
+      const int fid = s_id[threadIdx.x];
+      float* gb = g_ndc + (size_t)b * V * 3;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const float gx = s_g[threadIdx.x][2 * k], gy = s_g[threadIdx.x][2 * k + 1];
+        if (gx != 0.f || gy != 0.f) {
+          const int v = faces[3 * fid + k];
+          atomicAdd(gb + 3 * v, gx);
+          atomicAdd(gb + 3 * v + 1, gy);
         }
       }
     }

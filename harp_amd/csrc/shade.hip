@@ -132,6 +132,8 @@ struct Frag {
 template <bool BWD>
 __global__ void __launch_bounds__(256) shade_kernel(const harp_shade_args A) {
   __shared__ float s_red[32];
+  // per-vertex accumulators: 0-2 g_verts, 3-5 g_vnormals, 6-8 g_ndc
+  __shared__ VertexAccum<BWD ? 1024 : 1, 9> s_acc;
   const int b = blockIdx.z;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int xi = blockIdx.x * kTile + (lane & 15), yi = blockIdx.y * kTile + w * 4 + (lane >> 4);
@@ -146,6 +148,8 @@ __global__ void __launch_bounds__(256) shade_kernel(const harp_shade_args A) {
     act = act && (gc.x != 0.f || gc.y != 0.f || gc.z != 0.f);
     if (threadIdx.x < 32) s_red[threadIdx.x] = 0.f;
     if (__syncthreads_or(act ? 1 : 0) == 0) return;
+    s_acc.clear();
+    __syncthreads();
   } else if (!act) {
     if (in_img) { float* r = A.rgb + o * 3; r[0] = A.bg[0]; r[1] = A.bg[1]; r[2] = A.bg[2]; }
     return;
@@ -300,21 +304,27 @@ __global__ void __launch_bounds__(256) shade_kernel(const harp_shade_args A) {
       float gb0 = dot(v0, g_p) + dot(n0, g_n) + uv0x * gu + uv0y * gv;
       float gb1 = dot(v1, g_p) + dot(n1, g_n) + uv1x * gu + uv1y * gv;
       float gb2 = dot(v2, g_p) + dot(n2, g_n) + uv2x * gu + uv2y * gv;
+      float gnd[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      bary_bwd(g.t, px, py, g.br, gb0, gb1, gb2, gnd);
       float* gvb = A.g_verts + (size_t)b * V * 3;
       float* gnb = A.g_vnormals + (size_t)b * V * 3;
+      float* gdb = A.g_ndc + (size_t)b * V * 3;
       const int vi[3] = {g.i0, g.i1, g.i2};
       const float bw[3] = {b0, b1, b2};
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
-        atomicAdd(gvb + 3 * vi[k], g_p.x * bw[k]); atomicAdd(gvb + 3 * vi[k] + 1, g_p.y * bw[k]); atomicAdd(gvb + 3 * vi[k] + 2, g_p.z * bw[k]);
-        atomicAdd(gnb + 3 * vi[k], g_n.x * bw[k]); atomicAdd(gnb + 3 * vi[k] + 1, g_n.y * bw[k]); atomicAdd(gnb + 3 * vi[k] + 2, g_n.z * bw[k]);
-      }
-      float gnd[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      bary_bwd(g.t, px, py, g.br, gb0, gb1, gb2, gnd);
-      float* gdb = A.g_ndc + (size_t)b * V * 3;
+        const float vals[9] = {g_p.x * bw[k], g_p.y * bw[k], g_p.z * bw[k], g_n.x * bw[k], g_n.y * bw[k], g_n.z * bw[k],
+                               gnd[3 * k], gnd[3 * k + 1], gnd[3 * k + 2]};
+        const int slot = s_acc.find(vi[k]);
+        if (slot >= 0) {
 #pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        atomicAdd(gdb + 3 * vi[k], gnd[3 * k]); atomicAdd(gdb + 3 * vi[k] + 1, gnd[3 * k + 1]); atomicAdd(gdb + 3 * vi[k] + 2, gnd[3 * k + 2]);
+          for (int c = 0; c < 9; ++c) s_acc.add(slot, c, vals[c]);
+        } else {
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            atomicAdd(gvb + 3 * vi[k] + c, vals[c]); atomicAdd(gnb + 3 * vi[k] + c, vals[3 + c]); atomicAdd(gdb + 3 * vi[k] + c, vals[6 + c]);
+          }
+        }
       }
     }
   }
@@ -336,6 +346,21 @@ __global__ void __launch_bounds__(256) shade_kernel(const harp_shade_args A) {
         else if (A.g_light_T) atomicAdd(A.g_light_T + 3 * b + 2, s);
       }
     }
+    // flush the per-vertex accumulators: one global atomic per (vertex, component) per workgroup
+    float* gvb = A.g_verts + (size_t)b * V * 3;
+    float* gnb = A.g_vnormals + (size_t)b * V * 3;
+    float* gdb = A.g_ndc + (size_t)b * V * 3;
+    for (int i = threadIdx.x; i < 1024; i += 256) {
+      const int v = s_acc.key[i];
+      if (v < 0) continue;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float a0 = s_acc.val[i][c], a1 = s_acc.val[i][3 + c], a2 = s_acc.val[i][6 + c];
+        if (a0 != 0.f) atomicAdd(gvb + 3 * v + c, a0);
+        if (a1 != 0.f) atomicAdd(gnb + 3 * v + c, a1);
+        if (a2 != 0.f) atomicAdd(gdb + 3 * v + c, a2);
+      }
+    }
   }
 }
 
@@ -344,24 +369,41 @@ __global__ void __launch_bounds__(256) shade_kernel(const harp_shade_args A) {
 __global__ void __launch_bounds__(256) depth_bwd_kernel(const int32_t* __restrict__ face_id, const FaceRec* __restrict__ recs,
                                                         const int32_t* __restrict__ faces, const float* __restrict__ g_z,
                                                         int V, int F, int S, float* __restrict__ g_ndc) {
+  __shared__ VertexAccum<1024, 3> s_acc;
   const int b = blockIdx.z;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int xi = blockIdx.x * kTile + (lane & 15), yi = blockIdx.y * kTile + w * 4 + (lane >> 4);
-  if (xi >= S || yi >= S) return;
-  const size_t o = ((size_t)b * S + yi) * S + xi;
-  const float g = g_z[o];
-  const int f = face_id[o];
-  if (f < 0 || g == 0.f) return;
-  const Tri t = load_tri(recs + (size_t)b * F + f);
-  const float px = pix_to_ndc(xi, S), py = pix_to_ndc(yi, S);
-  const Bary br = bary_fwd(t, px, py);
-  float gnd[9] = {0.f, 0.f, g * br.b0, 0.f, 0.f, g * br.b1, 0.f, 0.f, g * br.b2};
-  bary_bwd(t, px, py, br, g * t.z0, g * t.z1, g * t.z2, gnd);
+  const bool in_img = xi < S && yi < S;
+  const size_t o = ((size_t)b * S + (in_img ? yi : 0)) * S + (in_img ? xi : 0);
+  const float g = in_img ? g_z[o] : 0.f;
+  const int f = in_img ? face_id[o] : -1;
+  const bool act = f >= 0 && g != 0.f;
+  if (__syncthreads_or(act ? 1 : 0) == 0) return;
+  s_acc.clear();
+  __syncthreads();
   float* gdb = g_ndc + (size_t)b * V * 3;
-  const int vi[3] = {faces[3 * f], faces[3 * f + 1], faces[3 * f + 2]};
+  if (act) {
+    const Tri t = load_tri(recs + (size_t)b * F + f);
+    const float px = pix_to_ndc(xi, S), py = pix_to_ndc(yi, S);
+    const Bary br = bary_fwd(t, px, py);
+    float gnd[9] = {0.f, 0.f, g * br.b0, 0.f, 0.f, g * br.b1, 0.f, 0.f, g * br.b2};
+    bary_bwd(t, px, py, br, g * t.z0, g * t.z1, g * t.z2, gnd);
+    const int vi[3] = {faces[3 * f], faces[3 * f + 1], faces[3 * f + 2]};
 #pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    atomicAdd(gdb + 3 * vi[k], gnd[3 * k]); atomicAdd(gdb + 3 * vi[k] + 1, gnd[3 * k + 1]); atomicAdd(gdb + 3 * vi[k] + 2, gnd[3 * k + 2]);
+    for (int k = 0; k < 3; ++k) {
+      const int slot = s_acc.find(vi[k]);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        if (slot >= 0) s_acc.add(slot, c, gnd[3 * k + c]); else atomicAdd(gdb + 3 * vi[k] + c, gnd[3 * k + c]);
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 1024; i += 256) {
+    const int v = s_acc.key[i];
+    if (v < 0) continue;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) if (s_acc.val[i][c] != 0.f) atomicAdd(gdb + 3 * v + c, s_acc.val[i][c]);
   }
 }
 

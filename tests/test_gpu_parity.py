@@ -1,0 +1,181 @@
+"""-m gpu parity tests: HIP path (through the C ABI) vs the CPU oracle on the same seeded inputs.
+
+Tolerances (fp32): images |d| <= 1e-4 on >= 99.9 % of pixels, identical nearest-face ids except near-tie /
+on-edge pixels (<= 1e-4 of the pixels), scalar losses rel 1e-5, gradients rel-L2 <= 2e-3 (float atomics + the conditioning of
+the soft-silhouette gradient: the oracle's own fp32-vs-fp64 gradients differ by up to 1e-3), parameters after Adam steps
+abs 1e-3 (one Adam step moves a parameter by ~lr)."""
+import numpy as np
+import pytest
+import torch
+
+from tests._scene import make_scene, oracle_params, rel
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def sc():
+    return make_scene(T=3, S=128, seed=0)
+
+
+def test_mano_lbs_golden_and_grad(golden_dir):
+    """ManoLayer (HIP) against the vectors produced by the reference's manopth.ManoLayer (tests/golden/make_golden.py)."""
+    import os
+    from harp_amd import synth
+    from harp_amd.manopth.manolayer import ManoLayer
+    g = np.load(os.path.join(golden_dir, "mano_layer.npz"))
+    layer = ManoLayer(flat_hand_mean=False, use_pca=False, model=synth.make_mano_model(seed=0), device=DEV)
+    t = lambda k: torch.from_numpy(g[k]).to(DEV)
+    pose, betas, trans = t("pose").requires_grad_(), t("betas").requires_grad_(), t("trans").requires_grad_()
+    verts, joints = layer(pose, betas, trans)
+    assert torch.allclose(verts.cpu(), torch.from_numpy(g["verts"]), atol=3e-3)        # mm
+    assert torch.allclose(joints.cpu(), torch.from_numpy(g["joints"]), atol=3e-3)
+    ((verts * t("wv")).sum() + (joints * t("wj")).sum()).backward()
+    for name, p in (("g_pose", pose), ("g_betas", betas), ("g_trans", trans)):
+        assert rel(p.grad.cpu(), torch.from_numpy(g[name])) < 1e-4, name
+    v0, j0 = layer(pose.detach(), betas.detach(), torch.zeros_like(trans))
+    assert torch.allclose(v0.cpu(), torch.from_numpy(g["verts_notrans"]), atol=3e-3)
+    assert torch.allclose(j0.cpu(), torch.from_numpy(g["joints_notrans"]), atol=3e-3)
+
+
+def test_rasterizer_and_silhouette(sc):
+    from harp_amd import ops
+    from oracle import harp_ref as H, p3d_like as P
+    S, focal, topo = 256, sc["focal"] * 2, sc["topo"]
+    params = dict(pose=sc["seq"]["pose"], rot=sc["seq"]["rot"], trans=sc["seq"]["trans"], shape=sc["seq"]["shape"].mean(0),
+                  verts_disps=torch.zeros(3093, 1))
+    fid = torch.arange(2)
+    with torch.no_grad():
+        _, v = H.prepare_mesh(params, fid, sc["model"], topo)
+        R, T = H.camera_RT(sc["seq"]["cam"][fid], S, focal)
+        _, ndc = P.world_to_ndc(v, R, T, focal, (S / 2, S / 2), S)
+    ndc = ndc.requires_grad_()
+    p2f, zb, bary, d = P.rasterize_meshes(ndc, topo["faces"], S, ops.SIL_BLUR, 50)
+    a_ref = P.sigmoid_alpha_blend(p2f, d, ops.SIL_SIGMA)
+    tgt = (torch.rand(2, S, S) > 0.5).float()
+    (a_ref - tgt).abs().mean().backward()
+    p2f1, zb1, _, _ = P.rasterize_meshes(ndc.detach(), topo["faces"], S, 0.0, 1)
+    fid_ref = torch.where(p2f1[..., 0] >= 0, p2f1[..., 0] % topo["faces"].shape[0], p2f1[..., 0]).int()
+    ndc_d = ndc.detach().to(DEV).requires_grad_()
+    faces_d = topo["faces"].int().to(DEV)
+    alpha, face_id = ops.soft_silhouette(ndc_d, faces_d, S)
+    (alpha - tgt.to(DEV)).abs().mean().backward()
+    assert ((alpha.cpu() - a_ref).abs() > 1e-4).float().mean() < 1e-3
+    assert (face_id.cpu() != fid_ref).float().mean() < 1e-4
+    assert rel(ndc_d.grad.cpu(), ndc.grad) < 2e-3
+    f2, z2, _, _ = ops.rasterize_fwd(ndc_d.detach(), faces_d, S, soft=False)
+    assert (f2.cpu() != fid_ref).float().mean() < 1e-4
+    m = (f2.cpu() == fid_ref)
+    assert (z2.cpu() - zb1[..., 0])[m].abs().max() < 1e-5
+    # empty and off-screen inputs: everything behind the camera -> all pixels empty, alpha 0
+    f3, z3, a3, _ = ops.rasterize_fwd(ndc_d.detach() * torch.tensor([1.0, 1.0, -1.0], device=DEV), faces_d, S, soft=True,
+                                      blur_radius=ops.SIL_BLUR, sigma=ops.SIL_SIGMA)
+    assert (f3 == -1).all() and (z3 == -1).all() and (a3 == 0).all()
+
+
+def test_full_step_losses_grads_and_adam(sc):
+    from harp_amd.engine import FitEngine, LOSS_NAMES
+    from oracle import harp_ref as H
+    T, S, B = sc["T"], sc["S"], 2
+    eng = FitEngine(sc["model_np"], sc["topo_np"], sc["tpl"]["verts_uvs"], sc["tpl"]["faces_uvs"], sc["uv_mask"].float(), sc["seq"], S,
+                    sc["focal"], B, device=DEV)
+    tg = sc["targets"]
+    eng.set_targets(tg["y_true"], tg["y_sil"], tg["y_sil_col"])
+    with torch.no_grad():
+        eng.params["verts_disps"].copy_(torch.randn(3093, 1) * 0.001)
+        eng.params["texture"].copy_(torch.rand(1, 512, 512, 3) * 0.5 + 0.3)
+        eng.params["normal_map"].copy_(torch.tensor([0., 0., 1.]).repeat(1, 512, 512, 1) + torch.randn(1, 512, 512, 3) * 0.1)
+        eng.params["trans"].copy_(torch.randn(T, 3) * 0.01)
+    eng.compute_reference_mesh()
+    P = oracle_params(sc, eng.params)
+    fid = torch.tensor([2, 0])
+    eng.fid.copy_(fid.int().to(DEV)); eng.tfid.copy_(fid.int().to(DEV))
+    eng.draw_texture_offsets(); eng.set_stage(True, True)
+    with torch.no_grad():
+        _, rv = H.prepare_mesh(P, torch.tensor([0]), sc["model"], sc["topo"])
+    assert (eng.ref_verts.cpu() - rv[0]).abs().max() < 1e-5
+    loss, total, aux = H.step_losses(P, fid, sc["model"], sc["topo"], tg, S, sc["focal"], rv, eng.dist_albedo.cpu().long(),
+                                     eng.dist_normal.cpu().long())
+    total.backward()
+    eng.forward_backward(True, True)
+    torch.cuda.synchronize()
+    lv = eng.losses()
+    for k in LOSS_NAMES:
+        assert abs(lv[k] - loss[k].item()) <= 1e-5 * abs(loss[k].item()) + 1e-8, (k, lv[k], loss[k].item())
+    assert ((eng.s["alpha"].cpu() - aux["y_sil_pred"]).abs() > 1e-4).float().mean() < 1e-3
+    assert ((eng.s["rgb"].cpu() - aux["y_pred"]).abs().max(-1).values > 1e-4).float().mean() < 1e-3
+    for k in ("pose", "cam", "verts_disps", "shape", "light_positions", "amb_ratio", "texture", "normal_map", "rot", "trans"):
+        assert rel(eng.grads[k].cpu(), P[k].grad) < 2e-3, (k, rel(eng.grads[k].cpu(), P[k].grad))
+    # ---- 3 optimiser steps (eager, then hipGraph capture + replay) vs torch.optim.Adam on the oracle
+    opt_c = torch.optim.Adam([{"params": [P["pose"], P["cam"]], "lr": 1e-3}, {"params": [P["verts_disps"], P["shape"]], "lr": 1e-3}])
+    opt_a = torch.optim.Adam([P["light_positions"], P["amb_ratio"], P["texture"], P["normal_map"]], lr=1e-2)
+    for it in range(3):
+        fid = torch.tensor([it % T, (it + 1) % T])
+        eng.step(fid, True, True, use_graph=(it > 0))
+        l2, total, _ = H.step_losses(P, fid, sc["model"], sc["topo"], tg, S, sc["focal"], rv, eng.dist_albedo.cpu().long(),
+                                     eng.dist_normal.cpu().long())
+        opt_c.zero_grad(); opt_a.zero_grad()
+        total.backward(); opt_c.step(); opt_a.step()
+    torch.cuda.synchronize()
+    for k in ("pose", "cam", "verts_disps", "shape", "light_positions", "amb_ratio", "texture", "normal_map"):
+        assert (eng.params[k].cpu() - P[k].detach()).abs().max() < 1e-3, k
+    # rot / trans have no optimiser in the reference (optimize_sequence.py:254-289): untouched
+    assert torch.equal(eng.params["rot"].cpu(), sc["seq"]["rot"])
+
+
+def test_stage_gating_and_no_shadow(sc):
+    """coarse-only / appearance-only stages (optimize_sequence.py:507-515) and the self_shadow=False renderer."""
+    from harp_amd.engine import FitEngine
+    from oracle import harp_ref as H
+    S, B = sc["S"], 2
+    tg = sc["targets"]
+    for shadow, coarse, app in ((True, True, False), (True, False, True), (False, True, True)):
+        eng = FitEngine(sc["model_np"], sc["topo_np"], sc["tpl"]["verts_uvs"], sc["tpl"]["faces_uvs"], sc["uv_mask"].float(), sc["seq"], S,
+                        sc["focal"], B, device=DEV, self_shadow=shadow)
+        eng.set_targets(tg["y_true"], tg["y_sil"], tg["y_sil_col"])
+        P = oracle_params(sc, eng.params)
+        fid = torch.tensor([1, 2])
+        eng.fid.copy_(fid.int().to(DEV)); eng.tfid.copy_(fid.int().to(DEV))
+        eng.draw_texture_offsets(); eng.set_stage(coarse, app)
+        with torch.no_grad():
+            _, rv = H.prepare_mesh(P, torch.tensor([0]), sc["model"], sc["topo"])
+        loss, total, _ = H.step_losses(P, fid, sc["model"], sc["topo"], tg, S, sc["focal"], rv, eng.dist_albedo.cpu().long(),
+                                       eng.dist_normal.cpu().long(), coarse=coarse, app=app, self_shadow=shadow)
+        total.backward()
+        eng.forward_backward(coarse, app)
+        torch.cuda.synchronize()
+        lv = eng.losses()
+        for k, v in loss.items():
+            assert abs(lv[k] - v.item()) <= 1e-5 * abs(v.item()) + 1e-8, (shadow, coarse, app, k)
+        keys = (["pose", "cam", "shape"] if coarse else []) + (["texture", "light_positions"] if app else [])
+        for k in keys:
+            assert rel(eng.grads[k].cpu(), P[k].grad) < 2e-3, (shadow, coarse, app, k, rel(eng.grads[k].cpu(), P[k].grad))
+
+
+def test_full_size_properties():
+    """BASELINE size (512^2, 32 frames) through size-independent properties: alpha in [0,1]; alpha == 1 wherever a face is hit
+    well inside; face ids valid; rgb == background exactly where nothing is hit; run-to-run identical forward."""
+    from harp_amd import ops, synth
+    import bench
+    eng, focal = bench.build_engine(0, 1, torch.device(DEV), T=32, img=512, B=32)
+    fid = torch.arange(32)
+    eng.step(fid, True, True, use_graph=False)
+    torch.cuda.synchronize()
+    a, f, rgb = eng.s["alpha"].clone(), eng.s["face_c"].clone(), eng.s["rgb"].clone()
+    assert (a >= 0).all() and (a <= 1).all()
+    assert (f >= -1).all() and (f < eng.topo.F).all()
+    cov = f >= 0
+    assert 0.05 < cov.float().mean() < 0.6
+    assert (a[cov] > 0.49).all()                      # inside a face => prob >= 0.5
+    assert (rgb[~cov] == 1.0).all()
+    assert torch.isfinite(rgb).all() and torch.isfinite(eng.g_buf).all()
+    lv = eng.losses()
+    assert all(np.isfinite(v) for v in lv.values())
+    with torch.no_grad():
+        eng.p_buf.copy_(eng.p_buf)                    # no-op; forward again on the UPDATED params must be deterministic
+    eng.fid.copy_(fid.int().to(DEV))
+    eng.forward_backward(True, True); torch.cuda.synchronize()
+    a1, f1, r1 = eng.s["alpha"].clone(), eng.s["face_c"].clone(), eng.s["rgb"].clone()
+    eng.forward_backward(True, True); torch.cuda.synchronize()
+    assert torch.equal(a1, eng.s["alpha"]) and torch.equal(f1, eng.s["face_c"]) and torch.equal(r1, eng.s["rgb"])
