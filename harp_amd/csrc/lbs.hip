@@ -182,29 +182,36 @@ __global__ void __launch_bounds__(256) lbs_skin_kernel(const harp_mano_model M, 
   }
 }
 
-// g_A[b][j][k] = sum_v w[v][j] M[b][v][k]   (192 lanes per frame)
+// g_A[b][j][k] += sum_{v in chunk} w[v][j] M[b][v][k]   (192 lanes per frame x kChunksA vertex chunks; g_A pre-zeroed)
+constexpr int kChunksA = 8;
 __global__ void __launch_bounds__(192) lbs_gA_kernel(const float* __restrict__ weights, const float* __restrict__ Mo,
                                                      float* __restrict__ g_A) {
   const int b = blockIdx.x, j = threadIdx.x / 12, k = threadIdx.x % 12;
+  const int per = (NV + kChunksA - 1) / kChunksA, v0 = blockIdx.y * per, v1 = min(NV, v0 + per);
   float acc = 0.f;
-  for (int v = 0; v < NV; ++v) acc += weights[v * NJ + j] * Mo[((size_t)b * NV + v) * 12 + k];
-  g_A[(b * NJ + j) * 12 + k] = acc;
+#pragma unroll 4
+  for (int v = v0; v < v1; ++v) acc += weights[v * NJ + j] * Mo[((size_t)b * NV + v) * 12 + k];
+  atomicAdd(&g_A[(b * NJ + j) * 12 + k], acc);
 }
 
-// g_pose_map[b][k] = sum_{vc} posedirs[vc][k] g_vp[b][vc];  g_beta_part[b][k] likewise with shapedirs (k<10)
+// g_pose_map[b][k] += sum_{vc in chunk} posedirs[vc][k] g_vp[b][vc];  g_beta_part[b][k] likewise with shapedirs (k<10)
+constexpr int kChunksP = 16;
 __global__ void __launch_bounds__(192) lbs_gpm_kernel(const harp_mano_model M, const float* __restrict__ g_vp,
                                                       float* __restrict__ g_pm, float* __restrict__ g_beta_b) {
   const int b = blockIdx.x, k = threadIdx.x;
+  const int per = (NV * 3 + kChunksP - 1) / kChunksP, i0 = blockIdx.y * per, i1 = min(NV * 3, i0 + per);
   const float* g = g_vp + (size_t)b * NV * 3;
   if (k < NP) {
     float acc = 0.f;
-    for (int i = 0; i < NV * 3; ++i) acc += M.posedirs[i * NP + k] * g[i];
-    g_pm[b * NP + k] = acc;
+#pragma unroll 4
+    for (int i = i0; i < i1; ++i) acc += M.posedirs[i * NP + k] * g[i];
+    atomicAdd(&g_pm[b * NP + k], acc);
   } else if (k < NP + NB) {
     const int kk = k - NP;
     float acc = 0.f;
-    for (int i = 0; i < NV * 3; ++i) acc += M.shapedirs_T[kk * NV * 3 + i] * g[i];
-    g_beta_b[b * NB + kk] = acc;
+#pragma unroll 4
+    for (int i = i0; i < i1; ++i) acc += M.shapedirs_T[kk * NV * 3 + i] * g[i];
+    atomicAdd(&g_beta_b[b * NB + kk], acc);
   }
 }
 
@@ -360,8 +367,10 @@ int harp_lbs_mano_bwd(const harp_mano_model* m, const float* pose, const float* 
   hipLaunchKernelGGL(lbs_gtrans_kernel, dim3(B), dim3(256), 0, stream, g_verts, w.g_j16, g_trans);
   hipLaunchKernelGGL(lbs_skin_kernel<true>, dim3((NV + 255) / 256, (B + FRAMES_PER_BLOCK - 1) / FRAMES_PER_BLOCK), dim3(256), 0, stream,
                      *m, betas, trans, w.pm, w.A, B, nullptr, g_verts, w.g_vp, w.Mo);
-  hipLaunchKernelGGL(lbs_gA_kernel, dim3(B), dim3(192), 0, stream, m->weights, w.Mo, w.g_A);
-  hipLaunchKernelGGL(lbs_gpm_kernel, dim3(B), dim3(192), 0, stream, *m, w.g_vp, w.g_pm, g_betas);
+  hipMemsetAsync(w.g_A, 0, sizeof(float) * (size_t)B * (192 + 135), stream);     // g_A | g_pm are adjacent in the workspace
+  hipMemsetAsync(g_betas, 0, sizeof(float) * (size_t)B * NB, stream);
+  hipLaunchKernelGGL(lbs_gA_kernel, dim3(B, kChunksA), dim3(192), 0, stream, m->weights, w.Mo, w.g_A);
+  hipLaunchKernelGGL(lbs_gpm_kernel, dim3(B, kChunksP), dim3(192), 0, stream, *m, w.g_vp, w.g_pm, g_betas);
   hipLaunchKernelGGL(lbs_chain_bwd_kernel, dim3(B), dim3(64), 0, stream, *m, pose, w.Rloc, w.G, w.Jrest, w.g_A, w.g_pm, w.g_j16,
                      g_pose, g_betas);
   HARP_CHECK_LAUNCH();

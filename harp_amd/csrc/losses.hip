@@ -64,90 +64,103 @@ __global__ void __launch_bounds__(64) kps_kernel(const float* __restrict__ gt, c
   }
 }
 
-// laplacian (uniform, Appendix A.11) | normal consistency (A.12) | ARAP (loss/arap.py:45-57); blockIdx.y = frame
-// w[0..2] = weights of (laplacian, normal, arap); loss[0..2] accumulate.
+// laplacian (uniform, Appendix A.11) | normal consistency (A.12) | ARAP (loss/arap.py:45-57); blockIdx.y = frame.
+// GATHER formulation, one lane per (frame, vertex), no atomics on the gradient: every lane re-derives the terms its vertex
+// takes part in (its own Laplacian row + its neighbours' rows, its incident edges, the face pairs it belongs to) from the
+// static CSR tables, and owns g_verts[b, u, :].  w[0..2] = weights of (laplacian, normal, arap); loss[0..2] accumulate.
 __global__ void __launch_bounds__(256) mesh_reg_kernel(const float* __restrict__ verts, const float* __restrict__ ref_verts,
                                                        const int32_t* __restrict__ nbr_off, const int32_t* __restrict__ nbr_idx,
-                                                       const int32_t* __restrict__ pairs, const int32_t* __restrict__ edges, int B,
-                                                       int V, int P, int E, const float* __restrict__ w, float* __restrict__ loss,
+                                                       const int32_t* __restrict__ pairs, const int32_t* __restrict__ vp_off,
+                                                       const int32_t* __restrict__ vp_idx, int B, int V, int P, int E,
+                                                       const float* __restrict__ w, float* __restrict__ loss,
                                                        float* __restrict__ g_verts) {
   __shared__ float red[4];
-  const int b = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+  const int b = blockIdx.y, u = blockIdx.x * 256 + threadIdx.x;
   const float* vb = verts + (size_t)b * V * 3;
-  float* gb = g_verts ? g_verts + (size_t)b * V * 3 : nullptr;
+  const bool grad = (w != nullptr) && (g_verts != nullptr);
+  const float w_lap = grad ? w[0] : 0.f, w_nc = grad ? w[1] : 0.f, w_ar = grad ? w[2] : 0.f;
   float l_lap = 0.f, l_nc = 0.f, l_ar = 0.f;
-  const bool grad = (w != nullptr) && (gb != nullptr);
-  if (i < V) {
-    const int s = nbr_off[i], e = nbr_off[i + 1];
-    float a[3] = {0.f, 0.f, 0.f};
-    for (int k = s; k < e; ++k) for (int c = 0; c < 3; ++c) a[c] += vb[3 * nbr_idx[k] + c];
-    const float invd = 1.0f / (float)(e - s);
-    float lv[3], n2 = 0.f;
-    for (int c = 0; c < 3; ++c) { lv[c] = a[c] * invd - vb[3 * i + c]; n2 += lv[c] * lv[c]; }
-    const float n = sqrtf(n2);
-    const float sc = 1.0f / ((float)V * (float)B);
-    l_lap = n * sc;
-    if (grad && n > 0.f) {
-      const float k = w[0] * sc / n;
-      for (int c = 0; c < 3; ++c) {
-        const float g = k * lv[c];
-        atomicAdd(gb + 3 * i + c, -g);
-        for (int q = s; q < e; ++q) atomicAdd(gb + 3 * nbr_idx[q] + c, g * invd);
+  float g[3] = {0.f, 0.f, 0.f};
+  if (u < V) {
+    const float pu[3] = {vb[3 * u], vb[3 * u + 1], vb[3 * u + 2]};
+    const float sc_lap = 1.0f / ((float)V * (float)B), sc_ar = 1.0f / ((float)E * (float)B), sc_nc = 1.0f / ((float)P * (float)B);
+    const int s = nbr_off[u], e = nbr_off[u + 1];
+    // --- own Laplacian row
+    {
+      float a[3] = {0.f, 0.f, 0.f};
+      for (int k = s; k < e; ++k) for (int c = 0; c < 3; ++c) a[c] += vb[3 * nbr_idx[k] + c];
+      const float invd = 1.0f / (float)(e - s);
+      float lv[3], n2 = 0.f;
+      for (int c = 0; c < 3; ++c) { lv[c] = a[c] * invd - pu[c]; n2 += lv[c] * lv[c]; }
+      const float n = sqrtf(n2);
+      l_lap = n * sc_lap;
+      if (n > 0.f) for (int c = 0; c < 3; ++c) g[c] -= w_lap * sc_lap / n * lv[c];
+    }
+    for (int k = s; k < e; ++k) {
+      const int nb = nbr_idx[k];
+      const float pn[3] = {vb[3 * nb], vb[3 * nb + 1], vb[3 * nb + 2]};
+      // --- neighbour's Laplacian row contains u with weight 1/deg(nb)
+      if (grad) {
+        const int s2 = nbr_off[nb], e2 = nbr_off[nb + 1];
+        float a[3] = {0.f, 0.f, 0.f};
+        for (int q = s2; q < e2; ++q) for (int c = 0; c < 3; ++c) a[c] += vb[3 * nbr_idx[q] + c];
+        const float invd = 1.0f / (float)(e2 - s2);
+        float lv[3], n2 = 0.f;
+        for (int c = 0; c < 3; ++c) { lv[c] = a[c] * invd - pn[c]; n2 += lv[c] * lv[c]; }
+        const float n = sqrtf(n2);
+        if (n > 0.f) for (int c = 0; c < 3; ++c) g[c] += w_lap * sc_lap / n * lv[c] * invd;
+      }
+      // --- ARAP on edge (u, nb); every edge is visited from both ends -> half the loss each
+      if (ref_verts) {
+        float d[3], l2 = 0.f, r2 = 0.f;
+        for (int c = 0; c < 3; ++c) {
+          d[c] = pu[c] - pn[c];
+          l2 += d[c] * d[c];
+          const float r = ref_verts[3 * u + c] - ref_verts[3 * nb + c];
+          r2 += r * r;
+        }
+        const float l = sqrtf(l2);
+        const float diff = l * 1000.0f - sqrtf(r2) * 1000.0f;
+        l_ar += 0.5f * diff * diff * sc_ar;
+        if (l > 0.f) for (int c = 0; c < 3; ++c) g[c] += w_ar * sc_ar * 2.0f * diff * 1000.0f / l * d[c];
       }
     }
-  }
-  if (i < P) {
-    const int i0 = pairs[4 * i], i1 = pairs[4 * i + 1], ia = pairs[4 * i + 2], ib = pairs[4 * i + 3];
-    float e[3], da[3], db[3];
-    for (int c = 0; c < 3; ++c) { e[c] = vb[3 * i1 + c] - vb[3 * i0 + c]; da[c] = vb[3 * ia + c] - vb[3 * i0 + c]; db[c] = vb[3 * ib + c] - vb[3 * i0 + c]; }
-    const float n0[3] = {e[1] * da[2] - e[2] * da[1], e[2] * da[0] - e[0] * da[2], e[0] * da[1] - e[1] * da[0]};
-    const float n1[3] = {-(e[1] * db[2] - e[2] * db[1]), -(e[2] * db[0] - e[0] * db[2]), -(e[0] * db[1] - e[1] * db[0])};
-    const float l0 = sqrtf(n0[0] * n0[0] + n0[1] * n0[1] + n0[2] * n0[2]), l1 = sqrtf(n1[0] * n1[0] + n1[1] * n1[1] + n1[2] * n1[2]);
-    const float dp = n0[0] * n1[0] + n0[1] * n1[1] + n0[2] * n1[2];
-    const float den = fmaxf(l0 * l1, 1e-8f);
-    const float cs = dp / den;
-    const float sc = 1.0f / ((float)P * (float)B);
-    l_nc = (1.0f - cs) * sc;
+    // --- normal consistency: the face pairs u belongs to (role 0 = v0, 1 = v1, 2 = a, 3 = b)
+    for (int k = vp_off[u]; k < vp_off[u + 1]; ++k) {
+      const int pr = vp_idx[k] >> 2, role = vp_idx[k] & 3;
+      const int i0 = pairs[4 * pr], i1 = pairs[4 * pr + 1], ia = pairs[4 * pr + 2], ib = pairs[4 * pr + 3];
+      float ev[3], da[3], db[3];
+      for (int c = 0; c < 3; ++c) { ev[c] = vb[3 * i1 + c] - vb[3 * i0 + c]; da[c] = vb[3 * ia + c] - vb[3 * i0 + c]; db[c] = vb[3 * ib + c] - vb[3 * i0 + c]; }
+      const float n0[3] = {ev[1] * da[2] - ev[2] * da[1], ev[2] * da[0] - ev[0] * da[2], ev[0] * da[1] - ev[1] * da[0]};
+      const float n1[3] = {-(ev[1] * db[2] - ev[2] * db[1]), -(ev[2] * db[0] - ev[0] * db[2]), -(ev[0] * db[1] - ev[1] * db[0])};
+      const float l0 = sqrtf(n0[0] * n0[0] + n0[1] * n0[1] + n0[2] * n0[2]), l1 = sqrtf(n1[0] * n1[0] + n1[1] * n1[1] + n1[2] * n1[2]);
+      const float dp = n0[0] * n1[0] + n0[1] * n1[1] + n0[2] * n1[2];
+      const float den = fmaxf(l0 * l1, 1e-8f);
+      const float cs = dp / den;
+      if (role == 0) l_nc += (1.0f - cs) * sc_nc;
+      if (grad) {
+        const float kk = -w_nc * sc_nc;                   // d/d cos
+        // torch 1.11 cosine_similarity: w12 / sqrt(clamp_min(w1*w2, eps^2)); the clamp is ACTIVE for mm-sized triangles
+        // (|n0||n1| ~ 1e-11 < 1e-8), where cos = w12 / eps and only the numerator carries gradient.
+        const bool clamped = !(l0 * l1 > 1e-8f);
+        float g0[3], g1[3];
+        for (int c = 0; c < 3; ++c) {
+          g0[c] = kk * (n1[c] / den - (clamped ? 0.f : cs * n0[c] / (l0 * l0)));
+          g1[c] = kk * (n0[c] / den - (clamped ? 0.f : cs * n1[c] / (l1 * l1)));
+        }
+        // n0 = e x da : g_e = da x g0, g_da = g0 x e ;  n1 = -(e x db): g_e += -(db x g1), g_db = -(g1 x e)
+        const float ge[3] = {da[1] * g0[2] - da[2] * g0[1] - (db[1] * g1[2] - db[2] * g1[1]),
+                             da[2] * g0[0] - da[0] * g0[2] - (db[2] * g1[0] - db[0] * g1[2]),
+                             da[0] * g0[1] - da[1] * g0[0] - (db[0] * g1[1] - db[1] * g1[0])};
+        const float gda[3] = {g0[1] * ev[2] - g0[2] * ev[1], g0[2] * ev[0] - g0[0] * ev[2], g0[0] * ev[1] - g0[1] * ev[0]};
+        const float gdb[3] = {-(g1[1] * ev[2] - g1[2] * ev[1]), -(g1[2] * ev[0] - g1[0] * ev[2]), -(g1[0] * ev[1] - g1[1] * ev[0])};
+        for (int c = 0; c < 3; ++c)
+          g[c] += (role == 1) ? ge[c] : (role == 2) ? gda[c] : (role == 3) ? gdb[c] : (-ge[c] - gda[c] - gdb[c]);
+      }
+    }
     if (grad) {
-      const float k = -w[1] * sc;                       // d/d cos
-      float g0[3], g1[3];
-      // torch 1.11 cosine_similarity: w12 / sqrt(clamp_min(w1*w2, eps^2)); the clamp is ACTIVE for mm-sized triangles
-      // (|n0||n1| ~ 1e-11 < 1e-8), where cos = w12 / eps and only the numerator carries gradient.
-      const bool clamped = !(l0 * l1 > 1e-8f);
-      for (int c = 0; c < 3; ++c) {
-        g0[c] = k * (n1[c] / den - (clamped ? 0.f : cs * n0[c] / (l0 * l0)));
-        g1[c] = k * (n0[c] / den - (clamped ? 0.f : cs * n1[c] / (l1 * l1)));
-      }
-      // n0 = e x da : g_e = da x g0, g_da = g0 x e ;  n1 = -(e x db): g_e += -(db x g1), g_db = -(g1 x e)
-      const float ge[3] = {da[1] * g0[2] - da[2] * g0[1] - (db[1] * g1[2] - db[2] * g1[1]),
-                           da[2] * g0[0] - da[0] * g0[2] - (db[2] * g1[0] - db[0] * g1[2]),
-                           da[0] * g0[1] - da[1] * g0[0] - (db[0] * g1[1] - db[1] * g1[0])};
-      const float gda[3] = {g0[1] * e[2] - g0[2] * e[1], g0[2] * e[0] - g0[0] * e[2], g0[0] * e[1] - g0[1] * e[0]};
-      const float gdb[3] = {-(g1[1] * e[2] - g1[2] * e[1]), -(g1[2] * e[0] - g1[0] * e[2]), -(g1[0] * e[1] - g1[1] * e[0])};
-      for (int c = 0; c < 3; ++c) {
-        atomicAdd(gb + 3 * i1 + c, ge[c]);
-        atomicAdd(gb + 3 * ia + c, gda[c]);
-        atomicAdd(gb + 3 * ib + c, gdb[c]);
-        atomicAdd(gb + 3 * i0 + c, -ge[c] - gda[c] - gdb[c]);
-      }
-    }
-  }
-  if (i < E && ref_verts) {
-    const int i0 = edges[2 * i], i1 = edges[2 * i + 1];
-    float d[3], l2 = 0.f, r2 = 0.f;
-    for (int c = 0; c < 3; ++c) {
-      d[c] = vb[3 * i0 + c] - vb[3 * i1 + c];
-      l2 += d[c] * d[c];
-      const float r = ref_verts[3 * i0 + c] - ref_verts[3 * i1 + c];
-      r2 += r * r;
-    }
-    const float l = sqrtf(l2);
-    const float diff = l * 1000.0f - sqrtf(r2) * 1000.0f;
-    const float sc = 1.0f / ((float)E * (float)B);
-    l_ar = diff * diff * sc;
-    if (grad && l > 0.f) {
-      const float k = w[2] * sc * 2.0f * diff * 1000.0f / l;
-      for (int c = 0; c < 3; ++c) { atomicAdd(gb + 3 * i0 + c, k * d[c]); atomicAdd(gb + 3 * i1 + c, -k * d[c]); }
+      float* o = g_verts + ((size_t)b * V + u) * 3;
+      o[0] += g[0]; o[1] += g[1]; o[2] += g[2];
     }
   }
   const float s0 = block_sum_256(l_lap, red), s1 = block_sum_256(l_nc, red), s2 = block_sum_256(l_ar, red);
@@ -313,12 +326,11 @@ int harp_kps_loss(const float* gt, const int32_t* fid, const float* pred, int B,
 }
 
 int harp_mesh_regularizers(const float* verts, const float* ref_verts, const int32_t* nbr_off, const int32_t* nbr_idx,
-                           const int32_t* nc_pairs, const int32_t* edges, int B, int V, int P, int E, const float* w, float* loss,
-                           float* g_verts, hipStream_t stream) {
-  if (!verts || !nbr_off || !nbr_idx || !nc_pairs || !edges || !loss) return HARP_ERR_ARG;
-  const int n = max(V, max(P, E));
-  hipLaunchKernelGGL(mesh_reg_kernel, dim3((n + 255) / 256, B), dim3(256), 0, stream, verts, ref_verts, nbr_off, nbr_idx, nc_pairs, edges,
-                     B, V, P, E, w, loss, g_verts);
+                           const int32_t* nc_pairs, const int32_t* vp_off, const int32_t* vp_idx, int B, int V, int P, int E,
+                           const float* w, float* loss, float* g_verts, hipStream_t stream) {
+  if (!verts || !nbr_off || !nbr_idx || !nc_pairs || !vp_off || !vp_idx || !loss) return HARP_ERR_ARG;
+  hipLaunchKernelGGL(mesh_reg_kernel, dim3((V + 255) / 256, B), dim3(256), 0, stream, verts, ref_verts, nbr_off, nbr_idx, nc_pairs, vp_off,
+                     vp_idx, B, V, P, E, w, loss, g_verts);
   HARP_CHECK_LAUNCH();
   return HARP_OK;
 }

@@ -58,7 +58,8 @@ __device__ __forceinline__ float seg_dist2(float px, float py, float ax, float a
 }
 
 __global__ void __launch_bounds__(256) face_setup_kernel(const float* __restrict__ ndc, const int32_t* __restrict__ faces,
-                                                         int V, int F, float r, FaceRec* __restrict__ recs) {
+                                                         int V, int F, float r, FaceRec* __restrict__ recs,
+                                                         float4* __restrict__ bbs) {
   const int f = blockIdx.x * blockDim.x + threadIdx.x;
   const int b = blockIdx.y;
   if (f >= F) return;
@@ -83,6 +84,7 @@ __global__ void __launch_bounds__(256) face_setup_kernel(const float* __restrict
                          fminf(t.y0, fminf(t.y1, t.y2)) - r, fmaxf(t.y0, fmaxf(t.y1, t.y2)) + r);
   }
   recs[(size_t)b * F + f] = rec;
+  bbs[(size_t)b * F + f] = rec.bb;      // contiguous copy: the binning pass streams it with fully coalesced 16-B loads
 }
 
 // Ascending-order compaction of `pred` across a 256-thread block. Returns this thread's slot (or -1) and
@@ -100,32 +102,35 @@ __device__ __forceinline__ int block_compact(bool pred, int running, int* lds_cn
   return pred ? pos : -1;
 }
 
-__global__ void __launch_bounds__(256) bin_faces_kernel(const FaceRec* __restrict__ recs, int F, int S, int nsx,
+// One WAVE per (frame, 64x64 super-tile): streams the frame's bboxes 64 at a time, ballot + popcount compaction,
+// no LDS, no barriers; the list comes out in ascending face order (== PyTorch3D's tie-break order).
+__global__ void __launch_bounds__(256) bin_faces_kernel(const float4* __restrict__ bbs, int F, int S, int nsx,
                                                         int32_t* __restrict__ bins, int32_t* __restrict__ bin_count) {
-  __shared__ int lds_cnt[4];
-  const int st = blockIdx.x, b = blockIdx.y;
+  const int lane = threadIdx.x & 63;
+  const int nst = nsx * nsx;
+  const int st = blockIdx.x * 4 + (threadIdx.x >> 6), b = blockIdx.y;
+  if (st >= nst) return;
   const int sx = st % nsx, sy = st / nsx;
   const int x_lo = sx * kSuper, x_hi = min(x_lo + kSuper, S) - 1;
   const int y_lo = sy * kSuper, y_hi = min(y_lo + kSuper, S) - 1;
   // NDC decreases with pixel index
   const float nx_hi = pix_to_ndc(x_lo, S), nx_lo = pix_to_ndc(x_hi, S);
   const float ny_hi = pix_to_ndc(y_lo, S), ny_lo = pix_to_ndc(y_hi, S);
-  const FaceRec* rb = recs + (size_t)b * F;
-  int32_t* out = bins + ((size_t)b * gridDim.x + st) * F;
+  const float4* bb = bbs + (size_t)b * F;
+  int32_t* out = bins + ((size_t)b * nst + st) * F;
   int running = 0;
-  for (int base = 0; base < F; base += 256) {
-    const int f = base + threadIdx.x;
+  for (int base = 0; base < F; base += 64) {
+    const int f = base + lane;
     bool hit = false;
     if (f < F) {
-      const float4 bb = rb[f].bb;
-      hit = !(nx_lo > bb.y || nx_hi < bb.x || ny_lo > bb.w || ny_hi < bb.z);
+      const float4 q = bb[f];
+      hit = !(nx_lo > q.y || nx_hi < q.x || ny_lo > q.w || ny_hi < q.z);
     }
-    int total;
-    const int pos = block_compact(hit, running, lds_cnt, total);
-    if (pos >= 0) out[pos] = f;
-    running += total;
+    const unsigned long long m = __ballot(hit);
+    if (hit) out[running + __popcll(m & ((1ull << lane) - 1ull))] = f;
+    running += __popcll(m);
   }
-  if (threadIdx.x == 0) bin_count[b * gridDim.x + st] = running;
+  if (lane == 0) bin_count[b * nst + st] = running;
 }
 
 // MODE 0: depth only (light view).  MODE 1: nearest face + silhouette product (camera view).
@@ -214,44 +219,75 @@ __global__ void __launch_bounds__(256) raster_kernel(const FaceRec* __restrict__
         const bool inbox = !(px > q.y || px < q.x || py > q.w || py < q.z);
         if (!__any(inbox && need)) continue;
         const float4 fa = s_a[j], fb = s_b[j];
-        Tri t = tri_from(fa, fb, make_float4(s_z2[j], 0.f, 0.f, 0.f));
-        float b0, b1, b2;
-        const bool inside = tri_bary(t, px, py, b0, b1, b2);
-        if (MODE != 2) {
-          if (inside && inbox && in_img) {
-            const float pz = b0 * t.z0 + b1 * t.z1 + b2 * t.z2;
-            if (pz >= 0.f && pz < best_z) { best_z = pz; best_f = s_id[j]; }
+        const Tri t = tri_from(fa, fb, make_float4(s_z2[j], 0.f, 0.f, 0.f));
+        // ---- cheap classification first (no divisions): un-normalised edge functions and their signs.
+        // inside  <=>  all perspective-corrected barycentrics > 0  <=>  e_i * sign(area') > 0 for all i   (z > 0 by culling)
+        const float e0 = edge_fn(px, py, t.x1, t.y1, t.x2, t.y2);
+        const float e1 = edge_fn(px, py, t.x2, t.y2, t.x0, t.y0);
+        const float e2 = edge_fn(px, py, t.x0, t.y0, t.x1, t.y1);
+        const float area = edge_fn(t.x2, t.y2, t.x0, t.y0, t.x1, t.y1) + kEps;
+        const float sg = (area > 0.f) ? 1.f : ((area < 0.f) ? -1.f : 0.f);
+        const float e0s = e0 * sg, e1s = e1 * sg, e2s = e2 * sg;
+        const bool inside = (e0s > 0.f) && (e1s > 0.f) && (e2s > 0.f);
+        const bool hard_hit = (MODE != 2) && inside && inbox && in_img;
+        bool soft = false;
+        if (MODE >= 1) {
+          soft = (MODE == 1) ? (inbox && in_img && prod != 0.f) : (inbox && need);
+          if (soft) {
+            // squared edge lengths: e0 <-> (v1,v2), e1 <-> (v2,v0), e2 <-> (v0,v1)
+            const float l12 = (t.x2 - t.x1) * (t.x2 - t.x1) + (t.y2 - t.y1) * (t.y2 - t.y1);
+            const float l20 = (t.x0 - t.x2) * (t.x0 - t.x2) + (t.y0 - t.y2) * (t.y0 - t.y2);
+            const float l01 = (t.x1 - t.x0) * (t.x1 - t.x0) + (t.y1 - t.y0) * (t.y1 - t.y0);
+            if (inside) {
+              // deeper than sqrt(18 sigma) inside every edge LINE (<= segment distance): sigmoid saturates to exactly 1 in
+              // fp32 (exp(-18) < 2^-24), so the factor (1-p) is exactly 0 — same result as the exact path, no div/exp.
+              const float K = 18.0f * sigma;
+              if (e0 * e0 > K * l12 && e1 * e1 > K * l20 && e2 * e2 > K * l01) {
+                if (MODE == 1) prod = 0.f;
+                soft = false;
+              }
+            } else {
+              // outside: the triangle lies beyond the line of any violated edge, so dist >= that line distance
+              const float Bf = blur * 1.00001f;
+              if ((e0s < 0.f && e0 * e0 >= Bf * l12) || (e1s < 0.f && e1 * e1 >= Bf * l20) || (e2s < 0.f && e2 * e2 >= Bf * l01)) soft = false;
+            }
           }
         }
-        if (MODE >= 1) {
-          const bool active = (MODE == 1) ? (inbox && in_img && prod != 0.f) : (inbox && need);
-          if (active) {
-            float ta, tb, tc;
-            const float d01 = seg_dist2(px, py, t.x0, t.y0, t.x1, t.y1, ta);
-            const float d02 = seg_dist2(px, py, t.x0, t.y0, t.x2, t.y2, tb);
-            const float d12 = seg_dist2(px, py, t.x1, t.y1, t.x2, t.y2, tc);
-            const float dist = fminf(d01, fminf(d02, d12));
-            if (inside || dist < blur) {
-              const float sd = inside ? -dist : dist;
-              const float p = 1.0f / (1.0f + expf(sd / sigma));   // sigmoid(-sd/sigma)
-              if (MODE == 1) {
-                prod *= (1.0f - p);
-              } else {
-                // d alpha / d sd = -P * p / sigma  (P = prod over all faces)
-                const float g_sd = ga * (-P * p / sigma);
-                const float gd = inside ? -g_sd : g_sd;     // d/d(dist^2)
-                // PointLineDistanceBackward on the argmin edge (t treated as constant)
-                int ia, ib; float ax, ay, bx, by, tt;
-                if (d01 <= d02 && d01 <= d12) { ia = 0; ib = 1; ax = t.x0; ay = t.y0; bx = t.x1; by = t.y1; tt = ta; }
-                else if (d02 <= d12)          { ia = 0; ib = 2; ax = t.x0; ay = t.y0; bx = t.x2; by = t.y2; tt = tb; }
-                else                          { ia = 1; ib = 2; ax = t.x1; ay = t.y1; bx = t.x2; by = t.y2; tt = tc; }
-                const float qx = ax + tt * (bx - ax), qy = ay + tt * (by - ay);
-                const float cx = gd * 2.f * (qx - px), cy = gd * 2.f * (qy - py);
-                atomicAdd(&s_g[j][2 * ia], (1.f - tt) * cx);
-                atomicAdd(&s_g[j][2 * ia + 1], (1.f - tt) * cy);
-                atomicAdd(&s_g[j][2 * ib], tt * cx);
-                atomicAdd(&s_g[j][2 * ib + 1], tt * cy);
-              }
+        if (!__any(hard_hit || soft)) continue;
+        if (hard_hit) {
+          // BarycentricCoordsForward + PerspectiveCorrection with reciprocals (<= 2 ulp from the IEEE-division form)
+          const float ra = __builtin_amdgcn_rcpf(area);
+          const float t0 = (e0 * ra) * t.z1 * t.z2, t1 = t.z0 * (e1 * ra) * t.z2, t2 = t.z0 * t.z1 * (e2 * ra);
+          const float rd = __builtin_amdgcn_rcpf(fmaxf(t0 + t1 + t2, kEps));
+          const float pz = (t0 * rd) * t.z0 + (t1 * rd) * t.z1 + (t2 * rd) * t.z2;
+          if (pz >= 0.f && pz < best_z) { best_z = pz; best_f = s_id[j]; }
+        }
+        if (MODE >= 1 && soft) {
+          float ta, tb, tc;
+          const float d01 = seg_dist2(px, py, t.x0, t.y0, t.x1, t.y1, ta);
+          const float d02 = seg_dist2(px, py, t.x0, t.y0, t.x2, t.y2, tb);
+          const float d12 = seg_dist2(px, py, t.x1, t.y1, t.x2, t.y2, tc);
+          const float dist = fminf(d01, fminf(d02, d12));
+          if (inside || dist < blur) {
+            const float sd = inside ? -dist : dist;
+            const float p = 1.0f / (1.0f + expf(sd / sigma));   // sigmoid(-sd/sigma)
+            if (MODE == 1) {
+              prod *= (1.0f - p);
+            } else {
+              // d alpha / d sd = -P * p / sigma  (P = prod over all faces)
+              const float g_sd = ga * (-P * p / sigma);
+              const float gd = inside ? -g_sd : g_sd;     // d/d(dist^2)
+              // PointLineDistanceBackward on the argmin edge (t treated as constant)
+              int ia, ib; float ax, ay, bx, by, tt;
+              if (d01 <= d02 && d01 <= d12) { ia = 0; ib = 1; ax = t.x0; ay = t.y0; bx = t.x1; by = t.y1; tt = ta; }
+              else if (d02 <= d12)          { ia = 0; ib = 2; ax = t.x0; ay = t.y0; bx = t.x2; by = t.y2; tt = tb; }
+              else                          { ia = 1; ib = 2; ax = t.x1; ay = t.y1; bx = t.x2; by = t.y2; tt = tc; }
+              const float qx = ax + tt * (bx - ax), qy = ay + tt * (by - ay);
+              const float cx = gd * 2.f * (qx - px), cy = gd * 2.f * (qy - py);
+              atomicAdd(&s_g[j][2 * ia], (1.f - tt) * cx);
+              atomicAdd(&s_g[j][2 * ia + 1], (1.f - tt) * cy);
+              atomicAdd(&s_g[j][2 * ib], tt * cx);
+              atomicAdd(&s_g[j][2 * ib + 1], tt * cy);
             }
           }
         }
@@ -290,16 +326,19 @@ extern "C" {
 size_t harp_rasterize_ws_bytes(int B, int F, int S) {
   const int nsx = (S + kSuper - 1) / kSuper;
   size_t recs = (size_t)B * F * sizeof(FaceRec);
+  size_t bbs = (size_t)B * F * sizeof(float4);
   size_t bins = (size_t)B * nsx * nsx * F * sizeof(int32_t);
   size_t cnt = (((size_t)B * nsx * nsx * sizeof(int32_t)) + 255) / 256 * 256;
-  return recs + bins + cnt;
+  return recs + bbs + bins + cnt;
 }
 
-static void ws_split(void* ws, int B, int F, int S, FaceRec** recs, int32_t** bins, int32_t** cnt) {
+static void ws_split(void* ws, int B, int F, int S, FaceRec** recs, int32_t** bins, int32_t** cnt, float4** bbs = nullptr) {
   const int nsx = (S + kSuper - 1) / kSuper;
   char* p = (char*)ws;
   *recs = (FaceRec*)p;
   p += (size_t)B * F * sizeof(FaceRec);
+  if (bbs) *bbs = (float4*)p;
+  p += (size_t)B * F * sizeof(float4);
   *bins = (int32_t*)p;
   p += (size_t)B * nsx * nsx * F * sizeof(int32_t);
   *cnt = (int32_t*)p;
@@ -313,12 +352,12 @@ static void ws_split(void* ws, int B, int F, int S, FaceRec** recs, int32_t** bi
 int harp_rasterize_fwd(const float* ndc, const int32_t* faces, int B, int V, int F, int S, int soft, float blur_radius,
                        float sigma, void* ws, int32_t* face_id, float* zbuf, float* alpha, hipStream_t stream) {
   if (!ndc || !faces || !ws || !face_id || B <= 0 || F <= 0 || S <= 0 || (soft && !alpha)) return HARP_ERR_ARG;
-  FaceRec* recs; int32_t *bins, *cnt;
-  ws_split(ws, B, F, S, &recs, &bins, &cnt);
+  FaceRec* recs; int32_t *bins, *cnt; float4* bbs;
+  ws_split(ws, B, F, S, &recs, &bins, &cnt, &bbs);
   const int nsx = (S + kSuper - 1) / kSuper;
   const float r = soft ? sqrtf(blur_radius) : 0.f;
-  hipLaunchKernelGGL(face_setup_kernel, dim3((F + 255) / 256, B), dim3(256), 0, stream, ndc, faces, V, F, r, recs);
-  hipLaunchKernelGGL(bin_faces_kernel, dim3(nsx * nsx, B), dim3(256), 0, stream, recs, F, S, nsx, bins, cnt);
+  hipLaunchKernelGGL(face_setup_kernel, dim3((F + 255) / 256, B), dim3(256), 0, stream, ndc, faces, V, F, r, recs, bbs);
+  hipLaunchKernelGGL(bin_faces_kernel, dim3((nsx * nsx + 3) / 4, B), dim3(256), 0, stream, bbs, F, S, nsx, bins, cnt);
   const dim3 grid((S + kTile - 1) / kTile, (S + kTile - 1) / kTile, B);
   if (soft)
     hipLaunchKernelGGL(raster_kernel<1>, grid, dim3(256), 0, stream, recs, bins, cnt, F, S, nsx, blur_radius, sigma,

@@ -238,7 +238,7 @@ class FitEngine:
             self._ck(L.harp_image_l1(p(s["alpha"]), p(self.y_sil), None, p(self.tfid), B, S * S, 1, wp(0), lp(0), p(s["g_alpha"]), st), "l1_sil")
             self._ck(L.harp_kps_loss(p(self.init_joints), p(self.fid), p(s["joints_m"]), B, 21, wp(1), lp(1), p(s["g_joints_m"]), st), "kps")
             self._ck(L.harp_sum_squares(p(self.params["verts_disps"]), V, wp(2), lp(2), p(self.grads["verts_disps"]), st), "disp_reg")
-            self._ck(L.harp_mesh_regularizers(p(s["vd"]), p(self.ref_verts), p(tp.nbr_off), p(tp.nbr_idx), p(tp.nc_pairs), p(tp.edges), B, V,
+            self._ck(L.harp_mesh_regularizers(p(s["vd"]), p(self.ref_verts), p(tp.nbr_off), p(tp.nbr_idx), p(tp.nc_pairs), p(tp.vp_off), p(tp.vp_idx), B, V,
                                               tp.nc_pairs.shape[0], tp.E, wp(3), lp(3), p(s["g_vd"]), st), "mesh_reg")
         if app:
             self._ck(L.harp_image_l1(p(s["rgb"]), p(self.y_true), p(self.y_sil_col), p(self.tfid), B, S * S * 3, 3, wp(6), lp(6), p(s["g_rgb"]), st),

@@ -74,7 +74,7 @@ class DeviceTopology:
     def __init__(self, topo, verts_uvs, faces_uvs, device):
         i32 = lambda a: torch.as_tensor(a, dtype=torch.int32).contiguous().to(device)
         self.V0, self.V = int(topo["n_verts0"]), int(topo["n_verts"])
-        for k in ("faces0", "edges0", "faces", "edges", "nbr_off", "nbr_idx", "vf_off", "vf_idx", "nc_pairs", "sub_off", "sub_idx"):
+        for k in ("faces0", "edges0", "faces", "edges", "nbr_off", "nbr_idx", "vf_off", "vf_idx", "nc_pairs", "vp_off", "vp_idx", "sub_off", "sub_idx"):
             setattr(self, k, i32(topo[k]))
         self.E0, self.F, self.E = self.edges0.shape[0], self.faces.shape[0], self.edges.shape[0]
         self.verts_uvs = torch.as_tensor(verts_uvs, dtype=torch.float32).reshape(-1, 2).contiguous().to(device)

@@ -28,7 +28,7 @@ def build_topology(faces0, n_verts0):
     """All static int tables for one template (numpy). Keys:
     faces0 (F0,3), edges0 (E0,2), faces (F,3) subdivided, edges (E,2) of the subdivided mesh,
     nbr_off/nbr_idx (vertex->neighbour CSR), vf_off/vf_idx (vertex->(face*3+corner) CSR),
-    nc_pairs (P,4), sub_off/sub_idx (base-vertex -> child midpoint CSR, for subdivide backward)."""
+    nc_pairs (P,4), vp_off/vp_idx (vertex->(pair*4+role) CSR), sub_off/sub_idx (base-vertex -> child midpoint CSR, for subdivide backward)."""
     faces0 = np.asarray(faces0, np.int64)
     edges0, faces = subdivide_topology(faces0, n_verts0)
     V = n_verts0 + len(edges0)
@@ -39,12 +39,13 @@ def build_topology(faces0, n_verts0):
     fc = np.arange(faces.size)
     vf_off, vf_idx = csr_from_pairs(faces.reshape(-1), fc, V)
     nc_pairs = normal_consistency_pairs(faces, V)
+    vp_off, vp_idx = csr_from_pairs(nc_pairs.reshape(-1), np.arange(nc_pairs.size), V)   # vertex -> pair*4+role
     srow = np.concatenate([edges0[:, 0], edges0[:, 1]])
     scol = np.concatenate([np.arange(len(edges0)), np.arange(len(edges0))]) + n_verts0
     sub_off, sub_idx = csr_from_pairs(srow, scol, n_verts0)
     return dict(faces0=faces0.astype(np.int32), edges0=edges0.astype(np.int32), faces=faces.astype(np.int32),
                 edges=edges.astype(np.int32), nbr_off=nbr_off, nbr_idx=nbr_idx, vf_off=vf_off, vf_idx=vf_idx,
-                nc_pairs=nc_pairs, sub_off=sub_off, sub_idx=sub_idx, n_verts0=n_verts0, n_verts=V)
+                nc_pairs=nc_pairs, vp_off=vp_off, vp_idx=vp_idx, sub_off=sub_off, sub_idx=sub_idx, n_verts0=n_verts0, n_verts=V)
 
 
 def make_mano_model(template=None, seed=0):

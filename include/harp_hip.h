@@ -136,10 +136,11 @@ int harp_image_l1(const float* pred, const float* target, const float* mask, con
 int harp_kps_loss(const float* gt, const int32_t* fid, const float* pred, int B, int n_joints_pred, const float* w, float* loss,
                   float* g_pred, hipStream_t stream);
 /* loss[0..2], w[0..2] = mesh_laplacian_smoothing, mesh_normal_consistency (optimize_sequence.py:536-537),
- * arap_loss (loss/arap.py:4-57; ref_verts (V,3), NULL skips it) */
+ * arap_loss (loss/arap.py:4-57; ref_verts (V,3), NULL skips it); nbr_*: vertex->neighbour CSR (= the edge list, E edges),
+ * nc_pairs (P,4) [v0,v1,a,b] per face pair sharing edge (v0,v1), vp_*: vertex -> (pair*4+role) CSR (harp_amd/topology.py) */
 int harp_mesh_regularizers(const float* verts, const float* ref_verts, const int32_t* nbr_off, const int32_t* nbr_idx,
-                           const int32_t* nc_pairs, const int32_t* edges, int B, int V, int P, int E, const float* w, float* loss,
-                           float* g_verts, hipStream_t stream);
+                           const int32_t* nc_pairs, const int32_t* vp_off, const int32_t* vp_idx, int B, int V, int P, int E,
+                           const float* w, float* loss, float* g_verts, hipStream_t stream);
 /* torch.sum(verts_disps ** 2) (optimize_sequence.py:533) */
 int harp_sum_squares(const float* x, int n, const float* w, float* loss, float* g, hipStream_t stream);
 /* albedo_reg / smooth_texture_reg (loss/texture_reg.py:5-30, 48-66) with the drawn integer offsets dist (H,W,2) */
