@@ -61,7 +61,7 @@ class ShadeArgs(ctypes.Structure):
                 [(n, _i) for n in ("B", "V", "F", "S", "Ht", "Wt")] +
                 [(n, _f) for n in ("focal", "ppx", "ppy")] + [("bg", _f * 3)] +
                 [(n, _vp) for n in ("rgb", "g_rgb", "g_tex", "g_nmap", "g_verts", "g_vnormals", "g_ndc", "g_zl", "g_light_pos",
-                                    "g_colors", "g_light_R", "g_light_T")])
+                                    "g_colors", "g_light_R", "g_light_T")] + [("debug_skip", _i)])
 
 
 SIGNATURES.update({

@@ -182,6 +182,12 @@ __global__ void __launch_bounds__(256) lbs_skin_kernel(const harp_mano_model M, 
   }
 }
 
+__global__ void zero2_kernel(float* __restrict__ a, int na, float* __restrict__ b, int nb) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < na) a[i] = 0.f;      // g_A | g_pm are adjacent in the workspace
+  if (i < nb) b[i] = 0.f;
+}
+
 // g_A[b][j][k] += sum_{v in chunk} w[v][j] M[b][v][k]   (192 lanes per frame x kChunksA vertex chunks; g_A pre-zeroed)
 constexpr int kChunksA = 8;
 __global__ void __launch_bounds__(192) lbs_gA_kernel(const float* __restrict__ weights, const float* __restrict__ Mo,
@@ -367,8 +373,8 @@ int harp_lbs_mano_bwd(const harp_mano_model* m, const float* pose, const float* 
   hipLaunchKernelGGL(lbs_gtrans_kernel, dim3(B), dim3(256), 0, stream, g_verts, w.g_j16, g_trans);
   hipLaunchKernelGGL(lbs_skin_kernel<true>, dim3((NV + 255) / 256, (B + FRAMES_PER_BLOCK - 1) / FRAMES_PER_BLOCK), dim3(256), 0, stream,
                      *m, betas, trans, w.pm, w.A, B, nullptr, g_verts, w.g_vp, w.Mo);
-  hipMemsetAsync(w.g_A, 0, sizeof(float) * (size_t)B * (192 + 135), stream);     // g_A | g_pm are adjacent in the workspace
-  hipMemsetAsync(g_betas, 0, sizeof(float) * (size_t)B * NB, stream);
+  // (a fill KERNEL, not hipMemsetAsync: memset nodes captured into a hipGraph were observed not to re-execute on replay)
+  hipLaunchKernelGGL(zero2_kernel, dim3((B * (192 + 135) + 255) / 256), dim3(256), 0, stream, w.g_A, B * (192 + 135), g_betas, B * NB);
   hipLaunchKernelGGL(lbs_gA_kernel, dim3(B, kChunksA), dim3(192), 0, stream, m->weights, w.Mo, w.g_A);
   hipLaunchKernelGGL(lbs_gpm_kernel, dim3(B, kChunksP), dim3(192), 0, stream, *m, w.g_vp, w.g_pm, g_betas);
   hipLaunchKernelGGL(lbs_chain_bwd_kernel, dim3(B), dim3(64), 0, stream, *m, pose, w.Rloc, w.G, w.Jrest, w.g_A, w.g_pm, w.g_j16,

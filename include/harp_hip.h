@@ -79,6 +79,7 @@ typedef struct harp_shade_args {
   float* g_colors;          /* 9 (+=) or NULL */
   float* g_light_R;         /* (B,9) (+=) or NULL */
   float* g_light_T;         /* (B,3) (+=) or NULL */
+  int debug_skip;           /* 0 in production; bit flags used only by tools/dev ablation timing */
 } harp_shade_args;
 int harp_shade_fwd(const harp_shade_args* a, hipStream_t stream);
 int harp_shade_bwd(const harp_shade_args* a, hipStream_t stream);
