@@ -207,10 +207,11 @@ class FitEngine:
             setattr(a, k, _lib.ptr(t))
         return a
 
-    def forward_backward(self, coarse=True, app=True):
-        """Enqueue forward + losses + backward for the frames in self.fid; gradients land in self.g_buf, loss terms
-        in self.loss_vec[:9] (unweighted, order LOSS_NAMES)."""
-        L, s, p, st, tp, B, S = _lib.lib(), self.s, _lib.ptr, _lib.stream(), self.topo, self.B, self.S
+    def forward_backward(self, coarse=True, app=True, B=None):
+        """Enqueue forward + losses + backward for the first B (default: batch_size) frames in self.fid; gradients land in
+        self.g_buf, loss terms in self.loss_vec[:9] (unweighted, order LOSS_NAMES)."""
+        B = self.B if B is None else int(B)
+        L, s, p, st, tp, S = _lib.lib(), self.s, _lib.ptr, _lib.stream(), self.topo, self.S
         V, F = tp.V, tp.F
         w = self.w_vec
         wp = lambda i: w.data_ptr() + 4 * i
@@ -280,9 +281,9 @@ class FitEngine:
 
     def allreduce(self):
         if self.world > 1:
-            import torch.distributed as dist
+            from .dist import allreduce_flat
             o, n = self.opt_span
-            dist.all_reduce(self.g_buf[o:o + n])          # one flat bucket (sum); 1/world is applied in the Adam kernel
+            allreduce_flat(self.g_buf[o:o + n])           # one flat bucket (sum); 1/world is applied in the Adam kernel
 
     def adam(self, coarse=True, app=True):
         L, p, st = _lib.lib(), _lib.ptr, _lib.stream()
@@ -319,18 +320,22 @@ class FitEngine:
         self.dist_normal.copy_(torch.normal(0.0, 2.0, (n, n, 2), generator=self.gen, device=self.dev).to(torch.int32))
 
     def step(self, fid, coarse=True, app=True, use_graph=True):
-        """One optimisation step on the frames `fid` (global frame ids, length == batch_size)."""
+        """One optimisation step on the frames `fid` (global frame ids, length <= batch_size; a shorter — last, partial —
+        batch runs eagerly, optimize_sequence.py:396-399)."""
         fid = torch.as_tensor(fid, dtype=torch.int32)
-        self.fid.copy_(fid.to(self.dev), non_blocking=True)
-        self.tfid.copy_((fid - self.target_offset).to(self.dev), non_blocking=True)
+        n = int(fid.shape[0])
+        if n > self.B:
+            raise ValueError(f"batch of {n} frames exceeds the engine's batch_size {self.B}")
+        self.fid[:n].copy_(fid.to(self.dev), non_blocking=True)
+        self.tfid[:n].copy_((fid - self.target_offset).to(self.dev), non_blocking=True)
         if app:
             self.draw_texture_offsets()
         key = (coarse, app)
         if getattr(self, "_stage", None) != key:
             self.set_stage(coarse, app)
             self._stage = key
-        if not use_graph or self.world > 1:
-            self.forward_backward(coarse, app)
+        if not use_graph or self.world > 1 or n != self.B:
+            self.forward_backward(coarse, app, B=n)
             self.allreduce()
             self.adam(coarse, app)
             return

@@ -81,6 +81,14 @@ class DeviceTopology:
         self.faces_uvs = i32(faces_uvs).reshape(-1, 3)
         self.device = device
 
+    def set_uvs(self, verts_uvs, faces_uvs):
+        """(re)bind the UV tables (TexturesUV(faces_uvs=, verts_uvs=), utils/visualize.py:84-87); accepts the reference's (1,VT,2)/(1,F,3)"""
+        key = (verts_uvs.data_ptr() if torch.is_tensor(verts_uvs) else id(verts_uvs), faces_uvs.data_ptr() if torch.is_tensor(faces_uvs) else id(faces_uvs))
+        if getattr(self, "_uv_key", None) != key:
+            self.verts_uvs = torch.as_tensor(verts_uvs, dtype=torch.float32).reshape(-1, 2).contiguous().to(self.device)
+            self.faces_uvs = torch.as_tensor(faces_uvs).to(torch.int32).reshape(-1, 3).contiguous().to(self.device)
+            self._uv_key = key
+
 
 def _f32(t):
     return t.contiguous().float()

@@ -1,0 +1,141 @@
+"""Mirror of the fitting API of the reference's optimize_sequence.py: get_mesh_subdivider (:67-89), init_params (:181-250),
+get_optimizers (:253-310) and optimize_hand_sequence (:313-816, loop body :446-582).
+
+`optimize_hand_sequence` keeps the reference's signature and schedule (stages, batch 18, shuffle, dense Adam groups and
+learning rates, ReduceLROnPlateau(patience=40) on the coarse group, checkpoint format) but runs every step through the fused
+engine (harp_amd/engine.py) on HBM-resident targets.  The per-op API (`prepare_mesh`, `render_image`, losses) stays available
+for callers that drive autograd themselves (`visualize_val`-style code)."""
+import numpy as np
+import torch
+
+from .engine import FitEngine, LOSS_NAMES
+from .synth import build_topology
+from .utils import file_utils
+from .utils.visualize import MeshSubdivider
+
+
+def get_mesh_subdivider(hand_layer, use_arm=False, device="cuda"):
+    """optimize_sequence.py:67-89"""
+    if use_arm:
+        raise NotImplementedError("SMPL-X arm template: SURVEY.md §8 row a2 (next)")
+    return MeshSubdivider(hand_layer.th_faces, 778, device)
+
+
+def load_uv_mask(configs, uv_size):
+    """optimize_sequence.py:174-178"""
+    from PIL import Image
+    uv_mask_pil = Image.open(configs["uv_mask"]).convert("L").resize(uv_size)
+    return torch.tensor(np.asarray(uv_mask_pil) / 255)
+
+
+def init_params(input_params, VERT_DISPS, VERT_DISPS_NORMALS, VERTS_COLOR, mano_faces, verts_textures, VERTS_UVS=None, FACES_UVS=None,
+                model_type="harp", use_arm=False, configs=None, device="cuda", uv_mask=None):
+    """optimize_sequence.py:181-250: the same dict (keys, shapes, initial values).  All leaves live on `device` (the reference keeps
+    most of them on the CPU and copies them every iteration)."""
+    if model_type != "harp" or verts_textures:
+        raise NotImplementedError("model_type 'harp' with UV textures is the path in scope (SURVEY.md §8)")
+    P = lambda t: torch.nn.Parameter(t.detach().clone().float().to(device), requires_grad=True)
+    params = {}
+    params["trans"], params["pose"], params["rot"] = P(input_params["trans"]), P(input_params["pose"]), P(input_params["rot"])
+    params["shape"] = P(input_params["shape"].mean(dim=0))
+    params["wrist_pose"] = P(torch.zeros([params["pose"].shape[0], 3]))
+    params["init_joints"] = input_params["joints"]
+    n_mesh_verts = 4083 if use_arm else 3093
+    params["verts_disps"] = P(torch.zeros(n_mesh_verts, 1 if (VERT_DISPS_NORMALS or not VERT_DISPS) else 3))
+    verts_rgb_init = torch.from_numpy(VERTS_COLOR) if VERTS_COLOR is not None else torch.ones(778, 3)
+    params["verts_rgb"] = P(verts_rgb_init)
+    params["verts_uvs"], params["faces_uvs"] = VERTS_UVS, FACES_UVS
+    params["texture"] = P(torch.tensor([232, 190, 172]).repeat(1, 512, 512, 1) / 255.)
+    params["uv_mask"] = uv_mask if uv_mask is not None else load_uv_mask(configs, params["texture"].shape[1:3])
+    params["normal_map"] = P(torch.tensor([0.0, 0.0, 1.0]).repeat(1, 512, 512, 1))
+    total_frame = input_params["cam"].shape[0]
+    params["light_positions"] = P(torch.tensor(((-0.5, -0.5, -0.5),)).repeat(total_frame, 1))
+    params["amb_ratio"] = P(torch.tensor(0.4))
+    params["mesh_faces"] = mano_faces
+    params["cam"] = P(input_params["cam"])
+    return params
+
+
+def get_optimizers(params, configs):
+    """optimize_sequence.py:253-310 (torch optimisers over the parameter dict, for callers using the autograd API)."""
+    pose_params = [params["pose"], params["cam"]]
+    shape_params = [params["verts_disps"], params["shape"]] if configs["use_vert_disp"] else [params["shape"]]
+    groups = [{"params": pose_params, "lr": 1.0e-3}]
+    if configs["use_arm"] and configs["opt_arm_pose"]:
+        groups.append({"params": [params["wrist_pose"], params["rot"]], "lr": 1.0e-3})
+    if not configs["known_appearance"]:
+        groups.append({"params": shape_params, "lr": 1.0e-3})
+    opt_coarse = torch.optim.Adam(groups)
+    app = [params["light_positions"], params["amb_ratio"]]
+    if not configs["known_appearance"]:
+        app += [params["texture"], params["normal_map"]]
+    opt_app = torch.optim.Adam(app, lr=1.0e-2)
+    sched_coarse = torch.optim.lr_scheduler.ReduceLROnPlateau(opt_coarse, patience=40)
+    return opt_coarse, opt_app, sched_coarse
+
+
+def stage_flags(epoch_id, training_stage):
+    """optimize_sequence.py:507-515 -> (COARSE_OPT, APP_OPT)"""
+    if epoch_id < training_stage[0]:
+        return True, False
+    if epoch_id < training_stage[0] + training_stage[1]:
+        return True, True
+    return False, True
+
+
+def optimize_hand_sequence(configs, input_params, images_dataset, val_params, val_images_dataset, hand_layer,
+                           VERTS_UVS=None, FACES_UVS=None, VERTS_COLOR=None, device="cuda", uv_mask=None, batch_size=18, log_fn=None,
+                           seed=0):
+    """Fit the sequence (optimize_sequence.py:313-596).  Returns the parameter dict in the reference's checkpoint layout.
+    `images_dataset[i]` -> (fid, y_true (S,S,3), y_sil (S,S,1), y_sil_eroded (S,S,1)) like utils/data_util.ImagesDataset."""
+    if configs["use_arm"] or configs["model_type"] != "harp" or configs["known_appearance"] or configs["start_from"]:
+        raise NotImplementedError("round 1: MANO 'harp' fitting from scratch (SURVEY.md §8; resume/known-appearance are §8f rows)")
+    S, T = configs["img_size"], input_params["pose"].shape[0]
+    faces0 = np.asarray(hand_layer.th_faces.detach().cpu())
+    topo = build_topology(faces0, 778)
+    if uv_mask is None:
+        uv_mask = load_uv_mask(configs, (512, 512))
+    eng = FitEngine(hand_layer._model_np, topo, torch.as_tensor(VERTS_UVS).reshape(-1, 2), torch.as_tensor(FACES_UVS).reshape(-1, 3),
+                    torch.as_tensor(uv_mask).float(), input_params, S, configs["focal_length"], batch_size, device=device,
+                    self_shadow=configs["self_shadow"], share_light_position=configs["share_light_position"], seed=seed)
+    items = [images_dataset[i] for i in range(len(images_dataset))]
+    eng.set_targets(torch.stack([torch.as_tensor(it[1]) for it in items]), torch.stack([torch.as_tensor(it[2]).reshape(S, S) for it in items]),
+                    torch.stack([torch.as_tensor(it[3]).reshape(S, S) for it in items]))
+    # ReduceLROnPlateau lives on the host; torch's own scheduler drives a dummy optimiser and the lr is mirrored to the device
+    dummy = torch.optim.Adam([torch.nn.Parameter(torch.zeros(1))], lr=1e-3)
+    sched = torch.optim.lr_scheduler.ReduceLROnPlateau(dummy, patience=40)
+    gen = torch.Generator().manual_seed(seed)
+    weights = torch.tensor([{"silhouette": 7.0, "kps_anchor": 10.0, "vert_disp_reg": 2.0, "laplacian": 4.0, "normal": 0.1, "arap": 0.2,
+                             "photo": 1.0, "albedo": 0.5, "normal_reg": 0.1}[k] for k in LOSS_NAMES], device=device)
+    for epoch_id in range(configs["total_epoch"]):
+        coarse, app = stage_flags(epoch_id, configs["training_stage"])
+        perm = torch.randperm(T, generator=gen)                                    # DataLoader(shuffle=True), :399
+        epoch_loss = torch.zeros((), device=device)
+        nb = 0
+        for s0 in range(0, T, batch_size):
+            eng.step(perm[s0:s0 + batch_size], coarse, app)
+            active = (eng.w_vec[:9] > 0).float()
+            epoch_loss += (eng.loss_vec[:9] * weights * active).sum()              # stays on the device: no per-term .cpu() sync (:559)
+            nb += 1
+        mean_loss = float(epoch_loss / nb)                                         # one sync per epoch
+        if not np.isfinite(mean_loss):
+            raise FloatingPointError(f"non-finite loss at epoch {epoch_id}")      # the reference drops into pdb (:525-527)
+        if coarse:
+            sched.step(mean_loss)                                                  # :581-582
+            eng.set_lr(lr_coarse=dummy.param_groups[0]["lr"])
+        if log_fn is not None:
+            log_fn(epoch_id, mean_loss, eng)
+        if epoch_id % 200 == 0 and epoch_id > 0:
+            file_utils.save_result(export_params(eng, input_params, VERTS_UVS, FACES_UVS, uv_mask, hand_layer), configs["base_output_dir"])
+    params = export_params(eng, input_params, VERTS_UVS, FACES_UVS, uv_mask, hand_layer)
+    file_utils.save_result(params, configs["base_output_dir"], test=configs["known_appearance"])     # :595-596
+    return params
+
+
+def export_params(eng, input_params, VERTS_UVS, FACES_UVS, uv_mask, hand_layer):
+    """the reference's parameter dict (init_params keys) from the engine's arena"""
+    out = {k: eng.params[k].detach().clone() for k in ("trans", "pose", "rot", "shape", "wrist_pose", "verts_disps", "texture", "normal_map",
+                                                       "light_positions", "amb_ratio", "cam")}
+    out.update(init_joints=input_params["joints"], verts_rgb=torch.ones(778, 3), verts_uvs=VERTS_UVS, faces_uvs=FACES_UVS,
+               uv_mask=torch.as_tensor(uv_mask), mesh_faces=hand_layer.th_faces)
+    return out

@@ -1,0 +1,133 @@
+"""Mirror of renderer/renderer_helper.py on the HIP kernels: same factory functions, same renderer call signature
+`renderer(mesh, principal_point=, focal_length=, T=, R=, [cam_T=, cam_R=,] materials=, image_size=) -> (B,S,S,4)`
+(utils/visualize.py:272-279, 304-313).  No (B,S,S,K) fragments exist: the soft-silhouette alpha and the K=1 hit come out of
+one fused raster walk, shading is one fused kernel (see csrc/raster.hip, csrc/shade.hip)."""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from .. import ops
+
+
+def _scalar(x):
+    return float(torch.as_tensor(x).reshape(-1)[0])
+
+
+def _pp(principal_point):
+    p = torch.as_tensor(principal_point, dtype=torch.float32).reshape(-1)
+    return float(p[0]), float(p[1])
+
+
+def _size(image_size):
+    return int(torch.as_tensor(image_size).reshape(-1)[0])
+
+
+def look_at_rotation(camera_position, at, up):
+    """PyTorch3D look_at_rotation, differentiable torch ops on (B,3) tensors."""
+    z = F.normalize(at - camera_position, eps=1e-5)
+    x = F.normalize(torch.cross(up.expand_as(z), z, dim=1), eps=1e-5)
+    y = F.normalize(torch.cross(z, x, dim=1), eps=1e-5)
+    close = torch.isclose(x, torch.zeros((), dtype=x.dtype, device=x.device), atol=5e-3).all(dim=1, keepdim=True)
+    if close.any():
+        x = torch.where(close, F.normalize(torch.cross(y, z, dim=1), eps=1e-5), x)
+    return torch.cat((x[:, None, :], y[:, None, :], z[:, None, :]), dim=1).transpose(1, 2)
+
+
+class SilhouetteRenderer:
+    """MeshRenderer(MeshRasterizer(K=50, blur), SoftSilhouetteShader) (renderer_helper.py:44-58)."""
+
+    def __init__(self, image_size, sigma, faces_per_pixel):
+        self.image_size, self.sigma = image_size, sigma
+        self.blur_radius = math.log(1.0 / 1e-4 - 1.0) * sigma                                       # renderer_helper.py:46
+        self.faces_per_pixel = faces_per_pixel      # K is not a buffer size here: every face within the blur radius contributes
+
+    def __call__(self, mesh, principal_point=None, focal_length=None, T=None, R=None, materials=None, image_size=None, **kw):
+        S = _size(image_size) if image_size is not None else self.image_size
+        dev = mesh.device
+        ndc = ops.project(mesh.verts_padded(), R.to(dev), T.to(dev), _scalar(focal_length), S, _pp(principal_point))
+        alpha, _ = ops.soft_silhouette(ndc, mesh.topo.faces, S, self.blur_radius, self.sigma)
+        ones = torch.ones_like(alpha)
+        return torch.stack([ones, ones, ones, alpha], -1)                                          # sigmoid_alpha_blend: RGB = 1, A = alpha
+
+
+class _PhongBase:
+    bg = (1.0, 1.0, 1.0)
+
+    def _shade(self, mesh, ndc, face_id, ws, materials, light_pos, colors, S, focal, pp, zl=None, light_R=None, light_T=None):
+        tex = mesh.textures
+        if tex is None:
+            raise ValueError("mesh.textures (TexturesUV) is required")
+        topo = mesh.topo
+        topo.set_uvs(tex.verts_uvs, tex.faces_uvs)
+        vn = mesh.verts_normals_padded()                                                            # renderer_helper.py:495
+        nm = materials.normal_maps.maps_padded()[0] if (materials is not None and materials.use_normal_map) else None
+        rgb = ops.shade(ndc, mesh.verts_padded(), vn, tex.maps_padded()[0], nm, light_pos, colors, face_id, ws, topo, S, focal,
+                        zl=zl, light_R=light_R, light_T=light_T, pp=pp, bg=self.bg)
+        a = (face_id >= 0).to(rgb.dtype)            # softmax_rgb_blend alpha for K=1 is sigmoid(-d/sigma) in (0.5,1]; HARP never reads it
+        return torch.cat([rgb, a[..., None]], -1)
+
+
+class PhongRenderer(_PhongBase):
+    """MeshRenderer(MeshRasterizer(K=1), SoftPhongShaderPBR) (renderer_helper.py:60-81, 106-190)."""
+
+    def __init__(self, image_size, light_posi):
+        self.image_size, self.light_posi = image_size, light_posi
+
+    def __call__(self, mesh, principal_point=None, focal_length=None, T=None, R=None, materials=None, image_size=None, **kw):
+        S, focal, pp, dev = _size(image_size), _scalar(focal_length), _pp(principal_point), mesh.device
+        ndc = ops.project(mesh.verts_padded(), R.to(dev), T.to(dev), focal, S, pp)
+        _, face_id, ws = ops.depth_raster(ndc, mesh.topo.faces, S)
+        lp = torch.as_tensor(self.light_posi, dtype=torch.float32, device=dev).reshape(-1, 3).expand(len(mesh), 3)
+        colors = torch.tensor([0.5] * 3 + [0.4] * 3 + [0.1] * 3, device=dev)                      # renderer_helper.py:70-73; shininess 0 -> constant specular
+        return self._shade(mesh, ndc, face_id, ws, materials, lp, colors, S, focal, pp)
+
+
+class MeshRendererShadow(_PhongBase):
+    """MeshRendererShadow(MeshRasterizer(K=1), SoftPhongShaderShadow) (renderer_helper.py:306-412, 416-451, 526-592)."""
+
+    def __init__(self, image_size, light_posi, amb_ratio):
+        self.image_size, self.light_posi, self.amb_ratio = image_size, light_posi, amb_ratio
+
+    def __call__(self, meshes_world, principal_point=None, focal_length=None, T=None, R=None, cam_T=None, cam_R=None, materials=None,
+                 image_size=None, **kw):
+        mesh = meshes_world
+        S, focal, pp, dev = _size(image_size), _scalar(focal_length), _pp(principal_point), mesh.device
+        verts = mesh.verts_padded()
+        ndc_l = ops.project(verts, R.to(dev), T.to(dev), focal, S, pp)                               # light view first (:344)
+        zl, _, _ = ops.depth_raster(ndc_l, mesh.topo.faces, S)
+        ndc_c = ops.project(verts, cam_R.to(dev), cam_T.to(dev), focal, S, pp)                       # camera view (:351-353)
+        _, face_id, ws = ops.depth_raster(ndc_c, mesh.topo.faces, S)
+        lp = torch.as_tensor(self.light_posi, dtype=torch.float32).to(dev).reshape(-1, 3).expand(len(mesh), 3)
+        amb = torch.as_tensor(self.amb_ratio, dtype=torch.float32).to(dev).reshape(()) * torch.ones(3, device=dev)   # :435-441
+        colors = torch.cat([amb, 1.0 - amb, torch.zeros(3, device=dev)])
+        return self._shade(mesh, ndc_c, face_id, ws, materials, lp, colors, S, focal, pp, zl=zl, light_R=R.to(dev), light_T=T.to(dev))
+
+
+def get_renderers(image_size, light_posi=((1.0, 1.0, -5.0),), silh_sigma=1e-7, silh_gamma=1e-1, silh_faces_per_pixel=50, device="cuda"):
+    """renderer_helper.py:26-103 -> (phong_renderer, silhouette_renderer, normal_renderer).  silh_gamma is inert in the
+    reference too (SoftSilhouetteShader ignores it: SURVEY.md Appendix C.7); the normal-visualisation renderer is eval/debug
+    only (out of scope) and returned as None."""
+    return PhongRenderer(image_size, light_posi), SilhouetteRenderer(image_size, silh_sigma, silh_faces_per_pixel), None
+
+
+def get_shadow_renderers(image_size, light_posi=((1.0, 1.0, -5.0),), silh_sigma=1e-7, silh_gamma=1e-1, silh_faces_per_pixel=50,
+                         amb_ratio=0.6, device="cuda"):
+    """renderer_helper.py:416-451"""
+    return MeshRendererShadow(image_size, light_posi, amb_ratio)
+
+
+def process_info_for_shadow(cam, light_positions, hand_verts_center, image_size, focal_length, device="cuda"):
+    """renderer_helper.py:454-468 (tiny (B,3) torch ops, differentiable)."""
+    cam = cam.to(device)
+    cam_T = torch.stack([-cam[:, 1], -cam[:, 2], 2 * focal_length / (image_size * cam[:, 0] + 1e-9)], dim=1)
+    at_light = light_positions.to(device)
+    B = cam.shape[0]
+    cam_R = torch.tensor([[-1., 0., 0.], [0., -1., 0.], [0., 0., 1.]], device=device).repeat(B, 1, 1)
+    radius = 1.5
+    d = at_light - hand_verts_center
+    pos = hand_verts_center + d * (radius / torch.linalg.norm(d, dim=1, keepdim=True))
+    light_R = look_at_rotation(pos, hand_verts_center, torch.tensor([[0.0, 1.0, 0.0]], device=device))
+    light_T = -torch.bmm(light_R.transpose(1, 2), pos[:, :, None])[:, :, 0]
+    return light_R, light_T, cam_R, cam_T

