@@ -133,20 +133,30 @@ __global__ void __launch_bounds__(256) bin_faces_kernel(const float4* __restrict
   if (lane == 0) bin_count[b * nst + st] = running;
 }
 
+__device__ __forceinline__ float rlane(float v, int srclane) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), srclane));
+}
+
+constexpr int kSub = 1024;   // ids per wave sub-list (4 sub-lists cover a 4096-entry super-tile list per round)
+
 // MODE 0: depth only (light view).  MODE 1: nearest face + silhouette product (camera view).
 // MODE 2: silhouette backward (rim pixels): scatter dL/d(ndc xy).
+//
+// Workgroup = 16x16 tile, wave = 16x4 strip, lane = pixel.  Two phases per round, ONE barrier between them:
+//   A  each wave streams a quarter of the super-tile's face list (ids + 16-B bboxes), keeps the faces whose dilated bbox
+//      touches the TILE and compacts their ids (ballot + popcount) into its own LDS sub-list;
+//   B  every wave walks all four sub-lists 64 faces at a time: lane i loads the 64-B record of face i into registers, the wave
+//      ballots the faces against its own strip, and each surviving face is broadcast from its owner lane with v_readlane
+//      (face data in SGPRs, pixel data in VGPRs).  No face data goes through LDS, no barrier inside the walk.
 template <int MODE>
-__global__ void __launch_bounds__(256) raster_kernel(const FaceRec* __restrict__ recs, const int32_t* __restrict__ bins,
-                                                     const int32_t* __restrict__ bin_count, int F, int S, int nsx,
-                                                     float blur, float sigma, int32_t* __restrict__ face_id,
+__global__ void __launch_bounds__(256) raster_kernel(const FaceRec* __restrict__ recs, const float4* __restrict__ bbs,
+                                                     const int32_t* __restrict__ bins, const int32_t* __restrict__ bin_count, int F,
+                                                     int S, int nsx, float blur, float sigma, int32_t* __restrict__ face_id,
                                                      float* __restrict__ zbuf, float* __restrict__ alpha,
                                                      const float* __restrict__ g_alpha, const int32_t* __restrict__ faces,
                                                      int V, float* __restrict__ g_ndc) {
-  __shared__ float4 s_a[kStage], s_b[kStage], s_bb[kStage];
-  __shared__ float s_z2[kStage];
-  __shared__ int32_t s_id[kStage];
-  __shared__ int lds_cnt[4];
-  __shared__ float s_g[MODE == 2 ? kStage : 1][6];   // MODE 2: per-staged-face gradient accumulators (x,y of 3 verts)
+  __shared__ int32_t s_ids[4][kSub];
+  __shared__ int s_cnt[4];
 
   const int b = blockIdx.z;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -159,6 +169,7 @@ __global__ void __launch_bounds__(256) raster_kernel(const FaceRec* __restrict__
   const int n = bin_count[b * nst + st];
   const int32_t* list = bins + ((size_t)b * nst + st) * F;
   const FaceRec* rb = recs + (size_t)b * F;
+  const float4* bbb = bbs + (size_t)b * F;
 
   // tile and wave-strip bounds in NDC (conservative supersets of the per-pixel bbox test)
   const float t_xhi = pix_to_ndc(tx0, S), t_xlo = pix_to_ndc(min(tx0 + kTile, S) - 1, S);
@@ -180,131 +191,164 @@ __global__ void __launch_bounds__(256) raster_kernel(const FaceRec* __restrict__
     // whole tile saturated / no upstream gradient -> nothing to do
     if (__syncthreads_or(need ? 1 : 0) == 0) return;
   }
+  const bool wave_need = __any(need);
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
 
-  for (int base = 0; base < n; base += kStage) {
-    // ---- stage: filter this round's list entries against the 16x16 tile, compact into LDS
-    const int e = base + threadIdx.x;
-    bool hit = false;
-    int id = 0;
-    float4 bb;
-    if (e < n) {
-      id = list[e];
-      bb = rb[id].bb;
-      hit = !(t_xlo > bb.y || t_xhi < bb.x || t_ylo > bb.w || t_yhi < bb.z);
-    }
-    int nl;
-    const int pos = block_compact(hit, 0, lds_cnt, nl);
-    if (pos >= 0) {
-      const FaceRec r = rb[id];
-      s_a[pos] = r.a; s_b[pos] = r.b; s_z2[pos] = r.c.x; s_bb[pos] = bb; s_id[pos] = id;
-    }
-    if (MODE == 2) {
+  for (int sbase = 0; sbase < n; sbase += 4 * kSub) {
+    const int nn = min(n - sbase, 4 * kSub);
+    // ---- phase A: this wave's quarter of the list -> s_ids[w]
+    const int q = (((nn + 3) >> 2) + 63) & ~63;
+    const int e_end = min((w + 1) * q, nn);
+    int cnt = 0;
+    for (int e0 = w * q; e0 < e_end; e0 += 256) {
+      // 4 independent (id -> bbox) gathers in flight per lane before the first ballot
+      int id[4];
+      bool hit[4];
+      float4 bb[4];
 #pragma unroll
-      for (int c = 0; c < 6; ++c) s_g[threadIdx.x][c] = 0.f;
-    }
-    __syncthreads();
-    // ---- walk: each wave ballots the staged faces against its 16x4 strip
-    for (int g = 0; g < nl; g += 64) {
-      const int i = g + lane;
-      bool whit = false;
-      if (i < nl) {
-        const float4 q = s_bb[i];
-        whit = !(t_xlo > q.y || t_xhi < q.x || w_ylo > q.w || w_yhi < q.z);
+      for (int u = 0; u < 4; ++u) {
+        const int e = e0 + 64 * u + lane;
+        id[u] = (e < e_end) ? list[sbase + e] : -1;
       }
-      unsigned long long m = __ballot(whit);
-      while (m) {
-        const int j = g + __ffsll((unsigned long long)m) - 1;
-        m &= m - 1;
-        const float4 q = s_bb[j];
-        const bool inbox = !(px > q.y || px < q.x || py > q.w || py < q.z);
-        if (!__any(inbox && need)) continue;
-        const float4 fa = s_a[j], fb = s_b[j];
-        const Tri t = tri_from(fa, fb, make_float4(s_z2[j], 0.f, 0.f, 0.f));
-        // ---- cheap classification first (no divisions): un-normalised edge functions and their signs.
-        // inside  <=>  all perspective-corrected barycentrics > 0  <=>  e_i * sign(area') > 0 for all i   (z > 0 by culling)
-        const float e0 = edge_fn(px, py, t.x1, t.y1, t.x2, t.y2);
-        const float e1 = edge_fn(px, py, t.x2, t.y2, t.x0, t.y0);
-        const float e2 = edge_fn(px, py, t.x0, t.y0, t.x1, t.y1);
-        const float area = edge_fn(t.x2, t.y2, t.x0, t.y0, t.x1, t.y1) + kEps;
-        const float sg = (area > 0.f) ? 1.f : ((area < 0.f) ? -1.f : 0.f);
-        const float e0s = e0 * sg, e1s = e1 * sg, e2s = e2 * sg;
-        const bool inside = (e0s > 0.f) && (e1s > 0.f) && (e2s > 0.f);
-        const bool hard_hit = (MODE != 2) && inside && inbox && in_img;
-        bool soft = false;
-        if (MODE >= 1) {
-          soft = (MODE == 1) ? (inbox && in_img && prod != 0.f) : (inbox && need);
-          if (soft) {
-            // squared edge lengths: e0 <-> (v1,v2), e1 <-> (v2,v0), e2 <-> (v0,v1)
-            const float l12 = (t.x2 - t.x1) * (t.x2 - t.x1) + (t.y2 - t.y1) * (t.y2 - t.y1);
-            const float l20 = (t.x0 - t.x2) * (t.x0 - t.x2) + (t.y0 - t.y2) * (t.y0 - t.y2);
-            const float l01 = (t.x1 - t.x0) * (t.x1 - t.x0) + (t.y1 - t.y0) * (t.y1 - t.y0);
-            if (inside) {
-              // deeper than sqrt(18 sigma) inside every edge LINE (<= segment distance): sigmoid saturates to exactly 1 in
-              // fp32 (exp(-18) < 2^-24), so the factor (1-p) is exactly 0 — same result as the exact path, no div/exp.
-              const float K = 18.0f * sigma;
-              if (e0 * e0 > K * l12 && e1 * e1 > K * l20 && e2 * e2 > K * l01) {
-                if (MODE == 1) prod = 0.f;
-                soft = false;
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (id[u] >= 0) bb[u] = bbb[id[u]];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        hit[u] = (id[u] >= 0) && !(t_xlo > bb[u].y || t_xhi < bb[u].x || t_ylo > bb[u].w || t_yhi < bb[u].z);
+        const unsigned long long m = __ballot(hit[u]);
+        if (hit[u]) s_ids[w][cnt + __popcll(m & lt_mask)] = id[u];
+        cnt += __popcll(m);
+      }
+    }
+    if (lane == 0) s_cnt[w] = cnt;
+    __syncthreads();
+    // ---- phase B: walk the four sub-lists
+    if (wave_need) {
+      {
+        // the four sub-lists are walked as one concatenated list so that every 64-face batch is full
+        const int c0 = s_cnt[0], c1 = s_cnt[1], c2 = s_cnt[2], c3 = s_cnt[3];
+        const int o1 = c0, o2 = c0 + c1, o3 = o2 + c2, c = o3 + c3;
+        for (int g = 0; g < c; g += 64) {
+          const int i = g + lane;
+          int my_id = -1;
+          float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rbv = ra, rbb = ra;
+          float rz2 = 0.f;
+          bool whit = false;
+          if (i < c) {
+            my_id = (i < o1) ? s_ids[0][i] : (i < o2) ? s_ids[1][i - o1] : (i < o3) ? s_ids[2][i - o2] : s_ids[3][i - o3];
+            const FaceRec* r = rb + my_id;
+            rbb = r->bb;
+            whit = !(t_xlo > rbb.y || t_xhi < rbb.x || w_ylo > rbb.w || w_yhi < rbb.z);
+            if (whit) { ra = r->a; rbv = r->b; rz2 = r->c.x; }
+          }
+          unsigned long long m = __ballot(whit);
+          while (m) {
+            const int j = __ffsll((unsigned long long)m) - 1;
+            m &= m - 1;
+            const float qx0 = rlane(rbb.x, j), qx1 = rlane(rbb.y, j), qy0 = rlane(rbb.z, j), qy1 = rlane(rbb.w, j);
+            const bool inbox = !(px > qx1 || px < qx0 || py > qy1 || py < qy0);
+            if (!__any(inbox && need)) continue;
+            Tri t;
+            t.x0 = rlane(ra.x, j); t.y0 = rlane(ra.y, j); t.z0 = rlane(ra.z, j); t.x1 = rlane(ra.w, j);
+            t.y1 = rlane(rbv.x, j); t.z1 = rlane(rbv.y, j); t.x2 = rlane(rbv.z, j); t.y2 = rlane(rbv.w, j);
+            t.z2 = rlane(rz2, j);
+            const int fid = __builtin_amdgcn_readlane(my_id, j);
+            // ---- cheap classification first (no divisions): un-normalised edge functions and their signs.
+            // inside  <=>  all perspective-corrected barycentrics > 0  <=>  e_i * sign(area') > 0 for all i   (z > 0 by culling)
+            const float e0 = edge_fn(px, py, t.x1, t.y1, t.x2, t.y2);
+            const float e1 = edge_fn(px, py, t.x2, t.y2, t.x0, t.y0);
+            const float e2 = edge_fn(px, py, t.x0, t.y0, t.x1, t.y1);
+            const float area = edge_fn(t.x2, t.y2, t.x0, t.y0, t.x1, t.y1) + kEps;
+            const float sg = (area > 0.f) ? 1.f : ((area < 0.f) ? -1.f : 0.f);
+            const float e0s = e0 * sg, e1s = e1 * sg, e2s = e2 * sg;
+            const bool inside = (e0s > 0.f) && (e1s > 0.f) && (e2s > 0.f);
+            const bool hard_hit = (MODE != 2) && inside && inbox && in_img;
+            bool soft = false;
+            if (MODE >= 1) {
+              soft = (MODE == 1) ? (inbox && in_img && prod != 0.f) : (inbox && need);
+              if (soft) {
+                // squared edge lengths: e0 <-> (v1,v2), e1 <-> (v2,v0), e2 <-> (v0,v1)
+                const float l12 = (t.x2 - t.x1) * (t.x2 - t.x1) + (t.y2 - t.y1) * (t.y2 - t.y1);
+                const float l20 = (t.x0 - t.x2) * (t.x0 - t.x2) + (t.y0 - t.y2) * (t.y0 - t.y2);
+                const float l01 = (t.x1 - t.x0) * (t.x1 - t.x0) + (t.y1 - t.y0) * (t.y1 - t.y0);
+                if (inside) {
+                  // deeper than sqrt(18 sigma) inside every edge LINE (<= segment distance): sigmoid saturates to exactly 1
+                  // in fp32 (exp(-18) < 2^-24), so the factor (1-p) is exactly 0 — same result as the exact path, no div/exp.
+                  const float K = 18.0f * sigma;
+                  if (e0 * e0 > K * l12 && e1 * e1 > K * l20 && e2 * e2 > K * l01) {
+                    if (MODE == 1) prod = 0.f;
+                    soft = false;
+                  }
+                } else {
+                  // outside: the triangle lies beyond the line of any violated edge, so dist >= that line distance
+                  const float Bf = blur * 1.00001f;
+                  if ((e0s < 0.f && e0 * e0 >= Bf * l12) || (e1s < 0.f && e1 * e1 >= Bf * l20) || (e2s < 0.f && e2 * e2 >= Bf * l01)) soft = false;
+                }
               }
-            } else {
-              // outside: the triangle lies beyond the line of any violated edge, so dist >= that line distance
-              const float Bf = blur * 1.00001f;
-              if ((e0s < 0.f && e0 * e0 >= Bf * l12) || (e1s < 0.f && e1 * e1 >= Bf * l20) || (e2s < 0.f && e2 * e2 >= Bf * l01)) soft = false;
             }
-          }
-        }
-        if (!__any(hard_hit || soft)) continue;
-        if (hard_hit) {
-          // BarycentricCoordsForward + PerspectiveCorrection with reciprocals (<= 2 ulp from the IEEE-division form)
-          const float ra = __builtin_amdgcn_rcpf(area);
-          const float t0 = (e0 * ra) * t.z1 * t.z2, t1 = t.z0 * (e1 * ra) * t.z2, t2 = t.z0 * t.z1 * (e2 * ra);
-          const float rd = __builtin_amdgcn_rcpf(fmaxf(t0 + t1 + t2, kEps));
-          const float pz = (t0 * rd) * t.z0 + (t1 * rd) * t.z1 + (t2 * rd) * t.z2;
-          if (pz >= 0.f && pz < best_z) { best_z = pz; best_f = s_id[j]; }
-        }
-        if (MODE >= 1 && soft) {
-          float ta, tb, tc;
-          const float d01 = seg_dist2(px, py, t.x0, t.y0, t.x1, t.y1, ta);
-          const float d02 = seg_dist2(px, py, t.x0, t.y0, t.x2, t.y2, tb);
-          const float d12 = seg_dist2(px, py, t.x1, t.y1, t.x2, t.y2, tc);
-          const float dist = fminf(d01, fminf(d02, d12));
-          if (inside || dist < blur) {
-            const float sd = inside ? -dist : dist;
-            const float p = 1.0f / (1.0f + expf(sd / sigma));   // sigmoid(-sd/sigma)
-            if (MODE == 1) {
-              prod *= (1.0f - p);
-            } else {
-              // d alpha / d sd = -P * p / sigma  (P = prod over all faces)
-              const float g_sd = ga * (-P * p / sigma);
-              const float gd = inside ? -g_sd : g_sd;     // d/d(dist^2)
-              // PointLineDistanceBackward on the argmin edge (t treated as constant)
-              int ia, ib; float ax, ay, bx, by, tt;
-              if (d01 <= d02 && d01 <= d12) { ia = 0; ib = 1; ax = t.x0; ay = t.y0; bx = t.x1; by = t.y1; tt = ta; }
-              else if (d02 <= d12)          { ia = 0; ib = 2; ax = t.x0; ay = t.y0; bx = t.x2; by = t.y2; tt = tb; }
-              else                          { ia = 1; ib = 2; ax = t.x1; ay = t.y1; bx = t.x2; by = t.y2; tt = tc; }
-              const float qx = ax + tt * (bx - ax), qy = ay + tt * (by - ay);
-              const float cx = gd * 2.f * (qx - px), cy = gd * 2.f * (qy - py);
-              atomicAdd(&s_g[j][2 * ia], (1.f - tt) * cx);
-              atomicAdd(&s_g[j][2 * ia + 1], (1.f - tt) * cy);
-              atomicAdd(&s_g[j][2 * ib], tt * cx);
-              atomicAdd(&s_g[j][2 * ib + 1], tt * cy);
+            if (!__any(hard_hit || soft)) continue;
+            if (hard_hit) {
+              // BarycentricCoordsForward + PerspectiveCorrection with reciprocals (<= 2 ulp from the IEEE-division form)
+              const float rcp_a = __builtin_amdgcn_rcpf(area);
+              const float t0 = (e0 * rcp_a) * t.z1 * t.z2, t1 = t.z0 * (e1 * rcp_a) * t.z2, t2 = t.z0 * t.z1 * (e2 * rcp_a);
+              const float rd = __builtin_amdgcn_rcpf(fmaxf(t0 + t1 + t2, kEps));
+              const float pz = (t0 * rd) * t.z0 + (t1 * rd) * t.z1 + (t2 * rd) * t.z2;
+              // ties keep the lower face id (PyTorch3D visits faces in ascending order and replaces only if strictly nearer)
+              if (pz >= 0.f && (pz < best_z || (pz == best_z && fid < best_f))) { best_z = pz; best_f = fid; }
             }
-          }
-        }
-      }
-    }
-    __syncthreads();
-    if (MODE == 2 && (int)threadIdx.x < nl) {
-      // flush: one global atomic per (staged face, vertex, component) per workgroup
-      const int fid = s_id[threadIdx.x];
-      float* gb = g_ndc + (size_t)b * V * 3;
+            if (MODE >= 1) {
+              float g6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+              bool contributed = false;
+              if (soft) {
+                float ta, tb, tc;
+                const float d01 = seg_dist2(px, py, t.x0, t.y0, t.x1, t.y1, ta);
+                const float d02 = seg_dist2(px, py, t.x0, t.y0, t.x2, t.y2, tb);
+                const float d12 = seg_dist2(px, py, t.x1, t.y1, t.x2, t.y2, tc);
+                const float dist = fminf(d01, fminf(d02, d12));
+                if (inside || dist < blur) {
+                  const float sd = inside ? -dist : dist;
+                  const float p = 1.0f / (1.0f + expf(sd / sigma));   // sigmoid(-sd/sigma)
+                  if (MODE == 1) {
+                    prod *= (1.0f - p);
+                  } else {
+                    // d alpha / d sd = -P * p / sigma  (P = prod over all faces)
+                    const float g_sd = ga * (-P * p / sigma);
+                    const float gd = inside ? -g_sd : g_sd;     // d/d(dist^2)
+                    // PointLineDistanceBackward on the argmin edge (t treated as constant)
+                    int ia, ib; float ax, ay, bx, by, tt;
+                    if (d01 <= d02 && d01 <= d12) { ia = 0; ib = 1; ax = t.x0; ay = t.y0; bx = t.x1; by = t.y1; tt = ta; }
+                    else if (d02 <= d12)          { ia = 0; ib = 2; ax = t.x0; ay = t.y0; bx = t.x2; by = t.y2; tt = tb; }
+                    else                          { ia = 1; ib = 2; ax = t.x1; ay = t.y1; bx = t.x2; by = t.y2; tt = tc; }
+                    const float qx = ax + tt * (bx - ax), qy = ay + tt * (by - ay);
+                    const float cx = gd * 2.f * (qx - px), cy = gd * 2.f * (qy - py);
 #pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        const float gx = s_g[threadIdx.x][2 * k], gy = s_g[threadIdx.x][2 * k + 1];
-        if (gx != 0.f || gy != 0.f) {
-          const int v = faces[3 * fid + k];
-          atomicAdd(gb + 3 * v, gx);
-          atomicAdd(gb + 3 * v + 1, gy);
+                    for (int k = 0; k < 3; ++k) {
+                      const float wk = (k == ia) ? (1.f - tt) : ((k == ib) ? tt : 0.f);
+                      g6[2 * k] = wk * cx; g6[2 * k + 1] = wk * cy;
+                    }
+                    contributed = true;
+                  }
+                }
+              }
+              if (MODE == 2 && __any(contributed)) {
+                // wave-level sum of this face's 6 gradient components, then ONE lane issues the global atomics
+#pragma unroll
+                for (int k = 0; k < 6; ++k) g6[k] = wave_sum(g6[k]);
+                if (lane == 0) {
+                  float* gb = g_ndc + (size_t)b * V * 3;
+#pragma unroll
+                  for (int k = 0; k < 3; ++k) {
+                    if (g6[2 * k] != 0.f || g6[2 * k + 1] != 0.f) {
+                      const int v = faces[3 * fid + k];
+                      atomicAdd(gb + 3 * v, g6[2 * k]);
+                      atomicAdd(gb + 3 * v + 1, g6[2 * k + 1]);
+                    }
+                  }
+                }
+              }
+            }
+          }
         }
       }
     }
@@ -360,10 +404,10 @@ int harp_rasterize_fwd(const float* ndc, const int32_t* faces, int B, int V, int
   hipLaunchKernelGGL(bin_faces_kernel, dim3((nsx * nsx + 3) / 4, B), dim3(256), 0, stream, bbs, F, S, nsx, bins, cnt);
   const dim3 grid((S + kTile - 1) / kTile, (S + kTile - 1) / kTile, B);
   if (soft)
-    hipLaunchKernelGGL(raster_kernel<1>, grid, dim3(256), 0, stream, recs, bins, cnt, F, S, nsx, blur_radius, sigma,
+    hipLaunchKernelGGL(raster_kernel<1>, grid, dim3(256), 0, stream, recs, bbs, bins, cnt, F, S, nsx, blur_radius, sigma,
                        face_id, zbuf, alpha, nullptr, nullptr, 0, nullptr);
   else
-    hipLaunchKernelGGL(raster_kernel<0>, grid, dim3(256), 0, stream, recs, bins, cnt, F, S, nsx, 0.f, 1.f, face_id, zbuf,
+    hipLaunchKernelGGL(raster_kernel<0>, grid, dim3(256), 0, stream, recs, bbs, bins, cnt, F, S, nsx, 0.f, 1.f, face_id, zbuf,
                        nullptr, nullptr, nullptr, 0, nullptr);
   HARP_CHECK_LAUNCH();
   return HARP_OK;
@@ -374,11 +418,11 @@ int harp_rasterize_fwd(const float* ndc, const int32_t* faces, int B, int V, int
 int harp_silhouette_bwd(const int32_t* faces, int B, int V, int F, int S, float blur_radius, float sigma, const void* ws,
                         const float* alpha, const float* g_alpha, float* g_ndc, hipStream_t stream) {
   if (!faces || !ws || !alpha || !g_alpha || !g_ndc) return HARP_ERR_ARG;
-  FaceRec* recs; int32_t *bins, *cnt;
-  ws_split((void*)ws, B, F, S, &recs, &bins, &cnt);
+  FaceRec* recs; int32_t *bins, *cnt; float4* bbs;
+  ws_split((void*)ws, B, F, S, &recs, &bins, &cnt, &bbs);
   const int nsx = (S + kSuper - 1) / kSuper;
   const dim3 grid((S + kTile - 1) / kTile, (S + kTile - 1) / kTile, B);
-  hipLaunchKernelGGL(raster_kernel<2>, grid, dim3(256), 0, stream, recs, bins, cnt, F, S, nsx, blur_radius, sigma, nullptr,
+  hipLaunchKernelGGL(raster_kernel<2>, grid, dim3(256), 0, stream, recs, bbs, bins, cnt, F, S, nsx, blur_radius, sigma, nullptr,
                      nullptr, (float*)alpha, g_alpha, faces, V, g_ndc);
   HARP_CHECK_LAUNCH();
   return HARP_OK;
