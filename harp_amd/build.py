@@ -12,7 +12,7 @@ import sys
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libharp_hip.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-munsafe-fp-atomics",
-         "-Wno-unused-result", "-DNDEBUG"]
+         "-Wno-unused-result", "-DNDEBUG"] + os.environ.get("HARP_EXTRA_FLAGS", "").split()
 
 
 def sources():
