@@ -17,9 +17,6 @@
 #include "harp_common.h"
 #include "harp_hip.h"
 
-#ifndef RASTER_EXP
-#define RASTER_EXP 0
-#endif
 namespace {
 
 constexpr int kStage = 256;   // faces staged in LDS per round (17 KB)
@@ -136,313 +133,189 @@ __global__ void __launch_bounds__(256) bin_faces_kernel(const float4* __restrict
   if (lane == 0) bin_count[b * nst + st] = running;
 }
 
-// Exact evaluation of one (pixel, face) pair on the soft-silhouette rim (PointTriangleDistanceForward + sigmoid):
-// MODE 1 accumulates log2(1-p) in Q20 fixed point (or sets the saturation flag), MODE 2 the gradient of the signed distance.
-template <int MODE>
-__device__ __forceinline__ void raster_exact(const Tri& t, float px, float py, int pl, int slot, float blur, float sigma, int* s_logp,
-                                             unsigned char* s_deep, const float* s_coef, float (*s_g)[6]) {
-  const float area = edge_fn(t.x2, t.y2, t.x0, t.y0, t.x1, t.y1) + kEps;
-  const float sg = (area > 0.f) ? 1.f : ((area < 0.f) ? -1.f : 0.f);
-  const bool inside = (edge_fn(px, py, t.x1, t.y1, t.x2, t.y2) * sg > 0.f) && (edge_fn(px, py, t.x2, t.y2, t.x0, t.y0) * sg > 0.f) &&
-                      (edge_fn(px, py, t.x0, t.y0, t.x1, t.y1) * sg > 0.f);
-  float ta, tb, tc;
-  const float d01 = seg_dist2(px, py, t.x0, t.y0, t.x1, t.y1, ta);
-  const float d02 = seg_dist2(px, py, t.x0, t.y0, t.x2, t.y2, tb);
-  const float d12 = seg_dist2(px, py, t.x1, t.y1, t.x2, t.y2, tc);
-  const float dist = fminf(d01, fminf(d02, d12));
-  if (!(inside || dist < blur)) return;
-  const float sd = inside ? -dist : dist;
-  const float p = 1.0f / (1.0f + expf(sd / sigma));   // sigmoid(-sd/sigma)
-  if (MODE == 1) {
-    const float q = 1.0f - p;
-    if (q == 0.f) s_deep[pl] = 1;
-    else atomicAdd(&s_logp[pl], (int)rintf(log2f(q) * 1048576.0f));
-  } else {
-    // d alpha / d sd = -P p / sigma; s_coef = ga * (-P / sigma)
-    const float g_sd = s_coef[pl] * p;
-    const float gd = inside ? -g_sd : g_sd;     // d/d(dist^2)
-    // PointLineDistanceBackward on the argmin edge (t treated as constant)
-    int ia, ib; float ax, ay, bx, by, tt;
-    if (d01 <= d02 && d01 <= d12) { ia = 0; ib = 1; ax = t.x0; ay = t.y0; bx = t.x1; by = t.y1; tt = ta; }
-    else if (d02 <= d12)          { ia = 0; ib = 2; ax = t.x0; ay = t.y0; bx = t.x2; by = t.y2; tt = tb; }
-    else                          { ia = 1; ib = 2; ax = t.x1; ay = t.y1; bx = t.x2; by = t.y2; tt = tc; }
-    const float qx = ax + tt * (bx - ax), qy = ay + tt * (by - ay);
-    const float cx = gd * 2.f * (qx - px), cy = gd * 2.f * (qy - py);
-    atomicAdd(&s_g[slot][2 * ia], (1.f - tt) * cx);
-    atomicAdd(&s_g[slot][2 * ia + 1], (1.f - tt) * cy);
-    atomicAdd(&s_g[slot][2 * ib], tt * cx);
-    atomicAdd(&s_g[slot][2 * ib + 1], tt * cy);
-  }
-}
-
-constexpr int kQCap = 4096;          // exact-path candidate queue (entries) per round
-constexpr int kPix = kSuper * kSuper;  // 4096 pixels of the LDS-resident screen tile
-constexpr int kBigArea = 128;          // faces whose clipped bbox exceeds this many pixels are rasterised by a whole wave
-constexpr int kBigCap = 64;            // per round; further large faces fall back to their owner lane
-
-__device__ __forceinline__ Tri tri_of(const FaceRec& r) {
-  Tri t;
-  t.x0 = r.a.x; t.y0 = r.a.y; t.z0 = r.a.z; t.x1 = r.a.w;
-  t.y1 = r.b.x; t.z1 = r.b.y; t.x2 = r.b.z; t.y2 = r.b.w;
-  t.z2 = r.c.x;
-  return t;
-}
-
-// per-face constants of the division-free classification
-struct FaceCtx {
-  Tri t;
-  float4 bb;
-  float sg, rcp_a, K12, K20, K01, B12, B20, B01;
-  int id, slot;
-};
-
-__device__ __forceinline__ FaceCtx face_ctx(const FaceRec& r, int id, int slot, float blur, float sigma) {
-  FaceCtx c;
-  c.t = tri_of(r);
-  c.bb = r.bb;
-  c.id = id; c.slot = slot;
-  const Tri& t = c.t;
-  const float area = edge_fn(t.x2, t.y2, t.x0, t.y0, t.x1, t.y1) + kEps;
-  c.sg = (area > 0.f) ? 1.f : ((area < 0.f) ? -1.f : 0.f);
-  c.rcp_a = __builtin_amdgcn_rcpf(area);
-  // squared edge lengths: e0 <-> (v1,v2), e1 <-> (v2,v0), e2 <-> (v0,v1)
-  const float l12 = (t.x2 - t.x1) * (t.x2 - t.x1) + (t.y2 - t.y1) * (t.y2 - t.y1);
-  const float l20 = (t.x0 - t.x2) * (t.x0 - t.x2) + (t.y0 - t.y2) * (t.y0 - t.y2);
-  const float l01 = (t.x1 - t.x0) * (t.x1 - t.x0) + (t.y1 - t.y0) * (t.y1 - t.y0);
-  c.K12 = 18.0f * sigma * l12; c.K20 = 18.0f * sigma * l20; c.K01 = 18.0f * sigma * l01;
-  const float Bf = blur * 1.00001f;
-  c.B12 = Bf * l12; c.B20 = Bf * l20; c.B01 = Bf * l01;
-  return c;
-}
-
-// One (pixel, face) visit of the cheap pass. px,py = pixel centre (NDC), pl = pixel index inside the LDS tile.
-template <int MODE>
-__device__ __forceinline__ void visit_pixel(const FaceCtx& c, float px, float py, int pl, float blur, float sigma,
-                                            unsigned long long* s_zb, int* s_logp, unsigned char* s_deep, const float* s_coef,
-                                            float (*s_g)[6], uint32_t* s_q, int* s_qn) {
-  const Tri& t = c.t;
-  // inside  <=>  all perspective-corrected barycentrics > 0  <=>  e_i * sign(area') > 0 for all i   (z > 0 by culling)
-  const float e0 = edge_fn(px, py, t.x1, t.y1, t.x2, t.y2);
-  const float e1 = edge_fn(px, py, t.x2, t.y2, t.x0, t.y0);
-  const float e2 = edge_fn(px, py, t.x0, t.y0, t.x1, t.y1);
-  const float e0s = e0 * c.sg, e1s = e1 * c.sg, e2s = e2 * c.sg;
-  const bool inside = (e0s > 0.f) && (e1s > 0.f) && (e2s > 0.f);
-  if (MODE != 2 && inside) {
-    // BarycentricCoordsForward + PerspectiveCorrection with reciprocals (<= 2 ulp from the IEEE-division form)
-    const float t0 = (e0 * c.rcp_a) * t.z1 * t.z2, t1 = t.z0 * (e1 * c.rcp_a) * t.z2, t2 = t.z0 * t.z1 * (e2 * c.rcp_a);
-    const float rd = __builtin_amdgcn_rcpf(fmaxf(t0 + t1 + t2, kEps));
-    const float pz = (t0 * rd) * t.z0 + (t1 * rd) * t.z1 + (t2 * rd) * t.z2;
-#if RASTER_EXP == 1
-    if (pz >= 0.f && pz < 0.0001f) atomicMin(&s_zb[pl], ((unsigned long long)__float_as_uint(pz) << 32) | (unsigned)c.id);
-#else
-    if (pz >= 0.f) atomicMin(&s_zb[pl], ((unsigned long long)__float_as_uint(pz) << 32) | (unsigned)c.id);
-#endif
-  }
-  if (MODE >= 1) {
-    bool soft = (MODE == 1) ? (s_deep[pl] == 0) : (s_coef[pl] != 0.f);
-    if (soft) {
-      if (inside) {
-        // deeper than sqrt(18 sigma) inside every edge LINE (<= segment distance): sigmoid saturates to exactly 1 in fp32
-        // (exp(-18) < 2^-24), the factor (1-p) is exactly 0 -> alpha = 1, no gradient.
-        if (e0 * e0 > c.K12 && e1 * e1 > c.K20 && e2 * e2 > c.K01) {
-          if (MODE == 1) s_deep[pl] = 1;
-          soft = false;
-        }
-      } else {
-        // outside: the triangle lies beyond the line of any violated edge, so dist >= that line distance >= blur
-        if ((e0s < 0.f && e0 * e0 >= c.B12) || (e1s < 0.f && e1 * e1 >= c.B20) || (e2s < 0.f && e2 * e2 >= c.B01)) soft = false;
-      }
-      if (soft) {
-        const int pos = atomicAdd(s_qn, 1);
-        const uint32_t ent = ((uint32_t)pl << 20) | (uint32_t)((MODE == 1) ? c.id : c.slot);
-        if (pos < kQCap) s_q[pos] = ent;
-        else raster_exact<MODE>(t, px, py, pl, c.slot, blur, sigma, s_logp, s_deep, s_coef, s_g);   // queue full: in place
-      }
-    }
-  }
-}
-
-// MODE 0: depth only (light view).  MODE 1: nearest face + soft-silhouette alpha (camera view).
-// MODE 2: silhouette backward: dL/dalpha -> dL/d(ndc xy) of the face vertices.
-//
-// One workgroup owns one 64x64 SCREEN TILE of one frame and keeps it in LDS for the whole kernel:
-//   zb[4096]   u64  (z bits << 32 | face id): K=1 z-buffer resolved with ds_min_u64 — ties go to the lower face id, exactly
-//                   PyTorch3D's visiting order, and the result does not depend on scheduling;
-//   logp[4096] i32  sum of round(2^20 log2(1-p_f)): the silhouette product in a fixed-point log domain — integer adds
-//                   commute, so alpha is bit-reproducible run to run although faces are processed concurrently;
-//   deep[4096] u8   "some face saturates this pixel" (1-p == 0 exactly in fp32)  =>  alpha = 1 exactly.
-// Each round takes 256 faces of the tile's list:
-//   1a  FACE-PARALLEL: one lane = one small face, walking the pixels of its own clipped bbox (small triangles — 8x8-px boxes
-//       here — keep ~40 % of the lanes useful instead of ~10 % for a pixel-parallel walk); faces with a large bbox are deferred;
-//   1b  the deferred large faces are rasterised by the whole workgroup, one pixel per lane (no lane waits for a sliver);
-//   2   the (pixel, face) pairs on the 0.3-px rim that need segment distances + exp were appended to an LDS queue by 1a/1b and
-//       are evaluated here fully lane-packed.
-// 1a/1b only do the division-free classification (edge-function signs, exact-saturation and far-outside bounds).
+// MODE 0: depth only (light view).  MODE 1: nearest face + silhouette product (camera view).
+// MODE 2: silhouette backward (rim pixels): scatter dL/d(ndc xy).
 template <int MODE>
 __global__ void __launch_bounds__(256) raster_kernel(const FaceRec* __restrict__ recs, const int32_t* __restrict__ bins,
-                                                     const int32_t* __restrict__ bin_count, int F, int S, int nsx, float blur,
-                                                     float sigma, int32_t* __restrict__ face_id, float* __restrict__ zbuf,
-                                                     float* __restrict__ alpha, const float* __restrict__ g_alpha,
-                                                     const int32_t* __restrict__ faces, int V, float* __restrict__ g_ndc) {
-  __shared__ unsigned long long s_zb[MODE == 2 ? 1 : kPix];
-  __shared__ int s_logp[MODE == 1 ? kPix : 1];
-  __shared__ unsigned char s_deep[MODE == 1 ? kPix : 1];
-  __shared__ float s_coef[MODE == 2 ? kPix : 1];        // MODE 2: ga * (-P / sigma) per pixel (0 = pixel needs nothing)
-  __shared__ float s_g[MODE == 2 ? 256 : 1][6];         // MODE 2: per-face gradient accumulators of the current round
-  __shared__ uint32_t s_q[MODE == 0 ? 1 : kQCap];
-  __shared__ int s_qn, s_nbig;
-  __shared__ FaceRec s_bigrec[kBigCap];                  // records of this round's deferred large faces
-  __shared__ int s_bigid[kBigCap], s_bigslot[kBigCap];
-  __shared__ float s_px[kSuper], s_py[kSuper];          // exact pixel-centre NDC of the tile's columns / rows (one division each)
+                                                     const int32_t* __restrict__ bin_count, int F, int S, int nsx,
+                                                     float blur, float sigma, int32_t* __restrict__ face_id,
+                                                     float* __restrict__ zbuf, float* __restrict__ alpha,
+                                                     const float* __restrict__ g_alpha, const int32_t* __restrict__ faces,
+                                                     int V, float* __restrict__ g_ndc) {
+  __shared__ float4 s_a[kStage], s_b[kStage], s_bb[kStage];
+  __shared__ float s_z2[kStage];
+  __shared__ int32_t s_id[kStage];
+  __shared__ int lds_cnt[4];
+  __shared__ float s_g[MODE == 2 ? kStage : 1][6];   // MODE 2: per-staged-face gradient accumulators (x,y of 3 verts)
 
-  const int st = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const int b = blockIdx.z;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int tx0 = blockIdx.x * kTile, ty0 = blockIdx.y * kTile;
+  const int xi = tx0 + (lane & 15), yi = ty0 + w * 4 + (lane >> 4);
+  const bool in_img = (xi < S) && (yi < S);
+  const float px = pix_to_ndc(xi, S), py = pix_to_ndc(yi, S);
+  const int st = (ty0 / kSuper) * nsx + (tx0 / kSuper);
   const int nst = nsx * nsx;
   const int n = bin_count[b * nst + st];
-  const int sx0 = (st % nsx) * kSuper, sy0 = (st / nsx) * kSuper;
-  const int sx1 = min(sx0 + kSuper, S) - 1, sy1 = min(sy0 + kSuper, S) - 1;
   const int32_t* list = bins + ((size_t)b * nst + st) * F;
   const FaceRec* rb = recs + (size_t)b * F;
-  const float fS = (float)S;
-  if (MODE != 2 && n == 0) {
-    // empty tile: nothing to resolve
-    for (int k = tid; k < kPix; k += 256) {
-      const int xi = sx0 + (k & 63), yi = sy0 + (k >> 6);
-      if (xi >= S || yi >= S) continue;
-      const size_t o = ((size_t)b * S + yi) * S + xi;
-      face_id[o] = -1;
-      if (zbuf) zbuf[o] = -1.0f;
-      if (MODE == 1) alpha[o] = 0.0f;
-    }
-    return;
-  }
 
-  // ---- init the LDS tile
-  bool any_need = false;
-  for (int k = tid; k < kPix; k += 256) {
-    if (MODE != 2) s_zb[k] = ~0ull;
-    if (MODE == 1) { s_logp[k] = 0; s_deep[k] = 0; }
-    if (MODE == 2) {
-      const int xi = sx0 + (k & 63), yi = sy0 + (k >> 6);
-      float c = 0.f;
-      if (xi < S && yi < S) {
-        const size_t o = ((size_t)b * S + yi) * S + xi;
-        const float P = 1.0f - alpha[o], ga = g_alpha[o];
-        if (P != 0.f && ga != 0.f) c = ga * (-P / sigma);
-      }
-      s_coef[k] = c;
-      any_need |= (c != 0.f);
-    }
-  }
-  if (tid == 0) { s_qn = 0; s_nbig = 0; }
-  if (tid < kSuper) { s_px[tid] = pix_to_ndc(sx0 + tid, S); s_py[tid] = pix_to_ndc(sy0 + tid, S); }
+  // tile and wave-strip bounds in NDC (conservative supersets of the per-pixel bbox test)
+  const float t_xhi = pix_to_ndc(tx0, S), t_xlo = pix_to_ndc(min(tx0 + kTile, S) - 1, S);
+  const float t_yhi = pix_to_ndc(ty0, S), t_ylo = pix_to_ndc(min(ty0 + kTile, S) - 1, S);
+  const float w_yhi = pix_to_ndc(ty0 + w * 4, S), w_ylo = pix_to_ndc(ty0 + w * 4 + 3, S);
+
+  float best_z = 3.0e38f;
+  int best_f = -1;
+  float prod = 1.0f;
+  float P = 0.f, ga = 0.f;
+  bool need = in_img;
   if (MODE == 2) {
-    if (__syncthreads_or(any_need ? 1 : 0) == 0) return;
-  } else {
-    __syncthreads();
+    if (in_img) {
+      const size_t o = ((size_t)b * S + yi) * S + xi;
+      P = 1.0f - alpha[o];
+      ga = g_alpha[o];
+    }
+    need = in_img && (P != 0.f) && (ga != 0.f);
+    // whole tile saturated / no upstream gradient -> nothing to do
+    if (__syncthreads_or(need ? 1 : 0) == 0) return;
   }
 
-  for (int base = 0; base < n; base += 256) {
-    // ================= phase 1a: one lane = one (small) face
-    const int e = base + tid;
+  for (int base = 0; base < n; base += kStage) {
+    // ---- stage: filter this round's list entries against the 16x16 tile, compact into LDS
+    const int e = base + threadIdx.x;
+    bool hit = false;
+    int id = 0;
+    float4 bb;
+    if (e < n) {
+      id = list[e];
+      bb = rb[id].bb;
+      hit = !(t_xlo > bb.y || t_xhi < bb.x || t_ylo > bb.w || t_yhi < bb.z);
+    }
+    int nl;
+    const int pos = block_compact(hit, 0, lds_cnt, nl);
+    if (pos >= 0) {
+      const FaceRec r = rb[id];
+      s_a[pos] = r.a; s_b[pos] = r.b; s_z2[pos] = r.c.x; s_bb[pos] = bb; s_id[pos] = id;
+    }
     if (MODE == 2) {
 #pragma unroll
-      for (int c = 0; c < 6; ++c) s_g[tid][c] = 0.f;
+      for (int c = 0; c < 6; ++c) s_g[threadIdx.x][c] = 0.f;
     }
-    if (e < n) {
-      const int id = list[e];
-      const FaceRec r = rb[id];
-      // pixel range of the dilated bbox (conservative by one pixel; the exact NDC test follows per pixel)
-      const int x_lo = max(sx0, (int)floorf((fS * (1.0f - r.bb.y) - 1.0f) * 0.5f));
-      const int x_hi = min(sx1, (int)ceilf((fS * (1.0f - r.bb.x) - 1.0f) * 0.5f));
-      const int y_lo = max(sy0, (int)floorf((fS * (1.0f - r.bb.w) - 1.0f) * 0.5f));
-      const int y_hi = min(sy1, (int)ceilf((fS * (1.0f - r.bb.z) - 1.0f) * 0.5f));
-      const int area_px = max(0, x_hi - x_lo + 1) * max(0, y_hi - y_lo + 1);
-      bool deferred = false;
-      if (area_px > kBigArea) {
-        const int pos = atomicAdd(&s_nbig, 1);
-        if (pos < kBigCap) { s_bigrec[pos] = r; s_bigid[pos] = id; s_bigslot[pos] = tid; deferred = true; }
+    __syncthreads();
+    // ---- walk: each wave ballots the staged faces against its 16x4 strip
+    for (int g = 0; g < nl; g += 64) {
+      const int i = g + lane;
+      bool whit = false;
+      if (i < nl) {
+        const float4 q = s_bb[i];
+        whit = !(t_xlo > q.y || t_xhi < q.x || w_ylo > q.w || w_yhi < q.z);
       }
-      if (!deferred && area_px > 0) {
-        const FaceCtx c = face_ctx(r, id, tid, blur, sigma);
-        // flattened walk over the clipped bbox: the wave iterates max(area) times, not max(width) * max(height)
-        int xi = x_lo, yi = y_lo;
-        for (int k = 0; k < area_px; ++k) {
-          const int lx = xi - sx0, ly = yi - sy0;
-          const float px = s_px[lx], py = s_py[ly];
-#if RASTER_EXP == 2
-          if (px > 5.f)
-#else
-          if (!(px > r.bb.y || px < r.bb.x || py > r.bb.w || py < r.bb.z))
-#endif
-            visit_pixel<MODE>(c, px, py, (ly << 6) | lx, blur, sigma, s_zb, s_logp, s_deep, s_coef, s_g, s_q, &s_qn);
-          if (++xi > x_hi) { xi = x_lo; ++yi; }
+      unsigned long long m = __ballot(whit);
+      while (m) {
+        const int j = g + __ffsll((unsigned long long)m) - 1;
+        m &= m - 1;
+        const float4 q = s_bb[j];
+        const bool inbox = !(px > q.y || px < q.x || py > q.w || py < q.z);
+        if (!__any(inbox && need)) continue;
+        const float4 fa = s_a[j], fb = s_b[j];
+        const Tri t = tri_from(fa, fb, make_float4(s_z2[j], 0.f, 0.f, 0.f));
+        // ---- cheap classification first (no divisions): un-normalised edge functions and their signs.
+        // inside  <=>  all perspective-corrected barycentrics > 0  <=>  e_i * sign(area') > 0 for all i   (z > 0 by culling)
+        const float e0 = edge_fn(px, py, t.x1, t.y1, t.x2, t.y2);
+        const float e1 = edge_fn(px, py, t.x2, t.y2, t.x0, t.y0);
+        const float e2 = edge_fn(px, py, t.x0, t.y0, t.x1, t.y1);
+        const float area = edge_fn(t.x2, t.y2, t.x0, t.y0, t.x1, t.y1) + kEps;
+        const float sg = (area > 0.f) ? 1.f : ((area < 0.f) ? -1.f : 0.f);
+        const float e0s = e0 * sg, e1s = e1 * sg, e2s = e2 * sg;
+        const bool inside = (e0s > 0.f) && (e1s > 0.f) && (e2s > 0.f);
+        const bool hard_hit = (MODE != 2) && inside && inbox && in_img;
+        bool soft = false;
+        if (MODE >= 1) {
+          soft = (MODE == 1) ? (inbox && in_img && prod != 0.f) : (inbox && need);
+          if (soft) {
+            // squared edge lengths: e0 <-> (v1,v2), e1 <-> (v2,v0), e2 <-> (v0,v1)
+            const float l12 = (t.x2 - t.x1) * (t.x2 - t.x1) + (t.y2 - t.y1) * (t.y2 - t.y1);
+            const float l20 = (t.x0 - t.x2) * (t.x0 - t.x2) + (t.y0 - t.y2) * (t.y0 - t.y2);
+            const float l01 = (t.x1 - t.x0) * (t.x1 - t.x0) + (t.y1 - t.y0) * (t.y1 - t.y0);
+            if (inside) {
+              // deeper than sqrt(18 sigma) inside every edge LINE (<= segment distance): sigmoid saturates to exactly 1 in
+              // fp32 (exp(-18) < 2^-24), so the factor (1-p) is exactly 0 — same result as the exact path, no div/exp.
+              const float K = 18.0f * sigma;
+              if (e0 * e0 > K * l12 && e1 * e1 > K * l20 && e2 * e2 > K * l01) {
+                if (MODE == 1) prod = 0.f;
+                soft = false;
+              }
+            } else {
+              // outside: the triangle lies beyond the line of any violated edge, so dist >= that line distance
+              const float Bf = blur * 1.00001f;
+              if ((e0s < 0.f && e0 * e0 >= Bf * l12) || (e1s < 0.f && e1 * e1 >= Bf * l20) || (e2s < 0.f && e2 * e2 >= Bf * l01)) soft = false;
+            }
+          }
         }
-      }
-    }
-    __syncthreads();
-    // ================= phase 1b: large faces, one WAVE per face, lanes stride over the pixels of its clipped bbox
-    const int nbig = min(s_nbig, kBigCap);
-    for (int i = (tid >> 6); i < nbig; i += 4) {
-      const FaceRec r = s_bigrec[i];
-      const FaceCtx c = face_ctx(r, s_bigid[i], s_bigslot[i], blur, sigma);
-      const int x_lo = max(sx0, (int)floorf((fS * (1.0f - r.bb.y) - 1.0f) * 0.5f));
-      const int x_hi = min(sx1, (int)ceilf((fS * (1.0f - r.bb.x) - 1.0f) * 0.5f));
-      const int y_lo = max(sy0, (int)floorf((fS * (1.0f - r.bb.w) - 1.0f) * 0.5f));
-      const int y_hi = min(sy1, (int)ceilf((fS * (1.0f - r.bb.z) - 1.0f) * 0.5f));
-      const int wpx = x_hi - x_lo + 1, area_px = wpx * (y_hi - y_lo + 1);
-      const float inv_w = 1.0f / (float)wpx;
-      for (int k = (tid & 63); k < area_px; k += 64) {
-        const int row = (int)(((float)k + 0.5f) * inv_w), col = k - row * wpx;      // exact for k < 4096
-        const int lx = x_lo + col - sx0, ly = y_lo + row - sy0;
-        const float px = s_px[lx], py = s_py[ly];
-        if (px > r.bb.y || px < r.bb.x || py > r.bb.w || py < r.bb.z) continue;
-        visit_pixel<MODE>(c, px, py, (ly << 6) | lx, blur, sigma, s_zb, s_logp, s_deep, s_coef, s_g, s_q, &s_qn);
-      }
-    }
-    __syncthreads();
-    if (tid == 0) s_nbig = 0;
-    if (MODE >= 1) {
-      // ================= phase 2: drain the queue, one lane = one (pixel, face) candidate
-      const int qn = min(s_qn, kQCap);
-      for (int i = tid; i < qn; i += 256) {
-        const uint32_t ent = s_q[i];
-        const int pl = (int)(ent >> 20), key = (int)(ent & 0xFFFFFu);
-        const int id = (MODE == 1) ? key : list[base + key];
-        const Tri t = tri_of(rb[id]);
-        const float px = s_px[pl & 63], py = s_py[pl >> 6];
-        raster_exact<MODE>(t, px, py, pl, key, blur, sigma, s_logp, s_deep, s_coef, s_g);
-      }
-      __syncthreads();
-      if (tid == 0) s_qn = 0;
-      if (MODE == 2 && e < n) {
-        // flush this round's per-face accumulators: <= 6 global atomics per (face, tile)
-        const int id = list[e];
-        float* gb = g_ndc + (size_t)b * V * 3;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-          const float gx = s_g[tid][2 * k], gy = s_g[tid][2 * k + 1];
-          if (gx != 0.f || gy != 0.f) {
-            const int v = faces[3 * id + k];
-            atomicAdd(gb + 3 * v, gx);
-            atomicAdd(gb + 3 * v + 1, gy);
+        if (!__any(hard_hit || soft)) continue;
+        if (hard_hit) {
+          // BarycentricCoordsForward + PerspectiveCorrection with reciprocals (<= 2 ulp from the IEEE-division form)
+          const float ra = __builtin_amdgcn_rcpf(area);
+          const float t0 = (e0 * ra) * t.z1 * t.z2, t1 = t.z0 * (e1 * ra) * t.z2, t2 = t.z0 * t.z1 * (e2 * ra);
+          const float rd = __builtin_amdgcn_rcpf(fmaxf(t0 + t1 + t2, kEps));
+          const float pz = (t0 * rd) * t.z0 + (t1 * rd) * t.z1 + (t2 * rd) * t.z2;
+          if (pz >= 0.f && pz < best_z) { best_z = pz; best_f = s_id[j]; }
+        }
+        if (MODE >= 1 && soft) {
+          float ta, tb, tc;
+          const float d01 = seg_dist2(px, py, t.x0, t.y0, t.x1, t.y1, ta);
+          const float d02 = seg_dist2(px, py, t.x0, t.y0, t.x2, t.y2, tb);
+          const float d12 = seg_dist2(px, py, t.x1, t.y1, t.x2, t.y2, tc);
+          const float dist = fminf(d01, fminf(d02, d12));
+          if (inside || dist < blur) {
+            const float sd = inside ? -dist : dist;
+            const float p = 1.0f / (1.0f + expf(sd / sigma));   // sigmoid(-sd/sigma)
+            if (MODE == 1) {
+              prod *= (1.0f - p);
+            } else {
+              // d alpha / d sd = -P * p / sigma  (P = prod over all faces)
+              const float g_sd = ga * (-P * p / sigma);
+              const float gd = inside ? -g_sd : g_sd;     // d/d(dist^2)
+              // PointLineDistanceBackward on the argmin edge (t treated as constant)
+              int ia, ib; float ax, ay, bx, by, tt;
+              if (d01 <= d02 && d01 <= d12) { ia = 0; ib = 1; ax = t.x0; ay = t.y0; bx = t.x1; by = t.y1; tt = ta; }
+              else if (d02 <= d12)          { ia = 0; ib = 2; ax = t.x0; ay = t.y0; bx = t.x2; by = t.y2; tt = tb; }
+              else                          { ia = 1; ib = 2; ax = t.x1; ay = t.y1; bx = t.x2; by = t.y2; tt = tc; }
+              const float qx = ax + tt * (bx - ax), qy = ay + tt * (by - ay);
+              const float cx = gd * 2.f * (qx - px), cy = gd * 2.f * (qy - py);
+              atomicAdd(&s_g[j][2 * ia], (1.f - tt) * cx);
+              atomicAdd(&s_g[j][2 * ia + 1], (1.f - tt) * cy);
+              atomicAdd(&s_g[j][2 * ib], tt * cx);
+              atomicAdd(&s_g[j][2 * ib + 1], tt * cy);
+            }
           }
         }
       }
     }
     __syncthreads();
+    if (MODE == 2 && (int)threadIdx.x < nl) {
+      // flush: one global atomic per (staged face, vertex, component) per workgroup
+      const int fid = s_id[threadIdx.x];
+      float* gb = g_ndc + (size_t)b * V * 3;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const float gx = s_g[threadIdx.x][2 * k], gy = s_g[threadIdx.x][2 * k + 1];
+        if (gx != 0.f || gy != 0.f) {
+          const int v = faces[3 * fid + k];
+          atomicAdd(gb + 3 * v, gx);
+          atomicAdd(gb + 3 * v + 1, gy);
+        }
+      }
+    }
+    __syncthreads();
   }
 
-  if (MODE != 2) {
-    for (int k = tid; k < kPix; k += 256) {
-      const int xi = sx0 + (k & 63), yi = sy0 + (k >> 6);
-      if (xi >= S || yi >= S) continue;
-      const size_t o = ((size_t)b * S + yi) * S + xi;
-      const unsigned long long zk = s_zb[k];
-      const bool hit = zk != ~0ull;
-      face_id[o] = hit ? (int)(zk & 0xFFFFFFFFu) : -1;
-      if (zbuf) zbuf[o] = hit ? __uint_as_float((unsigned)(zk >> 32)) : -1.0f;
-      if (MODE == 1) alpha[o] = s_deep[k] ? 1.0f : (1.0f - exp2f((float)s_logp[k] * (1.0f / 1048576.0f)));
-    }
+  if (MODE != 2 && in_img) {
+    const size_t o = ((size_t)b * S + yi) * S + xi;
+    face_id[o] = best_f;
+    if (zbuf) zbuf[o] = (best_f >= 0) ? best_z : -1.0f;
+    if (MODE == 1) alpha[o] = 1.0f - prod;
   }
 }
 
@@ -485,7 +358,7 @@ int harp_rasterize_fwd(const float* ndc, const int32_t* faces, int B, int V, int
   const float r = soft ? sqrtf(blur_radius) : 0.f;
   hipLaunchKernelGGL(face_setup_kernel, dim3((F + 255) / 256, B), dim3(256), 0, stream, ndc, faces, V, F, r, recs, bbs);
   hipLaunchKernelGGL(bin_faces_kernel, dim3((nsx * nsx + 3) / 4, B), dim3(256), 0, stream, bbs, F, S, nsx, bins, cnt);
-  const dim3 grid(nsx * nsx, B);
+  const dim3 grid((S + kTile - 1) / kTile, (S + kTile - 1) / kTile, B);
   if (soft)
     hipLaunchKernelGGL(raster_kernel<1>, grid, dim3(256), 0, stream, recs, bins, cnt, F, S, nsx, blur_radius, sigma,
                        face_id, zbuf, alpha, nullptr, nullptr, 0, nullptr);
@@ -501,10 +374,10 @@ int harp_rasterize_fwd(const float* ndc, const int32_t* faces, int B, int V, int
 int harp_silhouette_bwd(const int32_t* faces, int B, int V, int F, int S, float blur_radius, float sigma, const void* ws,
                         const float* alpha, const float* g_alpha, float* g_ndc, hipStream_t stream) {
   if (!faces || !ws || !alpha || !g_alpha || !g_ndc) return HARP_ERR_ARG;
-  FaceRec* recs; int32_t *bins, *cnt; float4* bbs;
-  ws_split((void*)ws, B, F, S, &recs, &bins, &cnt, &bbs);
+  FaceRec* recs; int32_t *bins, *cnt;
+  ws_split((void*)ws, B, F, S, &recs, &bins, &cnt);
   const int nsx = (S + kSuper - 1) / kSuper;
-  const dim3 grid(nsx * nsx, B);
+  const dim3 grid((S + kTile - 1) / kTile, (S + kTile - 1) / kTile, B);
   hipLaunchKernelGGL(raster_kernel<2>, grid, dim3(256), 0, stream, recs, bins, cnt, F, S, nsx, blur_radius, sigma, nullptr,
                      nullptr, (float*)alpha, g_alpha, faces, V, g_ndc);
   HARP_CHECK_LAUNCH();
