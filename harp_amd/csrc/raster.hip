@@ -165,6 +165,7 @@ __global__ void __launch_bounds__(256) raster_kernel(const FaceRec* __restrict__
   const float t_yhi = pix_to_ndc(ty0, S), t_ylo = pix_to_ndc(min(ty0 + kTile, S) - 1, S);
   const float w_yhi = pix_to_ndc(ty0 + w * 4, S), w_ylo = pix_to_ndc(ty0 + w * 4 + 3, S);
 
+  const float strip_r = (MODE == 0) ? 0.f : sqrtf(blur);
   float best_z = 3.0e38f;
   int best_f = -1;
   float prod = 1.0f;
@@ -210,6 +211,25 @@ __global__ void __launch_bounds__(256) raster_kernel(const FaceRec* __restrict__
       if (i < nl) {
         const float4 q = s_bb[i];
         whit = !(t_xlo > q.y || t_xhi < q.x || w_ylo > q.w || w_yhi < q.z);
+        if (whit) {
+          // tighter than the bbox: the strip (a rectangle of pixel centres) is rejected when it lies entirely beyond one edge
+          // LINE of the face by more than the blur radius r (edge function = signed line distance * edge length).
+          const float4 fa = s_a[i], fb = s_b[i];
+          const float X0 = fa.x, Y0 = fa.y, X1 = fa.w, Y1 = fb.x, X2 = fb.z, Y2 = fb.w;
+          const float ar = edge_fn(X2, Y2, X0, Y0, X1, Y1) + kEps;
+          const float sgn = (ar > 0.f) ? 1.f : -1.f;
+          const float ex[3] = {X1, X2, X0}, ey[3] = {Y1, Y2, Y0}, fx[3] = {X2, X0, X1}, fy[3] = {Y2, Y0, Y1};
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            // e(p) = (px-ax)(by-ay) - (py-ay)(bx-ax), a = (ex,ey), b = (fx,fy); maximum of sgn*e over the 4 strip corners
+            const float dx = fx[k] - ex[k], dy = fy[k] - ey[k];
+            const float c00 = sgn * ((t_xlo - ex[k]) * dy - (w_ylo - ey[k]) * dx), c10 = sgn * ((t_xhi - ex[k]) * dy - (w_ylo - ey[k]) * dx);
+            const float c01 = sgn * ((t_xlo - ex[k]) * dy - (w_yhi - ey[k]) * dx), c11 = sgn * ((t_xhi - ex[k]) * dy - (w_yhi - ey[k]) * dx);
+            const float emax = fmaxf(fmaxf(c00, c10), fmaxf(c01, c11));
+            const float margin = strip_r * sqrtf(dx * dx + dy * dy) * 1.0001f + 1e-12f;
+            if (emax < -margin) whit = false;
+          }
+        }
       }
       unsigned long long m = __ballot(whit);
       while (m) {
