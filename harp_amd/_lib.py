@@ -120,3 +120,18 @@ SIGNATURES.update({
     "harp_adam_tick": (_i, [_vp, _vp]),
     "harp_adam_apply": (_i, [_vp, _vp, _vp, _vp, _sz, _vp, _vp]),
 })
+
+
+class TreeModel(ctypes.Structure):
+    """mirror of `harp_tree_model` (include/harp_hip.h)"""
+    _fields_ = ([(n, _i) for n in ("NV", "NJ", "NB")] +
+                [(n, _vp) for n in ("v_template", "shapedirs_T", "posedirs_T", "posedirs", "J_template", "J_dirs", "weights", "pose_mean", "parents",
+                                    "pose_src")] + [("n_pose_in", _i), ("center_joint", _i), ("n_joints_out", _i), ("joint_src", _vp)])
+
+
+_trp = ctypes.POINTER(TreeModel)
+SIGNATURES.update({
+    "harp_lbs_tree_ws_floats": (_sz, [_trp, _i]),
+    "harp_lbs_tree_fwd": (_i, [_trp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
+    "harp_lbs_tree_bwd": (_i, [_trp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+})

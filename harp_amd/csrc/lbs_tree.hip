@@ -1,0 +1,374 @@
+// General kinematic-tree linear-blend skinning for gfx950 (forward + hand-written backward), used for the SMPL-X right-arm
+// layer: replaces SMPLXARM.forward (hand_models_harp/body_models.py:2163-2390) = smplx.lbs over the full 10 475-vertex body
+// followed by a slice to the 1026 arm vertices.  Here the model is sliced ONCE on the host (vertex arrays restricted to the arm,
+// joint regressor folded into J_template / J_dirs), so the kernels only ever touch the ~10 % of the body the reference keeps.
+//
+// Same structure as csrc/lbs.hip (MANO) with run-time sizes: Rodrigues in the smplx matrix form
+// (I + sin K + (1-cos) K^2, angle = |r + 1e-8|), arbitrary parents[] (parents[j] < j), an input->joint map (only the root, the
+// right wrist and the 15 right-hand joints are driven), recentring on one chain joint, and output joints that are either chain
+// joints or mesh vertices (finger tips).
+#include "harp_common.h"
+#include "harp_hip.h"
+
+namespace {
+
+constexpr int MAXJ = 64;          // joints
+constexpr int MAXB = 32;          // shape coefficients
+constexpr int FPB = 4;            // frames per workgroup in the skinning kernels
+
+// smplx.lbs.batch_rodrigues
+__device__ __forceinline__ void rod_fwd(const float r[3], float R[9]) {
+  const float e0 = r[0] + 1e-8f, e1 = r[1] + 1e-8f, e2 = r[2] + 1e-8f;
+  const float th = sqrtf(e0 * e0 + e1 * e1 + e2 * e2);
+  const float dx = r[0] / th, dy = r[1] / th, dz = r[2] / th;
+  const float s = sinf(th), c = 1.0f - cosf(th);
+  // K = [[0,-dz,dy],[dz,0,-dx],[-dy,dx,0]];  K^2 = d d^T - |d|^2 I
+  const float n2 = dx * dx + dy * dy + dz * dz;
+  R[0] = 1.f + c * (dx * dx - n2); R[1] = -s * dz + c * dx * dy;    R[2] = s * dy + c * dx * dz;
+  R[3] = s * dz + c * dx * dy;     R[4] = 1.f + c * (dy * dy - n2); R[5] = -s * dx + c * dy * dz;
+  R[6] = -s * dy + c * dx * dz;    R[7] = s * dx + c * dy * dz;     R[8] = 1.f + c * (dz * dz - n2);
+}
+
+__device__ __forceinline__ void rod_bwd(const float r[3], const float g[9], float gr[3]) {
+  const float e[3] = {r[0] + 1e-8f, r[1] + 1e-8f, r[2] + 1e-8f};
+  const float th = sqrtf(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]);
+  const float d[3] = {r[0] / th, r[1] / th, r[2] / th};
+  const float s = sinf(th), cs = cosf(th), c = 1.0f - cs;
+  const float n2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+  const float K[9] = {0.f, -d[2], d[1], d[2], 0.f, -d[0], -d[1], d[0], 0.f};
+  float K2[9];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) K2[i * 3 + j] = d[i] * d[j] - (i == j ? n2 : 0.f);
+  float g_th = 0.f;
+  for (int k = 0; k < 9; ++k) g_th += g[k] * (cs * K[k] + s * K2[k]);
+  // R = I + s K + c K K:  g_K = s G + c (G K^T + K^T G)
+  float gK[9];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      float a = 0.f;
+      for (int m = 0; m < 3; ++m) a += g[i * 3 + m] * K[j * 3 + m] + K[m * 3 + i] * g[m * 3 + j];
+      gK[i * 3 + j] = s * g[i * 3 + j] + c * a;
+    }
+  const float gd[3] = {gK[7] - gK[5], gK[2] - gK[6], gK[3] - gK[1]};
+  g_th -= (d[0] * gd[0] + d[1] * gd[1] + d[2] * gd[2]) / th;
+  for (int k = 0; k < 3; ++k) gr[k] = gd[k] / th + g_th * e[k] / th;
+}
+
+// one wave per frame.  in_pose (B, n_in, 3); writes pose_map (B,NP), A (B,NJ,12), G (B,NJ,12), Jrest (B,NJ,3), Rloc (B,NJ,9)
+__global__ void __launch_bounds__(64) tree_joints_kernel(const harp_tree_model M, const float* __restrict__ in_pose,
+                                                         const float* __restrict__ betas, float* __restrict__ pose_map,
+                                                         float* __restrict__ A, float* __restrict__ G, float* __restrict__ Jrest,
+                                                         float* __restrict__ Rloc) {
+  __shared__ float sR[MAXJ][9], sJ[MAXJ][3], sG[MAXJ][12];
+  const int b = blockIdx.x, l = threadIdx.x, NJ = M.NJ, NB = M.NB, NP = (NJ - 1) * 9;
+  for (int j = l; j < NJ; j += 64) {
+    float aa[3];
+    const int src = M.pose_src[j];
+    for (int c = 0; c < 3; ++c) aa[c] = M.pose_mean[3 * j + c] + (src >= 0 ? in_pose[((size_t)b * M.n_pose_in + src) * 3 + c] : 0.f);
+    float R[9];
+    rod_fwd(aa, R);
+    for (int k = 0; k < 9; ++k) { sR[j][k] = R[k]; Rloc[((size_t)b * NJ + j) * 9 + k] = R[k]; }
+    if (j > 0)
+      for (int k = 0; k < 9; ++k) pose_map[(size_t)b * NP + (j - 1) * 9 + k] = R[k] - ((k == 0 || k == 4 || k == 8) ? 1.f : 0.f);
+  }
+  for (int i = l; i < NJ * 3; i += 64) {
+    float acc = M.J_template[i];
+    for (int k = 0; k < NB; ++k) acc += M.J_dirs[i * NB + k] * betas[b * NB + k];
+    sJ[i / 3][i % 3] = acc;
+    Jrest[(size_t)b * NJ * 3 + i] = acc;
+  }
+  __syncthreads();
+  if (l == 0) {
+    // batch_rigid_transform: chain[i] = chain[parent] @ [R_i | J_i - J_parent]   (sequential: 55 tiny products)
+    for (int k = 0; k < 9; ++k) sG[0][(k / 3) * 4 + (k % 3)] = sR[0][k];
+    for (int r = 0; r < 3; ++r) sG[0][r * 4 + 3] = sJ[0][r];
+    for (int j = 1; j < NJ; ++j) {
+      const int p = M.parents[j];
+      const float rel[3] = {sJ[j][0] - sJ[p][0], sJ[j][1] - sJ[p][1], sJ[j][2] - sJ[p][2]};
+      for (int r = 0; r < 3; ++r) {
+        for (int c = 0; c < 3; ++c)
+          sG[j][r * 4 + c] = sG[p][r * 4] * sR[j][c] + sG[p][r * 4 + 1] * sR[j][3 + c] + sG[p][r * 4 + 2] * sR[j][6 + c];
+        sG[j][r * 4 + 3] = sG[p][r * 4] * rel[0] + sG[p][r * 4 + 1] * rel[1] + sG[p][r * 4 + 2] * rel[2] + sG[p][r * 4 + 3];
+      }
+    }
+  }
+  __syncthreads();
+  for (int j = l; j < NJ; j += 64) {
+    float* Ao = A + ((size_t)b * NJ + j) * 12;
+    float* Go = G + ((size_t)b * NJ + j) * 12;
+    for (int r = 0; r < 3; ++r) {
+      for (int c = 0; c < 3; ++c) { Ao[r * 4 + c] = sG[j][r * 4 + c]; Go[r * 4 + c] = sG[j][r * 4 + c]; }
+      Go[r * 4 + 3] = sG[j][r * 4 + 3];
+      Ao[r * 4 + 3] = sG[j][r * 4 + 3] - (sG[j][r * 4] * sJ[j][0] + sG[j][r * 4 + 1] * sJ[j][1] + sG[j][r * 4 + 2] * sJ[j][2]);
+    }
+  }
+}
+
+// blockIdx.x: vertex chunk (256), blockIdx.y: frame chunk (FPB).  Forward: verts = ((T [vp;1]) - centre + transl) * 1000.
+// Backward: g_vp = T^T g, M = g (x) [vp;1] per vertex (g = g_verts * 1000).
+template <bool BWD>
+__global__ void __launch_bounds__(256) tree_skin_kernel(const harp_tree_model M, const float* __restrict__ betas,
+                                                        const float* __restrict__ transl, const float* __restrict__ pose_map,
+                                                        const float* __restrict__ A, const float* __restrict__ G, int B,
+                                                        float* __restrict__ verts, const float* __restrict__ g_verts,
+                                                        float* __restrict__ g_vp, float* __restrict__ Mo) {
+  extern __shared__ float smem[];
+  const int NJ = M.NJ, NB = M.NB, NV = M.NV, NP = (NJ - 1) * 9;
+  float* s_pm = smem;                       // [FPB][NP]
+  float* s_beta = s_pm + FPB * NP;          // [FPB][NB]
+  float* s_A = s_beta + FPB * NB;           // [FPB][NJ*12]
+  float* s_c = s_A + FPB * NJ * 12;         // [FPB][3]  centre joint position
+  const int v = blockIdx.x * 256 + threadIdx.x;
+  const int b0 = blockIdx.y * FPB;
+  const int nb = min(FPB, B - b0);
+  for (int i = threadIdx.x; i < nb * NP; i += 256) s_pm[i] = pose_map[(size_t)b0 * NP + i];
+  for (int i = threadIdx.x; i < nb * NB; i += 256) s_beta[i] = betas[b0 * NB + i];
+  for (int i = threadIdx.x; i < nb * NJ * 12; i += 256) s_A[i] = A[(size_t)b0 * NJ * 12 + i];
+  for (int i = threadIdx.x; i < nb * 3; i += 256)
+    s_c[i] = (M.center_joint >= 0) ? G[((size_t)(b0 + i / 3) * NJ + M.center_joint) * 12 + (i % 3) * 4 + 3] : 0.f;
+  __syncthreads();
+  if (v >= NV) return;
+  float vp[FPB][3];
+  const float t0 = M.v_template[3 * v], t1 = M.v_template[3 * v + 1], t2 = M.v_template[3 * v + 2];
+#pragma unroll
+  for (int f = 0; f < FPB; ++f) { vp[f][0] = t0; vp[f][1] = t1; vp[f][2] = t2; }
+  const size_t row = (size_t)NV * 3;
+  for (int k = 0; k < NB; ++k) {
+    const float s0 = M.shapedirs_T[k * row + 3 * v], s1 = M.shapedirs_T[k * row + 3 * v + 1], s2 = M.shapedirs_T[k * row + 3 * v + 2];
+#pragma unroll
+    for (int f = 0; f < FPB; ++f) { const float c = s_beta[f * NB + k]; vp[f][0] += s0 * c; vp[f][1] += s1 * c; vp[f][2] += s2 * c; }
+  }
+  for (int k = 0; k < NP; ++k) {
+    const float p0 = M.posedirs_T[k * row + 3 * v], p1 = M.posedirs_T[k * row + 3 * v + 1], p2 = M.posedirs_T[k * row + 3 * v + 2];
+#pragma unroll
+    for (int f = 0; f < FPB; ++f) { const float c = s_pm[f * NP + k]; vp[f][0] += p0 * c; vp[f][1] += p1 * c; vp[f][2] += p2 * c; }
+  }
+  for (int f = 0; f < nb; ++f) {
+    float T[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) T[k] = 0.f;
+    for (int j = 0; j < NJ; ++j) {
+      const float w = M.weights[(size_t)v * NJ + j];
+      if (w != 0.f) {
+#pragma unroll
+        for (int k = 0; k < 12; ++k) T[k] += w * s_A[(f * NJ + j) * 12 + k];
+      }
+    }
+    const int b = b0 + f;
+    if (!BWD) {
+      for (int r = 0; r < 3; ++r) {
+        const float o = T[r * 4] * vp[f][0] + T[r * 4 + 1] * vp[f][1] + T[r * 4 + 2] * vp[f][2] + T[r * 4 + 3];
+        verts[((size_t)b * NV + v) * 3 + r] = (o - s_c[f * 3 + r] + transl[3 * b + r]) * 1000.0f;
+      }
+    } else {
+      float g[3];
+      for (int r = 0; r < 3; ++r) g[r] = g_verts[((size_t)b * NV + v) * 3 + r] * 1000.0f;
+      for (int c = 0; c < 3; ++c) g_vp[((size_t)b * NV + v) * 3 + c] = T[c] * g[0] + T[4 + c] * g[1] + T[8 + c] * g[2];
+      float* mo = Mo + ((size_t)b * NV + v) * 12;
+      for (int r = 0; r < 3; ++r) {
+        mo[r * 4] = g[r] * vp[f][0]; mo[r * 4 + 1] = g[r] * vp[f][1]; mo[r * 4 + 2] = g[r] * vp[f][2]; mo[r * 4 + 3] = g[r];
+      }
+    }
+  }
+}
+
+// joints (B,n_out,3) mm: chain joints (G_j.t - centre + transl) * 1000, vertex joints = verts[vid] (already final)
+__global__ void tree_joints_out_kernel(const harp_tree_model M, const float* __restrict__ G, const float* __restrict__ verts,
+                                       const float* __restrict__ transl, int B, float* __restrict__ joints) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, no = M.n_joints_out;
+  if (i >= B * no * 3) return;
+  const int b = i / (no * 3), k = (i / 3) % no, c = i % 3, src = M.joint_src[k];
+  if (src >= 0) {
+    const float ctr = (M.center_joint >= 0) ? G[((size_t)b * M.NJ + M.center_joint) * 12 + c * 4 + 3] : 0.f;
+    joints[i] = (G[((size_t)b * M.NJ + src) * 12 + c * 4 + 3] - ctr + transl[3 * b + c]) * 1000.0f;
+  } else {
+    joints[i] = verts[((size_t)b * M.NV + (-src - 1)) * 3 + c];
+  }
+}
+
+// g_joints -> g_Gt (B,NJ,3) chain-joint translation gradients [metres] (zero-initialised by the caller) and tip part into g_verts
+__global__ void tree_joints_bwd_kernel(const harp_tree_model M, const float* __restrict__ g_joints, int B, float* __restrict__ g_Gt,
+                                       float* __restrict__ g_verts) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, no = M.n_joints_out;
+  if (i >= B * no * 3) return;
+  const int b = i / (no * 3), k = (i / 3) % no, c = i % 3, src = M.joint_src[k];
+  if (src >= 0) atomicAdd(&g_Gt[((size_t)b * M.NJ + src) * 3 + c], g_joints[i] * 1000.0f);
+  else atomicAdd(&g_verts[((size_t)b * M.NV + (-src - 1)) * 3 + c], g_joints[i]);
+}
+
+// per frame: s = 1000 * sum_v g_verts + sum_chain g_Gt ; g_transl = s ; g_Gt[centre] -= s
+__global__ void __launch_bounds__(256) tree_center_bwd_kernel(const harp_tree_model M, const float* __restrict__ g_verts,
+                                                              float* __restrict__ g_Gt, float* __restrict__ g_transl) {
+  __shared__ float red[4];
+  const int b = blockIdx.x;
+  float a[3] = {0.f, 0.f, 0.f};
+  for (int v = threadIdx.x; v < M.NV; v += 256)
+    for (int c = 0; c < 3; ++c) a[c] += g_verts[((size_t)b * M.NV + v) * 3 + c] * 1000.0f;
+  for (int j = threadIdx.x; j < M.NJ; j += 256)
+    for (int c = 0; c < 3; ++c) a[c] += g_Gt[((size_t)b * M.NJ + j) * 3 + c];
+  for (int c = 0; c < 3; ++c) {
+    const float s = block_sum_256(a[c], red);
+    if (threadIdx.x == 0) {
+      g_transl[3 * b + c] = s;
+      if (M.center_joint >= 0) g_Gt[((size_t)b * M.NJ + M.center_joint) * 3 + c] -= s;
+    }
+  }
+}
+
+// g_A[b][j][k] += sum_{v in chunk} w[v][j] M[b][v][k]   (g_A pre-zeroed)
+constexpr int kChunksA = 8;
+__global__ void __launch_bounds__(256) tree_gA_kernel(const harp_tree_model M, const float* __restrict__ Mo, float* __restrict__ g_A) {
+  const int b = blockIdx.x, NJ = M.NJ, NV = M.NV;
+  const int per = (NV + kChunksA - 1) / kChunksA, v0 = blockIdx.y * per, v1 = min(NV, v0 + per);
+  for (int o = threadIdx.x; o < NJ * 12; o += 256) {
+    const int j = o / 12, k = o % 12;
+    float acc = 0.f;
+    for (int v = v0; v < v1; ++v) {
+      const float w = M.weights[(size_t)v * NJ + j];
+      if (w != 0.f) acc += w * Mo[((size_t)b * NV + v) * 12 + k];
+    }
+    if (acc != 0.f) atomicAdd(&g_A[((size_t)b * NJ) * 12 + o], acc);
+  }
+}
+
+// g_pose_map[b][k] += sum_{i in chunk} posedirs[i][k] g_vp[b][i]; g_beta likewise (both pre-zeroed)
+constexpr int kChunksP = 16;
+__global__ void __launch_bounds__(256) tree_gpm_kernel(const harp_tree_model M, const float* __restrict__ g_vp, float* __restrict__ g_pm,
+                                                       float* __restrict__ g_beta_b) {
+  const int b = blockIdx.x, NV3 = M.NV * 3, NP = (M.NJ - 1) * 9, NB = M.NB;
+  const int per = (NV3 + kChunksP - 1) / kChunksP, i0 = blockIdx.y * per, i1 = min(NV3, i0 + per);
+  const float* g = g_vp + (size_t)b * NV3;
+  for (int k = threadIdx.x; k < NP + NB; k += 256) {
+    float acc = 0.f;
+    if (k < NP) {
+#pragma unroll 4
+      for (int i = i0; i < i1; ++i) acc += M.posedirs[(size_t)i * NP + k] * g[i];
+      atomicAdd(&g_pm[(size_t)b * NP + k], acc);
+    } else {
+      const int kk = k - NP;
+#pragma unroll 4
+      for (int i = i0; i < i1; ++i) acc += M.shapedirs_T[(size_t)kk * NV3 + i] * g[i];
+      atomicAdd(&g_beta_b[b * NB + kk], acc);
+    }
+  }
+}
+
+// one wave per frame: chain + Rodrigues backward
+__global__ void __launch_bounds__(64) tree_chain_bwd_kernel(const harp_tree_model M, const float* __restrict__ in_pose,
+                                                            const float* __restrict__ Rloc, const float* __restrict__ G,
+                                                            const float* __restrict__ Jrest, const float* __restrict__ g_A,
+                                                            const float* __restrict__ g_pm, const float* __restrict__ g_Gt,
+                                                            float* __restrict__ g_in_pose, float* __restrict__ g_beta_b) {
+  __shared__ float gRG[MAXJ][9], gtG[MAXJ][3], gRl[MAXJ][9], gJ[MAXJ][3];
+  const int b = blockIdx.x, l = threadIdx.x, NJ = M.NJ, NB = M.NB, NP = (NJ - 1) * 9;
+  const float* Gb = G + (size_t)b * NJ * 12;
+  const float* Rb = Rloc + (size_t)b * NJ * 9;
+  const float* Jb = Jrest + (size_t)b * NJ * 3;
+  for (int j = l; j < NJ; j += 64) {
+    const float* ga = g_A + ((size_t)b * NJ + j) * 12;
+    for (int r = 0; r < 3; ++r) {
+      const float gt = ga[r * 4 + 3];
+      for (int c = 0; c < 3; ++c) gRG[j][r * 3 + c] = ga[r * 4 + c] - gt * Jb[j * 3 + c];
+      gtG[j][r] = gt + g_Gt[((size_t)b * NJ + j) * 3 + r];
+    }
+    for (int c = 0; c < 3; ++c) {
+      float acc = 0.f;
+      for (int r = 0; r < 3; ++r) acc -= Gb[j * 12 + r * 4 + c] * ga[r * 4 + 3];
+      gJ[j][c] = acc;
+    }
+    for (int k = 0; k < 9; ++k) gRl[j][k] = (j > 0) ? g_pm[(size_t)b * NP + (j - 1) * 9 + k] : 0.f;
+  }
+  __syncthreads();
+  if (l == 0) {
+    for (int j = NJ - 1; j >= 1; --j) {
+      const int p = M.parents[j];
+      const float rel[3] = {Jb[j * 3] - Jb[p * 3], Jb[j * 3 + 1] - Jb[p * 3 + 1], Jb[j * 3 + 2] - Jb[p * 3 + 2]};
+      float gl[3];
+      for (int c = 0; c < 3; ++c) gl[c] = Gb[p * 12 + c] * gtG[j][0] + Gb[p * 12 + 4 + c] * gtG[j][1] + Gb[p * 12 + 8 + c] * gtG[j][2];
+      for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) {
+          gRl[j][r * 3 + c] += Gb[p * 12 + r] * gRG[j][c] + Gb[p * 12 + 4 + r] * gRG[j][3 + c] + Gb[p * 12 + 8 + r] * gRG[j][6 + c];
+          gRG[p][r * 3 + c] += gRG[j][r * 3] * Rb[j * 9 + c * 3] + gRG[j][r * 3 + 1] * Rb[j * 9 + c * 3 + 1] +
+                               gRG[j][r * 3 + 2] * Rb[j * 9 + c * 3 + 2] + gtG[j][r] * rel[c];
+        }
+      for (int c = 0; c < 3; ++c) { gtG[p][c] += gtG[j][c]; gJ[p][c] -= gl[c]; gJ[j][c] += gl[c]; }
+    }
+    for (int k = 0; k < 9; ++k) gRl[0][k] += gRG[0][k];
+    for (int c = 0; c < 3; ++c) gJ[0][c] += gtG[0][c];
+  }
+  __syncthreads();
+  for (int j = l; j < NJ; j += 64) {
+    const int src = M.pose_src[j];
+    if (src < 0) continue;
+    float aa[3], gaa[3];
+    for (int c = 0; c < 3; ++c) aa[c] = M.pose_mean[3 * j + c] + in_pose[((size_t)b * M.n_pose_in + src) * 3 + c];
+    rod_bwd(aa, gRl[j], gaa);
+    for (int c = 0; c < 3; ++c) g_in_pose[((size_t)b * M.n_pose_in + src) * 3 + c] = gaa[c];
+  }
+  for (int k = l; k < NB; k += 64) {
+    float acc = g_beta_b[b * NB + k];
+    for (int i = 0; i < NJ * 3; ++i) acc += M.J_dirs[i * NB + k] * gJ[i / 3][i % 3];
+    g_beta_b[b * NB + k] = acc;
+  }
+}
+
+__global__ void zero_kernel(float* __restrict__ a, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) a[i] = 0.f;
+}
+
+struct TreeWs { float *pm, *A, *G, *Jrest, *Rloc, *g_vp, *Mo, *g_A, *g_pm, *g_Gt; };
+TreeWs tree_ws(const harp_tree_model* m, float* ws, int B) {
+  const size_t NJ = m->NJ, NV = m->NV, NP = (NJ - 1) * 9;
+  TreeWs w; float* p = ws;
+  w.pm = p; p += B * NP; w.A = p; p += B * NJ * 12; w.G = p; p += B * NJ * 12; w.Jrest = p; p += B * NJ * 3; w.Rloc = p; p += B * NJ * 9;
+  w.g_vp = p; p += B * NV * 3; w.Mo = p; p += B * NV * 12;
+  w.g_A = p; p += B * NJ * 12; w.g_pm = p; p += B * NP; w.g_Gt = p;     // g_A | g_pm | g_Gt adjacent (zeroed together)
+  return w;
+}
+
+size_t skin_smem(const harp_tree_model* m) { return sizeof(float) * (size_t)FPB * ((m->NJ - 1) * 9 + m->NB + m->NJ * 12 + 3); }
+
+}  // namespace
+
+extern "C" {
+
+size_t harp_lbs_tree_ws_floats(const harp_tree_model* m, int B) {
+  const size_t NJ = m->NJ, NV = m->NV, NP = (NJ - 1) * 9;
+  return (size_t)B * (NP + NJ * 12 * 2 + NJ * 3 + NJ * 9 + NV * 3 + NV * 12 + NJ * 12 + NP + NJ * 3);
+}
+
+int harp_lbs_tree_fwd(const harp_tree_model* m, const float* in_pose, const float* betas, const float* transl, int B, float* ws,
+                      float* verts, float* joints, hipStream_t stream) {
+  if (!m || !in_pose || !betas || !transl || !ws || !verts || !joints || B <= 0 || m->NJ > MAXJ || m->NB > MAXB) return HARP_ERR_ARG;
+  const TreeWs w = tree_ws(m, ws, B);
+  hipLaunchKernelGGL(tree_joints_kernel, dim3(B), dim3(64), 0, stream, *m, in_pose, betas, w.pm, w.A, w.G, w.Jrest, w.Rloc);
+  hipLaunchKernelGGL(tree_skin_kernel<false>, dim3((m->NV + 255) / 256, (B + FPB - 1) / FPB), dim3(256), skin_smem(m), stream, *m, betas,
+                     transl, w.pm, w.A, w.G, B, verts, nullptr, nullptr, nullptr);
+  hipLaunchKernelGGL(tree_joints_out_kernel, dim3((B * m->n_joints_out * 3 + 255) / 256), dim3(256), 0, stream, *m, w.G, verts, transl, B,
+                     joints);
+  HARP_CHECK_LAUNCH();
+  return HARP_OK;
+}
+
+// g_verts (B,NV,3) is MODIFIED (vertex-joint gradients are folded in). Outputs: g_in_pose (B,n_pose_in,3), g_betas (B,NB), g_transl (B,3).
+int harp_lbs_tree_bwd(const harp_tree_model* m, const float* in_pose, const float* betas, const float* transl, int B, float* ws,
+                      float* g_verts, const float* g_joints, float* g_in_pose, float* g_betas, float* g_transl, hipStream_t stream) {
+  if (!m || !in_pose || !betas || !ws || !g_verts || !g_joints || !g_in_pose || !g_betas || !g_transl) return HARP_ERR_ARG;
+  const TreeWs w = tree_ws(m, ws, B);
+  const size_t nz = (size_t)B * (m->NJ * 12 + (m->NJ - 1) * 9 + m->NJ * 3);
+  hipLaunchKernelGGL(zero_kernel, dim3((unsigned)((nz + 255) / 256)), dim3(256), 0, stream, w.g_A, nz);
+  hipLaunchKernelGGL(zero_kernel, dim3((B * m->NB + 255) / 256), dim3(256), 0, stream, g_betas, (size_t)B * m->NB);
+  hipLaunchKernelGGL(tree_joints_bwd_kernel, dim3((B * m->n_joints_out * 3 + 255) / 256), dim3(256), 0, stream, *m, g_joints, B, w.g_Gt, g_verts);
+  hipLaunchKernelGGL(tree_center_bwd_kernel, dim3(B), dim3(256), 0, stream, *m, g_verts, w.g_Gt, g_transl);
+  hipLaunchKernelGGL(tree_skin_kernel<true>, dim3((m->NV + 255) / 256, (B + FPB - 1) / FPB), dim3(256), skin_smem(m), stream, *m, betas,
+                     transl, w.pm, w.A, w.G, B, nullptr, g_verts, w.g_vp, w.Mo);
+  hipLaunchKernelGGL(tree_gA_kernel, dim3(B, kChunksA), dim3(256), 0, stream, *m, w.Mo, w.g_A);
+  hipLaunchKernelGGL(tree_gpm_kernel, dim3(B, kChunksP), dim3(256), 0, stream, *m, w.g_vp, w.g_pm, g_betas);
+  hipLaunchKernelGGL(tree_chain_bwd_kernel, dim3(B), dim3(64), 0, stream, *m, in_pose, w.Rloc, w.G, w.Jrest, w.g_A, w.g_pm, w.g_Gt, g_in_pose,
+                     g_betas);
+  HARP_CHECK_LAUNCH();
+  return HARP_OK;
+}
+
+}  // extern "C"

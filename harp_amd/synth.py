@@ -105,3 +105,51 @@ def make_sequence(model, T, S, seed=0, focal=None):
     cam = np.concatenate([s, txy], 1)
     f32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
     return dict(pose=f32(pose), rot=f32(rot), trans=torch.zeros(T, 3), shape=f32(shape), cam=f32(cam)), float(focal)
+
+
+SMPLX_PARENTS = [-1, 0, 0, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 9, 9, 12, 13, 14, 16, 17, 18, 19, 15, 15, 15, 20, 25, 26, 20, 28, 29, 20, 31, 32,
+                 20, 34, 35, 20, 37, 38, 21, 40, 41, 21, 43, 44, 21, 46, 47, 21, 49, 50, 21, 52, 53]
+
+
+def make_smplx_arm_model(template=None, seed=0):
+    """An SMPL-X-right-arm-shaped LBS model on the real arm topology (1026 v / 2032 f) with synthetic blend shapes, already
+    arm-sliced with the joint regressor folded in (see harp_amd/hand_models_harp/body_models.py): v_template (1026,3) m,
+    shapedirs (1026,3,20), posedirs (486, 3078), J_template (55,3), J_shapedirs (55,3,20), weights (1026,55), pose_mean (165,),
+    parents (55,), tip_verts (5,), faces (2032,3)."""
+    t = template or load_template("arm")
+    corr = np.load(os.path.join(_ASSETS, "arm_corr.npz"))
+    rng = np.random.default_rng(seed + 17)
+    v = t["base_verts"].astype(np.float64)
+    mano_from_arm = corr["mano_vert_from_arm"].astype(np.int64)
+    tip_verts = mano_from_arm[MANO_TIPS]                                   # thumb, index, middle, ring, pinky (arm-local ids)
+    hand = v[mano_from_arm]
+    axis = v[v[:, 0] > np.quantile(v[:, 0], 0.98)].mean(0) - hand.mean(0)  # hand -> upper arm direction
+    L = np.linalg.norm(axis)
+    axis /= L
+    wrist = hand[np.argsort((hand - hand.mean(0)) @ axis)[-30:]].mean(0)   # hand vertices closest to the forearm
+    J = np.zeros((55, 3))
+    J[21] = wrist
+    J[19] = wrist + axis * 0.55 * L                                        # right elbow
+    J[17] = wrist + axis * 1.05 * L                                        # right shoulder
+    J[14] = J[17] + axis * 0.08
+    J[9], J[6], J[3], J[0] = J[14] + axis * 0.05, J[14] + axis * 0.10, J[14] + axis * 0.15, J[14] + axis * 0.20
+    others = [j for j in range(55) if not J[j].any()]
+    J[others] = J[0] + rng.standard_normal((len(others), 3)) * 0.05
+    # SMPL-X right-hand joints: index 40-42, middle 43-45, pinky 46-48, ring 49-51, thumb 52-54
+    for base, tip in ((40, 1), (43, 2), (46, 4), (49, 3), (52, 0)):
+        for k, fr in enumerate((0.50, 0.68, 0.85)):
+            J[base + k] = wrist + (v[tip_verts[tip]] - wrist) * fr
+    active = [17, 19, 21] + list(range(40, 55))
+    d2 = ((v[:, None] - J[None, active]) ** 2).sum(-1)
+    w_act = np.exp(-d2 / (2 * 0.012 ** 2)) + 1e-9
+    w_act[:, :3] = np.exp(-d2[:, :3] / (2 * 0.05 ** 2)) + 1e-9             # broader influence of the arm joints
+    w = np.zeros((len(v), 55))
+    w[:, active] = w_act
+    w /= w.sum(1, keepdims=True)
+    pose_mean = np.zeros(165)
+    pose_mean[120:165] = rng.standard_normal(45) * 0.05                    # flat_hand_mean=False: right-hand mean pose
+    return dict(v_template=v.astype(np.float32), shapedirs=(rng.standard_normal((len(v), 3, 20)) * 1e-3).astype(np.float32),
+                posedirs=(rng.standard_normal((486, len(v) * 3)) * 1e-3).astype(np.float32), J_template=J.astype(np.float32),
+                J_shapedirs=(rng.standard_normal((55, 3, 20)) * 1e-3).astype(np.float32), weights=w.astype(np.float32),
+                pose_mean=pose_mean.astype(np.float32), parents=np.asarray(SMPLX_PARENTS, np.int32),
+                tip_verts=tip_verts.astype(np.int32), faces=t["faces0"].astype(np.int64))

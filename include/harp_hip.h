@@ -127,6 +127,34 @@ int harp_lbs_mano_fwd(const harp_mano_model* m, const float* pose, const float* 
 int harp_lbs_mano_bwd(const harp_mano_model* m, const float* pose, const float* betas, const float* trans, int B, float* ws,
                       float* g_verts, const float* g_joints, float* g_pose, float* g_betas, float* g_trans, hipStream_t stream);
 
+/* ---- kinematic-tree LBS (SMPL-X right arm) ------------------------------------------------------------------------
+ * replaces SMPLXARM.forward(..., return_type='mano_w_arm') (hand_models_harp/body_models.py:2163-2390: smplx.lbs :2335, recentre on
+ * the right wrist :2342-2343, transl :2378-2380, arm slice :2383-2390); call site utils/visualize.py:37-40.  The model is sliced
+ * to the arm vertices on the host (harp_amd/hand_models_harp/body_models.py), the joint regressor folded into J_template/J_dirs. */
+typedef struct harp_tree_model {
+  int NV, NJ, NB;              /* vertices kept, joints (<= 64), shape coefficients (<= 32) */
+  const float* v_template;     /* (NV,3) */
+  const float* shapedirs_T;    /* (NB, NV*3) */
+  const float* posedirs_T;     /* ((NJ-1)*9, NV*3)  (smplx layout) */
+  const float* posedirs;       /* (NV*3, (NJ-1)*9) */
+  const float* J_template;     /* (NJ,3) */
+  const float* J_dirs;         /* (NJ*3, NB) */
+  const float* weights;        /* (NV,NJ) */
+  const float* pose_mean;      /* (NJ*3) */
+  const int32_t* parents;      /* (NJ) parents[0] = -1, parents[j] < j */
+  const int32_t* pose_src;     /* (NJ) row of in_pose driving joint j, or -1 (axis-angle = pose_mean only) */
+  int n_pose_in;               /* rows of in_pose: (B, n_pose_in, 3) = [global_orient, right_wrist_pose, right_hand_pose(15)] */
+  int center_joint;            /* recentre on this chain joint (21 = right wrist) or -1 */
+  int n_joints_out;            /* 22 */
+  const int32_t* joint_src;    /* (n_joints_out): >= 0 chain joint id, < 0: vertex joint -(vertex id)-1 */
+} harp_tree_model;
+size_t harp_lbs_tree_ws_floats(const harp_tree_model* m, int B);
+/* verts (B,NV,3) mm, joints (B,n_joints_out,3) mm */
+int harp_lbs_tree_fwd(const harp_tree_model* m, const float* in_pose, const float* betas, const float* transl, int B, float* ws,
+                      float* verts, float* joints, hipStream_t stream);
+int harp_lbs_tree_bwd(const harp_tree_model* m, const float* in_pose, const float* betas, const float* transl, int B, float* ws,
+                      float* g_verts, const float* g_joints, float* g_in_pose, float* g_betas, float* g_transl, hipStream_t stream);
+
 /* ---- losses, texture helpers, optimiser ---------------------------------------------------------------------------
  * Every loss call accumulates (+=) its value into `loss` and, if `w` (device pointer to the weight(s) = d total/d term)
  * and the gradient output are non-NULL, its weighted gradient (+= unless noted). */

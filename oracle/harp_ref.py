@@ -310,3 +310,65 @@ def step_losses(params, fid, model, topo, targets, S, focal, ref_verts, dist_alb
         loss["normal_reg"] = normal_reg(params["normal_map"], dist_normal, params["uv_mask"])       # :553
     total = sum(l * LOSS_WEIGHTS[k] for k, l in loss.items())                                        # :556-558
     return loss, total, {"y_sil_pred": y_sil_pred, "y_pred": y_pred, "verts": verts, "joints": joints}
+
+
+# ----------------------------------------------------------------------------------------------
+# SMPL-X right-arm layer  (hand_models_harp/body_models.py:2163-2390; smplx.lbs is un-vendored -> PARITY UNPINNED,
+# restated from the published smplx/lbs.py algorithm)
+# ----------------------------------------------------------------------------------------------
+SMPLX_PARENTS = [-1, 0, 0, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 9, 9, 12, 13, 14, 16, 17, 18, 19, 15, 15, 15, 20, 25, 26, 20, 28, 29, 20, 31, 32,
+                 20, 34, 35, 20, 37, 38, 21, 40, 41, 21, 43, 44, 21, 46, 47, 21, 49, 50, 21, 52, 53]
+ARM_JOINT_IDX = [21, 52, 53, 54, 71, 40, 41, 42, 72, 43, 44, 45, 73, 49, 50, 51, 74, 46, 47, 48, 75, 19]   # smplx_arm_corr.pkl['mano_joint']
+
+
+def smplx_batch_rodrigues(rot_vecs):
+    """smplx.lbs.batch_rodrigues: I + sin K + (1-cos) K^2 with angle = |r + 1e-8|."""
+    angle = torch.norm(rot_vecs + 1e-8, dim=1, keepdim=True)
+    rot_dir = rot_vecs / angle
+    cos, sin = torch.cos(angle)[:, None], torch.sin(angle)[:, None]
+    rx, ry, rz = torch.split(rot_dir, 1, dim=1)
+    zeros = torch.zeros_like(rx)
+    K = torch.cat([zeros, -rz, ry, rz, zeros, -rx, -ry, rx, zeros], dim=1).view(-1, 3, 3)
+    ident = torch.eye(3, dtype=rot_vecs.dtype)[None]
+    return ident + sin * K + (1 - cos) * torch.bmm(K, K)
+
+
+def smplxarm_forward(model, betas, global_orient, transl, right_hand_pose, right_wrist_pose):
+    """SMPLXARM.forward(..., return_type='mano_w_arm') on an ARM-SLICED model dict (the LBS of the other ~9400 body vertices is
+    discarded by the reference's final slice, body_models.py:2383-2390, and the joint regressor is folded into J_template /
+    J_shapedirs): v_template (Va,3), shapedirs (Va,3,20), posedirs (486, Va*3), J_template (55,3), J_shapedirs (55,3,20),
+    weights (Va,55), pose_mean (165,), tip_verts (5,) arm-local ids of the right thumb..pinky tips.
+    Returns verts (B,Va,3) mm, joints (B,22,3) mm."""
+    B = betas.shape[0]
+    dt = betas.dtype
+    full_pose = torch.zeros(B, 55, 3, dtype=dt)
+    full_pose[:, 0] = global_orient                                                   # :2304
+    full_pose[:, 21] = right_wrist_pose                                               # body_pose[:, 60:63], :2299-2301
+    full_pose[:, 40:55] = right_hand_pose.reshape(B, 15, 3)
+    full_pose = full_pose.reshape(B, 165) + model["pose_mean"][None]                  # :2315
+    shape_components = torch.cat([betas, torch.zeros(B, 10, dtype=dt)], dim=-1)       # expression defaults to zeros, :2323
+    v_shaped = model["v_template"][None] + torch.einsum("bl,mkl->bmk", shape_components, model["shapedirs"])
+    J = model["J_template"][None] + torch.einsum("bl,jkl->bjk", shape_components, model["J_shapedirs"])
+    rot_mats = smplx_batch_rodrigues(full_pose.view(-1, 3)).view(B, 55, 3, 3)
+    pose_feature = (rot_mats[:, 1:] - torch.eye(3, dtype=dt)).view(B, -1)
+    v_posed = v_shaped + torch.matmul(pose_feature, model["posedirs"]).view(B, -1, 3)
+    parents = SMPLX_PARENTS
+    rel = J.clone()
+    rel[:, 1:] = J[:, 1:] - J[:, parents[1:]]
+    tm = torch.cat([torch.cat([rot_mats, rel[..., None]], -1), torch.tensor([0., 0., 0., 1.], dtype=dt).expand(B, 55, 1, 4)], -2)
+    chain = [tm[:, 0]]
+    for i in range(1, 55):
+        chain.append(torch.matmul(chain[parents[i]], tm[:, i]))
+    transforms = torch.stack(chain, dim=1)
+    posed_joints = transforms[:, :, :3, 3]
+    jh = torch.cat([J, torch.zeros(B, 55, 1, dtype=dt)], -1)[..., None]
+    rel_t = transforms - torch.nn.functional.pad(torch.matmul(transforms, jh), [3, 0])
+    T = torch.matmul(model["weights"][None].expand(B, -1, -1), rel_t.view(B, 55, 16)).view(B, -1, 4, 4)
+    vh = torch.cat([v_posed, torch.ones(B, v_posed.shape[1], 1, dtype=dt)], -1)
+    verts = torch.matmul(T, vh[..., None])[:, :, :3, 0]
+    wrist = posed_joints[:, None, 21, :]
+    verts, joints = verts - wrist, posed_joints - wrist                                # :2342-2343
+    tips = verts[:, model["tip_verts"].long()]                                         # vertex_joint_selector: joints 71..75
+    allj = torch.cat([joints, torch.zeros(B, 16, 3, dtype=dt), tips], 1)               # 55..70 are not selected by ARM_JOINT_IDX
+    verts, allj = verts + transl[:, None], allj + transl[:, None]                      # :2378-2380
+    return verts * 1000.0, allj[:, ARM_JOINT_IDX] * 1000.0                             # :2383-2390

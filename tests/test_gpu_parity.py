@@ -182,3 +182,32 @@ def test_full_size_properties():
     a1, f1, r1 = eng.s["alpha"].clone(), eng.s["face_c"].clone(), eng.s["rgb"].clone()
     eng.forward_backward(True, True); torch.cuda.synchronize()
     assert torch.equal(a1, eng.s["alpha"]) and torch.equal(f1, eng.s["face_c"]) and torch.equal(r1, eng.s["rgb"])
+
+
+def test_smplx_arm_lbs_vs_oracle():
+    """SMPLXARM (HIP tree LBS) against the oracle's restatement of SMPLXARM.forward / smplx.lbs (PARITY UNPINNED: smplx is un-vendored)."""
+    from harp_amd import synth
+    from harp_amd.hand_models_harp.body_models import SMPLXARM
+    from oracle import harp_ref as H
+    m = synth.make_smplx_arm_model(seed=0)
+    corr = np.load("harp_amd/assets/arm_corr.npz")
+    layer = SMPLXARM(m, m["faces"], corr["mano_vert_from_arm"], device=DEV)
+    mt = {k: torch.from_numpy(v) for k, v in m.items()}
+    g = torch.Generator().manual_seed(0)
+    B = 5
+    args = [torch.randn(B, 10, generator=g) * 0.5, torch.randn(B, 3, generator=g) * 0.3, torch.randn(B, 3, generator=g) * 0.02,
+            torch.randn(B, 45, generator=g) * 0.3, torch.randn(B, 3, generator=g) * 0.3]
+    cpu = [a.clone().requires_grad_() for a in args]
+    v_ref, j_ref = H.smplxarm_forward(mt, *cpu)
+    wv, wj = torch.randn(v_ref.shape, generator=g), torch.randn(j_ref.shape, generator=g)
+    ((v_ref * wv).sum() + (j_ref * wj).sum()).backward()
+    dev = [a.clone().to(DEV).requires_grad_() for a in args]
+    v, j = layer(betas=dev[0], global_orient=dev[1], transl=dev[2], right_hand_pose=dev[3], right_wrist_pose=dev[4], return_type="mano_w_arm")
+    assert v.shape == (B, 1026, 3) and j.shape == (B, 22, 3)
+    assert torch.allclose(v.cpu(), v_ref.detach(), atol=5e-3) and torch.allclose(j.cpu(), j_ref.detach(), atol=5e-3)      # mm
+    ((v * wv.to(DEV)).sum() + (j * wj.to(DEV)).sum()).backward()
+    for a, b, name in zip(dev, cpu, ("betas", "global_orient", "transl", "right_hand_pose", "right_wrist_pose")):
+        assert rel(a.grad.cpu(), b.grad) < 2e-4, (name, rel(a.grad.cpu(), b.grad))
+    vm, jm = layer(betas=dev[0].detach(), global_orient=dev[1].detach(), transl=dev[2].detach(), right_hand_pose=dev[3].detach(),
+                   right_wrist_pose=dev[4].detach(), return_type="mano")
+    assert vm.shape == (B, 778, 3) and jm.shape == (B, 21, 3)
