@@ -104,7 +104,8 @@ SIGNATURES.update({
 class FrameTables(ctypes.Structure):
     """mirror of `harp_frame_tables` (include/harp_hip.h)"""
     _fields_ = ([(n, _vp) for n in ("pose", "rot", "trans", "cam", "shape", "light_positions", "amb_ratio", "g_pose", "g_rot", "g_trans",
-                                    "g_cam", "g_shape", "g_light_positions", "g_amb_ratio")] + [("share_light", _i)])
+                                    "g_cam", "g_shape", "g_light_positions", "g_amb_ratio")] + [("share_light", _i)] +
+                [("wrist_pose", _vp), ("g_wrist_pose", _vp), ("n_betas_out", _i)])
 
 
 _tp = ctypes.POINTER(FrameTables)

@@ -37,9 +37,11 @@ __global__ void frame_setup_fwd_kernel(const harp_frame_tables t, const int32_t*
   }
   if (b >= B) return;
   const int f = fid[b];
-  for (int k = 0; k < 3; ++k) pose48[b * 48 + k] = t.rot[f * 3 + k];
-  for (int k = 0; k < 45; ++k) pose48[b * 48 + 3 + k] = t.pose[f * 45 + k];
-  for (int k = 0; k < 10; ++k) betas[b * 10 + k] = t.shape[k];
+  const int ps = t.wrist_pose ? 51 : 48, ho = t.wrist_pose ? 6 : 3, nbo = t.n_betas_out > 0 ? t.n_betas_out : 10;
+  for (int k = 0; k < 3; ++k) pose48[b * ps + k] = t.rot[f * 3 + k];
+  if (t.wrist_pose) for (int k = 0; k < 3; ++k) pose48[b * ps + 3 + k] = t.wrist_pose[f * 3 + k];
+  for (int k = 0; k < 45; ++k) pose48[b * ps + ho + k] = t.pose[f * 45 + k];
+  for (int k = 0; k < nbo; ++k) betas[b * nbo + k] = (k < 10) ? t.shape[k] : 0.f;
   for (int k = 0; k < 3; ++k) trans_b[b * 3 + k] = t.trans[f * 3 + k];
   const float c0 = t.cam[f * 3], c1 = t.cam[f * 3 + 1], c2 = t.cam[f * 3 + 2];
   cam_T[b * 3] = -c1; cam_T[b * 3 + 1] = -c2; cam_T[b * 3 + 2] = 2.0f * focal / ((float)S * c0 + 1e-9f);
@@ -62,11 +64,13 @@ __global__ void frame_setup_bwd_kernel(const harp_frame_tables t, const int32_t*
   if (b >= B) return;
   const int f = fid[b];
   // duplicates of a frame inside one batch are legal -> atomics
+  const int ps = t.wrist_pose ? 51 : 48, ho = t.wrist_pose ? 6 : 3, nbo = t.n_betas_out > 0 ? t.n_betas_out : 10;
   if (g_pose48) {
-    if (t.g_rot) for (int k = 0; k < 3; ++k) atomicAdd(t.g_rot + f * 3 + k, g_pose48[b * 48 + k]);
-    if (t.g_pose) for (int k = 0; k < 45; ++k) atomicAdd(t.g_pose + f * 45 + k, g_pose48[b * 48 + 3 + k]);
+    if (t.g_rot) for (int k = 0; k < 3; ++k) atomicAdd(t.g_rot + f * 3 + k, g_pose48[b * ps + k]);
+    if (t.wrist_pose && t.g_wrist_pose) for (int k = 0; k < 3; ++k) atomicAdd(t.g_wrist_pose + f * 3 + k, g_pose48[b * ps + 3 + k]);
+    if (t.g_pose) for (int k = 0; k < 45; ++k) atomicAdd(t.g_pose + f * 45 + k, g_pose48[b * ps + ho + k]);
   }
-  if (g_betas && t.g_shape) for (int k = 0; k < 10; ++k) atomicAdd(t.g_shape + k, g_betas[b * 10 + k]);
+  if (g_betas && t.g_shape) for (int k = 0; k < 10; ++k) atomicAdd(t.g_shape + k, g_betas[b * nbo + k]);
   if (g_trans_b && t.g_trans) for (int k = 0; k < 3; ++k) atomicAdd(t.g_trans + f * 3 + k, g_trans_b[b * 3 + k]);
   if (g_cam_T && t.g_cam) {
     const float c0 = t.cam[f * 3];

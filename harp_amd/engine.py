@@ -65,25 +65,34 @@ class FitEngine:
     """
 
     def __init__(self, model, topo, verts_uvs, faces_uvs, uv_mask, input_params, img_size, focal_length, batch_size,
-                 device="cuda", self_shadow=True, share_light_position=True, tex_size=512, rank=0, world_size=1, seed=0):
+                 device="cuda", self_shadow=True, share_light_position=True, tex_size=512, rank=0, world_size=1, seed=0,
+                 use_arm=False, opt_arm_pose=False):
         self.dev = torch.device(device)
         self.S, self.focal, self.B = int(img_size), float(focal_length), int(batch_size)
         self.self_shadow, self.share_light = bool(self_shadow), bool(share_light_position)
         self.rank, self.world = rank, world_size
         self.topo = ops.DeviceTopology(topo, verts_uvs, faces_uvs, self.dev)
-        self.dm = ManoDeviceModel(model, self.dev)
+        self.use_arm, self.opt_arm_pose = bool(use_arm), bool(opt_arm_pose)
+        if self.use_arm:                                                              # SMPL-X right arm (config use_arm, utils/config_utils.py:6)
+            from .hand_models_harp.body_models import TreeDeviceModel
+            self.dm = TreeDeviceModel(model, self.dev)
+            self.n_joints, self.pose_stride, self.n_betas = 22, 51, self.dm.NB
+        else:
+            self.dm = ManoDeviceModel(model, self.dev)
+            self.n_joints, self.pose_stride, self.n_betas = 21, 48, 10
         T = input_params["pose"].shape[0]
         self.T, V = T, self.topo.V
         self.Ht = self.Wt = tex_size
         # ---- parameter arena: [coarse group | appearance group | not optimised]  (optimize_sequence.py:253-310)
-        spec = [("pose", (T, 45)), ("cam", (T, 3)), ("verts_disps", (V, 1)), ("shape", (10,)),
+        spec = [("pose", (T, 45)), ("cam", (T, 3)), ("verts_disps", (V, 1)), ("shape", (10,)), ("rot", (T, 3)), ("wrist_pose", (T, 3)),
                 ("light_positions", (T, 3)), ("amb_ratio", ()), ("texture", (1, tex_size, tex_size, 3)), ("normal_map", (1, tex_size, tex_size, 3)),
-                ("rot", (T, 3)), ("trans", (T, 3)), ("wrist_pose", (T, 3))]
+                ("trans", (T, 3))]
         self.arena = _Arena(spec, self.dev)
         self.p_buf, self.g_buf, self.m_buf, self.v_buf = (self.arena.alloc() for _ in range(4))
         self.params = {k: self.arena.view(self.p_buf, k) for k, _ in spec}
         self.grads = {k: self.arena.view(self.g_buf, k) for k, _ in spec}
-        self.coarse_span = self.arena.span("pose", "shape")
+        # rot / wrist_pose join the coarse group only under use_arm & opt_arm_pose (optimize_sequence.py:264-268, 279-284)
+        self.coarse_span = self.arena.span("pose", "wrist_pose" if (self.use_arm and self.opt_arm_pose) else "shape")
         self.app_span = self.arena.span("light_positions", "normal_map")
         self.opt_span = (self.coarse_span[0], self.app_span[0] + self.app_span[1] - self.coarse_span[0])
         with torch.no_grad():                                                         # init_params (optimize_sequence.py:181-250)
@@ -102,6 +111,9 @@ class FitEngine:
             setattr(t, k, _lib.ptr(self.params[k]))
             setattr(t, "g_" + k, _lib.ptr(self.grads[k]))
         t.share_light = int(self.share_light)
+        if self.use_arm:
+            t.wrist_pose, t.g_wrist_pose = _lib.ptr(self.params["wrist_pose"]), _lib.ptr(self.grads["wrist_pose"])
+        t.n_betas_out = self.n_betas
         self.tables = t
         # ---- Adam hyper-parameters on the device (coarse lr 1e-3, appearance lr 1e-2; torch defaults otherwise)
         self.hyper_np = np.zeros(2, dtype=[("lr", "f4"), ("beta1", "f4"), ("beta2", "f4"), ("eps", "f4"), ("grad_scale", "f4"),
@@ -134,10 +146,11 @@ class FitEngine:
         z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
         L = _lib.lib()
         self.s = s = {}
-        s["pose48"], s["betas"], s["trans_b"] = f(B, 48), f(B, 10), f(B, 3)
+        s["pose48"], s["betas"], s["trans_b"] = f(B, self.pose_stride), f(B, self.n_betas), f(B, 3)
         s["cam_R"], s["cam_T"], s["light_pos"], s["colors"] = f(B, 9), f(B, 3), f(B, 3), f(9)
-        s["lbs_ws"] = f(L.harp_lbs_mano_ws_floats(B))
-        s["verts_mm"], s["joints_mm"], s["joints_m"] = f(B, 778, 3), f(B, 21, 3), f(B, 21, 3)
+        V0, NJo = self.topo.V0, self.n_joints
+        s["lbs_ws"] = f(L.harp_lbs_tree_ws_floats(ctypes.byref(self.dm.struct), B) if self.use_arm else L.harp_lbs_mano_ws_floats(B))
+        s["verts_mm"], s["joints_mm"], s["joints_m"] = f(B, V0, 3), f(B, NJo, 3), f(B, NJo, 3)
         s["vs"], s["n1"], s["il1"], s["vd"], s["n2"], s["il2"] = f(B, V, 3), f(B, V, 3), f(B, V), f(B, V, 3), f(B, V, 3), f(B, V)
         s["ndc_c"], s["ndc_l"], s["centroid"], s["light_R"], s["light_T"] = f(B, V, 3), f(B, V, 3), f(B, 3), f(B, 9), f(B, 3)
         s["ws_c"] = ops.rasterize_workspace(B, self.topo.F, S, dev)
@@ -149,9 +162,9 @@ class FitEngine:
         # gradients (zeroed every step in ONE memset: they are carved from one flat buffer)
         gspec = [("g_alpha", (B, S, S)), ("g_rgb", (B, S, S, 3)), ("g_zl", (B, S, S)), ("g_vd", (B, V, 3)), ("g_n2", (B, V, 3)),
                  ("g_ndc_c", (B, V, 3)), ("g_ndc_l", (B, V, 3)), ("g_n1", (B, V, 3)), ("g_vs", (B, V, 3)), ("g_tmp", (B, V, 3)),
-                 ("g_v0", (B, 778, 3)), ("g_joints_m", (B, 21, 3)), ("g_joints_mm", (B, 21, 3)), ("g_light_pos", (B, 3)), ("g_colors", (9,)),
+                 ("g_v0", (B, V0, 3)), ("g_joints_m", (B, NJo, 3)), ("g_joints_mm", (B, NJo, 3)), ("g_light_pos", (B, 3)), ("g_colors", (9,)),
                  ("g_light_R", (B, 9)), ("g_light_T", (B, 3)), ("g_cam_R", (B, 9)), ("g_cam_T", (B, 3)), ("g_centroid", (B, 3)),
-                 ("g_pose48", (B, 48)), ("g_betas", (B, 10)), ("g_trans_b", (B, 3)), ("g_nmap_n", (self.Ht, self.Wt, 3))]
+                 ("g_pose48", (B, self.pose_stride)), ("g_betas", (B, self.n_betas)), ("g_trans_b", (B, 3)), ("g_nmap_n", (self.Ht, self.Wt, 3))]
         self.garena = _Arena(gspec, dev)
         self.gs_buf = self.garena.alloc()
         for k, _ in gspec:
@@ -177,9 +190,10 @@ class FitEngine:
         self._ck(L.harp_frame_setup_fwd(ctypes.byref(self.tables), p(fid), B, self.S, self.focal, int(self.self_shadow), p(s["pose48"]),
                                         p(s["betas"]), p(s["trans_b"]), p(s["cam_R"]), p(s["cam_T"]), p(s["light_pos"]), p(s["colors"]), st),
                  "frame_setup_fwd")
-        self._ck(L.harp_lbs_mano_fwd(ctypes.byref(self.dm.struct), p(s["pose48"]), p(s["betas"]), p(s["trans_b"]), B, p(s["lbs_ws"]),
-                                     p(s["verts_mm"]), p(s["joints_mm"]), st), "lbs_fwd")
-        self._ck(L.harp_scale(p(s["joints_mm"]), 1e-3, B * 63, p(s["joints_m"]), st), "scale")          # visualize.py:46
+        lbs_fwd = L.harp_lbs_tree_fwd if self.use_arm else L.harp_lbs_mano_fwd
+        self._ck(lbs_fwd(ctypes.byref(self.dm.struct), p(s["pose48"]), p(s["betas"]), p(s["trans_b"]), B, p(s["lbs_ws"]),
+                         p(s["verts_mm"]), p(s["joints_mm"]), st), "lbs_fwd")
+        self._ck(L.harp_scale(p(s["joints_mm"]), 1e-3, B * self.n_joints * 3, p(s["joints_m"]), st), "scale")          # visualize.py:46
         self._ck(L.harp_subdivide_fwd(p(s["verts_mm"]), p(tp.edges0), B, tp.V0, tp.E0, 1e-3, p(s["vs"]), st), "subdivide_fwd")
         self._ck(L.harp_vertex_normals_fwd(p(s["vs"]), p(tp.faces), p(tp.vf_off), p(tp.vf_idx), B, tp.V, p(s["n1"]), p(s["il1"]),
                                            p(self.params["verts_disps"]), p(s["vd"]), st), "normals_displace_fwd")
@@ -237,7 +251,7 @@ class FitEngine:
         # ---- losses and their gradients
         if coarse:
             self._ck(L.harp_image_l1(p(s["alpha"]), p(self.y_sil), None, p(self.tfid), B, S * S, 1, wp(0), lp(0), p(s["g_alpha"]), st), "l1_sil")
-            self._ck(L.harp_kps_loss(p(self.init_joints), p(self.fid), p(s["joints_m"]), B, 21, wp(1), lp(1), p(s["g_joints_m"]), st), "kps")
+            self._ck(L.harp_kps_loss(p(self.init_joints), p(self.fid), p(s["joints_m"]), B, self.n_joints, wp(1), lp(1), p(s["g_joints_m"]), st), "kps")
             self._ck(L.harp_sum_squares(p(self.params["verts_disps"]), V, wp(2), lp(2), p(self.grads["verts_disps"]), st), "disp_reg")
             self._ck(L.harp_mesh_regularizers(p(s["vd"]), p(self.ref_verts), p(tp.nbr_off), p(tp.nbr_idx), p(tp.nc_pairs), p(tp.vp_off), p(tp.vp_idx), B, V,
                                               tp.nc_pairs.shape[0], tp.E, wp(3), lp(3), p(s["g_vd"]), st), "mesh_reg")
@@ -272,9 +286,10 @@ class FitEngine:
         self._ck(L.harp_vertex_normals_bwd(p(s["vs"]), p(tp.faces), p(tp.vf_off), p(tp.vf_idx), B, V, p(s["n1"]), p(s["il1"]), p(s["g_n1"]),
                                            p(s["g_tmp"]), p(s["g_vd"]), st), "normals_bwd1")        # g_vs aliases g_vd (vd = vs + n d)
         self._ck(L.harp_subdivide_bwd(p(s["g_vd"]), p(tp.sub_off), p(tp.sub_idx), B, tp.V0, V, 1e-3, p(s["g_v0"]), st), "subdivide_bwd")
-        self._ck(L.harp_scale(p(s["g_joints_m"]), 1e-3, B * 63, p(s["g_joints_mm"]), st), "scale_bwd")
-        self._ck(L.harp_lbs_mano_bwd(ctypes.byref(self.dm.struct), p(s["pose48"]), p(s["betas"]), p(s["trans_b"]), B, p(s["lbs_ws"]),
-                                     p(s["g_v0"]), p(s["g_joints_mm"]), p(s["g_pose48"]), p(s["g_betas"]), p(s["g_trans_b"]), st), "lbs_bwd")
+        self._ck(L.harp_scale(p(s["g_joints_m"]), 1e-3, B * self.n_joints * 3, p(s["g_joints_mm"]), st), "scale_bwd")
+        lbs_bwd = L.harp_lbs_tree_bwd if self.use_arm else L.harp_lbs_mano_bwd
+        self._ck(lbs_bwd(ctypes.byref(self.dm.struct), p(s["pose48"]), p(s["betas"]), p(s["trans_b"]), B, p(s["lbs_ws"]),
+                         p(s["g_v0"]), p(s["g_joints_mm"]), p(s["g_pose48"]), p(s["g_betas"]), p(s["g_trans_b"]), st), "lbs_bwd")
         self._ck(L.harp_frame_setup_bwd(ctypes.byref(self.tables), p(self.fid), B, S, self.focal, int(self.self_shadow), p(s["g_pose48"]),
                                         p(s["g_betas"]), p(s["g_trans_b"]), p(s["g_cam_T"]), p(s["g_light_pos"]) if app else None,
                                         p(s["g_colors"]) if app else None, st), "frame_setup_bwd")

@@ -206,6 +206,10 @@ typedef struct harp_frame_tables {
   const float *amb_ratio;                  /* (1,) pre-sigmoid */
   float *g_pose, *g_rot, *g_trans, *g_cam, *g_shape, *g_light_positions, *g_amb_ratio;   /* gradient arena (+=), NULL = skip */
   int share_light;                         /* configs["share_light_position"] */
+  /* SMPL-X arm path (use_arm): pose rows become [rot(3), wrist_pose(3), pose(45)] and betas are padded with zeros to n_betas_out */
+  const float *wrist_pose;                 /* (T,3) or NULL (MANO path: rows are [rot(3), pose(45)]) */
+  float *g_wrist_pose;
+  int n_betas_out;                         /* 10 (MANO) or 20 (SMPL-X: 10 betas + 10 zero expression coefficients) */
 } harp_frame_tables;
 int harp_frame_setup_fwd(const harp_frame_tables* t, const int32_t* fid, int B, int S, float focal, int self_shadow, float* pose48,
                          float* betas, float* trans_b, float* cam_R, float* cam_T, float* light_pos, float* colors,

@@ -104,13 +104,17 @@ def mano_forward(model, pose_coeffs, betas, trans):
 # ----------------------------------------------------------------------------------------------
 # Scene assembly (utils/visualize.py:16-108)
 # ----------------------------------------------------------------------------------------------
-def prepare_mesh(params, fid, model, topo):
-    """utils/visualize.py:16-88, MANO branch, with subdivision + normal displacement.
-    topo: dict with edges0 (E0,2), faces (F,3) long (subdivided). Returns joints (B,21,3) m, verts (B,V,3) m."""
+def prepare_mesh(params, fid, model, topo, use_arm=False):
+    """utils/visualize.py:16-88 (MANO branch :42-44 or SMPL-X arm branch :37-40), with subdivision + normal displacement.
+    topo: dict with edges0 (E0,2), faces (F,3) long (subdivided). Returns joints (B,21|22,3) m, verts (B,V,3) m."""
     B = fid.shape[0]
     pose_b, rot_b = params["pose"][fid], params["rot"][fid]                                          # :26-27
-    verts, joints = mano_forward(model, torch.cat((rot_b, pose_b), 1), params["shape"].repeat([B, 1]),
-                                 params["trans"][fid])                                               # :42-44
+    if use_arm:
+        verts, joints = smplxarm_forward(model, params["shape"].repeat([B, 1]), rot_b, params["trans"][fid], pose_b,
+                                         params["wrist_pose"][fid])                                  # :37-40
+    else:
+        verts, joints = mano_forward(model, torch.cat((rot_b, pose_b), 1), params["shape"].repeat([B, 1]),
+                                     params["trans"][fid])                                           # :42-44
     verts, joints = verts / 1000.0, joints / 1000.0                                                  # :45-46
     e = topo["edges0"]
     verts = torch.cat([verts, verts[:, e].mean(2)], 1)                                               # SubdivideMeshes (:52)
@@ -288,18 +292,18 @@ LOSS_WEIGHTS = {"silhouette": 7.0, "kps_anchor": 10.0, "vert_disp_reg": 2.0, "no
 
 
 def step_losses(params, fid, model, topo, targets, S, focal, ref_verts, dist_albedo, dist_normal,
-                coarse=True, app=True, self_shadow=True):
+                coarse=True, app=True, self_shadow=True, use_arm=False):
     """Loop body optimize_sequence.py:446-558 (VGG term excluded: SURVEY §8(f)). Returns (dict, weighted sum,
     aux dict with images)."""
     y_true, y_sil_true, y_sil_col = targets["y_true"][fid], targets["y_sil"][fid], targets["y_sil_col"][fid]
-    joints, verts = prepare_mesh(params, fid, model, topo)
+    joints, verts = prepare_mesh(params, fid, model, topo, use_arm=use_arm)
     cam = params["cam"][fid]
     y_sil_pred = render_silhouette(verts, topo["faces"], cam, S, focal)
     y_pred = render_rgb(verts, topo, params, cam, S, focal, self_shadow=self_shadow)
     loss = {}
     if coarse:
         loss["silhouette"] = F.l1_loss(y_sil_true, y_sil_pred)                                      # :519
-        loss["kps_anchor"] = kps_loss(params["init_joints"][fid], joints)                           # :524
+        loss["kps_anchor"] = kps_loss(params["init_joints"][fid], joints, use_arm=use_arm)          # :524
         loss["vert_disp_reg"] = torch.sum(params["verts_disps"] ** 2.0)                             # :533
         loss["laplacian"] = P.mesh_laplacian_smoothing_uniform(verts, topo["nbr_off"], topo["nbr_idx"])   # :536
         loss["normal"] = P.mesh_normal_consistency(verts, topo["nc_pairs"])                         # :537

@@ -211,3 +211,63 @@ def test_smplx_arm_lbs_vs_oracle():
     vm, jm = layer(betas=dev[0].detach(), global_orient=dev[1].detach(), transl=dev[2].detach(), right_hand_pose=dev[3].detach(),
                    right_wrist_pose=dev[4].detach(), return_type="mano")
     assert vm.shape == (B, 778, 3) and jm.shape == (B, 21, 3)
+
+
+def test_full_step_smplx_arm():
+    """use_arm=True path of the engine (SMPL-X right-arm LBS, 4083-vertex arm mesh, 22 joints, wrist_pose/rot optimised when
+    opt_arm_pose) vs the oracle."""
+    from harp_amd import synth
+    from harp_amd.engine import FitEngine, LOSS_NAMES
+    from oracle import harp_ref as H
+    torch.manual_seed(0)
+    tpl = synth.load_template("arm")
+    topo_np = synth.build_topology(tpl["faces0"], 1026)
+    m = synth.make_smplx_arm_model(tpl, seed=0)
+    mt = {k: torch.from_numpy(v) for k, v in m.items()}
+    topo = {k: torch.from_numpy(np.asarray(v)).long() if isinstance(v, np.ndarray) else v for k, v in topo_np.items()}
+    T, S, B = 3, 128, 2
+    focal = 1000.0 * S / 224.0
+    g = torch.Generator().manual_seed(1)
+    c = m["v_template"].mean(0)
+    seq = dict(pose=torch.randn(T, 45, generator=g) * 0.15, rot=torch.randn(T, 3, generator=g) * 0.2, trans=torch.randn(T, 3, generator=g) * 0.01,
+               shape=torch.randn(T, 10, generator=g) * 0.3,
+               cam=torch.tensor([[2 * focal / (S * 1.6), -float(c[0]), -float(c[1])]]).repeat(T, 1) + torch.randn(T, 3, generator=g) * 0.005)
+    wrist = torch.randn(T, 3, generator=g) * 0.2
+    P0 = dict(seq, shape=seq["shape"].mean(0), wrist_pose=wrist, verts_disps=torch.randn(4083, 1, generator=g) * 0.001,
+              light_positions=torch.tensor(((-0.5, -0.5, -0.5),)).repeat(T, 1), amb_ratio=torch.tensor(0.4),
+              texture=torch.rand(1, 512, 512, 3, generator=g) * 0.5 + 0.3, normal_map=torch.tensor([0., 0., 1.]).repeat(1, 512, 512, 1))
+    with torch.no_grad():
+        _, j = H.smplxarm_forward(mt, P0["shape"].repeat(T, 1), seq["rot"], seq["trans"], seq["pose"], wrist)
+    seq["joints"] = j[:, :21] + 2.0
+    uv_mask = torch.from_numpy(tpl["uv_mask"]).double() / 255
+    eng = FitEngine(m, topo_np, tpl["verts_uvs"], tpl["faces_uvs"], uv_mask.float(), seq, S, focal, B, device=DEV, use_arm=True, opt_arm_pose=True)
+    with torch.no_grad():
+        for k in ("wrist_pose", "verts_disps", "texture"):
+            eng.params[k].copy_(P0[k])
+    eng.compute_reference_mesh()
+    tg = dict(y_true=torch.rand(T, S, S, 3), y_sil=(torch.rand(T, S, S) > 0.5).float(), y_sil_col=(torch.rand(T, S, S) > 0.4).float())
+    eng.set_targets(tg["y_true"], tg["y_sil"], tg["y_sil_col"])
+    keys = ("pose", "cam", "verts_disps", "shape", "light_positions", "amb_ratio", "texture", "normal_map", "rot", "trans", "wrist_pose")
+    P = {k: eng.params[k].detach().cpu().clone().requires_grad_() for k in keys}
+    P.update(verts_uvs=torch.from_numpy(tpl["verts_uvs"]), faces_uvs=torch.from_numpy(tpl["faces_uvs"]).long(), uv_mask=uv_mask, init_joints=seq["joints"])
+    fid = torch.tensor([2, 0])
+    eng.fid.copy_(fid.int().to(DEV)); eng.tfid.copy_(fid.int().to(DEV))
+    eng.draw_texture_offsets(); eng.set_stage(True, True)
+    with torch.no_grad():
+        _, rv = H.prepare_mesh(P, torch.tensor([0]), mt, topo, use_arm=True)
+    loss, total, aux = H.step_losses(P, fid, mt, topo, tg, S, focal, rv, eng.dist_albedo.cpu().long(), eng.dist_normal.cpu().long(), use_arm=True)
+    total.backward()
+    eng.forward_backward(True, True)
+    torch.cuda.synchronize()
+    lv = eng.losses()
+    assert 0.02 < (eng.s["face_c"] >= 0).float().mean() < 0.9
+    for k in LOSS_NAMES:
+        assert abs(lv[k] - loss[k].item()) <= 2e-5 * abs(loss[k].item()) + 1e-8, (k, lv[k], loss[k].item())
+    for k in keys:
+        assert rel(eng.grads[k].cpu(), P[k].grad) < 3e-3, (k, rel(eng.grads[k].cpu(), P[k].grad))
+    # opt_arm_pose: rot and wrist_pose are inside the coarse Adam span and move; trans never does
+    before = {k: eng.params[k].clone() for k in ("rot", "wrist_pose", "trans")}
+    eng.step(fid, True, True, use_graph=False)
+    torch.cuda.synchronize()
+    assert not torch.equal(eng.params["rot"], before["rot"]) and not torch.equal(eng.params["wrist_pose"], before["wrist_pose"])
+    assert torch.equal(eng.params["trans"], before["trans"])
