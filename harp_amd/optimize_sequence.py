@@ -17,7 +17,7 @@ from .utils.visualize import MeshSubdivider
 def get_mesh_subdivider(hand_layer, use_arm=False, device="cuda"):
     """optimize_sequence.py:67-89"""
     if use_arm:
-        raise NotImplementedError("SMPL-X arm template: SURVEY.md §8 row a2 (next)")
+        return MeshSubdivider(hand_layer.right_arm_faces_tensor, 1026, device)
     return MeshSubdivider(hand_layer.th_faces, 778, device)
 
 
@@ -88,16 +88,18 @@ def optimize_hand_sequence(configs, input_params, images_dataset, val_params, va
                            seed=0):
     """Fit the sequence (optimize_sequence.py:313-596).  Returns the parameter dict in the reference's checkpoint layout.
     `images_dataset[i]` -> (fid, y_true (S,S,3), y_sil (S,S,1), y_sil_eroded (S,S,1)) like utils/data_util.ImagesDataset."""
-    if configs["use_arm"] or configs["model_type"] != "harp" or configs["known_appearance"] or configs["start_from"]:
-        raise NotImplementedError("round 1: MANO 'harp' fitting from scratch (SURVEY.md §8; resume/known-appearance are §8f rows)")
+    if configs["model_type"] != "harp" or configs["known_appearance"] or configs["start_from"]:
+        raise NotImplementedError("round 1: 'harp' fitting from scratch (SURVEY.md §8; resume/known-appearance are §8f rows)")
     S, T = configs["img_size"], input_params["pose"].shape[0]
-    faces0 = np.asarray(hand_layer.th_faces.detach().cpu())
-    topo = build_topology(faces0, 778)
+    use_arm = bool(configs["use_arm"])
+    faces0 = np.asarray((hand_layer.right_arm_faces_tensor if use_arm else hand_layer.th_faces).detach().cpu())
+    topo = build_topology(faces0, 1026 if use_arm else 778)
     if uv_mask is None:
         uv_mask = load_uv_mask(configs, (512, 512))
     eng = FitEngine(hand_layer._model_np, topo, torch.as_tensor(VERTS_UVS).reshape(-1, 2), torch.as_tensor(FACES_UVS).reshape(-1, 3),
                     torch.as_tensor(uv_mask).float(), input_params, S, configs["focal_length"], batch_size, device=device,
-                    self_shadow=configs["self_shadow"], share_light_position=configs["share_light_position"], seed=seed)
+                    self_shadow=configs["self_shadow"], share_light_position=configs["share_light_position"], seed=seed,
+                    use_arm=use_arm, opt_arm_pose=bool(configs.get("opt_arm_pose", False)))
     items = [images_dataset[i] for i in range(len(images_dataset))]
     eng.set_targets(torch.stack([torch.as_tensor(it[1]) for it in items]), torch.stack([torch.as_tensor(it[2]).reshape(S, S) for it in items]),
                     torch.stack([torch.as_tensor(it[3]).reshape(S, S) for it in items]))
@@ -137,5 +139,5 @@ def export_params(eng, input_params, VERTS_UVS, FACES_UVS, uv_mask, hand_layer):
     out = {k: eng.params[k].detach().clone() for k in ("trans", "pose", "rot", "shape", "wrist_pose", "verts_disps", "texture", "normal_map",
                                                        "light_positions", "amb_ratio", "cam")}
     out.update(init_joints=input_params["joints"], verts_rgb=torch.ones(778, 3), verts_uvs=VERTS_UVS, faces_uvs=FACES_UVS,
-               uv_mask=torch.as_tensor(uv_mask), mesh_faces=hand_layer.th_faces)
+               uv_mask=torch.as_tensor(uv_mask), mesh_faces=getattr(hand_layer, "right_arm_faces_tensor", getattr(hand_layer, "th_faces", None)))
     return out

@@ -28,15 +28,22 @@ def prepare_mesh(params, fid, mano_layer, verts_textures, mesh_subdivider, globa
                  shared_texture=True, use_arm=False):
     """utils/visualize.py:16-88 for the MANO + UV-texture path HARP runs (verts_textures=False, shared_texture=True, model_type
     'harp').  Returns (hand_joints (B,21,3) m, hand_verts (B,V,3) m, faces (B,F,3), textures)."""
-    if use_arm or configs.get("model_type", "harp") != "harp" or verts_textures:
-        raise NotImplementedError("round 1 covers the MANO / UV-texture path (SURVEY.md §8 a1, a3); SMPL-X arm is the next row (a2)")
+    if configs.get("model_type", "harp") != "harp" or verts_textures:
+        raise NotImplementedError("the 'harp' model type with UV textures is the path in scope (SURVEY.md §8)")
     if mesh_subdivider is None:
         raise NotImplementedError("HARP always subdivides (optimize_sequence.py:344-349)")
     fid = torch.as_tensor(fid).long()
     B = fid.shape[0]
     pose_batch, rot_batch = params["pose"][fid.to(params["pose"].device)], params["rot"][fid.to(params["rot"].device)]   # :26-27 (global_pose forced False, :20)
-    hand_verts, hand_joints = mano_layer(torch.cat((rot_batch, pose_batch), 1).to(device), params["shape"].repeat([B, 1]).to(device),
-                                         params["trans"][fid.to(params["trans"].device)].to(device))                     # :42-44
+    trans_batch = params["trans"][fid.to(params["trans"].device)].to(device)
+    if use_arm:
+        hand_verts, hand_joints = mano_layer(betas=params["shape"].repeat([B, 1]).to(device), global_orient=rot_batch.to(device),
+                                             transl=trans_batch, right_hand_pose=pose_batch.to(device),
+                                             right_wrist_pose=params["wrist_pose"][fid.to(params["wrist_pose"].device)].to(device),
+                                             return_type="mano_w_arm")                                                   # :37-40
+    else:
+        hand_verts, hand_joints = mano_layer(torch.cat((rot_batch, pose_batch), 1).to(device), params["shape"].repeat([B, 1]).to(device),
+                                             trans_batch)                                                                # :42-44
     hand_joints = hand_joints / 1000.0                                                                                   # :46
     topo = mesh_subdivider.topo
     vs = ops.subdivide(hand_verts, topo, 1.0 / 1000.0)                                                                  # :45, :50-52
