@@ -271,3 +271,31 @@ def test_full_step_smplx_arm():
     torch.cuda.synchronize()
     assert not torch.equal(eng.params["rot"], before["rot"]) and not torch.equal(eng.params["wrist_pose"], before["wrist_pose"])
     assert torch.equal(eng.params["trans"], before["trans"])
+
+
+@pytest.mark.parametrize("S,B", [(100, 1), (448, 1), (72, 3)])
+def test_rasterizer_odd_sizes(sc, S, B):
+    """image sides that are not multiples of the 16-px tile / 64-px super-tile (448 is the reference's default img_size), ragged
+    last tiles, single-frame batches; plus a frame whose hand is pushed mostly off-screen."""
+    from harp_amd import ops
+    from oracle import harp_ref as H, p3d_like as P
+    focal, topo = 1000.0 * S / 224.0, sc["topo"]
+    params = dict(pose=sc["seq"]["pose"], rot=sc["seq"]["rot"], trans=sc["seq"]["trans"], shape=sc["seq"]["shape"].mean(0),
+                  verts_disps=torch.zeros(3093, 1))
+    fid = torch.arange(B)
+    cam = sc["seq"]["cam"][fid].clone()
+    cam[0, 1] += 0.09                                  # frame 0: shifted towards / past the image border
+    with torch.no_grad():
+        _, v = H.prepare_mesh(params, fid, sc["model"], topo)
+        R, T = H.camera_RT(cam, S, focal)
+        _, ndc = P.world_to_ndc(v, R, T, focal, (S / 2, S / 2), S)
+    p2f, zb, bary, d = P.rasterize_meshes(ndc, topo["faces"], S, ops.SIL_BLUR, 50)
+    a_ref = P.sigmoid_alpha_blend(p2f, d, ops.SIL_SIGMA)
+    p2f1, zb1, _, _ = P.rasterize_meshes(ndc, topo["faces"], S, 0.0, 1)
+    fid_ref = torch.where(p2f1[..., 0] >= 0, p2f1[..., 0] % topo["faces"].shape[0], p2f1[..., 0]).int()
+    f, z, a, _ = ops.rasterize_fwd(ndc.to(DEV).contiguous(), topo["faces"].int().to(DEV), S, soft=True, blur_radius=ops.SIL_BLUR, sigma=ops.SIL_SIGMA)
+    assert f.shape == (B, S, S)
+    assert (f.cpu() != fid_ref).float().mean() < 2e-4
+    assert ((a.cpu() - a_ref).abs() > 1e-4).float().mean() < 1e-3
+    m = f.cpu() == fid_ref
+    assert (z.cpu() - zb1[..., 0])[m].abs().max() < 1e-5
