@@ -249,8 +249,14 @@ def main():
                "harp_image_l1": parts["S2"] * (12 + 12 + 4 + 12) * eng.B,
                "harp_depth_bwd": (geom_pos + parts["S2"] * 8 + parts["V"] * 12) * eng.B}
         ach = alg[dom] / (kt[dom] * 1e-3) / 1e9
+        # HBM traffic per launch comes from PMC counters, which cannot be read in-process: the last rocprofv3 FETCH_SIZE / WRITE_SIZE
+        # passes over this same command are committed as profiles/traffic_latest.json (see its _source field)
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+        if os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get(dom)
         out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                           "traffic": None, "algorithmic_bytes_per_launch": alg[dom], "avg_ms": kt[dom],
+                           "traffic": traffic, "algorithmic_bytes_per_launch": alg[dom], "avg_ms": kt[dom],
                            "kernel_ms": kt, "step_algorithmic_bytes": a_frame * eng.B + a_step,
                            "step_frac_of_hbm_roofline": (a_frame * eng.B + a_step) / (dt / args.steps) / 1e9 / HBM_PEAK_GBS}
         if not args.no_cpu_baseline:
