@@ -119,11 +119,13 @@ def kernel_roofline(eng, steps):
         orig[n] = getattr(L, n)
         setattr(L, n, Timed(n, orig[n]))
     try:
+        eng.overlap = False          # one stream: event pairs then bracket exactly one kernel group each
         for i in range(steps):
             fid = (torch.arange(eng.B) + i * eng.B) % (eng.T // eng.world) + eng.target_offset
             eng.step(fid, True, True, use_graph=False)
         torch.cuda.synchronize()
     finally:
+        eng.overlap = True
         for n in names:
             setattr(L, n, orig[n])
     ms = {n: [a.elapsed_time(b) for a, b in v] for n, v in rec.items()}

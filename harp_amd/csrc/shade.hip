@@ -130,7 +130,7 @@ struct Frag {
 };
 
 template <bool BWD>
-__global__ void __launch_bounds__(256) shade_kernel(const harp_shade_args A) {
+__global__ void __launch_bounds__(256, 3) shade_kernel(const harp_shade_args A) {
   __shared__ float s_red[32];
   // per-vertex accumulators: 0-2 g_verts, 3-5 g_vnormals, 6-8 g_ndc
   __shared__ VertexAccum<BWD ? 512 : 1, 9> s_acc;

@@ -169,6 +169,8 @@ class FitEngine:
         self.gs_buf = self.garena.alloc()
         for k, _ in gspec:
             s[k] = self.garena.view(self.gs_buf, k)
+        # g_alpha and g_rgb (the first two segments, 4/5 of the slab) are fully overwritten by harp_image_l1: only the rest is zeroed
+        self.gs_zero = self.gs_buf[self.garena.offsets["g_zl"][0]:]
         self._shade_args = None
 
     def set_targets(self, y_true, y_sil, y_sil_col, frame_offset=0):
@@ -225,74 +227,96 @@ class FitEngine:
         """Enqueue forward + losses + backward for the first B (default: batch_size) frames in self.fid; gradients land in
         self.g_buf, loss terms in self.loss_vec[:9] (unweighted, order LOSS_NAMES)."""
         B = self.B if B is None else int(B)
-        L, s, p, st, tp, S = _lib.lib(), self.s, _lib.ptr, _lib.stream(), self.topo, self.S
+        L, s, p, ST, tp, S = _lib.lib(), self.s, _lib.ptr, _lib.stream, self.topo, self.S
+        cur, side = torch.cuda.current_stream(), self._side_stream()
         V, F = tp.V, tp.F
         w = self.w_vec
         wp = lambda i: w.data_ptr() + 4 * i
         lp = lambda i: self.loss_vec.data_ptr() + 4 * i
         self.g_buf.zero_()
-        self.gs_buf.zero_()
+        self.gs_zero.zero_()
         self.loss_vec.zero_()
         self._mesh_forward(self.fid, B)
-        # ---- camera view: projection + fused K=1 / soft-silhouette raster
-        self._ck(L.harp_project_fwd(p(s["vd"]), p(s["cam_R"]), p(s["cam_T"]), B, V, self.focal, S / 2.0, S / 2.0, S, p(s["ndc_c"]), st), "project")
-        self._ck(L.harp_rasterize_fwd(p(s["ndc_c"]), p(tp.faces), B, V, F, S, 1, ops.SIL_BLUR, ops.SIL_SIGMA, p(s["ws_c"]), p(s["face_c"]),
-                                      None, p(s["alpha"]), st), "raster_cam")
-        if app:
-            if self.self_shadow:
-                self._ck(L.harp_centroid(p(s["vd"]), B, V, p(s["centroid"]), st), "centroid")
-                self._ck(L.harp_light_setup_fwd(p(s["centroid"]), p(s["light_pos"]), B, p(s["light_R"]), p(s["light_T"]), st), "light_setup")
-                self._ck(L.harp_project_fwd(p(s["vd"]), p(s["light_R"]), p(s["light_T"]), B, V, self.focal, S / 2.0, S / 2.0, S, p(s["ndc_l"]), st), "project_l")
-                self._ck(L.harp_rasterize_fwd(p(s["ndc_l"]), p(tp.faces), B, V, F, S, 0, 0.0, 1.0, p(s["ws_l"]), p(s["face_l"]), p(s["zl"]), None, st),
+        # ---- the light-view chain (centroid -> light camera -> projection -> K=1 raster) is independent of the camera-view chain:
+        #      it runs on a second HIP stream so the two latency-bound rasterisations overlap (fork / join is captured into the graph)
+        shadow = app and self.self_shadow
+        if not getattr(self, "overlap", True):
+            side = cur                                   # single-stream mode (used when individual kernels are timed with events)
+        if shadow:
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                self._ck(L.harp_centroid(p(s["vd"]), B, V, p(s["centroid"]), ST()), "centroid")
+                self._ck(L.harp_light_setup_fwd(p(s["centroid"]), p(s["light_pos"]), B, p(s["light_R"]), p(s["light_T"]), ST()), "light_setup")
+                self._ck(L.harp_project_fwd(p(s["vd"]), p(s["light_R"]), p(s["light_T"]), B, V, self.focal, S / 2.0, S / 2.0, S, p(s["ndc_l"]), ST()), "project_l")
+                self._ck(L.harp_rasterize_fwd(p(s["ndc_l"]), p(tp.faces), B, V, F, S, 0, 0.0, 1.0, p(s["ws_l"]), p(s["face_l"]), p(s["zl"]), None, ST()),
                          "raster_light")
-            self._ck(L.harp_normalize3_fwd(p(self.params["normal_map"]), self.Ht * self.Wt, p(s["nmap_n"]), st), "normalize3")
+        # ---- camera view: projection + fused K=1 / soft-silhouette raster
+        self._ck(L.harp_project_fwd(p(s["vd"]), p(s["cam_R"]), p(s["cam_T"]), B, V, self.focal, S / 2.0, S / 2.0, S, p(s["ndc_c"]), ST()), "project")
+        self._ck(L.harp_rasterize_fwd(p(s["ndc_c"]), p(tp.faces), B, V, F, S, 1, ops.SIL_BLUR, ops.SIL_SIGMA, p(s["ws_c"]), p(s["face_c"]),
+                                      None, p(s["alpha"]), ST()), "raster_cam")
+        if coarse:
+            self._ck(L.harp_image_l1(p(s["alpha"]), p(self.y_sil), None, p(self.tfid), B, S * S, 1, wp(0), lp(0), p(s["g_alpha"]), ST()), "l1_sil")
+            # the silhouette backward only needs g_alpha and the camera-view workspace: it overlaps with shading on the side stream
+            if shadow:
+                cur.wait_stream(side)                   # join the light chain first (the side stream is reused)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                self._ck(L.harp_silhouette_bwd(p(tp.faces), B, V, F, S, ops.SIL_BLUR, ops.SIL_SIGMA, p(s["ws_c"]), p(s["alpha"]), p(s["g_alpha"]),
+                                               p(s["g_ndc_c"]), ST()), "silhouette_bwd")
+        elif shadow:
+            cur.wait_stream(side)
+        if app:
+            self._ck(L.harp_normalize3_fwd(p(self.params["normal_map"]), self.Ht * self.Wt, p(s["nmap_n"]), ST()), "normalize3")
             a = self._shade_struct(B, app)
-            self._ck(L.harp_shade_fwd(ctypes.byref(a), st), "shade_fwd")
+            self._ck(L.harp_shade_fwd(ctypes.byref(a), ST()), "shade_fwd")
         # ---- losses and their gradients
         if coarse:
-            self._ck(L.harp_image_l1(p(s["alpha"]), p(self.y_sil), None, p(self.tfid), B, S * S, 1, wp(0), lp(0), p(s["g_alpha"]), st), "l1_sil")
-            self._ck(L.harp_kps_loss(p(self.init_joints), p(self.fid), p(s["joints_m"]), B, self.n_joints, wp(1), lp(1), p(s["g_joints_m"]), st), "kps")
-            self._ck(L.harp_sum_squares(p(self.params["verts_disps"]), V, wp(2), lp(2), p(self.grads["verts_disps"]), st), "disp_reg")
+            self._ck(L.harp_kps_loss(p(self.init_joints), p(self.fid), p(s["joints_m"]), B, self.n_joints, wp(1), lp(1), p(s["g_joints_m"]), ST()), "kps")
+            self._ck(L.harp_sum_squares(p(self.params["verts_disps"]), V, wp(2), lp(2), p(self.grads["verts_disps"]), ST()), "disp_reg")
             self._ck(L.harp_mesh_regularizers(p(s["vd"]), p(self.ref_verts), p(tp.nbr_off), p(tp.nbr_idx), p(tp.nc_pairs), p(tp.vp_off), p(tp.vp_idx), B, V,
-                                              tp.nc_pairs.shape[0], tp.E, wp(3), lp(3), p(s["g_vd"]), st), "mesh_reg")
+                                              tp.nc_pairs.shape[0], tp.E, wp(3), lp(3), p(s["g_vd"]), ST()), "mesh_reg")
         if app:
-            self._ck(L.harp_image_l1(p(s["rgb"]), p(self.y_true), p(self.y_sil_col), p(self.tfid), B, S * S * 3, 3, wp(6), lp(6), p(s["g_rgb"]), st),
+            self._ck(L.harp_image_l1(p(s["rgb"]), p(self.y_true), p(self.y_sil_col), p(self.tfid), B, S * S * 3, 3, wp(6), lp(6), p(s["g_rgb"]), ST()),
                      "l1_photo")
             self._ck(L.harp_texture_smooth_reg(p(self.params["texture"]), p(self.dist_albedo), p(self.uv_mask), self.Ht, self.Wt, wp(7), lp(7),
-                                               p(self.grads["texture"]), st), "albedo_reg")
-            self._ck(L.harp_close_to_z_reg(p(self.params["normal_map"]), self.Ht, self.Wt, 0.2, wp(8), lp(8), p(self.grads["normal_map"]), st), "close_z")
+                                               p(self.grads["texture"]), ST()), "albedo_reg")
+            self._ck(L.harp_close_to_z_reg(p(self.params["normal_map"]), self.Ht, self.Wt, 0.2, wp(8), lp(8), p(self.grads["normal_map"]), ST()), "close_z")
             self._ck(L.harp_texture_smooth_reg(p(self.params["normal_map"]), p(self.dist_normal), p(self.uv_mask), self.Ht, self.Wt, wp(8), lp(8),
-                                               p(self.grads["normal_map"]), st), "normal_smooth")
+                                               p(self.grads["normal_map"]), ST()), "normal_smooth")
         # ---- backward
         if app:
-            self._ck(L.harp_shade_bwd(ctypes.byref(a), st), "shade_bwd")
-            self._ck(L.harp_normalize3_bwd(p(self.params["normal_map"]), p(s["g_nmap_n"]), self.Ht * self.Wt, p(self.grads["normal_map"]), st), "normalize3_bwd")
+            self._ck(L.harp_shade_bwd(ctypes.byref(a), ST()), "shade_bwd")
+            self._ck(L.harp_normalize3_bwd(p(self.params["normal_map"]), p(s["g_nmap_n"]), self.Ht * self.Wt, p(self.grads["normal_map"]), ST()), "normalize3_bwd")
             if self.self_shadow:
-                self._ck(L.harp_depth_bwd(p(s["face_l"]), p(s["ws_l"]), p(tp.faces), p(s["g_zl"]), B, V, F, S, p(s["g_ndc_l"]), st), "depth_bwd")
+                self._ck(L.harp_depth_bwd(p(s["face_l"]), p(s["ws_l"]), p(tp.faces), p(s["g_zl"]), B, V, F, S, p(s["g_ndc_l"]), ST()), "depth_bwd")
                 self._ck(L.harp_project_bwd(p(s["vd"]), p(s["light_R"]), p(s["light_T"]), p(s["g_ndc_l"]), B, V, self.focal, S, p(s["g_vd"]),
-                                            p(s["g_light_R"]), p(s["g_light_T"]), st), "project_bwd_l")
+                                            p(s["g_light_R"]), p(s["g_light_T"]), ST()), "project_bwd_l")
                 self._ck(L.harp_light_setup_bwd(p(s["centroid"]), p(s["light_pos"]), p(s["g_light_R"]), p(s["g_light_T"]), B, V, p(s["g_light_pos"]),
-                                                p(s["g_centroid"]), p(s["g_vd"]), st), "light_setup_bwd")
+                                                p(s["g_centroid"]), p(s["g_vd"]), ST()), "light_setup_bwd")
         if coarse:
-            self._ck(L.harp_silhouette_bwd(p(tp.faces), B, V, F, S, ops.SIL_BLUR, ops.SIL_SIGMA, p(s["ws_c"]), p(s["alpha"]), p(s["g_alpha"]),
-                                           p(s["g_ndc_c"]), st), "silhouette_bwd")
+            cur.wait_stream(side)                       # silhouette_bwd (side stream) -> g_ndc_c complete
         self._ck(L.harp_project_bwd(p(s["vd"]), p(s["cam_R"]), p(s["cam_T"]), p(s["g_ndc_c"]), B, V, self.focal, S, p(s["g_vd"]), None,
-                                    p(s["g_cam_T"]), st), "project_bwd_c")
+                                    p(s["g_cam_T"]), ST()), "project_bwd_c")
         if app:
             self._ck(L.harp_vertex_normals_bwd(p(s["vd"]), p(tp.faces), p(tp.vf_off), p(tp.vf_idx), B, V, p(s["n2"]), p(s["il2"]), p(s["g_n2"]),
-                                               p(s["g_tmp"]), p(s["g_vd"]), st), "normals_bwd2")
-        self._ck(L.harp_displace_bwd(p(s["g_vd"]), p(s["n1"]), p(self.params["verts_disps"]), B, V, p(s["g_n1"]), p(self.grads["verts_disps"]), st),
+                                               p(s["g_tmp"]), p(s["g_vd"]), ST()), "normals_bwd2")
+        self._ck(L.harp_displace_bwd(p(s["g_vd"]), p(s["n1"]), p(self.params["verts_disps"]), B, V, p(s["g_n1"]), p(self.grads["verts_disps"]), ST()),
                  "displace_bwd")
         self._ck(L.harp_vertex_normals_bwd(p(s["vs"]), p(tp.faces), p(tp.vf_off), p(tp.vf_idx), B, V, p(s["n1"]), p(s["il1"]), p(s["g_n1"]),
-                                           p(s["g_tmp"]), p(s["g_vd"]), st), "normals_bwd1")        # g_vs aliases g_vd (vd = vs + n d)
-        self._ck(L.harp_subdivide_bwd(p(s["g_vd"]), p(tp.sub_off), p(tp.sub_idx), B, tp.V0, V, 1e-3, p(s["g_v0"]), st), "subdivide_bwd")
-        self._ck(L.harp_scale(p(s["g_joints_m"]), 1e-3, B * self.n_joints * 3, p(s["g_joints_mm"]), st), "scale_bwd")
+                                           p(s["g_tmp"]), p(s["g_vd"]), ST()), "normals_bwd1")        # g_vs aliases g_vd (vd = vs + n d)
+        self._ck(L.harp_subdivide_bwd(p(s["g_vd"]), p(tp.sub_off), p(tp.sub_idx), B, tp.V0, V, 1e-3, p(s["g_v0"]), ST()), "subdivide_bwd")
+        self._ck(L.harp_scale(p(s["g_joints_m"]), 1e-3, B * self.n_joints * 3, p(s["g_joints_mm"]), ST()), "scale_bwd")
         lbs_bwd = L.harp_lbs_tree_bwd if self.use_arm else L.harp_lbs_mano_bwd
         self._ck(lbs_bwd(ctypes.byref(self.dm.struct), p(s["pose48"]), p(s["betas"]), p(s["trans_b"]), B, p(s["lbs_ws"]),
-                         p(s["g_v0"]), p(s["g_joints_mm"]), p(s["g_pose48"]), p(s["g_betas"]), p(s["g_trans_b"]), st), "lbs_bwd")
+                         p(s["g_v0"]), p(s["g_joints_mm"]), p(s["g_pose48"]), p(s["g_betas"]), p(s["g_trans_b"]), ST()), "lbs_bwd")
         self._ck(L.harp_frame_setup_bwd(ctypes.byref(self.tables), p(self.fid), B, S, self.focal, int(self.self_shadow), p(s["g_pose48"]),
                                         p(s["g_betas"]), p(s["g_trans_b"]), p(s["g_cam_T"]), p(s["g_light_pos"]) if app else None,
-                                        p(s["g_colors"]) if app else None, st), "frame_setup_bwd")
+                                        p(s["g_colors"]) if app else None, ST()), "frame_setup_bwd")
+
+    def _side_stream(self):
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(device=self.dev)
+        return self._side
 
     def allreduce(self):
         if self.world > 1:
