@@ -112,7 +112,9 @@ def kernel_roofline(eng, steps):
             e0.record()
             r = self.fn(*a)
             e1.record()
-            rec[self.name].append((e0, e1))
+            # harp_rasterize_fwd: argument 6 is `soft` (1 = camera view with the fused soft silhouette, 0 = light-view depth pass)
+            key = self.name if self.name != "harp_rasterize_fwd" else ("raster_cam" if a[6] else "raster_light")
+            rec.setdefault(key, []).append((e0, e1))
             return r
 
     for n in names:
@@ -129,10 +131,7 @@ def kernel_roofline(eng, steps):
         for n in names:
             setattr(L, n, orig[n])
     ms = {n: [a.elapsed_time(b) for a, b in v] for n, v in rec.items()}
-    # harp_rasterize_fwd is called twice per step: even calls = camera (soft, K=1 + silhouette), odd = light (K=1)
-    cam = ms["harp_rasterize_fwd"][0::2]
-    light = ms["harp_rasterize_fwd"][1::2]
-    out = {"raster_cam_fwd(setup+bin+raster)": float(np.mean(cam)), "raster_light_fwd(setup+bin+raster)": float(np.mean(light))}
+    out = {"raster_cam_fwd(setup+bin+raster)": float(np.mean(ms["raster_cam"])), "raster_light_fwd(setup+bin+raster)": float(np.mean(ms["raster_light"]))}
     for n in names[1:]:
         if ms[n]:
             out[n] = float(np.mean(ms[n]))
