@@ -140,8 +140,35 @@ __global__ void __launch_bounds__(256, 3) shade_kernel(const harp_shade_args A) 
   __shared__ VertexAccum<BWD ? 1024 : 1, 6> s_tex;
   const int b = blockIdx.z;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int xi = blockIdx.x * kTile + (lane & 15), yi = blockIdx.y * kTile + w * 4 + (lane >> 4);
   const int S = A.S, V = A.V;
+  // forward: one 16x16 tile per workgroup.  backward: a 32x32 region = 2x2 tiles walked one after the other with the SAME LDS
+  // accumulators, so vertices / texels shared by neighbouring tiles are flushed once (memory-side float atomics are the cost).
+  constexpr int R = BWD ? 2 : 1;
+  if (BWD) {
+    bool any_act = false;
+#pragma unroll
+    for (int sub = 0; sub < R * R; ++sub) {
+      const int xi = (blockIdx.x * R + (sub & (R - 1))) * kTile + (lane & 15), yi = (blockIdx.y * R + (sub / R)) * kTile + w * 4 + (lane >> 4);
+      if (xi < S && yi < S) {
+        const size_t o = ((size_t)b * S + yi) * S + xi;
+        if (A.face_id[o] >= 0) {
+          const V3 gq = ld(A.g_rgb + o * 3);
+          any_act |= (gq.x != 0.f || gq.y != 0.f || gq.z != 0.f);
+        }
+      }
+    }
+    if (threadIdx.x < 32) s_red[threadIdx.x] = 0.f;
+    if (__syncthreads_or(any_act ? 1 : 0) == 0) return;
+    s_acc.clear();
+    s_tex.clear();
+    __syncthreads();
+  }
+  float racc[20];
+#pragma unroll
+  for (int k = 0; k < 20; ++k) racc[k] = 0.f;
+
+  for (int sub = 0; sub < R * R; ++sub) {
+  const int xi = (blockIdx.x * R + (sub & (R - 1))) * kTile + (lane & 15), yi = (blockIdx.y * R + (sub / R)) * kTile + w * 4 + (lane >> 4);
   const bool in_img = xi < S && yi < S;
   const size_t o = ((size_t)b * S + (in_img ? yi : 0)) * S + (in_img ? xi : 0);
   const int f = in_img ? A.face_id[o] : -1;
@@ -150,19 +177,10 @@ __global__ void __launch_bounds__(256, 3) shade_kernel(const harp_shade_args A) 
   if (BWD) {
     if (act) gc = ld(A.g_rgb + o * 3);
     act = act && (gc.x != 0.f || gc.y != 0.f || gc.z != 0.f);
-    if (threadIdx.x < 32) s_red[threadIdx.x] = 0.f;
-    if (__syncthreads_or(act ? 1 : 0) == 0) return;
-    s_acc.clear();
-    s_tex.clear();
-    __syncthreads();
   } else if (!act) {
     if (in_img) { float* r = A.rgb + o * 3; r[0] = A.bg[0]; r[1] = A.bg[1]; r[2] = A.bg[2]; }
     return;
   }
-  float racc[20];
-#pragma unroll
-  for (int k = 0; k < 20; ++k) racc[k] = 0.f;
-
   if (act) {
     const float px = pix_to_ndc(xi, S), py = pix_to_ndc(yi, S);
     const float* col = A.colors;               // amb(3) diff(3) spec(3)
@@ -256,9 +274,9 @@ __global__ void __launch_bounds__(256, 3) shade_kernel(const harp_shade_args A) 
       // c = lightc * texel + spec
       const V3 g_tex = mk(g_c.x * lightc.x, g_c.y * lightc.y, g_c.z * lightc.z);
       const V3 g_lc = mk(g_c.x * g.texel.x, g_c.y * g.texel.y, g_c.z * g.texel.z);
-      racc[0] = g_lc.x; racc[1] = g_lc.y; racc[2] = g_lc.z;                               // amb
-      racc[3] = g_lc.x * cosang * g.vis; racc[4] = g_lc.y * cosang * g.vis; racc[5] = g_lc.z * cosang * g.vis;  // diff
-      racc[6] = g_c.x; racc[7] = g_c.y; racc[8] = g_c.z;                                  // spec
+      racc[0] += g_lc.x; racc[1] += g_lc.y; racc[2] += g_lc.z;                               // amb
+      racc[3] += g_lc.x * cosang * g.vis; racc[4] += g_lc.y * cosang * g.vis; racc[5] += g_lc.z * cosang * g.vis;  // diff
+      racc[6] += g_c.x; racc[7] += g_c.y; racc[8] += g_c.z;                                  // spec
       const float g_dv = g_lc.x * dfc.x + g_lc.y * dfc.y + g_lc.z * dfc.z;               // d/d(cosang*vis)
       const float g_vis = g_dv * cosang;
       const float g_cos = (g.cosr > 0.f) ? g_dv * g.vis : 0.f;
@@ -270,7 +288,7 @@ __global__ void __launch_bounds__(256, 3) shade_kernel(const harp_shade_args A) 
       // cos = nn . lhat
       const V3 g_nn = g.lhat * g_cos, g_lhat = g.nn * g_cos;
       V3 g_ldir = (g.llen > 1e-6f) ? (g_lhat - g.lhat * dot(g.lhat, g_lhat)) * (1.0f / g.llen) : g_lhat * 1e6f;
-      racc[9] = g_ldir.x; racc[10] = g_ldir.y; racc[11] = g_ldir.z;                       // light_pos
+      racc[9] += g_ldir.x; racc[10] += g_ldir.y; racc[11] += g_ldir.z;                       // light_pos
       g_p = g_p - g_ldir;
       V3 g_nfin = (g.lnh > 1e-6f) ? (g_nn - g.nn * dot(g.nn, g_nn)) * (1.0f / g.lnh) : g_nn * 1e6f;
       V3 g_n = g_nfin;
@@ -326,8 +344,8 @@ __global__ void __launch_bounds__(256, 3) shade_kernel(const harp_shade_args A) 
         }
         const float* R = A.light_R + 9 * b;
         g_p = g_p + mk(R[2], R[5], R[8]) * g_zq;
-        racc[12] = g.p.x * g_zq; racc[13] = g.p.y * g_zq; racc[14] = g.p.z * g_zq;        // light_R[:,2]
-        racc[15] = g_zq;                                                                   // light_T.z
+        racc[12] += g.p.x * g_zq; racc[13] += g.p.y * g_zq; racc[14] += g.p.z * g_zq;        // light_R[:,2]
+        racc[15] += g_zq;                                                                   // light_T.z
       }
       // interpolation backward
       float gb0 = dot(v0, g_p) + dot(n0, g_n) + uv0x * gu + uv0y * gv;
@@ -358,6 +376,7 @@ __global__ void __launch_bounds__(256, 3) shade_kernel(const harp_shade_args A) 
       }
     }
   }
+  }   // sub-tile loop
   if (BWD) {
     // block-level reduction of the 16 per-frame / global scalars, then one atomic each
 #pragma unroll
@@ -463,7 +482,8 @@ int harp_shade_fwd(const harp_shade_args* a, hipStream_t stream) {
 
 int harp_shade_bwd(const harp_shade_args* a, hipStream_t stream) {
   if (!a || !a->face_id || !a->recs || !a->g_rgb || !a->g_verts || !a->g_vnormals || !a->g_ndc) return HARP_ERR_ARG;
-  const dim3 grid((a->S + kTile - 1) / kTile, (a->S + kTile - 1) / kTile, a->B);
+  const int R = 2 * kTile;      // the backward kernel walks 2x2 tiles per workgroup
+  const dim3 grid((a->S + R - 1) / R, (a->S + R - 1) / R, a->B);
   hipLaunchKernelGGL(shade_kernel<true>, grid, dim3(256), 0, stream, *a);
   HARP_CHECK_LAUNCH();
   return HARP_OK;
