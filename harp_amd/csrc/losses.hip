@@ -267,6 +267,28 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
   }
 }
 
+// The random neighbour offsets of albedo_reg / smooth_texture_reg (loss/texture_reg.py:15, 51): int(N(0, std)) per texel and axis,
+// truncated toward zero like torch's .to(torch.int).  Counter-based (hash of seed, draw counter, element index) + Box-Muller, so
+// every rank draws the same offsets and a captured graph produces fresh ones on each replay (the counter lives in device memory).
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+  return x;
+}
+__global__ void draw_offsets_kernel(uint32_t seed, int* __restrict__ counter, int n, float std, int32_t* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t c = (uint32_t)(*counter);
+  if (i < n) {
+    const uint32_t h1 = mix32(seed ^ mix32(c * 0x9E3779B9U + 0x85EBCA6BU) ^ mix32((uint32_t)i * 2u + 1u));
+    const uint32_t h2 = mix32(h1 ^ 0xC2B2AE35U ^ mix32((uint32_t)i * 2u + 2u + c));
+    const float u1 = ((float)(h1 >> 8) + 1.0f) * (1.0f / 16777217.0f), u2 = (float)(h2 >> 8) * (1.0f / 16777216.0f);
+    const float r = sqrtf(-2.0f * logf(u1));
+    const float z0 = r * cosf(6.28318530718f * u2), z1 = r * sinf(6.28318530718f * u2);
+    out[2 * i] = (int32_t)(z0 * std);
+    out[2 * i + 1] = (int32_t)(z1 * std);
+  }
+}
+__global__ void bump_counter_kernel(int* counter) { if (threadIdx.x == 0 && blockIdx.x == 0) *counter += 1; }
+
 // device-resident hyper-parameters so that a captured hipGraph can be replayed while step / lr change
 __global__ void adam_tick_kernel(harp_adam_hyper* h) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
@@ -291,6 +313,14 @@ __global__ void adam_dev_kernel(float* __restrict__ p, const float* __restrict__
 }  // namespace
 
 extern "C" {
+
+int harp_draw_texture_offsets(unsigned seed, int* counter_dev, int H, int W, float std, int32_t* dist, hipStream_t stream) {
+  if (!counter_dev || !dist) return HARP_ERR_ARG;
+  hipLaunchKernelGGL(draw_offsets_kernel, dim3((H * W + 255) / 256), dim3(256), 0, stream, seed, counter_dev, H * W, std, dist);
+  hipLaunchKernelGGL(bump_counter_kernel, dim3(1), dim3(64), 0, stream, counter_dev);
+  HARP_CHECK_LAUNCH();
+  return HARP_OK;
+}
 
 int harp_adam_tick(harp_adam_hyper* h, hipStream_t stream) {
   if (!h) return HARP_ERR_ARG;

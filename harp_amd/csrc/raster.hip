@@ -136,7 +136,8 @@ __global__ void __launch_bounds__(256) bin_faces_kernel(const float4* __restrict
 // MODE 0: depth only (light view).  MODE 1: nearest face + silhouette product (camera view).
 // MODE 2: silhouette backward (rim pixels): scatter dL/d(ndc xy).
 template <int MODE>
-__global__ void __launch_bounds__(256) raster_kernel(const FaceRec* __restrict__ recs, const int32_t* __restrict__ bins,
+__global__ void __launch_bounds__(256) raster_kernel(const FaceRec* __restrict__ recs, const float4* __restrict__ bbs,
+                                                     const int32_t* __restrict__ bins,
                                                      const int32_t* __restrict__ bin_count, int F, int S, int nsx,
                                                      float blur, float sigma, int32_t* __restrict__ face_id,
                                                      float* __restrict__ zbuf, float* __restrict__ alpha,
@@ -159,6 +160,7 @@ __global__ void __launch_bounds__(256) raster_kernel(const FaceRec* __restrict__
   const int n = bin_count[b * nst + st];
   const int32_t* list = bins + ((size_t)b * nst + st) * F;
   const FaceRec* rb = recs + (size_t)b * F;
+  const float4* bbb = bbs + (size_t)b * F;
 
   // tile and wave-strip bounds in NDC (conservative supersets of the per-pixel bbox test)
   const float t_xhi = pix_to_ndc(tx0, S), t_xlo = pix_to_ndc(min(tx0 + kTile, S) - 1, S);
@@ -190,7 +192,7 @@ __global__ void __launch_bounds__(256) raster_kernel(const FaceRec* __restrict__
     float4 bb;
     if (e < n) {
       id = list[e];
-      bb = rb[id].bb;
+      bb = bbb[id];          // contiguous 16-B bbox array (4 per 64-B line) instead of the 64-B-strided records
       hit = !(t_xlo > bb.y || t_xhi < bb.x || t_ylo > bb.w || t_yhi < bb.z);
     }
     int nl;
@@ -380,10 +382,10 @@ int harp_rasterize_fwd(const float* ndc, const int32_t* faces, int B, int V, int
   hipLaunchKernelGGL(bin_faces_kernel, dim3((nsx * nsx + 3) / 4, B), dim3(256), 0, stream, bbs, F, S, nsx, bins, cnt);
   const dim3 grid((S + kTile - 1) / kTile, (S + kTile - 1) / kTile, B);
   if (soft)
-    hipLaunchKernelGGL(raster_kernel<1>, grid, dim3(256), 0, stream, recs, bins, cnt, F, S, nsx, blur_radius, sigma,
+    hipLaunchKernelGGL(raster_kernel<1>, grid, dim3(256), 0, stream, recs, bbs, bins, cnt, F, S, nsx, blur_radius, sigma,
                        face_id, zbuf, alpha, nullptr, nullptr, 0, nullptr);
   else
-    hipLaunchKernelGGL(raster_kernel<0>, grid, dim3(256), 0, stream, recs, bins, cnt, F, S, nsx, 0.f, 1.f, face_id, zbuf,
+    hipLaunchKernelGGL(raster_kernel<0>, grid, dim3(256), 0, stream, recs, bbs, bins, cnt, F, S, nsx, 0.f, 1.f, face_id, zbuf,
                        nullptr, nullptr, nullptr, 0, nullptr);
   HARP_CHECK_LAUNCH();
   return HARP_OK;
@@ -394,11 +396,11 @@ int harp_rasterize_fwd(const float* ndc, const int32_t* faces, int B, int V, int
 int harp_silhouette_bwd(const int32_t* faces, int B, int V, int F, int S, float blur_radius, float sigma, const void* ws,
                         const float* alpha, const float* g_alpha, float* g_ndc, hipStream_t stream) {
   if (!faces || !ws || !alpha || !g_alpha || !g_ndc) return HARP_ERR_ARG;
-  FaceRec* recs; int32_t *bins, *cnt;
-  ws_split((void*)ws, B, F, S, &recs, &bins, &cnt);
+  FaceRec* recs; int32_t *bins, *cnt; float4* bbs;
+  ws_split((void*)ws, B, F, S, &recs, &bins, &cnt, &bbs);
   const int nsx = (S + kSuper - 1) / kSuper;
   const dim3 grid((S + kTile - 1) / kTile, (S + kTile - 1) / kTile, B);
-  hipLaunchKernelGGL(raster_kernel<2>, grid, dim3(256), 0, stream, recs, bins, cnt, F, S, nsx, blur_radius, sigma, nullptr,
+  hipLaunchKernelGGL(raster_kernel<2>, grid, dim3(256), 0, stream, recs, bbs, bins, cnt, F, S, nsx, blur_radius, sigma, nullptr,
                      nullptr, (float*)alpha, g_alpha, faces, V, g_ndc);
   HARP_CHECK_LAUNCH();
   return HARP_OK;

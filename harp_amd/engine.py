@@ -133,8 +133,8 @@ class FitEngine:
         self.tfid = torch.zeros(self.B, dtype=torch.int32, device=self.dev)
         self.dist_albedo = torch.zeros(tex_size, tex_size, 2, dtype=torch.int32, device=self.dev)
         self.dist_normal = torch.zeros(tex_size, tex_size, 2, dtype=torch.int32, device=self.dev)
-        self.gen = torch.Generator(device=self.dev)
-        self.gen.manual_seed(seed)                      # SAME seed on every rank
+        self.seed = int(seed) & 0x7FFFFFFF              # SAME seed on every rank
+        self.draw_counter = torch.zeros(1, dtype=torch.int32, device=self.dev)
         self.ref_verts = None
         self._graphs = {}
         self.compute_reference_mesh()
@@ -236,6 +236,8 @@ class FitEngine:
         self.g_buf.zero_()
         self.gs_zero.zero_()
         self.loss_vec.zero_()
+        if app and getattr(self, "auto_draw", True):
+            self.draw_texture_offsets()
         self._mesh_forward(self.fid, B)
         # ---- the light-view chain (centroid -> light camera -> projection -> K=1 raster) is independent of the camera-view chain:
         #      it runs on a second HIP stream so the two latency-bound rasterisations overlap (fork / join is captured into the graph)
@@ -353,22 +355,25 @@ class FitEngine:
 
     def draw_texture_offsets(self):
         """the random neighbour offsets of albedo_reg (std 1) / smooth_texture_reg (std 2), loss/texture_reg.py:15, 51 — drawn on the
-        device from a generator seeded identically on every rank."""
-        n = self.Ht
-        self.dist_albedo.copy_(torch.normal(0.0, 1.0, (n, n, 2), generator=self.gen, device=self.dev).to(torch.int32))
-        self.dist_normal.copy_(torch.normal(0.0, 2.0, (n, n, 2), generator=self.gen, device=self.dev).to(torch.int32))
+        device by a counter-based generator seeded identically on every rank (graph-replayable: the counter is device memory)."""
+        L, p, st = _lib.lib(), _lib.ptr, _lib.stream()
+        self._ck(L.harp_draw_texture_offsets(self.seed, p(self.draw_counter), self.Ht, self.Wt, 1.0, p(self.dist_albedo), st), "draw_offsets")
+        self._ck(L.harp_draw_texture_offsets(self.seed ^ 0x5bd1e995, p(self.draw_counter), self.Ht, self.Wt, 2.0, p(self.dist_normal), st), "draw_offsets")
 
     def step(self, fid, coarse=True, app=True, use_graph=True):
         """One optimisation step on the frames `fid` (global frame ids, length <= batch_size; a shorter — last, partial —
         batch runs eagerly, optimize_sequence.py:396-399)."""
-        fid = torch.as_tensor(fid, dtype=torch.int32)
+        fid = torch.as_tensor(fid)
         n = int(fid.shape[0])
         if n > self.B:
             raise ValueError(f"batch of {n} frames exceeds the engine's batch_size {self.B}")
-        self.fid[:n].copy_(fid.to(self.dev), non_blocking=True)
-        self.tfid[:n].copy_((fid - self.target_offset).to(self.dev), non_blocking=True)
-        if app:
-            self.draw_texture_offsets()
+        if fid.is_cuda:                                   # device-resident schedule: no host sync at all
+            self.fid[:n].copy_(fid, non_blocking=True)
+            self.tfid[:n].copy_(fid - self.target_offset, non_blocking=True)
+        else:
+            fid = fid.to(torch.int32)
+            self.fid[:n].copy_(fid.to(self.dev), non_blocking=True)
+            self.tfid[:n].copy_((fid - self.target_offset).to(self.dev), non_blocking=True)
         key = (coarse, app)
         if getattr(self, "_stage", None) != key:
             self.set_stage(coarse, app)

@@ -91,7 +91,7 @@ def test_full_step_losses_grads_and_adam(sc):
     P = oracle_params(sc, eng.params)
     fid = torch.tensor([2, 0])
     eng.fid.copy_(fid.int().to(DEV)); eng.tfid.copy_(fid.int().to(DEV))
-    eng.draw_texture_offsets(); eng.set_stage(True, True)
+    eng.auto_draw = False; eng.draw_texture_offsets(); eng.set_stage(True, True)
     with torch.no_grad():
         _, rv = H.prepare_mesh(P, torch.tensor([0]), sc["model"], sc["topo"])
     assert (eng.ref_verts.cpu() - rv[0]).abs().max() < 1e-5
@@ -110,6 +110,7 @@ def test_full_step_losses_grads_and_adam(sc):
     # ---- 3 optimiser steps (eager, then hipGraph capture + replay) vs torch.optim.Adam on the oracle
     opt_c = torch.optim.Adam([{"params": [P["pose"], P["cam"]], "lr": 1e-3}, {"params": [P["verts_disps"], P["shape"]], "lr": 1e-3}])
     opt_a = torch.optim.Adam([P["light_positions"], P["amb_ratio"], P["texture"], P["normal_map"]], lr=1e-2)
+    eng.auto_draw = True                       # from here on every step draws fresh offsets itself (inside the graph)
     for it in range(3):
         fid = torch.tensor([it % T, (it + 1) % T])
         eng.step(fid, True, True, use_graph=(it > 0))
@@ -140,7 +141,7 @@ def test_stage_gating_and_no_shadow(sc):
         P = oracle_params(sc, eng.params)
         fid = torch.tensor([1, 2])
         eng.fid.copy_(fid.int().to(DEV)); eng.tfid.copy_(fid.int().to(DEV))
-        eng.draw_texture_offsets(); eng.set_stage(coarse, app)
+        eng.auto_draw = False; eng.draw_texture_offsets(); eng.set_stage(coarse, app)
         with torch.no_grad():
             _, rv = H.prepare_mesh(P, torch.tensor([0]), sc["model"], sc["topo"])
         loss, total, _ = H.step_losses(P, fid, sc["model"], sc["topo"], tg, S, sc["focal"], rv, eng.dist_albedo.cpu().long(),
@@ -252,7 +253,7 @@ def test_full_step_smplx_arm():
     P.update(verts_uvs=torch.from_numpy(tpl["verts_uvs"]), faces_uvs=torch.from_numpy(tpl["faces_uvs"]).long(), uv_mask=uv_mask, init_joints=seq["joints"])
     fid = torch.tensor([2, 0])
     eng.fid.copy_(fid.int().to(DEV)); eng.tfid.copy_(fid.int().to(DEV))
-    eng.draw_texture_offsets(); eng.set_stage(True, True)
+    eng.auto_draw = False; eng.draw_texture_offsets(); eng.set_stage(True, True)
     with torch.no_grad():
         _, rv = H.prepare_mesh(P, torch.tensor([0]), mt, topo, use_arm=True)
     loss, total, aux = H.step_losses(P, fid, mt, topo, tg, S, focal, rv, eng.dist_albedo.cpu().long(), eng.dist_normal.cpu().long(), use_arm=True)
@@ -267,6 +268,7 @@ def test_full_step_smplx_arm():
         assert rel(eng.grads[k].cpu(), P[k].grad) < 3e-3, (k, rel(eng.grads[k].cpu(), P[k].grad))
     # opt_arm_pose: rot and wrist_pose are inside the coarse Adam span and move; trans never does
     before = {k: eng.params[k].clone() for k in ("rot", "wrist_pose", "trans")}
+    eng.auto_draw = True
     eng.step(fid, True, True, use_graph=False)
     torch.cuda.synchronize()
     assert not torch.equal(eng.params["rot"], before["rot"]) and not torch.equal(eng.params["wrist_pose"], before["wrist_pose"])
@@ -299,3 +301,24 @@ def test_rasterizer_odd_sizes(sc, S, B):
     assert ((a.cpu() - a_ref).abs() > 1e-4).float().mean() < 1e-3
     m = f.cpu() == fid_ref
     assert (z.cpu() - zb1[..., 0])[m].abs().max() < 1e-5
+
+
+def test_texture_offset_generator(sc):
+    """the device generator draws int(N(0,std)) like torch.normal(...).to(torch.int) (loss/texture_reg.py:15, 51): distribution,
+    same-seed reproducibility across engines (ranks), fresh values on every draw."""
+    from harp_amd.engine import FitEngine
+    mk = lambda seed: FitEngine(sc["model_np"], sc["topo_np"], sc["tpl"]["verts_uvs"], sc["tpl"]["faces_uvs"], sc["uv_mask"].float(), sc["seq"],
+                                sc["S"], sc["focal"], 2, device=DEV, seed=seed)
+    e1, e2, e3 = mk(5), mk(5), mk(6)
+    for e in (e1, e2, e3):
+        e.draw_texture_offsets()
+    torch.cuda.synchronize()
+    assert torch.equal(e1.dist_albedo, e2.dist_albedo) and torch.equal(e1.dist_normal, e2.dist_normal)
+    assert not torch.equal(e1.dist_albedo, e3.dist_albedo)
+    a, n = e1.dist_albedo.float().cpu(), e1.dist_normal.float().cpu()
+    assert abs((a == 0).float().mean() - 0.6827) < 0.01 and abs((a.abs() == 1).float().mean() - 0.2718) < 0.01     # |z|<1, 1<=|z|<2
+    assert abs(a.mean()) < 0.01 and abs(n.mean()) < 0.02 and abs((n == 0).float().mean() - 0.3829) < 0.01          # |z|<0.5 for std 2
+    prev = e1.dist_albedo.clone()
+    e1.draw_texture_offsets()
+    torch.cuda.synchronize()
+    assert not torch.equal(prev, e1.dist_albedo)

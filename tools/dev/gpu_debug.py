@@ -11,7 +11,7 @@ with torch.no_grad():
     eng.params["normal_map"].copy_(torch.tensor([0., 0., 1.]).repeat(1, 512, 512, 1) + torch.randn(1, 512, 512, 3) * 0.1)
     eng.params["trans"].copy_(torch.randn(3, 3) * 0.01)
 eng.compute_reference_mesh()
-fid = torch.tensor([2,0]).int().cuda(); eng.fid.copy_(fid); eng.tfid.copy_(fid); eng.draw_texture_offsets(); eng.set_stage(True, True)
+fid = torch.tensor([2,0]).int().cuda(); eng.fid.copy_(fid); eng.tfid.copy_(fid); eng.auto_draw = False; eng.draw_texture_offsets(); eng.set_stage(True, True)
 gs = []
 for i in range(4):
     eng.forward_backward(True, True); torch.cuda.synchronize()

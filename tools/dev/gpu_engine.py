@@ -30,7 +30,7 @@ Pm = {k: eng.params[k].detach().cpu().clone().requires_grad_() for k in ('pose',
 Pm.update(verts_uvs=torch.from_numpy(tpl['verts_uvs']), faces_uvs=torch.from_numpy(tpl['faces_uvs']).long(), uv_mask=uv_mask, init_joints=seq['joints'])
 fid = torch.tensor([2,0])
 eng.fid.copy_(fid.int().to(dev)); eng.tfid.copy_(fid.int().to(dev))
-eng.draw_texture_offsets(); eng.set_stage(True, True)
+eng.auto_draw = False; eng.draw_texture_offsets(); eng.set_stage(True, True)
 da, dn = eng.dist_albedo.cpu().long(), eng.dist_normal.cpu().long()
 with torch.no_grad():
     _, rv = H.prepare_mesh(Pm, torch.tensor([0]), model, topo)
@@ -50,6 +50,7 @@ for k in ('pose','cam','verts_disps','shape','light_positions','amb_ratio','text
 # ---- Adam parity over 3 steps (eager), same offsets
 opt_c = torch.optim.Adam([{'params':[Pm['pose'],Pm['cam']],'lr':1e-3},{'params':[Pm['verts_disps'],Pm['shape']],'lr':1e-3}])
 opt_a = torch.optim.Adam([Pm['light_positions'],Pm['amb_ratio'],Pm['texture'],Pm['normal_map']], lr=1e-2)
+eng.auto_draw = True
 for it in range(3):
     fid = torch.tensor([(it)%T, (it+1)%T])
     eng.step(fid, True, True, use_graph=(it>0))
