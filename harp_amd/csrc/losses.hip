@@ -178,7 +178,7 @@ __global__ void __launch_bounds__(256) sumsq_kernel(const float* __restrict__ d,
   float acc = 0.f;
   for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
     acc += d[i] * d[i];
-    if (w && g) g[i] += 2.0f * w[0] * d[i];
+    if (w && g) atomicAdd(&g[i], 2.0f * w[0] * d[i]);
   }
   const float s = block_sum_256(acc, red);
   if (threadIdx.x == 0) atomicAdd(loss, s);

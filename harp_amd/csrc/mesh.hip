@@ -128,7 +128,7 @@ __global__ void displace_bwd_kernel(const float* __restrict__ g_vd, const float*
     acc += dot3(g, ld3(n + o));
     st3(g_n + o, g * d);
   }
-  g_disp[i] += acc;
+  atomicAdd(&g_disp[i], acc);      // several micro-batches may run this concurrently
 }
 
 // MeshRasterizer.transform for PerspectiveCameras(in_ndc=False): view = v R + T (row vectors);

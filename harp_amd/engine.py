@@ -66,7 +66,7 @@ class FitEngine:
 
     def __init__(self, model, topo, verts_uvs, faces_uvs, uv_mask, input_params, img_size, focal_length, batch_size,
                  device="cuda", self_shadow=True, share_light_position=True, tex_size=512, rank=0, world_size=1, seed=0,
-                 use_arm=False, opt_arm_pose=False):
+                 use_arm=False, opt_arm_pose=False, micro_batches=1):
         self.dev = torch.device(device)
         self.S, self.focal, self.B = int(img_size), float(focal_length), int(batch_size)
         self.self_shadow, self.share_light = bool(self_shadow), bool(share_light_position)
@@ -126,11 +126,22 @@ class FitEngine:
         # ---- targets (set by set_targets) and per-step scratch
         self.y_true = self.y_sil = self.y_sil_col = None
         self.target_offset = 0
-        self._alloc_scratch(self.B)
         self.loss_vec = torch.zeros(16, dtype=torch.float32, device=self.dev)
         self.w_vec = torch.zeros(16, dtype=torch.float32, device=self.dev)
         self.fid = torch.zeros(self.B, dtype=torch.int32, device=self.dev)
         self.tfid = torch.zeros(self.B, dtype=torch.int32, device=self.dev)
+        # shared (frame-independent) scratch: the normalised normal map and its gradient
+        self.nmap_n = torch.empty(tex_size, tex_size, 3, dtype=torch.float32, device=self.dev)
+        self.g_nmap_n = torch.zeros(tex_size, tex_size, 3, dtype=torch.float32, device=self.dev)
+        self._main = self._alloc_lane(self.B, 0)
+        self._main["loss_vec"], self._main["w_vec"] = self.loss_vec, self.w_vec
+        self._activate(self._main)
+        # micro-batching (EXPERIMENTAL, off by default): the batch is split in `micro` lanes with their own scratch and streams, so
+        # that the latency-bound rasterisation of one lane overlaps with the atomics-bound shading backward of the other.  Measured:
+        # raster || shade_bwd overlap hides only ~40 % of the rasteriser (1.40 vs 1.60 ms), eager mode becomes launch-bound with 2x the
+        # launches, and capturing the 5-stream step into a hipGraph crashes in capture_end on ROCm 7.2 — so it stays at 1.
+        self.micro = int(micro_batches) if (micro_batches > 1 and self.B % micro_batches == 0) else 1
+        self._lanes = [self._alloc_lane(self.B // self.micro, i * (self.B // self.micro)) for i in range(self.micro)] if self.micro > 1 else []
         self.dist_albedo = torch.zeros(tex_size, tex_size, 2, dtype=torch.int32, device=self.dev)
         self.dist_normal = torch.zeros(tex_size, tex_size, 2, dtype=torch.int32, device=self.dev)
         self.seed = int(seed) & 0x7FFFFFFF              # SAME seed on every rank
@@ -140,12 +151,12 @@ class FitEngine:
         self.compute_reference_mesh()
 
     # ------------------------------------------------------------------------------------------------
-    def _alloc_scratch(self, B):
+    def _alloc_lane(self, B, lo):
+        """scratch + bookkeeping for B frames starting at position `lo` of the step's batch"""
         dev, V, S = self.dev, self.topo.V, self.S
         f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
-        z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
         L = _lib.lib()
-        self.s = s = {}
+        s = {}
         s["pose48"], s["betas"], s["trans_b"] = f(B, self.pose_stride), f(B, self.n_betas), f(B, 3)
         s["cam_R"], s["cam_T"], s["light_pos"], s["colors"] = f(B, 9), f(B, 3), f(B, 3), f(9)
         V0, NJo = self.topo.V0, self.n_joints
@@ -158,20 +169,26 @@ class FitEngine:
         s["face_c"] = torch.empty(B, S, S, dtype=torch.int32, device=dev)
         s["face_l"] = torch.empty(B, S, S, dtype=torch.int32, device=dev)
         s["alpha"], s["zl"], s["rgb"] = f(B, S, S), f(B, S, S), f(B, S, S, 3)
-        s["nmap_n"] = f(self.Ht, self.Wt, 3)
+        s["nmap_n"] = self.nmap_n
         # gradients (zeroed every step in ONE memset: they are carved from one flat buffer)
         gspec = [("g_alpha", (B, S, S)), ("g_rgb", (B, S, S, 3)), ("g_zl", (B, S, S)), ("g_vd", (B, V, 3)), ("g_n2", (B, V, 3)),
                  ("g_ndc_c", (B, V, 3)), ("g_ndc_l", (B, V, 3)), ("g_n1", (B, V, 3)), ("g_vs", (B, V, 3)), ("g_tmp", (B, V, 3)),
                  ("g_v0", (B, V0, 3)), ("g_joints_m", (B, NJo, 3)), ("g_joints_mm", (B, NJo, 3)), ("g_light_pos", (B, 3)), ("g_colors", (9,)),
                  ("g_light_R", (B, 9)), ("g_light_T", (B, 3)), ("g_cam_R", (B, 9)), ("g_cam_T", (B, 3)), ("g_centroid", (B, 3)),
-                 ("g_pose48", (B, self.pose_stride)), ("g_betas", (B, self.n_betas)), ("g_trans_b", (B, 3)), ("g_nmap_n", (self.Ht, self.Wt, 3))]
-        self.garena = _Arena(gspec, dev)
-        self.gs_buf = self.garena.alloc()
+                 ("g_pose48", (B, self.pose_stride)), ("g_betas", (B, self.n_betas)), ("g_trans_b", (B, 3))]
+        garena = _Arena(gspec, dev)
+        gs_buf = garena.alloc()
         for k, _ in gspec:
-            s[k] = self.garena.view(self.gs_buf, k)
+            s[k] = garena.view(gs_buf, k)
+        s["g_nmap_n"] = self.g_nmap_n
         # g_alpha and g_rgb (the first two segments, 4/5 of the slab) are fully overwritten by harp_image_l1: only the rest is zeroed
-        self.gs_zero = self.gs_buf[self.garena.offsets["g_zl"][0]:]
-        self._shade_args = None
+        return dict(s=s, gs_zero=gs_buf[garena.offsets["g_zl"][0]:], B=B, lo=lo, fid=self.fid[lo:lo + B], tfid=self.tfid[lo:lo + B],
+                    loss_vec=torch.zeros(16, dtype=torch.float32, device=dev), w_vec=torch.zeros(16, dtype=torch.float32, device=dev),
+                    stream=None, side=None)
+
+    def _activate(self, lane):
+        """point the step code at one lane's buffers (host-side bookkeeping only)"""
+        self.s, self.gs_zero, self._lane = lane["s"], lane["gs_zero"], lane
 
     def set_targets(self, y_true, y_sil, y_sil_col, frame_offset=0):
         """(Tl,S,S,3), (Tl,S,S), (Tl,S,S) fp32 for this rank's frames [frame_offset, frame_offset+Tl): kept resident in HBM
@@ -223,26 +240,32 @@ class FitEngine:
             setattr(a, k, _lib.ptr(t))
         return a
 
-    def forward_backward(self, coarse=True, app=True, B=None):
-        """Enqueue forward + losses + backward for the first B (default: batch_size) frames in self.fid; gradients land in
-        self.g_buf, loss terms in self.loss_vec[:9] (unweighted, order LOSS_NAMES)."""
-        B = self.B if B is None else int(B)
+    def forward_backward(self, coarse=True, app=True, B=None, shared_terms=True):
+        """Enqueue forward + losses + backward for the first B (default: the lane's size) frames of the active lane; gradients land
+        in self.g_buf, loss terms in the lane's loss_vec[:9] (unweighted, order LOSS_NAMES).  shared_terms=False skips everything that
+        does not depend on the frames (gradient-arena zeroing, offset draw, normal-map normalisation, displacement / texture
+        regularisers): the micro-batched step does those once around its lanes."""
+        lane = self._lane
+        B = lane["B"] if B is None else int(B)
+        lfid, ltfid, lloss = lane["fid"], lane["tfid"], lane["loss_vec"]
         L, s, p, ST, tp, S = _lib.lib(), self.s, _lib.ptr, _lib.stream, self.topo, self.S
         cur, side = torch.cuda.current_stream(), self._side_stream()
         V, F = tp.V, tp.F
-        w = self.w_vec
+        w = lane["w_vec"]
         wp = lambda i: w.data_ptr() + 4 * i
-        lp = lambda i: self.loss_vec.data_ptr() + 4 * i
-        self.g_buf.zero_()
+        lp = lambda i: lloss.data_ptr() + 4 * i
+        if shared_terms:
+            self.g_buf.zero_()
+            self.g_nmap_n.zero_()
         self.gs_zero.zero_()
-        self.loss_vec.zero_()
-        if app and getattr(self, "auto_draw", True):
+        lloss.zero_()
+        if shared_terms and app and getattr(self, "auto_draw", True):
             self.draw_texture_offsets()
-        self._mesh_forward(self.fid, B)
+        self._mesh_forward(lfid, B)
         # ---- the light-view chain (centroid -> light camera -> projection -> K=1 raster) is independent of the camera-view chain:
         #      it runs on a second HIP stream so the two latency-bound rasterisations overlap (fork / join is captured into the graph)
         shadow = app and self.self_shadow
-        if not getattr(self, "overlap", True):
+        if not getattr(self, "overlap", True) or not getattr(self, "_inner_overlap", True):
             side = cur                                   # single-stream mode (used when individual kernels are timed with events)
         if shadow:
             side.wait_stream(cur)
@@ -257,7 +280,7 @@ class FitEngine:
         self._ck(L.harp_rasterize_fwd(p(s["ndc_c"]), p(tp.faces), B, V, F, S, 1, ops.SIL_BLUR, ops.SIL_SIGMA, p(s["ws_c"]), p(s["face_c"]),
                                       None, p(s["alpha"]), ST()), "raster_cam")
         if coarse:
-            self._ck(L.harp_image_l1(p(s["alpha"]), p(self.y_sil), None, p(self.tfid), B, S * S, 1, wp(0), lp(0), p(s["g_alpha"]), ST()), "l1_sil")
+            self._ck(L.harp_image_l1(p(s["alpha"]), p(self.y_sil), None, p(ltfid), B, S * S, 1, wp(0), lp(0), p(s["g_alpha"]), ST()), "l1_sil")
             # the silhouette backward only needs g_alpha and the camera-view workspace: it overlaps with shading on the side stream
             if shadow:
                 cur.wait_stream(side)                   # join the light chain first (the side stream is reused)
@@ -268,27 +291,27 @@ class FitEngine:
         elif shadow:
             cur.wait_stream(side)
         if app:
-            self._ck(L.harp_normalize3_fwd(p(self.params["normal_map"]), self.Ht * self.Wt, p(s["nmap_n"]), ST()), "normalize3")
+            if shared_terms:
+                self._ck(L.harp_normalize3_fwd(p(self.params["normal_map"]), self.Ht * self.Wt, p(s["nmap_n"]), ST()), "normalize3")
             a = self._shade_struct(B, app)
             self._ck(L.harp_shade_fwd(ctypes.byref(a), ST()), "shade_fwd")
         # ---- losses and their gradients
         if coarse:
-            self._ck(L.harp_kps_loss(p(self.init_joints), p(self.fid), p(s["joints_m"]), B, self.n_joints, wp(1), lp(1), p(s["g_joints_m"]), ST()), "kps")
-            self._ck(L.harp_sum_squares(p(self.params["verts_disps"]), V, wp(2), lp(2), p(self.grads["verts_disps"]), ST()), "disp_reg")
+            self._ck(L.harp_kps_loss(p(self.init_joints), p(lfid), p(s["joints_m"]), B, self.n_joints, wp(1), lp(1), p(s["g_joints_m"]), ST()), "kps")
+            if shared_terms:
+                self._ck(L.harp_sum_squares(p(self.params["verts_disps"]), V, wp(2), lp(2), p(self.grads["verts_disps"]), ST()), "disp_reg")
             self._ck(L.harp_mesh_regularizers(p(s["vd"]), p(self.ref_verts), p(tp.nbr_off), p(tp.nbr_idx), p(tp.nc_pairs), p(tp.vp_off), p(tp.vp_idx), B, V,
                                               tp.nc_pairs.shape[0], tp.E, wp(3), lp(3), p(s["g_vd"]), ST()), "mesh_reg")
         if app:
-            self._ck(L.harp_image_l1(p(s["rgb"]), p(self.y_true), p(self.y_sil_col), p(self.tfid), B, S * S * 3, 3, wp(6), lp(6), p(s["g_rgb"]), ST()),
+            self._ck(L.harp_image_l1(p(s["rgb"]), p(self.y_true), p(self.y_sil_col), p(ltfid), B, S * S * 3, 3, wp(6), lp(6), p(s["g_rgb"]), ST()),
                      "l1_photo")
-            self._ck(L.harp_texture_smooth_reg(p(self.params["texture"]), p(self.dist_albedo), p(self.uv_mask), self.Ht, self.Wt, wp(7), lp(7),
-                                               p(self.grads["texture"]), ST()), "albedo_reg")
-            self._ck(L.harp_close_to_z_reg(p(self.params["normal_map"]), self.Ht, self.Wt, 0.2, wp(8), lp(8), p(self.grads["normal_map"]), ST()), "close_z")
-            self._ck(L.harp_texture_smooth_reg(p(self.params["normal_map"]), p(self.dist_normal), p(self.uv_mask), self.Ht, self.Wt, wp(8), lp(8),
-                                               p(self.grads["normal_map"]), ST()), "normal_smooth")
+            if shared_terms:
+                self._texture_terms(wp, lp)
         # ---- backward
         if app:
             self._ck(L.harp_shade_bwd(ctypes.byref(a), ST()), "shade_bwd")
-            self._ck(L.harp_normalize3_bwd(p(self.params["normal_map"]), p(s["g_nmap_n"]), self.Ht * self.Wt, p(self.grads["normal_map"]), ST()), "normalize3_bwd")
+            if shared_terms:
+                self._ck(L.harp_normalize3_bwd(p(self.params["normal_map"]), p(s["g_nmap_n"]), self.Ht * self.Wt, p(self.grads["normal_map"]), ST()), "normalize3_bwd")
             if self.self_shadow:
                 self._ck(L.harp_depth_bwd(p(s["face_l"]), p(s["ws_l"]), p(tp.faces), p(s["g_zl"]), B, V, F, S, p(s["g_ndc_l"]), ST()), "depth_bwd")
                 self._ck(L.harp_project_bwd(p(s["vd"]), p(s["light_R"]), p(s["light_T"]), p(s["g_ndc_l"]), B, V, self.focal, S, p(s["g_vd"]),
@@ -311,14 +334,60 @@ class FitEngine:
         lbs_bwd = L.harp_lbs_tree_bwd if self.use_arm else L.harp_lbs_mano_bwd
         self._ck(lbs_bwd(ctypes.byref(self.dm.struct), p(s["pose48"]), p(s["betas"]), p(s["trans_b"]), B, p(s["lbs_ws"]),
                          p(s["g_v0"]), p(s["g_joints_mm"]), p(s["g_pose48"]), p(s["g_betas"]), p(s["g_trans_b"]), ST()), "lbs_bwd")
-        self._ck(L.harp_frame_setup_bwd(ctypes.byref(self.tables), p(self.fid), B, S, self.focal, int(self.self_shadow), p(s["g_pose48"]),
+        self._ck(L.harp_frame_setup_bwd(ctypes.byref(self.tables), p(lfid), B, S, self.focal, int(self.self_shadow), p(s["g_pose48"]),
                                         p(s["g_betas"]), p(s["g_trans_b"]), p(s["g_cam_T"]), p(s["g_light_pos"]) if app else None,
                                         p(s["g_colors"]) if app else None, ST()), "frame_setup_bwd")
 
     def _side_stream(self):
-        if getattr(self, "_side", None) is None:
-            self._side = torch.cuda.Stream(device=self.dev)
-        return self._side
+        lane = self._lane
+        if lane["side"] is None:
+            lane["side"] = torch.cuda.Stream(device=self.dev)
+        return lane["side"]
+
+    def _texture_terms(self, wp, lp):
+        """albedo_reg + normal_reg (loss/texture_reg.py) with their gradients, straight into the gradient arena"""
+        L, p, st = _lib.lib(), _lib.ptr, _lib.stream()
+        self._ck(L.harp_texture_smooth_reg(p(self.params["texture"]), p(self.dist_albedo), p(self.uv_mask), self.Ht, self.Wt, wp(7), lp(7),
+                                           p(self.grads["texture"]), st), "albedo_reg")
+        self._ck(L.harp_close_to_z_reg(p(self.params["normal_map"]), self.Ht, self.Wt, 0.2, wp(8), lp(8), p(self.grads["normal_map"]), st), "close_z")
+        self._ck(L.harp_texture_smooth_reg(p(self.params["normal_map"]), p(self.dist_normal), p(self.uv_mask), self.Ht, self.Wt, wp(8), lp(8),
+                                           p(self.grads["normal_map"]), st), "normal_smooth")
+
+    def _step_micro(self, coarse, app):
+        """one full-batch forward+backward as `micro` concurrent lanes (each on its own HIP stream pair) around shared pre / post work"""
+        L, p = _lib.lib(), _lib.ptr
+        cur = torch.cuda.current_stream()
+        wp = lambda i: self.w_vec.data_ptr() + 4 * i
+        lp = lambda i: self.loss_vec.data_ptr() + 4 * i
+        V = self.topo.V
+        # ---- pre (shared)
+        self.g_buf.zero_()
+        self.g_nmap_n.zero_()
+        self.loss_vec.zero_()
+        if app:
+            if getattr(self, "auto_draw", True):
+                self.draw_texture_offsets()
+            self._ck(L.harp_normalize3_fwd(p(self.params["normal_map"]), self.Ht * self.Wt, p(self.nmap_n), _lib.stream()), "normalize3")
+        # ---- lanes
+        for lane in self._lanes:
+            if lane["stream"] is None:
+                lane["stream"] = torch.cuda.Stream(device=self.dev)
+            lane["stream"].wait_stream(cur)
+            with torch.cuda.stream(lane["stream"]):
+                self._activate(lane)
+                self.forward_backward(coarse, app, shared_terms=False)
+        self._activate(self._main)
+        for lane in self._lanes:
+            cur.wait_stream(lane["stream"])
+        # ---- post (shared): frame-independent terms, the normal-map normalisation backward, loss bookkeeping
+        if coarse:
+            self._ck(L.harp_sum_squares(p(self.params["verts_disps"]), V, wp(2), lp(2), p(self.grads["verts_disps"]), _lib.stream()), "disp_reg")
+        if app:
+            self._texture_terms(wp, lp)
+            self._ck(L.harp_normalize3_bwd(p(self.params["normal_map"]), p(self.g_nmap_n), self.Ht * self.Wt, p(self.grads["normal_map"]), _lib.stream()),
+                     "normalize3_bwd")
+        for lane in self._lanes:                       # mean-type terms: weighted average of the lanes' means
+            self.loss_vec.add_(lane["loss_vec"] * self._mean_mask, alpha=lane["B"] / self.B)
 
     def allreduce(self):
         if self.world > 1:
@@ -343,6 +412,11 @@ class FitEngine:
             if (coarse and k in COARSE_TERMS) or (app and k in APP_TERMS):
                 w[i] = LOSS_WEIGHTS[k]
         self.w_vec.copy_(w.to(self.dev))
+        # lanes see the mean-type weights scaled by their share of the batch (a mean over B frames = sum of lane means * B_lane / B)
+        mean_mask = torch.tensor([1.0 if k in ("silhouette", "kps_anchor", "laplacian", "normal", "arap", "photo") else 0.0 for k in LOSS_NAMES] + [0.0] * 7)
+        self._mean_mask = mean_mask.to(self.dev)
+        for lane in self._lanes:
+            lane["w_vec"].copy_((w * mean_mask * (lane["B"] / self.B)).to(self.dev))
 
     def set_lr(self, lr_coarse=None, lr_app=None):
         """host -> device hyper block (ReduceLROnPlateau lives on the host, optimize_sequence.py:309, 581-582)"""
@@ -378,8 +452,10 @@ class FitEngine:
         if getattr(self, "_stage", None) != key:
             self.set_stage(coarse, app)
             self._stage = key
+        use_micro = self.micro > 1 and n == self.B and getattr(self, "overlap", True)
+        fb = (lambda: self._step_micro(coarse, app)) if use_micro else (lambda: self.forward_backward(coarse, app, B=n))
         if not use_graph or self.world > 1 or n != self.B:
-            self.forward_backward(coarse, app, B=n)
+            fb()
             self.allreduce()
             self.adam(coarse, app)
             return
@@ -389,12 +465,12 @@ class FitEngine:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
-                self.forward_backward(coarse, app)
+                fb()
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
-                self.forward_backward(coarse, app)
+                fb()
                 self.adam(coarse, app)
             self._graphs[key] = g
             # the capture itself does not execute; fall through to the first replay
