@@ -181,6 +181,23 @@ def cpu_baseline(seed=0):
                       f"materialised), median of 2 steps after 1 warm-up, torch.set_num_threads({cores})"}
 
 
+class _StdoutToStderr:
+    """RCCL prints a version banner on fd 1 when the communicator is created; keep stdout for the ONE JSON line"""
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *a):
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -197,10 +214,17 @@ def main():
             raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 bench.py --gpus N")
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    if world > 1:
+    force_dist = os.environ.get("HARP_FORCE_DIST") == "1"      # exercise the RCCL code path (init, barrier, all-reduce, eager steps) on 1 GPU
+    if world > 1 or force_dist:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=device)
+        if force_dist and "MASTER_ADDR" not in os.environ:
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
+        with _StdoutToStderr():
+            dist.init_process_group("nccl", device_id=device)
+            dist.barrier()                               # communicator creation happens at the first collective
+            torch.cuda.synchronize()
     eng, focal = build_engine(rank, world, device)
+    eng.force_allreduce = force_dist
     Tl = eng.T // world
 
     # the whole frame schedule lives on the device (the reference's DataLoader hands over host tensors every step)
@@ -210,7 +234,7 @@ def main():
         return sched[i]
 
     def sync():
-        if world > 1:
+        if world > 1 or force_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -222,7 +246,7 @@ def main():
         eng.step(batch(args.warmup + i), True, True, use_graph=not args.no_graph)
     sync()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if world > 1 or force_dist:
         tmax = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
@@ -267,7 +291,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline()
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 or force_dist:
         dist.destroy_process_group()
 
 

@@ -23,6 +23,6 @@ def batches(lo, hi, batch_size, step):
 
 def allreduce_flat(bucket):
     """sum the flat gradient bucket over all ranks in one collective (no-op for a single process)"""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized():
         dist.all_reduce(bucket)
     return bucket

@@ -390,7 +390,7 @@ class FitEngine:
             self.loss_vec.add_(lane["loss_vec"] * self._mean_mask, alpha=lane["B"] / self.B)
 
     def allreduce(self):
-        if self.world > 1:
+        if self.world > 1 or getattr(self, "force_allreduce", False):
             from .dist import allreduce_flat
             o, n = self.opt_span
             allreduce_flat(self.g_buf[o:o + n])           # one flat bucket (sum); 1/world is applied in the Adam kernel
@@ -454,7 +454,7 @@ class FitEngine:
             self._stage = key
         use_micro = self.micro > 1 and n == self.B and getattr(self, "overlap", True)
         fb = (lambda: self._step_micro(coarse, app)) if use_micro else (lambda: self.forward_backward(coarse, app, B=n))
-        if not use_graph or self.world > 1 or n != self.B:
+        if not use_graph or self.world > 1 or n != self.B or getattr(self, "force_allreduce", False):
             fb()
             self.allreduce()
             self.adam(coarse, app)
