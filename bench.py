@@ -225,6 +225,7 @@ def main():
             torch.cuda.synchronize()
     eng, focal = build_engine(rank, world, device)
     eng.force_allreduce = force_dist
+    eng.graph_collectives = os.environ.get("HARP_GRAPH_COLLECTIVES", "0") == "1"
     Tl = eng.T // world
 
     # the whole frame schedule lives on the device (the reference's DataLoader hands over host tensors every step)

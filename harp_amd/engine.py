@@ -454,7 +454,8 @@ class FitEngine:
             self._stage = key
         use_micro = self.micro > 1 and n == self.B and getattr(self, "overlap", True)
         fb = (lambda: self._step_micro(coarse, app)) if use_micro else (lambda: self.forward_backward(coarse, app, B=n))
-        if not use_graph or self.world > 1 or n != self.B or getattr(self, "force_allreduce", False):
+        dist_on = self.world > 1 or getattr(self, "force_allreduce", False)
+        if not use_graph or n != self.B or (dist_on and not getattr(self, "graph_collectives", False)):
             fb()
             self.allreduce()
             self.adam(coarse, app)
@@ -471,6 +472,7 @@ class FitEngine:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 fb()
+                self.allreduce()                         # no-op for a single rank; RCCL all-reduce is captured into the graph otherwise
                 self.adam(coarse, app)
             self._graphs[key] = g
             # the capture itself does not execute; fall through to the first replay
