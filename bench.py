@@ -99,7 +99,7 @@ def kernel_roofline(eng, steps):
     same steps right after the timed region; algorithmic bytes per launch from SURVEY.md §8(d)."""
     from harp_amd import _lib
     L = _lib.lib()
-    names = ["harp_rasterize_fwd", "harp_shade_fwd", "harp_shade_bwd", "harp_silhouette_bwd", "harp_image_l1", "harp_depth_bwd"]
+    names = ["harp_rasterize_fwd", "harp_rasterize_l1_fwd", "harp_shade_fwd", "harp_shade_bwd", "harp_silhouette_bwd", "harp_depth_bwd"]
     rec = {n: [] for n in names}
     orig = {}
 
@@ -113,7 +113,7 @@ def kernel_roofline(eng, steps):
             r = self.fn(*a)
             e1.record()
             # harp_rasterize_fwd: argument 6 is `soft` (1 = camera view with the fused soft silhouette, 0 = light-view depth pass)
-            key = self.name if self.name != "harp_rasterize_fwd" else ("raster_cam" if a[6] else "raster_light")
+            key = self.name if "rasterize" not in self.name else ("raster_cam" if a[6] else "raster_light")
             rec.setdefault(key, []).append((e0, e1))
             return r
 
@@ -132,8 +132,8 @@ def kernel_roofline(eng, steps):
             setattr(L, n, orig[n])
     ms = {n: [a.elapsed_time(b) for a, b in v] for n, v in rec.items()}
     out = {"raster_cam_fwd(setup+bin+raster)": float(np.mean(ms["raster_cam"])), "raster_light_fwd(setup+bin+raster)": float(np.mean(ms["raster_light"]))}
-    for n in names[1:]:
-        if ms[n]:
+    for n in names[2:]:
+        if ms.get(n):
             out[n] = float(np.mean(ms[n]))
     return out
 
@@ -270,12 +270,11 @@ def main():
         # rasteriser sub-figure of SURVEY.md §8(d): geom_pos + S^2*(4+4+12+4) for the K=1 fragment set + S^2*4 for alpha
         dom = max(kt, key=kt.get)
         geom_pos = parts["V"] * 12 + parts["F"] * 12
-        alg = {"raster_cam_fwd(setup+bin+raster)": (geom_pos + parts["S2"] * 24 + parts["S2"] * 4) * eng.B,
+        alg = {"raster_cam_fwd(setup+bin+raster)": (geom_pos + parts["S2"] * 24 + parts["S2"] * 4 + parts["S2"] * 8) * eng.B,   # + fused silhouette L1: mask in, g_alpha out
                "raster_light_fwd(setup+bin+raster)": (geom_pos + parts["S2"] * 24) * eng.B,
-               "harp_shade_fwd": (parts["geom"] + parts["S2"] * (4 + 12 + 4)) * eng.B,
+               "harp_shade_fwd": (parts["geom"] + parts["S2"] * (4 + 12 + 4 + 12 + 4 + 12)) * eng.B,   # + fused photometric L1: y_true, mask in, g_rgb out
                "harp_shade_bwd": (parts["geom"] + parts["V"] * 36 + parts["S2"] * (4 + 12 + 4 + 4)) * eng.B + 2 * eng.Ht * eng.Wt * 12,
                "harp_silhouette_bwd": (geom_pos + parts["S2"] * 8 + parts["V"] * 12) * eng.B,
-               "harp_image_l1": parts["S2"] * (12 + 12 + 4 + 12) * eng.B,
                "harp_depth_bwd": (geom_pos + parts["S2"] * 8 + parts["V"] * 12) * eng.B}
         ach = alg[dom] / (kt[dom] * 1e-3) / 1e9
         # HBM traffic per launch comes from PMC counters, which cannot be read in-process: the last rocprofv3 FETCH_SIZE / WRITE_SIZE

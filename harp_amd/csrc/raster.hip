@@ -142,7 +142,9 @@ __global__ void __launch_bounds__(256) raster_kernel(const FaceRec* __restrict__
                                                      float blur, float sigma, int32_t* __restrict__ face_id,
                                                      float* __restrict__ zbuf, float* __restrict__ alpha,
                                                      const float* __restrict__ g_alpha, const int32_t* __restrict__ faces,
-                                                     int V, float* __restrict__ g_ndc) {
+                                                     int V, float* __restrict__ g_ndc, const float* __restrict__ l1_target,
+                                                     const int32_t* __restrict__ l1_fid, const float* __restrict__ l1_w,
+                                                     float* __restrict__ l1_loss, float* __restrict__ l1_grad, float l1_inv) {
   __shared__ float4 s_a[kStage], s_b[kStage], s_bb[kStage];
   __shared__ float s_z2[kStage];
   __shared__ int32_t s_id[kStage];
@@ -333,11 +335,26 @@ __global__ void __launch_bounds__(256) raster_kernel(const FaceRec* __restrict__
     __syncthreads();
   }
 
+  float l1_acc = 0.f;
   if (MODE != 2 && in_img) {
     const size_t o = ((size_t)b * S + yi) * S + xi;
     face_id[o] = best_f;
     if (zbuf) zbuf[o] = (best_f >= 0) ? best_z : -1.0f;
-    if (MODE == 1) alpha[o] = 1.0f - prod;
+    if (MODE == 1) {
+      const float a = 1.0f - prod;
+      alpha[o] = a;
+      if (l1_target) {
+        // fused torch.nn.L1Loss(y_sil_true, y_sil_pred) (optimize_sequence.py:519) and its gradient w.r.t. alpha
+        const float d = a - l1_target[((size_t)l1_fid[b] * S + yi) * S + xi];
+        l1_acc = fabsf(d);
+        l1_grad[o] = l1_w[0] * l1_inv * ((d > 0.f) - (d < 0.f));
+      }
+    }
+  }
+  if (MODE == 1 && l1_target) {
+    __shared__ float red[4];
+    const float sum = block_sum_256(l1_acc, red);
+    if (threadIdx.x == 0 && sum != 0.f) atomicAdd(l1_loss, sum * l1_inv);
   }
 }
 
@@ -371,9 +388,13 @@ static void ws_split(void* ws, int B, int F, int S, FaceRec** recs, int32_t** bi
 //   soft != 0: also accumulate the soft-silhouette alpha (blur_radius, sigma as in renderer_helper.py:44-58).
 //   Outputs (B,S,S): face_id i32 (frame-local, -1 empty), zbuf f32 or NULL (-1 empty), alpha f32 (soft only).
 //   ws: harp_rasterize_ws_bytes() bytes, 256-B aligned; must stay untouched until the matching backward ran.
-int harp_rasterize_fwd(const float* ndc, const int32_t* faces, int B, int V, int F, int S, int soft, float blur_radius,
-                       float sigma, void* ws, int32_t* face_id, float* zbuf, float* alpha, hipStream_t stream) {
+// Same, with the silhouette L1 loss fused into the camera-view raster epilogue (soft != 0): loss (+=) mean |alpha - y_sil[fid]|,
+// g_alpha = w * d loss / d alpha.  y_sil == NULL: plain rasterisation.
+int harp_rasterize_l1_fwd(const float* ndc, const int32_t* faces, int B, int V, int F, int S, int soft, float blur_radius,
+                          float sigma, void* ws, int32_t* face_id, float* zbuf, float* alpha, const float* l1_target,
+                          const int32_t* l1_fid, const float* l1_w, float* l1_loss, float* l1_grad, hipStream_t stream) {
   if (!ndc || !faces || !ws || !face_id || B <= 0 || F <= 0 || S <= 0 || (soft && !alpha)) return HARP_ERR_ARG;
+  if (l1_target && (!soft || !l1_fid || !l1_w || !l1_loss || !l1_grad)) return HARP_ERR_ARG;
   FaceRec* recs; int32_t *bins, *cnt; float4* bbs;
   ws_split(ws, B, F, S, &recs, &bins, &cnt, &bbs);
   const int nsx = (S + kSuper - 1) / kSuper;
@@ -383,12 +404,19 @@ int harp_rasterize_fwd(const float* ndc, const int32_t* faces, int B, int V, int
   const dim3 grid((S + kTile - 1) / kTile, (S + kTile - 1) / kTile, B);
   if (soft)
     hipLaunchKernelGGL(raster_kernel<1>, grid, dim3(256), 0, stream, recs, bbs, bins, cnt, F, S, nsx, blur_radius, sigma,
-                       face_id, zbuf, alpha, nullptr, nullptr, 0, nullptr);
+                       face_id, zbuf, alpha, nullptr, nullptr, 0, nullptr, l1_target, l1_fid, l1_w, l1_loss, l1_grad,
+                       1.0f / ((float)B * (float)S * (float)S));
   else
     hipLaunchKernelGGL(raster_kernel<0>, grid, dim3(256), 0, stream, recs, bbs, bins, cnt, F, S, nsx, 0.f, 1.f, face_id, zbuf,
-                       nullptr, nullptr, nullptr, 0, nullptr);
+                       nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f);
   HARP_CHECK_LAUNCH();
   return HARP_OK;
+}
+
+int harp_rasterize_fwd(const float* ndc, const int32_t* faces, int B, int V, int F, int S, int soft, float blur_radius,
+                       float sigma, void* ws, int32_t* face_id, float* zbuf, float* alpha, hipStream_t stream) {
+  return harp_rasterize_l1_fwd(ndc, faces, B, V, F, S, soft, blur_radius, sigma, ws, face_id, zbuf, alpha, nullptr, nullptr, nullptr,
+                               nullptr, nullptr, stream);
 }
 
 // Soft-silhouette backward: g_alpha (B,S,S) -> accumulates (atomicAdd) into g_ndc (B,V,3) (x,y components).
@@ -401,7 +429,7 @@ int harp_silhouette_bwd(const int32_t* faces, int B, int V, int F, int S, float 
   const int nsx = (S + kSuper - 1) / kSuper;
   const dim3 grid((S + kTile - 1) / kTile, (S + kTile - 1) / kTile, B);
   hipLaunchKernelGGL(raster_kernel<2>, grid, dim3(256), 0, stream, recs, bbs, bins, cnt, F, S, nsx, blur_radius, sigma, nullptr,
-                     nullptr, (float*)alpha, g_alpha, faces, V, g_ndc);
+                     nullptr, (float*)alpha, g_alpha, faces, V, g_ndc, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f);
   HARP_CHECK_LAUNCH();
   return HARP_OK;
 }

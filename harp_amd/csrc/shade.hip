@@ -179,8 +179,8 @@ __global__ void __launch_bounds__(256, 3) shade_kernel(const harp_shade_args A) 
     act = act && (gc.x != 0.f || gc.y != 0.f || gc.z != 0.f);
   } else if (!act) {
     if (in_img) { float* r = A.rgb + o * 3; r[0] = A.bg[0]; r[1] = A.bg[1]; r[2] = A.bg[2]; }
-    return;
   }
+  float out_rgb[3] = {A.bg[0], A.bg[1], A.bg[2]};
   if (act) {
     const float px = pix_to_ndc(xi, S), py = pix_to_ndc(yi, S);
     const float* col = A.colors;               // amb(3) diff(3) spec(3)
@@ -265,9 +265,10 @@ __global__ void __launch_bounds__(256, 3) shade_kernel(const harp_shade_args A) 
     const float denom = wnum + delta;
     if (!BWD) {
       float* r = A.rgb + o * 3;
-      r[0] = (wnum * c.x + delta * A.bg[0]) / denom;
-      r[1] = (wnum * c.y + delta * A.bg[1]) / denom;
-      r[2] = (wnum * c.z + delta * A.bg[2]) / denom;
+      out_rgb[0] = (wnum * c.x + delta * A.bg[0]) / denom;
+      out_rgb[1] = (wnum * c.y + delta * A.bg[1]) / denom;
+      out_rgb[2] = (wnum * c.z + delta * A.bg[2]) / denom;
+      r[0] = out_rgb[0]; r[1] = out_rgb[1]; r[2] = out_rgb[2];
     } else {
       const float wk = wnum / denom;
       const V3 g_c = gc * wk;
@@ -376,6 +377,23 @@ __global__ void __launch_bounds__(256, 3) shade_kernel(const harp_shade_args A) 
       }
     }
   }
+  if (!BWD && A.l1_target) {
+    // fused photometric term: torch.nn.L1Loss(y_true * m, y_pred * m) (optimize_sequence.py:543) and its gradient w.r.t. y_pred
+    float acc = 0.f;
+    if (in_img) {
+      const size_t to = ((size_t)A.l1_fid[b] * S + yi) * S + xi;
+      const float m = A.l1_mask ? A.l1_mask[to] : 1.f;
+      const float wk = A.l1_w[0] * A.l1_inv * m;
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch) {
+        const float d = out_rgb[ch] * m - A.l1_target[to * 3 + ch] * m;
+        acc += fabsf(d);
+        A.l1_grad[o * 3 + ch] = wk * ((d > 0.f) - (d < 0.f));
+      }
+    }
+    const float sum = block_sum_256(acc, s_red);
+    if (threadIdx.x == 0 && sum != 0.f) atomicAdd(A.l1_loss, sum * A.l1_inv);
+  }
   }   // sub-tile loop
   if (BWD) {
     // block-level reduction of the 16 per-frame / global scalars, then one atomic each
@@ -475,7 +493,12 @@ int harp_shade_fwd(const harp_shade_args* a, hipStream_t stream) {
       !a->light_pos || !a->colors || !a->rgb || (a->zl && (!a->light_R || !a->light_T)))
     return HARP_ERR_ARG;
   const dim3 grid((a->S + kTile - 1) / kTile, (a->S + kTile - 1) / kTile, a->B);
-  hipLaunchKernelGGL(shade_kernel<false>, grid, dim3(256), 0, stream, *a);
+  harp_shade_args b = *a;
+  if (b.l1_target) {
+    if (!b.l1_fid || !b.l1_w || !b.l1_loss || !b.l1_grad) return HARP_ERR_ARG;
+    b.l1_inv = 1.0f / ((float)b.B * (float)b.S * (float)b.S * 3.0f);
+  }
+  hipLaunchKernelGGL(shade_kernel<false>, grid, dim3(256), 0, stream, b);
   HARP_CHECK_LAUNCH();
   return HARP_OK;
 }

@@ -277,10 +277,11 @@ class FitEngine:
                          "raster_light")
         # ---- camera view: projection + fused K=1 / soft-silhouette raster
         self._ck(L.harp_project_fwd(p(s["vd"]), p(s["cam_R"]), p(s["cam_T"]), B, V, self.focal, S / 2.0, S / 2.0, S, p(s["ndc_c"]), ST()), "project")
-        self._ck(L.harp_rasterize_fwd(p(s["ndc_c"]), p(tp.faces), B, V, F, S, 1, ops.SIL_BLUR, ops.SIL_SIGMA, p(s["ws_c"]), p(s["face_c"]),
-                                      None, p(s["alpha"]), ST()), "raster_cam")
+        # the silhouette L1 term and its gradient are fused into the raster epilogue (no separate pass over alpha)
+        self._ck(L.harp_rasterize_l1_fwd(p(s["ndc_c"]), p(tp.faces), B, V, F, S, 1, ops.SIL_BLUR, ops.SIL_SIGMA, p(s["ws_c"]), p(s["face_c"]),
+                                         None, p(s["alpha"]), p(self.y_sil) if coarse else None, p(ltfid), wp(0), lp(0), p(s["g_alpha"]), ST()),
+                 "raster_cam")
         if coarse:
-            self._ck(L.harp_image_l1(p(s["alpha"]), p(self.y_sil), None, p(ltfid), B, S * S, 1, wp(0), lp(0), p(s["g_alpha"]), ST()), "l1_sil")
             # the silhouette backward only needs g_alpha and the camera-view workspace: it overlaps with shading on the side stream
             if shadow:
                 cur.wait_stream(side)                   # join the light chain first (the side stream is reused)
@@ -294,6 +295,9 @@ class FitEngine:
             if shared_terms:
                 self._ck(L.harp_normalize3_fwd(p(self.params["normal_map"]), self.Ht * self.Wt, p(s["nmap_n"]), ST()), "normalize3")
             a = self._shade_struct(B, app)
+            # the photometric L1 term and its gradient are fused into the shader (no separate pass over the image)
+            a.l1_target, a.l1_mask, a.l1_fid = p(self.y_true), p(self.y_sil_col), p(ltfid)
+            a.l1_w, a.l1_loss, a.l1_grad = wp(6), lp(6), p(s["g_rgb"])
             self._ck(L.harp_shade_fwd(ctypes.byref(a), ST()), "shade_fwd")
         # ---- losses and their gradients
         if coarse:
@@ -303,8 +307,6 @@ class FitEngine:
             self._ck(L.harp_mesh_regularizers(p(s["vd"]), p(self.ref_verts), p(tp.nbr_off), p(tp.nbr_idx), p(tp.nc_pairs), p(tp.vp_off), p(tp.vp_idx), B, V,
                                               tp.nc_pairs.shape[0], tp.E, wp(3), lp(3), p(s["g_vd"]), ST()), "mesh_reg")
         if app:
-            self._ck(L.harp_image_l1(p(s["rgb"]), p(self.y_true), p(self.y_sil_col), p(ltfid), B, S * S * 3, 3, wp(6), lp(6), p(s["g_rgb"]), ST()),
-                     "l1_photo")
             if shared_terms:
                 self._texture_terms(wp, lp)
         # ---- backward

@@ -33,6 +33,11 @@ typedef struct ihipStream_t* hipStream_t;
 size_t harp_rasterize_ws_bytes(int B, int F, int S);
 int harp_rasterize_fwd(const float* ndc, const int32_t* faces, int B, int V, int F, int S, int soft, float blur_radius,
                        float sigma, void* ws, int32_t* face_id, float* zbuf, float* alpha, hipStream_t stream);
+/* the same with torch.nn.L1Loss(y_sil_true, y_sil_pred) (optimize_sequence.py:519) fused into the raster epilogue: l1_target (T,S,S)
+ * indexed by l1_fid (B,), *l1_loss (+=) the mean, l1_grad (B,S,S) = l1_w[0] * d loss / d alpha.  l1_target == NULL: plain rasterisation. */
+int harp_rasterize_l1_fwd(const float* ndc, const int32_t* faces, int B, int V, int F, int S, int soft, float blur_radius,
+                          float sigma, void* ws, int32_t* face_id, float* zbuf, float* alpha, const float* l1_target,
+                          const int32_t* l1_fid, const float* l1_w, float* l1_loss, float* l1_grad, hipStream_t stream);
 /* replaces _C.rasterize_meshes_backward (grad_dists path) + sigmoid_alpha_blend backward; g_ndc (B,V,3) (+=) */
 int harp_silhouette_bwd(const int32_t* faces, int B, int V, int F, int S, float blur_radius, float sigma, const void* ws,
                         const float* alpha, const float* g_alpha, float* g_ndc, hipStream_t stream);
@@ -80,6 +85,15 @@ typedef struct harp_shade_args {
   float* g_light_R;         /* (B,9) (+=) or NULL */
   float* g_light_T;         /* (B,3) (+=) or NULL */
   int debug_skip;           /* 0 in production; bit flags used only by tools/dev ablation timing */
+  /* forward only, optional: fused photometric L1 (optimize_sequence.py:543): *l1_loss (+=) mean |y_pred*m - y_true[fid]*m|,
+   * l1_grad (B,S,S,3) = l1_w[0] * d loss / d y_pred.  l1_target == NULL disables it. */
+  const float* l1_target;   /* (T,S,S,3) */
+  const float* l1_mask;     /* (T,S,S) or NULL */
+  const int32_t* l1_fid;    /* (B,) */
+  const float* l1_w;
+  float* l1_loss;
+  float* l1_grad;
+  float l1_inv;             /* filled in by harp_shade_fwd */
 } harp_shade_args;
 int harp_shade_fwd(const harp_shade_args* a, hipStream_t stream);
 int harp_shade_bwd(const harp_shade_args* a, hipStream_t stream);
