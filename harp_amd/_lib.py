@@ -6,7 +6,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libharp_hip.so")
+LIB_PATH = os.environ.get("HARP_LIB_PATH") or os.path.join(_HERE, "csrc", "libharp_hip.so")   # override: A/B of kernel variants
 
 _vp, _i, _f, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
 

@@ -61,16 +61,19 @@ __device__ __forceinline__ float block_sum_256(float v, float* lds4) {
 // Pixels of one screen tile touch only a few dozen distinct vertices, so gradients are first summed with LDS float
 // atomics (ds_add_f32) and each (vertex, component) is then flushed with ONE global atomic per workgroup instead of one
 // per pixel.  A full table (probe limit hit) falls back to direct global atomics, so it is always correct.
-template <int SLOTS, int NV>
+// T = double by default: on gfx950 ds_add_f32 retires ~1 lane per 3 clocks (193 clk per wave64 instruction, measured with
+// tools/dev/micro/lds_atomics*.hip, independent of the address pattern) while ds_add_f64 takes 8.7 clk (44 clk with 4 lanes per
+// address) and ds_add_u32 4.8 clk — fp32 LDS atomics were the dominant cost of every backward kernel that used them.
+template <int SLOTS, int NV, typename T = double>
 struct VertexAccum {
   int key[SLOTS];
-  float val[SLOTS][NV];
+  T val[SLOTS][NV];
 
   __device__ __forceinline__ void clear() {
     for (int i = threadIdx.x; i < SLOTS; i += blockDim.x) {
       key[i] = -1;
 #pragma unroll
-      for (int c = 0; c < NV; ++c) val[i][c] = 0.f;
+      for (int c = 0; c < NV; ++c) val[i][c] = (T)0;
     }
   }
   // returns slot or -1 (table full)
@@ -83,5 +86,5 @@ struct VertexAccum {
     }
     return -1;
   }
-  __device__ __forceinline__ void add(int slot, int c, float x) { atomicAdd(&val[slot][c], x); }
+  __device__ __forceinline__ void add(int slot, int c, float x) { atomicAdd(&val[slot][c], (T)x); }
 };

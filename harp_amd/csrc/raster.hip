@@ -149,7 +149,8 @@ __global__ void __launch_bounds__(256) raster_kernel(const FaceRec* __restrict__
   __shared__ float s_z2[kStage];
   __shared__ int32_t s_id[kStage];
   __shared__ int lds_cnt[4];
-  __shared__ float s_g[MODE == 2 ? kStage : 1][6];   // MODE 2: per-staged-face gradient accumulators (x,y of 3 verts)
+  // MODE 2: per-staged-face gradient accumulators (x,y of 3 verts).  double: ds_add_f64 is ~20x faster than ds_add_f32 on gfx950
+  __shared__ double s_g[MODE == 2 ? kStage : 1][6];
 
   const int b = blockIdx.z;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -205,7 +206,7 @@ __global__ void __launch_bounds__(256) raster_kernel(const FaceRec* __restrict__
     }
     if (MODE == 2) {
 #pragma unroll
-      for (int c = 0; c < 6; ++c) s_g[threadIdx.x][c] = 0.f;
+      for (int c = 0; c < 6; ++c) s_g[threadIdx.x][c] = 0.0;
     }
     __syncthreads();
     // ---- walk: each wave ballots the staged faces against its 16x4 strip
@@ -308,10 +309,10 @@ __global__ void __launch_bounds__(256) raster_kernel(const FaceRec* __restrict__
               else                          { ia = 1; ib = 2; ax = t.x1; ay = t.y1; bx = t.x2; by = t.y2; tt = tc; }
               const float qx = ax + tt * (bx - ax), qy = ay + tt * (by - ay);
               const float cx = gd * 2.f * (qx - px), cy = gd * 2.f * (qy - py);
-              atomicAdd(&s_g[j][2 * ia], (1.f - tt) * cx);
-              atomicAdd(&s_g[j][2 * ia + 1], (1.f - tt) * cy);
-              atomicAdd(&s_g[j][2 * ib], tt * cx);
-              atomicAdd(&s_g[j][2 * ib + 1], tt * cy);
+              atomicAdd(&s_g[j][2 * ia], (double)((1.f - tt) * cx));
+              atomicAdd(&s_g[j][2 * ia + 1], (double)((1.f - tt) * cy));
+              atomicAdd(&s_g[j][2 * ib], (double)(tt * cx));
+              atomicAdd(&s_g[j][2 * ib + 1], (double)(tt * cy));
             }
           }
         }
@@ -324,7 +325,7 @@ __global__ void __launch_bounds__(256) raster_kernel(const FaceRec* __restrict__
       float* gb = g_ndc + (size_t)b * V * 3;
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
-        const float gx = s_g[threadIdx.x][2 * k], gy = s_g[threadIdx.x][2 * k + 1];
+        const float gx = (float)s_g[threadIdx.x][2 * k], gy = (float)s_g[threadIdx.x][2 * k + 1];
         if (gx != 0.f || gy != 0.f) {
           const int v = faces[3 * fid + k];
           atomicAdd(gb + 3 * v, gx);

@@ -14,6 +14,31 @@
 
 namespace {
 
+#ifndef SHADE_R
+#define SHADE_R 1            // the backward walks SHADE_R x SHADE_R tiles per workgroup
+#endif
+#ifndef SHADE_TEX_SLOTS
+#define SHADE_TEX_SLOTS 512
+#endif
+#ifndef SHADE_VTX_SLOTS
+#define SHADE_VTX_SLOTS 256
+#endif
+#ifndef SHADE_ACC_T
+#define SHADE_ACC_T double
+#endif
+#ifndef SHADE_OCC
+#define SHADE_OCC 3
+#endif
+constexpr int kTexSlots = SHADE_TEX_SLOTS, kVtxSlots = SHADE_VTX_SLOTS, kBwdR = SHADE_R;
+#ifndef SHADE_PRERED
+#define SHADE_PRERED 19      // xor distances of the lane-merge butterfly before the vertex LDS atomics (1 | 2 | 16)
+#endif
+// value of lane (lane ^ bit): DPP quad permutes for 1 and 2, ds_bpermute otherwise
+__device__ __forceinline__ int lane_xor(int x, int bit) {
+  if (bit == 1) return __builtin_amdgcn_mov_dpp(x, 0xB1, 0xF, 0xF, true);
+  if (bit == 2) return __builtin_amdgcn_mov_dpp(x, 0x4E, 0xF, 0xF, true);
+  return __shfl_xor(x, bit);
+}
 struct V3 { float x, y, z; };
 __device__ __forceinline__ V3 mk(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
 __device__ __forceinline__ V3 ld(const float* p) { return mk(p[0], p[1], p[2]); }
@@ -130,20 +155,21 @@ struct Frag {
 };
 
 template <bool BWD>
-__global__ void __launch_bounds__(256, 3) shade_kernel(const harp_shade_args A) {
+__global__ void __launch_bounds__(256, SHADE_OCC) shade_kernel(const harp_shade_args A) {
   __shared__ float s_red[32];
   // per-vertex accumulators: 0-2 g_verts, 3-5 g_vnormals, 6-8 g_ndc
-  __shared__ VertexAccum<BWD ? 512 : 1, 9> s_acc;
+  __shared__ VertexAccum<BWD ? kVtxSlots : 1, 9, SHADE_ACC_T> s_acc;
   // per-texel accumulators (key = texel index): 0-2 albedo gradient, 3-5 normal-map gradient. Neighbouring pixels share
   // bilinear corners (~1.4 px per texel), and same-line float atomics serialise in L2: pre-summing in LDS cuts the global
   // atomics ~4x and removes the contention (ablation: the two texture scatters were 1.75 of 2.6 ms).
-  __shared__ VertexAccum<BWD ? 1024 : 1, 6> s_tex;
+  __shared__ VertexAccum<BWD ? kTexSlots : 1, 6, SHADE_ACC_T> s_tex;
   const int b = blockIdx.z;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int S = A.S, V = A.V;
-  // forward: one 16x16 tile per workgroup.  backward: a 32x32 region = 2x2 tiles walked one after the other with the SAME LDS
-  // accumulators, so vertices / texels shared by neighbouring tiles are flushed once (memory-side float atomics are the cost).
-  constexpr int R = BWD ? 2 : 1;
+  // forward: one 16x16 tile per workgroup.  backward: SHADE_R x SHADE_R tiles walked one after the other with the SAME LDS
+  // accumulators (vertices / texels shared by neighbouring tiles are then flushed once).  With the double-precision tables one
+  // tile per workgroup at 3 workgroups per CU measured the same as 2x2 tiles at 2 per CU and keeps the table load factor at ~0.6.
+  constexpr int R = BWD ? kBwdR : 1;
   if (BWD) {
     bool any_act = false;
 #pragma unroll
@@ -181,6 +207,12 @@ __global__ void __launch_bounds__(256, 3) shade_kernel(const harp_shade_args A) 
     if (in_img) { float* r = A.rgb + o * 3; r[0] = A.bg[0]; r[1] = A.bg[1]; r[2] = A.bg[2]; }
   }
   float out_rgb[3] = {A.bg[0], A.bg[1], A.bg[2]};
+  float vsc[BWD ? 27 : 1];   // backward: gradient of the face's 3 vertices x (position, normal, ndc), scattered after the branch
+  int vidx[3] = {0, 0, 0};
+  if (BWD) {
+#pragma unroll
+    for (int c = 0; c < 27; ++c) vsc[BWD ? c : 0] = 0.f;
+  }
   if (act) {
     const float px = pix_to_ndc(xi, S), py = pix_to_ndc(yi, S);
     const float* col = A.colors;               // amb(3) diff(3) spec(3)
@@ -354,24 +386,51 @@ __global__ void __launch_bounds__(256, 3) shade_kernel(const harp_shade_args A) 
       float gb2 = dot(v2, g_p) + dot(n2, g_n) + uv2x * gu + uv2y * gv;
       float gnd[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       bary_bwd(g.t, px, py, g.br, gb0, gb1, gb2, gnd);
+      const float bw[3] = {b0, b1, b2};
+      vidx[0] = g.i0; vidx[1] = g.i1; vidx[2] = g.i2;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        vsc[9 * k + 0] = g_p.x * bw[k]; vsc[9 * k + 1] = g_p.y * bw[k]; vsc[9 * k + 2] = g_p.z * bw[k];
+        vsc[9 * k + 3] = g_n.x * bw[k]; vsc[9 * k + 4] = g_n.y * bw[k]; vsc[9 * k + 5] = g_n.z * bw[k];
+        vsc[9 * k + 6] = gnd[3 * k]; vsc[9 * k + 7] = gnd[3 * k + 1]; vsc[9 * k + 8] = gnd[3 * k + 2];
+      }
+    }
+  }
+  if (BWD && !(A.debug_skip & 8)) {
+    // vertex gradients: lanes are 16x4 pixels and a face covers ~16 of them, so neighbouring lanes mostly add to the SAME three
+    // vertices and same-address LDS atomics serialise.  Merge lanes that hit the same face first (butterfly over SHADE_PRERED's
+    // xor distances: 1, 2 = x neighbours through DPP, 16 = the row below through ds_bpermute), then only the surviving lanes add.
+    bool alive = act;
+    const int fk = act ? f : -1;
+#pragma unroll
+    for (int bit = 1; bit < 64; bit <<= 1) {
+      if (!(SHADE_PRERED & bit)) continue;
+      const int fo = lane_xor(fk, bit);
+      const int ao = lane_xor(alive ? 1 : 0, bit);
+      const bool same = alive && ao && fo == fk;
+      const bool lower = !(lane & bit);
+#pragma unroll
+      for (int c = 0; c < 27; ++c) {
+        const float o2 = __int_as_float(lane_xor(__float_as_int(vsc[c]), bit));
+        if (same && lower) vsc[c] += o2;
+      }
+      if (same && !lower) alive = false;
+    }
+    if (alive) {
       float* gvb = A.g_verts + (size_t)b * V * 3;
       float* gnb = A.g_vnormals + (size_t)b * V * 3;
       float* gdb = A.g_ndc + (size_t)b * V * 3;
-      const int vi[3] = {g.i0, g.i1, g.i2};
-      const float bw[3] = {b0, b1, b2};
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
-        const float vals[9] = {g_p.x * bw[k], g_p.y * bw[k], g_p.z * bw[k], g_n.x * bw[k], g_n.y * bw[k], g_n.z * bw[k],
-                               gnd[3 * k], gnd[3 * k + 1], gnd[3 * k + 2]};
-        const int slot = (A.debug_skip & 8) ? 0 : s_acc.find(vi[k]);
-        if (A.debug_skip & 8) {
-        } else if (slot >= 0) {
+        const int slot = s_acc.find(vidx[k]);
+        if (slot >= 0) {
 #pragma unroll
-          for (int c = 0; c < 9; ++c) s_acc.add(slot, c, vals[c]);
+          for (int c = 0; c < 9; ++c) s_acc.add(slot, c, vsc[9 * k + c]);
         } else {
 #pragma unroll
           for (int c = 0; c < 3; ++c) {
-            atomicAdd(gvb + 3 * vi[k] + c, vals[c]); atomicAdd(gnb + 3 * vi[k] + c, vals[3 + c]); atomicAdd(gdb + 3 * vi[k] + c, vals[6 + c]);
+            atomicAdd(gvb + 3 * vidx[k] + c, vsc[9 * k + c]); atomicAdd(gnb + 3 * vidx[k] + c, vsc[9 * k + 3 + c]);
+            atomicAdd(gdb + 3 * vidx[k] + c, vsc[9 * k + 6 + c]);
           }
         }
       }
@@ -413,27 +472,29 @@ __global__ void __launch_bounds__(256, 3) shade_kernel(const harp_shade_args A) 
         else if (A.g_light_T) atomicAdd(A.g_light_T + 3 * b + 2, s);
       }
     }
-    // flush the per-vertex accumulators: one global atomic per (vertex, component) per workgroup
+    // flush the LDS accumulators: one global float atomic per (key, component) per workgroup.  (A variant that appended the
+    // entries to per-bucket lists and summed them in a second kernel with plain stores was measured SLOWER: the memory-side
+    // atomics are fire-and-forget, the cost of this kernel was the LDS side — see DESIGN.md.)
     float* gvb = A.g_verts + (size_t)b * V * 3;
     float* gnb = A.g_vnormals + (size_t)b * V * 3;
     float* gdb = A.g_ndc + (size_t)b * V * 3;
-    for (int i = threadIdx.x; i < 512; i += 256) {
+    for (int i = threadIdx.x; i < kVtxSlots; i += 256) {
       const int v = s_acc.key[i];
-      if (v < 0) continue;
+      if (v < 0 || (A.debug_skip & 32)) continue;
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
-        const float a0 = s_acc.val[i][c], a1 = s_acc.val[i][3 + c], a2 = s_acc.val[i][6 + c];
+        const float a0 = (float)s_acc.val[i][c], a1 = (float)s_acc.val[i][3 + c], a2 = (float)s_acc.val[i][6 + c];
         if (a0 != 0.f) atomicAdd(gvb + 3 * v + c, a0);
         if (a1 != 0.f) atomicAdd(gnb + 3 * v + c, a1);
         if (a2 != 0.f) atomicAdd(gdb + 3 * v + c, a2);
       }
     }
-    for (int i = threadIdx.x; i < 1024; i += 256) {
+    for (int i = threadIdx.x; i < kTexSlots; i += 256) {
       const int key = s_tex.key[i];
-      if (key < 0) continue;
+      if (key < 0 || (A.debug_skip & 16)) continue;
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
-        const float a0 = s_tex.val[i][c], a1 = s_tex.val[i][3 + c];
+        const float a0 = (float)s_tex.val[i][c], a1 = (float)s_tex.val[i][3 + c];
         if (a0 != 0.f) atomicAdd(A.g_tex + (size_t)key * 3 + c, a0);
         if (a1 != 0.f) atomicAdd(A.g_nmap + (size_t)key * 3 + c, a1);
       }
@@ -480,7 +541,7 @@ __global__ void __launch_bounds__(256) depth_bwd_kernel(const int32_t* __restric
     const int v = s_acc.key[i];
     if (v < 0) continue;
 #pragma unroll
-    for (int c = 0; c < 3; ++c) if (s_acc.val[i][c] != 0.f) atomicAdd(gdb + 3 * v + c, s_acc.val[i][c]);
+    for (int c = 0; c < 3; ++c) if (s_acc.val[i][c] != 0) atomicAdd(gdb + 3 * v + c, (float)s_acc.val[i][c]);
   }
 }
 
@@ -505,7 +566,7 @@ int harp_shade_fwd(const harp_shade_args* a, hipStream_t stream) {
 
 int harp_shade_bwd(const harp_shade_args* a, hipStream_t stream) {
   if (!a || !a->face_id || !a->recs || !a->g_rgb || !a->g_verts || !a->g_vnormals || !a->g_ndc) return HARP_ERR_ARG;
-  const int R = 2 * kTile;      // the backward kernel walks 2x2 tiles per workgroup
+  const int R = kBwdR * kTile;      // the backward kernel walks kBwdR x kBwdR tiles per workgroup
   const dim3 grid((a->S + R - 1) / R, (a->S + R - 1) / R, a->B);
   hipLaunchKernelGGL(shade_kernel<true>, grid, dim3(256), 0, stream, *a);
   HARP_CHECK_LAUNCH();

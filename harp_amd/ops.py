@@ -4,6 +4,8 @@ These are the building blocks the reference-API mirror modules (renderer/, utils
 fused engine call.  Every op takes/returns plain contiguous float32/int32 HIP tensors."""
 import math
 
+import ctypes
+
 import torch
 
 from . import _lib
