@@ -44,7 +44,8 @@ def build_engine(rank, world, device, T=T_FRAMES, img=S, B=B_PER_GPU, seed=0):
     seq, focal = synth.make_sequence(model, T, img, seed=seed)
     seq["joints"] = torch.zeros(T, 21, 3)
     eng = FitEngine(model, topo, tpl["verts_uvs"], tpl["faces_uvs"], tpl["uv_mask"].astype(np.float32) / 255.0, seq, img, focal, B,
-                    device=device, rank=rank, world_size=world, seed=seed)
+                    device=device, rank=rank, world_size=world, seed=seed,
+                    micro_batches=int(os.environ.get("HARP_MICRO_BATCHES", "1")))
     # ---- synthetic targets: render a perturbed "ground-truth" parameter set with the engine itself
     Tl = T // world
     lo = rank * Tl
@@ -230,9 +231,7 @@ def main():
 
     # the whole frame schedule lives on the device (the reference's DataLoader hands over host tensors every step)
     sched = torch.stack([(torch.arange(eng.B) + i * eng.B) % Tl + eng.target_offset for i in range(args.warmup + args.steps)]).to(torch.int32).to(device)
-
-    def batch(i):
-        return sched[i]
+    eng.set_schedule(sched)                     # step(None, ...) advances through it inside the captured graph: zero host-side copies
 
     def sync():
         if world > 1 or force_dist:
@@ -240,11 +239,11 @@ def main():
         torch.cuda.synchronize()
 
     for i in range(args.warmup):
-        eng.step(batch(i), True, True, use_graph=not args.no_graph)
+        eng.step(None, True, True, use_graph=not args.no_graph)
     sync()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        eng.step(batch(args.warmup + i), True, True, use_graph=not args.no_graph)
+        eng.step(None, True, True, use_graph=not args.no_graph)
     sync()
     dt = time.perf_counter() - t0
     if world > 1 or force_dist:

@@ -148,6 +148,20 @@ __global__ void scale_kernel(const float* __restrict__ x, float s, int n, float*
   if (i < n) y[i] = x[i] * s;
 }
 
+// One row of a device-resident batch schedule -> the step's frame ids (and target-local ids); bumps the row counter.  Lives inside
+// the step's hipGraph so that a replay needs no host-side copy at all.
+__global__ void schedule_next_kernel(const int32_t* __restrict__ sched, int n_rows, int B, int target_offset,
+                                     int32_t* __restrict__ counter, int32_t* __restrict__ fid, int32_t* __restrict__ tfid) {
+  const int row = (int)((unsigned)counter[0] % (unsigned)n_rows);
+  for (int i = threadIdx.x; i < B; i += blockDim.x) {
+    const int f = sched[(size_t)row * B + i];
+    fid[i] = f;
+    tfid[i] = f - target_offset;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) counter[0] = row + 1;
+}
+
 }  // namespace
 
 extern "C" {
@@ -194,6 +208,14 @@ int harp_light_setup_bwd(const float* centroid, const float* light_pos, const fl
 int harp_scale(const float* x, float s, int n, float* y, hipStream_t stream) {
   if (!x || !y) return HARP_ERR_ARG;
   hipLaunchKernelGGL(scale_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, x, s, n, y);
+  HARP_CHECK_LAUNCH();
+  return HARP_OK;
+}
+
+int harp_schedule_next(const int32_t* schedule, int n_rows, int B, int target_offset, int32_t* counter, int32_t* fid, int32_t* tfid,
+                       hipStream_t stream) {
+  if (!schedule || !counter || !fid || !tfid || n_rows <= 0 || B <= 0) return HARP_ERR_ARG;
+  hipLaunchKernelGGL(schedule_next_kernel, dim3(1), dim3(256), 0, stream, schedule, n_rows, B, target_offset, counter, fid, tfid);
   HARP_CHECK_LAUNCH();
   return HARP_OK;
 }

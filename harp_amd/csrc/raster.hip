@@ -119,16 +119,24 @@ __global__ void __launch_bounds__(256) bin_faces_kernel(const float4* __restrict
   const float4* bb = bbs + (size_t)b * F;
   int32_t* out = bins + ((size_t)b * nst + st) * F;
   int running = 0;
-  for (int base = 0; base < F; base += 64) {
-    const int f = base + lane;
-    bool hit = false;
-    if (f < F) {
-      const float4 q = bb[f];
-      hit = !(nx_lo > q.y || nx_hi < q.x || ny_lo > q.w || ny_hi < q.z);
+  // the loop is a chain of dependent ballots but the loads are independent: issue kUnroll of them before the first use, otherwise
+  // every iteration pays a full L2 round trip (measured 50 us for 97 iterations at F = 6152; 2 waves per SIMD cannot hide it)
+  constexpr int kUnroll = 8;
+  for (int base = 0; base < F; base += 64 * kUnroll) {
+    float4 q[kUnroll];
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) {
+      const int f = base + u * 64 + lane;
+      q[u] = (f < F) ? bb[f] : make_float4(3.0e38f, -3.0e38f, 3.0e38f, -3.0e38f);
     }
-    const unsigned long long m = __ballot(hit);
-    if (hit) out[running + __popcll(m & ((1ull << lane) - 1ull))] = f;
-    running += __popcll(m);
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) {
+      const int f = base + u * 64 + lane;
+      const bool hit = !(nx_lo > q[u].y || nx_hi < q[u].x || ny_lo > q[u].w || ny_hi < q[u].z);
+      const unsigned long long m = __ballot(hit);
+      if (hit) out[running + __popcll(m & ((1ull << lane) - 1ull))] = f;
+      running += __popcll(m);
+    }
   }
   if (lane == 0) bin_count[b * nst + st] = running;
 }

@@ -436,14 +436,38 @@ class FitEngine:
         self._ck(L.harp_draw_texture_offsets(self.seed, p(self.draw_counter), self.Ht, self.Wt, 1.0, p(self.dist_albedo), st), "draw_offsets")
         self._ck(L.harp_draw_texture_offsets(self.seed ^ 0x5bd1e995, p(self.draw_counter), self.Ht, self.Wt, 2.0, p(self.dist_normal), st), "draw_offsets")
 
+    def set_schedule(self, schedule):
+        """(n_rows, batch_size) global frame ids, kept on the device: `step(None, ...)` then takes the next row (wrapping around)
+        inside the step's hipGraph, so a replay needs no host-side copy at all (the reference's DataLoader hands a host tensor over
+        every step, optimize_sequence.py:399, :446)."""
+        sch = torch.as_tensor(schedule).to(torch.int32).to(self.dev).contiguous()
+        if sch.dim() != 2 or sch.shape[1] != self.B:
+            raise ValueError(f"schedule must be (n_rows, {self.B}), got {tuple(sch.shape)}")
+        self.schedule = sch
+        self.schedule_row = torch.zeros(1, dtype=torch.int32, device=self.dev)
+        self._graphs = {}                               # graphs captured against an older schedule buffer are stale
+
+    def _schedule_next(self):
+        self._ck(_lib.lib().harp_schedule_next(_lib.ptr(self.schedule), int(self.schedule.shape[0]), self.B, self.target_offset,
+                                               _lib.ptr(self.schedule_row), _lib.ptr(self.fid), _lib.ptr(self.tfid), _lib.stream()),
+                 "schedule_next")
+
     def step(self, fid, coarse=True, app=True, use_graph=True):
         """One optimisation step on the frames `fid` (global frame ids, length <= batch_size; a shorter — last, partial —
-        batch runs eagerly, optimize_sequence.py:396-399)."""
-        fid = torch.as_tensor(fid)
-        n = int(fid.shape[0])
+        batch runs eagerly, optimize_sequence.py:396-399).  fid=None: the next row of the schedule given to `set_schedule`."""
+        scheduled = fid is None
+        if scheduled:
+            if getattr(self, "schedule", None) is None:
+                raise ValueError("step(None, ...) needs set_schedule() first")
+            n = self.B
+        else:
+            fid = torch.as_tensor(fid)
+            n = int(fid.shape[0])
         if n > self.B:
             raise ValueError(f"batch of {n} frames exceeds the engine's batch_size {self.B}")
-        if fid.is_cuda:                                   # device-resident schedule: no host sync at all
+        if scheduled:
+            pass
+        elif fid.is_cuda:                                 # device-resident batch: no host sync at all
             self.fid[:n].copy_(fid, non_blocking=True)
             self.tfid[:n].copy_(fid - self.target_offset, non_blocking=True)
         else:
@@ -455,28 +479,33 @@ class FitEngine:
             self.set_stage(coarse, app)
             self._stage = key
         use_micro = self.micro > 1 and n == self.B and getattr(self, "overlap", True)
-        fb = (lambda: self._step_micro(coarse, app)) if use_micro else (lambda: self.forward_backward(coarse, app, B=n))
+        fb0 = (lambda: self._step_micro(coarse, app)) if use_micro else (lambda: self.forward_backward(coarse, app, B=n))
+        fb = (lambda: (self._schedule_next(), fb0())) if scheduled else fb0
         dist_on = self.world > 1 or getattr(self, "force_allreduce", False)
         if not use_graph or n != self.B or (dist_on and not getattr(self, "graph_collectives", False)):
             fb()
             self.allreduce()
             self.adam(coarse, app)
             return
-        g = self._graphs.get(key)
+        gkey = (coarse, app, scheduled)
+        g = self._graphs.get(gkey)
         if g is None:
             # warm-up on a side stream, then capture (torch's documented recipe)
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
+            row = self.schedule_row.clone() if scheduled else None
             with torch.cuda.stream(side):
                 fb()
             torch.cuda.current_stream().wait_stream(side)
+            if scheduled:
+                self.schedule_row.copy_(row)             # the warm-up pass must not consume a schedule row
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 fb()
                 self.allreduce()                         # no-op for a single rank; RCCL all-reduce is captured into the graph otherwise
                 self.adam(coarse, app)
-            self._graphs[key] = g
+            self._graphs[gkey] = g
             # the capture itself does not execute; fall through to the first replay
         g.replay()
 

@@ -322,3 +322,31 @@ def test_texture_offset_generator(sc):
     e1.draw_texture_offsets()
     torch.cuda.synchronize()
     assert not torch.equal(prev, e1.dist_albedo)
+
+
+def test_device_schedule_matches_explicit_batches(sc):
+    """step(None, ...) walks the device-resident schedule inside the captured graph (harp_schedule_next): same parameters as passing the
+    same batches explicitly, including the wrap-around and the warm-up pass of the first capture not consuming a row."""
+    from harp_amd.engine import FitEngine
+    tg = sc["targets"]
+    rows = torch.tensor([[2, 0], [1, 2], [0, 1]], dtype=torch.int32)
+
+    def run(scheduled):
+        eng = FitEngine(sc["model_np"], sc["topo_np"], sc["tpl"]["verts_uvs"], sc["tpl"]["faces_uvs"], sc["uv_mask"].float(), sc["seq"], sc["S"],
+                        sc["focal"], 2, device=DEV, seed=3)
+        eng.set_targets(tg["y_true"], tg["y_sil"], tg["y_sil_col"])
+        if scheduled:
+            eng.set_schedule(rows)
+        for i in range(5):                           # 5 steps over 3 rows: wraps around
+            eng.step(None if scheduled else rows[i % 3].to(DEV), True, True, use_graph=True)
+        torch.cuda.synchronize()
+        return eng
+    a, b = run(True), run(False)
+    assert torch.equal(a.fid.cpu(), rows[4 % 3]) and int(a.schedule_row.item()) == 2
+    for k in ("pose", "cam", "verts_disps", "shape", "light_positions"):
+        assert (a.params[k] - b.params[k]).abs().max().item() < 2e-3, k          # Adam steps are sign-like: atomics order can flip a tiny gradient
+    d = (a.params["texture"] - b.params["texture"]).abs()
+    assert d.mean().item() < 2e-5 and (d > 1e-3).float().mean().item() < 1e-3
+    with pytest.raises(ValueError):
+        FitEngine(sc["model_np"], sc["topo_np"], sc["tpl"]["verts_uvs"], sc["tpl"]["faces_uvs"], sc["uv_mask"].float(), sc["seq"], sc["S"],
+                  sc["focal"], 2, device=DEV).step(None)

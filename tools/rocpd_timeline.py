@@ -1,0 +1,32 @@
+"""Print the kernel timeline of the last full step in a rocprofv3 rocpd database: start offset, duration, gap to the previous
+kernel's end, kernel name.  Steps are delimited by the Adam tick kernel.   python tools/rocpd_timeline.py DB [marker-substring]"""
+import sqlite3
+import sys
+
+
+def main(path, marker="adam_tick"):
+    db = sqlite3.connect(path)
+    cur = db.cursor()
+    cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
+    name = "name" if "name" in cols else [c for c in cols if "name" in c][0]
+    extra = ", stream_id" if "stream_id" in cols else (", queue_id" if "queue_id" in cols else "")
+    rows = cur.execute(f"select {name}, start, end{extra} from kernels order by start").fetchall()
+    marks = [i for i, r in enumerate(rows) if marker in r[0]]
+    if len(marks) < 4:
+        print("not enough steps"); return
+    # a step = from after the second-to-last pair of markers to the last marker
+    ends = marks[1::2] if len(marks) % 2 == 0 else marks
+    lo, hi = ends[-2] + 2, ends[-1] + 2
+    seg = rows[lo:hi]
+    t0 = seg[0][1]
+    prev_end = t0
+    print(f"{'start_us':>9s} {'dur_us':>8s} {'gap_us':>8s} {'q':>4s}  kernel")
+    for r in seg:
+        q = r[3] if len(r) > 3 else 0
+        print(f"{(r[1]-t0)/1e3:9.1f} {(r[2]-r[1])/1e3:8.1f} {(r[1]-prev_end)/1e3:8.1f} {str(q)[-4:]:>4s}  {r[0][:90]}")
+        prev_end = max(prev_end, r[2])
+    print(f"step span {(max(r[2] for r in seg)-t0)/1e3:.1f} us, kernels {len(seg)}, sum of durations {sum(r[2]-r[1] for r in seg)/1e3:.1f} us")
+
+
+if __name__ == "__main__":
+    main(*sys.argv[1:])
