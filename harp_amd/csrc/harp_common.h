@@ -86,5 +86,16 @@ struct VertexAccum {
     }
     return -1;
   }
+  // slot of an existing key or -1 (never inserts)
+  __device__ __forceinline__ int lookup(int v) const {
+    unsigned h = ((unsigned)v * 2654435761u) & (SLOTS - 1);
+    for (int probe = 0; probe < 32; ++probe) {
+      const int k = key[h];
+      if (k == v) return (int)h;
+      if (k == -1) return -1;
+      h = (h + 1) & (SLOTS - 1);
+    }
+    return -1;
+  }
   __device__ __forceinline__ void add(int slot, int c, float x) { atomicAdd(&val[slot][c], (T)x); }
 };

@@ -195,6 +195,76 @@ __global__ void __launch_bounds__(256) raster_kernel(const FaceRec* __restrict__
     if (__syncthreads_or(need ? 1 : 0) == 0) return;
   }
 
+  unsigned hq = 0u;
+  unsigned long long sq = 0ull;
+  int hn = 0, sn = 0;
+  // ---- phase 2: every lane pops its own queued faces (LDS gathers with per-lane addresses)
+  auto drain = [&]() {
+    if (MODE != 2) {
+      while (__any(hn > 0)) {
+        if (hn > 0) {
+          const int j = (int)(hq & 0xffu);
+          hq >>= 8; --hn;
+          const Tri t = tri_from(s_a[j], s_b[j], make_float4(s_z2[j], 0.f, 0.f, 0.f));
+          const float e0 = edge_fn(px, py, t.x1, t.y1, t.x2, t.y2);
+          const float e1 = edge_fn(px, py, t.x2, t.y2, t.x0, t.y0);
+          const float e2 = edge_fn(px, py, t.x0, t.y0, t.x1, t.y1);
+          const float area = edge_fn(t.x2, t.y2, t.x0, t.y0, t.x1, t.y1) + kEps;
+          // BarycentricCoordsForward + PerspectiveCorrection with reciprocals (<= 2 ulp from the IEEE-division form)
+          const float ra = __builtin_amdgcn_rcpf(area);
+          const float t0 = (e0 * ra) * t.z1 * t.z2, t1 = t.z0 * (e1 * ra) * t.z2, t2 = t.z0 * t.z1 * (e2 * ra);
+          const float rd = __builtin_amdgcn_rcpf(fmaxf(t0 + t1 + t2, kEps));
+          const float pz = (t0 * rd) * t.z0 + (t1 * rd) * t.z1 + (t2 * rd) * t.z2;
+          if (pz >= 0.f && pz < best_z) { best_z = pz; best_f = s_id[j]; }
+        }
+      }
+    }
+    if (MODE >= 1) {
+      while (__any(sn > 0)) {
+        if (sn > 0) {
+          const int j = (int)(sq & 0xffull);
+          sq >>= 8; --sn;
+          if (MODE == 2 || prod != 0.f) {
+            const Tri t = tri_from(s_a[j], s_b[j], make_float4(0.f, 0.f, 0.f, 0.f));
+            const float e0 = edge_fn(px, py, t.x1, t.y1, t.x2, t.y2);
+            const float e1 = edge_fn(px, py, t.x2, t.y2, t.x0, t.y0);
+            const float e2 = edge_fn(px, py, t.x0, t.y0, t.x1, t.y1);
+            const float area = edge_fn(t.x2, t.y2, t.x0, t.y0, t.x1, t.y1) + kEps;
+            const float sg = (area > 0.f) ? 1.f : ((area < 0.f) ? -1.f : 0.f);
+            const bool inside = (e0 * sg > 0.f) && (e1 * sg > 0.f) && (e2 * sg > 0.f);
+            float ta, tb, tc;
+            const float d01 = seg_dist2(px, py, t.x0, t.y0, t.x1, t.y1, ta);
+            const float d02 = seg_dist2(px, py, t.x0, t.y0, t.x2, t.y2, tb);
+            const float d12 = seg_dist2(px, py, t.x1, t.y1, t.x2, t.y2, tc);
+            const float dist = fminf(d01, fminf(d02, d12));
+            if (inside || dist < blur) {
+              const float sd = inside ? -dist : dist;
+              const float p = 1.0f / (1.0f + expf(sd / sigma));   // sigmoid(-sd/sigma)
+              if (MODE == 1) {
+                prod *= (1.0f - p);
+              } else {
+                // d alpha / d sd = -P * p / sigma  (P = prod over all faces)
+                const float g_sd = ga * (-P * p / sigma);
+                const float gd = inside ? -g_sd : g_sd;     // d/d(dist^2)
+                // PointLineDistanceBackward on the argmin edge (t treated as constant)
+                int ia, ib; float ax, ay, bx, by, tt;
+                if (d01 <= d02 && d01 <= d12) { ia = 0; ib = 1; ax = t.x0; ay = t.y0; bx = t.x1; by = t.y1; tt = ta; }
+                else if (d02 <= d12)          { ia = 0; ib = 2; ax = t.x0; ay = t.y0; bx = t.x2; by = t.y2; tt = tb; }
+                else                          { ia = 1; ib = 2; ax = t.x1; ay = t.y1; bx = t.x2; by = t.y2; tt = tc; }
+                const float qx = ax + tt * (bx - ax), qy = ay + tt * (by - ay);
+                const float cx = gd * 2.f * (qx - px), cy = gd * 2.f * (qy - py);
+                atomicAdd(&s_g[j][2 * ia], (double)((1.f - tt) * cx));
+                atomicAdd(&s_g[j][2 * ia + 1], (double)((1.f - tt) * cy));
+                atomicAdd(&s_g[j][2 * ib], (double)(tt * cx));
+                atomicAdd(&s_g[j][2 * ib + 1], (double)(tt * cy));
+              }
+            }
+          }
+        }
+      }
+    }
+  };
+
   for (int base = 0; base < n; base += kStage) {
     // ---- stage: filter this round's list entries against the 16x16 tile, compact into LDS
     const int e = base + threadIdx.x;
@@ -244,17 +314,19 @@ __global__ void __launch_bounds__(256) raster_kernel(const FaceRec* __restrict__
           }
         }
       }
+      // ---- phase 1: classify only.  The expensive parts (depth interpolation of a hit, the three segment distances + exp of a
+      // rim face) used to run for the whole wave whenever ANY lane needed them (~130 VALU instructions per face iteration); each lane
+      // now queues the staged-face indices it needs (hard: 4 x 8 bit, soft: 8 x 8 bit) and the queues are drained per lane, in
+      // ascending face order (same tie-break, same product order => bit-identical results), a handful of iterations per strip.
       unsigned long long m = __ballot(whit);
       while (m) {
         const int j = g + __ffsll((unsigned long long)m) - 1;
         m &= m - 1;
         const float4 q = s_bb[j];
-        const bool inbox = !(px > q.y || px < q.x || py > q.w || py < q.z);
-        if (!__any(inbox && need)) continue;
+        const bool inbox = in_img && !(px > q.y || px < q.x || py > q.w || py < q.z);
+        if (!__any(inbox && (MODE == 2 ? need : true))) continue;
         const float4 fa = s_a[j], fb = s_b[j];
-        const Tri t = tri_from(fa, fb, make_float4(s_z2[j], 0.f, 0.f, 0.f));
-        // ---- cheap classification first (no divisions): un-normalised edge functions and their signs.
-        // inside  <=>  all perspective-corrected barycentrics > 0  <=>  e_i * sign(area') > 0 for all i   (z > 0 by culling)
+        const Tri t = tri_from(fa, fb, make_float4(0.f, 0.f, 0.f, 0.f));
         const float e0 = edge_fn(px, py, t.x1, t.y1, t.x2, t.y2);
         const float e1 = edge_fn(px, py, t.x2, t.y2, t.x0, t.y0);
         const float e2 = edge_fn(px, py, t.x0, t.y0, t.x1, t.y1);
@@ -262,12 +334,10 @@ __global__ void __launch_bounds__(256) raster_kernel(const FaceRec* __restrict__
         const float sg = (area > 0.f) ? 1.f : ((area < 0.f) ? -1.f : 0.f);
         const float e0s = e0 * sg, e1s = e1 * sg, e2s = e2 * sg;
         const bool inside = (e0s > 0.f) && (e1s > 0.f) && (e2s > 0.f);
-        const bool hard_hit = (MODE != 2) && inside && inbox && in_img;
-        bool soft = false;
+        if (MODE != 2 && inside && inbox) { hq |= (unsigned)j << (8 * hn); ++hn; }
         if (MODE >= 1) {
-          soft = (MODE == 1) ? (inbox && in_img && prod != 0.f) : (inbox && need);
+          bool soft = (MODE == 1) ? (inbox && prod != 0.f) : (inbox && need);
           if (soft) {
-            // squared edge lengths: e0 <-> (v1,v2), e1 <-> (v2,v0), e2 <-> (v0,v1)
             const float l12 = (t.x2 - t.x1) * (t.x2 - t.x1) + (t.y2 - t.y1) * (t.y2 - t.y1);
             const float l20 = (t.x0 - t.x2) * (t.x0 - t.x2) + (t.y0 - t.y2) * (t.y0 - t.y2);
             const float l01 = (t.x1 - t.x0) * (t.x1 - t.x0) + (t.y1 - t.y0) * (t.y1 - t.y0);
@@ -284,48 +354,13 @@ __global__ void __launch_bounds__(256) raster_kernel(const FaceRec* __restrict__
               const float Bf = blur * 1.00001f;
               if ((e0s < 0.f && e0 * e0 >= Bf * l12) || (e1s < 0.f && e1 * e1 >= Bf * l20) || (e2s < 0.f && e2 * e2 >= Bf * l01)) soft = false;
             }
+            if (soft) { sq |= (unsigned long long)j << (8 * sn); ++sn; }
           }
         }
-        if (!__any(hard_hit || soft)) continue;
-        if (hard_hit) {
-          // BarycentricCoordsForward + PerspectiveCorrection with reciprocals (<= 2 ulp from the IEEE-division form)
-          const float ra = __builtin_amdgcn_rcpf(area);
-          const float t0 = (e0 * ra) * t.z1 * t.z2, t1 = t.z0 * (e1 * ra) * t.z2, t2 = t.z0 * t.z1 * (e2 * ra);
-          const float rd = __builtin_amdgcn_rcpf(fmaxf(t0 + t1 + t2, kEps));
-          const float pz = (t0 * rd) * t.z0 + (t1 * rd) * t.z1 + (t2 * rd) * t.z2;
-          if (pz >= 0.f && pz < best_z) { best_z = pz; best_f = s_id[j]; }
-        }
-        if (MODE >= 1 && soft) {
-          float ta, tb, tc;
-          const float d01 = seg_dist2(px, py, t.x0, t.y0, t.x1, t.y1, ta);
-          const float d02 = seg_dist2(px, py, t.x0, t.y0, t.x2, t.y2, tb);
-          const float d12 = seg_dist2(px, py, t.x1, t.y1, t.x2, t.y2, tc);
-          const float dist = fminf(d01, fminf(d02, d12));
-          if (inside || dist < blur) {
-            const float sd = inside ? -dist : dist;
-            const float p = 1.0f / (1.0f + expf(sd / sigma));   // sigmoid(-sd/sigma)
-            if (MODE == 1) {
-              prod *= (1.0f - p);
-            } else {
-              // d alpha / d sd = -P * p / sigma  (P = prod over all faces)
-              const float g_sd = ga * (-P * p / sigma);
-              const float gd = inside ? -g_sd : g_sd;     // d/d(dist^2)
-              // PointLineDistanceBackward on the argmin edge (t treated as constant)
-              int ia, ib; float ax, ay, bx, by, tt;
-              if (d01 <= d02 && d01 <= d12) { ia = 0; ib = 1; ax = t.x0; ay = t.y0; bx = t.x1; by = t.y1; tt = ta; }
-              else if (d02 <= d12)          { ia = 0; ib = 2; ax = t.x0; ay = t.y0; bx = t.x2; by = t.y2; tt = tb; }
-              else                          { ia = 1; ib = 2; ax = t.x1; ay = t.y1; bx = t.x2; by = t.y2; tt = tc; }
-              const float qx = ax + tt * (bx - ax), qy = ay + tt * (by - ay);
-              const float cx = gd * 2.f * (qx - px), cy = gd * 2.f * (qy - py);
-              atomicAdd(&s_g[j][2 * ia], (double)((1.f - tt) * cx));
-              atomicAdd(&s_g[j][2 * ia + 1], (double)((1.f - tt) * cy));
-              atomicAdd(&s_g[j][2 * ib], (double)(tt * cx));
-              atomicAdd(&s_g[j][2 * ib + 1], (double)(tt * cy));
-            }
-          }
-        }
+        if (__any(hn == 4 || sn == 8)) drain();
       }
     }
+    drain();            // staged indices are only valid within this round
     __syncthreads();
     if (MODE == 2 && (int)threadIdx.x < nl) {
       // flush: one global atomic per (staged face, vertex, component) per workgroup

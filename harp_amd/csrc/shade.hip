@@ -30,6 +30,7 @@ namespace {
 #define SHADE_OCC 3
 #endif
 constexpr int kTexSlots = SHADE_TEX_SLOTS, kVtxSlots = SHADE_VTX_SLOTS, kBwdR = SHADE_R;
+constexpr int kTexRows = 512;   // row buckets of the sorted texel flush (a tile touching a taller span of texel rows flushes unsorted)
 #ifndef SHADE_PRERED
 #define SHADE_PRERED 19      // xor distances of the lane-merge butterfly before the vertex LDS atomics (1 | 2 | 16)
 #endif
@@ -39,6 +40,56 @@ __device__ __forceinline__ int lane_xor(int x, int bit) {
   if (bit == 2) return __builtin_amdgcn_mov_dpp(x, 0x4E, 0xF, 0xF, true);
   return __shfl_xor(x, bit);
 }
+// Counting sort of the occupied slots of an LDS hash table by key row (key / width): returns the number of occupied slots and
+// fills s_order[0..n) with slot indices in row order, or -1 when the rows span more than kTexRows (caller flushes unsorted).
+// Called by all 256 threads of the workgroup; ylo/yhi = the row range this lane touched (0x7fffffff / -1 if none).
+template <int SLOTS>
+__device__ __forceinline__ int sort_slots_by_row(const int* __restrict__ keys, int width, int ylo, int yhi, int* s_box, int* s_hist,
+                                                 int* s_order, int* s_wsum) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();                        // previous users of the scratch arrays are done
+  if (threadIdx.x == 0) { s_box[0] = 0x7fffffff; s_box[1] = -1; }
+  for (int i = threadIdx.x; i < kTexRows; i += 256) s_hist[i] = 0;
+  __syncthreads();
+#pragma unroll
+  for (int o2 = 32; o2 >= 1; o2 >>= 1) { ylo = min(ylo, __shfl_xor(ylo, o2)); yhi = max(yhi, __shfl_xor(yhi, o2)); }
+  if (lane == 0 && yhi >= 0) { atomicMin(&s_box[0], ylo); atomicMax(&s_box[1], yhi); }
+  __syncthreads();
+  const int ymin = s_box[0], bh = s_box[1] - s_box[0] + 1;
+  if (s_box[1] < 0 || bh > kTexRows) return -1;
+  constexpr int SPT = (SLOTS + 255) / 256;
+  int rank[SPT], row[SPT];
+#pragma unroll
+  for (int j = 0; j < SPT; ++j) {
+    const int i = threadIdx.x + 256 * j;
+    const int key = i < SLOTS ? keys[i] : -1;
+    row[j] = key >= 0 ? key / width - ymin : -1;
+    if (row[j] >= kTexRows) row[j] = -1;    // cannot happen (keys lie inside the lanes' row range); keeps the scatter in bounds
+    rank[j] = row[j] >= 0 ? atomicAdd(&s_hist[row[j]], 1) : 0;
+  }
+  __syncthreads();
+  constexpr int RPT = kTexRows / 256;
+  int cnt[RPT], sum = 0;
+#pragma unroll
+  for (int r = 0; r < RPT; ++r) { cnt[r] = s_hist[threadIdx.x * RPT + r]; sum += cnt[r]; }
+  int incl = sum;
+#pragma unroll
+  for (int o2 = 1; o2 < 64; o2 <<= 1) { const int up = __shfl_up(incl, o2); if (lane >= o2) incl += up; }
+  if (lane == 63) s_wsum[w] = incl;
+  __syncthreads();
+  int base = incl - sum;
+  for (int i = 0; i < w; ++i) base += s_wsum[i];
+  const int total = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
+#pragma unroll
+  for (int r = 0; r < RPT; ++r) { s_hist[threadIdx.x * RPT + r] = base; base += cnt[r]; }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < SPT; ++j)
+    if (row[j] >= 0) s_order[s_hist[row[j]] + rank[j]] = threadIdx.x + 256 * j;
+  __syncthreads();
+  return total;
+}
+
 struct V3 { float x, y, z; };
 __device__ __forceinline__ V3 mk(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
 __device__ __forceinline__ V3 ld(const float* p) { return mk(p[0], p[1], p[2]); }
@@ -192,6 +243,7 @@ __global__ void __launch_bounds__(256, SHADE_OCC) shade_kernel(const harp_shade_
   float racc[20];
 #pragma unroll
   for (int k = 0; k < 20; ++k) racc[k] = 0.f;
+  int tb_y0 = 0x7fffffff, tb_y1 = -1;   // backward: range of texel rows this lane touched
 
   for (int sub = 0; sub < R * R; ++sub) {
   const int xi = (blockIdx.x * R + (sub & (R - 1))) * kTile + (lane & 15), yi = (blockIdx.y * R + (sub / R)) * kTile + w * 4 + (lane >> 4);
@@ -351,6 +403,7 @@ __global__ void __launch_bounds__(256, SHADE_OCC) shade_kernel(const harp_shade_
         for (int k = 0; k < 4; ++k) {
           if (cx[k] >= A.Wt || cy[k] >= A.Ht || cw[k] == 0.f) continue;
           const int key = cy[k] * A.Wt + cx[k];
+          tb_y0 = min(tb_y0, cy[k]); tb_y1 = max(tb_y1, cy[k]);
           const int slot = s_tex.find(key);
           const float vals[6] = {g_tex.x * cw[k], g_tex.y * cw[k], g_tex.z * cw[k], g_m_keep.x * cw[k], g_m_keep.y * cw[k], g_m_keep.z * cw[k]};
           if (slot >= 0) {
@@ -371,6 +424,8 @@ __global__ void __launch_bounds__(256, SHADE_OCC) shade_kernel(const harp_shade_
         for (int k = 0; k < 9; ++k) {
           const float d = g_vis * (1.0f / 9.0f) * sg[k] * (1.0f - sg[k]) * 1000.0f;
           if (d != 0.f) {
+            // (an LDS table for these taps was measured slower than the direct atomics: 9 hash probes per pixel cost more than the
+            //  semi-coalesced memory-side adds they save)
             if (A.g_zl && !(A.debug_skip & 4)) atomicAdd(A.g_zl + (size_t)b * S * S + tapo[k], d);
             g_zq -= d;
           }
@@ -489,14 +544,35 @@ __global__ void __launch_bounds__(256, SHADE_OCC) shade_kernel(const harp_shade_
         if (a2 != 0.f) atomicAdd(gdb + 3 * v + c, a2);
       }
     }
-    for (int i = threadIdx.x; i < kTexSlots; i += 256) {
-      const int key = s_tex.key[i];
-      if (key < 0 || (A.debug_skip & 16)) continue;
+    // texels: random-address float atomics cost one memory request per lane (21 G/s measured) while lanes on
+    // consecutive addresses share requests (330 G/s).  The occupied slots are therefore counting-sorted by row (LDS histogram +
+    // scan; the rows of one screen tile hold <= ~25 neighbouring texels, also across a chart seam) and flushed in that order.
+    __shared__ int s_box[2];
+    __shared__ int s_hist[kTexRows];
+    __shared__ int s_order[kTexSlots];
+    __shared__ int s_wsum[4];
+    if (!(A.debug_skip & 16)) {
+      const int total = sort_slots_by_row<kTexSlots>(s_tex.key, A.Wt, tb_y0, tb_y1, s_box, s_hist, s_order, s_wsum);
+      if (total >= 0) {
+        for (int i = threadIdx.x; i < total * 3; i += 256) {      // lanes = (texel, channel): consecutive addresses within a row
+          const int e = i / 3, c = i - 3 * e;
+          const int slot = s_order[e];
+          const int key = s_tex.key[slot];
+          const float a0 = (float)s_tex.val[slot][c], a1 = (float)s_tex.val[slot][3 + c];
+          if (a0 != 0.f) atomicAdd(A.g_tex + (size_t)key * 3 + c, a0);
+          if (a1 != 0.f) atomicAdd(A.g_nmap + (size_t)key * 3 + c, a1);
+        }
+      } else {
+        for (int i = threadIdx.x; i < kTexSlots; i += 256) {
+          const int key = s_tex.key[i];
+          if (key < 0) continue;
 #pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        const float a0 = (float)s_tex.val[i][c], a1 = (float)s_tex.val[i][3 + c];
-        if (a0 != 0.f) atomicAdd(A.g_tex + (size_t)key * 3 + c, a0);
-        if (a1 != 0.f) atomicAdd(A.g_nmap + (size_t)key * 3 + c, a1);
+          for (int c = 0; c < 3; ++c) {
+            const float a0 = (float)s_tex.val[i][c], a1 = (float)s_tex.val[i][3 + c];
+            if (a0 != 0.f) atomicAdd(A.g_tex + (size_t)key * 3 + c, a0);
+            if (a1 != 0.f) atomicAdd(A.g_nmap + (size_t)key * 3 + c, a1);
+          }
+        }
       }
     }
   }
