@@ -99,3 +99,32 @@ struct VertexAccum {
   }
   __device__ __forceinline__ void add(int slot, int c, float x) { atomicAdd(&val[slot][c], (T)x); }
 };
+
+// value of lane (lane ^ bit): DPP quad permutes for 1 and 2, ds_bpermute otherwise
+__device__ __forceinline__ int lane_xor(int x, int bit) {
+  if (bit == 1) return __builtin_amdgcn_mov_dpp(x, 0xB1, 0xF, 0xF, true);
+  if (bit == 2) return __builtin_amdgcn_mov_dpp(x, 0x4E, 0xF, 0xF, true);
+  return __shfl_xor(x, bit);
+}
+
+// Lanes of a 16x4-pixel wave that hit the same face add to the same vertices, and same-address LDS atomics serialise: merge such
+// lanes first with a butterfly over the xor distances in MASK (1, 2 = x neighbours, 16 = the row below).  After the call only lanes
+// with alive == true hold (summed) values; `fk` = face id (or a negative value for inactive lanes).
+template <int N, int MASK>
+__device__ __forceinline__ void merge_same_face(float* v, int fk, bool& alive, int lane) {
+#pragma unroll
+  for (int bit = 1; bit < 64; bit <<= 1) {
+    if (!(MASK & bit)) continue;
+    const int fo = lane_xor(fk, bit);
+    const int ao = lane_xor(alive ? 1 : 0, bit);
+    const bool same = alive && ao && fo == fk;
+    const bool lower = !(lane & bit);
+#pragma unroll
+    for (int c = 0; c < N; ++c) {
+      const float o2 = __int_as_float(lane_xor(__float_as_int(v[c]), bit));
+      if (same && lower) v[c] += o2;
+    }
+    if (same && !lower) alive = false;
+  }
+}
+

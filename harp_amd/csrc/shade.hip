@@ -34,12 +34,6 @@ constexpr int kTexRows = 512;   // row buckets of the sorted texel flush (a tile
 #ifndef SHADE_PRERED
 #define SHADE_PRERED 19      // xor distances of the lane-merge butterfly before the vertex LDS atomics (1 | 2 | 16)
 #endif
-// value of lane (lane ^ bit): DPP quad permutes for 1 and 2, ds_bpermute otherwise
-__device__ __forceinline__ int lane_xor(int x, int bit) {
-  if (bit == 1) return __builtin_amdgcn_mov_dpp(x, 0xB1, 0xF, 0xF, true);
-  if (bit == 2) return __builtin_amdgcn_mov_dpp(x, 0x4E, 0xF, 0xF, true);
-  return __shfl_xor(x, bit);
-}
 // Counting sort of the occupied slots of an LDS hash table by key row (key / width): returns the number of occupied slots and
 // fills s_order[0..n) with slot indices in row order, or -1 when the rows span more than kTexRows (caller flushes unsorted).
 // Called by all 256 threads of the workgroup; ylo/yhi = the row range this lane touched (0x7fffffff / -1 if none).
@@ -456,21 +450,7 @@ __global__ void __launch_bounds__(256, SHADE_OCC) shade_kernel(const harp_shade_
     // vertices and same-address LDS atomics serialise.  Merge lanes that hit the same face first (butterfly over SHADE_PRERED's
     // xor distances: 1, 2 = x neighbours through DPP, 16 = the row below through ds_bpermute), then only the surviving lanes add.
     bool alive = act;
-    const int fk = act ? f : -1;
-#pragma unroll
-    for (int bit = 1; bit < 64; bit <<= 1) {
-      if (!(SHADE_PRERED & bit)) continue;
-      const int fo = lane_xor(fk, bit);
-      const int ao = lane_xor(alive ? 1 : 0, bit);
-      const bool same = alive && ao && fo == fk;
-      const bool lower = !(lane & bit);
-#pragma unroll
-      for (int c = 0; c < 27; ++c) {
-        const float o2 = __int_as_float(lane_xor(__float_as_int(vsc[c]), bit));
-        if (same && lower) vsc[c] += o2;
-      }
-      if (same && !lower) alive = false;
-    }
+    merge_same_face<27, SHADE_PRERED>(vsc, act ? f : -1, alive, lane);
     if (alive) {
       float* gvb = A.g_verts + (size_t)b * V * 3;
       float* gnb = A.g_vnormals + (size_t)b * V * 3;
@@ -583,7 +563,7 @@ __global__ void __launch_bounds__(256, SHADE_OCC) shade_kernel(const harp_shade_
 __global__ void __launch_bounds__(256) depth_bwd_kernel(const int32_t* __restrict__ face_id, const FaceRec* __restrict__ recs,
                                                         const int32_t* __restrict__ faces, const float* __restrict__ g_z,
                                                         int V, int F, int S, float* __restrict__ g_ndc) {
-  __shared__ VertexAccum<1024, 3> s_acc;
+  __shared__ VertexAccum<256, 3> s_acc;
   const int b = blockIdx.z;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int xi = blockIdx.x * kTile + (lane & 15), yi = blockIdx.y * kTile + w * 4 + (lane >> 4);
@@ -596,12 +576,17 @@ __global__ void __launch_bounds__(256) depth_bwd_kernel(const int32_t* __restric
   s_acc.clear();
   __syncthreads();
   float* gdb = g_ndc + (size_t)b * V * 3;
+  float gnd[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (act) {
     const Tri t = load_tri(recs + (size_t)b * F + f);
     const float px = pix_to_ndc(xi, S), py = pix_to_ndc(yi, S);
     const Bary br = bary_fwd(t, px, py);
-    float gnd[9] = {0.f, 0.f, g * br.b0, 0.f, 0.f, g * br.b1, 0.f, 0.f, g * br.b2};
+    gnd[2] = g * br.b0; gnd[5] = g * br.b1; gnd[8] = g * br.b2;
     bary_bwd(t, px, py, br, g * t.z0, g * t.z1, g * t.z2, gnd);
+  }
+  bool alive = act;
+  merge_same_face<9, SHADE_PRERED>(gnd, act ? f : -1, alive, lane);   // lanes on the same face add to the same three vertices
+  if (alive) {
     const int vi[3] = {faces[3 * f], faces[3 * f + 1], faces[3 * f + 2]};
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
@@ -613,7 +598,7 @@ __global__ void __launch_bounds__(256) depth_bwd_kernel(const int32_t* __restric
     }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < 1024; i += 256) {
+  for (int i = threadIdx.x; i < 256; i += 256) {
     const int v = s_acc.key[i];
     if (v < 0) continue;
 #pragma unroll
