@@ -29,6 +29,37 @@ struct FaceRec {
   float4 bb;  // xmin-r xmax+r ymin-r ymax+r   (empty box => culled face)
 };
 
+// Layout of a rasteriser workspace (harp_rasterize_ws_bytes): face records | contiguous bboxes | per-super-tile face lists |
+// list lengths | heaviest-first launch order of the (frame, super-tile) pairs.
+struct RasterWs { FaceRec* recs; float4* bbs; int32_t* bins; int32_t* cnt; int32_t* order; int nsx; };
+inline RasterWs raster_ws_split(void* ws, int B, int F, int S) {
+  RasterWs r;
+  r.nsx = (S + kSuper - 1) / kSuper;
+  char* p = (char*)ws;
+  r.recs = (FaceRec*)p;   p += (size_t)B * F * sizeof(FaceRec);
+  r.bbs = (float4*)p;     p += (size_t)B * F * sizeof(float4);
+  r.bins = (int32_t*)p;   p += (size_t)B * r.nsx * r.nsx * F * sizeof(int32_t);
+  r.cnt = (int32_t*)p;    p += (((size_t)B * r.nsx * r.nsx * sizeof(int32_t)) + 255) / 256 * 256;
+  r.order = (int32_t*)p;
+  return r;
+}
+// workgroups of the 1-D tile grid: launch-order slots rounded up to a multiple of 8 (one per XCD) x 16 tiles per super-tile
+inline unsigned tile_grid(int B, int nsx) { return (unsigned)(((B * nsx * nsx + 7) / 8) * 8 * (kSuper / kTile) * (kSuper / kTile)); }
+// Decode a workgroup id of that grid: consecutive ids go round-robin over the 8 XCDs, so the 16 tiles of one super-tile (same bin
+// list, same face records, neighbouring pixels) stay on one XCD / one L2; slots follow the heaviest-first order.  false = no tile.
+__device__ __forceinline__ bool tile_decode(const int32_t* __restrict__ order, int B, int nsx, int S, int& b, int& st, int& tx0, int& ty0) {
+  constexpr int kTps = (kSuper / kTile) * (kSuper / kTile);
+  const int nst = nsx * nsx;
+  const int xcd = blockIdx.x & 7, rr = blockIdx.x >> 3;
+  const int sub = rr % kTps, slot = (rr / kTps) * 8 + xcd;
+  if (slot >= B * nst) return false;
+  const int entry = order[slot];
+  b = entry / nst; st = entry - b * nst;
+  tx0 = ((st % nsx) * (kSuper / kTile) + (sub & 3)) * kTile;
+  ty0 = ((st / nsx) * (kSuper / kTile) + (sub >> 2)) * kTile;
+  return tx0 < S && ty0 < S;
+}
+
 __device__ __forceinline__ float pix_to_ndc(int i, int S) {
   // pixel index -> NDC of its centre; PyTorch3D flips both axes: pixel 0 is at +1-1/S.
   return -1.0f + (2.0f * (float)(S - 1 - i) + 1.0f) / (float)S;

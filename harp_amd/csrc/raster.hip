@@ -185,18 +185,10 @@ __global__ void __launch_bounds__(256) raster_kernel(const FaceRec* __restrict__
   // MODE 2: per-staged-face gradient accumulators (x,y of 3 verts).  double: ds_add_f64 is ~20x faster than ds_add_f32 on gfx950
   __shared__ double s_g[MODE == 2 ? kStage : 1][6];
 
-  // 1-D grid over (launch-order slot, tile of the 4x4 in a super-tile).  Consecutive workgroup ids go round-robin over the 8
-  // XCDs: the 16 tiles of one super-tile (same bin list, same face records) are kept on one XCD / one L2.
-  constexpr int kTps = (kSuper / kTile) * (kSuper / kTile);
+  int b, st, tx0, ty0;
+  if (!tile_decode(order, B, nsx, S, b, st, tx0, ty0)) return;     // 1-D grid in heaviest-first order (harp_common.h)
   const int nst = nsx * nsx;
-  const int xcd = blockIdx.x & 7, rr = blockIdx.x >> 3;
-  const int sub = rr % kTps, slot = (rr / kTps) * 8 + xcd;
-  if (slot >= B * nst) return;
-  const int entry = order[slot];
-  const int b = entry / nst, st = entry - b * nst;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int tx0 = ((st % nsx) * (kSuper / kTile) + (sub & 3)) * kTile, ty0 = ((st / nsx) * (kSuper / kTile) + (sub >> 2)) * kTile;
-  if (tx0 >= S || ty0 >= S) return;
   const int xi = tx0 + (lane & 15), yi = ty0 + w * 4 + (lane >> 4);
   const bool in_img = (xi < S) && (yi < S);
   const float px = pix_to_ndc(xi, S), py = pix_to_ndc(yi, S);
@@ -447,23 +439,6 @@ size_t harp_rasterize_ws_bytes(int B, int F, int S) {
   return recs + bbs + bins + 2 * cnt;      // counts + launch order
 }
 
-// workgroups of the 1-D raster grid: slots rounded up to a multiple of 8 (one per XCD) x 16 tiles
-static unsigned raster_grid(int B, int nsx) { return (unsigned)(((B * nsx * nsx + 7) / 8) * 8 * (kSuper / kTile) * (kSuper / kTile)); }
-
-static void ws_split(void* ws, int B, int F, int S, FaceRec** recs, int32_t** bins, int32_t** cnt, float4** bbs, int32_t** order) {
-  const int nsx = (S + kSuper - 1) / kSuper;
-  char* p = (char*)ws;
-  *recs = (FaceRec*)p;
-  p += (size_t)B * F * sizeof(FaceRec);
-  if (bbs) *bbs = (float4*)p;
-  p += (size_t)B * F * sizeof(float4);
-  *bins = (int32_t*)p;
-  p += (size_t)B * nsx * nsx * F * sizeof(int32_t);
-  *cnt = (int32_t*)p;
-  p += (((size_t)B * nsx * nsx * sizeof(int32_t)) + 255) / 256 * 256;
-  *order = (int32_t*)p;
-}
-
 // Forward rasterisation of B frames sharing one face table.
 //   ndc (B,V,3) f32 [x_ndc, y_ndc, z_view]; faces (F,3) i32.
 //   soft != 0: also accumulate the soft-silhouette alpha (blur_radius, sigma as in renderer_helper.py:44-58).
@@ -476,14 +451,14 @@ int harp_rasterize_l1_fwd(const float* ndc, const int32_t* faces, int B, int V, 
                           const int32_t* l1_fid, const float* l1_w, float* l1_loss, float* l1_grad, hipStream_t stream) {
   if (!ndc || !faces || !ws || !face_id || B <= 0 || F <= 0 || S <= 0 || (soft && !alpha)) return HARP_ERR_ARG;
   if (l1_target && (!soft || !l1_fid || !l1_w || !l1_loss || !l1_grad)) return HARP_ERR_ARG;
-  FaceRec* recs; int32_t *bins, *cnt, *order; float4* bbs;
-  ws_split(ws, B, F, S, &recs, &bins, &cnt, &bbs, &order);
-  const int nsx = (S + kSuper - 1) / kSuper;
+  const RasterWs W = raster_ws_split(ws, B, F, S);
+  FaceRec* recs = W.recs; int32_t *bins = W.bins, *cnt = W.cnt, *order = W.order; float4* bbs = W.bbs;
+  const int nsx = W.nsx;
   const float r = soft ? sqrtf(blur_radius) : 0.f;
   hipLaunchKernelGGL(face_setup_kernel, dim3((F + 255) / 256, B), dim3(256), 0, stream, ndc, faces, V, F, r, recs, bbs);
   hipLaunchKernelGGL(bin_faces_kernel, dim3((nsx * nsx + 3) / 4, B), dim3(256), 0, stream, bbs, F, S, nsx, bins, cnt);
   hipLaunchKernelGGL(order_tiles_kernel, dim3(1), dim3(1024), 0, stream, cnt, B * nsx * nsx, order);
-  const dim3 grid(raster_grid(B, nsx));
+  const dim3 grid(tile_grid(B, nsx));
   if (soft)
     hipLaunchKernelGGL(raster_kernel<1>, grid, dim3(256), 0, stream, recs, bbs, bins, cnt, order, B, F, S, nsx, blur_radius, sigma,
                        face_id, zbuf, alpha, nullptr, nullptr, 0, nullptr, l1_target, l1_fid, l1_w, l1_loss, l1_grad,
@@ -506,10 +481,10 @@ int harp_rasterize_fwd(const float* ndc, const int32_t* faces, int B, int V, int
 int harp_silhouette_bwd(const int32_t* faces, int B, int V, int F, int S, float blur_radius, float sigma, const void* ws,
                         const float* alpha, const float* g_alpha, float* g_ndc, hipStream_t stream) {
   if (!faces || !ws || !alpha || !g_alpha || !g_ndc) return HARP_ERR_ARG;
-  FaceRec* recs; int32_t *bins, *cnt, *order; float4* bbs;
-  ws_split((void*)ws, B, F, S, &recs, &bins, &cnt, &bbs, &order);
-  const int nsx = (S + kSuper - 1) / kSuper;
-  const dim3 grid(raster_grid(B, nsx));
+  const RasterWs W = raster_ws_split((void*)ws, B, F, S);
+  FaceRec* recs = W.recs; int32_t *bins = W.bins, *cnt = W.cnt, *order = W.order; float4* bbs = W.bbs;
+  const int nsx = W.nsx;
+  const dim3 grid(tile_grid(B, nsx));
   hipLaunchKernelGGL(raster_kernel<2>, grid, dim3(256), 0, stream, recs, bbs, bins, cnt, order, B, F, S, nsx, blur_radius, sigma, nullptr,
                      nullptr, (float*)alpha, g_alpha, faces, V, g_ndc, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f);
   HARP_CHECK_LAUNCH();

@@ -14,9 +14,6 @@
 
 namespace {
 
-#ifndef SHADE_R
-#define SHADE_R 1            // the backward walks SHADE_R x SHADE_R tiles per workgroup
-#endif
 #ifndef SHADE_TEX_SLOTS
 #define SHADE_TEX_SLOTS 512
 #endif
@@ -29,7 +26,7 @@ namespace {
 #ifndef SHADE_OCC
 #define SHADE_OCC 3
 #endif
-constexpr int kTexSlots = SHADE_TEX_SLOTS, kVtxSlots = SHADE_VTX_SLOTS, kBwdR = SHADE_R;
+constexpr int kTexSlots = SHADE_TEX_SLOTS, kVtxSlots = SHADE_VTX_SLOTS;
 constexpr int kTexRows = 512;   // row buckets of the sorted texel flush (a tile touching a taller span of texel rows flushes unsorted)
 #ifndef SHADE_PRERED
 #define SHADE_PRERED 19      // xor distances of the lane-merge butterfly before the vertex LDS atomics (1 | 2 | 16)
@@ -200,7 +197,7 @@ struct Frag {
 };
 
 template <bool BWD>
-__global__ void __launch_bounds__(256, SHADE_OCC) shade_kernel(const harp_shade_args A) {
+__global__ void __launch_bounds__(256, SHADE_OCC) shade_kernel(const harp_shade_args A, const int32_t* __restrict__ order, int nsx) {
   __shared__ float s_red[32];
   // per-vertex accumulators: 0-2 g_verts, 3-5 g_vnormals, 6-8 g_ndc
   __shared__ VertexAccum<BWD ? kVtxSlots : 1, 9, SHADE_ACC_T> s_acc;
@@ -208,18 +205,18 @@ __global__ void __launch_bounds__(256, SHADE_OCC) shade_kernel(const harp_shade_
   // bilinear corners (~1.4 px per texel), and same-line float atomics serialise in L2: pre-summing in LDS cuts the global
   // atomics ~4x and removes the contention (ablation: the two texture scatters were 1.75 of 2.6 ms).
   __shared__ VertexAccum<BWD ? kTexSlots : 1, 6, SHADE_ACC_T> s_tex;
-  const int b = blockIdx.z;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int S = A.S, V = A.V;
-  // forward: one 16x16 tile per workgroup.  backward: SHADE_R x SHADE_R tiles walked one after the other with the SAME LDS
-  // accumulators (vertices / texels shared by neighbouring tiles are then flushed once).  With the double-precision tables one
-  // tile per workgroup at 3 workgroups per CU measured the same as 2x2 tiles at 2 per CU and keeps the table load factor at ~0.6.
-  constexpr int R = BWD ? kBwdR : 1;
+  // one 16x16 tile per workgroup, dispatched in the rasteriser's heaviest-first super-tile order (harp_common.h: tile_decode): the
+  // tiles with covered pixels run first and densely instead of interleaved with the ~80 % background tiles.
+  int b, st_unused, tx0, ty0;
+  if (!tile_decode(order, A.B, nsx, S, b, st_unused, tx0, ty0)) return;
+  constexpr int R = 1;
   if (BWD) {
     bool any_act = false;
 #pragma unroll
     for (int sub = 0; sub < R * R; ++sub) {
-      const int xi = (blockIdx.x * R + (sub & (R - 1))) * kTile + (lane & 15), yi = (blockIdx.y * R + (sub / R)) * kTile + w * 4 + (lane >> 4);
+      const int xi = tx0 + (lane & 15), yi = ty0 + w * 4 + (lane >> 4);
       if (xi < S && yi < S) {
         const size_t o = ((size_t)b * S + yi) * S + xi;
         if (A.face_id[o] >= 0) {
@@ -240,7 +237,7 @@ __global__ void __launch_bounds__(256, SHADE_OCC) shade_kernel(const harp_shade_
   int tb_y0 = 0x7fffffff, tb_y1 = -1;   // backward: range of texel rows this lane touched
 
   for (int sub = 0; sub < R * R; ++sub) {
-  const int xi = (blockIdx.x * R + (sub & (R - 1))) * kTile + (lane & 15), yi = (blockIdx.y * R + (sub / R)) * kTile + w * 4 + (lane >> 4);
+  const int xi = tx0 + (lane & 15), yi = ty0 + w * 4 + (lane >> 4);
   const bool in_img = xi < S && yi < S;
   const size_t o = ((size_t)b * S + (in_img ? yi : 0)) * S + (in_img ? xi : 0);
   const int f = in_img ? A.face_id[o] : -1;
@@ -562,11 +559,13 @@ __global__ void __launch_bounds__(256, SHADE_OCC) shade_kernel(const harp_shade_
 // zbuf = sum_i bary_i z_i  ->  g on the face's NDC vertices (rasterize_meshes_backward, grad_zbuf path).
 __global__ void __launch_bounds__(256) depth_bwd_kernel(const int32_t* __restrict__ face_id, const FaceRec* __restrict__ recs,
                                                         const int32_t* __restrict__ faces, const float* __restrict__ g_z,
-                                                        int V, int F, int S, float* __restrict__ g_ndc) {
+                                                        int V, int F, int S, float* __restrict__ g_ndc,
+                                                        const int32_t* __restrict__ order, int B, int nsx) {
   __shared__ VertexAccum<256, 3> s_acc;
-  const int b = blockIdx.z;
+  int b, st_unused, tx0, ty0;
+  if (!tile_decode(order, B, nsx, S, b, st_unused, tx0, ty0)) return;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int xi = blockIdx.x * kTile + (lane & 15), yi = blockIdx.y * kTile + w * 4 + (lane >> 4);
+  const int xi = tx0 + (lane & 15), yi = ty0 + w * 4 + (lane >> 4);
   const bool in_img = xi < S && yi < S;
   const size_t o = ((size_t)b * S + (in_img ? yi : 0)) * S + (in_img ? xi : 0);
   const float g = in_img ? g_z[o] : 0.f;
@@ -614,22 +613,22 @@ int harp_shade_fwd(const harp_shade_args* a, hipStream_t stream) {
   if (!a || !a->face_id || !a->recs || !a->faces || !a->faces_uvs || !a->verts_uvs || !a->verts || !a->vnormals || !a->tex ||
       !a->light_pos || !a->colors || !a->rgb || (a->zl && (!a->light_R || !a->light_T)))
     return HARP_ERR_ARG;
-  const dim3 grid((a->S + kTile - 1) / kTile, (a->S + kTile - 1) / kTile, a->B);
+  const RasterWs W = raster_ws_split((void*)a->recs, a->B, a->F, a->S);
+  const dim3 grid(tile_grid(a->B, W.nsx));
   harp_shade_args b = *a;
   if (b.l1_target) {
     if (!b.l1_fid || !b.l1_w || !b.l1_loss || !b.l1_grad) return HARP_ERR_ARG;
     b.l1_inv = 1.0f / ((float)b.B * (float)b.S * (float)b.S * 3.0f);
   }
-  hipLaunchKernelGGL(shade_kernel<false>, grid, dim3(256), 0, stream, b);
+  hipLaunchKernelGGL(shade_kernel<false>, grid, dim3(256), 0, stream, b, (const int32_t*)W.order, W.nsx);
   HARP_CHECK_LAUNCH();
   return HARP_OK;
 }
 
 int harp_shade_bwd(const harp_shade_args* a, hipStream_t stream) {
   if (!a || !a->face_id || !a->recs || !a->g_rgb || !a->g_verts || !a->g_vnormals || !a->g_ndc) return HARP_ERR_ARG;
-  const int R = kBwdR * kTile;      // the backward kernel walks kBwdR x kBwdR tiles per workgroup
-  const dim3 grid((a->S + R - 1) / R, (a->S + R - 1) / R, a->B);
-  hipLaunchKernelGGL(shade_kernel<true>, grid, dim3(256), 0, stream, *a);
+  const RasterWs W = raster_ws_split((void*)a->recs, a->B, a->F, a->S);
+  hipLaunchKernelGGL(shade_kernel<true>, dim3(tile_grid(a->B, W.nsx)), dim3(256), 0, stream, *a, (const int32_t*)W.order, W.nsx);
   HARP_CHECK_LAUNCH();
   return HARP_OK;
 }
@@ -638,8 +637,9 @@ int harp_shade_bwd(const harp_shade_args* a, hipStream_t stream) {
 int harp_depth_bwd(const int32_t* face_id, const void* ws, const int32_t* faces, const float* g_z, int B, int V, int F, int S,
                    float* g_ndc, hipStream_t stream) {
   if (!face_id || !ws || !faces || !g_z || !g_ndc) return HARP_ERR_ARG;
-  const dim3 grid((S + kTile - 1) / kTile, (S + kTile - 1) / kTile, B);
-  hipLaunchKernelGGL(depth_bwd_kernel, grid, dim3(256), 0, stream, face_id, (const FaceRec*)ws, faces, g_z, V, F, S, g_ndc);
+  const RasterWs W = raster_ws_split((void*)ws, B, F, S);
+  hipLaunchKernelGGL(depth_bwd_kernel, dim3(tile_grid(B, W.nsx)), dim3(256), 0, stream, face_id, (const FaceRec*)ws, faces, g_z, V, F, S, g_ndc,
+                     (const int32_t*)W.order, B, W.nsx);
   HARP_CHECK_LAUNCH();
   return HARP_OK;
 }
