@@ -138,5 +138,5 @@ SIGNATURES.update({
     "harp_lbs_tree_fwd": (_i, [_trp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "harp_lbs_tree_bwd": (_i, [_trp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
 })
-SIGNATURES["harp_draw_texture_offsets"] = (_i, [ctypes.c_uint, _vp, _i, _i, _f, _vp, _vp])
+SIGNATURES["harp_draw_texture_offsets"] = (_i, [ctypes.c_uint, _vp, _i, _i, _f, _vp, _f, _vp, _vp])
 SIGNATURES["harp_rasterize_l1_fwd"] = (_i, [_vp, _vp, _i, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp])

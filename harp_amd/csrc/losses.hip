@@ -68,6 +68,9 @@ __global__ void __launch_bounds__(64) kps_kernel(const float* __restrict__ gt, c
 // GATHER formulation, one lane per (frame, vertex), no atomics on the gradient: every lane re-derives the terms its vertex
 // takes part in (its own Laplacian row + its neighbours' rows, its incident edges, the face pairs it belongs to) from the
 // static CSR tables, and owns g_verts[b, u, :].  w[0..2] = weights of (laplacian, normal, arap); loss[0..2] accumulate.
+// STAGE: the frame's vertices are first copied to LDS (V*12 B, dynamic) and every neighbour / pair gather reads from there: a lane
+// walks ~100 dependent gathers and with only ~1.5 waves per SIMD in flight the L2 round trips were the whole cost (53 -> 15 us).
+template <bool STAGE>
 __global__ void __launch_bounds__(256) mesh_reg_kernel(const float* __restrict__ verts, const float* __restrict__ ref_verts,
                                                        const int32_t* __restrict__ nbr_off, const int32_t* __restrict__ nbr_idx,
                                                        const int32_t* __restrict__ pairs, const int32_t* __restrict__ vp_off,
@@ -75,9 +78,18 @@ __global__ void __launch_bounds__(256) mesh_reg_kernel(const float* __restrict__
                                                        const float* __restrict__ w, float* __restrict__ loss,
                                                        float* __restrict__ g_verts) {
   __shared__ float red[4];
+  extern __shared__ float s_verts[];
   const int b = blockIdx.y, u = blockIdx.x * 256 + threadIdx.x;
   const float* vb = verts + (size_t)b * V * 3;
+  if (STAGE) {
+    for (int i = threadIdx.x; i < V * 3; i += 256) s_verts[i] = vb[i];
+    __syncthreads();
+    vb = s_verts;
+  }
   const bool grad = (w != nullptr) && (g_verts != nullptr);
+  // blockIdx.z picks the term (0 Laplacian, 1 ARAP, 2 normal consistency): three times the waves in flight and a third of the
+  // dependent gather chain per lane; the three partial gradients meet in g_verts through (coalesced) float atomics.
+  const int term = blockIdx.z;
   const float w_lap = grad ? w[0] : 0.f, w_nc = grad ? w[1] : 0.f, w_ar = grad ? w[2] : 0.f;
   float l_lap = 0.f, l_nc = 0.f, l_ar = 0.f;
   float g[3] = {0.f, 0.f, 0.f};
@@ -86,7 +98,7 @@ __global__ void __launch_bounds__(256) mesh_reg_kernel(const float* __restrict__
     const float sc_lap = 1.0f / ((float)V * (float)B), sc_ar = 1.0f / ((float)E * (float)B), sc_nc = 1.0f / ((float)P * (float)B);
     const int s = nbr_off[u], e = nbr_off[u + 1];
     // --- own Laplacian row
-    {
+    if (term == 0) {
       float a[3] = {0.f, 0.f, 0.f};
       for (int k = s; k < e; ++k) for (int c = 0; c < 3; ++c) a[c] += vb[3 * nbr_idx[k] + c];
       const float invd = 1.0f / (float)(e - s);
@@ -96,11 +108,11 @@ __global__ void __launch_bounds__(256) mesh_reg_kernel(const float* __restrict__
       l_lap = n * sc_lap;
       if (n > 0.f) for (int c = 0; c < 3; ++c) g[c] -= w_lap * sc_lap / n * lv[c];
     }
-    for (int k = s; k < e; ++k) {
+    if (term < 2) for (int k = s; k < e; ++k) {
       const int nb = nbr_idx[k];
       const float pn[3] = {vb[3 * nb], vb[3 * nb + 1], vb[3 * nb + 2]};
       // --- neighbour's Laplacian row contains u with weight 1/deg(nb)
-      if (grad) {
+      if (grad && term == 0) {
         const int s2 = nbr_off[nb], e2 = nbr_off[nb + 1];
         float a[3] = {0.f, 0.f, 0.f};
         for (int q = s2; q < e2; ++q) for (int c = 0; c < 3; ++c) a[c] += vb[3 * nbr_idx[q] + c];
@@ -111,7 +123,7 @@ __global__ void __launch_bounds__(256) mesh_reg_kernel(const float* __restrict__
         if (n > 0.f) for (int c = 0; c < 3; ++c) g[c] += w_lap * sc_lap / n * lv[c] * invd;
       }
       // --- ARAP on edge (u, nb); every edge is visited from both ends -> half the loss each
-      if (ref_verts) {
+      if (ref_verts && term == 1) {
         float d[3], l2 = 0.f, r2 = 0.f;
         for (int c = 0; c < 3; ++c) {
           d[c] = pu[c] - pn[c];
@@ -126,7 +138,7 @@ __global__ void __launch_bounds__(256) mesh_reg_kernel(const float* __restrict__
       }
     }
     // --- normal consistency: the face pairs u belongs to (role 0 = v0, 1 = v1, 2 = a, 3 = b)
-    for (int k = vp_off[u]; k < vp_off[u + 1]; ++k) {
+    if (term == 2) for (int k = vp_off[u]; k < vp_off[u + 1]; ++k) {
       const int pr = vp_idx[k] >> 2, role = vp_idx[k] & 3;
       const int i0 = pairs[4 * pr], i1 = pairs[4 * pr + 1], ia = pairs[4 * pr + 2], ib = pairs[4 * pr + 3];
       float ev[3], da[3], db[3];
@@ -160,7 +172,7 @@ __global__ void __launch_bounds__(256) mesh_reg_kernel(const float* __restrict__
     }
     if (grad) {
       float* o = g_verts + ((size_t)b * V + u) * 3;
-      o[0] += g[0]; o[1] += g[1]; o[2] += g[2];
+      atomicAdd(o, g[0]); atomicAdd(o + 1, g[1]); atomicAdd(o + 2, g[2]);
     }
   }
   const float s0 = block_sum_256(l_lap, red), s1 = block_sum_256(l_nc, red), s2 = block_sum_256(l_ar, red);
@@ -189,20 +201,21 @@ __global__ void __launch_bounds__(256) tex_smooth_kernel(const float* __restrict
                                                          const float* __restrict__ mask, int H, int W, const float* __restrict__ w,
                                                          float* __restrict__ loss, float* __restrict__ g) {
   __shared__ float red[4];
-  const int i = blockIdx.x * 256 + threadIdx.x;
   float acc = 0.f;
-  if (i < H * W) {
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < H * W; i += gridDim.x * 256) {
     const int x = i / W, y = i % W;                    // reference names: x = row, y = column
     const int tx = min(max(x + dist[2 * i], 0), H - 1), ty = min(max(y + dist[2 * i + 1], 0), W - 1);
     const int j = tx * W + ty;
     const float m = mask ? mask[i] : 1.f;
     const float k = (w ? w[0] : 0.f) * m / (3.0f * (float)(H * W));
+    float a1 = 0.f;
     for (int c = 0; c < 3; ++c) {
       const float d = t[3 * i + c] - t[3 * j + c];
-      acc += fabsf(d);
-      if (w && g && d != 0.f) { atomicAdd(g + 3 * i + c, k * sgn(d)); atomicAdd(g + 3 * j + c, -k * sgn(d)); }
+      a1 += fabsf(d);
+      // (texels outside the UV mask carry k == 0: no gradient traffic for them)
+      if (w && g && d != 0.f && k != 0.f) { atomicAdd(g + 3 * i + c, k * sgn(d)); atomicAdd(g + 3 * j + c, -k * sgn(d)); }
     }
-    acc = acc / 3.0f * m;
+    acc += a1 / 3.0f * m;
   }
   const float s = block_sum_256(acc, red);
   if (threadIdx.x == 0) atomicAdd(loss, s / (float)(H * W));
@@ -274,17 +287,22 @@ __device__ __forceinline__ uint32_t mix32(uint32_t x) {
   x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
   return x;
 }
-__global__ void draw_offsets_kernel(uint32_t seed, int* __restrict__ counter, int n, float std, int32_t* __restrict__ out) {
+__device__ __forceinline__ void draw_pair(uint32_t seed, uint32_t c, int i, float std, int32_t* __restrict__ out) {
+  const uint32_t h1 = mix32(seed ^ mix32(c * 0x9E3779B9U + 0x85EBCA6BU) ^ mix32((uint32_t)i * 2u + 1u));
+  const uint32_t h2 = mix32(h1 ^ 0xC2B2AE35U ^ mix32((uint32_t)i * 2u + 2u + c));
+  const float u1 = ((float)(h1 >> 8) + 1.0f) * (1.0f / 16777217.0f), u2 = (float)(h2 >> 8) * (1.0f / 16777216.0f);
+  const float r = sqrtf(-2.0f * logf(u1));
+  const float z0 = r * cosf(6.28318530718f * u2), z1 = r * sinf(6.28318530718f * u2);
+  out[2 * i] = (int32_t)(z0 * std);
+  out[2 * i + 1] = (int32_t)(z1 * std);
+}
+__global__ void draw_offsets_kernel(uint32_t seed, int* __restrict__ counter, int n, float std, int32_t* __restrict__ out, float std2,
+                                    int32_t* __restrict__ out2) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const uint32_t c = (uint32_t)(*counter);
+  const uint32_t c = (uint32_t)counter[0];
   if (i < n) {
-    const uint32_t h1 = mix32(seed ^ mix32(c * 0x9E3779B9U + 0x85EBCA6BU) ^ mix32((uint32_t)i * 2u + 1u));
-    const uint32_t h2 = mix32(h1 ^ 0xC2B2AE35U ^ mix32((uint32_t)i * 2u + 2u + c));
-    const float u1 = ((float)(h1 >> 8) + 1.0f) * (1.0f / 16777217.0f), u2 = (float)(h2 >> 8) * (1.0f / 16777216.0f);
-    const float r = sqrtf(-2.0f * logf(u1));
-    const float z0 = r * cosf(6.28318530718f * u2), z1 = r * sinf(6.28318530718f * u2);
-    out[2 * i] = (int32_t)(z0 * std);
-    out[2 * i + 1] = (int32_t)(z1 * std);
+    draw_pair(seed, c, i, std, out);
+    if (out2) draw_pair(seed ^ 0x5bd1e995U, c + 0x632BE5ABU, i, std2, out2);
   }
 }
 __global__ void bump_counter_kernel(int* counter) { if (threadIdx.x == 0 && blockIdx.x == 0) *counter += 1; }
@@ -314,9 +332,10 @@ __global__ void adam_dev_kernel(float* __restrict__ p, const float* __restrict__
 
 extern "C" {
 
-int harp_draw_texture_offsets(unsigned seed, int* counter_dev, int H, int W, float std, int32_t* dist, hipStream_t stream) {
+int harp_draw_texture_offsets(unsigned seed, int* counter_dev, int H, int W, float std, int32_t* dist, float std2, int32_t* dist2,
+                              hipStream_t stream) {
   if (!counter_dev || !dist) return HARP_ERR_ARG;
-  hipLaunchKernelGGL(draw_offsets_kernel, dim3((H * W + 255) / 256), dim3(256), 0, stream, seed, counter_dev, H * W, std, dist);
+  hipLaunchKernelGGL(draw_offsets_kernel, dim3((H * W + 255) / 256), dim3(256), 0, stream, seed, counter_dev, H * W, std, dist, std2, dist2);
   hipLaunchKernelGGL(bump_counter_kernel, dim3(1), dim3(64), 0, stream, counter_dev);
   HARP_CHECK_LAUNCH();
   return HARP_OK;
@@ -359,8 +378,13 @@ int harp_mesh_regularizers(const float* verts, const float* ref_verts, const int
                            const int32_t* nc_pairs, const int32_t* vp_off, const int32_t* vp_idx, int B, int V, int P, int E,
                            const float* w, float* loss, float* g_verts, hipStream_t stream) {
   if (!verts || !nbr_off || !nbr_idx || !nc_pairs || !vp_off || !vp_idx || !loss) return HARP_ERR_ARG;
-  hipLaunchKernelGGL(mesh_reg_kernel, dim3((V + 255) / 256, B), dim3(256), 0, stream, verts, ref_verts, nbr_off, nbr_idx, nc_pairs, vp_off,
-                     vp_idx, B, V, P, E, w, loss, g_verts);
+  const size_t lds = (size_t)V * 3 * sizeof(float);
+  if (lds <= 60 * 1024)
+    hipLaunchKernelGGL(mesh_reg_kernel<true>, dim3((V + 255) / 256, B, 3), dim3(256), lds, stream, verts, ref_verts, nbr_off, nbr_idx, nc_pairs,
+                       vp_off, vp_idx, B, V, P, E, w, loss, g_verts);
+  else
+    hipLaunchKernelGGL(mesh_reg_kernel<false>, dim3((V + 255) / 256, B, 3), dim3(256), 0, stream, verts, ref_verts, nbr_off, nbr_idx, nc_pairs,
+                       vp_off, vp_idx, B, V, P, E, w, loss, g_verts);
   HARP_CHECK_LAUNCH();
   return HARP_OK;
 }
@@ -375,7 +399,7 @@ int harp_sum_squares(const float* x, int n, const float* w, float* loss, float* 
 int harp_texture_smooth_reg(const float* tex, const int32_t* dist, const float* mask, int H, int W, const float* w, float* loss,
                             float* g_tex, hipStream_t stream) {
   if (!tex || !dist || !loss) return HARP_ERR_ARG;
-  hipLaunchKernelGGL(tex_smooth_kernel, dim3((H * W + 255) / 256), dim3(256), 0, stream, tex, dist, mask, H, W, w, loss, g_tex);
+  hipLaunchKernelGGL(tex_smooth_kernel, dim3(min((H * W + 255) / 256, 512)), dim3(256), 0, stream, tex, dist, mask, H, W, w, loss, g_tex);
   HARP_CHECK_LAUNCH();
   return HARP_OK;
 }

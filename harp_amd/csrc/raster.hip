@@ -102,6 +102,29 @@ __device__ __forceinline__ int block_compact(bool pred, int running, int* lds_cn
   return pred ? pos : -1;
 }
 
+// Heaviest-first launch order of the (frame, super-tile) pairs: a counting sort of the bin counts by magnitude (33 buckets of
+// count leading zeros).  The raster grid is 1-D over this order, so the workgroups with real work are dispatched first and
+// densely (the natural (x, y, frame) order interleaves them with ~75 % empty tiles: measured average occupancy was < 3 of 8
+// waves per SIMD) and the longest ones do not end up in the tail.
+__device__ void order_tiles(const int32_t* __restrict__ bin_count, int total, int32_t* __restrict__ order, int* hist, int* base) {
+  if (threadIdx.x < 33) hist[threadIdx.x] = 0;
+  __syncthreads();
+  for (int i = threadIdx.x; i < total; i += blockDim.x) {
+    const int n = bin_count[i];
+    atomicAdd(&hist[n > 0 ? __clz(n) : 32], 1);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int run = 0;
+    for (int k = 0; k < 33; ++k) { base[k] = run; run += hist[k]; }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < total; i += blockDim.x) {
+    const int n = bin_count[i];
+    order[atomicAdd(&base[n > 0 ? __clz(n) : 32], 1)] = i;
+  }
+}
+
 // One WAVE per (frame, 64x64 super-tile): streams the frame's bboxes 64 at a time, ballot + popcount compaction,
 // no LDS, no barriers; the list comes out in ascending face order (== PyTorch3D's tie-break order).
 __global__ void __launch_bounds__(256) bin_faces_kernel(const float4* __restrict__ bbs, int F, int S, int nsx,
@@ -141,28 +164,11 @@ __global__ void __launch_bounds__(256) bin_faces_kernel(const float4* __restrict
   if (lane == 0) bin_count[b * nst + st] = running;
 }
 
-// Heaviest-first launch order of the (frame, super-tile) pairs: a counting sort of the bin counts by magnitude (33 buckets of
-// count leading zeros).  The raster grid is 1-D over this order, so the workgroups with real work are dispatched first and
-// densely (the natural (x, y, frame) order interleaves them with ~75 % empty tiles: measured average occupancy was < 3 of 8
-// waves per SIMD) and the longest ones do not end up in the tail.
+// (Folding this into the binning pass with a "last workgroup done" ticket was measured: 512 same-address ticket atomics cost ~35 us,
+//  8x the launch they save.)
 __global__ void __launch_bounds__(1024) order_tiles_kernel(const int32_t* __restrict__ bin_count, int total, int32_t* __restrict__ order) {
-  __shared__ int hist[33], base[33];
-  if (threadIdx.x < 33) hist[threadIdx.x] = 0;
-  __syncthreads();
-  for (int i = threadIdx.x; i < total; i += 1024) {
-    const int n = bin_count[i];
-    atomicAdd(&hist[n > 0 ? __clz(n) : 32], 1);
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    int run = 0;
-    for (int k = 0; k < 33; ++k) { base[k] = run; run += hist[k]; }
-  }
-  __syncthreads();
-  for (int i = threadIdx.x; i < total; i += 1024) {
-    const int n = bin_count[i];
-    order[atomicAdd(&base[n > 0 ? __clz(n) : 32], 1)] = i;
-  }
+  __shared__ int s_hist[33], s_base[33];
+  order_tiles(bin_count, total, order, s_hist, s_base);
 }
 
 // MODE 0: depth only (light view).  MODE 1: nearest face + silhouette product (camera view).

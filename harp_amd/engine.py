@@ -88,7 +88,14 @@ class FitEngine:
                 ("light_positions", (T, 3)), ("amb_ratio", ()), ("texture", (1, tex_size, tex_size, 3)), ("normal_map", (1, tex_size, tex_size, 3)),
                 ("trans", (T, 3))]
         self.arena = _Arena(spec, self.dev)
-        self.p_buf, self.g_buf, self.m_buf, self.v_buf = (self.arena.alloc() for _ in range(4))
+        self.p_buf, self.m_buf, self.v_buf = (self.arena.alloc() for _ in range(3))
+        # everything that is zeroed at the start of a step lives in ONE slab (a single fill kernel): the lane's per-frame gradient
+        # scratch, the normal-map gradient, the gradient arena and the loss vector
+        self.fid = torch.zeros(self.B, dtype=torch.int32, device=self.dev)
+        self.tfid = torch.zeros(self.B, dtype=torch.int32, device=self.dev)
+        self.nmap_n = torch.empty(tex_size, tex_size, 3, dtype=torch.float32, device=self.dev)
+        self._main = self._alloc_lane(self.B, 0, extra=[("g_nmap_n", (tex_size, tex_size, 3)), ("g_buf", (self.arena.size,)), ("loss_vec", (16,))])
+        self.g_buf, self.g_nmap_n, self.loss_vec = (self._main["s"][k] for k in ("g_buf", "g_nmap_n", "loss_vec"))
         self.params = {k: self.arena.view(self.p_buf, k) for k, _ in spec}
         self.grads = {k: self.arena.view(self.g_buf, k) for k, _ in spec}
         # rot / wrist_pose join the coarse group only under use_arm & opt_arm_pose (optimize_sequence.py:264-268, 279-284)
@@ -126,15 +133,9 @@ class FitEngine:
         # ---- targets (set by set_targets) and per-step scratch
         self.y_true = self.y_sil = self.y_sil_col = None
         self.target_offset = 0
-        self.loss_vec = torch.zeros(16, dtype=torch.float32, device=self.dev)
         self.w_vec = torch.zeros(16, dtype=torch.float32, device=self.dev)
-        self.fid = torch.zeros(self.B, dtype=torch.int32, device=self.dev)
-        self.tfid = torch.zeros(self.B, dtype=torch.int32, device=self.dev)
-        # shared (frame-independent) scratch: the normalised normal map and its gradient
-        self.nmap_n = torch.empty(tex_size, tex_size, 3, dtype=torch.float32, device=self.dev)
-        self.g_nmap_n = torch.zeros(tex_size, tex_size, 3, dtype=torch.float32, device=self.dev)
-        self._main = self._alloc_lane(self.B, 0)
         self._main["loss_vec"], self._main["w_vec"] = self.loss_vec, self.w_vec
+        self._main["owns_shared"] = True               # its zero slab also covers g_buf / g_nmap_n / loss_vec
         self._activate(self._main)
         # micro-batching (EXPERIMENTAL, off by default): the batch is split in `micro` lanes with their own scratch and streams, so
         # that the latency-bound rasterisation of one lane overlaps with the atomics-bound shading backward of the other.  Measured:
@@ -151,7 +152,7 @@ class FitEngine:
         self.compute_reference_mesh()
 
     # ------------------------------------------------------------------------------------------------
-    def _alloc_lane(self, B, lo):
+    def _alloc_lane(self, B, lo, extra=()):
         """scratch + bookkeeping for B frames starting at position `lo` of the step's batch"""
         dev, V, S = self.dev, self.topo.V, self.S
         f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
@@ -175,12 +176,13 @@ class FitEngine:
                  ("g_ndc_c", (B, V, 3)), ("g_ndc_l", (B, V, 3)), ("g_n1", (B, V, 3)), ("g_vs", (B, V, 3)), ("g_tmp", (B, V, 3)),
                  ("g_v0", (B, V0, 3)), ("g_joints_m", (B, NJo, 3)), ("g_joints_mm", (B, NJo, 3)), ("g_light_pos", (B, 3)), ("g_colors", (9,)),
                  ("g_light_R", (B, 9)), ("g_light_T", (B, 3)), ("g_cam_R", (B, 9)), ("g_cam_T", (B, 3)), ("g_centroid", (B, 3)),
-                 ("g_pose48", (B, self.pose_stride)), ("g_betas", (B, self.n_betas)), ("g_trans_b", (B, 3))]
+                 ("g_pose48", (B, self.pose_stride)), ("g_betas", (B, self.n_betas)), ("g_trans_b", (B, 3))] + list(extra)
         garena = _Arena(gspec, dev)
         gs_buf = garena.alloc()
         for k, _ in gspec:
             s[k] = garena.view(gs_buf, k)
-        s["g_nmap_n"] = self.g_nmap_n
+        if "g_nmap_n" not in s:
+            s["g_nmap_n"] = self.g_nmap_n
         # g_alpha and g_rgb (the first two segments, 4/5 of the slab) are fully overwritten by harp_image_l1: only the rest is zeroed
         return dict(s=s, gs_zero=gs_buf[garena.offsets["g_zl"][0]:], B=B, lo=lo, fid=self.fid[lo:lo + B], tfid=self.tfid[lo:lo + B],
                     loss_vec=torch.zeros(16, dtype=torch.float32, device=dev), w_vec=torch.zeros(16, dtype=torch.float32, device=dev),
@@ -254,11 +256,12 @@ class FitEngine:
         w = lane["w_vec"]
         wp = lambda i: w.data_ptr() + 4 * i
         lp = lambda i: lloss.data_ptr() + 4 * i
-        if shared_terms:
+        if shared_terms and not lane.get("owns_shared"):
             self.g_buf.zero_()
             self.g_nmap_n.zero_()
-        self.gs_zero.zero_()
-        lloss.zero_()
+        self.gs_zero.zero_()                             # main lane: one fill also covers g_buf, g_nmap_n and the loss vector
+        if not lane.get("owns_shared"):
+            lloss.zero_()
         if shared_terms and app and getattr(self, "auto_draw", True):
             self.draw_texture_offsets()
         self._mesh_forward(lfid, B)
@@ -433,8 +436,8 @@ class FitEngine:
         """the random neighbour offsets of albedo_reg (std 1) / smooth_texture_reg (std 2), loss/texture_reg.py:15, 51 — drawn on the
         device by a counter-based generator seeded identically on every rank (graph-replayable: the counter is device memory)."""
         L, p, st = _lib.lib(), _lib.ptr, _lib.stream()
-        self._ck(L.harp_draw_texture_offsets(self.seed, p(self.draw_counter), self.Ht, self.Wt, 1.0, p(self.dist_albedo), st), "draw_offsets")
-        self._ck(L.harp_draw_texture_offsets(self.seed ^ 0x5bd1e995, p(self.draw_counter), self.Ht, self.Wt, 2.0, p(self.dist_normal), st), "draw_offsets")
+        self._ck(L.harp_draw_texture_offsets(self.seed, p(self.draw_counter), self.Ht, self.Wt, 1.0, p(self.dist_albedo), 2.0, p(self.dist_normal), st),
+                 "draw_offsets")
 
     def set_schedule(self, schedule):
         """(n_rows, batch_size) global frame ids, kept on the device: `step(None, ...)` then takes the next row (wrapping around)

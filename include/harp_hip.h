@@ -190,8 +190,10 @@ int harp_sum_squares(const float* x, int n, const float* w, float* loss, float* 
 int harp_texture_smooth_reg(const float* tex, const int32_t* dist, const float* mask, int H, int W, const float* w, float* loss,
                             float* g_tex, hipStream_t stream);
 /* draws dist (H,W,2) = int(N(0,std)) like torch.normal(...).to(torch.int) at loss/texture_reg.py:15, 51, from a counter-based generator
- * (same values on every rank for the same seed; *counter_dev is advanced on the device so graph replays draw fresh offsets) */
-int harp_draw_texture_offsets(unsigned seed, int* counter_dev, int H, int W, float std, int32_t* dist, hipStream_t stream);
+ * (same values on every rank for the same seed) and, if dist2 != NULL, an independent second set with std2 in the same launch.
+ * *counter_dev (one int, device memory) is advanced on the device after the draw, so graph replays draw fresh offsets. */
+int harp_draw_texture_offsets(unsigned seed, int* counter_dev, int H, int W, float std, int32_t* dist, float std2, int32_t* dist2,
+                              hipStream_t stream);
 /* scale * close_to_z_reg (loss/texture_reg.py:40-45) */
 int harp_close_to_z_reg(const float* nm, int H, int W, float scale, const float* w, float* loss, float* g_nm, hipStream_t stream);
 /* F.normalize(normal_map, dim=-1) (utils/visualize.py:99); n = number of texels */
