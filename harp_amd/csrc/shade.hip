@@ -27,6 +27,7 @@ namespace {
 #define SHADE_OCC 3
 #endif
 constexpr int kTexSlots = SHADE_TEX_SLOTS, kVtxSlots = SHADE_VTX_SLOTS;
+constexpr int kZlW = 32, kZlH = 24;   // LDS window of the shadow-map gradient (light pixels)
 constexpr int kTexRows = 512;   // row buckets of the sorted texel flush (a tile touching a taller span of texel rows flushes unsorted)
 #ifndef SHADE_PRERED
 #define SHADE_PRERED 19      // xor distances of the lane-merge butterfly before the vertex LDS atomics (1 | 2 | 16)
@@ -205,6 +206,8 @@ __global__ void __launch_bounds__(256, SHADE_OCC) shade_kernel(const harp_shade_
   // bilinear corners (~1.4 px per texel), and same-line float atomics serialise in L2: pre-summing in LDS cuts the global
   // atomics ~4x and removes the contention (ablation: the two texture scatters were 1.75 of 2.6 ms).
   __shared__ VertexAccum<BWD ? kTexSlots : 1, 6, SHADE_ACC_T> s_tex;
+  __shared__ double s_zwin[BWD ? kZlW * kZlH : 1];   // light-view depth-map gradient window (see below)
+  __shared__ int s_zbox[2];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int S = A.S, V = A.V;
   // one 16x16 tile per workgroup, dispatched in the rasteriser's heaviest-first super-tile order (harp_common.h: tile_decode): the
@@ -252,9 +255,13 @@ __global__ void __launch_bounds__(256, SHADE_OCC) shade_kernel(const harp_shade_
   float out_rgb[3] = {A.bg[0], A.bg[1], A.bg[2]};
   float vsc[BWD ? 27 : 1];   // backward: gradient of the face's 3 vertices x (position, normal, ndc), scattered after the branch
   int vidx[3] = {0, 0, 0};
+  float zd[BWD ? 9 : 1];     // backward: gradient of the 3x3 shadow-map taps (row-major), scattered after the branch
+  int zix = -0x40000000, ziy = -0x40000000;   // light-view pixel of this lane's hit point (unclamped); sentinel = no taps
   if (BWD) {
 #pragma unroll
     for (int c = 0; c < 27; ++c) vsc[BWD ? c : 0] = 0.f;
+#pragma unroll
+    for (int c = 0; c < 9; ++c) zd[BWD ? c : 0] = 0.f;
   }
   if (act) {
     const float px = pix_to_ndc(xi, S), py = pix_to_ndc(yi, S);
@@ -415,12 +422,11 @@ __global__ void __launch_bounds__(256, SHADE_OCC) shade_kernel(const harp_shade_
         for (int k = 0; k < 9; ++k) {
           const float d = g_vis * (1.0f / 9.0f) * sg[k] * (1.0f - sg[k]) * 1000.0f;
           if (d != 0.f) {
-            // (an LDS table for these taps was measured slower than the direct atomics: 9 hash probes per pixel cost more than the
-            //  semi-coalesced memory-side adds they save)
-            if (A.g_zl && !(A.debug_skip & 4)) atomicAdd(A.g_zl + (size_t)b * S * S + tapo[k], d);
+            zd[BWD ? k : 0] = d;
             g_zq -= d;
           }
         }
+        zix = g.ix; ziy = g.iy;
         const float* R = A.light_R + 9 * b;
         g_p = g_p + mk(R[2], R[5], R[8]) * g_zq;
         racc[12] += g.p.x * g_zq; racc[13] += g.p.y * g_zq; racc[14] += g.p.z * g_zq;        // light_R[:,2]
@@ -439,6 +445,46 @@ __global__ void __launch_bounds__(256, SHADE_OCC) shade_kernel(const harp_shade_
         vsc[9 * k + 0] = g_p.x * bw[k]; vsc[9 * k + 1] = g_p.y * bw[k]; vsc[9 * k + 2] = g_p.z * bw[k];
         vsc[9 * k + 3] = g_n.x * bw[k]; vsc[9 * k + 4] = g_n.y * bw[k]; vsc[9 * k + 5] = g_n.z * bw[k];
         vsc[9 * k + 6] = gnd[3 * k]; vsc[9 * k + 7] = gnd[3 * k + 1]; vsc[9 * k + 8] = gnd[3 * k + 2];
+      }
+    }
+  }
+  if (BWD && A.zl && A.g_zl && !(A.debug_skip & 4)) {
+    // light-view depth-map gradient: 9 taps per pixel, and the 3x3 windows of neighbouring pixels overlap almost completely.  The
+    // taps of the tile are summed in a direct-mapped LDS window (kZlW x kZlH light pixels anchored at the tile's smallest tap
+    // column / row: no hashing, ds_add_f64) and flushed row-major with one coalesced atomic per touched light pixel; taps outside
+    // the window (strong magnification) go straight to memory.  (Tried before: an LDS hash table - 9 probes per pixel, slower than
+    // the direct atomics; DPP hand-over between x-neighbours - exact but only -20 %, it needs equal light rows.)
+    if (threadIdx.x == 0) { s_zbox[0] = 0x7fffffff; s_zbox[1] = 0x7fffffff; }
+    for (int i = threadIdx.x; i < kZlW * kZlH; i += 256) s_zwin[i] = 0.0;
+    __syncthreads();
+    const bool has = zix > -0x40000000;
+    int mx = has ? min(max(zix - 1, 0), S - 1) : 0x7fffffff, my = has ? min(max(ziy - 1, 0), S - 1) : 0x7fffffff;
+#pragma unroll
+    for (int o2 = 32; o2 >= 1; o2 >>= 1) { mx = min(mx, __shfl_xor(mx, o2)); my = min(my, __shfl_xor(my, o2)); }
+    if (lane == 0 && mx != 0x7fffffff) { atomicMin(&s_zbox[0], mx); atomicMin(&s_zbox[1], my); }
+    __syncthreads();
+    const int x0 = s_zbox[0], y0 = s_zbox[1];
+    float* gz = A.g_zl + (size_t)b * S * S;
+    if (has) {
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const int yy = min(max(ziy + r - 1, 0), S - 1);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const float d = zd[BWD ? 3 * r + c : 0];
+          if (d == 0.f) continue;
+          const int xx = min(max(zix + c - 1, 0), S - 1);
+          const int wx = xx - x0, wy = yy - y0;
+          if (wx < kZlW && wy < kZlH) atomicAdd(&s_zwin[wy * kZlW + wx], (double)d);
+          else atomicAdd(gz + yy * S + xx, d);
+        }
+      }
+    }
+    __syncthreads();
+    if (x0 != 0x7fffffff) {
+      for (int i = threadIdx.x; i < kZlW * kZlH; i += 256) {
+        const double v = s_zwin[i];
+        if (v != 0.0) atomicAdd(gz + (size_t)(y0 + i / kZlW) * S + x0 + (i % kZlW), (float)v);
       }
     }
   }
@@ -525,9 +571,11 @@ __global__ void __launch_bounds__(256, SHADE_OCC) shade_kernel(const harp_shade_
     // consecutive addresses share requests (330 G/s).  The occupied slots are therefore counting-sorted by row (LDS histogram +
     // scan; the rows of one screen tile hold <= ~25 neighbouring texels, also across a chart seam) and flushed in that order.
     __shared__ int s_box[2];
-    __shared__ int s_hist[kTexRows];
-    __shared__ int s_order[kTexSlots];
     __shared__ int s_wsum[4];
+    // the sort scratch reuses the (already flushed) shadow-gradient window: keeps the kernel at 3 workgroups per CU
+    static_assert(sizeof(double) * kZlW * kZlH >= sizeof(int) * (kTexRows + kTexSlots), "window too small for the sort scratch");
+    int* s_hist = (int*)s_zwin;
+    int* s_order = s_hist + kTexRows;
     if (!(A.debug_skip & 16)) {
       const int total = sort_slots_by_row<kTexSlots>(s_tex.key, A.Wt, tb_y0, tb_y1, s_box, s_hist, s_order, s_wsum);
       if (total >= 0) {
