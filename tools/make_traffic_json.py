@@ -1,0 +1,57 @@
+"""profiles/traffic_latest.json from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE) over the same bench command:
+    python tools/make_traffic_json.py FETCH.db WRITE.db "<command the passes profiled>" > profiles/traffic_latest.json
+Per-launch HBM bytes of bench.py's kernel groups = 2 * FETCH_SIZE * 1024 + WRITE_SIZE * 1024 (KiB counters; gfx950 FETCH_SIZE
+under-reports coalesced reads 2x - calibrated on the Adam kernel)."""
+import json
+import sqlite3
+import sys
+from collections import defaultdict
+
+
+def per_launch(path, counter):
+    db = sqlite3.connect(path)
+    cur = db.cursor()
+    cols = [r[1] for r in cur.execute("pragma table_info(pmc_events)")]
+    idx = {c: i for i, c in enumerate(cols)}
+    tot, disp = defaultdict(float), defaultdict(set)
+    for r in cur.execute("select * from pmc_events"):
+        name = r[idx["name"]] if "name" in idx else r[idx["kernel_name"]]
+        if r[idx["counter_name"]] != counter:
+            continue
+        tot[name] += r[idx["value"] if "value" in idx else idx["counter_value"]]
+        disp[name].add(r[idx["dispatch_id"]])
+    return {k: (tot[k] / len(disp[k]), len(disp[k])) for k in tot}
+
+
+GROUPS = {
+    "harp_shade_bwd": (("shade_kernel<true>", 1.0),),
+    "harp_shade_fwd": (("shade_kernel<false>", 1.0),),
+    # face_setup / bin_faces / order_tiles run once per view: their per-launch averages are over both views already
+    "raster_cam_fwd(setup+bin+raster)": (("raster_kernel<1>", 1.0), ("face_setup_kernel", 1.0), ("bin_faces_kernel", 1.0), ("order_tiles_kernel", 1.0)),
+    "raster_light_fwd(setup+bin+raster)": (("raster_kernel<0>", 1.0), ("face_setup_kernel", 1.0), ("bin_faces_kernel", 1.0), ("order_tiles_kernel", 1.0)),
+    "harp_silhouette_bwd": (("raster_kernel<2>", 1.0),),
+    "harp_depth_bwd": (("depth_bwd_kernel", 1.0),),
+}
+
+
+def main(fetch_db, write_db, cmd):
+    f, w = per_launch(fetch_db, "FETCH_SIZE"), per_launch(write_db, "WRITE_SIZE")
+    out = {"_source": f"rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes) -- {cmd}; per-launch averages; "
+                      "HBM bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (gfx950: FETCH_SIZE under-reports coalesced reads by 2x, calibrated on "
+                      "adam_dev_kernel; WRITE_SIZE calibrated on the raster outputs).  tools/make_traffic_json.py"}
+    detail = {}
+    for key, parts in GROUPS.items():
+        b = 0.0
+        for sub, wgt in parts:
+            for name in set(f) | set(w):
+                if sub in name:
+                    fb, wb = f.get(name, (0, 0))[0], w.get(name, (0, 0))[0]
+                    b += wgt * (2 * fb * 1024 + wb * 1024)
+                    detail[name[:60]] = {"fetch_KiB": round(fb, 1), "write_KiB": round(wb, 1), "launches": f.get(name, (0, 0))[1]}
+        out[key] = int(b)
+    out["_per_kernel"] = detail
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main(*sys.argv[1:4])
