@@ -138,5 +138,20 @@ SIGNATURES.update({
     "harp_lbs_tree_fwd": (_i, [_trp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "harp_lbs_tree_bwd": (_i, [_trp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
 })
+
+
+class MeshChain(ctypes.Structure):
+    """mirror of `harp_mesh_chain` (include/harp_hip.h)"""
+    _fields_ = ([(n, _vp) for n in ("edges0", "vf_off", "vf_tri", "sub_off", "sub_idx", "disp")] +
+                [(n, _i) for n in ("B", "V0", "E0", "NJ", "S")] + [("focal", _f), ("shadow", _i), ("has_normal_grad", _i)] +
+                [(n, _vp) for n in ("verts_mm", "joints_mm", "cam_R", "cam_T", "light_pos",
+                                    "joints_m", "vs", "n1", "il1", "vd", "n2", "il2", "ndc_c", "centroid", "light_R", "light_T", "ndc_l",
+                                    "g_ndc_c", "g_ndc_l", "g_n2", "g_joints_m", "g_vd", "g_light_R", "g_light_T",
+                                    "g_v0", "g_joints_mm", "g_light_pos", "g_cam_T", "g_disp")])
+
+
+SIGNATURES["harp_mesh_chain_max_vertices"] = (_i, [])
+SIGNATURES["harp_mesh_chain_fwd"] = (_i, [ctypes.POINTER(MeshChain), _vp])
+SIGNATURES["harp_mesh_chain_bwd"] = (_i, [ctypes.POINTER(MeshChain), _vp])
 SIGNATURES["harp_draw_texture_offsets"] = (_i, [ctypes.c_uint, _vp, _i, _i, _f, _vp, _f, _vp, _vp])
 SIGNATURES["harp_rasterize_l1_fwd"] = (_i, [_vp, _vp, _i, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp])

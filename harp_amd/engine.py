@@ -149,6 +149,8 @@ class FitEngine:
         self.draw_counter = torch.zeros(1, dtype=torch.int32, device=self.dev)
         self.ref_verts = None
         self._graphs = {}
+        # per-frame fused mesh chain (csrc/chain.hip): 22 launches -> 2; needs the frame's mesh to fit its LDS staging
+        self.fused_chain = self.topo.V <= _lib.lib().harp_mesh_chain_max_vertices()
         self.compute_reference_mesh()
 
     # ------------------------------------------------------------------------------------------------
@@ -205,8 +207,26 @@ class FitEngine:
         if rc != 0:
             raise RuntimeError(f"{what} failed with status {rc}")
 
-    def _mesh_forward(self, fid, B):
-        """frame_setup .. normals: fills the scratch geometry for the B frames in `fid` (int32 device tensor)."""
+    def _chain_struct(self, B, shadow, has_normal_grad):
+        """harp_mesh_chain over the active lane's scratch (fused per-frame mesh chain, csrc/chain.hip)"""
+        s, p, tp = self.s, _lib.ptr, self.topo
+        c = _lib.MeshChain()
+        for k, t in (("edges0", tp.edges0), ("vf_off", tp.vf_off), ("vf_tri", tp.vf_tri), ("sub_off", tp.sub_off),
+                     ("sub_idx", tp.sub_idx), ("disp", self.params["verts_disps"]), ("verts_mm", s["verts_mm"]), ("joints_mm", s["joints_mm"]),
+                     ("cam_R", s["cam_R"]), ("cam_T", s["cam_T"]), ("light_pos", s["light_pos"]), ("joints_m", s["joints_m"]), ("vs", s["vs"]),
+                     ("n1", s["n1"]), ("il1", s["il1"]), ("vd", s["vd"]), ("n2", s["n2"]), ("il2", s["il2"]), ("ndc_c", s["ndc_c"]),
+                     ("centroid", s["centroid"]), ("light_R", s["light_R"]), ("light_T", s["light_T"]), ("ndc_l", s["ndc_l"]),
+                     ("g_ndc_c", s["g_ndc_c"]), ("g_ndc_l", s["g_ndc_l"]), ("g_n2", s["g_n2"]), ("g_joints_m", s["g_joints_m"]), ("g_vd", s["g_vd"]),
+                     ("g_light_R", s["g_light_R"]), ("g_light_T", s["g_light_T"]), ("g_v0", s["g_v0"]), ("g_joints_mm", s["g_joints_mm"]),
+                     ("g_light_pos", s["g_light_pos"]), ("g_cam_T", s["g_cam_T"]), ("g_disp", self.grads["verts_disps"])):
+            setattr(c, k, p(t))
+        c.B, c.V0, c.E0, c.NJ, c.S = B, tp.V0, tp.E0, self.n_joints, self.S
+        c.focal, c.shadow, c.has_normal_grad = self.focal, int(shadow), int(has_normal_grad)
+        return c
+
+    def _mesh_forward(self, fid, B, shadow=False):
+        """frame_setup .. normals (and, fused, both projections + the light camera): fills the scratch geometry for the B frames in
+        `fid` (int32 device tensor).  Returns True when the fused chain ran (projections / light camera already done)."""
         L, s, p, st, tp = _lib.lib(), self.s, _lib.ptr, _lib.stream(), self.topo
         self._ck(L.harp_frame_setup_fwd(ctypes.byref(self.tables), p(fid), B, self.S, self.focal, int(self.self_shadow), p(s["pose48"]),
                                         p(s["betas"]), p(s["trans_b"]), p(s["cam_R"]), p(s["cam_T"]), p(s["light_pos"]), p(s["colors"]), st),
@@ -214,12 +234,16 @@ class FitEngine:
         lbs_fwd = L.harp_lbs_tree_fwd if self.use_arm else L.harp_lbs_mano_fwd
         self._ck(lbs_fwd(ctypes.byref(self.dm.struct), p(s["pose48"]), p(s["betas"]), p(s["trans_b"]), B, p(s["lbs_ws"]),
                          p(s["verts_mm"]), p(s["joints_mm"]), st), "lbs_fwd")
+        if self.fused_chain:
+            self._ck(L.harp_mesh_chain_fwd(ctypes.byref(self._chain_struct(B, shadow, False)), st), "mesh_chain_fwd")
+            return True
         self._ck(L.harp_scale(p(s["joints_mm"]), 1e-3, B * self.n_joints * 3, p(s["joints_m"]), st), "scale")          # visualize.py:46
         self._ck(L.harp_subdivide_fwd(p(s["verts_mm"]), p(tp.edges0), B, tp.V0, tp.E0, 1e-3, p(s["vs"]), st), "subdivide_fwd")
         self._ck(L.harp_vertex_normals_fwd(p(s["vs"]), p(tp.faces), p(tp.vf_off), p(tp.vf_idx), B, tp.V, p(s["n1"]), p(s["il1"]),
                                            p(self.params["verts_disps"]), p(s["vd"]), st), "normals_displace_fwd")
         self._ck(L.harp_vertex_normals_fwd(p(s["vd"]), p(tp.faces), p(tp.vf_off), p(tp.vf_idx), B, tp.V, p(s["n2"]), p(s["il2"]),
                                            None, None, st), "normals_fwd")
+        return False
 
     @torch.no_grad()
     def compute_reference_mesh(self):
@@ -264,22 +288,25 @@ class FitEngine:
             lloss.zero_()
         if shared_terms and app and getattr(self, "auto_draw", True):
             self.draw_texture_offsets()
-        self._mesh_forward(lfid, B)
+        shadow = app and self.self_shadow
+        fused = self._mesh_forward(lfid, B, shadow)      # fused chain: both projections and the light camera are done as well
         # ---- the light-view chain (centroid -> light camera -> projection -> K=1 raster) is independent of the camera-view chain:
         #      it runs on a second HIP stream so the two latency-bound rasterisations overlap (fork / join is captured into the graph)
-        shadow = app and self.self_shadow
         if not getattr(self, "overlap", True) or not getattr(self, "_inner_overlap", True):
             side = cur                                   # single-stream mode (used when individual kernels are timed with events)
         if shadow:
             side.wait_stream(cur)
             with torch.cuda.stream(side):
-                self._ck(L.harp_centroid(p(s["vd"]), B, V, p(s["centroid"]), ST()), "centroid")
-                self._ck(L.harp_light_setup_fwd(p(s["centroid"]), p(s["light_pos"]), B, p(s["light_R"]), p(s["light_T"]), ST()), "light_setup")
-                self._ck(L.harp_project_fwd(p(s["vd"]), p(s["light_R"]), p(s["light_T"]), B, V, self.focal, S / 2.0, S / 2.0, S, p(s["ndc_l"]), ST()), "project_l")
+                if not fused:
+                    self._ck(L.harp_centroid(p(s["vd"]), B, V, p(s["centroid"]), ST()), "centroid")
+                    self._ck(L.harp_light_setup_fwd(p(s["centroid"]), p(s["light_pos"]), B, p(s["light_R"]), p(s["light_T"]), ST()), "light_setup")
+                    self._ck(L.harp_project_fwd(p(s["vd"]), p(s["light_R"]), p(s["light_T"]), B, V, self.focal, S / 2.0, S / 2.0, S, p(s["ndc_l"]), ST()),
+                             "project_l")
                 self._ck(L.harp_rasterize_fwd(p(s["ndc_l"]), p(tp.faces), B, V, F, S, 0, 0.0, 1.0, p(s["ws_l"]), p(s["face_l"]), p(s["zl"]), None, ST()),
                          "raster_light")
         # ---- camera view: projection + fused K=1 / soft-silhouette raster
-        self._ck(L.harp_project_fwd(p(s["vd"]), p(s["cam_R"]), p(s["cam_T"]), B, V, self.focal, S / 2.0, S / 2.0, S, p(s["ndc_c"]), ST()), "project")
+        if not fused:
+            self._ck(L.harp_project_fwd(p(s["vd"]), p(s["cam_R"]), p(s["cam_T"]), B, V, self.focal, S / 2.0, S / 2.0, S, p(s["ndc_c"]), ST()), "project")
         # the silhouette L1 term and its gradient are fused into the raster epilogue (no separate pass over alpha)
         self._ck(L.harp_rasterize_l1_fwd(p(s["ndc_c"]), p(tp.faces), B, V, F, S, 1, ops.SIL_BLUR, ops.SIL_SIGMA, p(s["ws_c"]), p(s["face_c"]),
                                          None, p(s["alpha"]), p(self.y_sil) if coarse else None, p(ltfid), wp(0), lp(0), p(s["g_alpha"]), ST()),
@@ -319,23 +346,28 @@ class FitEngine:
                 self._ck(L.harp_normalize3_bwd(p(self.params["normal_map"]), p(s["g_nmap_n"]), self.Ht * self.Wt, p(self.grads["normal_map"]), ST()), "normalize3_bwd")
             if self.self_shadow:
                 self._ck(L.harp_depth_bwd(p(s["face_l"]), p(s["ws_l"]), p(tp.faces), p(s["g_zl"]), B, V, F, S, p(s["g_ndc_l"]), ST()), "depth_bwd")
-                self._ck(L.harp_project_bwd(p(s["vd"]), p(s["light_R"]), p(s["light_T"]), p(s["g_ndc_l"]), B, V, self.focal, S, p(s["g_vd"]),
-                                            p(s["g_light_R"]), p(s["g_light_T"]), ST()), "project_bwd_l")
-                self._ck(L.harp_light_setup_bwd(p(s["centroid"]), p(s["light_pos"]), p(s["g_light_R"]), p(s["g_light_T"]), B, V, p(s["g_light_pos"]),
-                                                p(s["g_centroid"]), p(s["g_vd"]), ST()), "light_setup_bwd")
+                if not fused:
+                    self._ck(L.harp_project_bwd(p(s["vd"]), p(s["light_R"]), p(s["light_T"]), p(s["g_ndc_l"]), B, V, self.focal, S, p(s["g_vd"]),
+                                                p(s["g_light_R"]), p(s["g_light_T"]), ST()), "project_bwd_l")
+                    self._ck(L.harp_light_setup_bwd(p(s["centroid"]), p(s["light_pos"]), p(s["g_light_R"]), p(s["g_light_T"]), B, V, p(s["g_light_pos"]),
+                                                    p(s["g_centroid"]), p(s["g_vd"]), ST()), "light_setup_bwd")
         if coarse:
             cur.wait_stream(side)                       # silhouette_bwd (side stream) -> g_ndc_c complete
-        self._ck(L.harp_project_bwd(p(s["vd"]), p(s["cam_R"]), p(s["cam_T"]), p(s["g_ndc_c"]), B, V, self.focal, S, p(s["g_vd"]), None,
-                                    p(s["g_cam_T"]), ST()), "project_bwd_c")
-        if app:
-            self._ck(L.harp_vertex_normals_bwd(p(s["vd"]), p(tp.faces), p(tp.vf_off), p(tp.vf_idx), B, V, p(s["n2"]), p(s["il2"]), p(s["g_n2"]),
-                                               p(s["g_tmp"]), p(s["g_vd"]), ST()), "normals_bwd2")
-        self._ck(L.harp_displace_bwd(p(s["g_vd"]), p(s["n1"]), p(self.params["verts_disps"]), B, V, p(s["g_n1"]), p(self.grads["verts_disps"]), ST()),
-                 "displace_bwd")
-        self._ck(L.harp_vertex_normals_bwd(p(s["vs"]), p(tp.faces), p(tp.vf_off), p(tp.vf_idx), B, V, p(s["n1"]), p(s["il1"]), p(s["g_n1"]),
-                                           p(s["g_tmp"]), p(s["g_vd"]), ST()), "normals_bwd1")        # g_vs aliases g_vd (vd = vs + n d)
-        self._ck(L.harp_subdivide_bwd(p(s["g_vd"]), p(tp.sub_off), p(tp.sub_idx), B, tp.V0, V, 1e-3, p(s["g_v0"]), ST()), "subdivide_bwd")
-        self._ck(L.harp_scale(p(s["g_joints_m"]), 1e-3, B * self.n_joints * 3, p(s["g_joints_mm"]), ST()), "scale_bwd")
+        if fused:
+            # projections, light camera, both vertex-normal passes, displacement, subdivision and the mm scaling: one launch
+            self._ck(L.harp_mesh_chain_bwd(ctypes.byref(self._chain_struct(B, shadow, app)), ST()), "mesh_chain_bwd")
+        else:
+            self._ck(L.harp_project_bwd(p(s["vd"]), p(s["cam_R"]), p(s["cam_T"]), p(s["g_ndc_c"]), B, V, self.focal, S, p(s["g_vd"]), None,
+                                        p(s["g_cam_T"]), ST()), "project_bwd_c")
+            if app:
+                self._ck(L.harp_vertex_normals_bwd(p(s["vd"]), p(tp.faces), p(tp.vf_off), p(tp.vf_idx), B, V, p(s["n2"]), p(s["il2"]), p(s["g_n2"]),
+                                                   p(s["g_tmp"]), p(s["g_vd"]), ST()), "normals_bwd2")
+            self._ck(L.harp_displace_bwd(p(s["g_vd"]), p(s["n1"]), p(self.params["verts_disps"]), B, V, p(s["g_n1"]), p(self.grads["verts_disps"]), ST()),
+                     "displace_bwd")
+            self._ck(L.harp_vertex_normals_bwd(p(s["vs"]), p(tp.faces), p(tp.vf_off), p(tp.vf_idx), B, V, p(s["n1"]), p(s["il1"]), p(s["g_n1"]),
+                                               p(s["g_tmp"]), p(s["g_vd"]), ST()), "normals_bwd1")        # g_vs aliases g_vd (vd = vs + n d)
+            self._ck(L.harp_subdivide_bwd(p(s["g_vd"]), p(tp.sub_off), p(tp.sub_idx), B, tp.V0, V, 1e-3, p(s["g_v0"]), ST()), "subdivide_bwd")
+            self._ck(L.harp_scale(p(s["g_joints_m"]), 1e-3, B * self.n_joints * 3, p(s["g_joints_mm"]), ST()), "scale_bwd")
         lbs_bwd = L.harp_lbs_tree_bwd if self.use_arm else L.harp_lbs_mano_bwd
         self._ck(lbs_bwd(ctypes.byref(self.dm.struct), p(s["pose48"]), p(s["betas"]), p(s["trans_b"]), B, p(s["lbs_ws"]),
                          p(s["g_v0"]), p(s["g_joints_mm"]), p(s["g_pose48"]), p(s["g_betas"]), p(s["g_trans_b"]), ST()), "lbs_bwd")

@@ -6,6 +6,7 @@ import math
 
 import ctypes
 
+import numpy as np
 import torch
 
 from . import _lib
@@ -79,6 +80,10 @@ class DeviceTopology:
         for k in ("faces0", "edges0", "faces", "edges", "nbr_off", "nbr_idx", "vf_off", "vf_idx", "nc_pairs", "vp_off", "vp_idx", "sub_off", "sub_idx"):
             setattr(self, k, i32(topo[k]))
         self.E0, self.F, self.E = self.edges0.shape[0], self.faces.shape[0], self.edges.shape[0]
+        # expanded vertex -> incident-face table for the fused mesh chain: (i0, i1, i2, corner) per CSR entry, one 16-B load
+        fc = torch.as_tensor(np.asarray(topo["vf_idx"]), dtype=torch.int64)
+        fa = torch.as_tensor(np.asarray(topo["faces"]), dtype=torch.int64)
+        self.vf_tri = torch.cat([fa[fc // 3], (fc % 3)[:, None]], 1).to(torch.int32).contiguous().to(device)
         self.verts_uvs = torch.as_tensor(verts_uvs, dtype=torch.float32).reshape(-1, 2).contiguous().to(device)
         self.faces_uvs = i32(faces_uvs).reshape(-1, 3)
         self.device = device

@@ -169,6 +169,63 @@ int harp_lbs_tree_fwd(const harp_tree_model* m, const float* in_pose, const floa
 int harp_lbs_tree_bwd(const harp_tree_model* m, const float* in_pose, const float* betas, const float* transl, int B, float* ws,
                       float* g_verts, const float* g_joints, float* g_in_pose, float* g_betas, float* g_transl, hipStream_t stream);
 
+/* ---- fused per-frame mesh chain -----------------------------------------------------------------------------------
+ * One launch (one 1024-thread workgroup per frame, the frame's mesh staged in LDS) for everything utils/visualize.py:45-64
+ * (prepare_mesh: /1000, SubdivideMeshes, verts_normals, displacement), Meshes.verts_normals_packed of the displaced mesh
+ * (renderer_helper.py:495), hand_verts.mean(1) + process_info_for_shadow (optimize_sequence.py:476, renderer_helper.py:454-468) and
+ * MeshRasterizer.transform of both views do between the hand layer and the rasterisers — and one launch for their autograd.
+ * Same arithmetic as harp_subdivide_* / harp_vertex_normals_* / harp_displace_bwd / harp_centroid / harp_light_setup_* /
+ * harp_project_*; exists because every kernel node of a captured step costs ~4.5 us of dispatch latency.  V0 + E0 <=
+ * harp_mesh_chain_max_vertices().  All pointers device memory; "(+=)" outputs accumulate. */
+typedef struct harp_mesh_chain {
+  const int32_t* edges0;    /* (E0,2) base-mesh edges (midpoint i = V0 + i) */
+  const int32_t* vf_off;    /* (V+1) vertex -> incident (face, corner) CSR offsets */
+  const int32_t* vf_tri;    /* (nnz,4) per CSR entry: the incident face's vertex ids i0, i1, i2 and this vertex's corner (16-B aligned) */
+  const int32_t* sub_off;   /* (V0+1) base vertex -> midpoint CSR (backward) */
+  const int32_t* sub_idx;
+  const float* disp;        /* (V,) verts_disps */
+  int B, V0, E0, NJ, S;
+  float focal;
+  int shadow;               /* light-view outputs / gradients wanted */
+  int has_normal_grad;      /* backward: g_n2 is given (appearance stage) */
+  /* forward in */
+  const float* verts_mm;    /* (B,V0,3) hand-layer vertices, millimetres */
+  const float* joints_mm;   /* (B,NJ,3) */
+  const float* cam_R;       /* (B,9) */
+  const float* cam_T;       /* (B,3) */
+  const float* light_pos;   /* (B,3) */
+  /* forward out (backward in) */
+  float* joints_m;          /* (B,NJ,3) */
+  float* vs;                /* (B,V,3) subdivided, metres */
+  float* n1;                /* (B,V,3) its unit vertex normals */
+  float* il1;               /* (B,V) 1/|N| (0 where clamped) */
+  float* vd;                /* (B,V,3) displaced */
+  float* n2;                /* (B,V,3) */
+  float* il2;               /* (B,V) */
+  float* ndc_c;             /* (B,V,3) camera view */
+  float* centroid;          /* (B,3)   shadow only */
+  float* light_R;           /* (B,9)   shadow only */
+  float* light_T;           /* (B,3)   shadow only */
+  float* ndc_l;             /* (B,V,3) shadow only */
+  /* backward in */
+  const float* g_ndc_c;     /* (B,V,3) */
+  const float* g_ndc_l;     /* (B,V,3) shadow only */
+  const float* g_n2;        /* (B,V,3) if has_normal_grad */
+  const float* g_joints_m;  /* (B,NJ,3) */
+  const float* g_vd;        /* (B,V,3) gradient w.r.t. the displaced vertices gathered so far (mesh regularisers, shader) */
+  const float* g_light_R;   /* (B,9)  the shader's share, shadow only */
+  const float* g_light_T;   /* (B,3) */
+  /* backward out */
+  float* g_v0;              /* (B,V0,3) w.r.t. verts_mm */
+  float* g_joints_mm;       /* (B,NJ,3) */
+  float* g_light_pos;       /* (B,3) (+=) shadow only */
+  float* g_cam_T;           /* (B,3) (+=) */
+  float* g_disp;            /* (V,)  (+=, atomics over frames) */
+} harp_mesh_chain;
+int harp_mesh_chain_max_vertices(void);
+int harp_mesh_chain_fwd(const harp_mesh_chain* a, hipStream_t stream);
+int harp_mesh_chain_bwd(const harp_mesh_chain* a, hipStream_t stream);
+
 /* ---- losses, texture helpers, optimiser ---------------------------------------------------------------------------
  * Every loss call accumulates (+=) its value into `loss` and, if `w` (device pointer to the weight(s) = d total/d term)
  * and the gradient output are non-NULL, its weighted gradient (+= unless noted). */

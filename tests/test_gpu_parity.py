@@ -350,3 +350,38 @@ def test_device_schedule_matches_explicit_batches(sc):
     with pytest.raises(ValueError):
         FitEngine(sc["model_np"], sc["topo_np"], sc["tpl"]["verts_uvs"], sc["tpl"]["faces_uvs"], sc["uv_mask"].float(), sc["seq"], sc["S"],
                   sc["focal"], 2, device=DEV).step(None)
+
+
+@pytest.mark.parametrize("coarse,app", [(True, True), (True, False), (False, True)])
+def test_fused_mesh_chain_matches_building_blocks(sc, coarse, app):
+    """harp_mesh_chain_fwd/bwd (one workgroup per frame, mesh staged in LDS) against the stand-alone subdivide / normals / displace /
+    centroid / light-camera / projection kernels it fuses: same geometry, same losses, same gradient arena."""
+    from harp_amd.engine import FitEngine
+    tg = sc["targets"]
+    eng = FitEngine(sc["model_np"], sc["topo_np"], sc["tpl"]["verts_uvs"], sc["tpl"]["faces_uvs"], sc["uv_mask"].float(), sc["seq"], sc["S"],
+                    sc["focal"], 3, device=DEV, seed=1)
+    eng.set_targets(tg["y_true"], tg["y_sil"], tg["y_sil_col"])
+    with torch.no_grad():
+        eng.params["verts_disps"].copy_(torch.randn(3093, 1) * 0.001)
+        eng.params["texture"].copy_(torch.rand(1, 512, 512, 3) * 0.5 + 0.3)
+        eng.params["normal_map"].copy_(torch.tensor([0., 0., 1.]).repeat(1, 512, 512, 1) + torch.randn(1, 512, 512, 3) * 0.1)
+    fid = torch.tensor([2, 0, 1], dtype=torch.int32, device=DEV)
+    eng.fid.copy_(fid); eng.tfid.copy_(fid)
+    eng.auto_draw = False; eng.draw_texture_offsets(); eng.set_stage(coarse, app)
+    assert eng.fused_chain
+    out = {}
+    for fused in (False, True):
+        eng.fused_chain = fused
+        eng.forward_backward(coarse, app)
+        torch.cuda.synchronize()
+        out[fused] = (eng.g_buf.clone(), eng.loss_vec.clone(), eng.s["vd"].clone(), eng.s["n2"].clone(), eng.s["ndc_c"].clone(),
+                      eng.s["ndc_l"].clone() if (app and eng.self_shadow) else None)
+    for a, b in zip(out[True][2:], out[False][2:]):        # fp contraction differs between the two compilations: a few ulp of |N| ~ 1e-6
+        if a is not None:
+            assert (a - b).abs().max().item() < 5e-5
+    assert rel(out[True][1].cpu(), out[False][1].cpu()) < 1e-6
+    g1, g0 = out[True][0].cpu(), out[False][0].cpu()
+    for k in ("pose", "cam", "verts_disps", "shape", "light_positions", "texture", "normal_map"):
+        o, n = eng.arena.offsets[k][0], eng.arena.offsets[k][1]
+        if g0[o:o + n].abs().max() > 0:
+            assert rel(g1[o:o + n], g0[o:o + n]) < 5e-4, k       # atomics order + the conditioning of the silhouette-rim gradient
