@@ -55,8 +55,10 @@ __global__ void frame_setup_bwd_kernel(const harp_frame_tables t, const int32_t*
                                        int self_shadow, const float* __restrict__ g_pose48, const float* __restrict__ g_betas,
                                        const float* __restrict__ g_trans_b, const float* __restrict__ g_cam_T,
                                        const float* __restrict__ g_light_pos, const float* __restrict__ g_colors) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b == 0 && self_shadow && g_colors && t.g_amb_ratio) {
+  // one wave per frame, one lane per element: the ~70 scatter atomics of a frame are issued at once (one lane per frame walked
+  // them one after the other: 22 us of pure latency)
+  const int b = blockIdx.x, k = threadIdx.x;
+  if (b == 0 && k == 0 && self_shadow && g_colors && t.g_amb_ratio) {
     const float amb = 1.0f / (1.0f + expf(-t.amb_ratio[0]));
     const float g_amb = (g_colors[0] + g_colors[1] + g_colors[2]) - (g_colors[3] + g_colors[4] + g_colors[5]);
     atomicAdd(t.g_amb_ratio, g_amb * amb * (1.0f - amb));
@@ -65,23 +67,26 @@ __global__ void frame_setup_bwd_kernel(const harp_frame_tables t, const int32_t*
   const int f = fid[b];
   // duplicates of a frame inside one batch are legal -> atomics
   const int ps = t.wrist_pose ? 51 : 48, ho = t.wrist_pose ? 6 : 3, nbo = t.n_betas_out > 0 ? t.n_betas_out : 10;
-  if (g_pose48) {
-    if (t.g_rot) for (int k = 0; k < 3; ++k) atomicAdd(t.g_rot + f * 3 + k, g_pose48[b * ps + k]);
-    if (t.wrist_pose && t.g_wrist_pose) for (int k = 0; k < 3; ++k) atomicAdd(t.g_wrist_pose + f * 3 + k, g_pose48[b * ps + 3 + k]);
-    if (t.g_pose) for (int k = 0; k < 45; ++k) atomicAdd(t.g_pose + f * 45 + k, g_pose48[b * ps + ho + k]);
+  if (g_pose48 && k < ps) {
+    const float g = g_pose48[b * ps + k];
+    if (k < 3) { if (t.g_rot) atomicAdd(t.g_rot + f * 3 + k, g); }
+    else if (k < ho) { if (t.g_wrist_pose) atomicAdd(t.g_wrist_pose + f * 3 + (k - 3), g); }
+    else if (t.g_pose) atomicAdd(t.g_pose + f * 45 + (k - ho), g);
   }
-  if (g_betas && t.g_shape) for (int k = 0; k < 10; ++k) atomicAdd(t.g_shape + k, g_betas[b * nbo + k]);
-  if (g_trans_b && t.g_trans) for (int k = 0; k < 3; ++k) atomicAdd(t.g_trans + f * 3 + k, g_trans_b[b * 3 + k]);
-  if (g_cam_T && t.g_cam) {
-    const float c0 = t.cam[f * 3];
-    const float den = (float)S * c0 + 1e-9f;
-    atomicAdd(t.g_cam + f * 3, g_cam_T[b * 3 + 2] * (-2.0f * focal * (float)S / (den * den)));
-    atomicAdd(t.g_cam + f * 3 + 1, -g_cam_T[b * 3]);
-    atomicAdd(t.g_cam + f * 3 + 2, -g_cam_T[b * 3 + 1]);
+  if (g_betas && t.g_shape && k < 10) atomicAdd(t.g_shape + k, g_betas[b * nbo + k]);
+  if (g_trans_b && t.g_trans && k < 3) atomicAdd(t.g_trans + f * 3 + k, g_trans_b[b * 3 + k]);
+  if (g_cam_T && t.g_cam && k < 3) {
+    if (k == 0) {
+      const float c0 = t.cam[f * 3];
+      const float den = (float)S * c0 + 1e-9f;
+      atomicAdd(t.g_cam + f * 3, g_cam_T[b * 3 + 2] * (-2.0f * focal * (float)S / (den * den)));
+    } else {
+      atomicAdd(t.g_cam + f * 3 + k, -g_cam_T[b * 3 + (k - 1)]);
+    }
   }
-  if (g_light_pos && t.g_light_positions) {
+  if (g_light_pos && t.g_light_positions && k < 3) {
     const int lf = t.share_light ? 0 : f;
-    for (int k = 0; k < 3; ++k) atomicAdd(t.g_light_positions + lf * 3 + k, g_light_pos[b * 3 + k]);
+    atomicAdd(t.g_light_positions + lf * 3 + k, g_light_pos[b * 3 + k]);
   }
 }
 
@@ -180,7 +185,7 @@ int harp_frame_setup_bwd(const harp_frame_tables* t, const int32_t* fid, int B, 
                          const float* g_pose48, const float* g_betas, const float* g_trans_b, const float* g_cam_T,
                          const float* g_light_pos, const float* g_colors, hipStream_t stream) {
   if (!t || !fid) return HARP_ERR_ARG;
-  hipLaunchKernelGGL(frame_setup_bwd_kernel, dim3((B + 63) / 64), dim3(64), 0, stream, *t, fid, B, S, focal, self_shadow, g_pose48,
+  hipLaunchKernelGGL(frame_setup_bwd_kernel, dim3(B), dim3(64), 0, stream, *t, fid, B, S, focal, self_shadow, g_pose48,
                      g_betas, g_trans_b, g_cam_T, g_light_pos, g_colors);
   HARP_CHECK_LAUNCH();
   return HARP_OK;

@@ -124,39 +124,65 @@ __global__ void __launch_bounds__(64) lbs_joints_kernel(const harp_mano_model M,
 }
 
 // blockIdx.x: vertex chunk (256), blockIdx.y: frame chunk (8)
+constexpr int kSkinVerts = 64, kSkinSlices = 4;     // 256 threads = 64 vertices x 4 blend-shape slices
 template <bool BWD>
 __global__ void __launch_bounds__(256) lbs_skin_kernel(const harp_mano_model M, const float* __restrict__ betas,
                                                        const float* __restrict__ trans, const float* __restrict__ pose_map,
                                                        const float* __restrict__ A, int B, float* __restrict__ verts,
                                                        const float* __restrict__ g_verts, float* __restrict__ g_vp,
                                                        float* __restrict__ Mo) {
+  // 64 vertices x 4 slices of the blend-shape index per workgroup: a lane walks 135/4 + 10/4 dependent load trips instead of 145
+  // (the kernel is a chain of L2 round trips, not arithmetic: 16 workgroups of 256 vertices took 31 us), partial sums meet in LDS,
+  // then every lane skins its vertex for the frames f = slice, slice + 4, ...
   __shared__ float s_pm[FRAMES_PER_BLOCK][NP], s_beta[FRAMES_PER_BLOCK][NB], s_A[FRAMES_PER_BLOCK][NJ * 12];
-  const int v = blockIdx.x * 256 + threadIdx.x;
+  __shared__ float s_part[kSkinSlices][FRAMES_PER_BLOCK * 3][kSkinVerts];
+  const int vl = threadIdx.x & (kSkinVerts - 1), ks = threadIdx.x / kSkinVerts;
+  const int v = blockIdx.x * kSkinVerts + vl;
   const int b0 = blockIdx.y * FRAMES_PER_BLOCK;
   const int nb = min(FRAMES_PER_BLOCK, B - b0);
   for (int i = threadIdx.x; i < nb * NP; i += 256) s_pm[i / NP][i % NP] = pose_map[b0 * NP + i];
   for (int i = threadIdx.x; i < nb * NB; i += 256) s_beta[i / NB][i % NB] = betas[b0 * NB + i];
   for (int i = threadIdx.x; i < nb * NJ * 12; i += 256) s_A[i / (NJ * 12)][i % (NJ * 12)] = A[b0 * NJ * 12 + i];
   __syncthreads();
-  if (v >= NV) return;
+  const bool ok = v < NV;
   float vp[FRAMES_PER_BLOCK][3];
-  const float t0 = M.v_template[3 * v], t1 = M.v_template[3 * v + 1], t2 = M.v_template[3 * v + 2];
+  {
+    const float t0 = (ok && ks == 0) ? M.v_template[3 * v] : 0.f, t1 = (ok && ks == 0) ? M.v_template[3 * v + 1] : 0.f,
+                t2 = (ok && ks == 0) ? M.v_template[3 * v + 2] : 0.f;
 #pragma unroll
-  for (int f = 0; f < FRAMES_PER_BLOCK; ++f) { vp[f][0] = t0; vp[f][1] = t1; vp[f][2] = t2; }
-  for (int k = 0; k < NB; ++k) {
-    const float s0 = M.shapedirs_T[k * NV * 3 + 3 * v], s1 = M.shapedirs_T[k * NV * 3 + 3 * v + 1], s2 = M.shapedirs_T[k * NV * 3 + 3 * v + 2];
-#pragma unroll
-    for (int f = 0; f < FRAMES_PER_BLOCK; ++f) { const float c = s_beta[f][k]; vp[f][0] += s0 * c; vp[f][1] += s1 * c; vp[f][2] += s2 * c; }
+    for (int f = 0; f < FRAMES_PER_BLOCK; ++f) { vp[f][0] = t0; vp[f][1] = t1; vp[f][2] = t2; }
   }
-  for (int k = 0; k < NP; ++k) {
-    const float p0 = M.posedirs_T[k * NV * 3 + 3 * v], p1 = M.posedirs_T[k * NV * 3 + 3 * v + 1], p2 = M.posedirs_T[k * NV * 3 + 3 * v + 2];
+  if (ok) {
+    for (int k = ks; k < NB; k += kSkinSlices) {
+      const float s0 = M.shapedirs_T[k * NV * 3 + 3 * v], s1 = M.shapedirs_T[k * NV * 3 + 3 * v + 1], s2 = M.shapedirs_T[k * NV * 3 + 3 * v + 2];
 #pragma unroll
-    for (int f = 0; f < FRAMES_PER_BLOCK; ++f) { const float c = s_pm[f][k]; vp[f][0] += p0 * c; vp[f][1] += p1 * c; vp[f][2] += p2 * c; }
+      for (int f = 0; f < FRAMES_PER_BLOCK; ++f) { const float c = s_beta[f][k]; vp[f][0] += s0 * c; vp[f][1] += s1 * c; vp[f][2] += s2 * c; }
+    }
+#pragma unroll 4
+    for (int k = ks; k < NP; k += kSkinSlices) {
+      const float p0 = M.posedirs_T[k * NV * 3 + 3 * v], p1 = M.posedirs_T[k * NV * 3 + 3 * v + 1], p2 = M.posedirs_T[k * NV * 3 + 3 * v + 2];
+#pragma unroll
+      for (int f = 0; f < FRAMES_PER_BLOCK; ++f) { const float c = s_pm[f][k]; vp[f][0] += p0 * c; vp[f][1] += p1 * c; vp[f][2] += p2 * c; }
+    }
   }
+#pragma unroll
+  for (int f = 0; f < FRAMES_PER_BLOCK; ++f)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) s_part[ks][f * 3 + c][vl] = vp[f][c];
+  __syncthreads();
+  if (!ok) return;
   float w[NJ];
 #pragma unroll
   for (int j = 0; j < NJ; ++j) w[j] = M.weights[v * NJ + j];
-  for (int f = 0; f < nb; ++f) {
+  for (int f = ks; f < nb; f += kSkinSlices) {
+    float q[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      float a = 0.f;
+#pragma unroll
+      for (int sl = 0; sl < kSkinSlices; ++sl) a += s_part[sl][f * 3 + c][vl];
+      q[c] = a;
+    }
     float T[12];
 #pragma unroll
     for (int k = 0; k < 12; ++k) T[k] = 0.f;
@@ -167,7 +193,7 @@ __global__ void __launch_bounds__(256) lbs_skin_kernel(const harp_mano_model M, 
     const int b = b0 + f;
     if (!BWD) {
       for (int r = 0; r < 3; ++r) {
-        const float o = T[r * 4] * vp[f][0] + T[r * 4 + 1] * vp[f][1] + T[r * 4 + 2] * vp[f][2] + T[r * 4 + 3];
+        const float o = T[r * 4] * q[0] + T[r * 4 + 1] * q[1] + T[r * 4 + 2] * q[2] + T[r * 4 + 3];
         verts[((size_t)b * NV + v) * 3 + r] = (o + trans[3 * b + r]) * 1000.0f;
       }
     } else {
@@ -176,7 +202,7 @@ __global__ void __launch_bounds__(256) lbs_skin_kernel(const harp_mano_model M, 
       for (int c = 0; c < 3; ++c) g_vp[((size_t)b * NV + v) * 3 + c] = T[c] * g[0] + T[4 + c] * g[1] + T[8 + c] * g[2];
       float* mo = Mo + ((size_t)b * NV + v) * 12;
       for (int r = 0; r < 3; ++r) {
-        mo[r * 4] = g[r] * vp[f][0]; mo[r * 4 + 1] = g[r] * vp[f][1]; mo[r * 4 + 2] = g[r] * vp[f][2]; mo[r * 4 + 3] = g[r];
+        mo[r * 4] = g[r] * q[0]; mo[r * 4 + 1] = g[r] * q[1]; mo[r * 4 + 2] = g[r] * q[2]; mo[r * 4 + 3] = g[r];
       }
     }
   }
@@ -201,7 +227,7 @@ __global__ void __launch_bounds__(192) lbs_gA_kernel(const float* __restrict__ w
 }
 
 // g_pose_map[b][k] += sum_{vc in chunk} posedirs[vc][k] g_vp[b][vc];  g_beta_part[b][k] likewise with shapedirs (k<10)
-constexpr int kChunksP = 16;
+constexpr int kChunksP = 64;      // short dependent load chains: 37 trips per lane instead of 146 (23 -> ~8 us)
 __global__ void __launch_bounds__(192) lbs_gpm_kernel(const harp_mano_model M, const float* __restrict__ g_vp,
                                                       float* __restrict__ g_pm, float* __restrict__ g_beta_b) {
   const int b = blockIdx.x, k = threadIdx.x;
@@ -209,13 +235,13 @@ __global__ void __launch_bounds__(192) lbs_gpm_kernel(const harp_mano_model M, c
   const float* g = g_vp + (size_t)b * NV * 3;
   if (k < NP) {
     float acc = 0.f;
-#pragma unroll 4
+#pragma unroll 8
     for (int i = i0; i < i1; ++i) acc += M.posedirs[i * NP + k] * g[i];
     atomicAdd(&g_pm[b * NP + k], acc);
   } else if (k < NP + NB) {
     const int kk = k - NP;
     float acc = 0.f;
-#pragma unroll 4
+#pragma unroll 8
     for (int i = i0; i < i1; ++i) acc += M.shapedirs_T[kk * NV * 3 + i] * g[i];
     atomicAdd(&g_beta_b[b * NB + kk], acc);
   }
@@ -357,7 +383,7 @@ int harp_lbs_mano_fwd(const harp_mano_model* m, const float* pose, const float* 
   if (!m || !pose || !betas || !trans || !ws || !verts || !joints || B <= 0) return HARP_ERR_ARG;
   const LbsWs w = lbs_ws(ws, B);
   hipLaunchKernelGGL(lbs_joints_kernel, dim3(B), dim3(64), 0, stream, *m, pose, betas, w.pm, w.A, w.j16, w.Jrest, w.Rloc, w.G);
-  hipLaunchKernelGGL(lbs_skin_kernel<false>, dim3((NV + 255) / 256, (B + FRAMES_PER_BLOCK - 1) / FRAMES_PER_BLOCK), dim3(256), 0, stream,
+  hipLaunchKernelGGL(lbs_skin_kernel<false>, dim3((NV + kSkinVerts - 1) / kSkinVerts, (B + FRAMES_PER_BLOCK - 1) / FRAMES_PER_BLOCK), dim3(256), 0, stream,
                      *m, betas, trans, w.pm, w.A, B, verts, nullptr, nullptr, nullptr);
   hipLaunchKernelGGL(lbs_joints_out_kernel, dim3((B * 63 + 255) / 256), dim3(256), 0, stream, w.j16, verts, trans, B, joints);
   HARP_CHECK_LAUNCH();
@@ -371,7 +397,7 @@ int harp_lbs_mano_bwd(const harp_mano_model* m, const float* pose, const float* 
   const LbsWs w = lbs_ws(ws, B);
   hipLaunchKernelGGL(lbs_joints_bwd_kernel, dim3((B * 63 + 255) / 256), dim3(256), 0, stream, g_joints, B, w.g_j16, g_verts);
   hipLaunchKernelGGL(lbs_gtrans_kernel, dim3(B), dim3(256), 0, stream, g_verts, w.g_j16, g_trans);
-  hipLaunchKernelGGL(lbs_skin_kernel<true>, dim3((NV + 255) / 256, (B + FRAMES_PER_BLOCK - 1) / FRAMES_PER_BLOCK), dim3(256), 0, stream,
+  hipLaunchKernelGGL(lbs_skin_kernel<true>, dim3((NV + kSkinVerts - 1) / kSkinVerts, (B + FRAMES_PER_BLOCK - 1) / FRAMES_PER_BLOCK), dim3(256), 0, stream,
                      *m, betas, trans, w.pm, w.A, B, nullptr, g_verts, w.g_vp, w.Mo);
   // (a fill KERNEL, not hipMemsetAsync: memset nodes captured into a hipGraph were observed not to re-execute on replay)
   hipLaunchKernelGGL(zero2_kernel, dim3((B * (192 + 135) + 255) / 256), dim3(256), 0, stream, w.g_A, B * (192 + 135), g_betas, B * NB);

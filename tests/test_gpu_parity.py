@@ -123,7 +123,8 @@ def test_full_step_losses_grads_and_adam(sc):
     # atomics can legitimately move differently by a fraction of lr, so the bound is on the mean and on the outlier FRACTION.
     for k in ("pose", "cam", "verts_disps", "shape", "light_positions", "amb_ratio", "texture", "normal_map"):
         d = (eng.params[k].cpu() - P[k].detach()).abs()
-        assert d.mean() < 2e-5 and (d > 1e-3).float().mean() < 1e-4, (k, d.mean().item(), d.max().item())
+        # (small tensors: at most 2 such elements — verts_disps has 3093 entries and its gradient is an atomics sum over frames)
+        assert d.mean() < 2e-5 and (d > 1e-3).float().mean() < max(1e-4, 2.5 / d.numel()), (k, d.mean().item(), d.max().item())
     # rot / trans have no optimiser in the reference (optimize_sequence.py:254-289): untouched
     assert torch.equal(eng.params["rot"].cpu(), sc["seq"]["rot"])
 
