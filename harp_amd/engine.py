@@ -434,6 +434,10 @@ class FitEngine:
 
     def adam(self, coarse=True, app=True):
         L, p, st = _lib.lib(), _lib.ptr, _lib.stream()
+        # parameters outside the reference's optimiser groups (known_appearance: shape / displacement / texture / normal map,
+        # optimize_sequence.py:264-289) keep a zero gradient: with m = v = 0 the dense Adam update of such an element is exactly 0
+        for k in getattr(self, "frozen", ()):
+            self.grads[k].zero_()
         for on, idx, (o, n) in ((coarse, 0, self.coarse_span), (app, 1, self.app_span)):
             if not on:
                 continue

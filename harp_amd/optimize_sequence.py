@@ -11,6 +11,7 @@ import torch
 from .engine import FitEngine, LOSS_NAMES
 from .synth import build_topology
 from .utils import file_utils
+from .utils.data_util import ResidentTargets
 from .utils.visualize import MeshSubdivider
 
 
@@ -88,8 +89,8 @@ def optimize_hand_sequence(configs, input_params, images_dataset, val_params, va
                            seed=0):
     """Fit the sequence (optimize_sequence.py:313-596).  Returns the parameter dict in the reference's checkpoint layout.
     `images_dataset[i]` -> (fid, y_true (S,S,3), y_sil (S,S,1), y_sil_eroded (S,S,1)) like utils/data_util.ImagesDataset."""
-    if configs["model_type"] != "harp" or configs["known_appearance"] or configs["start_from"]:
-        raise NotImplementedError("round 1: 'harp' fitting from scratch (SURVEY.md §8; resume/known-appearance are §8f rows)")
+    if configs["model_type"] != "harp":
+        raise NotImplementedError("only model_type 'harp' (SURVEY.md §8: 'html' / 'nimble' are out of scope)")
     S, T = configs["img_size"], input_params["pose"].shape[0]
     use_arm = bool(configs["use_arm"])
     faces0 = np.asarray((hand_layer.right_arm_faces_tensor if use_arm else hand_layer.th_faces).detach().cpu())
@@ -100,9 +101,12 @@ def optimize_hand_sequence(configs, input_params, images_dataset, val_params, va
                     torch.as_tensor(uv_mask).float(), input_params, S, configs["focal_length"], batch_size, device=device,
                     self_shadow=configs["self_shadow"], share_light_position=configs["share_light_position"], seed=seed,
                     use_arm=use_arm, opt_arm_pose=bool(configs.get("opt_arm_pose", False)))
-    items = [images_dataset[i] for i in range(len(images_dataset))]
-    eng.set_targets(torch.stack([torch.as_tensor(it[1]) for it in items]), torch.stack([torch.as_tensor(it[2]).reshape(S, S) for it in items]),
-                    torch.stack([torch.as_tensor(it[3]).reshape(S, S) for it in items]))
+    eng.set_targets(*ResidentTargets(images_dataset).tensors())      # decoded once, resident in HBM (utils/data_util.py)
+    if configs["start_from"]:
+        restore_checkpoint(eng, configs, input_params)
+    if configs["known_appearance"]:
+        # optimize_sequence.py:264-289: shape / displacement leave opt_coarse, texture / normal map leave opt_app
+        eng.frozen = ("verts_disps", "shape", "texture", "normal_map")
     # ReduceLROnPlateau lives on the host; torch's own scheduler drives a dummy optimiser and the lr is mirrored to the device
     dummy = torch.optim.Adam([torch.nn.Parameter(torch.zeros(1))], lr=1e-3)
     sched = torch.optim.lr_scheduler.ReduceLROnPlateau(dummy, patience=40)
@@ -132,6 +136,34 @@ def optimize_hand_sequence(configs, input_params, images_dataset, val_params, va
     params = export_params(eng, input_params, VERTS_UVS, FACES_UVS, uv_mask, hand_layer)
     file_utils.save_result(params, configs["base_output_dir"], test=configs["known_appearance"])     # :595-596
     return params
+
+
+def restore_checkpoint(eng, configs, input_params):
+    """Resume from `configs["start_from"]/saved_params[_test].pkl` the way optimize_sequence.py:355-389 does — including its
+    re-initialisation: the pose track is re-interpolated linearly between every 30th frame, `trans` and `rot` are replaced by their
+    sequence means, parameters missing from older checkpoints get the init_params defaults; with known_appearance (and not
+    pose_already_opt) pose / trans / rot / cam restart from the METRO input instead."""
+    known, posed = bool(configs["known_appearance"]), bool(configs["pose_already_opt"])
+    ck = file_utils.load_result(configs["start_from"], device="cpu", test=known and posed)
+    ck = {k: (v.detach() if torch.is_tensor(v) else v) for k, v in ck.items()}
+    if known and not posed:
+        for k in ("trans", "pose", "rot", "cam"):
+            ck[k] = input_params[k].detach().clone()
+    T = eng.params["pose"].shape[0]
+    if ck["pose"].shape[0] != T:
+        raise ValueError(f"checkpoint holds {ck['pose'].shape[0]} frames, the sequence has {T}")
+    pose = ck["pose"].clone()
+    for i in range(T // 30 - 1):
+        for j in range(30):
+            pose[i * 30 + j] = ((30 - j) * ck["pose"][i * 30] + j * ck["pose"][i * 30 + 30]) / 30.0
+    ck["pose"] = pose
+    ck["trans"] = torch.zeros_like(ck["trans"]) + ck["trans"].mean(0)
+    ck["rot"] = torch.zeros_like(ck["rot"]) + ck["rot"].mean(0)
+    with torch.no_grad():
+        for k in ("trans", "pose", "rot", "shape", "wrist_pose", "verts_disps", "texture", "normal_map", "light_positions", "amb_ratio", "cam"):
+            if k in ck and ck[k] is not None:                     # absent keys keep the init_params defaults the engine starts with
+                eng.params[k].copy_(torch.as_tensor(ck[k]).to(eng.dev).reshape(eng.params[k].shape))
+    eng.compute_reference_mesh()                                  # ARAP reference = frame 0 under the restored parameters (:429-435)
 
 
 def export_params(eng, input_params, VERTS_UVS, FACES_UVS, uv_mask, hand_layer):
