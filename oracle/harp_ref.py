@@ -376,3 +376,41 @@ def smplxarm_forward(model, betas, global_orient, transl, right_hand_pose, right
     allj = torch.cat([joints, torch.zeros(B, 16, 3, dtype=dt), tips], 1)               # 55..70 are not selected by ARM_JOINT_IDX
     verts, allj = verts + transl[:, None], allj + transl[:, None]                      # :2378-2380
     return verts * 1000.0, allj[:, ARM_JOINT_IDX] * 1000.0                             # :2383-2390
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# temporal smoothness terms (reference loss/smooth.py:29-131; not called by the main loop — SURVEY.md §8f rank 4).
+# Pinned by tests/golden/smooth.npz (generated by importing the reference).
+def _neighbour_frames(fid, n_frames):
+    """loss/smooth.py:38-39: previous / next frame id, clamped at the boundaries of each n_frames-long sequence"""
+    fid_r = torch.where(fid % n_frames == n_frames - 1, fid, fid + 1)
+    fid_l = torch.where(fid % n_frames == 0, fid, fid - 1)
+    return fid_l, fid_r
+
+
+def smooth_pose_loss(params, fid, model, n_frames):
+    """LossSmoothPoses.smooth_pose (loss/smooth.py:35-73), MANO branch: root-aligned joints (mm) vs the detached mean of the
+    (previous, current, next) frames' root-aligned joints, sum of squares / N."""
+    N = len(fid)
+    fl, fr = _neighbour_frames(fid, n_frames)
+    J = []
+    for f in (fl, fid, fr):
+        _, j = mano_forward(model, torch.cat((params["rot"][f], params["pose"][f]), 1), params["shape"].repeat(N, 1), params["trans"][f])
+        J.append(j - j[:, 0:1])
+    interp = ((J[0] + J[1] + J[2]) / 3.0).detach()
+    return torch.sum((J[1] - interp) ** 2) / N
+
+
+def smooth_root_loss(params, fid, model, n_frames, focal_length, res):
+    """LossSmoothRoots.smooth_root (loss/smooth.py:86-131): camera translation (visualize.py convention without the sign flips) plus
+    the DETACHED root joint in metres, vs the detached 3-frame mean."""
+    N = len(fid)
+    fl, fr = _neighbour_frames(fid, n_frames)
+    R = []
+    for f in (fl, fid, fr):
+        _, j = mano_forward(model, torch.cat((params["rot"][f], params["pose"][f]), 1), params["shape"].repeat(N, 1), params["trans"][f])
+        cam = params["cam"][f]
+        t = torch.stack([cam[:, 1], cam[:, 2], 2 * focal_length / (res * cam[:, 0] + 1e-9)], dim=1)
+        R.append(t + j[:, 0].detach() / 1000.0)
+    interp = ((R[0] + R[1] + R[2]) / 3.0).detach()
+    return torch.sum((R[1] - interp) ** 2) / N

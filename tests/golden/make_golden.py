@@ -6,6 +6,8 @@ Writes small .npz fixtures (data only) next to this script:
   mano_layer.npz   ManoLayer.forward (manopth/manolayer.py:108-296) on the synthetic MANO-shaped model
   losses.npz       kps_loss (loss/kps_loss.py), arap_loss (loss/arap.py), albedo_reg / normal_reg
                    (loss/texture_reg.py, CPU RNG seeded; the drawn integer offsets are stored too)
+  smooth.npz       LossSmoothPoses.smooth_pose / LossSmoothRoots.smooth_root (loss/smooth.py) through the reference ManoLayer,
+                   values + gradients w.r.t. rot / pose / shape / trans / cam
 The reference modules that need PyTorch3D cannot be imported and are not covered.
 """
 import os
@@ -109,6 +111,19 @@ def main():
                         tex=tex.detach().numpy(), nm=nm.detach().numpy(), mask=mask.numpy(),
                         albedo_dist=d1.numpy(), albedo_loss=lt.item(), albedo_grad=tex.grad.numpy(),
                         normal_dist=d2.numpy(), normal_loss=ln.item(), normal_grad=nm.grad.numpy())
+    # ---- temporal smoothness terms (loss/smooth.py:29-131; dead in the main loop, used by the preprocessing fit — SURVEY §8f rank 4)
+    from loss.smooth import LossSmoothPoses, LossSmoothRoots
+    T, nF = 12, 6                                         # two "sequences" of 6 frames: clamping at both kinds of boundary
+    sp = {"rot": (torch.randn(T, 3, generator=g) * 0.3).requires_grad_(True), "pose": (torch.randn(T, 45, generator=g) * 0.3).requires_grad_(True),
+          "shape": (torch.randn(1, 10, generator=g) * 0.5).requires_grad_(True), "trans": (torch.randn(T, 3, generator=g) * 0.02).requires_grad_(True),
+          "cam": (torch.tensor([[0.9, 0.02, -0.03]]).repeat(T, 1) + torch.randn(T, 3, generator=g) * 0.02).requires_grad_(True)}
+    sfid = torch.tensor([0, 5, 6, 7, 11, 3])
+    l_pose = LossSmoothPoses(nF).smooth_pose(sp, sfid, layer, device="cpu")
+    l_root = LossSmoothRoots(nF, 1000.0, 224).smooth_root(sp, sfid, layer, device="cpu")
+    (l_pose + 1e4 * l_root).backward()
+    np.savez_compressed(os.path.join(HERE, "smooth.npz"), fid=sfid.numpy(), n_frames=nF, focal=1000.0, res=224,
+                        **{k: v.detach().numpy() for k, v in sp.items()}, smooth_pose=l_pose.item(), smooth_root=l_root.item(),
+                        **{"g_" + k: v.grad.numpy() for k, v in sp.items()})
     print("golden fixtures written:", [f for f in os.listdir(HERE) if f.endswith(".npz")])
 
 

@@ -163,3 +163,27 @@ def test_resume_and_known_appearance(tmp_path):
     assert not torch.equal(p2["pose"].cpu(), p1["pose"].cpu()) and not torch.equal(p2["light_positions"].cpu(), p1["light_positions"].cpu())
     assert torch.equal(p2["trans"].cpu(), (torch.zeros_like(p1["trans"]) + p1["trans"].mean(0)).cpu())      # no optimiser on trans
     assert os.path.exists(second + "saved_params_test.pkl")
+
+
+def test_smooth_losses_through_hip_layer(golden_dir):
+    """harp_amd.loss.smooth (one batched HIP LBS call for the 3-frame window) vs the golden values / gradients produced by the
+    reference's loss/smooth.py + ManoLayer (tests/golden/smooth.npz)."""
+    import os
+    from harp_amd import synth
+    from harp_amd.loss.smooth import LossSmoothPoses, LossSmoothRoots
+    from harp_amd.manopth.manolayer import ManoLayer
+    d = np.load(os.path.join(golden_dir, "smooth.npz"))
+    tpl = synth.load_template("hand")
+    layer = ManoLayer(flat_hand_mean=False, use_pca=False, model=synth.make_mano_model(tpl, seed=0), device=DEV)
+    P = {k: torch.from_numpy(d[k]).to(DEV).requires_grad_(True) for k in ("rot", "pose", "shape", "trans", "cam")}
+    fid = torch.from_numpy(d["fid"]).to(DEV)
+    nF = int(d["n_frames"])
+    lp = LossSmoothPoses(nF).smooth_pose(P, fid, layer, device=DEV)
+    lr = LossSmoothRoots(nF, float(d["focal"]), int(d["res"])).smooth_root(P, fid, layer, device=DEV)
+    assert abs(lp.item() - float(d["smooth_pose"])) <= 2e-5 * abs(float(d["smooth_pose"]))
+    assert abs(lr.item() - float(d["smooth_root"])) <= 2e-5 * abs(float(d["smooth_root"]))
+    (lp + 1e4 * lr).backward()
+    for k in ("rot", "pose", "shape", "cam"):
+        assert rel(P[k].grad.cpu(), torch.from_numpy(d["g_" + k])) < 5e-4, k
+    # the root alignment cancels the translation exactly: d/d(trans) is pure rounding noise (~1e-3 against pose gradients of ~1e3)
+    assert (P["trans"].grad.cpu() - torch.from_numpy(d["g_trans"])).abs().max() < 0.05

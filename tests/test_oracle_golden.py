@@ -68,3 +68,23 @@ def test_template_subdivision_kat():
         F0 = f // 4
         assert (topo["faces"][:3 * F0, 0] < v0).all() and (topo["faces"][:3 * F0, 1:] >= v0).all()
         assert (topo["faces"][3 * F0:] >= v0).all()
+
+
+def test_smooth_losses_golden(golden_dir):
+    """oracle restatement of loss/smooth.py vs values + gradients produced by the reference itself"""
+    from harp_amd import synth
+    from oracle import harp_ref as H
+    d = np.load(os.path.join(golden_dir, "smooth.npz"))
+    tpl = synth.load_template("hand")
+    model = {k: torch.from_numpy(v) for k, v in synth.make_mano_model(tpl, seed=0).items()}
+    P = {k: torch.from_numpy(d[k]).clone().requires_grad_(True) for k in ("rot", "pose", "shape", "trans", "cam")}
+    fid = torch.from_numpy(d["fid"])
+    nF = int(d["n_frames"])
+    lp = H.smooth_pose_loss(P, fid, model, nF)
+    lr = H.smooth_root_loss(P, fid, model, nF, float(d["focal"]), float(d["res"]))
+    assert abs(lp.item() - float(d["smooth_pose"])) <= 1e-5 * abs(float(d["smooth_pose"]))
+    assert abs(lr.item() - float(d["smooth_root"])) <= 1e-5 * abs(float(d["smooth_root"]))
+    (lp + 1e4 * lr).backward()
+    for k in ("rot", "pose", "shape", "trans", "cam"):
+        g, want = P[k].grad, torch.from_numpy(d["g_" + k])
+        assert (g - want).norm() <= 2e-4 * want.norm() + 1e-6, k
