@@ -344,6 +344,7 @@ class FitEngine:
             self._ck(L.harp_shade_bwd(ctypes.byref(a), ST()), "shade_bwd")
             if shared_terms:
                 self._ck(L.harp_normalize3_bwd(p(self.params["normal_map"]), p(s["g_nmap_n"]), self.Ht * self.Wt, p(self.grads["normal_map"]), ST()), "normalize3_bwd")
+                self._allreduce_maps_early()
             if self.self_shadow:
                 self._ck(L.harp_depth_bwd(p(s["face_l"]), p(s["ws_l"]), p(tp.faces), p(s["g_zl"]), B, V, F, S, p(s["g_ndc_l"]), ST()), "depth_bwd")
                 if not fused:
@@ -426,11 +427,34 @@ class FitEngine:
         for lane in self._lanes:                       # mean-type terms: weighted average of the lanes' means
             self.loss_vec.add_(lane["loss_vec"] * self._mean_mask, alpha=lane["B"] / self.B)
 
+    def _dist_on(self):
+        return self.world > 1 or getattr(self, "force_allreduce", False)
+
+    def _allreduce_maps_early(self):
+        """The texture + normal-map gradients (6.29 of the 6.36 MB bucket) are final once the shading backward and normalize3_bwd
+        are enqueued, ~0.25 ms before the mesh / LBS backward tail ends: their all-reduce is started there (async, on RCCL's own
+        stream) and overlaps with that tail; `allreduce()` then only has the small remainder [pose .. amb_ratio] left to send."""
+        if not self._dist_on() or not getattr(self, "overlap_allreduce", True) or torch.cuda.is_current_stream_capturing():
+            return
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()):
+            return
+        o = self.arena.offsets["texture"][0]
+        e = self.arena.span("texture", "normal_map")
+        self._early_work = dist.all_reduce(self.g_buf[o:o + e[1]], async_op=True)
+        self._early_from = o
+
     def allreduce(self):
-        if self.world > 1 or getattr(self, "force_allreduce", False):
+        if self._dist_on():
             from .dist import allreduce_flat
             o, n = self.opt_span
-            allreduce_flat(self.g_buf[o:o + n])           # one flat bucket (sum); 1/world is applied in the Adam kernel
+            work = getattr(self, "_early_work", None)
+            if work is not None:
+                allreduce_flat(self.g_buf[o:self._early_from])      # everything before the maps (they are the tail of the bucket)
+                work.wait()                                         # current stream waits for the early collective
+                self._early_work = None
+            else:
+                allreduce_flat(self.g_buf[o:o + n])       # one flat bucket (sum); 1/world is applied in the Adam kernel
 
     def adam(self, coarse=True, app=True):
         L, p, st = _lib.lib(), _lib.ptr, _lib.stream()
@@ -520,7 +544,7 @@ class FitEngine:
         use_micro = self.micro > 1 and n == self.B and getattr(self, "overlap", True)
         fb0 = (lambda: self._step_micro(coarse, app)) if use_micro else (lambda: self.forward_backward(coarse, app, B=n))
         fb = (lambda: (self._schedule_next(), fb0())) if scheduled else fb0
-        dist_on = self.world > 1 or getattr(self, "force_allreduce", False)
+        dist_on = self._dist_on()
         if not use_graph or n != self.B or (dist_on and not getattr(self, "graph_collectives", False)):
             fb()
             self.allreduce()

@@ -386,3 +386,33 @@ def test_fused_mesh_chain_matches_building_blocks(sc, coarse, app):
         o, n = eng.arena.offsets[k][0], eng.arena.offsets[k][1]
         if g0[o:o + n].abs().max() > 0:
             assert rel(g1[o:o + n], g0[o:o + n]) < 5e-4, k       # atomics order + the conditioning of the silhouette-rim gradient
+
+
+def test_rccl_path_on_one_rank(sc):
+    """The N>1 step (eager forward/backward, early async all-reduce of the texture / normal-map gradients overlapped with the mesh
+    backward, small remainder afterwards, Adam) on a 1-rank RCCL group: same parameters as the plain single-GPU step."""
+    import os
+    import torch.distributed as dist
+    from harp_amd.engine import FitEngine
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
+        dist.init_process_group("nccl", rank=0, world_size=1)
+    tg = sc["targets"]
+
+    def run(force):
+        eng = FitEngine(sc["model_np"], sc["topo_np"], sc["tpl"]["verts_uvs"], sc["tpl"]["faces_uvs"], sc["uv_mask"].float(), sc["seq"], sc["S"],
+                        sc["focal"], 2, device=DEV, seed=2)
+        eng.set_targets(tg["y_true"], tg["y_sil"], tg["y_sil_col"])
+        eng.force_allreduce = force
+        for i in range(3):
+            eng.step(torch.tensor([i % 3, (i + 1) % 3]), True, True, use_graph=False)     # (a graph capture warm-up would draw one more set of offsets)
+        torch.cuda.synchronize()
+        return eng
+    a, b = run(True), run(False)
+    assert getattr(a, "_early_work", None) is None
+    for k in ("pose", "cam", "verts_disps", "shape", "light_positions"):
+        assert (a.params[k] - b.params[k]).abs().max().item() < 2e-3, k
+    d = (a.params["texture"] - b.params["texture"]).abs()
+    assert d.mean().item() < 2e-5 and (d > 1e-3).float().mean().item() < 1e-3
+    dist.destroy_process_group()
