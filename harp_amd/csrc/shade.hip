@@ -521,11 +521,17 @@ __global__ void __launch_bounds__(256, SHADE_OCC) shade_kernel(const harp_shade_
       const size_t to = ((size_t)A.l1_fid[b] * S + yi) * S + xi;
       const float m = A.l1_mask ? A.l1_mask[to] : 1.f;
       const float wk = A.l1_w[0] * A.l1_inv * m;
+      // a masked-out pixel (the eroded silhouette is 0 on ~80 % of the image) contributes exactly 0: its target is not even read;
+      // the gradient image is only consumed where a face was hit (harp_shade_bwd), so it is only written there
+      if (m != 0.f) {
 #pragma unroll
-      for (int ch = 0; ch < 3; ++ch) {
-        const float d = out_rgb[ch] * m - A.l1_target[to * 3 + ch] * m;
-        acc += fabsf(d);
-        A.l1_grad[o * 3 + ch] = wk * ((d > 0.f) - (d < 0.f));
+        for (int ch = 0; ch < 3; ++ch) {
+          const float d = out_rgb[ch] * m - A.l1_target[to * 3 + ch] * m;
+          acc += fabsf(d);
+          if (f >= 0) A.l1_grad[o * 3 + ch] = wk * ((d > 0.f) - (d < 0.f));
+        }
+      } else if (f >= 0) {
+        A.l1_grad[o * 3] = 0.f; A.l1_grad[o * 3 + 1] = 0.f; A.l1_grad[o * 3 + 2] = 0.f;
       }
     }
     const float sum = block_sum_256(acc, s_red);
@@ -616,8 +622,9 @@ __global__ void __launch_bounds__(256) depth_bwd_kernel(const int32_t* __restric
   const int xi = tx0 + (lane & 15), yi = ty0 + w * 4 + (lane >> 4);
   const bool in_img = xi < S && yi < S;
   const size_t o = ((size_t)b * S + (in_img ? yi : 0)) * S + (in_img ? xi : 0);
-  const float g = in_img ? g_z[o] : 0.f;
   const int f = in_img ? face_id[o] : -1;
+  if (__syncthreads_or(f >= 0 ? 1 : 0) == 0) return;          // tile without faces: do not even read the gradient image
+  const float g = (f >= 0) ? g_z[o] : 0.f;
   const bool act = f >= 0 && g != 0.f;
   if (__syncthreads_or(act ? 1 : 0) == 0) return;
   s_acc.clear();

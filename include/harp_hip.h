@@ -86,7 +86,8 @@ typedef struct harp_shade_args {
   float* g_light_T;         /* (B,3) (+=) or NULL */
   int debug_skip;           /* 0 in production; bit flags used only by tools/dev ablation timing */
   /* forward only, optional: fused photometric L1 (optimize_sequence.py:543): *l1_loss (+=) mean |y_pred*m - y_true[fid]*m|,
-   * l1_grad (B,S,S,3) = l1_w[0] * d loss / d y_pred.  l1_target == NULL disables it. */
+   * l1_grad (B,S,S,3) = l1_w[0] * d loss / d y_pred, WRITTEN ONLY AT COVERED PIXELS (face_id >= 0: the only ones harp_shade_bwd reads).
+   * l1_target == NULL disables it. */
   const float* l1_target;   /* (T,S,S,3) */
   const float* l1_mask;     /* (T,S,S) or NULL */
   const int32_t* l1_fid;    /* (B,) */
