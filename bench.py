@@ -278,13 +278,17 @@ def main():
         ach = alg[dom] / (kt[dom] * 1e-3) / 1e9
         # HBM traffic per launch comes from PMC counters, which cannot be read in-process: the last rocprofv3 FETCH_SIZE / WRITE_SIZE
         # passes over this same command are committed as profiles/traffic_latest.json (see its _source field)
-        traffic = None
+        traffic, tjson = None, {}
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get(dom)
+            tjson = json.load(open(tpath))
+            traffic = tjson.get(dom)
+        # the same figures for every timed kernel group (north_star asks for the rasteriser's fraction explicitly)
+        per_kernel = {k: {"avg_ms": kt[k], "algorithmic_bytes": alg[k], "achieved_GBps": alg[k] / (kt[k] * 1e-3) / 1e9,
+                          "frac": alg[k] / (kt[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": tjson.get(k)} for k in kt}
         out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                            "traffic": traffic, "algorithmic_bytes_per_launch": alg[dom], "avg_ms": kt[dom],
-                           "kernel_ms": kt, "step_algorithmic_bytes": a_frame * eng.B + a_step,
+                           "kernel_ms": kt, "per_kernel": per_kernel, "step_algorithmic_bytes": a_frame * eng.B + a_step,
                            "step_frac_of_hbm_roofline": (a_frame * eng.B + a_step) / (dt / args.steps) / 1e9 / HBM_PEAK_GBS}
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()

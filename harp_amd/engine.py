@@ -289,14 +289,34 @@ class FitEngine:
         if shared_terms and app and getattr(self, "auto_draw", True):
             self.draw_texture_offsets()
         shadow = app and self.self_shadow
-        fused = self._mesh_forward(lfid, B, shadow)      # fused chain: both projections and the light camera are done as well
-        # ---- the light-view chain (centroid -> light camera -> projection -> K=1 raster) is independent of the camera-view chain:
-        #      it runs on a second HIP stream so the two latency-bound rasterisations overlap (fork / join is captured into the graph)
         if not getattr(self, "overlap", True) or not getattr(self, "_inner_overlap", True):
             side = cur                                   # single-stream mode (used when individual kernels are timed with events)
-        if shadow:
+        sched_early = getattr(self, "early_terms", True)
+        # ---- terms that depend on the parameters only (normal-map normalisation, texture regularisers, displacement regulariser) go
+        #      first on the second stream: they run under the LBS / mesh chain, which is a string of small latency-bound launches
+        def param_terms():
+            if app and shared_terms:
+                self._ck(L.harp_normalize3_fwd(p(self.params["normal_map"]), self.Ht * self.Wt, p(s["nmap_n"]), ST()), "normalize3")
+                self._texture_terms(wp, lp)
+            if coarse and shared_terms:
+                self._ck(L.harp_sum_squares(p(self.params["verts_disps"]), V, wp(2), lp(2), p(self.grads["verts_disps"]), ST()), "disp_reg")
+
+        def mesh_terms():
+            if coarse:
+                self._ck(L.harp_kps_loss(p(self.init_joints), p(lfid), p(s["joints_m"]), B, self.n_joints, wp(1), lp(1), p(s["g_joints_m"]), ST()), "kps")
+                self._ck(L.harp_mesh_regularizers(p(s["vd"]), p(self.ref_verts), p(tp.nbr_off), p(tp.nbr_idx), p(tp.nc_pairs), p(tp.vp_off), p(tp.vp_idx), B, V,
+                                                  tp.nc_pairs.shape[0], tp.E, wp(3), lp(3), p(s["g_vd"]), ST()), "mesh_reg")
+        if sched_early:
             side.wait_stream(cur)
             with torch.cuda.stream(side):
+                param_terms()
+        fused = self._mesh_forward(lfid, B, shadow)      # fused chain: both projections and the light camera are done as well
+        # ---- the light-view chain (centroid -> light camera -> projection -> K=1 raster) is independent of the camera-view chain:
+        #      it runs on the second HIP stream so the two rasterisations overlap (fork / join is captured into the graph); the mesh
+        #      regularisers and the key-point term follow it there (the light raster is the shorter of the two)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            if shadow:
                 if not fused:
                     self._ck(L.harp_centroid(p(s["vd"]), B, V, p(s["centroid"]), ST()), "centroid")
                     self._ck(L.harp_light_setup_fwd(p(s["centroid"]), p(s["light_pos"]), B, p(s["light_R"]), p(s["light_T"]), ST()), "light_setup")
@@ -304,6 +324,8 @@ class FitEngine:
                              "project_l")
                 self._ck(L.harp_rasterize_fwd(p(s["ndc_l"]), p(tp.faces), B, V, F, S, 0, 0.0, 1.0, p(s["ws_l"]), p(s["face_l"]), p(s["zl"]), None, ST()),
                          "raster_light")
+            if sched_early:
+                mesh_terms()
         # ---- camera view: projection + fused K=1 / soft-silhouette raster
         if not fused:
             self._ck(L.harp_project_fwd(p(s["vd"]), p(s["cam_R"]), p(s["cam_T"]), B, V, self.focal, S / 2.0, S / 2.0, S, p(s["ndc_c"]), ST()), "project")
@@ -311,34 +333,22 @@ class FitEngine:
         self._ck(L.harp_rasterize_l1_fwd(p(s["ndc_c"]), p(tp.faces), B, V, F, S, 1, ops.SIL_BLUR, ops.SIL_SIGMA, p(s["ws_c"]), p(s["face_c"]),
                                          None, p(s["alpha"]), p(self.y_sil) if coarse else None, p(ltfid), wp(0), lp(0), p(s["g_alpha"]), ST()),
                  "raster_cam")
+        cur.wait_stream(side)                           # join: light depth map, regulariser gradients, normalised normal map
         if coarse:
             # the silhouette backward only needs g_alpha and the camera-view workspace: it overlaps with shading on the side stream
-            if shadow:
-                cur.wait_stream(side)                   # join the light chain first (the side stream is reused)
             side.wait_stream(cur)
             with torch.cuda.stream(side):
                 self._ck(L.harp_silhouette_bwd(p(tp.faces), B, V, F, S, ops.SIL_BLUR, ops.SIL_SIGMA, p(s["ws_c"]), p(s["alpha"]), p(s["g_alpha"]),
                                                p(s["g_ndc_c"]), ST()), "silhouette_bwd")
-        elif shadow:
-            cur.wait_stream(side)
+        if not sched_early:
+            param_terms()
+            mesh_terms()
         if app:
-            if shared_terms:
-                self._ck(L.harp_normalize3_fwd(p(self.params["normal_map"]), self.Ht * self.Wt, p(s["nmap_n"]), ST()), "normalize3")
             a = self._shade_struct(B, app)
             # the photometric L1 term and its gradient are fused into the shader (no separate pass over the image)
             a.l1_target, a.l1_mask, a.l1_fid = p(self.y_true), p(self.y_sil_col), p(ltfid)
             a.l1_w, a.l1_loss, a.l1_grad = wp(6), lp(6), p(s["g_rgb"])
             self._ck(L.harp_shade_fwd(ctypes.byref(a), ST()), "shade_fwd")
-        # ---- losses and their gradients
-        if coarse:
-            self._ck(L.harp_kps_loss(p(self.init_joints), p(lfid), p(s["joints_m"]), B, self.n_joints, wp(1), lp(1), p(s["g_joints_m"]), ST()), "kps")
-            if shared_terms:
-                self._ck(L.harp_sum_squares(p(self.params["verts_disps"]), V, wp(2), lp(2), p(self.grads["verts_disps"]), ST()), "disp_reg")
-            self._ck(L.harp_mesh_regularizers(p(s["vd"]), p(self.ref_verts), p(tp.nbr_off), p(tp.nbr_idx), p(tp.nc_pairs), p(tp.vp_off), p(tp.vp_idx), B, V,
-                                              tp.nc_pairs.shape[0], tp.E, wp(3), lp(3), p(s["g_vd"]), ST()), "mesh_reg")
-        if app:
-            if shared_terms:
-                self._texture_terms(wp, lp)
         # ---- backward
         if app:
             self._ck(L.harp_shade_bwd(ctypes.byref(a), ST()), "shade_bwd")
