@@ -29,17 +29,23 @@ __device__ __forceinline__ V3 normz_bwd(V3 n, float len, float eps, V3 g) {
   return (len > eps) ? (g - n * dot(n, g)) * (1.0f / len) : g * (1.0f / eps);
 }
 
-// sum over the 1024 threads of the workgroup; `red` = 16 floats of LDS.  All threads get the result.
-__device__ __forceinline__ float block_sum_1024(float v, float* red) {
-  v = wave_sum(v);
+// N sums over the workgroup with two barriers in total (instead of 2N): red = 16*N floats of LDS, results in out[0..N) (LDS).
+template <int N>
+__device__ __forceinline__ void block_sum_n(const float* v, float* red, float* out) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  __syncthreads();
-  if (lane == 0) red[w] = v;
-  __syncthreads();
-  float s = 0.f;
 #pragma unroll
-  for (int i = 0; i < kChainThreads / 64; ++i) s += red[i];
-  return s;
+  for (int k = 0; k < N; ++k) {
+    const float s = wave_sum(v[k]);
+    if (lane == 0) red[w * N + k] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < N) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < kChainThreads / 64; ++i) s += red[i * N + threadIdx.x];
+    out[threadIdx.x] = s;
+  }
+  __syncthreads();
 }
 
 // process_info_for_shadow + look_at_rotation (same arithmetic as glue.hip:light_setup_kernel)
@@ -96,7 +102,7 @@ __device__ __forceinline__ V3 project(V3 p, const float* r, const float* T, floa
 
 __global__ void __launch_bounds__(kChainThreads) mesh_chain_fwd_kernel(const harp_mesh_chain A) {
   extern __shared__ float s_p[];               // V*3 positions: first the subdivided mesh, then the displaced one
-  __shared__ float s_red[16];
+  __shared__ float s_red3[16 * 3], s_tot3[3];
   __shared__ float s_cam[12];                  // light R (9) + T (3)
   const int b = blockIdx.x, tid = threadIdx.x;
   const int V0 = A.V0, V = A.V0 + A.E0;
@@ -153,9 +159,10 @@ __global__ void __launch_bounds__(kChainThreads) mesh_chain_fwd_kernel(const har
     }
   }
   if (!A.shadow) return;
-  const float cx = block_sum_1024(csum.x, s_red), cy = block_sum_1024(csum.y, s_red), cz = block_sum_1024(csum.z, s_red);
+  const float cs3[3] = {csum.x, csum.y, csum.z};
+  block_sum_n<3>(cs3, s_red3, s_tot3);
   if (tid == 0) {
-    const V3 c = mk(cx / V, cy / V, cz / V);
+    const V3 c = mk(s_tot3[0] / V, s_tot3[1] / V, s_tot3[2] / V);
     const LightCam k = light_cam(c, ld(A.light_pos + 3 * b));
     st(A.centroid + 3 * b, c);
     const float R[9] = {k.x.x, k.y.x, k.z.x, k.x.y, k.y.y, k.z.y, k.x.z, k.y.z, k.z.z};
@@ -211,7 +218,7 @@ __device__ __forceinline__ V3 normal_len_bwd(V3 n, float il, V3 g) { return (il 
 
 __global__ void __launch_bounds__(kChainThreads) mesh_chain_bwd_kernel(const harp_mesh_chain A) {
   extern __shared__ float s_mem[];             // [positions V*3 | gN V*3 | g V*3]
-  __shared__ float s_red[16];
+  __shared__ float s_red12[16 * 12], s_tot[12];
   __shared__ float s_gc[3];
   const int b = blockIdx.x, tid = threadIdx.x;
   const int V0 = A.V0, V = A.V0 + A.E0;
@@ -235,10 +242,9 @@ __global__ void __launch_bounds__(kChainThreads) mesh_chain_bwd_kernel(const har
       const V3 gv = project_bwd(ld(s_p + 3 * i), ld(A.g_ndc_l + fo + 3 * i), lR, lT, A.focal, half, gr);
       st(s_g + 3 * i, ld(s_g + 3 * i) + gv);
     }
-    float gs[12];
-#pragma unroll
-    for (int k = 0; k < 12; ++k) gs[k] = block_sum_1024(gr[k], s_red);
+    block_sum_n<12>(gr, s_red12, s_tot);
     if (tid == 0) {
+      const float* gs = s_tot;
       // totals of dL/d(light_R), dL/d(light_T): the shader's share is already in g_light_R / g_light_T
       float gR[9], gT[3];
       for (int k = 0; k < 9; ++k) gR[k] = A.g_light_R[9 * b + k] + gs[k];
@@ -280,11 +286,8 @@ __global__ void __launch_bounds__(kChainThreads) mesh_chain_bwd_kernel(const har
       const V3 gv = project_bwd(ld(s_p + 3 * i), ld(A.g_ndc_c + fo + 3 * i), cR, cT, A.focal, half, gr);
       st(s_g + 3 * i, ld(s_g + 3 * i) + gv);
     }
-#pragma unroll
-    for (int k = 9; k < 12; ++k) {
-      const float s = block_sum_1024(gr[k], s_red);
-      if (tid == 0 && s != 0.f) A.g_cam_T[3 * b + (k - 9)] += s;
-    }
+    block_sum_n<3>(gr + 9, s_red12, s_tot);
+    if (tid < 3 && s_tot[tid] != 0.f) A.g_cam_T[3 * b + tid] += s_tot[tid];
   }
   // ---- normals of the displaced mesh (the shader's g_n2)
   if (A.has_normal_grad) {
@@ -365,11 +368,11 @@ int harp_mesh_chain_bwd(const harp_mesh_chain* a, hipStream_t stream) {
                      !a->g_light_pos)))
     return HARP_ERR_ARG;
   const size_t lds = (size_t)(a->V0 + a->E0) * 9 * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {      // up to 144 KB of dynamic LDS (3 buffers of V*12 B)
-    if (hipFuncSetAttribute((const void*)mesh_chain_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256) != hipSuccess)
+  static size_t attr_lds = 0;      // dynamic LDS above 64 KB has to be requested (3 buffers of V*12 B: 111 KB hand, 147 KB arm)
+  if (lds > attr_lds) {
+    if (hipFuncSetAttribute((const void*)mesh_chain_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return HARP_ERR_ARG;
-    attr_set = true;
+    attr_lds = lds;
   }
   hipLaunchKernelGGL(mesh_chain_bwd_kernel, dim3(a->B), dim3(kChainThreads), lds, stream, *a);
   HARP_CHECK_LAUNCH();

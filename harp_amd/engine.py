@@ -286,8 +286,6 @@ class FitEngine:
         self.gs_zero.zero_()                             # main lane: one fill also covers g_buf, g_nmap_n and the loss vector
         if not lane.get("owns_shared"):
             lloss.zero_()
-        if shared_terms and app and getattr(self, "auto_draw", True):
-            self.draw_texture_offsets()
         shadow = app and self.self_shadow
         if not getattr(self, "overlap", True) or not getattr(self, "_inner_overlap", True):
             side = cur                                   # single-stream mode (used when individual kernels are timed with events)
@@ -296,6 +294,8 @@ class FitEngine:
         #      first on the second stream: they run under the LBS / mesh chain, which is a string of small latency-bound launches
         def param_terms():
             if app and shared_terms:
+                if getattr(self, "auto_draw", True):
+                    self.draw_texture_offsets()
                 self._ck(L.harp_normalize3_fwd(p(self.params["normal_map"]), self.Ht * self.Wt, p(s["nmap_n"]), ST()), "normalize3")
                 self._texture_terms(wp, lp)
             if coarse and shared_terms:
