@@ -166,7 +166,7 @@ def cpu_baseline(seed=0):
     with torch.no_grad():
         _, rv = H.prepare_mesh(P, torch.tensor([0]), model, topo)
     times = []
-    for it in range(3):
+    for it in range(9):
         t0 = time.time()
         fid = torch.tensor([it % T])
         da = torch.normal(0, 1.0, (512, 512, 2)).to(torch.int).long()
@@ -179,7 +179,7 @@ def cpu_baseline(seed=0):
     sec = float(np.median(times[1:]))
     return {"value": 1.0 / sec, "unit": "frames/s", "cores": cores, "kind": "port",
             "sample": f"oracle/harp_ref.step_losses + autograd + torch.optim.Adam, 1 frame/step at {S}x{S} (K=50 silhouette fragments "
-                      f"materialised), median of 2 steps after 1 warm-up, torch.set_num_threads({cores})"}
+                      f"materialised), median of 8 steps after 1 warm-up (~10 s of CPU work), torch.set_num_threads({cores})"}
 
 
 class _StdoutToStderr:
