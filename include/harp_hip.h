@@ -84,7 +84,8 @@ typedef struct harp_shade_args {
   float* g_colors;          /* 9 (+=) or NULL */
   float* g_light_R;         /* (B,9) (+=) or NULL */
   float* g_light_T;         /* (B,3) (+=) or NULL */
-  int debug_skip;           /* 0 in production; bit flags used only by tools/dev ablation timing */
+  int debug_skip;           /* 0 in production.  Ablation timing only (tools/dev/gpu_variant.py): 1/2 no texel adds, 4 no shadow-tap
+                             * gradient, 8 no vertex adds, 16 no texel flush, 32 no vertex flush — results are then WRONG by design */
   /* forward only, optional: fused photometric L1 (optimize_sequence.py:543): *l1_loss (+=) mean |y_pred*m - y_true[fid]*m|,
    * l1_grad (B,S,S,3) = l1_w[0] * d loss / d y_pred, WRITTEN ONLY AT COVERED PIXELS (face_id >= 0: the only ones harp_shade_bwd reads).
    * l1_target == NULL disables it. */

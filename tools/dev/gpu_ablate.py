@@ -18,7 +18,3 @@ cov = (eng.s['face_c']>=0).float().mean().item()
 print('coverage', cov, 'active px', cov*32*512*512)
 for name, fl in [('full',0),('no tex',1),('no nmap',2),('no tex+nmap',3),('no zl',4),('no vertex hash',8),('no tex/nmap/zl',7),('none of the scatters',15)]:
     print(f'{name:22s} {timeit(fl):8.3f} ms')
-print('--- without the bucket workspace (direct atomic flush)')
-a.bwd_ws = None
-for name, fl in [('full',0),('no tex+nmap',3),('no zl',4),('no vertex hash',8),('none of the scatters',15)]:
-    print(f'{name:22s} {timeit(fl):8.3f} ms')
