@@ -44,8 +44,7 @@ def build_engine(rank, world, device, T=T_FRAMES, img=S, B=B_PER_GPU, seed=0):
     seq, focal = synth.make_sequence(model, T, img, seed=seed)
     seq["joints"] = torch.zeros(T, 21, 3)
     eng = FitEngine(model, topo, tpl["verts_uvs"], tpl["faces_uvs"], tpl["uv_mask"].astype(np.float32) / 255.0, seq, img, focal, B,
-                    device=device, rank=rank, world_size=world, seed=seed,
-                    micro_batches=int(os.environ.get("HARP_MICRO_BATCHES", "1")))
+                    device=device, rank=rank, world_size=world, seed=seed)
     # ---- synthetic targets: render a perturbed "ground-truth" parameter set with the engine itself
     Tl = T // world
     lo = rank * Tl

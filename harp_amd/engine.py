@@ -66,7 +66,7 @@ class FitEngine:
 
     def __init__(self, model, topo, verts_uvs, faces_uvs, uv_mask, input_params, img_size, focal_length, batch_size,
                  device="cuda", self_shadow=True, share_light_position=True, tex_size=512, rank=0, world_size=1, seed=0,
-                 use_arm=False, opt_arm_pose=False, micro_batches=1):
+                 use_arm=False, opt_arm_pose=False):
         self.dev = torch.device(device)
         self.S, self.focal, self.B = int(img_size), float(focal_length), int(batch_size)
         self.self_shadow, self.share_light = bool(self_shadow), bool(share_light_position)
@@ -137,12 +137,6 @@ class FitEngine:
         self._main["loss_vec"], self._main["w_vec"] = self.loss_vec, self.w_vec
         self._main["owns_shared"] = True               # its zero slab also covers g_buf / g_nmap_n / loss_vec
         self._activate(self._main)
-        # micro-batching (EXPERIMENTAL, off by default): the batch is split in `micro` lanes with their own scratch and streams, so
-        # that the latency-bound rasterisation of one lane overlaps with the atomics-bound shading backward of the other.  Measured:
-        # raster || shade_bwd overlap hides only ~40 % of the rasteriser (1.40 vs 1.60 ms), eager mode becomes launch-bound with 2x the
-        # launches, and capturing the 5-stream step into a hipGraph crashes in capture_end on ROCm 7.2 — so it stays at 1.
-        self.micro = int(micro_batches) if (micro_batches > 1 and self.B % micro_batches == 0) else 1
-        self._lanes = [self._alloc_lane(self.B // self.micro, i * (self.B // self.micro)) for i in range(self.micro)] if self.micro > 1 else []
         self.dist_albedo = torch.zeros(tex_size, tex_size, 2, dtype=torch.int32, device=self.dev)
         self.dist_normal = torch.zeros(tex_size, tex_size, 2, dtype=torch.int32, device=self.dev)
         self.seed = int(seed) & 0x7FFFFFFF              # SAME seed on every rank
@@ -268,9 +262,8 @@ class FitEngine:
 
     def forward_backward(self, coarse=True, app=True, B=None, shared_terms=True):
         """Enqueue forward + losses + backward for the first B (default: the lane's size) frames of the active lane; gradients land
-        in self.g_buf, loss terms in the lane's loss_vec[:9] (unweighted, order LOSS_NAMES).  shared_terms=False skips everything that
-        does not depend on the frames (gradient-arena zeroing, offset draw, normal-map normalisation, displacement / texture
-        regularisers): the micro-batched step does those once around its lanes."""
+        in self.g_buf, loss terms in loss_vec[:9] (unweighted, order LOSS_NAMES).  shared_terms=False skips everything that does not
+        depend on the frames (gradient-arena zeroing, offset draw, normal-map normalisation, displacement / texture regularisers)."""
         lane = self._lane
         B = lane["B"] if B is None else int(B)
         lfid, ltfid, lloss = lane["fid"], lane["tfid"], lane["loss_vec"]
@@ -401,42 +394,6 @@ class FitEngine:
         self._ck(L.harp_texture_smooth_reg(p(self.params["normal_map"]), p(self.dist_normal), p(self.uv_mask), self.Ht, self.Wt, wp(8), lp(8),
                                            p(self.grads["normal_map"]), st), "normal_smooth")
 
-    def _step_micro(self, coarse, app):
-        """one full-batch forward+backward as `micro` concurrent lanes (each on its own HIP stream pair) around shared pre / post work"""
-        L, p = _lib.lib(), _lib.ptr
-        cur = torch.cuda.current_stream()
-        wp = lambda i: self.w_vec.data_ptr() + 4 * i
-        lp = lambda i: self.loss_vec.data_ptr() + 4 * i
-        V = self.topo.V
-        # ---- pre (shared)
-        self.g_buf.zero_()
-        self.g_nmap_n.zero_()
-        self.loss_vec.zero_()
-        if app:
-            if getattr(self, "auto_draw", True):
-                self.draw_texture_offsets()
-            self._ck(L.harp_normalize3_fwd(p(self.params["normal_map"]), self.Ht * self.Wt, p(self.nmap_n), _lib.stream()), "normalize3")
-        # ---- lanes
-        for lane in self._lanes:
-            if lane["stream"] is None:
-                lane["stream"] = torch.cuda.Stream(device=self.dev)
-            lane["stream"].wait_stream(cur)
-            with torch.cuda.stream(lane["stream"]):
-                self._activate(lane)
-                self.forward_backward(coarse, app, shared_terms=False)
-        self._activate(self._main)
-        for lane in self._lanes:
-            cur.wait_stream(lane["stream"])
-        # ---- post (shared): frame-independent terms, the normal-map normalisation backward, loss bookkeeping
-        if coarse:
-            self._ck(L.harp_sum_squares(p(self.params["verts_disps"]), V, wp(2), lp(2), p(self.grads["verts_disps"]), _lib.stream()), "disp_reg")
-        if app:
-            self._texture_terms(wp, lp)
-            self._ck(L.harp_normalize3_bwd(p(self.params["normal_map"]), p(self.g_nmap_n), self.Ht * self.Wt, p(self.grads["normal_map"]), _lib.stream()),
-                     "normalize3_bwd")
-        for lane in self._lanes:                       # mean-type terms: weighted average of the lanes' means
-            self.loss_vec.add_(lane["loss_vec"] * self._mean_mask, alpha=lane["B"] / self.B)
-
     def _dist_on(self):
         return self.world > 1 or getattr(self, "force_allreduce", False)
 
@@ -487,11 +444,6 @@ class FitEngine:
             if (coarse and k in COARSE_TERMS) or (app and k in APP_TERMS):
                 w[i] = LOSS_WEIGHTS[k]
         self.w_vec.copy_(w.to(self.dev))
-        # lanes see the mean-type weights scaled by their share of the batch (a mean over B frames = sum of lane means * B_lane / B)
-        mean_mask = torch.tensor([1.0 if k in ("silhouette", "kps_anchor", "laplacian", "normal", "arap", "photo") else 0.0 for k in LOSS_NAMES] + [0.0] * 7)
-        self._mean_mask = mean_mask.to(self.dev)
-        for lane in self._lanes:
-            lane["w_vec"].copy_((w * mean_mask * (lane["B"] / self.B)).to(self.dev))
 
     def set_lr(self, lr_coarse=None, lr_app=None):
         """host -> device hyper block (ReduceLROnPlateau lives on the host, optimize_sequence.py:309, 581-582)"""
@@ -551,8 +503,7 @@ class FitEngine:
         if getattr(self, "_stage", None) != key:
             self.set_stage(coarse, app)
             self._stage = key
-        use_micro = self.micro > 1 and n == self.B and getattr(self, "overlap", True)
-        fb0 = (lambda: self._step_micro(coarse, app)) if use_micro else (lambda: self.forward_backward(coarse, app, B=n))
+        fb0 = lambda: self.forward_backward(coarse, app, B=n)
         fb = (lambda: (self._schedule_next(), fb0())) if scheduled else fb0
         dist_on = self._dist_on()
         if not use_graph or n != self.B or (dist_on and not getattr(self, "graph_collectives", False)):
