@@ -16,7 +16,7 @@ def timeit(a, flags=0, n=20):
 out = [os.path.basename(os.environ.get('HARP_LIB_PATH', 'default'))]
 for mode in (False,):
     a = eng._shade_struct(32, True)
-    out.append(' '.join(f'{k}={timeit(a, fl):.3f}' for k, fl in (('full', 0), ('notex', 3), ('novtx', 8), ('none', 15), ('notexflush', 16), ('novtxflush', 32), ('noflush', 48), ('noflush_nozl', 52))))
+    out.append(' '.join(f'{k}={timeit(a, fl):.3f}' for k, fl in (('full', 0), ('notex', 3), ('novtx', 8), ('none', 15), ('notexflush', 16), ('novtxflush', 32), ('noflush', 48), ('noflush_nozl', 52), ('none', 15 | 48), ('none_noshadow', 15 | 48 | 64), ('none_nonmap', 15 | 48 | 128), ('none_noshadow_nonmap', 15 | 48 | 192))))
     eng._graphs = {}
     for _ in range(3): eng.step(fid, True, True, use_graph=True)
     torch.cuda.synchronize(); t = time.perf_counter()
