@@ -258,7 +258,8 @@ def main():
            "config": {"workload": "C3/C4: 256-frame 512x512 sequence, subdivided MANO hand 3093v/6152f/3327uv, self-shadow, "
                                   "coarse+appearance terms (displacement+texture stage, VGG excluded), dense Adam",
                       "frames_per_gpu_per_step": eng.B, "global_batch": world * eng.B, "sequence_frames": eng.T,
-                      "parallelism": f"dp{world} (frames sharded, 1 flat all-reduce of {eng.opt_span[1] * 4} B)",
+                      "parallelism": f"dp{world} (frames sharded; flat gradient bucket of {eng.opt_span[1] * 4} B all-reduced over RCCL: the texture/normal-map "
+                                     f"part overlapped with the mesh backward, the remainder before Adam)",
                       "hipgraph": (not args.no_graph) and world == 1},
            "losses_finite": finite}
     if rank == 0 and world == 1:
