@@ -62,13 +62,14 @@ class ShadeArgs(ctypes.Structure):
                 [(n, _f) for n in ("focal", "ppx", "ppy")] + [("bg", _f * 3)] +
                 [(n, _vp) for n in ("rgb", "g_rgb", "g_tex", "g_nmap", "g_verts", "g_vnormals", "g_ndc", "g_zl", "g_light_pos",
                                     "g_colors", "g_light_R", "g_light_T")] + [("debug_skip", _i)] +
-                [(n, _vp) for n in ("l1_target", "l1_mask", "l1_fid", "l1_w", "l1_loss", "l1_grad")] + [("l1_inv", _f)])
+                [(n, _vp) for n in ("l1_target", "l1_mask", "l1_fid", "l1_w", "l1_loss", "l1_grad")] + [("l1_inv", _f), ("texnm", _vp)])
 
 
 SIGNATURES.update({
     "harp_depth_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "harp_shade_fwd": (_i, [ctypes.POINTER(ShadeArgs), _vp]),
     "harp_shade_bwd": (_i, [ctypes.POINTER(ShadeArgs), _vp]),
+    "harp_pack_texels": (_i, [_vp, _vp, _i, _vp, _vp]),
     "harp_subdivide_fwd": (_i, [_vp, _vp, _i, _i, _i, _f, _vp, _vp]),
     "harp_subdivide_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _vp, _vp]),
     "harp_vertex_normals_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),

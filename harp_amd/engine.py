@@ -94,6 +94,7 @@ class FitEngine:
         self.fid = torch.zeros(self.B, dtype=torch.int32, device=self.dev)
         self.tfid = torch.zeros(self.B, dtype=torch.int32, device=self.dev)
         self.nmap_n = torch.empty(tex_size, tex_size, 3, dtype=torch.float32, device=self.dev)
+        self.texnm = torch.empty(tex_size, tex_size, 8, dtype=torch.float32, device=self.dev)      # interleaved albedo + normal map
         self._main = self._alloc_lane(self.B, 0, extra=[("g_nmap_n", (tex_size, tex_size, 3)), ("g_buf", (self.arena.size,)), ("loss_vec", (16,))])
         self.g_buf, self.g_nmap_n, self.loss_vec = (self._main["s"][k] for k in ("g_buf", "g_nmap_n", "loss_vec"))
         self.params = {k: self.arena.view(self.p_buf, k) for k, _ in spec}
@@ -253,6 +254,8 @@ class FitEngine:
                             s["light_T"] if self.self_shadow else None, self.S, self.focal, (self.S / 2.0, self.S / 2.0), (1.0, 1.0, 1.0))
         a.B = B
         a.rgb = _lib.ptr(s["rgb"])
+        if getattr(self, "packed_texels", True):
+            a.texnm = _lib.ptr(self.texnm)
         for k, t in (("g_rgb", s["g_rgb"]), ("g_tex", self.grads["texture"]), ("g_nmap", s["g_nmap_n"]), ("g_verts", s["g_vd"]),
                      ("g_vnormals", s["g_n2"]), ("g_ndc", s["g_ndc_c"]), ("g_zl", s["g_zl"] if self.self_shadow else None),
                      ("g_light_pos", s["g_light_pos"]), ("g_colors", s["g_colors"]),
@@ -290,6 +293,8 @@ class FitEngine:
                 if getattr(self, "auto_draw", True):
                     self.draw_texture_offsets()
                 self._ck(L.harp_normalize3_fwd(p(self.params["normal_map"]), self.Ht * self.Wt, p(s["nmap_n"]), ST()), "normalize3")
+                if getattr(self, "packed_texels", True):
+                    self._ck(L.harp_pack_texels(p(self.params["texture"]), p(s["nmap_n"]), self.Ht * self.Wt, p(self.texnm), ST()), "pack_texels")
                 self._texture_terms(wp, lp)
             if coarse and shared_terms:
                 self._ck(L.harp_sum_squares(p(self.params["verts_disps"]), V, wp(2), lp(2), p(self.grads["verts_disps"]), ST()), "disp_reg")

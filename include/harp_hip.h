@@ -96,7 +96,11 @@ typedef struct harp_shade_args {
   float* l1_loss;
   float* l1_grad;
   float l1_inv;             /* filled in by harp_shade_fwd */
+  /* optional (fwd and bwd): the SAME tex / nmap interleaved by harp_pack_texels; halves the cache lines of the bilinear footprint */
+  const void* texnm;
 } harp_shade_args;
+/* interleaves albedo (Ht*Wt,3) and the normalised normal map (Ht*Wt,3) into out (Ht*Wt,8): [r g b nx | ny nz 0 0], 16-B aligned */
+int harp_pack_texels(const float* tex, const float* nmap, int n_texels, float* out, hipStream_t stream);
 int harp_shade_fwd(const harp_shade_args* a, hipStream_t stream);
 int harp_shade_bwd(const harp_shade_args* a, hipStream_t stream);
 
