@@ -208,44 +208,10 @@ __global__ void __launch_bounds__(256) lbs_skin_kernel(const harp_mano_model M, 
   }
 }
 
-__global__ void zero2_kernel(float* __restrict__ a, int na, float* __restrict__ b, int nb) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < na) a[i] = 0.f;      // g_A | g_pm are adjacent in the workspace
-  if (i < nb) b[i] = 0.f;
-}
-
 // g_A[b][j][k] += sum_{v in chunk} w[v][j] M[b][v][k]   (192 lanes per frame x kChunksA vertex chunks; g_A pre-zeroed)
 constexpr int kChunksA = 8;
-__global__ void __launch_bounds__(192) lbs_gA_kernel(const float* __restrict__ weights, const float* __restrict__ Mo,
-                                                     float* __restrict__ g_A) {
-  const int b = blockIdx.x, j = threadIdx.x / 12, k = threadIdx.x % 12;
-  const int per = (NV + kChunksA - 1) / kChunksA, v0 = blockIdx.y * per, v1 = min(NV, v0 + per);
-  float acc = 0.f;
-#pragma unroll 4
-  for (int v = v0; v < v1; ++v) acc += weights[v * NJ + j] * Mo[((size_t)b * NV + v) * 12 + k];
-  atomicAdd(&g_A[(b * NJ + j) * 12 + k], acc);
-}
-
 // g_pose_map[b][k] += sum_{vc in chunk} posedirs[vc][k] g_vp[b][vc];  g_beta_part[b][k] likewise with shapedirs (k<10)
 constexpr int kChunksP = 64;      // short dependent load chains: 37 trips per lane instead of 146 (23 -> ~8 us)
-__global__ void __launch_bounds__(192) lbs_gpm_kernel(const harp_mano_model M, const float* __restrict__ g_vp,
-                                                      float* __restrict__ g_pm, float* __restrict__ g_beta_b) {
-  const int b = blockIdx.x, k = threadIdx.x;
-  const int per = (NV * 3 + kChunksP - 1) / kChunksP, i0 = blockIdx.y * per, i1 = min(NV * 3, i0 + per);
-  const float* g = g_vp + (size_t)b * NV * 3;
-  if (k < NP) {
-    float acc = 0.f;
-#pragma unroll 8
-    for (int i = i0; i < i1; ++i) acc += M.posedirs[i * NP + k] * g[i];
-    atomicAdd(&g_pm[b * NP + k], acc);
-  } else if (k < NP + NB) {
-    const int kk = k - NP;
-    float acc = 0.f;
-#pragma unroll 8
-    for (int i = i0; i < i1; ++i) acc += M.shapedirs_T[kk * NV * 3 + i] * g[i];
-    atomicAdd(&g_beta_b[b * NB + kk], acc);
-  }
-}
 
 // one wave per frame: chain + Rodrigues backward. g_j16 (B,16,3): gradient on the 16 chain joint positions (metres).
 __global__ void __launch_bounds__(64) lbs_chain_bwd_kernel(const harp_mano_model M, const float* __restrict__ pose,
@@ -322,6 +288,37 @@ __global__ void __launch_bounds__(64) lbs_chain_bwd_kernel(const harp_mano_model
   }
 }
 
+// the two independent reductions of the skinning backward in ONE launch: blockIdx.y < kChunksA -> g_A chunk, else g_pm / g_beta chunk
+__global__ void __launch_bounds__(192) lbs_gA_gpm_kernel(const harp_mano_model M, const float* __restrict__ weights, const float* __restrict__ Mo,
+                                                         float* __restrict__ g_A, const float* __restrict__ g_vp, float* __restrict__ g_pm,
+                                                         float* __restrict__ g_beta_b) {
+  const int b = blockIdx.x;
+  if ((int)blockIdx.y < kChunksA) {
+    const int j = threadIdx.x / 12, k = threadIdx.x % 12;
+    const int per = (NV + kChunksA - 1) / kChunksA, v0 = blockIdx.y * per, v1 = min(NV, v0 + per);
+    float acc = 0.f;
+#pragma unroll 4
+    for (int v = v0; v < v1; ++v) acc += weights[v * NJ + j] * Mo[((size_t)b * NV + v) * 12 + k];
+    atomicAdd(&g_A[(b * NJ + j) * 12 + k], acc);
+    return;
+  }
+  const int k = threadIdx.x, cy = blockIdx.y - kChunksA;
+  const int per = (NV * 3 + kChunksP - 1) / kChunksP, i0 = cy * per, i1 = min(NV * 3, i0 + per);
+  const float* g = g_vp + (size_t)b * NV * 3;
+  if (k < NP) {
+    float acc = 0.f;
+#pragma unroll 8
+    for (int i = i0; i < i1; ++i) acc += M.posedirs[i * NP + k] * g[i];
+    atomicAdd(&g_pm[b * NP + k], acc);
+  } else if (k < NP + NB) {
+    const int kk = k - NP;
+    float acc = 0.f;
+#pragma unroll 8
+    for (int i = i0; i < i1; ++i) acc += M.shapedirs_T[kk * NV * 3 + i] * g[i];
+    atomicAdd(&g_beta_b[b * NB + kk], acc);
+  }
+}
+
 __constant__ int c_tips[5] = {745, 317, 444, 556, 673};                                                  // manolayer.py:270
 __constant__ int c_reorder[21] = {0, 13, 14, 15, 16, 1, 2, 3, 17, 4, 5, 6, 18, 10, 11, 12, 19, 7, 8, 9, 20};  // :279
 
@@ -336,8 +333,12 @@ __global__ void lbs_joints_out_kernel(const float* __restrict__ j16, const float
 }
 
 // split g_joints (B,21,3) into g_j16 (B,16,3) [metres] and adds the tip part into g_verts (B,778,3)
-__global__ void lbs_joints_bwd_kernel(const float* __restrict__ g_joints, int B, float* __restrict__ g_j16, float* __restrict__ g_verts) {
+// ... and clears the two reduction buffers of the later stages (g_A | g_pm adjacent in the workspace, g_betas): one launch less
+__global__ void lbs_joints_bwd_kernel(const float* __restrict__ g_joints, int B, float* __restrict__ g_j16, float* __restrict__ g_verts,
+                                      float* __restrict__ za, int na, float* __restrict__ zb, int nb) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  for (int k = i; k < na; k += gridDim.x * blockDim.x) za[k] = 0.f;
+  for (int k = i; k < nb; k += gridDim.x * blockDim.x) zb[k] = 0.f;
   if (i >= B * 21 * 3) return;
   const int b = i / 63, k = (i % 63) / 3, c = i % 3, src = c_reorder[k];
   if (src < NJ) g_j16[(b * NJ + src) * 3 + c] = g_joints[i] * 1000.0f;
@@ -395,14 +396,12 @@ int harp_lbs_mano_bwd(const harp_mano_model* m, const float* pose, const float* 
                       float* g_verts, const float* g_joints, float* g_pose, float* g_betas, float* g_trans, hipStream_t stream) {
   if (!m || !pose || !betas || !ws || !g_verts || !g_joints || !g_pose || !g_betas || !g_trans) return HARP_ERR_ARG;
   const LbsWs w = lbs_ws(ws, B);
-  hipLaunchKernelGGL(lbs_joints_bwd_kernel, dim3((B * 63 + 255) / 256), dim3(256), 0, stream, g_joints, B, w.g_j16, g_verts);
+  hipLaunchKernelGGL(lbs_joints_bwd_kernel, dim3((B * 63 + 255) / 256), dim3(256), 0, stream, g_joints, B, w.g_j16, g_verts, w.g_A,
+                     B * (192 + 135), g_betas, B * NB);
   hipLaunchKernelGGL(lbs_gtrans_kernel, dim3(B), dim3(256), 0, stream, g_verts, w.g_j16, g_trans);
   hipLaunchKernelGGL(lbs_skin_kernel<true>, dim3((NV + kSkinVerts - 1) / kSkinVerts, (B + FRAMES_PER_BLOCK - 1) / FRAMES_PER_BLOCK), dim3(256), 0, stream,
                      *m, betas, trans, w.pm, w.A, B, nullptr, g_verts, w.g_vp, w.Mo);
-  // (a fill KERNEL, not hipMemsetAsync: memset nodes captured into a hipGraph were observed not to re-execute on replay)
-  hipLaunchKernelGGL(zero2_kernel, dim3((B * (192 + 135) + 255) / 256), dim3(256), 0, stream, w.g_A, B * (192 + 135), g_betas, B * NB);
-  hipLaunchKernelGGL(lbs_gA_kernel, dim3(B, kChunksA), dim3(192), 0, stream, m->weights, w.Mo, w.g_A);
-  hipLaunchKernelGGL(lbs_gpm_kernel, dim3(B, kChunksP), dim3(192), 0, stream, *m, w.g_vp, w.g_pm, g_betas);
+  hipLaunchKernelGGL(lbs_gA_gpm_kernel, dim3(B, kChunksA + kChunksP), dim3(192), 0, stream, *m, m->weights, w.Mo, w.g_A, w.g_vp, w.g_pm, g_betas);
   hipLaunchKernelGGL(lbs_chain_bwd_kernel, dim3(B), dim3(64), 0, stream, *m, pose, w.Rloc, w.G, w.Jrest, w.g_A, w.g_pm, w.g_j16,
                      g_pose, g_betas);
   HARP_CHECK_LAUNCH();
