@@ -121,7 +121,7 @@ SIGNATURES.update({
 })
 
 SIGNATURES.update({
-    "harp_adam_tick": (_i, [_vp, _vp]),
+    "harp_adam_tick": (_i, [_vp, _i, _vp]),
     "harp_adam_apply": (_i, [_vp, _vp, _vp, _vp, _sz, _vp, _vp]),
 })
 

@@ -308,8 +308,9 @@ __global__ void draw_offsets_kernel(uint32_t seed, int* __restrict__ counter, in
 __global__ void bump_counter_kernel(int* counter) { if (threadIdx.x == 0 && blockIdx.x == 0) *counter += 1; }
 
 // device-resident hyper-parameters so that a captured hipGraph can be replayed while step / lr change
-__global__ void adam_tick_kernel(harp_adam_hyper* h) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
+__global__ void adam_tick_kernel(harp_adam_hyper* hs, int count) {
+  if (blockIdx.x == 0 && (int)threadIdx.x < count) {
+    harp_adam_hyper* h = hs + threadIdx.x;
     h->step += 1;
     const double bc1 = 1.0 - pow((double)h->beta1, (double)h->step), bc2 = 1.0 - pow((double)h->beta2, (double)h->step);
     h->step_size = (float)((double)h->lr / bc1);
@@ -341,9 +342,9 @@ int harp_draw_texture_offsets(unsigned seed, int* counter_dev, int H, int W, flo
   return HARP_OK;
 }
 
-int harp_adam_tick(harp_adam_hyper* h, hipStream_t stream) {
-  if (!h) return HARP_ERR_ARG;
-  hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(64), 0, stream, h);
+int harp_adam_tick(harp_adam_hyper* h, int count, hipStream_t stream) {
+  if (!h || count < 1 || count > 64) return HARP_ERR_ARG;
+  hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(64), 0, stream, h, count);
   HARP_CHECK_LAUNCH();
   return HARP_OK;
 }

@@ -434,11 +434,13 @@ class FitEngine:
         # optimize_sequence.py:264-289) keep a zero gradient: with m = v = 0 the dense Adam update of such an element is exactly 0
         for k in getattr(self, "frozen", ()):
             self.grads[k].zero_()
-        for on, idx, (o, n) in ((coarse, 0, self.coarse_span), (app, 1, self.app_span)):
-            if not on:
-                continue
+        groups = [(idx, span) for on, idx, span in ((coarse, 0, self.coarse_span), (app, 1, self.app_span)) if on]
+        if len(groups) == 2:                            # the two hyper-parameter structs are adjacent: one tick launch for both
+            self._ck(L.harp_adam_tick(self.hyper.data_ptr(), 2, st), "adam_tick")
+        for idx, (o, n) in groups:
             h = self.hyper.data_ptr() + idx * self._hyper_stride
-            self._ck(L.harp_adam_tick(h, st), "adam_tick")
+            if len(groups) == 1:
+                self._ck(L.harp_adam_tick(h, 1, st), "adam_tick")
             self._ck(L.harp_adam_apply(self.p_buf.data_ptr() + 4 * o, self.g_buf.data_ptr() + 4 * o, self.m_buf.data_ptr() + 4 * o,
                                        self.v_buf.data_ptr() + 4 * o, n, h, st), "adam_apply")
 

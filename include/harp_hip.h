@@ -273,7 +273,7 @@ typedef struct harp_adam_hyper {
   int step;
   float step_size, inv_sqrt_bc2;   /* derived by harp_adam_tick */
 } harp_adam_hyper;
-int harp_adam_tick(harp_adam_hyper* h_dev, hipStream_t stream);
+int harp_adam_tick(harp_adam_hyper* h_dev, int count, hipStream_t stream);   /* `count` consecutive structs (one per param group) */
 int harp_adam_apply(float* p, const float* g, float* m, float* v, size_t n, const harp_adam_hyper* h_dev, hipStream_t stream);
 
 /* ---- per-frame glue of the fitting loop ---------------------------------------------------------------------------
