@@ -351,8 +351,13 @@ class FitEngine:
         if app:
             self._ck(L.harp_shade_bwd(ctypes.byref(a), ST()), "shade_bwd")
             if shared_terms:
-                self._ck(L.harp_normalize3_bwd(p(self.params["normal_map"]), p(s["g_nmap_n"]), self.Ht * self.Wt, p(self.grads["normal_map"]), ST()), "normalize3_bwd")
-                self._allreduce_maps_early()
+                # off the critical path: the normal-map chain rule (and, for N > 1, the early all-reduce of the map gradients) runs on
+                # the second stream while the main stream continues with the light-view depth backward
+                side.wait_stream(cur)
+                with torch.cuda.stream(side):
+                    self._ck(L.harp_normalize3_bwd(p(self.params["normal_map"]), p(s["g_nmap_n"]), self.Ht * self.Wt, p(self.grads["normal_map"]), ST()),
+                             "normalize3_bwd")
+                    self._allreduce_maps_early()
             if self.self_shadow:
                 self._ck(L.harp_depth_bwd(p(s["face_l"]), p(s["ws_l"]), p(tp.faces), p(s["g_zl"]), B, V, F, S, p(s["g_ndc_l"]), ST()), "depth_bwd")
                 if not fused:
@@ -360,8 +365,7 @@ class FitEngine:
                                                 p(s["g_light_R"]), p(s["g_light_T"]), ST()), "project_bwd_l")
                     self._ck(L.harp_light_setup_bwd(p(s["centroid"]), p(s["light_pos"]), p(s["g_light_R"]), p(s["g_light_T"]), B, V, p(s["g_light_pos"]),
                                                     p(s["g_centroid"]), p(s["g_vd"]), ST()), "light_setup_bwd")
-        if coarse:
-            cur.wait_stream(side)                       # silhouette_bwd (side stream) -> g_ndc_c complete
+        cur.wait_stream(side)                           # silhouette_bwd -> g_ndc_c, normalize3_bwd -> normal-map gradient complete
         if fused:
             # projections, light camera, both vertex-normal passes, displacement, subdivision and the mm scaling: one launch
             self._ck(L.harp_mesh_chain_bwd(ctypes.byref(self._chain_struct(B, shadow, app)), ST()), "mesh_chain_bwd")
