@@ -1,10 +1,11 @@
 """Print the kernel timeline of the last full step in a rocprofv3 rocpd database: start offset, duration, gap to the previous
-kernel's end, kernel name.  Steps are delimited by the Adam tick kernel.   python tools/rocpd_timeline.py DB [marker-substring]"""
+kernel's end, kernel name.  A step runs from one marker kernel (default: the schedule_next kernel that opens every step) to the
+next.   python tools/rocpd_timeline.py DB [marker-substring]"""
 import sqlite3
 import sys
 
 
-def main(path, marker="adam_tick"):
+def main(path, marker="schedule_next"):
     db = sqlite3.connect(path)
     cur = db.cursor()
     cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
@@ -12,11 +13,9 @@ def main(path, marker="adam_tick"):
     extra = ", stream_id" if "stream_id" in cols else (", queue_id" if "queue_id" in cols else "")
     rows = cur.execute(f"select {name}, start, end{extra} from kernels order by start").fetchall()
     marks = [i for i, r in enumerate(rows) if marker in r[0]]
-    if len(marks) < 4:
+    if len(marks) < 3:
         print("not enough steps"); return
-    # a step = from after the second-to-last pair of markers to the last marker
-    ends = marks[1::2] if len(marks) % 2 == 0 else marks
-    lo, hi = ends[-2] + 2, ends[-1] + 2
+    lo, hi = marks[-2], marks[-1]
     seg = rows[lo:hi]
     t0 = seg[0][1]
     prev_end = t0
