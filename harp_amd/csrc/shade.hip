@@ -646,10 +646,12 @@ __global__ void pack_texels_kernel(const float* __restrict__ tex, const float* _
 __global__ void __launch_bounds__(256) depth_bwd_kernel(const int32_t* __restrict__ face_id, const FaceRec* __restrict__ recs,
                                                         const int32_t* __restrict__ faces, const float* __restrict__ g_z,
                                                         int V, int F, int S, float* __restrict__ g_ndc,
-                                                        const int32_t* __restrict__ order, int B, int nsx) {
+                                                        const int32_t* __restrict__ order, const int32_t* __restrict__ bin_count,
+                                                        int B, int nsx) {
   __shared__ VertexAccum<256, 3> s_acc;
-  int b, st_unused, tx0, ty0;
-  if (!tile_decode(order, B, nsx, S, b, st_unused, tx0, ty0)) return;
+  int b, st, tx0, ty0;
+  if (!tile_decode(order, B, nsx, S, b, st, tx0, ty0)) return;
+  if (bin_count[b * nsx * nsx + st] == 0) return;             // super-tile without a single face: nothing was rasterised there
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int xi = tx0 + (lane & 15), yi = ty0 + w * 4 + (lane >> 4);
   const bool in_img = xi < S && yi < S;
@@ -733,7 +735,7 @@ int harp_depth_bwd(const int32_t* face_id, const void* ws, const int32_t* faces,
   if (!face_id || !ws || !faces || !g_z || !g_ndc) return HARP_ERR_ARG;
   const RasterWs W = raster_ws_split((void*)ws, B, F, S);
   hipLaunchKernelGGL(depth_bwd_kernel, dim3(tile_grid(B, W.nsx)), dim3(256), 0, stream, face_id, (const FaceRec*)ws, faces, g_z, V, F, S, g_ndc,
-                     (const int32_t*)W.order, B, W.nsx);
+                     (const int32_t*)W.order, (const int32_t*)W.cnt, B, W.nsx);
   HARP_CHECK_LAUNCH();
   return HARP_OK;
 }
