@@ -50,7 +50,7 @@ __device__ __forceinline__ float seg_dist2(float px, float py, float ax, float a
   const float bax = bx - ax, bay = by - ay;
   const float l2 = bax * bax + bay * bay;
   if (l2 <= kEps) { tt = 1.f; return (px - bx) * (px - bx) + (py - by) * (py - by); }
-  float t = (bax * (px - ax) + bay * (py - ay)) / l2;
+  float t = (bax * (px - ax) + bay * (py - ay)) * __builtin_amdgcn_rcpf(l2);      // <= 1.5 ulp from the IEEE quotient
   t = fminf(fmaxf(t, 0.f), 1.f);
   tt = t;
   const float qx = ax + t * bax, qy = ay + t * bay;
@@ -225,6 +225,7 @@ __global__ void __launch_bounds__(256) raster_kernel(const FaceRec* __restrict__
     if (__syncthreads_or(need ? 1 : 0) == 0) return;
   }
 
+  const float inv_sigma = 1.0f / sigma;
   unsigned hq = 0u;
   unsigned long long sq = 0ull;
   int hn = 0, sn = 0;
@@ -269,12 +270,12 @@ __global__ void __launch_bounds__(256) raster_kernel(const FaceRec* __restrict__
             const float dist = fminf(d01, fminf(d02, d12));
             if (inside || dist < blur) {
               const float sd = inside ? -dist : dist;
-              const float p = 1.0f / (1.0f + expf(sd / sigma));   // sigmoid(-sd/sigma)
+              const float p = __builtin_amdgcn_rcpf(1.0f + expf(sd * inv_sigma));   // sigmoid(-sd/sigma), reciprocal forms (<= 2 ulp)
               if (MODE == 1) {
                 prod *= (1.0f - p);
               } else {
                 // d alpha / d sd = -P * p / sigma  (P = prod over all faces)
-                const float g_sd = ga * (-P * p / sigma);
+                const float g_sd = ga * (-P * p * inv_sigma);
                 const float gd = inside ? -g_sd : g_sd;     // d/d(dist^2)
                 // PointLineDistanceBackward on the argmin edge (t treated as constant)
                 int ia, ib; float ax, ay, bx, by, tt;
