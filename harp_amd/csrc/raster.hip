@@ -270,7 +270,7 @@ __global__ void __launch_bounds__(256) raster_kernel(const FaceRec* __restrict__
             const float dist = fminf(d01, fminf(d02, d12));
             if (inside || dist < blur) {
               const float sd = inside ? -dist : dist;
-              const float p = __builtin_amdgcn_rcpf(1.0f + expf(sd * inv_sigma));   // sigmoid(-sd/sigma), reciprocal forms (<= 2 ulp)
+              const float p = __builtin_amdgcn_rcpf(1.0f + __expf(sd * inv_sigma));   // sigmoid(-sd/sigma): fast exp + reciprocal (rel. error ~1e-6 at |x| ~ 18; image tolerance 1e-4)
               if (MODE == 1) {
                 prod *= (1.0f - p);
               } else {
