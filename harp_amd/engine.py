@@ -146,6 +146,18 @@ class FitEngine:
         self._graphs = {}
         # per-frame fused mesh chain (csrc/chain.hip): 22 launches -> 2; needs the frame's mesh to fit its LDS staging
         self.fused_chain = self.topo.V <= _lib.lib().harp_mesh_chain_max_vertices()
+        # ---- switches (all on in production; tools/dev and bench.py flip some of them to measure their effect)
+        self.overlap = True              # second HIP stream (light view, silhouette backward, parameter-only terms); False: one stream
+        self.early_terms = True          # parameter-only terms / mesh regularisers scheduled on the second stream
+        self.packed_texels = True        # shaders read the interleaved albedo + normal-map array (harp_pack_texels)
+        self.auto_draw = True            # draw fresh texture-regulariser offsets every step (False: the caller draws)
+        self.overlap_allreduce = True    # N > 1: all-reduce of the map gradients overlapped with the mesh / LBS backward
+        self.graph_collectives = False   # N > 1: capture the RCCL all-reduce into the step graph (verified on 1 rank only)
+        self.force_allreduce = False     # run the N > 1 code path on a single rank (tests, bench HARP_FORCE_DIST)
+        self.frozen = ()                 # parameters kept out of the optimiser groups (known_appearance)
+        self.schedule = None
+        self._stage = None
+        self._early_work = None
         self.compute_reference_mesh()
 
     # ------------------------------------------------------------------------------------------------
@@ -254,7 +266,7 @@ class FitEngine:
                             s["light_T"] if self.self_shadow else None, self.S, self.focal, (self.S / 2.0, self.S / 2.0), (1.0, 1.0, 1.0))
         a.B = B
         a.rgb = _lib.ptr(s["rgb"])
-        if getattr(self, "packed_texels", True):
+        if self.packed_texels:
             a.texnm = _lib.ptr(self.texnm)
         for k, t in (("g_rgb", s["g_rgb"]), ("g_tex", self.grads["texture"]), ("g_nmap", s["g_nmap_n"]), ("g_verts", s["g_vd"]),
                      ("g_vnormals", s["g_n2"]), ("g_ndc", s["g_ndc_c"]), ("g_zl", s["g_zl"] if self.self_shadow else None),
@@ -283,17 +295,17 @@ class FitEngine:
         if not lane.get("owns_shared"):
             lloss.zero_()
         shadow = app and self.self_shadow
-        if not getattr(self, "overlap", True) or not getattr(self, "_inner_overlap", True):
+        if not self.overlap:
             side = cur                                   # single-stream mode (used when individual kernels are timed with events)
-        sched_early = getattr(self, "early_terms", True)
+        sched_early = self.early_terms
         # ---- terms that depend on the parameters only (normal-map normalisation, texture regularisers, displacement regulariser) go
         #      first on the second stream: they run under the LBS / mesh chain, which is a string of small latency-bound launches
         def param_terms():
             if app and shared_terms:
-                if getattr(self, "auto_draw", True):
+                if self.auto_draw:
                     self.draw_texture_offsets()
                 self._ck(L.harp_normalize3_fwd(p(self.params["normal_map"]), self.Ht * self.Wt, p(s["nmap_n"]), ST()), "normalize3")
-                if getattr(self, "packed_texels", True):
+                if self.packed_texels:
                     self._ck(L.harp_pack_texels(p(self.params["texture"]), p(s["nmap_n"]), self.Ht * self.Wt, p(self.texnm), ST()), "pack_texels")
                 self._texture_terms(wp, lp)
             if coarse and shared_terms:
@@ -404,13 +416,13 @@ class FitEngine:
                                            p(self.grads["normal_map"]), st), "normal_smooth")
 
     def _dist_on(self):
-        return self.world > 1 or getattr(self, "force_allreduce", False)
+        return self.world > 1 or self.force_allreduce
 
     def _allreduce_maps_early(self):
         """The texture + normal-map gradients (6.29 of the 6.36 MB bucket) are final once the shading backward and normalize3_bwd
         are enqueued, ~0.25 ms before the mesh / LBS backward tail ends: their all-reduce is started there (async, on RCCL's own
         stream) and overlaps with that tail; `allreduce()` then only has the small remainder [pose .. amb_ratio] left to send."""
-        if not self._dist_on() or not getattr(self, "overlap_allreduce", True) or torch.cuda.is_current_stream_capturing():
+        if not self._dist_on() or not self.overlap_allreduce or torch.cuda.is_current_stream_capturing():
             return
         import torch.distributed as dist
         if not (dist.is_available() and dist.is_initialized()):
@@ -424,7 +436,7 @@ class FitEngine:
         if self._dist_on():
             from .dist import allreduce_flat
             o, n = self.opt_span
-            work = getattr(self, "_early_work", None)
+            work = self._early_work
             if work is not None:
                 allreduce_flat(self.g_buf[o:self._early_from])      # everything before the maps (they are the tail of the bucket)
                 work.wait()                                         # current stream waits for the early collective
@@ -436,7 +448,7 @@ class FitEngine:
         L, p, st = _lib.lib(), _lib.ptr, _lib.stream()
         # parameters outside the reference's optimiser groups (known_appearance: shape / displacement / texture / normal map,
         # optimize_sequence.py:264-289) keep a zero gradient: with m = v = 0 the dense Adam update of such an element is exactly 0
-        for k in getattr(self, "frozen", ()):
+        for k in self.frozen:
             self.grads[k].zero_()
         groups = [(idx, span) for on, idx, span in ((coarse, 0, self.coarse_span), (app, 1, self.app_span)) if on]
         if len(groups) == 2:                            # the two hyper-parameter structs are adjacent: one tick launch for both
@@ -493,7 +505,7 @@ class FitEngine:
         batch runs eagerly, optimize_sequence.py:396-399).  fid=None: the next row of the schedule given to `set_schedule`."""
         scheduled = fid is None
         if scheduled:
-            if getattr(self, "schedule", None) is None:
+            if self.schedule is None:
                 raise ValueError("step(None, ...) needs set_schedule() first")
             n = self.B
         else:
@@ -511,13 +523,13 @@ class FitEngine:
             self.fid[:n].copy_(fid.to(self.dev), non_blocking=True)
             self.tfid[:n].copy_((fid - self.target_offset).to(self.dev), non_blocking=True)
         key = (coarse, app)
-        if getattr(self, "_stage", None) != key:
+        if self._stage != key:
             self.set_stage(coarse, app)
             self._stage = key
         fb0 = lambda: self.forward_backward(coarse, app, B=n)
         fb = (lambda: (self._schedule_next(), fb0())) if scheduled else fb0
         dist_on = self._dist_on()
-        if not use_graph or n != self.B or (dist_on and not getattr(self, "graph_collectives", False)):
+        if not use_graph or n != self.B or (dist_on and not self.graph_collectives):
             fb()
             self.allreduce()
             self.adam(coarse, app)
