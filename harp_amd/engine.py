@@ -158,6 +158,7 @@ class FitEngine:
         self.schedule = None
         self._stage = None
         self._early_work = None
+        self.perceptual = None           # optional VGG feature term of the appearance stage (set_perceptual)
         self.compute_reference_mesh()
 
     # ------------------------------------------------------------------------------------------------
@@ -208,6 +209,8 @@ class FitEngine:
         self.y_sil = y_sil.to(self.dev).float().contiguous()
         self.y_sil_col = y_sil_col.to(self.dev).float().contiguous()
         self.target_offset = int(frame_offset)
+        if getattr(self, "perceptual", None) is not None:                            # cached target features belong to the old targets
+            self.set_perceptual(self.perceptual, self.perceptual_weight, autocast=self._vgg_autocast)
 
     # ------------------------------------------------------------------------------------------------
     def _ck(self, rc, what):
@@ -359,6 +362,8 @@ class FitEngine:
             a.l1_target, a.l1_mask, a.l1_fid = p(self.y_true), p(self.y_sil_col), p(ltfid)
             a.l1_w, a.l1_loss, a.l1_grad = wp(6), lp(6), p(s["g_rgb"])
             self._ck(L.harp_shade_fwd(ctypes.byref(a), ST()), "shade_fwd")
+            if self.perceptual is not None:
+                self._perceptual_term(B, ltfid, lloss)
         # ---- backward
         if app:
             self._ck(L.harp_shade_bwd(ctypes.byref(a), ST()), "shade_bwd")
@@ -399,6 +404,65 @@ class FitEngine:
         self._ck(L.harp_frame_setup_bwd(ctypes.byref(self.tables), p(lfid), B, S, self.focal, int(self.self_shadow), p(s["g_pose48"]),
                                         p(s["g_betas"]), p(s["g_trans_b"]), p(s["g_cam_T"]), p(s["g_light_pos"]) if app else None,
                                         p(s["g_colors"]) if app else None, ST()), "frame_setup_bwd")
+
+    # ---- optional perceptual term (optimize_sequence.py:405, 546-547) -------------------------------
+    def set_perceptual(self, vgg, weight=1.0, cache_bytes=64 << 30, autocast=None):
+        """Add `weight * L1(vgg(y_pred * mask), vgg(y_true * mask))` to the appearance stage.  `vgg`: harp_amd.model.vgg.Vgg16Features
+        (None removes the term).  The convolutions are torch / MIOpen library calls with autograd, so steps run eagerly (no hipGraph)
+        while the term is on.  The target features do not change during a fit: when they fit `cache_bytes` for all resident frames
+        (123 floats per pixel, 126 MB per 512x512 frame — 256 frames are 32 GB of the 288 GB) they are computed once and kept in
+        HBM, which removes one of the step's two VGG forward passes.  autocast: e.g. torch.bfloat16 to run the convolutions on the
+        bf16 MFMA path (default None = fp32 like the reference)."""
+        self.perceptual = None if vgg is None else vgg.to(self.dev).eval()
+        self.perceptual_weight = float(weight)
+        self._vgg_autocast = autocast
+        self._vgg_cache = None
+        self._graphs = {}
+        if vgg is None or self.y_true is None:
+            return
+        T, S = self.y_true.shape[0], self.S
+        per_frame = 4 * (S * S * 64 + (S // 2) ** 2 * 128 + (S // 4) ** 2 * 256 + (S // 8) ** 2 * 512)
+        if T * per_frame <= cache_bytes:
+            chunks = []
+            for t0 in range(0, T, self.B):
+                idx = torch.arange(t0, min(T, t0 + self.B), device=self.dev)
+                chunks.append(self._vgg_target_features(idx, skip_input=True))
+            self._vgg_cache = [torch.cat([c[i] for c in chunks]) for i in range(4)]
+
+    def _vgg_run(self, x, skip_input=False):
+        if self._vgg_autocast is not None:
+            with torch.autocast("cuda", dtype=self._vgg_autocast):
+                f = self.perceptual.features(x, skip_input=skip_input, weighted=False)
+            return [t.float() for t in f]
+        return self.perceptual.features(x, skip_input=skip_input, weighted=False)
+
+    def _vgg_target_features(self, idx, skip_input=False):
+        with torch.no_grad():
+            m = self.y_sil_col[idx].unsqueeze(-1)
+            return self._vgg_run((self.y_true[idx] * m).permute(0, 3, 1, 2), skip_input=skip_input)
+
+    def _perceptual_term(self, B, ltfid, lloss):
+        """torch autograd through the VGG stack for d(term)/d(y_pred); the result joins the photometric gradient the shader backward
+        consumes (that buffer is only defined at covered pixels — the fused L1 writes nothing elsewhere — hence the where)."""
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("the perceptual term cannot be captured into a hipGraph; step(..., use_graph=False)")
+        s = self.s
+        idx = ltfid[:B].long()
+        m = self.y_sil_col[idx].unsqueeze(-1)
+        leaf = s["rgb"][:B].detach().requires_grad_(True)
+        with torch.enable_grad():
+            fp = self._vgg_run((leaf * m).permute(0, 3, 1, 2))
+            if self._vgg_cache is not None:
+                ft = [(self.y_true[idx] * m).permute(0, 3, 1, 2).flatten(start_dim=1)] + [c[idx] for c in self._vgg_cache]
+            else:
+                ft = self._vgg_target_features(idx)
+            n = sum(f.shape[1] for f in fp) * B
+            # == L1Loss over the concatenated weighted rows: |w a - w b| = |w| |a - b|, so the layer weights scale the partial sums
+            loss = sum(abs(w) * (a - b).abs().sum() for w, a, b in zip(self.perceptual.layers_weights, fp, ft)) / n
+            (g,) = torch.autograd.grad(loss, leaf)
+        lloss[9:10].copy_(loss.detach().reshape(1))
+        covered = (s["face_c"][:B] >= 0).unsqueeze(-1)
+        s["g_rgb"][:B] = torch.where(covered, s["g_rgb"][:B] + self.perceptual_weight * g, torch.zeros((), device=self.dev))
 
     def _side_stream(self):
         lane = self._lane
@@ -529,7 +593,7 @@ class FitEngine:
         fb0 = lambda: self.forward_backward(coarse, app, B=n)
         fb = (lambda: (self._schedule_next(), fb0())) if scheduled else fb0
         dist_on = self._dist_on()
-        if not use_graph or n != self.B or (dist_on and not self.graph_collectives):
+        if not use_graph or n != self.B or (dist_on and not self.graph_collectives) or (app and self.perceptual is not None):
             fb()
             self.allreduce()
             self.adam(coarse, app)
@@ -559,4 +623,7 @@ class FitEngine:
     def losses(self):
         """dict of the last step's unweighted loss terms (one D2H copy; call sparingly)."""
         v = self.loss_vec.cpu().tolist()
-        return {k: v[i] for i, k in enumerate(LOSS_NAMES)}
+        out = {k: v[i] for i, k in enumerate(LOSS_NAMES)}
+        if self.perceptual is not None:
+            out["vgg"] = v[9]
+        return out

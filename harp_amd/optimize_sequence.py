@@ -86,7 +86,7 @@ def stage_flags(epoch_id, training_stage):
 
 def optimize_hand_sequence(configs, input_params, images_dataset, val_params, val_images_dataset, hand_layer,
                            VERTS_UVS=None, FACES_UVS=None, VERTS_COLOR=None, device="cuda", uv_mask=None, batch_size=18, log_fn=None,
-                           seed=0):
+                           seed=0, vgg=None):
     """Fit the sequence (optimize_sequence.py:313-596).  Returns the parameter dict in the reference's checkpoint layout.
     `images_dataset[i]` -> (fid, y_true (S,S,3), y_sil (S,S,1), y_sil_eroded (S,S,1)) like utils/data_util.ImagesDataset."""
     if configs["model_type"] != "harp":
@@ -102,6 +102,13 @@ def optimize_hand_sequence(configs, input_params, images_dataset, val_params, va
                     self_shadow=configs["self_shadow"], share_light_position=configs["share_light_position"], seed=seed,
                     use_arm=use_arm, opt_arm_pose=bool(configs.get("opt_arm_pose", False)))
     eng.set_targets(*ResidentTargets(images_dataset).tensors())      # decoded once, resident in HBM (utils/data_util.py)
+    # perceptual term (:404-405, :546-547): needs the pretrained VGG16 filters, which cannot be downloaded here — pass a ready module
+    # (`vgg=`) or the path of torchvision's vgg16 state dict (configs["vgg_weights"]); without either the term is left out
+    if vgg is None and configs.get("vgg_weights"):
+        from .model.vgg import Vgg16Features
+        vgg = Vgg16Features(layers_weights=[1, 1 / 16, 1 / 8, 1 / 4, 1], weights=configs["vgg_weights"])
+    if vgg is not None:
+        eng.set_perceptual(vgg, weight=1.0)
     if configs["start_from"]:
         restore_checkpoint(eng, configs, input_params)
     if configs["known_appearance"]:
@@ -122,6 +129,8 @@ def optimize_hand_sequence(configs, input_params, images_dataset, val_params, va
             eng.step(perm[s0:s0 + batch_size], coarse, app)
             active = (eng.w_vec[:9] > 0).float()
             epoch_loss += (eng.loss_vec[:9] * weights * active).sum()              # stays on the device: no per-term .cpu() sync (:559)
+            if app and eng.perceptual is not None:
+                epoch_loss += eng.loss_vec[9] * eng.perceptual_weight
             nb += 1
         mean_loss = float(epoch_loss / nb)                                         # one sync per epoch
         if not np.isfinite(mean_loss):

@@ -317,6 +317,40 @@ def step_losses(params, fid, model, topo, targets, S, focal, ref_verts, dist_alb
 
 
 # ----------------------------------------------------------------------------------------------
+# Perceptual term  (model/vgg.py:10-56, optimize_sequence.py:405, 546-547).  torchvision and the pretrained
+# VGG16 file are absent from the build image -> PARITY UNPINNED; restated from the published VGG16 "D"
+# configuration (torchvision vgg16.features[0:23]: 3x3 conv pad 1 + ReLU, 2x2/2 max-pool at 4, 9, 16).
+# ----------------------------------------------------------------------------------------------
+VGG16_CONV_AT = (0, 2, 5, 7, 10, 12, 14, 17, 19, 21)
+VGG16_TAPS = (3, 8, 15, 22)                 # relu1_2, relu2_2, relu3_3, relu4_3 = last layer of slice1..4
+
+
+def vgg16_features(filters, x, layers_weights):
+    """filters: {layer index: (weight (O,I,3,3), bias (O,))}; x (N,3,H,W) -> (N, L) concatenation of the weighted flattened
+    input and tap activations (model/vgg.py:38-56)."""
+    rows = [layers_weights[0] * x.flatten(start_dim=1)]
+    h, tap = x, 1
+    for ix in range(23):
+        if ix in VGG16_CONV_AT:
+            h = F.conv2d(h, filters[ix][0], filters[ix][1], padding=1)
+        elif ix in (4, 9, 16):
+            h = F.max_pool2d(h, 2, 2)
+        else:
+            h = F.relu(h)
+        if ix in VGG16_TAPS:
+            rows.append(layers_weights[tap] * h.flatten(start_dim=1))
+            tap += 1
+    return torch.cat(rows, 1)
+
+
+def perceptual_loss(filters, layers_weights, y_pred, y_true, y_sil_col):
+    """optimize_sequence.py:546-547 (weight 1.0, :419)."""
+    m = y_sil_col.unsqueeze(-1)
+    return F.l1_loss(vgg16_features(filters, (y_pred * m).permute(0, 3, 1, 2), layers_weights),
+                     vgg16_features(filters, (y_true * m).permute(0, 3, 1, 2), layers_weights))
+
+
+# ----------------------------------------------------------------------------------------------
 # SMPL-X right-arm layer  (hand_models_harp/body_models.py:2163-2390; smplx.lbs is un-vendored -> PARITY UNPINNED,
 # restated from the published smplx/lbs.py algorithm, SURVEY.md Appendix A.13)
 # ----------------------------------------------------------------------------------------------

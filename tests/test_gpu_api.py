@@ -187,3 +187,33 @@ def test_smooth_losses_through_hip_layer(golden_dir):
         assert rel(P[k].grad.cpu(), torch.from_numpy(d["g_" + k])) < 5e-4, k
     # the root alignment cancels the translation exactly: d/d(trans) is pure rounding noise (~1e-3 against pose gradients of ~1e3)
     assert (P["trans"].grad.cpu() - torch.from_numpy(d["g_trans"])).abs().max() < 0.05
+
+
+def test_fit_with_perceptual_term(tmp_path):
+    """the entry point with the VGG term on (random filters from a torchvision-layout file named in the config): the appearance stages run
+    eagerly, the reported epoch loss includes the term, the fit stays finite"""
+    from harp_amd.manopth.manolayer import ManoLayer
+    from harp_amd.model.vgg import Vgg16Features
+    from harp_amd.optimize_sequence import optimize_hand_sequence
+    from harp_amd.utils.config_utils import get_config
+    sc = make_scene(T=4, S=96, seed=4)
+    S = sc["S"]
+    src = Vgg16Features(weights="random", seed=7)
+    path = str(tmp_path / "vgg16.pth")
+    torch.save({f"features.{k.split('.')[1]}.{k.split('.')[2]}": v for k, v in src.state_dict().items()}, path)
+    layer = ManoLayer(flat_hand_mean=False, use_pca=False, model=sc["model_np"], device=DEV)
+    tg = sc["targets"]
+    ds = [(i, tg["y_true"][i], tg["y_sil"][i][..., None], tg["y_sil_col"][i][..., None]) for i in range(4)]
+    hist = {}
+    for use_vgg in (False, True):
+        cfg = get_config(write_yaml=True, use_arm=False, img_size=S, focal_length=sc["focal"], total_epoch=3, training_stage=[0, 0, 3],
+                         base_output_dir=str(tmp_path) + "/")
+        if use_vgg:
+            cfg["vgg_weights"] = path
+        seen = []
+        optimize_hand_sequence(cfg, sc["seq"], ds, None, None, layer, torch.from_numpy(sc["tpl"]["verts_uvs"])[None],
+                               torch.from_numpy(sc["tpl"]["faces_uvs"])[None], device=DEV, uv_mask=sc["uv_mask"], batch_size=2,
+                               log_fn=lambda e, l, eng: seen.append((l, eng.losses().get("vgg"))))
+        hist[use_vgg] = seen
+    assert all(v is None for _, v in hist[False]) and all(v is not None and v > 0 for _, v in hist[True])
+    assert all(np.isfinite(l) for l, _ in hist[True])

@@ -419,3 +419,52 @@ def test_rccl_path_on_one_rank(sc):
     d = (a.params["texture"] - b.params["texture"]).abs()
     assert d.mean().item() < 2e-5 and (d > 1e-3).float().mean().item() < 1e-3
     dist.destroy_process_group()
+
+
+def test_perceptual_term_gradients(sc):
+    """the optional VGG term: engine (HIP shader backward fed by torch/MIOpen VGG autograd) against the oracle's
+    renderer + functional VGG16 on the CPU, same seeded random filters; all other weights zero so only this term's gradient is seen"""
+    from harp_amd.engine import FitEngine
+    from harp_amd.model.vgg import Vgg16Features
+    from oracle import harp_ref as H
+    T, S, B = sc["T"], sc["S"], 2
+    LW = [1, 1 / 16, 1 / 8, 1 / 4, 1]
+    eng = FitEngine(sc["model_np"], sc["topo_np"], sc["tpl"]["verts_uvs"], sc["tpl"]["faces_uvs"], sc["uv_mask"].float(), sc["seq"], S,
+                    sc["focal"], B, device=DEV)
+    tg = sc["targets"]
+    eng.set_targets(tg["y_true"], tg["y_sil"], tg["y_sil_col"])
+    g = torch.Generator().manual_seed(5)
+    with torch.no_grad():
+        eng.params["texture"].copy_(torch.rand(1, 512, 512, 3, generator=g) * 0.5 + 0.3)
+        eng.params["trans"].copy_(torch.randn(T, 3, generator=g) * 0.01)
+    eng.compute_reference_mesh()
+    vgg = Vgg16Features(layers_weights=LW, weights="random", seed=2)
+    sd = {k: v.clone() for k, v in vgg.state_dict().items()}
+    filters = {int(k.split(".")[1]): (sd[k], sd[k.replace("weight", "bias")]) for k in sd if k.endswith("weight")}
+    P = oracle_params(sc, eng.params)
+    fid = torch.tensor([1, 2])
+    aux = {}
+    verts = H.prepare_mesh(P, fid, sc["model"], sc["topo"])[1]
+    y_pred = H.render_rgb(verts, sc["topo"], P, P["cam"][fid], S, sc["focal"], self_shadow=True)
+    ref = H.perceptual_loss(filters, LW, y_pred, tg["y_true"][fid], tg["y_sil_col"][fid])
+    ref.backward()
+    for cached in (True, False):
+        eng.set_perceptual(vgg, weight=1.0, cache_bytes=(64 << 30) if cached else 0)
+        assert (eng._vgg_cache is not None) == cached
+        eng.fid.copy_(fid.int().to(DEV)); eng.tfid.copy_(fid.int().to(DEV))
+        eng.set_stage(False, True)
+        eng.w_vec.zero_()
+        eng.forward_backward(False, True)
+        torch.cuda.synchronize()
+        lv = eng.losses()
+        assert abs(lv["vgg"] - ref.item()) <= 2e-5 * abs(ref.item()), (lv["vgg"], ref.item())
+        # L1 of feature differences: where a feature difference is at fp32-noise level its sign (= its whole gradient contribution)
+        # depends on the convolution's summation order (MIOpen vs the CPU), hence a looser bound than for the other terms
+        for k in ("texture", "normal_map", "light_positions", "amb_ratio", "pose", "cam", "shape"):
+            assert rel(eng.grads[k].cpu(), P[k].grad) < 2e-2, (cached, k, rel(eng.grads[k].cpu(), P[k].grad))
+    # a full step with the term on runs eagerly and moves the appearance parameters
+    before = eng.params["texture"].clone()
+    eng.step(fid, False, True)
+    torch.cuda.synchronize()
+    assert not eng._graphs and (eng.params["texture"] - before).abs().max() > 0
+    assert torch.isfinite(eng.p_buf).all()

@@ -1,0 +1,70 @@
+"""CPU: the VGG16 feature module of the perceptual term (harp_amd/model/vgg.py) against the oracle's functional restatement with
+the same filters; state-dict layouts; loud failure without weights.  (Pretrained filters do not exist here: parity unpinned.)"""
+import pytest
+import torch
+
+from harp_amd.model.vgg import Vgg16Features, feature_length
+
+LW = [1, 1 / 16, 1 / 8, 1 / 4, 1]          # optimize_sequence.py:405
+
+
+def _filters(vgg):
+    sd = vgg.state_dict()
+    return {int(k.split(".")[1]): (sd[k], sd[k.replace("weight", "bias")]) for k in sd if k.endswith("weight")}
+
+
+def test_layout_matches_vgg16_features():
+    vgg = Vgg16Features(layers_weights=LW, weights="random")
+    shapes = {k: tuple(v.shape) for k, v in vgg.state_dict().items() if k.endswith("weight")}
+    assert shapes == {"slice1.0.weight": (64, 3, 3, 3), "slice1.2.weight": (64, 64, 3, 3), "slice2.5.weight": (128, 64, 3, 3),
+                      "slice2.7.weight": (128, 128, 3, 3), "slice3.10.weight": (256, 128, 3, 3), "slice3.12.weight": (256, 256, 3, 3),
+                      "slice3.14.weight": (256, 256, 3, 3), "slice4.17.weight": (512, 256, 3, 3), "slice4.19.weight": (512, 512, 3, 3),
+                      "slice4.21.weight": (512, 512, 3, 3)}
+    assert not any(p.requires_grad for p in vgg.parameters())
+    assert Vgg16Features(weights="random").layers_weights == [1 / 32, 1 / 16, 1 / 8, 1 / 4, 1]       # model/vgg.py:16-17
+
+
+def test_forward_against_oracle_and_l1_of_parts():
+    from oracle import harp_ref as H
+    vgg = Vgg16Features(layers_weights=LW, weights="random", seed=3)
+    torch.manual_seed(0)
+    x, y = torch.rand(2, 3, 32, 40), torch.rand(2, 3, 32, 40)
+    out = vgg(x)
+    assert out.shape == (2, feature_length(32, 40))
+    ref = H.vgg16_features(_filters(vgg), x, LW)
+    assert torch.allclose(out, ref, rtol=1e-5, atol=1e-6)
+    # the engine sums |a-b| slice by slice instead of concatenating: same number
+    fa, fb = vgg.features(x), vgg.features(y)
+    parts = sum((a - b).abs().sum() for a, b in zip(fa, fb)) / (2 * out.shape[1])
+    assert abs(parts.item() - torch.nn.functional.l1_loss(vgg(x), vgg(y)).item()) < 1e-6
+    # gradient w.r.t. the image flows although the filters are frozen
+    xg = x.clone().requires_grad_(True)
+    torch.nn.functional.l1_loss(vgg(xg), vgg(y)).backward()
+    assert xg.grad.abs().sum() > 0
+
+
+def test_state_dict_layouts(tmp_path):
+    src = Vgg16Features(layers_weights=LW, weights="random", seed=1)
+    x = torch.rand(1, 3, 16, 16)
+    # torchvision's layout ("features.N.*", plus entries this module does not use) from a file
+    tv = {f"features.{k.split('.')[1]}.{k.split('.')[2]}": v for k, v in src.state_dict().items()}
+    tv["features.24.weight"] = torch.zeros(512, 512, 3, 3)
+    tv["classifier.0.weight"] = torch.zeros(4, 4)
+    path = tmp_path / "vgg16.pth"
+    torch.save(tv, path)
+    assert torch.equal(Vgg16Features(layers_weights=LW, weights=str(path))(x), src(x))
+    # the reference module's own layout
+    assert torch.equal(Vgg16Features(layers_weights=LW, weights=src.state_dict())(x), src(x))
+    del tv["features.21.bias"]
+    with pytest.raises(KeyError):
+        Vgg16Features(weights=tv)
+
+
+def test_no_silent_random_fallback():
+    try:
+        import torchvision  # noqa: F401
+        pytest.skip("torchvision present: weights=None takes the pretrained filters")
+    except ImportError:
+        pass
+    with pytest.raises(RuntimeError):
+        Vgg16Features()
