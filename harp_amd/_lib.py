@@ -95,6 +95,7 @@ SIGNATURES.update({
     "harp_kps_loss": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
     "harp_mesh_regularizers": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "harp_sum_squares": (_i, [_vp, _i, _vp, _vp, _vp, _vp]),
+    "harp_mse": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
     "harp_texture_smooth_reg": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
     "harp_close_to_z_reg": (_i, [_vp, _i, _i, _f, _vp, _vp, _vp, _vp]),
     "harp_normalize3_fwd": (_i, [_vp, _i, _vp, _vp]),

@@ -196,6 +196,22 @@ __global__ void __launch_bounds__(256) sumsq_kernel(const float* __restrict__ d,
   if (threadIdx.x == 0) atomicAdd(loss, s);
 }
 
+// torch.nn.MSELoss()(x, y) and its gradient w.r.t. x (metro_modifications/hand_utils.py:71-87): the per-iteration objective of the
+// MANO-to-METRO fit.  g is overwritten (not accumulated): it is the only term of that loop.
+__global__ void __launch_bounds__(256) mse_kernel(const float* __restrict__ x, const float* __restrict__ y, int n, float* __restrict__ loss,
+                                                  float* __restrict__ g) {
+  __shared__ float red[4];
+  const float inv_n = 1.0f / (float)n;
+  float acc = 0.f;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const float d = x[i] - y[i];
+    acc += d * d;
+    if (g) g[i] = 2.0f * d * inv_n;
+  }
+  const float s = block_sum_256(acc, red);
+  if (threadIdx.x == 0) atomicAdd(loss, s * inv_n);
+}
+
 // albedo_reg / smooth_texture_reg (loss/texture_reg.py:5-30, 48-66): mean_xy( ||t[x,y]-t[x+dx,y+dy]||_1 / 3 * mask )
 __global__ void __launch_bounds__(256) tex_smooth_kernel(const float* __restrict__ t, const int32_t* __restrict__ dist,
                                                          const float* __restrict__ mask, int H, int W, const float* __restrict__ w,
@@ -393,6 +409,13 @@ int harp_mesh_regularizers(const float* verts, const float* ref_verts, const int
 int harp_sum_squares(const float* x, int n, const float* w, float* loss, float* g, hipStream_t stream) {
   if (!x || !loss) return HARP_ERR_ARG;
   hipLaunchKernelGGL(sumsq_kernel, dim3(min((n + 255) / 256, 64)), dim3(256), 0, stream, x, n, w, loss, g);
+  HARP_CHECK_LAUNCH();
+  return HARP_OK;
+}
+
+int harp_mse(const float* x, const float* y, int n, float* loss, float* g_x, hipStream_t stream) {
+  if (!x || !y || !loss || n <= 0) return HARP_ERR_ARG;
+  hipLaunchKernelGGL(mse_kernel, dim3(min((n + 255) / 256, 1024)), dim3(256), 0, stream, x, y, n, loss, g_x);
   HARP_CHECK_LAUNCH();
   return HARP_OK;
 }

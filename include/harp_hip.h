@@ -249,6 +249,9 @@ int harp_mesh_regularizers(const float* verts, const float* ref_verts, const int
                            const float* w, float* loss, float* g_verts, hipStream_t stream);
 /* torch.sum(verts_disps ** 2) (optimize_sequence.py:533) */
 int harp_sum_squares(const float* x, int n, const float* w, float* loss, float* g, hipStream_t stream);
+/* torch.nn.MSELoss()(x, y) over n elements, ACCUMULATED into *loss (zero it first), and d/dx written to g_x (may be NULL): the
+ * objective of the MANO-to-METRO vertex fit (metro_modifications/hand_utils.py:71, 80, 100) */
+int harp_mse(const float* x, const float* y, int n, float* loss, float* g_x, hipStream_t stream);
 /* albedo_reg / smooth_texture_reg (loss/texture_reg.py:5-30, 48-66) with the drawn integer offsets dist (H,W,2) */
 int harp_texture_smooth_reg(const float* tex, const int32_t* dist, const float* mask, int H, int W, const float* w, float* loss,
                             float* g_tex, hipStream_t stream);
