@@ -212,6 +212,12 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 bench.py --gpus N")
+    # development aid: HARP_ALL_ON_GPU0=1 + HARP_DIST_BACKEND=gloo runs an N-process job on a ONE-GPU box (every rank on cuda:0, the
+    # collectives through gloo) to exercise the N > 1 control flow end to end; its timing means nothing and is marked as such
+    shared_gpu = os.environ.get("HARP_ALL_ON_GPU0") == "1"
+    backend = os.environ.get("HARP_DIST_BACKEND", "nccl")
+    if shared_gpu:
+        local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     force_dist = os.environ.get("HARP_FORCE_DIST") == "1"      # exercise the RCCL code path (init, barrier, all-reduce, eager steps) on 1 GPU
@@ -220,7 +226,7 @@ def main():
         if force_dist and "MASTER_ADDR" not in os.environ:
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
         with _StdoutToStderr():
-            dist.init_process_group("nccl", device_id=device)
+            dist.init_process_group(backend, **({"device_id": device} if backend == "nccl" else {}))
             dist.barrier()                               # communicator creation happens at the first collective
             torch.cuda.synchronize()
     eng, focal = build_engine(rank, world, device)
@@ -251,6 +257,14 @@ def main():
         dt = float(tmax.item())
     losses = eng.losses()
     finite = all(np.isfinite(v) for v in losses.values())
+    consistent = None
+    if world > 1 or force_dist:
+        # data-parallel invariant (outside the timed region): every rank holds the same parameters after the same all-reduced updates
+        cs = eng.p_buf[:eng.opt_span[0] + eng.opt_span[1]].double().abs().sum().reshape(1)
+        hi, lo = cs.clone(), cs.clone()
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        consistent = bool((hi == lo).item())
     frames = world * eng.B * args.steps
     out = {"metric": "render+loss+backward+Adam frames/sec, 512x512 MANO hand mesh", "value": frames / dt, "unit": "frames/s",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -262,6 +276,10 @@ def main():
                                      f"part overlapped with the mesh backward, the remainder before Adam)",
                       "hipgraph": (not args.no_graph) and world == 1},
            "losses_finite": finite}
+    if consistent is not None:
+        out["ranks_consistent"] = consistent
+    if shared_gpu or backend != "nccl":
+        out["invalid_timing"] = f"development run: backend={backend}, all ranks on one GPU={shared_gpu}"
     if rank == 0 and world == 1:
         a_frame, a_step, parts = algorithmic_bytes(eng)
         kt = kernel_roofline(eng, 4)
