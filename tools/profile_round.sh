@@ -1,0 +1,18 @@
+#!/bin/bash
+# Regenerates the committed evidence set for one round tag (run on the GPU box, e.g. through gpurun):
+#   tools/profile_round.sh r01_k     ->  gpurun_out/<tag>_{bench.json,bench_under_rocprof.json,kernel_stats_default_bench_graph.txt,timeline_one_step.txt}
+# (copy them into profiles/ afterwards).  PMC passes (FETCH_SIZE / WRITE_SIZE -> traffic_latest.json) are separate runs, see
+# tools/make_traffic_json.py; they must not be combined with trace domains other than --kernel-trace.
+set -u
+tag=${1:-rXX}
+out=gpurun_out
+mkdir -p $out
+export TMPDIR=/tmp
+python bench.py > $out/${tag}_bench.json 2> $out/${tag}_bench.err
+timeout 900 rocprofv3 --kernel-trace --stats -d $out/prof_$tag -o run -- python bench.py --steps 40 --warmup 8 --no-cpu-baseline \
+    > $out/${tag}_bench_under_rocprof.json 2> $out/${tag}_prof.err
+db=$(find $out/prof_$tag -name "*.db" | head -1)
+python tools/rocpd_stats.py $db > $out/${tag}_kernel_stats_default_bench_graph.txt
+python tools/rocpd_timeline.py $db > $out/${tag}_timeline_one_step.txt
+rm -rf $out/prof_$tag
+tail -c 600 $out/${tag}_bench.json
