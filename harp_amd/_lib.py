@@ -124,6 +124,7 @@ SIGNATURES.update({
 SIGNATURES.update({
     "harp_adam_tick": (_i, [_vp, _i, _vp]),
     "harp_adam_apply": (_i, [_vp, _vp, _vp, _vp, _sz, _vp, _vp]),
+    "harp_adam_apply2": (_i, [_vp, _vp, _vp, _vp, _sz, _sz, _sz, _sz, _vp, _vp]),
 })
 
 

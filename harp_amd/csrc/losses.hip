@@ -345,6 +345,23 @@ __global__ void adam_dev_kernel(float* __restrict__ p, const float* __restrict__
   }
 }
 
+// two parameter groups (their own hyper-parameter structs, adjacent in memory) in ONE launch: elements [0, n0) of the grid map to
+// [o0, o0 + n0), the rest to [o1, o1 + n1) of the same four arenas
+__global__ void adam_dev2_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                 size_t o0, size_t n0, size_t o1, size_t n1, const harp_adam_hyper* __restrict__ hs) {
+  for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < n0 + n1; k += (size_t)gridDim.x * blockDim.x) {
+    const bool first = k < n0;
+    const harp_adam_hyper* h = hs + (first ? 0 : 1);
+    const size_t i = first ? o0 + k : o1 + (k - n0);
+    const float beta1 = h->beta1, beta2 = h->beta2;
+    const float gi = g[i] * h->grad_scale;
+    const float mi = m[i] + (gi - m[i]) * (1.0f - beta1);
+    const float vi = v[i] * beta2 + (1.0f - beta2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    p[i] -= h->step_size * (mi / (sqrtf(vi) * h->inv_sqrt_bc2 + h->eps));
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -369,6 +386,15 @@ int harp_adam_apply(float* p, const float* g, float* m, float* v, size_t n, cons
   if (!p || !g || !m || !v || !h) return HARP_ERR_ARG;
   const int blocks = (int)min((size_t)2048, (n + 255) / 256);
   hipLaunchKernelGGL(adam_dev_kernel, dim3(blocks), dim3(256), 0, stream, p, g, m, v, n, h);
+  HARP_CHECK_LAUNCH();
+  return HARP_OK;
+}
+
+int harp_adam_apply2(float* p, const float* g, float* m, float* v, size_t o0, size_t n0, size_t o1, size_t n1, const harp_adam_hyper* h2,
+                     hipStream_t stream) {
+  if (!p || !g || !m || !v || !h2 || n0 + n1 == 0) return HARP_ERR_ARG;
+  const int blocks = (int)min((size_t)2048, (n0 + n1 + 255) / 256);
+  hipLaunchKernelGGL(adam_dev2_kernel, dim3(blocks), dim3(256), 0, stream, p, g, m, v, o0, n0, o1, n1, h2);
   HARP_CHECK_LAUNCH();
   return HARP_OK;
 }

@@ -280,7 +280,7 @@ class FitEngine:
             setattr(a, k, _lib.ptr(t))
         return a
 
-    def forward_backward(self, coarse=True, app=True, B=None, shared_terms=True):
+    def forward_backward(self, coarse=True, app=True, B=None, shared_terms=True, tick=False):
         """Enqueue forward + losses + backward for the first B (default: the lane's size) frames of the active lane; gradients land
         in self.g_buf, loss terms in loss_vec[:9] (unweighted, order LOSS_NAMES).  shared_terms=False skips everything that does not
         depend on the frames (gradient-arena zeroing, offset draw, normal-map normalisation, displacement / texture regularisers)."""
@@ -306,6 +306,8 @@ class FitEngine:
         # ---- terms that depend on the parameters only (normal-map normalisation, texture regularisers, displacement regulariser) go
         #      first on the second stream: they run under the LBS / mesh chain, which is a string of small latency-bound launches
         def param_terms():
+            if tick:
+                self._adam_tick(coarse, app)             # only touches the hyper-parameter block: off the serial tail of the step
             if app and shared_terms:
                 if self.auto_draw:
                     self.draw_texture_offsets()
@@ -523,21 +525,30 @@ class FitEngine:
             else:
                 allreduce_flat(self.g_buf[o:o + n])       # one flat bucket (sum); 1/world is applied in the Adam kernel
 
-    def adam(self, coarse=True, app=True):
+    def _adam_tick(self, coarse, app):
+        """advance step / bias corrections of the stage's optimiser(s) — any time before `adam(..., tick=False)` of the same step"""
+        L, st = _lib.lib(), _lib.stream()
+        if coarse and app:                               # the two hyper-parameter structs are adjacent: one launch for both
+            self._ck(L.harp_adam_tick(self.hyper.data_ptr(), 2, st), "adam_tick")
+        elif coarse or app:
+            self._ck(L.harp_adam_tick(self.hyper.data_ptr() + (0 if coarse else 1) * self._hyper_stride, 1, st), "adam_tick")
+
+    def adam(self, coarse=True, app=True, tick=True):
         L, p, st = _lib.lib(), _lib.ptr, _lib.stream()
         # parameters outside the reference's optimiser groups (known_appearance: shape / displacement / texture / normal map,
         # optimize_sequence.py:264-289) keep a zero gradient: with m = v = 0 the dense Adam update of such an element is exactly 0
         for k in self.frozen:
             self.grads[k].zero_()
-        groups = [(idx, span) for on, idx, span in ((coarse, 0, self.coarse_span), (app, 1, self.app_span)) if on]
-        if len(groups) == 2:                            # the two hyper-parameter structs are adjacent: one tick launch for both
-            self._ck(L.harp_adam_tick(self.hyper.data_ptr(), 2, st), "adam_tick")
-        for idx, (o, n) in groups:
-            h = self.hyper.data_ptr() + idx * self._hyper_stride
-            if len(groups) == 1:
-                self._ck(L.harp_adam_tick(h, 1, st), "adam_tick")
-            self._ck(L.harp_adam_apply(self.p_buf.data_ptr() + 4 * o, self.g_buf.data_ptr() + 4 * o, self.m_buf.data_ptr() + 4 * o,
-                                       self.v_buf.data_ptr() + 4 * o, n, h, st), "adam_apply")
+        if tick:
+            self._adam_tick(coarse, app)
+        bufs = (self.p_buf.data_ptr(), self.g_buf.data_ptr(), self.m_buf.data_ptr(), self.v_buf.data_ptr())
+        if coarse and app:                               # both groups in one launch
+            (o0, n0), (o1, n1) = self.coarse_span, self.app_span
+            self._ck(L.harp_adam_apply2(*bufs, o0, n0, o1, n1, self.hyper.data_ptr(), st), "adam_apply2")
+        elif coarse or app:
+            o, n = self.coarse_span if coarse else self.app_span
+            h = self.hyper.data_ptr() + (0 if coarse else 1) * self._hyper_stride
+            self._ck(L.harp_adam_apply(*(b + 4 * o for b in bufs), n, h, st), "adam_apply")
 
     # ------------------------------------------------------------------------------------------------
     def set_stage(self, coarse, app):
@@ -605,13 +616,13 @@ class FitEngine:
         if self._stage != key:
             self.set_stage(coarse, app)
             self._stage = key
-        fb0 = lambda: self.forward_backward(coarse, app, B=n)
+        fb0 = lambda: self.forward_backward(coarse, app, B=n, tick=True)
         fb = (lambda: (self._schedule_next(), fb0())) if scheduled else fb0
         dist_on = self._dist_on()
         if not use_graph or n != self.B or (dist_on and not self.graph_collectives) or (app and self.perceptual is not None):
             fb()
             self.allreduce()
-            self.adam(coarse, app)
+            self.adam(coarse, app, tick=False)
             return
         gkey = (coarse, app, scheduled)
         g = self._graphs.get(gkey)
@@ -620,17 +631,19 @@ class FitEngine:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             row = self.schedule_row.clone() if scheduled else None
+            hyper = self.hyper.clone()
             with torch.cuda.stream(side):
                 fb()
             torch.cuda.current_stream().wait_stream(side)
+            self.hyper.copy_(hyper)                      # the warm-up pass must not advance the optimiser's step count ...
             if scheduled:
-                self.schedule_row.copy_(row)             # the warm-up pass must not consume a schedule row
+                self.schedule_row.copy_(row)             # ... nor consume a schedule row
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 fb()
                 self.allreduce()                         # no-op for a single rank; RCCL all-reduce is captured into the graph otherwise
-                self.adam(coarse, app)
+                self.adam(coarse, app, tick=False)
             self._graphs[gkey] = g
             # the capture itself does not execute; fall through to the first replay
         g.replay()

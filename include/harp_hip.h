@@ -278,6 +278,10 @@ typedef struct harp_adam_hyper {
 } harp_adam_hyper;
 int harp_adam_tick(harp_adam_hyper* h_dev, int count, hipStream_t stream);   /* `count` consecutive structs (one per param group) */
 int harp_adam_apply(float* p, const float* g, float* m, float* v, size_t n, const harp_adam_hyper* h_dev, hipStream_t stream);
+/* both optimisers of a stage (opt_coarse + opt_app, optimize_sequence.py:567-573) in one launch: elements [o0, o0+n0) of the four
+ * arenas step with h2_dev[0], elements [o1, o1+n1) with h2_dev[1] */
+int harp_adam_apply2(float* p, const float* g, float* m, float* v, size_t o0, size_t n0, size_t o1, size_t n1,
+                     const harp_adam_hyper* h2_dev, hipStream_t stream);
 
 /* ---- per-frame glue of the fitting loop ---------------------------------------------------------------------------
  * replaces the row gathers params[k][fid] of utils/visualize.py:26-27,38-39 / optimize_sequence.py:464, the camera
