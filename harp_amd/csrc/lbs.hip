@@ -332,32 +332,31 @@ __global__ void lbs_joints_out_kernel(const float* __restrict__ j16, const float
                          : verts[((size_t)b * NV + c_tips[src - NJ]) * 3 + c];
 }
 
-// split g_joints (B,21,3) into g_j16 (B,16,3) [metres] and adds the tip part into g_verts (B,778,3)
-// ... and clears the two reduction buffers of the later stages (g_A | g_pm adjacent in the workspace, g_betas): one launch less
-__global__ void lbs_joints_bwd_kernel(const float* __restrict__ g_joints, int B, float* __restrict__ g_j16, float* __restrict__ g_verts,
-                                      float* __restrict__ za, int na, float* __restrict__ zb, int nb) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  for (int k = i; k < na; k += gridDim.x * blockDim.x) za[k] = 0.f;
-  for (int k = i; k < nb; k += gridDim.x * blockDim.x) zb[k] = 0.f;
-  if (i >= B * 21 * 3) return;
-  const int b = i / 63, k = (i % 63) / 3, c = i % 3, src = c_reorder[k];
-  if (src < NJ) g_j16[(b * NJ + src) * 3 + c] = g_joints[i] * 1000.0f;
-  else g_verts[((size_t)b * NV + c_tips[src - NJ]) * 3 + c] += g_joints[i];
-}
-
-// g_trans[b] = 1000 * (sum_v g_verts + sum_{chain joints} g_joints)
-__global__ void __launch_bounds__(256) lbs_gtrans_kernel(const float* __restrict__ g_verts, const float* __restrict__ g_j16,
-                                                         float* __restrict__ g_trans) {
+// One workgroup per frame: splits g_joints (21,3) into g_j16 (16,3) [metres] and adds the finger-tip part into g_verts (778,3);
+// then g_trans[b] = 1000 * (sum_v g_verts + sum_{chain joints} g_joints).  All workgroups together also clear the two reduction
+// buffers of the later stages (g_A | g_pm adjacent in the workspace, g_betas).
+__global__ void __launch_bounds__(256) lbs_joints_bwd_kernel(const float* __restrict__ g_joints, int B, float* __restrict__ g_j16,
+                                                             float* __restrict__ g_verts, float* __restrict__ g_trans,
+                                                             float* __restrict__ za, int na, float* __restrict__ zb, int nb) {
   __shared__ float red[4];
-  const int b = blockIdx.x;
+  const int b = blockIdx.x, t = threadIdx.x, i = b * 256 + t;
+  for (int k = i; k < na; k += gridDim.x * 256) za[k] = 0.f;
+  for (int k = i; k < nb; k += gridDim.x * 256) zb[k] = 0.f;
+  if (t < 63) {
+    const int k = t / 3, c = t % 3, src = c_reorder[k];
+    const float gj = g_joints[b * 63 + t];
+    if (src < NJ) g_j16[(b * NJ + src) * 3 + c] = gj * 1000.0f;
+    else g_verts[((size_t)b * NV + c_tips[src - NJ]) * 3 + c] += gj;
+  }
+  __syncthreads();                                     // the tip gradients and g_j16 of this frame are read back below
   float a[3] = {0.f, 0.f, 0.f};
-  for (int v = threadIdx.x; v < NV; v += 256)
+  for (int v = t; v < NV; v += 256)
     for (int c = 0; c < 3; ++c) a[c] += g_verts[((size_t)b * NV + v) * 3 + c] * 1000.0f;
-  for (int j = threadIdx.x; j < NJ; j += 256)
+  for (int j = t; j < NJ; j += 256)
     for (int c = 0; c < 3; ++c) a[c] += g_j16[(b * NJ + j) * 3 + c];
   for (int c = 0; c < 3; ++c) {
-    const float s = block_sum_256(a[c], red);
-    if (threadIdx.x == 0) g_trans[3 * b + c] = s;
+    const float sum = block_sum_256(a[c], red);
+    if (t == 0) g_trans[3 * b + c] = sum;
   }
 }
 
@@ -396,9 +395,8 @@ int harp_lbs_mano_bwd(const harp_mano_model* m, const float* pose, const float* 
                       float* g_verts, const float* g_joints, float* g_pose, float* g_betas, float* g_trans, hipStream_t stream) {
   if (!m || !pose || !betas || !ws || !g_verts || !g_joints || !g_pose || !g_betas || !g_trans) return HARP_ERR_ARG;
   const LbsWs w = lbs_ws(ws, B);
-  hipLaunchKernelGGL(lbs_joints_bwd_kernel, dim3((B * 63 + 255) / 256), dim3(256), 0, stream, g_joints, B, w.g_j16, g_verts, w.g_A,
-                     B * (192 + 135), g_betas, B * NB);
-  hipLaunchKernelGGL(lbs_gtrans_kernel, dim3(B), dim3(256), 0, stream, g_verts, w.g_j16, g_trans);
+  hipLaunchKernelGGL(lbs_joints_bwd_kernel, dim3(B), dim3(256), 0, stream, g_joints, B, w.g_j16, g_verts, g_trans, w.g_A, B * (192 + 135),
+                     g_betas, B * NB);
   hipLaunchKernelGGL(lbs_skin_kernel<true>, dim3((NV + kSkinVerts - 1) / kSkinVerts, (B + FRAMES_PER_BLOCK - 1) / FRAMES_PER_BLOCK), dim3(256), 0, stream,
                      *m, betas, trans, w.pm, w.A, B, nullptr, g_verts, w.g_vp, w.Mo);
   hipLaunchKernelGGL(lbs_gA_gpm_kernel, dim3(B, kChunksA + kChunksP), dim3(192), 0, stream, *m, m->weights, w.Mo, w.g_A, w.g_vp, w.g_pm, g_betas);
