@@ -186,6 +186,7 @@ __global__ void __launch_bounds__(256) raster_kernel(const FaceRec* __restrict__
                                                      float* __restrict__ l1_loss, float* __restrict__ l1_grad, float l1_inv) {
   __shared__ float4 s_a[kStage], s_b[kStage], s_bb[kStage];
   __shared__ float s_z2[kStage];
+  __shared__ float4 s_fc[MODE == 1 ? kStage : 1];      // per staged face: sign of the area, squared edge lengths l12, l20, l01
   __shared__ int32_t s_id[kStage];
   __shared__ int lds_cnt[4];
   // MODE 2: per-staged-face gradient accumulators (x,y of 3 verts).  double: ds_add_f64 is ~20x faster than ds_add_f32 on gfx950
@@ -312,6 +313,15 @@ __global__ void __launch_bounds__(256) raster_kernel(const FaceRec* __restrict__
     if (pos >= 0) {
       const FaceRec r = rb[id];
       s_a[pos] = r.a; s_b[pos] = r.b; s_z2[pos] = r.c.x; s_bb[pos] = bb; s_id[pos] = id;
+      if (MODE == 1) {
+        // constants of the face that every (face, strip) classification below used to recompute on all 64 lanes
+        const Tri t = tri_from(r.a, r.b, make_float4(0.f, 0.f, 0.f, 0.f));
+        const float area = edge_fn(t.x2, t.y2, t.x0, t.y0, t.x1, t.y1) + kEps;
+        s_fc[pos] = make_float4((area > 0.f) ? 1.f : ((area < 0.f) ? -1.f : 0.f),
+                                (t.x2 - t.x1) * (t.x2 - t.x1) + (t.y2 - t.y1) * (t.y2 - t.y1),
+                                (t.x0 - t.x2) * (t.x0 - t.x2) + (t.y0 - t.y2) * (t.y0 - t.y2),
+                                (t.x1 - t.x0) * (t.x1 - t.x0) + (t.y1 - t.y0) * (t.y1 - t.y0));
+      }
     }
     if (MODE == 2) {
 #pragma unroll
@@ -361,17 +371,25 @@ __global__ void __launch_bounds__(256) raster_kernel(const FaceRec* __restrict__
         const float e0 = edge_fn(px, py, t.x1, t.y1, t.x2, t.y2);
         const float e1 = edge_fn(px, py, t.x2, t.y2, t.x0, t.y0);
         const float e2 = edge_fn(px, py, t.x0, t.y0, t.x1, t.y1);
-        const float area = edge_fn(t.x2, t.y2, t.x0, t.y0, t.x1, t.y1) + kEps;
-        const float sg = (area > 0.f) ? 1.f : ((area < 0.f) ? -1.f : 0.f);
+        float sg, l12 = 0.f, l20 = 0.f, l01 = 0.f;
+        if (MODE == 1) {
+          const float4 fc = s_fc[j];
+          sg = fc.x; l12 = fc.y; l20 = fc.z; l01 = fc.w;
+        } else {
+          const float area = edge_fn(t.x2, t.y2, t.x0, t.y0, t.x1, t.y1) + kEps;
+          sg = (area > 0.f) ? 1.f : ((area < 0.f) ? -1.f : 0.f);
+        }
         const float e0s = e0 * sg, e1s = e1 * sg, e2s = e2 * sg;
         const bool inside = (e0s > 0.f) && (e1s > 0.f) && (e2s > 0.f);
         if (MODE != 2 && inside && inbox) { hq |= (unsigned)j << (8 * hn); ++hn; }
         if (MODE >= 1) {
           bool soft = (MODE == 1) ? (inbox && prod != 0.f) : (inbox && need);
           if (soft) {
-            const float l12 = (t.x2 - t.x1) * (t.x2 - t.x1) + (t.y2 - t.y1) * (t.y2 - t.y1);
-            const float l20 = (t.x0 - t.x2) * (t.x0 - t.x2) + (t.y0 - t.y2) * (t.y0 - t.y2);
-            const float l01 = (t.x1 - t.x0) * (t.x1 - t.x0) + (t.y1 - t.y0) * (t.y1 - t.y0);
+            if (MODE == 2) {       // (few pairs get here in the backward pass: recomputing beats staging the constants, measured)
+              l12 = (t.x2 - t.x1) * (t.x2 - t.x1) + (t.y2 - t.y1) * (t.y2 - t.y1);
+              l20 = (t.x0 - t.x2) * (t.x0 - t.x2) + (t.y0 - t.y2) * (t.y0 - t.y2);
+              l01 = (t.x1 - t.x0) * (t.x1 - t.x0) + (t.y1 - t.y0) * (t.y1 - t.y0);
+            }
             if (inside) {
               // deeper than sqrt(18 sigma) inside every edge LINE (<= segment distance): sigmoid saturates to exactly 1 in
               // fp32 (exp(-18) < 2^-24), so the factor (1-p) is exactly 0 — same result as the exact path, no div/exp.
