@@ -155,6 +155,7 @@ class FitEngine:
         self.overlap_allreduce = True    # N > 1: all-reduce of the map gradients overlapped with the mesh / LBS backward
         self.graph_collectives = False   # N > 1: capture the RCCL all-reduce into the step graph (verified on 1 rank only)
         self.force_allreduce = False     # run the N > 1 code path on a single rank (tests, bench HARP_FORCE_DIST)
+        self.mesh_terms_first = True     # key-point term + mesh regularisers run before the light raster (under the raster set-up) instead of after it
         self.camera_first = True        # enqueue the camera-view raster chain (the longer one) before the light-view chain: +0.75 %
         self.frozen = ()                 # parameters kept out of the optimiser groups (known_appearance)
         self.schedule = None
@@ -337,6 +338,8 @@ class FitEngine:
             else:
                 side.wait_event(fork)
             with torch.cuda.stream(side):
+                if sched_early and self.mesh_terms_first:
+                    mesh_terms()
                 if shadow:
                     if not fused:
                         self._ck(L.harp_centroid(p(s["vd"]), B, V, p(s["centroid"]), ST()), "centroid")
@@ -345,7 +348,7 @@ class FitEngine:
                                  "project_l")
                     self._ck(L.harp_rasterize_fwd(p(s["ndc_l"]), p(tp.faces), B, V, F, S, 0, 0.0, 1.0, p(s["ws_l"]), p(s["face_l"]), p(s["zl"]), None, ST()),
                              "raster_light")
-                if sched_early:
+                if sched_early and not self.mesh_terms_first:
                     mesh_terms()
 
         def camera_view():
