@@ -164,21 +164,28 @@ def cpu_baseline(seed=0):
     opt_a = torch.optim.Adam([P["light_positions"], P["amb_ratio"], P["texture"], P["normal_map"]], lr=1e-2)
     with torch.no_grad():
         _, rv = H.prepare_mesh(P, torch.tensor([0]), model, topo)
-    times = []
-    for it in range(9):
-        t0 = time.time()
-        fid = torch.tensor([it % T])
-        da = torch.normal(0, 1.0, (512, 512, 2)).to(torch.int).long()
-        dn = torch.normal(0, 2.0, (512, 512, 2)).to(torch.int).long()
-        _, total, _ = H.step_losses(P, fid, model, topo, tg, S, focal, rv, da, dn)
-        opt_c.zero_grad(); opt_a.zero_grad()
-        total.backward()
-        opt_c.step(); opt_a.step()
-        times.append(time.time() - t0)
-    sec = float(np.median(times[1:]))
+    def timed_steps(n):
+        times = []
+        for it in range(n):
+            t0 = time.time()
+            fid = torch.tensor([it % T])
+            da = torch.normal(0, 1.0, (512, 512, 2)).to(torch.int).long()
+            dn = torch.normal(0, 2.0, (512, 512, 2)).to(torch.int).long()
+            _, total, _ = H.step_losses(P, fid, model, topo, tg, S, focal, rv, da, dn)
+            opt_c.zero_grad(); opt_a.zero_grad()
+            total.backward()
+            opt_c.step(); opt_a.step()
+            times.append(time.time() - t0)
+        return float(np.median(times[1:]))
+
+    sec = timed_steps(9)
+    torch.set_num_threads(1)                             # also a single-core figure
+    sec1 = timed_steps(4)
+    torch.set_num_threads(cores)
     return {"value": 1.0 / sec, "unit": "frames/s", "cores": cores, "kind": "port",
             "sample": f"oracle/harp_ref.step_losses + autograd + torch.optim.Adam, 1 frame/step at {S}x{S} (K=50 silhouette fragments "
-                      f"materialised), median of 8 steps after 1 warm-up (~10 s of CPU work), torch.set_num_threads({cores})"}
+                      f"materialised), median of 8 steps after 1 warm-up (~10 s of CPU work), torch.set_num_threads({cores})",
+            "single_core": {"value": 1.0 / sec1, "unit": "frames/s", "cores": 1, "sample": "same step, median of 3 after 1 warm-up"}}
 
 
 class _StdoutToStderr:
