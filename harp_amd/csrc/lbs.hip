@@ -124,6 +124,9 @@ __global__ void __launch_bounds__(64) lbs_joints_kernel(const harp_mano_model M,
 }
 
 // blockIdx.x: vertex chunk (256), blockIdx.y: frame chunk (8)
+#ifndef LBS_SKIN_BATCH
+#define LBS_SKIN_BATCH 34
+#endif
 constexpr int kSkinVerts = 64, kSkinSlices = 4;     // 256 threads = 64 vertices x 4 blend-shape slices
 template <bool BWD>
 __global__ void __launch_bounds__(256) lbs_skin_kernel(const harp_mano_model M, const float* __restrict__ betas,
@@ -158,11 +161,24 @@ __global__ void __launch_bounds__(256) lbs_skin_kernel(const harp_mano_model M, 
 #pragma unroll
       for (int f = 0; f < FRAMES_PER_BLOCK; ++f) { const float c = s_beta[f][k]; vp[f][0] += s0 * c; vp[f][1] += s1 * c; vp[f][2] += s2 * c; }
     }
-#pragma unroll 4
-    for (int k = ks; k < NP; k += kSkinSlices) {
-      const float p0 = M.posedirs_T[k * NV * 3 + 3 * v], p1 = M.posedirs_T[k * NV * 3 + 3 * v + 1], p2 = M.posedirs_T[k * NV * 3 + 3 * v + 2];
+    // the blend-shape rows come from HBM / MALL (1.26 MB, evicted from L2 by the rest of the step): the loop is a chain of DRAM round
+    // trips, so kSkinBatch rows are requested before the first one is used
+    constexpr int kSkinBatch = LBS_SKIN_BATCH;
+    for (int k0 = ks; k0 < NP; k0 += kSkinSlices * kSkinBatch) {
+      float pr[kSkinBatch][3];
 #pragma unroll
-      for (int f = 0; f < FRAMES_PER_BLOCK; ++f) { const float c = s_pm[f][k]; vp[f][0] += p0 * c; vp[f][1] += p1 * c; vp[f][2] += p2 * c; }
+      for (int u = 0; u < kSkinBatch; ++u) {
+        const int k = min(k0 + u * kSkinSlices, NP - 1);
+        pr[u][0] = M.posedirs_T[k * NV * 3 + 3 * v]; pr[u][1] = M.posedirs_T[k * NV * 3 + 3 * v + 1]; pr[u][2] = M.posedirs_T[k * NV * 3 + 3 * v + 2];
+      }
+#pragma unroll
+      for (int u = 0; u < kSkinBatch; ++u) {
+        const int k = k0 + u * kSkinSlices;
+        if (k < NP) {
+#pragma unroll
+          for (int f = 0; f < FRAMES_PER_BLOCK; ++f) { const float c = s_pm[f][k]; vp[f][0] += pr[u][0] * c; vp[f][1] += pr[u][1] * c; vp[f][2] += pr[u][2] * c; }
+        }
+      }
     }
   }
 #pragma unroll
