@@ -197,13 +197,15 @@ class FitEngine:
         if "g_nmap_n" not in s:
             s["g_nmap_n"] = self.g_nmap_n
         # g_alpha and g_rgb (the first two segments, 4/5 of the slab) are fully overwritten by harp_image_l1: only the rest is zeroed
-        return dict(s=s, gs_zero=gs_buf[garena.offsets["g_zl"][0]:], B=B, lo=lo, fid=self.fid[lo:lo + B], tfid=self.tfid[lo:lo + B],
+        # ... and of the rest, g_zl (B*S*S floats, 9/10 of it) is first touched by the shader backward: it is cleared on the second
+        # stream, off the head of the step; the small remainder is cleared first thing on the main stream
+        return dict(s=s, gs_zero=gs_buf[garena.offsets["g_vd"][0]:], gs_zero_late=s["g_zl"], B=B, lo=lo, fid=self.fid[lo:lo + B], tfid=self.tfid[lo:lo + B],
                     loss_vec=torch.zeros(16, dtype=torch.float32, device=dev), w_vec=torch.zeros(16, dtype=torch.float32, device=dev),
                     stream=None, side=None)
 
     def _activate(self, lane):
         """point the step code at one lane's buffers (host-side bookkeeping only)"""
-        self.s, self.gs_zero, self._lane = lane["s"], lane["gs_zero"], lane
+        self.s, self.gs_zero, self.gs_zero_late, self._lane = lane["s"], lane["gs_zero"], lane["gs_zero_late"], lane
 
     def set_targets(self, y_true, y_sil, y_sil_col, frame_offset=0):
         """(Tl,S,S,3), (Tl,S,S), (Tl,S,S) fp32 for this rank's frames [frame_offset, frame_offset+Tl): kept resident in HBM
@@ -307,6 +309,7 @@ class FitEngine:
         # ---- terms that depend on the parameters only (normal-map normalisation, texture regularisers, displacement regulariser) go
         #      first on the second stream: they run under the LBS / mesh chain, which is a string of small latency-bound launches
         def param_terms():
+            self.gs_zero_late.zero_()
             if tick:
                 self._adam_tick(coarse, app)             # only touches the hyper-parameter block: off the serial tail of the step
             if app and shared_terms:
