@@ -124,9 +124,6 @@ __global__ void __launch_bounds__(64) lbs_joints_kernel(const harp_mano_model M,
 }
 
 // blockIdx.x: vertex chunk (256), blockIdx.y: frame chunk (8)
-#ifndef LBS_SKIN_BATCH
-#define LBS_SKIN_BATCH 34
-#endif
 constexpr int kSkinVerts = 64, kSkinSlices = 4;     // 256 threads = 64 vertices x 4 blend-shape slices
 template <bool BWD>
 __global__ void __launch_bounds__(256) lbs_skin_kernel(const harp_mano_model M, const float* __restrict__ betas,
@@ -143,42 +140,50 @@ __global__ void __launch_bounds__(256) lbs_skin_kernel(const harp_mano_model M, 
   const int v = blockIdx.x * kSkinVerts + vl;
   const int b0 = blockIdx.y * FRAMES_PER_BLOCK;
   const int nb = min(FRAMES_PER_BLOCK, B - b0);
+  // Every load of the (static) model tables is issued BEFORE the staging barrier: the rows come from HBM / MALL (1.26 MB of pose
+  // blend shapes, evicted from L2 by the rest of the step), so the kernel is a chain of DRAM round trips, not arithmetic — with all of
+  // them in flight at once (this slice's 34 pose rows, 3 shape rows, template, 16 skinning weights) it pays one trip instead of a dozen.
+  const bool ok = v < NV;
+  const int vc = ok ? v : NV - 1;
+  constexpr int kRowsP = (NP + kSkinSlices - 1) / kSkinSlices, kRowsB = (NB + kSkinSlices - 1) / kSkinSlices;
+  float pr[kRowsP][3], sr[kRowsB][3], w[NJ], tp[3];
+#pragma unroll
+  for (int u = 0; u < kRowsP; ++u) {
+    const int k = min(ks + u * kSkinSlices, NP - 1);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) pr[u][c] = M.posedirs_T[k * NV * 3 + 3 * vc + c];
+  }
+#pragma unroll
+  for (int u = 0; u < kRowsB; ++u) {
+    const int k = min(ks + u * kSkinSlices, NB - 1);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) sr[u][c] = M.shapedirs_T[k * NV * 3 + 3 * vc + c];
+  }
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) w[j] = M.weights[vc * NJ + j];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) tp[c] = (ks == 0) ? M.v_template[3 * vc + c] : 0.f;
   for (int i = threadIdx.x; i < nb * NP; i += 256) s_pm[i / NP][i % NP] = pose_map[b0 * NP + i];
   for (int i = threadIdx.x; i < nb * NB; i += 256) s_beta[i / NB][i % NB] = betas[b0 * NB + i];
   for (int i = threadIdx.x; i < nb * NJ * 12; i += 256) s_A[i / (NJ * 12)][i % (NJ * 12)] = A[b0 * NJ * 12 + i];
   __syncthreads();
-  const bool ok = v < NV;
   float vp[FRAMES_PER_BLOCK][3];
-  {
-    const float t0 = (ok && ks == 0) ? M.v_template[3 * v] : 0.f, t1 = (ok && ks == 0) ? M.v_template[3 * v + 1] : 0.f,
-                t2 = (ok && ks == 0) ? M.v_template[3 * v + 2] : 0.f;
 #pragma unroll
-    for (int f = 0; f < FRAMES_PER_BLOCK; ++f) { vp[f][0] = t0; vp[f][1] = t1; vp[f][2] = t2; }
-  }
-  if (ok) {
-    for (int k = ks; k < NB; k += kSkinSlices) {
-      const float s0 = M.shapedirs_T[k * NV * 3 + 3 * v], s1 = M.shapedirs_T[k * NV * 3 + 3 * v + 1], s2 = M.shapedirs_T[k * NV * 3 + 3 * v + 2];
+  for (int f = 0; f < FRAMES_PER_BLOCK; ++f) { vp[f][0] = tp[0]; vp[f][1] = tp[1]; vp[f][2] = tp[2]; }
 #pragma unroll
-      for (int f = 0; f < FRAMES_PER_BLOCK; ++f) { const float c = s_beta[f][k]; vp[f][0] += s0 * c; vp[f][1] += s1 * c; vp[f][2] += s2 * c; }
+  for (int u = 0; u < kRowsB; ++u) {
+    const int k = ks + u * kSkinSlices;
+    if (k < NB) {
+#pragma unroll
+      for (int f = 0; f < FRAMES_PER_BLOCK; ++f) { const float c = s_beta[f][k]; vp[f][0] += sr[u][0] * c; vp[f][1] += sr[u][1] * c; vp[f][2] += sr[u][2] * c; }
     }
-    // the blend-shape rows come from HBM / MALL (1.26 MB, evicted from L2 by the rest of the step): the loop is a chain of DRAM round
-    // trips, so kSkinBatch rows are requested before the first one is used
-    constexpr int kSkinBatch = LBS_SKIN_BATCH;
-    for (int k0 = ks; k0 < NP; k0 += kSkinSlices * kSkinBatch) {
-      float pr[kSkinBatch][3];
+  }
 #pragma unroll
-      for (int u = 0; u < kSkinBatch; ++u) {
-        const int k = min(k0 + u * kSkinSlices, NP - 1);
-        pr[u][0] = M.posedirs_T[k * NV * 3 + 3 * v]; pr[u][1] = M.posedirs_T[k * NV * 3 + 3 * v + 1]; pr[u][2] = M.posedirs_T[k * NV * 3 + 3 * v + 2];
-      }
+  for (int u = 0; u < kRowsP; ++u) {
+    const int k = ks + u * kSkinSlices;
+    if (k < NP) {
 #pragma unroll
-      for (int u = 0; u < kSkinBatch; ++u) {
-        const int k = k0 + u * kSkinSlices;
-        if (k < NP) {
-#pragma unroll
-          for (int f = 0; f < FRAMES_PER_BLOCK; ++f) { const float c = s_pm[f][k]; vp[f][0] += pr[u][0] * c; vp[f][1] += pr[u][1] * c; vp[f][2] += pr[u][2] * c; }
-        }
-      }
+      for (int f = 0; f < FRAMES_PER_BLOCK; ++f) { const float c = s_pm[f][k]; vp[f][0] += pr[u][0] * c; vp[f][1] += pr[u][1] * c; vp[f][2] += pr[u][2] * c; }
     }
   }
 #pragma unroll
@@ -187,9 +192,6 @@ __global__ void __launch_bounds__(256) lbs_skin_kernel(const harp_mano_model M, 
     for (int c = 0; c < 3; ++c) s_part[ks][f * 3 + c][vl] = vp[f][c];
   __syncthreads();
   if (!ok) return;
-  float w[NJ];
-#pragma unroll
-  for (int j = 0; j < NJ; ++j) w[j] = M.weights[v * NJ + j];
   for (int f = ks; f < nb; f += kSkinSlices) {
     float q[3];
 #pragma unroll
