@@ -14,6 +14,11 @@
 
 namespace {
 
+// Reciprocal-based division / square root (v_rcp_f32, v_sqrt_f32: 1 ulp each; the IEEE-exact forms cost ~10 VALU instructions apiece
+// and made up a quarter of the forward shader's instruction count).  Image tolerance is 1e-4 absolute, gradients 1e-3 relative.
+__device__ __forceinline__ float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float fsqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+
 #ifndef SHADE_TEX_SLOTS
 #define SHADE_TEX_SLOTS 512
 #endif
@@ -104,14 +109,16 @@ struct Bary { float b0, b1, b2, w0, w1, w2, area, den; bool den_clamped; };
 __device__ __forceinline__ Bary bary_fwd(const Tri& t, float px, float py) {
   Bary r;
   r.area = edge_fn(t.x2, t.y2, t.x0, t.y0, t.x1, t.y1) + kEps;
-  r.w0 = edge_fn(px, py, t.x1, t.y1, t.x2, t.y2) / r.area;
-  r.w1 = edge_fn(px, py, t.x2, t.y2, t.x0, t.y0) / r.area;
-  r.w2 = edge_fn(px, py, t.x0, t.y0, t.x1, t.y1) / r.area;
+  const float ra = rcp(r.area);
+  r.w0 = edge_fn(px, py, t.x1, t.y1, t.x2, t.y2) * ra;
+  r.w1 = edge_fn(px, py, t.x2, t.y2, t.x0, t.y0) * ra;
+  r.w2 = edge_fn(px, py, t.x0, t.y0, t.x1, t.y1) * ra;
   const float t0 = r.w0 * t.z1 * t.z2, t1 = t.z0 * r.w1 * t.z2, t2 = t.z0 * t.z1 * r.w2;
   const float s = t0 + t1 + t2;
   r.den_clamped = !(s > kEps);
   r.den = fmaxf(s, kEps);
-  r.b0 = t0 / r.den; r.b1 = t1 / r.den; r.b2 = t2 / r.den;
+  const float rd = rcp(r.den);
+  r.b0 = t0 * rd; r.b1 = t1 * rd; r.b2 = t2 * rd;
   return r;
 }
 
@@ -126,17 +133,19 @@ __device__ __forceinline__ void edge_bwd(float g, float px, float py, float ax, 
 __device__ __forceinline__ void bary_bwd(const Tri& t, float px, float py, const Bary& r, float gb0, float gb1, float gb2,
                                          float* out) {
   const float t0 = r.w0 * t.z1 * t.z2, t1 = t.z0 * r.w1 * t.z2, t2 = t.z0 * t.z1 * r.w2;
-  float gt0 = gb0 / r.den, gt1 = gb1 / r.den, gt2 = gb2 / r.den;
+  const float rd = rcp(r.den);
+  float gt0 = gb0 * rd, gt1 = gb1 * rd, gt2 = gb2 * rd;
   if (!r.den_clamped) {
-    const float c = (gb0 * t0 + gb1 * t1 + gb2 * t2) / (r.den * r.den);
+    const float c = (gb0 * t0 + gb1 * t1 + gb2 * t2) * (rd * rd);
     gt0 -= c; gt1 -= c; gt2 -= c;
   }
   const float gw0 = gt0 * t.z1 * t.z2, gw1 = gt1 * t.z0 * t.z2, gw2 = gt2 * t.z0 * t.z1;
   out[2] += gt1 * r.w1 * t.z2 + gt2 * r.w2 * t.z1;                // z0
   out[5] += gt0 * r.w0 * t.z2 + gt2 * r.w2 * t.z0;                // z1
   out[8] += gt0 * r.w0 * t.z1 + gt1 * r.w1 * t.z0;                // z2
-  const float ge0 = gw0 / r.area, ge1 = gw1 / r.area, ge2 = gw2 / r.area;
-  const float garea = -(gw0 * r.w0 + gw1 * r.w1 + gw2 * r.w2) / r.area;
+  const float ra = rcp(r.area);
+  const float ge0 = gw0 * ra, ge1 = gw1 * ra, ge2 = gw2 * ra;
+  const float garea = -(gw0 * r.w0 + gw1 * r.w1 + gw2 * r.w2) * ra;
   // e0 = edge(p, v1, v2); e1 = edge(p, v2, v0); e2 = edge(p, v0, v1); area = edge(v2, v0, v1)
   edge_bwd(ge0, px, py, t.x1, t.y1, t.x2, t.y2, out[3], out[4], out[6], out[7]);
   edge_bwd(ge1, px, py, t.x2, t.y2, t.x0, t.y0, out[6], out[7], out[0], out[1]);
@@ -317,21 +326,21 @@ __global__ void __launch_bounds__(256, SHADE_OCC) shade_kernel(const harp_shade_
     if (A.nmap) {
       if (!packed) g.m = bil_sample(A.nmap, g.bs, A.Wt, A.Ht, BWD ? &mdx : nullptr, &mdy);
       g.s = (g.n.z >= 0.f) ? 1.f : -1.f;
-      g.a = -1.0f / (g.s + g.n.z);
+      g.a = -rcp(g.s + g.n.z);
       const float bb = g.n.x * g.n.y * g.a;
       g.tu = mk(1.f + g.s * g.n.x * g.n.x * g.a, g.s * bb, -g.s * g.n.x);
       g.tv = mk(bb, g.s + g.n.y * g.n.y * g.a, -g.n.y);
       g.nprime = g.tu * (-g.m.x) + g.tv * (-g.m.y) + g.n * g.m.z;
-      g.lnp = sqrtf(dot(g.nprime, g.nprime));
-      g.nhat = g.nprime * (1.0f / fmaxf(g.lnp, 1e-12f));
+      g.lnp = fsqrt(dot(g.nprime, g.nprime));
+      g.nhat = g.nprime * rcp(fmaxf(g.lnp, 1e-12f));
       nfin = g.nhat;
     }
     // PointLights.diffuse: normalize(n, eps 1e-6) . normalize(L - p, eps 1e-6)
-    g.lnh = sqrtf(dot(nfin, nfin));
-    g.nn = nfin * (1.0f / fmaxf(g.lnh, 1e-6f));
+    g.lnh = fsqrt(dot(nfin, nfin));
+    g.nn = nfin * rcp(fmaxf(g.lnh, 1e-6f));
     g.ldir = ld(A.light_pos + 3 * b) - g.p;
-    g.llen = sqrtf(dot(g.ldir, g.ldir));
-    g.lhat = g.ldir * (1.0f / fmaxf(g.llen, 1e-6f));
+    g.llen = fsqrt(dot(g.ldir, g.ldir));
+    g.lhat = g.ldir * rcp(fmaxf(g.llen, 1e-6f));
     g.cosr = dot(g.nn, g.lhat);
     const float cosang = fmaxf(g.cosr, 0.f);
     // shadow (renderer_helper.py:379-408)
@@ -344,7 +353,8 @@ __global__ void __launch_bounds__(256, SHADE_OCC) shade_kernel(const harp_shade_
       const float* T = A.light_T + 3 * b;
       g.q = mk(g.p.x * R[0] + g.p.y * R[3] + g.p.z * R[6] + T[0], g.p.x * R[1] + g.p.y * R[4] + g.p.z * R[7] + T[1],
                g.p.x * R[2] + g.p.y * R[5] + g.p.z * R[8] + T[2]);
-      const float xn = (A.focal * g.q.x / g.q.z - A.ppx + half) / half, yn = (A.focal * g.q.y / g.q.z - A.ppy + half) / half;
+      const float rqz = rcp(g.q.z), rhalf = rcp(half);
+      const float xn = (A.focal * g.q.x * rqz - A.ppx + half) * rhalf, yn = (A.focal * g.q.y * rqz - A.ppy + half) * rhalf;
       const float xs = half - half * xn, ys = half - half * yn;
       // torch .round().long(): half-to-even; non-finite -> clamp below makes it harmless
       g.ix = (int)rintf(fminf(fmaxf(xs, -1.0e6f), 1.0e6f));
@@ -359,26 +369,27 @@ __global__ void __launch_bounds__(256, SHADE_OCC) shade_kernel(const harp_shade_
           sg[k] = sigmoidf((A.zl[(size_t)b * S * S + tapo[k]] - aa) * 1000.0f);
           acc += sg[k];
         }
-      g.vis = acc / 9.0f;
+      g.vis = acc * (1.0f / 9.0f);
     }
     const V3 amb = ld(col), dfc = ld(col + 3), spc = ld(col + 6);
     const V3 lightc = mk(amb.x + dfc.x * cosang * g.vis, amb.y + dfc.y * cosang * g.vis, amb.z + dfc.z * cosang * g.vis);
     const V3 c = mk(lightc.x * g.texel.x + spc.x, lightc.y * g.texel.y + spc.y, lightc.z * g.texel.z + spc.z);
     // softmax_rgb_blend, K=1, blur=0 (Appendix A.4); prob in (0.5,1] is taken as 1 (error <= 2e-10)
     const float zpix = b0 * g.t.z0 + b1 * g.t.z1 + b2 * g.t.z2;
-    const float zinv = (100.0f - zpix) / 99.0f;
+    const float zinv = (100.0f - zpix) * (1.0f / 99.0f);
     const float zmax = fmaxf(zinv, 1e-10f);
-    const float wnum = expf((zinv - zmax) / 1e-4f);
-    const float delta = fmaxf(expf((1e-10f - zmax) / 1e-4f), 1e-10f);
+    const float wnum = __expf((zinv - zmax) * 1e4f);
+    const float delta = fmaxf(__expf((1e-10f - zmax) * 1e4f), 1e-10f);
     const float denom = wnum + delta;
     if (!BWD) {
       float* r = A.rgb + o * 3;
-      out_rgb[0] = (wnum * c.x + delta * A.bg[0]) / denom;
-      out_rgb[1] = (wnum * c.y + delta * A.bg[1]) / denom;
-      out_rgb[2] = (wnum * c.z + delta * A.bg[2]) / denom;
+      const float rden = rcp(denom);
+      out_rgb[0] = (wnum * c.x + delta * A.bg[0]) * rden;
+      out_rgb[1] = (wnum * c.y + delta * A.bg[1]) * rden;
+      out_rgb[2] = (wnum * c.z + delta * A.bg[2]) * rden;
       r[0] = out_rgb[0]; r[1] = out_rgb[1]; r[2] = out_rgb[2];
     } else {
-      const float wk = wnum / denom;
+      const float wk = wnum * rcp(denom);
       const V3 g_c = gc * wk;
       // c = lightc * texel + spec
       const V3 g_tex = mk(g_c.x * lightc.x, g_c.y * lightc.y, g_c.z * lightc.z);
@@ -396,13 +407,13 @@ __global__ void __launch_bounds__(256, SHADE_OCC) shade_kernel(const harp_shade_
       V3 g_p = mk(0.f, 0.f, 0.f);
       // cos = nn . lhat
       const V3 g_nn = g.lhat * g_cos, g_lhat = g.nn * g_cos;
-      V3 g_ldir = (g.llen > 1e-6f) ? (g_lhat - g.lhat * dot(g.lhat, g_lhat)) * (1.0f / g.llen) : g_lhat * 1e6f;
+      V3 g_ldir = (g.llen > 1e-6f) ? (g_lhat - g.lhat * dot(g.lhat, g_lhat)) * rcp(g.llen) : g_lhat * 1e6f;
       racc[9] += g_ldir.x; racc[10] += g_ldir.y; racc[11] += g_ldir.z;                       // light_pos
       g_p = g_p - g_ldir;
-      V3 g_nfin = (g.lnh > 1e-6f) ? (g_nn - g.nn * dot(g.nn, g_nn)) * (1.0f / g.lnh) : g_nn * 1e6f;
+      V3 g_nfin = (g.lnh > 1e-6f) ? (g_nn - g.nn * dot(g.nn, g_nn)) * rcp(g.lnh) : g_nn * 1e6f;
       V3 g_n = g_nfin;
       if (A.nmap) {
-        const V3 g_np = (g.lnp > 1e-12f) ? (g_nfin - g.nhat * dot(g.nhat, g_nfin)) * (1.0f / g.lnp) : g_nfin * 1e12f;
+        const V3 g_np = (g.lnp > 1e-12f) ? (g_nfin - g.nhat * dot(g.nhat, g_nfin)) * rcp(g.lnp) : g_nfin * 1e12f;
         const V3 g_m = mk(-dot(g.tu, g_np), -dot(g.tv, g_np), dot(g.n, g_np));
         g_m_keep = g_m;
         gu += dot(g_m, mdx) * (float)(A.Wt - 1);
