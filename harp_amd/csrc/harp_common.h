@@ -31,7 +31,7 @@ struct FaceRec {
 
 // Layout of a rasteriser workspace (harp_rasterize_ws_bytes): face records | contiguous bboxes | per-super-tile face lists |
 // list lengths | heaviest-first launch order of the (frame, super-tile) pairs.
-struct RasterWs { FaceRec* recs; float4* bbs; int32_t* bins; int32_t* cnt; int32_t* order; int nsx; };
+struct RasterWs { FaceRec* recs; float4* bbs; int32_t* bins; int32_t* cnt; int32_t* order; int32_t* nact; int nsx; };
 inline RasterWs raster_ws_split(void* ws, int B, int F, int S) {
   RasterWs r;
   r.nsx = (S + kSuper - 1) / kSuper;
@@ -40,24 +40,40 @@ inline RasterWs raster_ws_split(void* ws, int B, int F, int S) {
   r.bbs = (float4*)p;     p += (size_t)B * F * sizeof(float4);
   r.bins = (int32_t*)p;   p += (size_t)B * r.nsx * r.nsx * F * sizeof(int32_t);
   r.cnt = (int32_t*)p;    p += (((size_t)B * r.nsx * r.nsx * sizeof(int32_t)) + 255) / 256 * 256;
-  r.order = (int32_t*)p;
+  r.order = (int32_t*)p;  p += (((size_t)B * r.nsx * r.nsx * sizeof(int32_t)) + 255) / 256 * 256;
+  r.nact = (int32_t*)p;   // one int: number of super-tiles that hold faces = number of leading launch-order slots with work
   return r;
 }
 // workgroups of the 1-D tile grid: launch-order slots rounded up to a multiple of 8 (one per XCD) x 16 tiles per super-tile
 inline unsigned tile_grid(int B, int nsx) { return (unsigned)(((B * nsx * nsx + 7) / 8) * 8 * (kSuper / kTile) * (kSuper / kTile)); }
 // Decode a workgroup id of that grid: consecutive ids go round-robin over the 8 XCDs, so the 16 tiles of one super-tile (same bin
-// list, same face records, neighbouring pixels) stay on one XCD / one L2; slots follow the heaviest-first order.  false = no tile.
-__device__ __forceinline__ bool tile_decode(const int32_t* __restrict__ order, int B, int nsx, int S, int& b, int& st, int& tx0, int& ty0) {
+// list, same face records, neighbouring pixels) stay on one XCD / one L2; slots follow the heaviest-first order.
+// Returns 0: no tile; 1: tile of a super-tile that holds faces; 2: tile of an EMPTY super-tile.  The slots are ordered heaviest-first,
+// so "empty" is slot >= *nact: one scalar load, no dependent trip through the bin counts.  3/4 of the workgroups of a launch are such
+// tiles and every one of them used to walk order -> bin count / face ids -> exit: with 5 workgroups per CU in flight that chain, not
+// the shading, was a third of the forward shader's time.  coords_if_empty = false: return 2 without touching `order`.
+__device__ __forceinline__ int tile_decode(const int32_t* __restrict__ order, const int32_t* __restrict__ nact, int B, int nsx, int S,
+                                           int& b, int& st, int& tx0, int& ty0, int& sub, bool coords_if_empty = true) {
   constexpr int kTps = (kSuper / kTile) * (kSuper / kTile);
   const int nst = nsx * nsx;
   const int xcd = blockIdx.x & 7, rr = blockIdx.x >> 3;
-  const int sub = rr % kTps, slot = (rr / kTps) * 8 + xcd;
-  if (slot >= B * nst) return false;
+  const int slot = (rr / kTps) * 8 + xcd;
+  sub = rr % kTps;
+  if (slot >= B * nst) return 0;
+  const bool empty = slot >= nact[0];
+  if (empty && !coords_if_empty) return 2;
   const int entry = order[slot];
   b = entry / nst; st = entry - b * nst;
   tx0 = ((st % nsx) * (kSuper / kTile) + (sub & 3)) * kTile;
   ty0 = ((st / nsx) * (kSuper / kTile) + (sub >> 2)) * kTile;
-  return tx0 < S && ty0 < S;
+  if (!(tx0 < S && ty0 < S)) return 0;
+  return empty ? 2 : 1;
+}
+// Pixels of a whole 64x64 super-tile spread over a 256-thread workgroup (16 each, 64-wide coalesced rows): k = 0..15
+__device__ __forceinline__ void supertile_pixel(int k, int sx0, int sy0, int& xi, int& yi) {
+  const int idx = k * 256 + (int)threadIdx.x;
+  xi = sx0 + (idx & (kSuper - 1));
+  yi = sy0 + (idx >> 6);
 }
 
 __device__ __forceinline__ float pix_to_ndc(int i, int S) {

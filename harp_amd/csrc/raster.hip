@@ -106,7 +106,8 @@ __device__ __forceinline__ int block_compact(bool pred, int running, int* lds_cn
 // count leading zeros).  The raster grid is 1-D over this order, so the workgroups with real work are dispatched first and
 // densely (the natural (x, y, frame) order interleaves them with ~75 % empty tiles: measured average occupancy was < 3 of 8
 // waves per SIMD) and the longest ones do not end up in the tail.
-__device__ void order_tiles(const int32_t* __restrict__ bin_count, int total, int32_t* __restrict__ order, int* hist, int* base) {
+__device__ void order_tiles(const int32_t* __restrict__ bin_count, int total, int32_t* __restrict__ order, int32_t* __restrict__ nact,
+                            int* hist, int* base) {
   if (threadIdx.x < 33) hist[threadIdx.x] = 0;
   __syncthreads();
   for (int i = threadIdx.x; i < total; i += blockDim.x) {
@@ -117,6 +118,7 @@ __device__ void order_tiles(const int32_t* __restrict__ bin_count, int total, in
   if (threadIdx.x == 0) {
     int run = 0;
     for (int k = 0; k < 33; ++k) { base[k] = run; run += hist[k]; }
+    nact[0] = base[32];                      // bucket 32 = empty lists: everything before it has work
   }
   __syncthreads();
   for (int i = threadIdx.x; i < total; i += blockDim.x) {
@@ -166,9 +168,10 @@ __global__ void __launch_bounds__(256) bin_faces_kernel(const float4* __restrict
 
 // (Folding this into the binning pass with a "last workgroup done" ticket was measured: 512 same-address ticket atomics cost ~35 us,
 //  8x the launch they save.)
-__global__ void __launch_bounds__(1024) order_tiles_kernel(const int32_t* __restrict__ bin_count, int total, int32_t* __restrict__ order) {
+__global__ void __launch_bounds__(1024) order_tiles_kernel(const int32_t* __restrict__ bin_count, int total, int32_t* __restrict__ order,
+                                                           int32_t* __restrict__ nact) {
   __shared__ int s_hist[33], s_base[33];
-  order_tiles(bin_count, total, order, s_hist, s_base);
+  order_tiles(bin_count, total, order, nact, s_hist, s_base);
 }
 
 // MODE 0: depth only (light view).  MODE 1: nearest face + silhouette product (camera view).
@@ -176,8 +179,8 @@ __global__ void __launch_bounds__(1024) order_tiles_kernel(const int32_t* __rest
 template <int MODE>
 __global__ void __launch_bounds__(256) raster_kernel(const FaceRec* __restrict__ recs, const float4* __restrict__ bbs,
                                                      const int32_t* __restrict__ bins,
-                                                     const int32_t* __restrict__ bin_count, const int32_t* __restrict__ order, int B,
-                                                     int F, int S, int nsx,
+                                                     const int32_t* __restrict__ bin_count, const int32_t* __restrict__ order,
+                                                     const int32_t* __restrict__ nact, int B, int F, int S, int nsx,
                                                      float blur, float sigma, int32_t* __restrict__ face_id,
                                                      float* __restrict__ zbuf, float* __restrict__ alpha,
                                                      const float* __restrict__ g_alpha, const int32_t* __restrict__ faces,
@@ -192,8 +195,48 @@ __global__ void __launch_bounds__(256) raster_kernel(const FaceRec* __restrict__
   // MODE 2: per-staged-face gradient accumulators (x,y of 3 verts).  double: ds_add_f64 is ~20x faster than ds_add_f32 on gfx950
   __shared__ double s_g[MODE == 2 ? kStage : 1][6];
 
-  int b, st, tx0, ty0;
-  if (!tile_decode(order, B, nsx, S, b, st, tx0, ty0)) return;     // 1-D grid in heaviest-first order (harp_common.h)
+  int b, st, tx0, ty0, sub;
+  const int kind = tile_decode(order, nact, B, nsx, S, b, st, tx0, ty0, sub, MODE != 2);   // 1-D grid in heaviest-first order (harp_common.h)
+  if (kind == 0) return;
+  if (kind == 2) {
+    // super-tile without a single face.  Backward: nothing to do.  Forward: its first workgroup writes the empty-pixel outputs (and
+    // the fused silhouette L1 against alpha = 0) for all 64x64 pixels, the other 15 leave at once.
+    if (MODE == 2 || sub != 0) return;
+    float acc = 0.f;
+    float tg[16];
+    const bool l1 = (MODE == 1) && l1_target != nullptr;
+    const float* trow = l1 ? l1_target + (size_t)l1_fid[b] * S * S : nullptr;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {            // all 16 target loads in flight before the first store
+      int xi, yi;
+      supertile_pixel(k, tx0, ty0, xi, yi);
+      tg[k] = (l1 && xi < S && yi < S) ? trow[(size_t)yi * S + xi] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      int xi, yi;
+      supertile_pixel(k, tx0, ty0, xi, yi);
+      if (xi < S && yi < S) {
+        const size_t o = ((size_t)b * S + yi) * S + xi;
+        face_id[o] = -1;
+        if (zbuf) zbuf[o] = -1.0f;
+        if (MODE == 1) {
+          alpha[o] = 0.f;
+          if (l1) {
+            const float d = 0.f - tg[k];
+            acc += fabsf(d);
+            l1_grad[o] = l1_w[0] * l1_inv * ((d > 0.f) - (d < 0.f));
+          }
+        }
+      }
+    }
+    if (MODE == 1 && l1_target) {
+      __shared__ float red0[4];
+      const float sum = block_sum_256(acc, red0);
+      if (threadIdx.x == 0 && sum != 0.f) atomicAdd(l1_loss, sum * l1_inv);
+    }
+    return;
+  }
   const int nst = nsx * nsx;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int xi = tx0 + (lane & 15), yi = ty0 + w * 4 + (lane >> 4);
@@ -461,7 +504,7 @@ size_t harp_rasterize_ws_bytes(int B, int F, int S) {
   size_t bbs = (size_t)B * F * sizeof(float4);
   size_t bins = (size_t)B * nsx * nsx * F * sizeof(int32_t);
   size_t cnt = (((size_t)B * nsx * nsx * sizeof(int32_t)) + 255) / 256 * 256;
-  return recs + bbs + bins + 2 * cnt;      // counts + launch order
+  return recs + bbs + bins + 2 * cnt + 256;      // counts + launch order + number of non-empty super-tiles
 }
 
 // Forward rasterisation of B frames sharing one face table.
@@ -482,14 +525,14 @@ int harp_rasterize_l1_fwd(const float* ndc, const int32_t* faces, int B, int V, 
   const float r = soft ? sqrtf(blur_radius) : 0.f;
   hipLaunchKernelGGL(face_setup_kernel, dim3((F + 255) / 256, B), dim3(256), 0, stream, ndc, faces, V, F, r, recs, bbs);
   hipLaunchKernelGGL(bin_faces_kernel, dim3((nsx * nsx + 3) / 4, B), dim3(256), 0, stream, bbs, F, S, nsx, bins, cnt);
-  hipLaunchKernelGGL(order_tiles_kernel, dim3(1), dim3(1024), 0, stream, cnt, B * nsx * nsx, order);
+  hipLaunchKernelGGL(order_tiles_kernel, dim3(1), dim3(1024), 0, stream, cnt, B * nsx * nsx, order, W.nact);
   const dim3 grid(tile_grid(B, nsx));
   if (soft)
-    hipLaunchKernelGGL(raster_kernel<1>, grid, dim3(256), 0, stream, recs, bbs, bins, cnt, order, B, F, S, nsx, blur_radius, sigma,
+    hipLaunchKernelGGL(raster_kernel<1>, grid, dim3(256), 0, stream, recs, bbs, bins, cnt, order, W.nact, B, F, S, nsx, blur_radius, sigma,
                        face_id, zbuf, alpha, nullptr, nullptr, 0, nullptr, l1_target, l1_fid, l1_w, l1_loss, l1_grad,
                        1.0f / ((float)B * (float)S * (float)S));
   else
-    hipLaunchKernelGGL(raster_kernel<0>, grid, dim3(256), 0, stream, recs, bbs, bins, cnt, order, B, F, S, nsx, 0.f, 1.f, face_id, zbuf,
+    hipLaunchKernelGGL(raster_kernel<0>, grid, dim3(256), 0, stream, recs, bbs, bins, cnt, order, W.nact, B, F, S, nsx, 0.f, 1.f, face_id, zbuf,
                        nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f);
   HARP_CHECK_LAUNCH();
   return HARP_OK;
@@ -510,7 +553,7 @@ int harp_silhouette_bwd(const int32_t* faces, int B, int V, int F, int S, float 
   FaceRec* recs = W.recs; int32_t *bins = W.bins, *cnt = W.cnt, *order = W.order; float4* bbs = W.bbs;
   const int nsx = W.nsx;
   const dim3 grid(tile_grid(B, nsx));
-  hipLaunchKernelGGL(raster_kernel<2>, grid, dim3(256), 0, stream, recs, bbs, bins, cnt, order, B, F, S, nsx, blur_radius, sigma, nullptr,
+  hipLaunchKernelGGL(raster_kernel<2>, grid, dim3(256), 0, stream, recs, bbs, bins, cnt, order, W.nact, B, F, S, nsx, blur_radius, sigma, nullptr,
                      nullptr, (float*)alpha, g_alpha, faces, V, g_ndc, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f);
   HARP_CHECK_LAUNCH();
   return HARP_OK;

@@ -231,7 +231,8 @@ struct Frag {
 };
 
 template <bool BWD>
-__global__ void __launch_bounds__(256, SHADE_OCC) shade_kernel(const harp_shade_args A, const int32_t* __restrict__ order, int nsx) {
+__global__ void __launch_bounds__(256, SHADE_OCC) shade_kernel(const harp_shade_args A, const int32_t* __restrict__ order,
+                                                               const int32_t* __restrict__ nact, int nsx) {
   __shared__ float s_red[32];
   // per-vertex accumulators: 0-2 g_verts, 3-5 g_vnormals, 6-8 g_ndc
   __shared__ VertexAccum<BWD ? kVtxSlots : 1, 9, SHADE_ACC_T> s_acc;
@@ -245,8 +246,23 @@ __global__ void __launch_bounds__(256, SHADE_OCC) shade_kernel(const harp_shade_
   const int S = A.S, V = A.V;
   // one 16x16 tile per workgroup, dispatched in the rasteriser's heaviest-first super-tile order (harp_common.h: tile_decode): the
   // tiles with covered pixels run first and densely instead of interleaved with the ~80 % background tiles.
-  int b, st_unused, tx0, ty0;
-  if (!tile_decode(order, A.B, nsx, S, b, st_unused, tx0, ty0)) return;
+  int b, st_unused, tx0, ty0, tsub;
+  const int kind = tile_decode(order, nact, A.B, nsx, S, b, st_unused, tx0, ty0, tsub, !BWD);
+  if (kind == 0) return;
+  if (kind == 2) {
+    // super-tile without a single face (3/4 of the launch): no gradient in the backward pass; in the forward pass its first workgroup
+    // writes the background colour for all 64x64 pixels and the other 15 leave at once
+    if (BWD || tsub != 0) return;
+    for (int k = 0; k < 16; ++k) {
+      int xi, yi;
+      supertile_pixel(k, tx0, ty0, xi, yi);
+      if (xi < S && yi < S) {
+        float* r = A.rgb + (((size_t)b * S + yi) * S + xi) * 3;
+        r[0] = A.bg[0]; r[1] = A.bg[1]; r[2] = A.bg[2];
+      }
+    }
+    return;
+  }
   constexpr int R = 1;
   if (BWD) {
     bool any_act = false;
@@ -658,12 +674,11 @@ __global__ void pack_texels_kernel(const float* __restrict__ tex, const float* _
 __global__ void __launch_bounds__(256) depth_bwd_kernel(const int32_t* __restrict__ face_id, const FaceRec* __restrict__ recs,
                                                         const int32_t* __restrict__ faces, const float* __restrict__ g_z,
                                                         int V, int F, int S, float* __restrict__ g_ndc,
-                                                        const int32_t* __restrict__ order, const int32_t* __restrict__ bin_count,
+                                                        const int32_t* __restrict__ order, const int32_t* __restrict__ nact,
                                                         int B, int nsx) {
   __shared__ VertexAccum<256, 3> s_acc;
-  int b, st, tx0, ty0;
-  if (!tile_decode(order, B, nsx, S, b, st, tx0, ty0)) return;
-  if (bin_count[b * nsx * nsx + st] == 0) return;             // super-tile without a single face: nothing was rasterised there
+  int b, st, tx0, ty0, tsub;
+  if (tile_decode(order, nact, B, nsx, S, b, st, tx0, ty0, tsub, false) != 1) return;   // no tile / super-tile without a single face
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int xi = tx0 + (lane & 15), yi = ty0 + w * 4 + (lane >> 4);
   const bool in_img = xi < S && yi < S;
@@ -728,7 +743,7 @@ int harp_shade_fwd(const harp_shade_args* a, hipStream_t stream) {
     if (!b.l1_fid || !b.l1_w || !b.l1_loss || !b.l1_grad) return HARP_ERR_ARG;
     b.l1_inv = 1.0f / ((float)b.B * (float)b.S * (float)b.S * 3.0f);
   }
-  hipLaunchKernelGGL(shade_kernel<false>, grid, dim3(256), 0, stream, b, (const int32_t*)W.order, W.nsx);
+  hipLaunchKernelGGL(shade_kernel<false>, grid, dim3(256), 0, stream, b, (const int32_t*)W.order, (const int32_t*)W.nact, W.nsx);
   HARP_CHECK_LAUNCH();
   return HARP_OK;
 }
@@ -736,7 +751,7 @@ int harp_shade_fwd(const harp_shade_args* a, hipStream_t stream) {
 int harp_shade_bwd(const harp_shade_args* a, hipStream_t stream) {
   if (!a || !a->face_id || !a->recs || !a->g_rgb || !a->g_verts || !a->g_vnormals || !a->g_ndc) return HARP_ERR_ARG;
   const RasterWs W = raster_ws_split((void*)a->recs, a->B, a->F, a->S);
-  hipLaunchKernelGGL(shade_kernel<true>, dim3(tile_grid(a->B, W.nsx)), dim3(256), 0, stream, *a, (const int32_t*)W.order, W.nsx);
+  hipLaunchKernelGGL(shade_kernel<true>, dim3(tile_grid(a->B, W.nsx)), dim3(256), 0, stream, *a, (const int32_t*)W.order, (const int32_t*)W.nact, W.nsx);
   HARP_CHECK_LAUNCH();
   return HARP_OK;
 }
@@ -747,7 +762,7 @@ int harp_depth_bwd(const int32_t* face_id, const void* ws, const int32_t* faces,
   if (!face_id || !ws || !faces || !g_z || !g_ndc) return HARP_ERR_ARG;
   const RasterWs W = raster_ws_split((void*)ws, B, F, S);
   hipLaunchKernelGGL(depth_bwd_kernel, dim3(tile_grid(B, W.nsx)), dim3(256), 0, stream, face_id, (const FaceRec*)ws, faces, g_z, V, F, S, g_ndc,
-                     (const int32_t*)W.order, (const int32_t*)W.cnt, B, W.nsx);
+                     (const int32_t*)W.order, (const int32_t*)W.nact, B, W.nsx);
   HARP_CHECK_LAUNCH();
   return HARP_OK;
 }
