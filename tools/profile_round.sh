@@ -15,4 +15,12 @@ db=$(find $out/prof_$tag -name "*.db" | head -1)
 python tools/rocpd_stats.py $db > $out/${tag}_kernel_stats_default_bench_graph.txt
 python tools/rocpd_timeline.py $db > $out/${tag}_timeline_one_step.txt
 rm -rf $out/prof_$tag
+# HBM traffic per kernel: two separate PMC passes (counters only with --kernel-trace, never with other trace domains)
+cmd="python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-graph"
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout 600 rocprofv3 --kernel-trace --pmc $c -d $out/pmc_${tag}_$c -o run -- $cmd > /dev/null 2> $out/${tag}_pmc_$c.err
+done
+python tools/make_traffic_json.py $(find $out/pmc_${tag}_FETCH_SIZE -name "*.db" | head -1) $(find $out/pmc_${tag}_WRITE_SIZE -name "*.db" | head -1) \
+    "$cmd" > $out/${tag}_traffic.json
+rm -rf $out/pmc_${tag}_FETCH_SIZE $out/pmc_${tag}_WRITE_SIZE
 tail -c 600 $out/${tag}_bench.json
