@@ -72,6 +72,25 @@ def test_rasterizer_and_silhouette(sc):
     f3, z3, a3, _ = ops.rasterize_fwd(ndc_d.detach() * torch.tensor([1.0, 1.0, -1.0], device=DEV), faces_d, S, soft=True,
                                       blur_radius=ops.SIL_BLUR, sigma=ops.SIL_SIGMA)
     assert (f3 == -1).all() and (z3 == -1).all() and (a3 == 0).all()
+    # the fused silhouette L1 on such frames (every super-tile takes the empty-tile path): |0 - y| averaged, gradient -w/N where y > 0;
+    # one frame empty + one regular frame in the same launch, against the unfused computation
+    from harp_amd import _lib
+    L, p = _lib.lib(), _lib.ptr
+    mixed = ndc_d.detach().clone()
+    mixed[0, :, 2] *= -1.0
+    B, V, F = 2, mixed.shape[1], faces_d.shape[0]
+    ws = ops.rasterize_workspace(B, F, S, DEV)
+    fi, al = torch.empty(B, S, S, dtype=torch.int32, device=DEV), torch.empty(B, S, S, device=DEV)
+    y = tgt.to(DEV).contiguous()
+    tf = torch.tensor([1, 0], dtype=torch.int32, device=DEV)                     # frame b compares against target tf[b]
+    w, loss, g = torch.tensor([7.0], device=DEV), torch.zeros(1, device=DEV), torch.full((B, S, S), 9.0, device=DEV)
+    _lib.check(L.harp_rasterize_l1_fwd(p(mixed), p(faces_d), B, V, F, S, 1, ops.SIL_BLUR, ops.SIL_SIGMA, p(ws), p(fi), None, p(al), p(y), p(tf),
+                                       p(w), p(loss), p(g), _lib.stream()), "harp_rasterize_l1_fwd")
+    a_un, _ = ops.soft_silhouette(mixed, faces_d, S)
+    assert torch.equal(al, a_un.detach()) and (al[0] == 0).all() and (fi[0] == -1).all()
+    d = al - y[tf.long()]
+    assert abs(loss.item() - d.abs().mean().item()) <= 1e-5 * d.abs().mean().item()
+    assert torch.allclose(g, 7.0 * torch.sign(d) / d.numel(), rtol=1e-6, atol=0)
 
 
 def test_full_step_losses_grads_and_adam(sc):
