@@ -238,6 +238,7 @@ def main():
             torch.cuda.synchronize()
     eng, focal = build_engine(rank, world, device)
     eng.force_allreduce = force_dist
+    eng.keep_image = False                      # the step consumes the rendered image inside the shader (fused L1): it is not written out
     eng.graph_collectives = os.environ.get("HARP_GRAPH_COLLECTIVES", "0") == "1"
     Tl = eng.T // world
 
@@ -296,7 +297,7 @@ def main():
         geom_pos = parts["V"] * 12 + parts["F"] * 12
         alg = {"raster_cam_fwd(setup+bin+raster)": (geom_pos + parts["S2"] * 24 + parts["S2"] * 4 + parts["S2"] * 8) * eng.B,   # + fused silhouette L1: mask in, g_alpha out
                "raster_light_fwd(setup+bin+raster)": (geom_pos + parts["S2"] * 24) * eng.B,
-               "harp_shade_fwd": (parts["geom"] + parts["S2"] * (4 + 12 + 4 + 12 + 4 + 12)) * eng.B,   # + fused photometric L1: y_true, mask in, g_rgb out
+               "harp_shade_fwd": (parts["geom"] + parts["S2"] * (4 + (12 if eng.keep_image else 0) + 4 + 12 + 4 + 12)) * eng.B,   # + fused photometric L1: y_true, mask in, g_rgb out; the image itself only if kept
                "harp_shade_bwd": (parts["geom"] + parts["V"] * 36 + parts["S2"] * (4 + 12 + 4 + 4)) * eng.B + 2 * eng.Ht * eng.Wt * 12,
                "harp_silhouette_bwd": (geom_pos + parts["S2"] * 8 + parts["V"] * 12) * eng.B,
                "harp_depth_bwd": (geom_pos + parts["S2"] * 8 + parts["V"] * 12) * eng.B}

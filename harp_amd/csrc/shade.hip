@@ -252,7 +252,7 @@ __global__ void __launch_bounds__(256, SHADE_OCC) shade_kernel(const harp_shade_
   if (kind == 2) {
     // super-tile without a single face (3/4 of the launch): no gradient in the backward pass; in the forward pass its first workgroup
     // writes the background colour for all 64x64 pixels and the other 15 leave at once
-    if (BWD || tsub != 0) return;
+    if (BWD || tsub != 0 || !A.rgb) return;
     for (int k = 0; k < 16; ++k) {
       int xi, yi;
       supertile_pixel(k, tx0, ty0, xi, yi);
@@ -299,7 +299,7 @@ __global__ void __launch_bounds__(256, SHADE_OCC) shade_kernel(const harp_shade_
     if (act) gc = ld(A.g_rgb + o * 3);
     act = act && (gc.x != 0.f || gc.y != 0.f || gc.z != 0.f);
   } else if (!act) {
-    if (in_img) { float* r = A.rgb + o * 3; r[0] = A.bg[0]; r[1] = A.bg[1]; r[2] = A.bg[2]; }
+    if (in_img && A.rgb) { float* r = A.rgb + o * 3; r[0] = A.bg[0]; r[1] = A.bg[1]; r[2] = A.bg[2]; }
   }
   float out_rgb[3] = {A.bg[0], A.bg[1], A.bg[2]};
   float vsc[BWD ? 27 : 1];   // backward: gradient of the face's 3 vertices x (position, normal, ndc), scattered after the branch
@@ -398,12 +398,11 @@ __global__ void __launch_bounds__(256, SHADE_OCC) shade_kernel(const harp_shade_
     const float delta = fmaxf(__expf((1e-10f - zmax) * 1e4f), 1e-10f);
     const float denom = wnum + delta;
     if (!BWD) {
-      float* r = A.rgb + o * 3;
       const float rden = rcp(denom);
       out_rgb[0] = (wnum * c.x + delta * A.bg[0]) * rden;
       out_rgb[1] = (wnum * c.y + delta * A.bg[1]) * rden;
       out_rgb[2] = (wnum * c.z + delta * A.bg[2]) * rden;
-      r[0] = out_rgb[0]; r[1] = out_rgb[1]; r[2] = out_rgb[2];
+      if (A.rgb) { float* r = A.rgb + o * 3; r[0] = out_rgb[0]; r[1] = out_rgb[1]; r[2] = out_rgb[2]; }
     } else {
       const float wk = wnum * rcp(denom);
       const V3 g_c = gc * wk;
@@ -734,7 +733,7 @@ int harp_pack_texels(const float* tex, const float* nmap, int n_texels, float* o
 
 int harp_shade_fwd(const harp_shade_args* a, hipStream_t stream) {
   if (!a || !a->face_id || !a->recs || !a->faces || !a->faces_uvs || !a->verts_uvs || !a->verts || !a->vnormals || !a->tex ||
-      !a->light_pos || !a->colors || !a->rgb || (a->zl && (!a->light_R || !a->light_T)))
+      !a->light_pos || !a->colors || (!a->rgb && !a->l1_target) || (a->zl && (!a->light_R || !a->light_T)))
     return HARP_ERR_ARG;
   const RasterWs W = raster_ws_split((void*)a->recs, a->B, a->F, a->S);
   const dim3 grid(tile_grid(a->B, W.nsx));

@@ -155,6 +155,7 @@ class FitEngine:
         self.overlap_allreduce = True    # N > 1: all-reduce of the map gradients overlapped with the mesh / LBS backward
         self.graph_collectives = False   # N > 1: capture the RCCL all-reduce into the step graph (verified on 1 rank only)
         self.force_allreduce = False     # run the N > 1 code path on a single rank (tests, bench HARP_FORCE_DIST)
+        self.keep_image = True           # shader forward writes the rendered image s["rgb"] (False: loss + gradient only)
         self.mesh_terms_first = True     # key-point term + mesh regularisers run before the light raster (under the raster set-up) instead of after it
         self.camera_first = True        # enqueue the camera-view raster chain (the longer one) before the light-view chain: +0.75 %
         self.frozen = ()                 # parameters kept out of the optimiser groups (known_appearance)
@@ -273,7 +274,8 @@ class FitEngine:
                             s["colors"], s["zl"] if self.self_shadow else None, s["light_R"] if self.self_shadow else None,
                             s["light_T"] if self.self_shadow else None, self.S, self.focal, (self.S / 2.0, self.S / 2.0), (1.0, 1.0, 1.0))
         a.B = B
-        a.rgb = _lib.ptr(s["rgb"])
+        # the fused photometric L1 needs no materialised image: with keep_image = False (fitting loops) the 4 MB / frame write is skipped
+        a.rgb = _lib.ptr(s["rgb"]) if (self.keep_image or self.perceptual is not None) else None
         if self.packed_texels:
             a.texnm = _lib.ptr(self.texnm)
         for k, t in (("g_rgb", s["g_rgb"]), ("g_tex", self.grads["texture"]), ("g_nmap", s["g_nmap_n"]), ("g_verts", s["g_vd"]),

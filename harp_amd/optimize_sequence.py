@@ -109,6 +109,7 @@ def optimize_hand_sequence(configs, input_params, images_dataset, val_params, va
         vgg = Vgg16Features(layers_weights=[1, 1 / 16, 1 / 8, 1 / 4, 1], weights=configs["vgg_weights"])
     if vgg is not None:
         eng.set_perceptual(vgg, weight=1.0)
+    eng.keep_image = False                                           # the fused L1 consumes y_pred in the shader; nothing reads the image back
     if configs["start_from"]:
         restore_checkpoint(eng, configs, input_params)
     if configs["known_appearance"]:

@@ -71,7 +71,8 @@ typedef struct harp_shade_args {
   int B, V, F, S, Ht, Wt;
   float focal, ppx, ppy;
   float bg[3];
-  float* rgb;               /* out (B,S,S,3) */
+  float* rgb;               /* out (B,S,S,3); may be NULL when l1_target is set: the loss and its gradient are produced without
+                             * materialising the image (4 MB per 512x512 frame that nothing in an optimisation step reads back) */
   /* backward only */
   const float* g_rgb;       /* (B,S,S,3) */
   float* g_tex;             /* (Ht,Wt,3) (+=) or NULL */

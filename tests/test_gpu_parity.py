@@ -487,3 +487,31 @@ def test_perceptual_term_gradients(sc):
     torch.cuda.synchronize()
     assert not eng._graphs and (eng.params["texture"] - before).abs().max() > 0
     assert torch.isfinite(eng.p_buf).all()
+
+
+def test_loss_only_shading_matches_image_mode(sc):
+    """keep_image = False (what the fitting loop and bench.py use): the shader forward does not write the rendered image; losses and
+    gradients are the same numbers (up to the order of the float atomics)"""
+    from harp_amd.engine import FitEngine
+    T, S, B = sc["T"], sc["S"], 2
+    tg = sc["targets"]
+    res = {}
+    for keep in (True, False):
+        eng = FitEngine(sc["model_np"], sc["topo_np"], sc["tpl"]["verts_uvs"], sc["tpl"]["faces_uvs"], sc["uv_mask"].float(), sc["seq"], S,
+                        sc["focal"], B, device=DEV)
+        eng.set_targets(tg["y_true"], tg["y_sil"], tg["y_sil_col"])
+        g = torch.Generator().manual_seed(11)
+        with torch.no_grad():
+            eng.params["texture"].copy_(torch.rand(1, 512, 512, 3, generator=g) * 0.5 + 0.3)
+        eng.keep_image = keep
+        eng.s["rgb"].fill_(-5.0)
+        fid = torch.tensor([0, 2])
+        eng.fid.copy_(fid.int().to(DEV)); eng.tfid.copy_(fid.int().to(DEV))
+        eng.auto_draw = False; eng.draw_texture_offsets(); eng.set_stage(True, True)
+        eng.forward_backward(True, True)
+        torch.cuda.synchronize()
+        res[keep] = (eng.losses(), eng.g_buf.clone(), eng.s["rgb"].clone())
+    assert (res[False][2] == -5.0).all() and (res[True][2] != -5.0).all()
+    for k, v in res[True][0].items():
+        assert abs(v - res[False][0][k]) <= 1e-6 * abs(v) + 1e-12, k
+    assert rel(res[False][1].cpu(), res[True][1].cpu()) < 1e-5
