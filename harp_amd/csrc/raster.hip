@@ -186,7 +186,7 @@ __global__ void __launch_bounds__(256) raster_kernel(const FaceRec* __restrict__
                                                      const float* __restrict__ g_alpha, const int32_t* __restrict__ faces,
                                                      int V, float* __restrict__ g_ndc, const float* __restrict__ l1_target,
                                                      const int32_t* __restrict__ l1_fid, const float* __restrict__ l1_w,
-                                                     float* __restrict__ l1_loss, float* __restrict__ l1_grad, float l1_inv) {
+                                                     float* __restrict__ l1_loss, float* __restrict__ l1_grad, float l1_inv, int sparse) {
   __shared__ float4 s_a[kStage], s_b[kStage], s_bb[kStage];
   __shared__ float s_z2[kStage];
   __shared__ float4 s_fc[MODE == 1 ? kStage : 1];      // per staged face: sign of the area, squared edge lengths l12, l20, l01
@@ -218,14 +218,13 @@ __global__ void __launch_bounds__(256) raster_kernel(const FaceRec* __restrict__
       supertile_pixel(k, tx0, ty0, xi, yi);
       if (xi < S && yi < S) {
         const size_t o = ((size_t)b * S + yi) * S + xi;
-        face_id[o] = -1;
-        if (zbuf) zbuf[o] = -1.0f;
-        if (MODE == 1) {
-          alpha[o] = 0.f;
-          if (l1) {
-            const float d = 0.f - tg[k];
-            acc += fabsf(d);
-            l1_grad[o] = l1_w[0] * l1_inv * ((d > 0.f) - (d < 0.f));
+        if (l1) acc += fabsf(tg[k]);                       // |alpha - y| with alpha = 0
+        if (!sparse) {
+          face_id[o] = -1;
+          if (zbuf) zbuf[o] = -1.0f;
+          if (MODE == 1) {
+            alpha[o] = 0.f;
+            if (l1) l1_grad[o] = l1_w[0] * l1_inv * (float)((0.f > tg[k]) - (0.f < tg[k]));
           }
         }
       }
@@ -530,10 +529,10 @@ int harp_rasterize_l1_fwd(const float* ndc, const int32_t* faces, int B, int V, 
   if (soft)
     hipLaunchKernelGGL(raster_kernel<1>, grid, dim3(256), 0, stream, recs, bbs, bins, cnt, order, W.nact, B, F, S, nsx, blur_radius, sigma,
                        face_id, zbuf, alpha, nullptr, nullptr, 0, nullptr, l1_target, l1_fid, l1_w, l1_loss, l1_grad,
-                       1.0f / ((float)B * (float)S * (float)S));
+                       1.0f / ((float)B * (float)S * (float)S), (soft & 2) ? 1 : 0);
   else
     hipLaunchKernelGGL(raster_kernel<0>, grid, dim3(256), 0, stream, recs, bbs, bins, cnt, order, W.nact, B, F, S, nsx, 0.f, 1.f, face_id, zbuf,
-                       nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f);
+                       nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0);
   HARP_CHECK_LAUNCH();
   return HARP_OK;
 }
@@ -554,7 +553,7 @@ int harp_silhouette_bwd(const int32_t* faces, int B, int V, int F, int S, float 
   const int nsx = W.nsx;
   const dim3 grid(tile_grid(B, nsx));
   hipLaunchKernelGGL(raster_kernel<2>, grid, dim3(256), 0, stream, recs, bbs, bins, cnt, order, W.nact, B, F, S, nsx, blur_radius, sigma, nullptr,
-                     nullptr, (float*)alpha, g_alpha, faces, V, g_ndc, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f);
+                     nullptr, (float*)alpha, g_alpha, faces, V, g_ndc, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0);
   HARP_CHECK_LAUNCH();
   return HARP_OK;
 }

@@ -361,7 +361,10 @@ class FitEngine:
             if not fused:
                 self._ck(L.harp_project_fwd(p(s["vd"]), p(s["cam_R"]), p(s["cam_T"]), B, V, self.focal, S / 2.0, S / 2.0, S, p(s["ndc_c"]), ST()), "project")
             # the silhouette L1 term and its gradient are fused into the raster epilogue (no separate pass over alpha)
-            self._ck(L.harp_rasterize_l1_fwd(p(s["ndc_c"]), p(tp.faces), B, V, F, S, 1, ops.SIL_BLUR, ops.SIL_SIGMA, p(s["ws_c"]), p(s["face_c"]),
+            # without keep_image nothing reads face ids / alpha / g_alpha in super-tiles that hold no face (shaders and the silhouette
+            # backward skip them): soft = 3 leaves those 3/4 of the three images unwritten
+            sparse = 0 if (self.keep_image or self.perceptual is not None) else 2
+            self._ck(L.harp_rasterize_l1_fwd(p(s["ndc_c"]), p(tp.faces), B, V, F, S, 1 | sparse, ops.SIL_BLUR, ops.SIL_SIGMA, p(s["ws_c"]), p(s["face_c"]),
                                              None, p(s["alpha"]), p(self.y_sil) if coarse else None, p(ltfid), wp(0), lp(0), p(s["g_alpha"]), ST()),
                      "raster_cam")
         if self.camera_first:
