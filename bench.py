@@ -112,8 +112,8 @@ def kernel_roofline(eng, steps):
             e0.record()
             r = self.fn(*a)
             e1.record()
-            # harp_rasterize_fwd: argument 6 is `soft` (1 = camera view with the fused soft silhouette, 0 = light-view depth pass)
-            key = self.name if "rasterize" not in self.name else ("raster_cam" if a[6] else "raster_light")
+            # harp_rasterize_fwd: argument 6 is `soft` (bit 0 = camera view with the fused soft silhouette, else the light-view depth pass)
+            key = self.name if "rasterize" not in self.name else ("raster_cam" if (a[6] & 1) else "raster_light")
             rec.setdefault(key, []).append((e0, e1))
             return r
 

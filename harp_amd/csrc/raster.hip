@@ -219,9 +219,9 @@ __global__ void __launch_bounds__(256) raster_kernel(const FaceRec* __restrict__
       if (xi < S && yi < S) {
         const size_t o = ((size_t)b * S + yi) * S + xi;
         if (l1) acc += fabsf(tg[k]);                       // |alpha - y| with alpha = 0
+        if (zbuf) zbuf[o] = -1.0f;                          // depth maps stay complete: shadow taps may land one pixel outside a face's super-tile
         if (!sparse) {
           face_id[o] = -1;
-          if (zbuf) zbuf[o] = -1.0f;
           if (MODE == 1) {
             alpha[o] = 0.f;
             if (l1) l1_grad[o] = l1_w[0] * l1_inv * (float)((0.f > tg[k]) - (0.f < tg[k]));
@@ -516,23 +516,23 @@ size_t harp_rasterize_ws_bytes(int B, int F, int S) {
 int harp_rasterize_l1_fwd(const float* ndc, const int32_t* faces, int B, int V, int F, int S, int soft, float blur_radius,
                           float sigma, void* ws, int32_t* face_id, float* zbuf, float* alpha, const float* l1_target,
                           const int32_t* l1_fid, const float* l1_w, float* l1_loss, float* l1_grad, hipStream_t stream) {
-  if (!ndc || !faces || !ws || !face_id || B <= 0 || F <= 0 || S <= 0 || (soft && !alpha)) return HARP_ERR_ARG;
-  if (l1_target && (!soft || !l1_fid || !l1_w || !l1_loss || !l1_grad)) return HARP_ERR_ARG;
+  if (!ndc || !faces || !ws || !face_id || B <= 0 || F <= 0 || S <= 0 || ((soft & 1) && !alpha)) return HARP_ERR_ARG;
+  if (l1_target && (!(soft & 1) || !l1_fid || !l1_w || !l1_loss || !l1_grad)) return HARP_ERR_ARG;
   const RasterWs W = raster_ws_split(ws, B, F, S);
   FaceRec* recs = W.recs; int32_t *bins = W.bins, *cnt = W.cnt, *order = W.order; float4* bbs = W.bbs;
   const int nsx = W.nsx;
-  const float r = soft ? sqrtf(blur_radius) : 0.f;
+  const float r = (soft & 1) ? sqrtf(blur_radius) : 0.f;
   hipLaunchKernelGGL(face_setup_kernel, dim3((F + 255) / 256, B), dim3(256), 0, stream, ndc, faces, V, F, r, recs, bbs);
   hipLaunchKernelGGL(bin_faces_kernel, dim3((nsx * nsx + 3) / 4, B), dim3(256), 0, stream, bbs, F, S, nsx, bins, cnt);
   hipLaunchKernelGGL(order_tiles_kernel, dim3(1), dim3(1024), 0, stream, cnt, B * nsx * nsx, order, W.nact);
   const dim3 grid(tile_grid(B, nsx));
-  if (soft)
+  if (soft & 1)
     hipLaunchKernelGGL(raster_kernel<1>, grid, dim3(256), 0, stream, recs, bbs, bins, cnt, order, W.nact, B, F, S, nsx, blur_radius, sigma,
                        face_id, zbuf, alpha, nullptr, nullptr, 0, nullptr, l1_target, l1_fid, l1_w, l1_loss, l1_grad,
                        1.0f / ((float)B * (float)S * (float)S), (soft & 2) ? 1 : 0);
   else
     hipLaunchKernelGGL(raster_kernel<0>, grid, dim3(256), 0, stream, recs, bbs, bins, cnt, order, W.nact, B, F, S, nsx, 0.f, 1.f, face_id, zbuf,
-                       nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0);
+                       nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, (soft & 2) ? 1 : 0);
   HARP_CHECK_LAUNCH();
   return HARP_OK;
 }

@@ -351,7 +351,8 @@ class FitEngine:
                         self._ck(L.harp_light_setup_fwd(p(s["centroid"]), p(s["light_pos"]), B, p(s["light_R"]), p(s["light_T"]), ST()), "light_setup")
                         self._ck(L.harp_project_fwd(p(s["vd"]), p(s["light_R"]), p(s["light_T"]), B, V, self.focal, S / 2.0, S / 2.0, S, p(s["ndc_l"]), ST()),
                                  "project_l")
-                    self._ck(L.harp_rasterize_fwd(p(s["ndc_l"]), p(tp.faces), B, V, F, S, 0, 0.0, 1.0, p(s["ws_l"]), p(s["face_l"]), p(s["zl"]), None, ST()),
+                    self._ck(L.harp_rasterize_fwd(p(s["ndc_l"]), p(tp.faces), B, V, F, S, 0 if self.keep_image else 2, 0.0, 1.0, p(s["ws_l"]), p(s["face_l"]),
+                                                  p(s["zl"]), None, ST()),
                              "raster_light")
                 if sched_early and not self.mesh_terms_first:
                     mesh_terms()

@@ -35,8 +35,8 @@ int harp_rasterize_fwd(const float* ndc, const int32_t* faces, int B, int V, int
                        float sigma, void* ws, int32_t* face_id, float* zbuf, float* alpha, hipStream_t stream);
 /* the same with torch.nn.L1Loss(y_sil_true, y_sil_pred) (optimize_sequence.py:519) fused into the raster epilogue: l1_target (T,S,S)
  * indexed by l1_fid (B,), *l1_loss (+=) the mean, l1_grad (B,S,S) = l1_w[0] * d loss / d alpha.  l1_target == NULL: plain rasterisation. */
-/* soft bit 1 (value 2, with the fused L1 only): SPARSE outputs — face_id / alpha / l1_grad are left unwritten in 64x64 super-tiles
- * that hold no face (their contribution to the loss is still accumulated).  For callers whose consumers skip those super-tiles too
+/* soft bit 0: soft silhouette on.  soft bit 1 (value 2): SPARSE outputs — face_id / alpha / l1_grad are left unwritten in 64x64
+ * super-tiles that hold no face (their contribution to the loss is still accumulated; zbuf is always written everywhere).  For callers whose consumers skip those super-tiles too
  * (harp_shade_*, harp_silhouette_bwd do): 3/4 of a hand image is such background. */
 int harp_rasterize_l1_fwd(const float* ndc, const int32_t* faces, int B, int V, int F, int S, int soft, float blur_radius,
                           float sigma, void* ws, int32_t* face_id, float* zbuf, float* alpha, const float* l1_target,
