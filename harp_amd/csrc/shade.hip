@@ -252,14 +252,34 @@ __global__ void __launch_bounds__(256, SHADE_OCC) shade_kernel(const harp_shade_
   if (kind == 2) {
     // super-tile without a single face (3/4 of the launch): no gradient in the backward pass; in the forward pass its first workgroup
     // writes the background colour for all 64x64 pixels and the other 15 leave at once
-    if (BWD || tsub != 0 || !A.rgb) return;
+    if (BWD || tsub != 0 || (!A.rgb && !A.l1_target)) return;
+    // background colour everywhere; the fused photometric term still counts these pixels where the mask is set (|bg - y| m), they
+    // only have no gradient
+    float acc = 0.f;
+    float mk_[16];
+    const size_t tbase = A.l1_target ? (size_t)A.l1_fid[b] * S * S : 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      int xi, yi;
+      supertile_pixel(k, tx0, ty0, xi, yi);
+      mk_[k] = (A.l1_target && xi < S && yi < S) ? (A.l1_mask ? A.l1_mask[tbase + (size_t)yi * S + xi] : 1.f) : 0.f;
+    }
+#pragma unroll
     for (int k = 0; k < 16; ++k) {
       int xi, yi;
       supertile_pixel(k, tx0, ty0, xi, yi);
       if (xi < S && yi < S) {
-        float* r = A.rgb + (((size_t)b * S + yi) * S + xi) * 3;
-        r[0] = A.bg[0]; r[1] = A.bg[1]; r[2] = A.bg[2];
+        if (A.rgb) { float* r = A.rgb + (((size_t)b * S + yi) * S + xi) * 3; r[0] = A.bg[0]; r[1] = A.bg[1]; r[2] = A.bg[2]; }
+        const float m = mk_[k];
+        if (m != 0.f) {
+          const float* t = A.l1_target + (tbase + (size_t)yi * S + xi) * 3;
+          acc += fabsf(A.bg[0] * m - t[0] * m) + fabsf(A.bg[1] * m - t[1] * m) + fabsf(A.bg[2] * m - t[2] * m);
+        }
       }
+    }
+    if (A.l1_target) {
+      const float sum = block_sum_256(acc, s_red);
+      if (threadIdx.x == 0 && sum != 0.f) atomicAdd(A.l1_loss, sum * A.l1_inv);
     }
     return;
   }

@@ -515,3 +515,44 @@ def test_loss_only_shading_matches_image_mode(sc):
     for k, v in res[True][0].items():
         assert abs(v - res[False][0][k]) <= 1e-6 * abs(v) + 1e-12, k
     assert rel(res[False][1].cpu(), res[True][1].cpu()) < 1e-5
+
+
+def test_losses_with_empty_supertiles():
+    """S = 256: 16 super-tiles per frame, most of them without a face.  Their pixels take the empty-super-tile paths of the rasteriser
+    and the shader, which must still count them in the silhouette and photometric terms (mask and target set there); both image
+    modes against the oracle."""
+    from harp_amd.engine import FitEngine, LOSS_NAMES
+    from oracle import harp_ref as H
+    sc = make_scene(T=2, S=256, seed=4)
+    S, B = 256, 2
+    tg = sc["targets"]
+    fid = torch.tensor([1, 0])
+    ref = None
+    for keep in (True, False):
+        eng = FitEngine(sc["model_np"], sc["topo_np"], sc["tpl"]["verts_uvs"], sc["tpl"]["faces_uvs"], sc["uv_mask"].float(), sc["seq"], S,
+                        sc["focal"], B, device=DEV)
+        eng.set_targets(tg["y_true"], tg["y_sil"], tg["y_sil_col"])
+        g = torch.Generator().manual_seed(21)
+        with torch.no_grad():
+            eng.params["texture"].copy_(torch.rand(1, 512, 512, 3, generator=g) * 0.5 + 0.3)
+            eng.params["normal_map"].copy_(torch.tensor([0., 0., 1.]).repeat(1, 512, 512, 1) + torch.randn(1, 512, 512, 3, generator=g) * 0.1)
+        eng.keep_image = keep
+        eng.fid.copy_(fid.int().to(DEV)); eng.tfid.copy_(fid.int().to(DEV))
+        eng.auto_draw = False; eng.draw_texture_offsets(); eng.set_stage(True, True)
+        eng.forward_backward(True, True)
+        torch.cuda.synchronize()
+        nact = int(eng.s["ws_c"][-256:].view(torch.int32)[0])
+        assert 0 < nact < B * 16, nact                    # some super-tiles hold faces, some do not
+        if ref is None:
+            P = oracle_params(sc, eng.params)
+            with torch.no_grad():
+                _, rv = H.prepare_mesh(P, torch.tensor([0]), sc["model"], sc["topo"])
+            ref, total, _ = H.step_losses(P, fid, sc["model"], sc["topo"], tg, S, sc["focal"], rv, eng.dist_albedo.cpu().long(),
+                                          eng.dist_normal.cpu().long())
+            total.backward()
+            gref = {k: P[k].grad.clone() for k in ("pose", "cam", "texture", "shape")}
+        lv = eng.losses()
+        for k in LOSS_NAMES:
+            assert abs(lv[k] - ref[k].item()) <= 1e-5 * abs(ref[k].item()) + 1e-8, (keep, k, lv[k], ref[k].item())
+        for k, g in gref.items():
+            assert rel(eng.grads[k].cpu(), g) < 2e-3, (keep, k)
