@@ -62,7 +62,7 @@ class ShadeArgs(ctypes.Structure):
                 [(n, _f) for n in ("focal", "ppx", "ppy")] + [("bg", _f * 3)] +
                 [(n, _vp) for n in ("rgb", "g_rgb", "g_tex", "g_nmap", "g_verts", "g_vnormals", "g_ndc", "g_zl", "g_light_pos",
                                     "g_colors", "g_light_R", "g_light_T")] + [("debug_skip", _i)] +
-                [(n, _vp) for n in ("l1_target", "l1_mask", "l1_fid", "l1_w", "l1_loss", "l1_grad")] + [("l1_inv", _f), ("texnm", _vp)])
+                [(n, _vp) for n in ("l1_target", "l1_mask", "l1_fid", "l1_w", "l1_loss", "l1_grad")] + [("l1_inv", _f), ("texnm", _vp), ("l1_bg_sums", _vp)])
 
 
 SIGNATURES.update({
@@ -157,4 +157,4 @@ SIGNATURES["harp_mesh_chain_max_vertices"] = (_i, [])
 SIGNATURES["harp_mesh_chain_fwd"] = (_i, [ctypes.POINTER(MeshChain), _vp])
 SIGNATURES["harp_mesh_chain_bwd"] = (_i, [ctypes.POINTER(MeshChain), _vp])
 SIGNATURES["harp_draw_texture_offsets"] = (_i, [ctypes.c_uint, _vp, _i, _i, _f, _vp, _f, _vp, _vp])
-SIGNATURES["harp_rasterize_l1_fwd"] = (_i, [_vp, _vp, _i, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp])
+SIGNATURES["harp_rasterize_l1_fwd"] = (_i, [_vp, _vp, _i, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp])

@@ -176,6 +176,8 @@ __global__ void __launch_bounds__(1024) order_tiles_kernel(const int32_t* __rest
 
 // MODE 0: depth only (light view).  MODE 1: nearest face + silhouette product (camera view).
 // MODE 2: silhouette backward (rim pixels): scatter dL/d(ndc xy).
+__device__ __forceinline__ int nst_of(int nsx) { return nsx * nsx; }
+
 template <int MODE>
 __global__ void __launch_bounds__(256) raster_kernel(const FaceRec* __restrict__ recs, const float4* __restrict__ bbs,
                                                      const int32_t* __restrict__ bins,
@@ -186,7 +188,8 @@ __global__ void __launch_bounds__(256) raster_kernel(const FaceRec* __restrict__
                                                      const float* __restrict__ g_alpha, const int32_t* __restrict__ faces,
                                                      int V, float* __restrict__ g_ndc, const float* __restrict__ l1_target,
                                                      const int32_t* __restrict__ l1_fid, const float* __restrict__ l1_w,
-                                                     float* __restrict__ l1_loss, float* __restrict__ l1_grad, float l1_inv, int sparse) {
+                                                     float* __restrict__ l1_loss, float* __restrict__ l1_grad, float l1_inv, int sparse,
+                                                     const float* __restrict__ l1_bg_sums) {
   __shared__ float4 s_a[kStage], s_b[kStage], s_bb[kStage];
   __shared__ float s_z2[kStage];
   __shared__ float4 s_fc[MODE == 1 ? kStage : 1];      // per staged face: sign of the area, squared edge lengths l12, l20, l01
@@ -202,6 +205,14 @@ __global__ void __launch_bounds__(256) raster_kernel(const FaceRec* __restrict__
     // super-tile without a single face.  Backward: nothing to do.  Forward: its first workgroup writes the empty-pixel outputs (and
     // the fused silhouette L1 against alpha = 0) for all 64x64 pixels, the other 15 leave at once.
     if (MODE == 2 || sub != 0) return;
+    if (MODE == 1 && sparse && l1_target && l1_bg_sums) {
+      // nothing to write, and the loss of an un-rendered super-tile against a static target is a constant: one table look-up
+      if (threadIdx.x == 0) {
+        const float sum = l1_bg_sums[(size_t)l1_fid[b] * nst_of(nsx) + st];
+        if (sum != 0.f) atomicAdd(l1_loss, sum * l1_inv);
+      }
+      return;
+    }
     float acc = 0.f;
     float tg[16];
     const bool l1 = (MODE == 1) && l1_target != nullptr;
@@ -515,7 +526,8 @@ size_t harp_rasterize_ws_bytes(int B, int F, int S) {
 // g_alpha = w * d loss / d alpha.  y_sil == NULL: plain rasterisation.
 int harp_rasterize_l1_fwd(const float* ndc, const int32_t* faces, int B, int V, int F, int S, int soft, float blur_radius,
                           float sigma, void* ws, int32_t* face_id, float* zbuf, float* alpha, const float* l1_target,
-                          const int32_t* l1_fid, const float* l1_w, float* l1_loss, float* l1_grad, hipStream_t stream) {
+                          const int32_t* l1_fid, const float* l1_w, float* l1_loss, float* l1_grad, const float* l1_bg_sums,
+                          hipStream_t stream) {
   if (!ndc || !faces || !ws || !face_id || B <= 0 || F <= 0 || S <= 0 || ((soft & 1) && !alpha)) return HARP_ERR_ARG;
   if (l1_target && (!(soft & 1) || !l1_fid || !l1_w || !l1_loss || !l1_grad)) return HARP_ERR_ARG;
   const RasterWs W = raster_ws_split(ws, B, F, S);
@@ -529,10 +541,10 @@ int harp_rasterize_l1_fwd(const float* ndc, const int32_t* faces, int B, int V, 
   if (soft & 1)
     hipLaunchKernelGGL(raster_kernel<1>, grid, dim3(256), 0, stream, recs, bbs, bins, cnt, order, W.nact, B, F, S, nsx, blur_radius, sigma,
                        face_id, zbuf, alpha, nullptr, nullptr, 0, nullptr, l1_target, l1_fid, l1_w, l1_loss, l1_grad,
-                       1.0f / ((float)B * (float)S * (float)S), (soft & 2) ? 1 : 0);
+                       1.0f / ((float)B * (float)S * (float)S), (soft & 2) ? 1 : 0, l1_bg_sums);
   else
     hipLaunchKernelGGL(raster_kernel<0>, grid, dim3(256), 0, stream, recs, bbs, bins, cnt, order, W.nact, B, F, S, nsx, 0.f, 1.f, face_id, zbuf,
-                       nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, (soft & 2) ? 1 : 0);
+                       nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, (soft & 2) ? 1 : 0, nullptr);
   HARP_CHECK_LAUNCH();
   return HARP_OK;
 }
@@ -540,7 +552,7 @@ int harp_rasterize_l1_fwd(const float* ndc, const int32_t* faces, int B, int V, 
 int harp_rasterize_fwd(const float* ndc, const int32_t* faces, int B, int V, int F, int S, int soft, float blur_radius,
                        float sigma, void* ws, int32_t* face_id, float* zbuf, float* alpha, hipStream_t stream) {
   return harp_rasterize_l1_fwd(ndc, faces, B, V, F, S, soft, blur_radius, sigma, ws, face_id, zbuf, alpha, nullptr, nullptr, nullptr,
-                               nullptr, nullptr, stream);
+                               nullptr, nullptr, nullptr, stream);
 }
 
 // Soft-silhouette backward: g_alpha (B,S,S) -> accumulates (atomicAdd) into g_ndc (B,V,3) (x,y components).
@@ -553,7 +565,7 @@ int harp_silhouette_bwd(const int32_t* faces, int B, int V, int F, int S, float 
   const int nsx = W.nsx;
   const dim3 grid(tile_grid(B, nsx));
   hipLaunchKernelGGL(raster_kernel<2>, grid, dim3(256), 0, stream, recs, bbs, bins, cnt, order, W.nact, B, F, S, nsx, blur_radius, sigma, nullptr,
-                     nullptr, (float*)alpha, g_alpha, faces, V, g_ndc, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0);
+                     nullptr, (float*)alpha, g_alpha, faces, V, g_ndc, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0, nullptr);
   HARP_CHECK_LAUNCH();
   return HARP_OK;
 }

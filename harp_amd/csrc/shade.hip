@@ -253,6 +253,14 @@ __global__ void __launch_bounds__(256, SHADE_OCC) shade_kernel(const harp_shade_
     // super-tile without a single face (3/4 of the launch): no gradient in the backward pass; in the forward pass its first workgroup
     // writes the background colour for all 64x64 pixels and the other 15 leave at once
     if (BWD || tsub != 0 || (!A.rgb && !A.l1_target)) return;
+    if (!A.rgb && A.l1_bg_sums) {
+      // loss-only mode against static targets: the background term of this super-tile is a constant, looked up
+      if (threadIdx.x == 0) {
+        const float sum = A.l1_bg_sums[(size_t)A.l1_fid[b] * nsx * nsx + st_unused];
+        if (sum != 0.f) atomicAdd(A.l1_loss, sum * A.l1_inv);
+      }
+      return;
+    }
     // background colour everywhere; the fused photometric term still counts these pixels where the mask is set (|bg - y| m), they
     // only have no gradient
     float acc = 0.f;

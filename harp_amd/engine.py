@@ -28,6 +28,7 @@ from .manopth.manolayer import ManoDeviceModel
 LOSS_NAMES = ["silhouette", "kps_anchor", "vert_disp_reg", "laplacian", "normal", "arap", "photo", "albedo", "normal_reg"]
 LOSS_WEIGHTS = {"silhouette": 7.0, "kps_anchor": 10.0, "vert_disp_reg": 2.0, "laplacian": 4.0, "normal": 0.1, "arap": 0.2,
                 "photo": 1.0, "albedo": 0.5, "normal_reg": 0.1}                     # optimize_sequence.py:411-422 (vgg: §8f "next")
+BG_COLOR = (1.0, 1.0, 1.0)          # background of the shading pass (renderer_helper.py BlendParams default)
 COARSE_TERMS = LOSS_NAMES[:6]
 APP_TERMS = LOSS_NAMES[6:]
 
@@ -134,6 +135,7 @@ class FitEngine:
         self._hyper_stride = self.hyper_np.dtype.itemsize
         # ---- targets (set by set_targets) and per-step scratch
         self.y_true = self.y_sil = self.y_sil_col = None
+        self.bg_sil = self.bg_photo = None
         self.target_offset = 0
         self.w_vec = torch.zeros(16, dtype=torch.float32, device=self.dev)
         self._main["loss_vec"], self._main["w_vec"] = self.loss_vec, self.w_vec
@@ -215,6 +217,18 @@ class FitEngine:
         self.y_sil = y_sil.to(self.dev).float().contiguous()
         self.y_sil_col = y_sil_col.to(self.dev).float().contiguous()
         self.target_offset = int(frame_offset)
+        # the targets are static during a fit: what an un-rendered 64x64 super-tile contributes to the two image terms is a constant per
+        # (target frame, super-tile) — sum of y_sil for the silhouette L1 (alpha = 0), sum of |bg - y| * mask for the photometric L1 —
+        # tabulated once here; the loss-only kernels (keep_image = False) look it up instead of reading 3/4 of the targets every step
+        T, S, nsx = self.y_sil.shape[0], self.S, (self.S + 63) // 64
+        pad = nsx * 64 - S
+        def tile_sums(img):                                                          # (T,S,S) -> (T, nsx*nsx), super-tile st = sy * nsx + sx
+            x = torch.nn.functional.pad(img.double(), (0, pad, 0, pad))
+            return x.reshape(T, nsx, 64, nsx, 64).sum((2, 4)).reshape(T, nsx * nsx).float().contiguous()
+        self.bg_sil = tile_sums(self.y_sil)
+        bg = torch.tensor(BG_COLOR, dtype=torch.float32, device=self.dev)
+        m = self.y_sil_col.unsqueeze(-1)
+        self.bg_photo = tile_sums((bg * m - self.y_true * m).abs().sum(-1))
         if getattr(self, "perceptual", None) is not None:                            # cached target features belong to the old targets
             self.set_perceptual(self.perceptual, self.perceptual_weight, autocast=self._vgg_autocast)
 
@@ -272,10 +286,11 @@ class FitEngine:
         s, tp = self.s, self.topo
         a = ops._shade_args(s["face_c"], s["ws_c"], tp, s["vd"][:B], s["n2"][:B], self.params["texture"][0], s["nmap_n"], s["light_pos"],
                             s["colors"], s["zl"] if self.self_shadow else None, s["light_R"] if self.self_shadow else None,
-                            s["light_T"] if self.self_shadow else None, self.S, self.focal, (self.S / 2.0, self.S / 2.0), (1.0, 1.0, 1.0))
+                            s["light_T"] if self.self_shadow else None, self.S, self.focal, (self.S / 2.0, self.S / 2.0), BG_COLOR)
         a.B = B
         # the fused photometric L1 needs no materialised image: with keep_image = False (fitting loops) the 4 MB / frame write is skipped
         a.rgb = _lib.ptr(s["rgb"]) if (self.keep_image or self.perceptual is not None) else None
+        a.l1_bg_sums = _lib.ptr(self.bg_photo) if self.bg_photo is not None else None
         if self.packed_texels:
             a.texnm = _lib.ptr(self.texnm)
         for k, t in (("g_rgb", s["g_rgb"]), ("g_tex", self.grads["texture"]), ("g_nmap", s["g_nmap_n"]), ("g_verts", s["g_vd"]),
@@ -366,7 +381,8 @@ class FitEngine:
             # backward skip them): soft = 3 leaves those 3/4 of the three images unwritten
             sparse = 0 if (self.keep_image or self.perceptual is not None) else 2
             self._ck(L.harp_rasterize_l1_fwd(p(s["ndc_c"]), p(tp.faces), B, V, F, S, 1 | sparse, ops.SIL_BLUR, ops.SIL_SIGMA, p(s["ws_c"]), p(s["face_c"]),
-                                             None, p(s["alpha"]), p(self.y_sil) if coarse else None, p(ltfid), wp(0), lp(0), p(s["g_alpha"]), ST()),
+                                             None, p(s["alpha"]), p(self.y_sil) if coarse else None, p(ltfid), wp(0), lp(0), p(s["g_alpha"]),
+                                             p(self.bg_sil) if sparse else None, ST()),
                      "raster_cam")
         if self.camera_first:
             fork = cur.record_event()                   # fork point = end of the mesh chain, before the camera-view launches

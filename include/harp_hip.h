@@ -38,9 +38,13 @@ int harp_rasterize_fwd(const float* ndc, const int32_t* faces, int B, int V, int
 /* soft bit 0: soft silhouette on.  soft bit 1 (value 2): SPARSE outputs — face_id / alpha / l1_grad are left unwritten in 64x64
  * super-tiles that hold no face (their contribution to the loss is still accumulated; zbuf is always written everywhere).  For callers whose consumers skip those super-tiles too
  * (harp_shade_*, harp_silhouette_bwd do): 3/4 of a hand image is such background. */
+/* l1_bg_sums (optional, used with sparse outputs): (T, nsx*nsx) per target frame and 64x64 super-tile, the term's sum over the
+ * super-tile when nothing is rendered there (sum of y_sil) — targets are static during a fit, so the background part of the loss is
+ * a table look-up instead of a pass over 3/4 of the target image every step. */
 int harp_rasterize_l1_fwd(const float* ndc, const int32_t* faces, int B, int V, int F, int S, int soft, float blur_radius,
                           float sigma, void* ws, int32_t* face_id, float* zbuf, float* alpha, const float* l1_target,
-                          const int32_t* l1_fid, const float* l1_w, float* l1_loss, float* l1_grad, hipStream_t stream);
+                          const int32_t* l1_fid, const float* l1_w, float* l1_loss, float* l1_grad, const float* l1_bg_sums,
+                          hipStream_t stream);
 /* replaces _C.rasterize_meshes_backward (grad_dists path) + sigmoid_alpha_blend backward; g_ndc (B,V,3) (+=) */
 int harp_silhouette_bwd(const int32_t* faces, int B, int V, int F, int S, float blur_radius, float sigma, const void* ws,
                         const float* alpha, const float* g_alpha, float* g_ndc, hipStream_t stream);
@@ -102,6 +106,10 @@ typedef struct harp_shade_args {
   float l1_inv;             /* filled in by harp_shade_fwd */
   /* optional (fwd and bwd): the SAME tex / nmap interleaved by harp_pack_texels; halves the cache lines of the bilinear footprint */
   const void* texnm;
+  /* optional, used when rgb == NULL: (T, nsx*nsx) per target frame and 64x64 super-tile, sum over its pixels and channels of
+   * |bg_c - y_c| * mask — the photometric term of a super-tile that holds no face (static targets: a table instead of reading mask
+   * and target of 3/4 of the image every step) */
+  const float* l1_bg_sums;
 } harp_shade_args;
 /* interleaves albedo (Ht*Wt,3) and the normalised normal map (Ht*Wt,3) into out (Ht*Wt,8): [r g b nx | ny nz 0 0], 16-B aligned */
 int harp_pack_texels(const float* tex, const float* nmap, int n_texels, float* out, hipStream_t stream);

@@ -85,7 +85,7 @@ def test_rasterizer_and_silhouette(sc):
     tf = torch.tensor([1, 0], dtype=torch.int32, device=DEV)                     # frame b compares against target tf[b]
     w, loss, g = torch.tensor([7.0], device=DEV), torch.zeros(1, device=DEV), torch.full((B, S, S), 9.0, device=DEV)
     _lib.check(L.harp_rasterize_l1_fwd(p(mixed), p(faces_d), B, V, F, S, 1, ops.SIL_BLUR, ops.SIL_SIGMA, p(ws), p(fi), None, p(al), p(y), p(tf),
-                                       p(w), p(loss), p(g), _lib.stream()), "harp_rasterize_l1_fwd")
+                                       p(w), p(loss), p(g), None, _lib.stream()), "harp_rasterize_l1_fwd")
     a_un, _ = ops.soft_silhouette(mixed, faces_d, S)
     assert torch.equal(al, a_un.detach()) and (al[0] == 0).all() and (fi[0] == -1).all()
     d = al - y[tf.long()]
