@@ -547,10 +547,14 @@ def test_losses_with_empty_supertiles():
             P = oracle_params(sc, eng.params)
             with torch.no_grad():
                 _, rv = H.prepare_mesh(P, torch.tensor([0]), sc["model"], sc["topo"])
-            ref, total, _ = H.step_losses(P, fid, sc["model"], sc["topo"], tg, S, sc["focal"], rv, eng.dist_albedo.cpu().long(),
-                                          eng.dist_normal.cpu().long())
+            ref, total, aux = H.step_losses(P, fid, sc["model"], sc["topo"], tg, S, sc["focal"], rv, eng.dist_albedo.cpu().long(),
+                                            eng.dist_normal.cpu().long())
             total.backward()
             gref = {k: P[k].grad.clone() for k in ("pose", "cam", "texture", "shape")}
+        if keep:            # full images, background super-tiles included
+            assert ((eng.s["alpha"].cpu() - aux["y_sil_pred"]).abs() > 1e-4).float().mean() < 1e-3
+            assert ((eng.s["rgb"].cpu() - aux["y_pred"]).abs().max(-1).values > 1e-4).float().mean() < 1e-3
+            assert (eng.s["face_c"] >= 0).float().mean() > 0.02
         lv = eng.losses()
         for k in LOSS_NAMES:
             assert abs(lv[k] - ref[k].item()) <= 1e-5 * abs(ref[k].item()) + 1e-8, (keep, k, lv[k], ref[k].item())
