@@ -118,7 +118,7 @@ SIGNATURES.update({
     "harp_light_setup_fwd": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
     "harp_light_setup_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
     "harp_scale": (_i, [_vp, _f, _i, _vp, _vp]),
-    "harp_schedule_next": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "harp_schedule_next": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp]),
 })
 
 SIGNATURES.update({

@@ -164,6 +164,7 @@ class FitEngine:
         self.schedule = None
         self._stage = None
         self._early_work = None
+        self._loss_cleared = False
         self.perceptual = None           # optional VGG feature term of the appearance stage (set_perceptual)
         self.compute_reference_mesh()
 
@@ -316,9 +317,16 @@ class FitEngine:
         if shared_terms and not lane.get("owns_shared"):
             self.g_buf.zero_()
             self.g_nmap_n.zero_()
-        self.gs_zero.zero_()                             # main lane: one fill also covers g_buf, g_nmap_n and the loss vector
-        if not lane.get("owns_shared"):
-            lloss.zero_()
+        # the loss vector is the only cleared buffer the main stream touches before it joins the second one: when schedule_next has
+        # cleared it already, the big slab clear moves to the second stream, off the head of the step
+        fill_side = self._loss_cleared and self.early_terms and self.overlap and bool(lane.get("owns_shared"))
+        self._loss_cleared = False
+        if fill_side:
+            pass
+        else:
+            self.gs_zero.zero_()                         # main lane: one fill also covers g_buf, g_nmap_n and the loss vector
+            if not lane.get("owns_shared"):
+                lloss.zero_()
         shadow = app and self.self_shadow
         if not self.overlap:
             side = cur                                   # single-stream mode (used when individual kernels are timed with events)
@@ -326,6 +334,8 @@ class FitEngine:
         # ---- terms that depend on the parameters only (normal-map normalisation, texture regularisers, displacement regulariser) go
         #      first on the second stream: they run under the LBS / mesh chain, which is a string of small latency-bound launches
         def param_terms():
+            if fill_side:
+                self.gs_zero[:-16].zero_()               # everything but the loss vector (last 16 floats of the slab)
             self.gs_zero_late.zero_()
             if tick:
                 self._adam_tick(coarse, app)             # only touches the hyper-parameter block: off the serial tail of the step
@@ -614,9 +624,11 @@ class FitEngine:
         self._graphs = {}                               # graphs captured against an older schedule buffer are stale
 
     def _schedule_next(self):
+        # the same launch clears the loss vector: with it gone from the slab clear, that one runs on the second stream (forward_backward)
         self._ck(_lib.lib().harp_schedule_next(_lib.ptr(self.schedule), int(self.schedule.shape[0]), self.B, self.target_offset,
-                                               _lib.ptr(self.schedule_row), _lib.ptr(self.fid), _lib.ptr(self.tfid), _lib.stream()),
-                 "schedule_next")
+                                               _lib.ptr(self.schedule_row), _lib.ptr(self.fid), _lib.ptr(self.tfid), _lib.ptr(self.loss_vec), 16,
+                                               _lib.stream()), "schedule_next")
+        self._loss_cleared = True
 
     def step(self, fid, coarse=True, app=True, use_graph=True):
         """One optimisation step on the frames `fid` (global frame ids, length <= batch_size; a shorter — last, partial —

@@ -325,7 +325,7 @@ int harp_scale(const float* x, float s, int n, float* y, hipStream_t stream);
 /* replaces the DataLoader's batch of frame ids (optimize_sequence.py:396-399, :446): row (counter[0] mod n_rows) of a device-resident
  * (n_rows,B) int32 schedule -> fid (B,), tfid = fid - target_offset; then counter[0] = row + 1.  Graph-replayable. */
 int harp_schedule_next(const int32_t* schedule, int n_rows, int B, int target_offset, int32_t* counter, int32_t* fid, int32_t* tfid,
-                       hipStream_t stream);
+                       float* zero, int n_zero, hipStream_t stream);   /* zero (optional): n_zero floats cleared in the same launch (loss vector) */
 
 #ifdef __cplusplus
 }
