@@ -282,7 +282,9 @@ def main():
                       "frames_per_gpu_per_step": eng.B, "global_batch": world * eng.B, "sequence_frames": eng.T,
                       "parallelism": f"dp{world} (frames sharded; flat gradient bucket of {eng.opt_span[1] * 4} B all-reduced over RCCL: the texture/normal-map "
                                      f"part overlapped with the mesh backward, the remainder before Adam)",
-                      "hipgraph": (not args.no_graph) and world == 1},
+                      "hipgraph": (not args.no_graph) and world == 1,
+                      "rendered_image": "consumed inside the shader by the fused photometric L1 (loss, gradient and parameter update are the "
+                                        "step's outputs; the reference's y_pred temporary is not written to HBM — FitEngine.keep_image=True writes it)"},
            "losses_finite": finite}
     if consistent is not None:
         out["ranks_consistent"] = consistent
