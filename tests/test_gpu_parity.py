@@ -203,6 +203,18 @@ def test_full_size_properties():
     a1, f1, r1 = eng.s["alpha"].clone(), eng.s["face_c"].clone(), eng.s["rgb"].clone()
     eng.forward_backward(True, True); torch.cuda.synchronize()
     assert torch.equal(a1, eng.s["alpha"]) and torch.equal(f1, eng.s["face_c"]) and torch.equal(r1, eng.s["rgb"])
+    # the loss-only mode of the fitting loop / bench.py (no image written, background super-tiles neither written nor read, their loss
+    # from the static-target tables) gives the same losses and gradients at full size
+    eng.auto_draw = False
+    full = (eng.losses(), eng.g_buf.clone())
+    eng.keep_image = False
+    eng.forward_backward(True, True); torch.cuda.synchronize()
+    lean = (eng.losses(), eng.g_buf.clone())
+    for k, v in full[0].items():
+        assert abs(v - lean[0][k]) <= 2e-6 * abs(v) + 1e-12, (k, v, lean[0][k])
+    assert rel(lean[1].cpu(), full[1].cpu()) < 1e-5
+    nact = int(eng.s["ws_c"][-256:].view(torch.int32)[0])
+    assert 0 < nact < 32 * 64 // 2                      # most 64x64 super-tiles of a hand image are background
 
 
 def test_smplx_arm_lbs_vs_oracle():
