@@ -285,8 +285,9 @@ def main():
                       "parallelism": f"dp{world} (frames sharded; flat gradient bucket of {eng.opt_span[1] * 4} B all-reduced over RCCL: the texture/normal-map "
                                      f"part overlapped with the mesh backward, the remainder before Adam)",
                       "hipgraph": (not args.no_graph) and world == 1,
-                      "rendered_image": "consumed inside the shader by the fused photometric L1 (loss, gradient and parameter update are the "
-                                        "step's outputs; the reference's y_pred temporary is not written to HBM — FitEngine.keep_image=True writes it)"},
+                      "rendered_image": "not materialised: the shader backward recomputes the colour and forms the photometric L1 and its gradient "
+                                        "itself, so the step has no forward shading launch (loss, gradients and the parameter update are its "
+                                        "outputs; FitEngine.keep_image=True renders and writes y_pred like the reference)"},
            "losses_finite": finite}
     if consistent is not None:
         out["ranks_consistent"] = consistent
@@ -298,11 +299,13 @@ def main():
         # dominant kernel: the fused camera-view rasteriser (K=1 + soft silhouette); its algorithmic bytes per frame are the
         # rasteriser sub-figure of SURVEY.md §8(d): geom_pos + S^2*(4+4+12+4) for the K=1 fragment set + S^2*4 for alpha
         dom = max(kt, key=kt.get)
+        fused = "harp_shade_fwd" not in kt           # loss-only mode: the photometric L1 is formed inside the shader backward
         geom_pos = parts["V"] * 12 + parts["F"] * 12
         alg = {"raster_cam_fwd(setup+bin+raster)": (geom_pos + parts["S2"] * 24 + parts["S2"] * 4 + parts["S2"] * 8) * eng.B,   # + fused silhouette L1: mask in, g_alpha out
                "raster_light_fwd(setup+bin+raster)": (geom_pos + parts["S2"] * 24) * eng.B,
                "harp_shade_fwd": (parts["geom"] + parts["S2"] * (4 + (12 if eng.keep_image else 0) + 4 + 12 + 4 + 12)) * eng.B,   # + fused photometric L1: y_true, mask in, g_rgb out; the image itself only if kept
-               "harp_shade_bwd": (parts["geom"] + parts["V"] * 36 + parts["S2"] * (4 + 12 + 4 + 4)) * eng.B + 2 * eng.Ht * eng.Wt * 12,
+               # (fused-loss mode: no forward launch; the backward pass reads target + mask instead of the gradient image)
+               "harp_shade_bwd": (parts["geom"] + parts["V"] * 36 + parts["S2"] * (4 + (12 + 4 if fused else 12) + 4 + 4)) * eng.B + 2 * eng.Ht * eng.Wt * 12,
                "harp_silhouette_bwd": (geom_pos + parts["S2"] * 8 + parts["V"] * 12) * eng.B,
                "harp_depth_bwd": (geom_pos + parts["S2"] * 8 + parts["V"] * 12) * eng.B}
         ach = alg[dom] / (kt[dom] * 1e-3) / 1e9

@@ -247,13 +247,17 @@ __global__ void __launch_bounds__(256, SHADE_OCC) shade_kernel(const harp_shade_
   // one 16x16 tile per workgroup, dispatched in the rasteriser's heaviest-first super-tile order (harp_common.h: tile_decode): the
   // tiles with covered pixels run first and densely instead of interleaved with the ~80 % background tiles.
   int b, st_unused, tx0, ty0, tsub;
-  const int kind = tile_decode(order, nact, A.B, nsx, S, b, st_unused, tx0, ty0, tsub, !BWD);
+  // backward pass with l1_target set and g_rgb == NULL = FUSED-LOSS mode: no forward launch at all — the backward pass recomputes the
+  // colour anyway, so it also forms the photometric L1 (value and gradient) itself; the forward kernel's only remaining products in a
+  // fitting step were that loss and a gradient image the backward pass read back.
+  const bool fused_loss = BWD && A.l1_target != nullptr && A.g_rgb == nullptr;
+  const int kind = tile_decode(order, nact, A.B, nsx, S, b, st_unused, tx0, ty0, tsub, !BWD || fused_loss);
   if (kind == 0) return;
   if (kind == 2) {
     // super-tile without a single face (3/4 of the launch): no gradient in the backward pass; in the forward pass its first workgroup
     // writes the background colour for all 64x64 pixels and the other 15 leave at once
-    if (BWD || tsub != 0 || (!A.rgb && !A.l1_target)) return;
-    if (!A.rgb && A.l1_bg_sums) {
+    if ((BWD && !fused_loss) || tsub != 0 || (!A.rgb && !A.l1_target)) return;
+    if ((!A.rgb || BWD) && A.l1_bg_sums) {
       // loss-only mode against static targets: the background term of this super-tile is a constant, looked up
       if (threadIdx.x == 0) {
         const float sum = A.l1_bg_sums[(size_t)A.l1_fid[b] * nsx * nsx + st_unused];
@@ -277,7 +281,7 @@ __global__ void __launch_bounds__(256, SHADE_OCC) shade_kernel(const harp_shade_
       int xi, yi;
       supertile_pixel(k, tx0, ty0, xi, yi);
       if (xi < S && yi < S) {
-        if (A.rgb) { float* r = A.rgb + (((size_t)b * S + yi) * S + xi) * 3; r[0] = A.bg[0]; r[1] = A.bg[1]; r[2] = A.bg[2]; }
+        if (!BWD && A.rgb) { float* r = A.rgb + (((size_t)b * S + yi) * S + xi) * 3; r[0] = A.bg[0]; r[1] = A.bg[1]; r[2] = A.bg[2]; }
         const float m = mk_[k];
         if (m != 0.f) {
           const float* t = A.l1_target + (tbase + (size_t)yi * S + xi) * 3;
@@ -294,17 +298,32 @@ __global__ void __launch_bounds__(256, SHADE_OCC) shade_kernel(const harp_shade_
   constexpr int R = 1;
   if (BWD) {
     bool any_act = false;
+    float bg_loss = 0.f;
 #pragma unroll
     for (int sub = 0; sub < R * R; ++sub) {
       const int xi = tx0 + (lane & 15), yi = ty0 + w * 4 + (lane >> 4);
       if (xi < S && yi < S) {
         const size_t o = ((size_t)b * S + yi) * S + xi;
-        if (A.face_id[o] >= 0) {
+        const bool hit = A.face_id[o] >= 0;
+        if (fused_loss) {
+          const size_t to = ((size_t)A.l1_fid[b] * S + yi) * S + xi;
+          const float m = A.l1_mask ? A.l1_mask[to] : 1.f;
+          any_act |= hit && (m != 0.f);
+          if (!hit && m != 0.f) {        // uncovered pixel inside the mask: background colour against the target, no gradient
+            const float* t = A.l1_target + to * 3;
+            bg_loss += fabsf(A.bg[0] * m - t[0] * m) + fabsf(A.bg[1] * m - t[1] * m) + fabsf(A.bg[2] * m - t[2] * m);
+          }
+        } else if (hit) {
           const V3 gq = ld(A.g_rgb + o * 3);
           any_act |= (gq.x != 0.f || gq.y != 0.f || gq.z != 0.f);
         }
       }
     }
+    if (fused_loss) {
+      const float sum = block_sum_256(bg_loss, s_red);
+      if (threadIdx.x == 0 && sum != 0.f) atomicAdd(A.l1_loss, sum * A.l1_inv);
+    }
+    __syncthreads();
     if (threadIdx.x < 32) s_red[threadIdx.x] = 0.f;
     if (__syncthreads_or(any_act ? 1 : 0) == 0) return;
     s_acc.clear();
@@ -323,7 +342,15 @@ __global__ void __launch_bounds__(256, SHADE_OCC) shade_kernel(const harp_shade_
   const int f = in_img ? A.face_id[o] : -1;
   V3 gc = mk(0.f, 0.f, 0.f);
   bool act = f >= 0;
-  if (BWD) {
+  float l1_m = 0.f;
+  size_t l1_to = 0;
+  if (BWD && fused_loss) {
+    if (act) {
+      l1_to = ((size_t)A.l1_fid[b] * S + yi) * S + xi;
+      l1_m = A.l1_mask ? A.l1_mask[l1_to] : 1.f;
+    }
+    act = act && (l1_m != 0.f);
+  } else if (BWD) {
     if (act) gc = ld(A.g_rgb + o * 3);
     act = act && (gc.x != 0.f || gc.y != 0.f || gc.z != 0.f);
   } else if (!act) {
@@ -433,6 +460,20 @@ __global__ void __launch_bounds__(256, SHADE_OCC) shade_kernel(const harp_shade_
       if (A.rgb) { float* r = A.rgb + o * 3; r[0] = out_rgb[0]; r[1] = out_rgb[1]; r[2] = out_rgb[2]; }
     } else {
       const float wk = wnum * rcp(denom);
+      if (fused_loss) {
+        // the forward colour of this pixel, the L1 against the target and its gradient (same expressions as the forward kernel)
+        const float rden = rcp(denom);
+        const float o3[3] = {(wnum * c.x + delta * A.bg[0]) * rden, (wnum * c.y + delta * A.bg[1]) * rden, (wnum * c.z + delta * A.bg[2]) * rden};
+        const float wl = A.l1_w[0] * A.l1_inv * l1_m;
+        float gq[3];
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+          const float d = o3[ch] * l1_m - A.l1_target[l1_to * 3 + ch] * l1_m;
+          racc[16] += fabsf(d);
+          gq[ch] = wl * (float)((d > 0.f) - (d < 0.f));
+        }
+        gc = mk(gq[0], gq[1], gq[2]);
+      }
       const V3 g_c = gc * wk;
       // c = lightc * texel + spec
       const V3 g_tex = mk(g_c.x * lightc.x, g_c.y * lightc.y, g_c.z * lightc.z);
@@ -618,6 +659,10 @@ __global__ void __launch_bounds__(256, SHADE_OCC) shade_kernel(const harp_shade_
     if (threadIdx.x == 0 && sum != 0.f) atomicAdd(A.l1_loss, sum * A.l1_inv);
   }
   }   // sub-tile loop
+  if (BWD && fused_loss) {
+    const float sum = block_sum_256(racc[16], s_red + 16);      // (s_red[0..15] are the scalar-gradient accumulators below)
+    if (threadIdx.x == 0 && sum != 0.f) atomicAdd(A.l1_loss, sum * A.l1_inv);
+  }
   if (BWD) {
     // block-level reduction of the 16 per-frame / global scalars, then one atomic each
 #pragma unroll
@@ -776,9 +821,18 @@ int harp_shade_fwd(const harp_shade_args* a, hipStream_t stream) {
 }
 
 int harp_shade_bwd(const harp_shade_args* a, hipStream_t stream) {
-  if (!a || !a->face_id || !a->recs || !a->g_rgb || !a->g_verts || !a->g_vnormals || !a->g_ndc) return HARP_ERR_ARG;
+  if (!a || !a->face_id || !a->recs || !a->g_verts || !a->g_vnormals || !a->g_ndc) return HARP_ERR_ARG;
+  harp_shade_args b = *a;
+  if (!b.g_rgb) {
+    // fused-loss mode (no harp_shade_fwd call at all): the photometric L1 and its gradient are formed here; the background part of
+    // the term in super-tiles without a face comes from the static-target table, which is mandatory in this mode
+    if (!b.l1_target || !b.l1_fid || !b.l1_w || !b.l1_loss || !b.l1_bg_sums) return HARP_ERR_ARG;
+    b.l1_inv = 1.0f / ((float)b.B * (float)b.S * (float)b.S * 3.0f);
+  } else {
+    b.l1_target = nullptr;          // a caller that hands over the gradient image gets the plain backward pass
+  }
   const RasterWs W = raster_ws_split((void*)a->recs, a->B, a->F, a->S);
-  hipLaunchKernelGGL(shade_kernel<true>, dim3(tile_grid(a->B, W.nsx)), dim3(256), 0, stream, *a, (const int32_t*)W.order, (const int32_t*)W.nact, W.nsx);
+  hipLaunchKernelGGL(shade_kernel<true>, dim3(tile_grid(a->B, W.nsx)), dim3(256), 0, stream, b, (const int32_t*)W.order, (const int32_t*)W.nact, W.nsx);
   HARP_CHECK_LAUNCH();
   return HARP_OK;
 }

@@ -157,6 +157,7 @@ class FitEngine:
         self.overlap_allreduce = True    # N > 1: all-reduce of the map gradients overlapped with the mesh / LBS backward
         self.graph_collectives = False   # N > 1: capture the RCCL all-reduce into the step graph (verified on 1 rank only)
         self.force_allreduce = False     # run the N > 1 code path on a single rank (tests, bench HARP_FORCE_DIST)
+        self.fused_loss = bool(int(os.environ.get("HARP_FUSED_LOSS", "1")))   # loss-only mode: photometric L1 formed inside the shader backward
         self.keep_image = True           # shader forward writes the rendered image s["rgb"] (False: loss + gradient only)
         self.mesh_terms_first = True     # key-point term + mesh regularisers run before the light raster (under the raster set-up) instead of after it
         self.camera_first = True        # enqueue the camera-view raster chain (the longer one) before the light-view chain: +0.75 %
@@ -416,7 +417,13 @@ class FitEngine:
             # the photometric L1 term and its gradient are fused into the shader (no separate pass over the image)
             a.l1_target, a.l1_mask, a.l1_fid = p(self.y_true), p(self.y_sil_col), p(ltfid)
             a.l1_w, a.l1_loss, a.l1_grad = wp(6), lp(6), p(s["g_rgb"])
-            self._ck(L.harp_shade_fwd(ctypes.byref(a), ST()), "shade_fwd")
+            # fitting loop (no image kept, no perceptual term): there is no forward shading launch — the backward pass recomputes the
+            # colour anyway and forms the photometric L1 and its gradient itself (harp_shade_bwd with g_rgb == NULL)
+            fused_loss = self.fused_loss and not self.keep_image and self.perceptual is None and self.bg_photo is not None
+            if fused_loss:
+                a.g_rgb = None
+            else:
+                self._ck(L.harp_shade_fwd(ctypes.byref(a), ST()), "shade_fwd")
             if self.perceptual is not None:
                 self._perceptual_term(B, ltfid, lloss)
         # ---- backward
