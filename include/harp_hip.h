@@ -114,6 +114,9 @@ typedef struct harp_shade_args {
 /* interleaves albedo (Ht*Wt,3) and the normalised normal map (Ht*Wt,3) into out (Ht*Wt,8): [r g b nx | ny nz 0 0], 16-B aligned */
 int harp_pack_texels(const float* tex, const float* nmap, int n_texels, float* out, hipStream_t stream);
 int harp_shade_fwd(const harp_shade_args* a, hipStream_t stream);
+/* backward of the shading pass.  g_rgb != NULL: plain backward of an upstream gradient image.  g_rgb == NULL (FUSED-LOSS mode, needs
+ * l1_target / l1_fid / l1_w / l1_loss / l1_bg_sums): no harp_shade_fwd call is needed at all — the pass recomputes the colour anyway,
+ * forms torch.nn.L1Loss(y_true * m, y_pred * m) (optimize_sequence.py:543) and its gradient itself and accumulates the loss value. */
 int harp_shade_bwd(const harp_shade_args* a, hipStream_t stream);
 
 /* ---- mesh preparation --------------------------------------------------------------------------------------------
