@@ -130,7 +130,7 @@ __global__ void __launch_bounds__(256) lbs_skin_kernel(const harp_mano_model M, 
                                                        const float* __restrict__ trans, const float* __restrict__ pose_map,
                                                        const float* __restrict__ A, int B, float* __restrict__ verts,
                                                        const float* __restrict__ g_verts, float* __restrict__ g_vp,
-                                                       float* __restrict__ Mo) {
+                                                       float* __restrict__ Mo, float* __restrict__ vposed) {
   // 64 vertices x 4 slices of the blend-shape index per workgroup: a lane walks 135/4 + 10/4 dependent load trips instead of 145
   // (the kernel is a chain of L2 round trips, not arithmetic: 16 workgroups of 256 vertices took 31 us), partial sums meet in LDS,
   // then every lane skins its vertex for the frames f = slice, slice + 4, ...
@@ -146,28 +146,33 @@ __global__ void __launch_bounds__(256) lbs_skin_kernel(const harp_mano_model M, 
   const bool ok = v < NV;
   const int vc = ok ? v : NV - 1;
   constexpr int kRowsP = (NP + kSkinSlices - 1) / kSkinSlices, kRowsB = (NB + kSkinSlices - 1) / kSkinSlices;
-  float pr[kRowsP][3], sr[kRowsB][3], w[NJ], tp[3];
+  float pr[BWD ? 1 : kRowsP][3], sr[BWD ? 1 : kRowsB][3], w[NJ], tp[3];
+  if (!BWD) {
 #pragma unroll
-  for (int u = 0; u < kRowsP; ++u) {
-    const int k = min(ks + u * kSkinSlices, NP - 1);
+    for (int u = 0; u < kRowsP; ++u) {
+      const int k = min(ks + u * kSkinSlices, NP - 1);
 #pragma unroll
-    for (int c = 0; c < 3; ++c) pr[u][c] = M.posedirs_T[k * NV * 3 + 3 * vc + c];
-  }
+      for (int c = 0; c < 3; ++c) pr[BWD ? 0 : u][c] = M.posedirs_T[k * NV * 3 + 3 * vc + c];
+    }
 #pragma unroll
-  for (int u = 0; u < kRowsB; ++u) {
-    const int k = min(ks + u * kSkinSlices, NB - 1);
+    for (int u = 0; u < kRowsB; ++u) {
+      const int k = min(ks + u * kSkinSlices, NB - 1);
 #pragma unroll
-    for (int c = 0; c < 3; ++c) sr[u][c] = M.shapedirs_T[k * NV * 3 + 3 * vc + c];
+      for (int c = 0; c < 3; ++c) sr[BWD ? 0 : u][c] = M.shapedirs_T[k * NV * 3 + 3 * vc + c];
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) tp[c] = (ks == 0) ? M.v_template[3 * vc + c] : 0.f;
   }
 #pragma unroll
   for (int j = 0; j < NJ; ++j) w[j] = M.weights[vc * NJ + j];
-#pragma unroll
-  for (int c = 0; c < 3; ++c) tp[c] = (ks == 0) ? M.v_template[3 * vc + c] : 0.f;
-  for (int i = threadIdx.x; i < nb * NP; i += 256) s_pm[i / NP][i % NP] = pose_map[b0 * NP + i];
-  for (int i = threadIdx.x; i < nb * NB; i += 256) s_beta[i / NB][i % NB] = betas[b0 * NB + i];
+  if (!BWD) {
+    for (int i = threadIdx.x; i < nb * NP; i += 256) s_pm[i / NP][i % NP] = pose_map[b0 * NP + i];
+    for (int i = threadIdx.x; i < nb * NB; i += 256) s_beta[i / NB][i % NB] = betas[b0 * NB + i];
+  }
   for (int i = threadIdx.x; i < nb * NJ * 12; i += 256) s_A[i / (NJ * 12)][i % (NJ * 12)] = A[b0 * NJ * 12 + i];
   __syncthreads();
-  float vp[FRAMES_PER_BLOCK][3];
+  float vp[BWD ? 1 : FRAMES_PER_BLOCK][3];
+  if (!BWD) {
 #pragma unroll
   for (int f = 0; f < FRAMES_PER_BLOCK; ++f) { vp[f][0] = tp[0]; vp[f][1] = tp[1]; vp[f][2] = tp[2]; }
 #pragma unroll
@@ -189,17 +194,25 @@ __global__ void __launch_bounds__(256) lbs_skin_kernel(const harp_mano_model M, 
 #pragma unroll
   for (int f = 0; f < FRAMES_PER_BLOCK; ++f)
 #pragma unroll
-    for (int c = 0; c < 3; ++c) s_part[ks][f * 3 + c][vl] = vp[f][c];
+    for (int c = 0; c < 3; ++c) s_part[ks][f * 3 + c][vl] = vp[BWD ? 0 : f][c];
   __syncthreads();
+  }   // !BWD
   if (!ok) return;
   for (int f = ks; f < nb; f += kSkinSlices) {
     float q[3];
+    if (!BWD) {
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      float a = 0.f;
+      for (int c = 0; c < 3; ++c) {
+        float a = 0.f;
 #pragma unroll
-      for (int sl = 0; sl < kSkinSlices; ++sl) a += s_part[sl][f * 3 + c][vl];
-      q[c] = a;
+        for (int sl = 0; sl < kSkinSlices; ++sl) a += s_part[sl][f * 3 + c][vl];
+        q[c] = a;
+      }
+      // the posed vertex is kept in the workspace for the backward pass: that kernel then needs neither the blend-shape rows (a DRAM
+      // round trip over 1.26 MB) nor the partial-sum exchange
+      for (int c = 0; c < 3; ++c) vposed[((size_t)(b0 + f) * NV + v) * 3 + c] = q[c];
+    } else {
+      for (int c = 0; c < 3; ++c) q[c] = vposed[((size_t)(b0 + f) * NV + v) * 3 + c];
     }
     float T[12];
 #pragma unroll
@@ -383,16 +396,17 @@ __global__ void __launch_bounds__(256) lbs_joints_bwd_kernel(const float* __rest
 extern "C" {
 
 size_t harp_lbs_mano_ws_floats(int B) {
-  // pose_map 135 | A 192 | j16 48 | Jrest 48 | Rloc 144 | G 192 | g_vp 2334 | M 9336 | g_A 192 | g_pm 135 | g_j16 48
-  return (size_t)B * (135 + 192 + 48 + 48 + 144 + 192 + 2334 + 9336 + 192 + 135 + 48);
+  // pose_map 135 | A 192 | j16 48 | Jrest 48 | Rloc 144 | G 192 | g_vp 2334 | M 9336 | g_A 192 | g_pm 135 | g_j16 48 | v_posed 2334
+  return (size_t)B * (135 + 192 + 48 + 48 + 144 + 192 + 2334 + 9336 + 192 + 135 + 48 + 2334);
 }
 
-struct LbsWs { float *pm, *A, *j16, *Jrest, *Rloc, *G, *g_vp, *Mo, *g_A, *g_pm, *g_j16; };
+struct LbsWs { float *pm, *A, *j16, *Jrest, *Rloc, *G, *g_vp, *Mo, *g_A, *g_pm, *g_j16, *vposed; };
 static LbsWs lbs_ws(float* ws, int B) {
   LbsWs w; float* p = ws;
   w.pm = p; p += (size_t)B * 135; w.A = p; p += (size_t)B * 192; w.j16 = p; p += (size_t)B * 48; w.Jrest = p; p += (size_t)B * 48;
   w.Rloc = p; p += (size_t)B * 144; w.G = p; p += (size_t)B * 192; w.g_vp = p; p += (size_t)B * 2334; w.Mo = p; p += (size_t)B * 9336;
-  w.g_A = p; p += (size_t)B * 192; w.g_pm = p; p += (size_t)B * 135; w.g_j16 = p;
+  w.g_A = p; p += (size_t)B * 192; w.g_pm = p; p += (size_t)B * 135; w.g_j16 = p; p += (size_t)B * 48;
+  w.vposed = p;      // posed vertices of the forward pass, read by the backward skinning kernel
   return w;
 }
 
@@ -402,7 +416,7 @@ int harp_lbs_mano_fwd(const harp_mano_model* m, const float* pose, const float* 
   const LbsWs w = lbs_ws(ws, B);
   hipLaunchKernelGGL(lbs_joints_kernel, dim3(B), dim3(64), 0, stream, *m, pose, betas, w.pm, w.A, w.j16, w.Jrest, w.Rloc, w.G);
   hipLaunchKernelGGL(lbs_skin_kernel<false>, dim3((NV + kSkinVerts - 1) / kSkinVerts, (B + FRAMES_PER_BLOCK - 1) / FRAMES_PER_BLOCK), dim3(256), 0, stream,
-                     *m, betas, trans, w.pm, w.A, B, verts, nullptr, nullptr, nullptr);
+                     *m, betas, trans, w.pm, w.A, B, verts, nullptr, nullptr, nullptr, w.vposed);
   hipLaunchKernelGGL(lbs_joints_out_kernel, dim3((B * 63 + 255) / 256), dim3(256), 0, stream, w.j16, verts, trans, B, joints);
   HARP_CHECK_LAUNCH();
   return HARP_OK;
@@ -416,7 +430,7 @@ int harp_lbs_mano_bwd(const harp_mano_model* m, const float* pose, const float* 
   hipLaunchKernelGGL(lbs_joints_bwd_kernel, dim3(B), dim3(256), 0, stream, g_joints, B, w.g_j16, g_verts, g_trans, w.g_A, B * (192 + 135),
                      g_betas, B * NB);
   hipLaunchKernelGGL(lbs_skin_kernel<true>, dim3((NV + kSkinVerts - 1) / kSkinVerts, (B + FRAMES_PER_BLOCK - 1) / FRAMES_PER_BLOCK), dim3(256), 0, stream,
-                     *m, betas, trans, w.pm, w.A, B, nullptr, g_verts, w.g_vp, w.Mo);
+                     *m, betas, trans, w.pm, w.A, B, nullptr, g_verts, w.g_vp, w.Mo, w.vposed);
   hipLaunchKernelGGL(lbs_gA_gpm_kernel, dim3(B, kChunksA + kChunksP), dim3(192), 0, stream, *m, m->weights, w.Mo, w.g_A, w.g_vp, w.g_pm, g_betas);
   hipLaunchKernelGGL(lbs_chain_bwd_kernel, dim3(B), dim3(64), 0, stream, *m, pose, w.Rloc, w.G, w.Jrest, w.g_A, w.g_pm, w.g_j16,
                      g_pose, g_betas);
