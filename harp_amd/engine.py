@@ -157,7 +157,7 @@ class FitEngine:
         self.overlap_allreduce = True    # N > 1: all-reduce of the map gradients overlapped with the mesh / LBS backward
         self.graph_collectives = False   # N > 1: capture the RCCL all-reduce into the step graph (verified on 1 rank only)
         self.force_allreduce = False     # run the N > 1 code path on a single rank (tests, bench HARP_FORCE_DIST)
-        self.fused_loss = bool(int(os.environ.get("HARP_FUSED_LOSS", "1")))   # loss-only mode: photometric L1 formed inside the shader backward
+        self.fused_loss = True           # loss-only mode: photometric L1 formed inside the shader backward (no forward shading launch)
         self.keep_image = True           # shader forward writes the rendered image s["rgb"] (False: loss + gradient only)
         self.mesh_terms_first = True     # key-point term + mesh regularisers run before the light raster (under the raster set-up) instead of after it
         self.camera_first = True        # enqueue the camera-view raster chain (the longer one) before the light-view chain: +0.75 %
