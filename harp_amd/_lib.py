@@ -158,3 +158,12 @@ SIGNATURES["harp_mesh_chain_fwd"] = (_i, [ctypes.POINTER(MeshChain), _vp])
 SIGNATURES["harp_mesh_chain_bwd"] = (_i, [ctypes.POINTER(MeshChain), _vp])
 SIGNATURES["harp_draw_texture_offsets"] = (_i, [ctypes.c_uint, _vp, _i, _i, _f, _vp, _f, _vp, _vp])
 SIGNATURES["harp_rasterize_l1_fwd"] = (_i, [_vp, _vp, _i, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp])
+
+# data-parallel exchange (csrc/comm.hip): RCCL bound at run time, all-reduce enqueued on the caller's stream
+SIGNATURES.update({
+    "harp_comm_unique_id": (_i, [_vp]),
+    "harp_comm_create": (_i, [_vp, _i, _i, ctypes.POINTER(_vp)]),
+    "harp_comm_destroy": (_i, [_vp]),
+    "harp_allreduce_flat": (_i, [_vp, _vp, _sz, _vp]),
+})
+COMM_ID_BYTES = 128

@@ -1,10 +1,21 @@
 """Data-parallel plumbing (new capability: the reference is single-device): frames of a sequence are
 sharded over ranks in contiguous blocks, every rank keeps the full parameter arena, and the flat fp32 gradient bucket is
-summed with ONE all-reduce per step (RCCL over xGMI on the GPU box: backend "nccl"; gloo in the CPU tests).  The 1/world
-factor is applied by the Adam kernel (`grad_scale`), so mean-type losses average over ranks and frame-independent
-regularisers (computed identically on every rank from the same RNG seed) are counted once."""
+summed with ONE all-reduce per step.  The 1/world factor is applied by the Adam kernel (`grad_scale`), so mean-type losses
+average over ranks and frame-independent regularisers (computed identically on every rank from the same RNG seed) are counted
+once.
+
+Two transports:
+  * `RcclComm` — the production path on a GPU node: RCCL called directly through the C ABI (`harp_allreduce_flat`, csrc/comm.hip)
+    on the caller's HIP stream.  It is a plain enqueue, so the collective is a node of the step's hipGraph like every kernel.
+    The communicator is bootstrapped with 128 opaque bytes that rank 0 hands to the others over `torch.distributed` (any backend).
+  * `torch.distributed.all_reduce` — used when no RcclComm exists (the gloo CPU tests, and N processes sharing one GPU, which RCCL
+    refuses: "duplicate GPU")."""
+import ctypes
+
 import torch
 import torch.distributed as dist
+
+from . import _lib
 
 
 def shard_frames(T, rank, world):
@@ -21,8 +32,55 @@ def batches(lo, hi, batch_size, step):
     return (torch.arange(batch_size) + step * batch_size) % n + lo
 
 
-def allreduce_flat(bucket):
-    """sum the flat gradient bucket over all ranks in one collective (no-op for a single process)"""
-    if dist.is_available() and dist.is_initialized():
+def allreduce_flat(bucket, comm=None):
+    """sum the flat gradient bucket over all ranks in one collective, in place (no-op for a single process without a communicator)"""
+    if comm is not None:
+        comm.allreduce(bucket)
+    elif dist.is_available() and dist.is_initialized():
         dist.all_reduce(bucket)
     return bucket
+
+
+class RcclComm:
+    """RCCL communicator owned by the C-ABI library (harp_comm_* / harp_allreduce_flat in include/harp_hip.h)."""
+
+    def __init__(self, rank, world, uid_bytes):
+        h = ctypes.c_void_p()
+        _lib.check(_lib.lib().harp_comm_create(uid_bytes, int(rank), int(world), ctypes.byref(h)), "harp_comm_create")
+        self.handle, self.rank, self.world = h, int(rank), int(world)
+
+    @staticmethod
+    def unique_id():
+        buf = ctypes.create_string_buffer(_lib.COMM_ID_BYTES)
+        _lib.check(_lib.lib().harp_comm_unique_id(buf), "harp_comm_unique_id")
+        return buf.raw
+
+    @classmethod
+    def from_process_group(cls, device=None):
+        """one communicator spanning the default torch.distributed group: rank 0 draws the id, everybody receives it"""
+        if not (dist.is_available() and dist.is_initialized()):
+            raise RuntimeError("RcclComm.from_process_group needs an initialised torch.distributed group (bootstrap channel)")
+        rank, world = dist.get_rank(), dist.get_world_size()
+        if device is not None:
+            torch.cuda.set_device(device)
+        box = [cls.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        return cls(rank, world, box[0])
+
+    @classmethod
+    def single(cls):
+        """1-rank communicator (tests / HARP_FORCE_DIST): exercises the same RCCL launch path without a bootstrap channel"""
+        return cls(0, 1, cls.unique_id())
+
+    def allreduce(self, t, stream=None):
+        """in-place sum of a contiguous fp32 HIP tensor, enqueued on `stream` (default: torch's current stream)"""
+        if t.dtype != torch.float32:
+            raise TypeError("harp_allreduce_flat reduces float32 buckets")
+        _lib.check(_lib.lib().harp_allreduce_flat(self.handle, _lib.ptr(t), t.numel(), _lib.stream() if stream is None else stream),
+                   "harp_allreduce_flat")
+        return t
+
+    def destroy(self):
+        if self.handle:
+            _lib.lib().harp_comm_destroy(self.handle)
+            self.handle = ctypes.c_void_p()

@@ -155,13 +155,15 @@ class FitEngine:
         self.packed_texels = True        # shaders read the interleaved albedo + normal-map array (harp_pack_texels)
         self.auto_draw = True            # draw fresh texture-regulariser offsets every step (False: the caller draws)
         self.overlap_allreduce = True    # N > 1: all-reduce of the map gradients overlapped with the mesh / LBS backward
-        self.graph_collectives = False   # N > 1: capture the RCCL all-reduce into the step graph (verified on 1 rank only)
+        self.graph_collectives = False   # N > 1 over torch.distributed (no RcclComm): capture its all-reduce into the step graph (opt-in)
+        self.comm = None                 # harp_amd.dist.RcclComm: direct RCCL all-reduce on the step's stream (graph node by default), set_comm()
         self.force_allreduce = False     # run the N > 1 code path on a single rank (tests, bench HARP_FORCE_DIST)
         self.fused_loss = True           # loss-only mode: photometric L1 formed inside the shader backward (no forward shading launch)
         self.keep_image = True           # shader forward writes the rendered image s["rgb"] (False: loss + gradient only)
         self.mesh_terms_first = True     # key-point term + mesh regularisers run before the light raster (under the raster set-up) instead of after it
         self.camera_first = True        # enqueue the camera-view raster chain (the longer one) before the light-view chain: +0.75 %
         self.frozen = ()                 # parameters kept out of the optimiser groups (known_appearance)
+        self.disabled_terms = frozenset()   # loss terms left out of the objective altogether (set_disabled_terms)
         self.schedule = None
         self._stage = None
         self._early_work = None
@@ -219,6 +221,7 @@ class FitEngine:
         self.y_sil = y_sil.to(self.dev).float().contiguous()
         self.y_sil_col = y_sil_col.to(self.dev).float().contiguous()
         self.target_offset = int(frame_offset)
+        self._graphs = {}                               # captured graphs hold the raw pointers of the previous target buffers
         # the targets are static during a fit: what an un-rendered 64x64 super-tile contributes to the two image terms is a constant per
         # (target frame, super-tile) — sum of y_sil for the silhouette L1 (alpha = 0), sum of |bg - y| * mask for the photometric L1 —
         # tabulated once here; the loss-only kernels (keep_image = False) look it up instead of reading 3/4 of the targets every step
@@ -282,7 +285,10 @@ class FitEngine:
         """ARAP reference = frame-0 mesh under the initial parameters (optimize_sequence.py:429-435)."""
         fid0 = torch.zeros(1, dtype=torch.int32, device=self.dev)
         self._mesh_forward(fid0, 1)
-        self.ref_verts = self.s["vd"][0].clone()
+        if self.ref_verts is None:
+            self.ref_verts = self.s["vd"][0].clone()
+        else:
+            self.ref_verts.copy_(self.s["vd"][0])       # same buffer: graphs captured against it stay valid
 
     def _shade_struct(self, B, app):
         s, tp = self.s, self.topo
@@ -332,6 +338,7 @@ class FitEngine:
         if not self.overlap:
             side = cur                                   # single-stream mode (used when individual kernels are timed with events)
         sched_early = self.early_terms
+        off = self.disabled_terms
         # ---- terms that depend on the parameters only (normal-map normalisation, texture regularisers, displacement regulariser) go
         #      first on the second stream: they run under the LBS / mesh chain, which is a string of small latency-bound launches
         def param_terms():
@@ -347,12 +354,13 @@ class FitEngine:
                 if self.packed_texels:
                     self._ck(L.harp_pack_texels(p(self.params["texture"]), p(s["nmap_n"]), self.Ht * self.Wt, p(self.texnm), ST()), "pack_texels")
                 self._texture_terms(wp, lp)
-            if coarse and shared_terms:
+            if coarse and shared_terms and "vert_disp_reg" not in off:
                 self._ck(L.harp_sum_squares(p(self.params["verts_disps"]), V, wp(2), lp(2), p(self.grads["verts_disps"]), ST()), "disp_reg")
 
         def mesh_terms():
-            if coarse:
+            if coarse and "kps_anchor" not in off:
                 self._ck(L.harp_kps_loss(p(self.init_joints), p(lfid), p(s["joints_m"]), B, self.n_joints, wp(1), lp(1), p(s["g_joints_m"]), ST()), "kps")
+            if coarse and not off.issuperset(("laplacian", "normal", "arap")):      # (individually disabled ones carry weight 0)
                 self._ck(L.harp_mesh_regularizers(p(s["vd"]), p(self.ref_verts), p(tp.nbr_off), p(tp.nbr_idx), p(tp.nc_pairs), p(tp.vp_off), p(tp.vp_idx), B, V,
                                                   tp.nc_pairs.shape[0], tp.E, wp(3), lp(3), p(s["g_vd"]), ST()), "mesh_reg")
         if sched_early:
@@ -543,31 +551,62 @@ class FitEngine:
     def _dist_on(self):
         return self.world > 1 or self.force_allreduce
 
+    def set_comm(self, comm):
+        """harp_amd.dist.RcclComm (or None): the gradient bucket is then reduced by `harp_allreduce_flat` on the step's own streams — a
+        plain enqueue, captured into the step's hipGraph like every kernel — instead of through torch.distributed."""
+        self.comm = comm
+        self._graphs = {}
+
+    def _comm_stream(self):
+        if getattr(self, "_cstream", None) is None:
+            self._cstream = torch.cuda.Stream(device=self.dev)
+        return self._cstream
+
     def _allreduce_maps_early(self):
         """The texture + normal-map gradients (6.29 of the 6.36 MB bucket) are final once the shading backward and normalize3_bwd
-        are enqueued, ~0.25 ms before the mesh / LBS backward tail ends: their all-reduce is started there (async, on RCCL's own
-        stream) and overlaps with that tail; `allreduce()` then only has the small remainder [pose .. amb_ratio] left to send."""
-        if not self._dist_on() or not self.overlap_allreduce or torch.cuda.is_current_stream_capturing():
+        are enqueued, ~0.25 ms before the mesh / LBS backward tail ends: their all-reduce is started there and overlaps with that
+        tail; `allreduce()` then only has the small remainder [pose .. amb_ratio] left to send.  RcclComm: both collectives go to one
+        communication stream (forked from / joined into the step's stream with events — all capturable), so the two operations on the
+        communicator stay ordered.  torch.distributed: async_op on the process group's own stream."""
+        if not self._dist_on() or not self.overlap_allreduce:
+            return
+        o = self.arena.offsets["texture"][0]
+        e = self.arena.span("texture", "normal_map")
+        if self.comm is not None:
+            cur, cs = torch.cuda.current_stream(), self._comm_stream()
+            cs.wait_stream(cur)
+            self.comm.allreduce(self.g_buf[o:o + e[1]], stream=cs.cuda_stream)
+            self._early_from = o
+            self._early_work = "rccl"
+            return
+        if torch.cuda.is_current_stream_capturing():
             return
         import torch.distributed as dist
         if not (dist.is_available() and dist.is_initialized()):
             return
-        o = self.arena.offsets["texture"][0]
-        e = self.arena.span("texture", "normal_map")
         self._early_work = dist.all_reduce(self.g_buf[o:o + e[1]], async_op=True)
         self._early_from = o
 
     def allreduce(self):
-        if self._dist_on():
-            from .dist import allreduce_flat
-            o, n = self.opt_span
-            work = self._early_work
+        if not self._dist_on():
+            return
+        from .dist import allreduce_flat
+        o, n = self.opt_span
+        work, self._early_work = self._early_work, None
+        if self.comm is not None:
             if work is not None:
-                allreduce_flat(self.g_buf[o:self._early_from])      # everything before the maps (they are the tail of the bucket)
-                work.wait()                                         # current stream waits for the early collective
-                self._early_work = None
+                cur, cs = torch.cuda.current_stream(), self._comm_stream()
+                cs.wait_stream(cur)                                 # the remainder is final only now (end of the backward tail)
+                self.comm.allreduce(self.g_buf[o:self._early_from], stream=cs.cuda_stream)
+                cur.wait_stream(cs)
             else:
-                allreduce_flat(self.g_buf[o:o + n])       # one flat bucket (sum); 1/world is applied in the Adam kernel
+                self.comm.allreduce(self.g_buf[o:o + n])            # one flat bucket (sum); 1/world is applied in the Adam kernel
+            return
+        if work is not None:
+            allreduce_flat(self.g_buf[o:self._early_from])          # everything before the maps (they are the tail of the bucket)
+            work.wait()                                             # current stream waits for the early collective
+        else:
+            allreduce_flat(self.g_buf[o:o + n])
 
     def _adam_tick(self, coarse, app):
         """advance step / bias corrections of the stage's optimiser(s) — any time before `adam(..., tick=False)` of the same step"""
@@ -598,9 +637,21 @@ class FitEngine:
     def set_stage(self, coarse, app):
         w = torch.zeros(16)
         for i, k in enumerate(LOSS_NAMES):
-            if (coarse and k in COARSE_TERMS) or (app and k in APP_TERMS):
+            if ((coarse and k in COARSE_TERMS) or (app and k in APP_TERMS)) and k not in self.disabled_terms:
                 w[i] = LOSS_WEIGHTS[k]
         self.w_vec.copy_(w.to(self.dev))
+
+    def set_disabled_terms(self, names):
+        """Leave loss terms out of the objective: weight 0, kernels not launched, loss value reported as 0.  The reference fits a test
+        sequence with a known appearance (`known_appearance`) WITHOUT the key-point anchor and the mesh regularisers
+        (optimize_sequence.py:523, 531: kps_anchor, vert_disp_reg, laplacian, normal, arap)."""
+        names = frozenset(names)
+        unknown = names - set(LOSS_NAMES)
+        if unknown:
+            raise ValueError(f"unknown loss terms {sorted(unknown)}")
+        self.disabled_terms = names
+        self._stage = None                               # weights are re-uploaded by the next step()
+        self._graphs = {}
 
     def set_lr(self, lr_coarse=None, lr_app=None):
         """host -> device hyper block (ReduceLROnPlateau lives on the host, optimize_sequence.py:309, 581-582)"""
@@ -636,9 +687,11 @@ class FitEngine:
                                                _lib.stream()), "schedule_next")
         self._loss_cleared = True
 
-    def step(self, fid, coarse=True, app=True, use_graph=True):
-        """One optimisation step on the frames `fid` (global frame ids, length <= batch_size; a shorter — last, partial —
-        batch runs eagerly, optimize_sequence.py:396-399).  fid=None: the next row of the schedule given to `set_schedule`."""
+    def step(self, fid, coarse=True, app=True, use_graph=True, tfid=None):
+        """One optimisation step on the frames `fid` (global frame ids = rows of the parameter tables, length <= batch_size; a shorter —
+        last, partial — batch runs eagerly, optimize_sequence.py:396-399).  fid=None: the next row of the schedule given to
+        `set_schedule`.  tfid: rows of the resident targets these frames compare against (default fid - target_offset, i.e. targets
+        stored in frame order); a dataset that holds a subset / another order of the frames passes its own item indices."""
         scheduled = fid is None
         if scheduled:
             if self.schedule is None:
@@ -651,13 +704,13 @@ class FitEngine:
             raise ValueError(f"batch of {n} frames exceeds the engine's batch_size {self.B}")
         if scheduled:
             pass
-        elif fid.is_cuda:                                 # device-resident batch: no host sync at all
-            self.fid[:n].copy_(fid, non_blocking=True)
-            self.tfid[:n].copy_(fid - self.target_offset, non_blocking=True)
         else:
-            fid = fid.to(torch.int32)
-            self.fid[:n].copy_(fid.to(self.dev), non_blocking=True)
-            self.tfid[:n].copy_((fid - self.target_offset).to(self.dev), non_blocking=True)
+            t = (fid - self.target_offset) if tfid is None else torch.as_tensor(tfid)
+            if int(t.shape[0]) != n:
+                raise ValueError("tfid must have one entry per frame of the batch")
+            # (a device-resident batch costs no host sync at all)
+            self.fid[:n].copy_(fid.to(torch.int32).to(self.dev), non_blocking=True)
+            self.tfid[:n].copy_(t.to(torch.int32).to(self.dev), non_blocking=True)
         key = (coarse, app)
         if self._stage != key:
             self.set_stage(coarse, app)
@@ -665,23 +718,30 @@ class FitEngine:
         fb0 = lambda: self.forward_backward(coarse, app, B=n, tick=True)
         fb = (lambda: (self._schedule_next(), fb0())) if scheduled else fb0
         dist_on = self._dist_on()
-        if not use_graph or n != self.B or (dist_on and not self.graph_collectives) or (app and self.perceptual is not None):
+        graph_ok = (not dist_on) or self.comm is not None or self.graph_collectives
+        if not use_graph or n != self.B or not graph_ok or (app and self.perceptual is not None):
             fb()
             self.allreduce()
             self.adam(coarse, app, tick=False)
             return
-        gkey = (coarse, app, scheduled)
+        # every switch the enqueued launch sequence depends on is part of the key: flipping one re-captures instead of replaying a
+        # graph recorded for another configuration
+        gkey = (coarse, app, scheduled, self.keep_image, self.fused_loss, self.self_shadow, tuple(self.frozen), self.overlap, self.early_terms,
+                self.packed_texels, self.auto_draw, self.mesh_terms_first, self.camera_first, self.fused_chain, dist_on, self.overlap_allreduce,
+                self.comm is not None)
         g = self._graphs.get(gkey)
         if g is None:
             # warm-up on a side stream, then capture (torch's documented recipe)
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             row = self.schedule_row.clone() if scheduled else None
-            hyper = self.hyper.clone()
+            hyper, draws = self.hyper.clone(), self.draw_counter.clone()
             with torch.cuda.stream(side):
                 fb()
+                self.allreduce()                         # completes (and clears) the early all-reduce the warm-up pass started
             torch.cuda.current_stream().wait_stream(side)
             self.hyper.copy_(hyper)                      # the warm-up pass must not advance the optimiser's step count ...
+            self.draw_counter.copy_(draws)               # ... nor the texture-offset generator (same draws as an eager run with this seed)
             if scheduled:
                 self.schedule_row.copy_(row)             # ... nor consume a schedule row
             torch.cuda.synchronize()

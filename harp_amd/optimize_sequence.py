@@ -101,7 +101,10 @@ def optimize_hand_sequence(configs, input_params, images_dataset, val_params, va
                     torch.as_tensor(uv_mask).float(), input_params, S, configs["focal_length"], batch_size, device=device,
                     self_shadow=configs["self_shadow"], share_light_position=configs["share_light_position"], seed=seed,
                     use_arm=use_arm, opt_arm_pose=bool(configs.get("opt_arm_pose", False)))
-    eng.set_targets(*ResidentTargets(images_dataset).tensors())      # decoded once, resident in HBM (utils/data_util.py)
+    rt = ResidentTargets(images_dataset)                             # decoded once, resident in HBM (utils/data_util.py)
+    if int(rt.fid.min()) < 0 or int(rt.fid.max()) >= T:
+        raise ValueError(f"dataset frame ids span [{int(rt.fid.min())}, {int(rt.fid.max())}] but the parameter tables hold {T} frames")
+    eng.set_targets(*rt.tensors())
     # perceptual term (:404-405, :546-547): needs the pretrained VGG16 filters, which cannot be downloaded here — pass a ready module
     # (`vgg=`) or the path of torchvision's vgg16 state dict (configs["vgg_weights"]); without either the term is left out
     if vgg is None and configs.get("vgg_weights"):
@@ -115,6 +118,8 @@ def optimize_hand_sequence(configs, input_params, images_dataset, val_params, va
     if configs["known_appearance"]:
         # optimize_sequence.py:264-289: shape / displacement leave opt_coarse, texture / normal map leave opt_app
         eng.frozen = ("verts_disps", "shape", "texture", "normal_map")
+        # ... and the key-point anchor and the mesh regularisers are not part of a test sequence's objective (:523, :531)
+        eng.set_disabled_terms(("kps_anchor", "vert_disp_reg", "laplacian", "normal", "arap"))
     # ReduceLROnPlateau lives on the host; torch's own scheduler drives a dummy optimiser and the lr is mirrored to the device
     dummy = torch.optim.Adam([torch.nn.Parameter(torch.zeros(1))], lr=1e-3)
     sched = torch.optim.lr_scheduler.ReduceLROnPlateau(dummy, patience=40)
@@ -123,11 +128,12 @@ def optimize_hand_sequence(configs, input_params, images_dataset, val_params, va
                              "photo": 1.0, "albedo": 0.5, "normal_reg": 0.1}[k] for k in LOSS_NAMES], device=device)
     for epoch_id in range(configs["total_epoch"]):
         coarse, app = stage_flags(epoch_id, configs["training_stage"])
-        perm = torch.randperm(T, generator=gen)                                    # DataLoader(shuffle=True), :399
+        perm = torch.randperm(len(rt), generator=gen)                              # DataLoader(shuffle=True) over the DATASET's items, :399
         epoch_loss = torch.zeros((), device=device)
         nb = 0
-        for s0 in range(0, T, batch_size):
-            eng.step(perm[s0:s0 + batch_size], coarse, app)
+        for s0 in range(0, len(rt), batch_size):
+            item = perm[s0:s0 + batch_size]
+            eng.step(rt.fid[item], coarse, app, tfid=item)                         # parameter rows = the items' own fids (:446, :464)
             active = (eng.w_vec[:9] > 0).float()
             epoch_loss += (eng.loss_vec[:9] * weights * active).sum()              # stays on the device: no per-term .cpu() sync (:559)
             if app and eng.perceptual is not None:

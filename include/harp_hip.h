@@ -6,7 +6,8 @@
  *
  * Conventions: plain device pointers + sizes; float32 / int32, contiguous row-major; no hidden allocation (outputs and
  * workspaces are caller-provided); every call only enqueues work on `stream` (hipStream_t passed as void*-compatible
- * handle) and returns 0 on success (1 = bad argument, 2+hipError = launch failure); nothing throws across the ABI.
+ * handle) and returns 0 on success (1 = bad argument, 2+hipError = launch failure, 1000 = RCCL not found, 1001+ncclResult = RCCL
+ * error); nothing throws across the ABI.
  * "(+=)" marks accumulate-into outputs (caller zero-initialises).
  */
 #ifndef HARP_HIP_H
@@ -329,6 +330,22 @@ int harp_scale(const float* x, float s, int n, float* y, hipStream_t stream);
  * (n_rows,B) int32 schedule -> fid (B,), tfid = fid - target_offset; then counter[0] = row + 1.  Graph-replayable. */
 int harp_schedule_next(const int32_t* schedule, int n_rows, int B, int target_offset, int32_t* counter, int32_t* fid, int32_t* tfid,
                        float* zero, int n_zero, hipStream_t stream);   /* zero (optional): n_zero floats cleared in the same launch (loss vector) */
+
+/* ---- data-parallel exchange (RCCL over xGMI) -------------------------------------------------------------------------
+ * New capability: the reference is single-device.  Frames of a sequence are sharded over the GPUs of a node; between
+ * `sum_loss.backward()` and `opt_coarse.step() / opt_app.step()` (optimize_sequence.py:567-573) every rank sums the flat fp32
+ * gradient bucket [pose .. normal_map] of the parameter arena in place (1/world is applied by the Adam kernel's grad_scale).
+ * RCCL is bound with dlopen at the first harp_comm_* call (the copy an embedding PyTorch process has mapped is reused).
+ * harp_comm_unique_id: rank 0 obtains HARP_COMM_ID_BYTES opaque bytes and hands them to every rank over any side channel;
+ * harp_comm_create: collective over all ranks, binds the calling thread's current HIP device; the handle is opaque.
+ * harp_allreduce_flat only enqueues on `stream` (no host synchronisation), so it can be captured into a hipGraph. */
+#define HARP_COMM_ID_BYTES 128
+#define HARP_ERR_NO_RCCL 1000
+#define HARP_ERR_COMM 1001
+int harp_comm_unique_id(void* id_out);
+int harp_comm_create(const void* id, int rank, int world, void** comm_out);
+int harp_comm_destroy(void* comm);
+int harp_allreduce_flat(void* comm, float* buf, size_t n, hipStream_t stream);
 
 #ifdef __cplusplus
 }
