@@ -75,11 +75,15 @@ class DeviceTopology:
     """int32 HBM copies of the host tables of harp_amd.synth.build_topology / topology.py."""
 
     def __init__(self, topo, verts_uvs, faces_uvs, device):
-        i32 = lambda a: torch.as_tensor(a, dtype=torch.int32).contiguous().to(device)
+        def i32(a):
+            t = torch.as_tensor(np.asarray(a), dtype=torch.int32).contiguous()
+            if t.numel() == 0:                             # un-subdivided template: empty tables still need a valid device pointer
+                t = torch.zeros((1,) + tuple(t.shape[1:]), dtype=torch.int32)
+            return t.to(device)
         self.V0, self.V = int(topo["n_verts0"]), int(topo["n_verts"])
         for k in ("faces0", "edges0", "faces", "edges", "nbr_off", "nbr_idx", "vf_off", "vf_idx", "nc_pairs", "vp_off", "vp_idx", "sub_off", "sub_idx"):
             setattr(self, k, i32(topo[k]))
-        self.E0, self.F, self.E = self.edges0.shape[0], self.faces.shape[0], self.edges.shape[0]
+        self.E0, self.F, self.E = int(np.asarray(topo["edges0"]).shape[0]), self.faces.shape[0], self.edges.shape[0]
         # expanded vertex -> incident-face table for the fused mesh chain: (i0, i1, i2, corner) per CSR entry, one 16-B load
         fc = torch.as_tensor(np.asarray(topo["vf_idx"]), dtype=torch.int64)
         fa = torch.as_tensor(np.asarray(topo["faces"]), dtype=torch.int64)

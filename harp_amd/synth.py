@@ -48,6 +48,23 @@ def build_topology(faces0, n_verts0):
                 nc_pairs=nc_pairs, vp_off=vp_off, vp_idx=vp_idx, sub_off=sub_off, sub_idx=sub_idx, n_verts0=n_verts0, n_verts=V)
 
 
+def build_raw_topology(faces0, n_verts0):
+    """The same tables for the UN-subdivided template: `prepare_mesh(..., mesh_subdivider=None)` (utils/visualize.py:51-56) and
+    BASELINE config C1 (raw 778-vertex / 1538-face MANO mesh).  V == V0, no midpoints (E0 = 0, empty subdivision tables)."""
+    faces = np.asarray(faces0, np.int64)
+    V = int(n_verts0)
+    edges, _ = unique_edges(faces, V)
+    rows = np.concatenate([edges[:, 0], edges[:, 1]])
+    cols = np.concatenate([edges[:, 1], edges[:, 0]])
+    nbr_off, nbr_idx = csr_from_pairs(rows, cols, V)
+    vf_off, vf_idx = csr_from_pairs(faces.reshape(-1), np.arange(faces.size), V)
+    nc_pairs = normal_consistency_pairs(faces, V)
+    vp_off, vp_idx = csr_from_pairs(nc_pairs.reshape(-1), np.arange(nc_pairs.size), V)
+    return dict(faces0=faces.astype(np.int32), edges0=np.zeros((0, 2), np.int32), faces=faces.astype(np.int32), edges=edges.astype(np.int32),
+                nbr_off=nbr_off, nbr_idx=nbr_idx, vf_off=vf_off, vf_idx=vf_idx, nc_pairs=nc_pairs, vp_off=vp_off, vp_idx=vp_idx,
+                sub_off=np.zeros(V + 1, np.int32), sub_idx=np.zeros(0, np.int32), n_verts0=V, n_verts=V)
+
+
 def make_mano_model(template=None, seed=0):
     """A MANO-shaped LBS model on the real MANO topology with synthetic blend shapes (float32 numpy):
     v_template (778,3) m, shapedirs (778,3,10), posedirs (778,3,135), J_regressor (16,778),

@@ -24,14 +24,26 @@ class MeshSubdivider:
         raise TypeError("call prepare_mesh(..., mesh_subdivider=this) — subdivision is fused into the mesh-prep kernels")
 
 
+_RAW_TOPO = {}
+
+
+def raw_topology(mesh_faces, n_verts, device):
+    """static tables of the UN-subdivided template (prepare_mesh with mesh_subdivider=None, utils/visualize.py:51-56), built once"""
+    f = torch.as_tensor(mesh_faces).detach().cpu().reshape(-1, 3)
+    key = (f.data_ptr() if torch.is_tensor(mesh_faces) and not mesh_faces.is_cuda else hash(f.numpy().tobytes()), int(n_verts), str(device))
+    if key not in _RAW_TOPO:
+        from ..synth import build_raw_topology
+        t = build_raw_topology(f.numpy(), int(n_verts))
+        _RAW_TOPO[key] = ops.DeviceTopology(t, torch.zeros(1, 2), torch.zeros(t["faces"].shape[0], 3, dtype=torch.int32), device)
+    return _RAW_TOPO[key]
+
+
 def prepare_mesh(params, fid, mano_layer, verts_textures, mesh_subdivider, global_pose, configs, device="cuda", vis_normal=False,
                  shared_texture=True, use_arm=False):
     """utils/visualize.py:16-88 for the MANO + UV-texture path HARP runs (verts_textures=False, shared_texture=True, model_type
     'harp').  Returns (hand_joints (B,21,3) m, hand_verts (B,V,3) m, faces (B,F,3), textures)."""
     if configs.get("model_type", "harp") != "harp" or verts_textures:
         raise NotImplementedError("the 'harp' model type with UV textures is the path in scope (SURVEY.md §8)")
-    if mesh_subdivider is None:
-        raise NotImplementedError("HARP always subdivides (optimize_sequence.py:344-349)")
     fid = torch.as_tensor(fid).long()
     B = fid.shape[0]
     pose_batch, rot_batch = params["pose"][fid.to(params["pose"].device)], params["rot"][fid.to(params["rot"].device)]   # :26-27 (global_pose forced False, :20)
@@ -45,8 +57,12 @@ def prepare_mesh(params, fid, mano_layer, verts_textures, mesh_subdivider, globa
         hand_verts, hand_joints = mano_layer(torch.cat((rot_batch, pose_batch), 1).to(device), params["shape"].repeat([B, 1]).to(device),
                                              trans_batch)                                                                # :42-44
     hand_joints = hand_joints / 1000.0                                                                                   # :46
-    topo = mesh_subdivider.topo
-    vs = ops.subdivide(hand_verts, topo, 1.0 / 1000.0)                                                                  # :45, :50-52
+    if mesh_subdivider is None:                                                                                          # :51-56: the raw template mesh (config C1)
+        topo = raw_topology(params["mesh_faces"], hand_verts.shape[1], device)
+        vs = hand_verts / 1000.0                                                                                         # :45
+    else:
+        topo = mesh_subdivider.topo
+        vs = ops.subdivide(hand_verts, topo, 1.0 / 1000.0)                                                              # :45, :50-52
     disp = params["verts_disps"]
     if disp is not None:
         if disp.shape[1] != 1:

@@ -34,3 +34,144 @@ def oracle_params(sc, source):
 
 def rel(a, b):
     return ((a - b).norm() / (b.norm() + 1e-30)).item()
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Fit cases at the BASELINE.json sizes: an engine on the GPU + everything the fp64 oracle needs for the same inputs.
+# ----------------------------------------------------------------------------------------------------------------------
+def erode(mask, iters=2):
+    """3x3 erosion x2 (utils/data_util.py:17-20)"""
+    m = mask[:, None]
+    for _ in range(iters):
+        m = -torch.nn.functional.max_pool2d(-m, 3, stride=1, padding=1)
+    return m[:, 0]
+
+
+def make_fit_case(kind="hand", T=2, S=512, B=2, seed=0, device="cuda", raw=False, **engine_kw):
+    """FitEngine for `kind` in {"hand", "arm"} (raw=True: the UN-subdivided 778-vertex MANO mesh, config C1) with non-trivial
+    parameters and REALISTIC targets — rendered by the engine from a perturbed "ground-truth" parameter set like bench.py does
+    (SURVEY.md §8d), so the silhouette / photometric gradients are coherent rather than noise.  Returns a dict with the engine
+    and the CPU tensors the oracle consumes."""
+    from harp_amd.engine import FitEngine
+    g = torch.Generator().manual_seed(seed + 100)
+    if kind == "hand":
+        tpl = synth.load_template("hand")
+        topo_np = synth.build_raw_topology(tpl["faces0"], 778) if raw else synth.build_topology(tpl["faces0"], 778)
+        model_np = synth.make_mano_model(tpl, seed=seed)
+        seq, focal = synth.make_sequence(model_np, T, S, seed=seed)
+        kw = {}
+    else:
+        tpl = synth.load_template("arm")
+        topo_np = synth.build_topology(tpl["faces0"], 1026)
+        model_np = synth.make_smplx_arm_model(tpl, seed=seed)
+        focal = 1000.0 * S / 224.0
+        c = model_np["v_template"].mean(0)
+        seq = dict(pose=torch.randn(T, 45, generator=g) * 0.15, rot=torch.randn(T, 3, generator=g) * 0.2, trans=torch.randn(T, 3, generator=g) * 0.01,
+                   shape=torch.randn(T, 10, generator=g) * 0.3,
+                   cam=torch.tensor([[2 * focal / (S * 1.6), -float(c[0]), -float(c[1])]]).repeat(T, 1) + torch.randn(T, 3, generator=g) * 0.005)
+        kw = dict(use_arm=True, opt_arm_pose=True)
+    kw.update(engine_kw)
+    V = int(topo_np["n_verts"])
+    if raw:      # no UV layout for the raw mesh (C1 is silhouette-only): dummy tables, never sampled by a coarse-only stage
+        verts_uvs, faces_uvs = np.zeros((1, 2), np.float32), np.zeros((topo_np["faces"].shape[0], 3), np.int32)
+    else:
+        verts_uvs, faces_uvs = tpl["verts_uvs"], tpl["faces_uvs"]
+    uv_mask = torch.from_numpy(tpl["uv_mask"]).double() / 255
+    seq["joints"] = torch.zeros(T, 21, 3)
+    eng = FitEngine(model_np, topo_np, verts_uvs, faces_uvs, uv_mask.float(), seq, S, focal, B, device=device, **kw)
+    # ---- "ground truth": perturbed pose / camera / shape / displacement / texture -> rendered targets
+    cur = {k: eng.params[k].clone() for k in ("pose", "cam", "shape", "verts_disps", "texture", "normal_map", "trans", "wrist_pose")}
+    dev = eng.dev
+    with torch.no_grad():
+        eng.params["pose"].add_((torch.randn(T, 45, generator=g) * 0.05).to(dev))
+        eng.params["cam"][:, 1:].add_((torch.randn(T, 2, generator=g) * 0.004).to(dev))
+        eng.params["shape"].add_((torch.randn(10, generator=g) * 0.3).to(dev))
+        eng.params["verts_disps"].copy_((torch.randn(V, 1, generator=g) * 0.0008).to(dev))
+        tex = torch.nn.functional.interpolate(torch.rand(1, 3, 32, 32, generator=g), size=512, mode="bilinear")[0].permute(1, 2, 0)
+        eng.params["texture"].copy_((0.35 + 0.5 * tex)[None].to(dev))
+    y_true = torch.empty(T, S, S, 3, device=dev)
+    y_sil = torch.empty(T, S, S, device=dev)
+    joints = torch.empty(T, eng.n_joints, 3, device=dev)
+    eng.y_true, eng.y_sil, eng.y_sil_col = y_true, y_sil, y_sil          # placeholders: the losses of this pass are ignored
+    eng.set_stage(False, not raw)
+    for s0 in range(0, T, B):
+        n = min(B, T - s0)
+        eng.fid[:n].copy_(torch.arange(s0, s0 + n, dtype=torch.int32).to(dev))
+        eng.tfid.zero_()
+        eng.forward_backward(coarse=True, app=not raw, B=n)
+        joints[s0:s0 + n] = eng.s["joints_mm"][:n]
+        y_sil[s0:s0 + n] = (eng.s["alpha"][:n] > 0.5).float()
+        if not raw:
+            y_true[s0:s0 + n] = eng.s["rgb"][:n]
+    if raw:
+        y_true.fill_(1.0)
+    torch.cuda.synchronize()
+    # ---- the parameters the step is evaluated at: the initial ones plus a displacement / texture / normal-map / translation state
+    with torch.no_grad():
+        for k, v in cur.items():
+            eng.params[k].copy_(v)
+        eng.params["verts_disps"].copy_((torch.randn(V, 1, generator=g) * 0.0006).to(dev))
+        if not raw:
+            eng.params["texture"].copy_((torch.rand(1, 512, 512, 3, generator=g) * 0.3 + 0.45).to(dev))
+            eng.params["normal_map"].copy_((torch.tensor([0., 0., 1.]).repeat(1, 512, 512, 1) + torch.randn(1, 512, 512, 3, generator=g) * 0.1).to(dev))
+        eng.params["trans"].copy_((torch.randn(T, 3, generator=g) * 0.01).to(dev))
+        if kind == "arm":
+            eng.params["wrist_pose"].copy_((torch.randn(T, 3, generator=g) * 0.2).to(dev))
+    init_joints = (joints[:, :21] + torch.randn(T, 21, 3, generator=g).to(dev) * 2.0).contiguous()    # METRO-like noisy anchors (mm)
+    eng.init_joints = init_joints                                # (T,21,3) also for the arm: kps_loss drops its 22nd joint (loss/kps_loss.py:7-8)
+    y_col = erode(y_sil)
+    eng.set_targets(y_true, y_sil, y_col)
+    eng.compute_reference_mesh()
+    eng.g_buf.zero_()
+    targets = dict(y_true=y_true.cpu(), y_sil=y_sil.cpu(), y_sil_col=y_col.cpu())
+    model = {k: torch.from_numpy(np.asarray(v)) for k, v in model_np.items()}
+    topo = {k: torch.from_numpy(np.asarray(v)).long() if isinstance(v, np.ndarray) else v for k, v in topo_np.items()}
+    return dict(eng=eng, kind=kind, model=model, topo=topo, tpl=tpl, targets=targets, focal=focal, S=S, T=T, B=B, uv_mask=uv_mask,
+                init_joints=init_joints.cpu(), verts_uvs=torch.from_numpy(np.asarray(verts_uvs, np.float32)),
+                faces_uvs=torch.from_numpy(np.asarray(faces_uvs)).long())
+
+
+ORACLE_KEYS = ("pose", "cam", "verts_disps", "shape", "light_positions", "amb_ratio", "texture", "normal_map", "rot", "trans", "wrist_pose")
+
+
+def oracle_inputs(case, dtype=torch.float64):
+    """leaf tensors (requires_grad) cloned from the engine's parameters in `dtype`, plus model / targets in the same dtype"""
+    eng = case["eng"]
+    P = {k: eng.params[k].detach().cpu().to(dtype).clone().requires_grad_() for k in ORACLE_KEYS}
+    P.update(verts_uvs=case["verts_uvs"].to(dtype), faces_uvs=case["faces_uvs"], uv_mask=case["uv_mask"], init_joints=case["init_joints"].to(dtype))
+    model = {k: (v.to(dtype) if v.is_floating_point() else v) for k, v in case["model"].items()}
+    targets = {k: v.to(dtype) for k, v in case["targets"].items()}
+    return P, model, targets
+
+
+def oracle_step(case, fid, dtype=torch.float64, coarse=True, app=True, P=None, model=None, targets=None, terms=None):
+    """loss dict, weighted total (backward() already run -> P[k].grad), aux images of the oracle for the engine's current parameters and
+    texture-regulariser offsets.  terms: restrict the objective to these loss names (e.g. ("silhouette",) for config C1)."""
+    eng = case["eng"]
+    if P is None:
+        P, model, targets = oracle_inputs(case, dtype)
+    use_arm = case["kind"] == "arm"
+    rv = case.get(("ref_verts", dtype))
+    if rv is None:          # ARAP reference = frame 0 under the INITIAL parameters (optimize_sequence.py:429-435): computed once, like the engine
+        with torch.no_grad():
+            _, rv = H.prepare_mesh(P, torch.tensor([0]), model, case["topo"], use_arm=use_arm)
+        case[("ref_verts", dtype)] = rv
+    loss, total, aux = H.step_losses(P, fid, model, case["topo"], targets, case["S"], case["focal"], rv, eng.dist_albedo.cpu().long(),
+                                     eng.dist_normal.cpu().long(), coarse=coarse, app=app, self_shadow=eng.self_shadow, use_arm=use_arm)
+    if terms is not None:
+        total = sum(loss[k] * H.LOSS_WEIGHTS[k] for k in terms)
+    total.backward()
+    return P, loss, total, aux, rv
+
+
+def engine_eval(case, fid, coarse=True, app=True, tfid=None):
+    """one forward + backward of the engine on frames `fid` with the current offsets (no Adam)"""
+    eng = case["eng"]
+    n = len(fid)
+    eng.fid[:n].copy_(torch.as_tensor(fid).int().to(eng.dev))
+    eng.tfid[:n].copy_(torch.as_tensor(fid if tfid is None else tfid).int().to(eng.dev))
+    eng.auto_draw = False
+    eng.set_stage(coarse, app)
+    eng.forward_backward(coarse, app, B=n)
+    torch.cuda.synchronize()
+    return eng.losses()
