@@ -152,6 +152,11 @@ def process_info_for_shadow(cam, light_positions, center, S, focal):
     return light_R, light_T, cam_R, cam_T
 
 
+def _depth_tie(p2f2, zbuf2, tol=1e-5):
+    """(test infrastructure) pixels whose nearest and second-nearest face are closer in depth than float32 can order (K=2 fragments)"""
+    return (p2f2[..., 1] >= 0) & ((zbuf2[..., 1] - zbuf2[..., 0]).abs() < tol * zbuf2[..., 0].abs())
+
+
 def compute_tangent(normals):
     """pbr_materials.py:58-77."""
     x, y, z = normals[..., 0], normals[..., 1], normals[..., 2]
@@ -170,7 +175,7 @@ def apply_normal_map(pixel_normals, nm):
     return F.normalize(out, dim=-1)
 
 
-def render_rgb(verts, topo, params, cam, S, focal, self_shadow=True, light_positions=None, return_aux=False):
+def render_rgb(verts, topo, params, cam, S, focal, self_shadow=True, light_positions=None, return_aux=False, flag_ambiguous=False):
     """RGB pass. self_shadow=True: render_image_with_RT + MeshRendererShadow.forward + SoftPhongShaderShadow
     (utils/visualize.py:288-319, renderer_helper.py:331-412, 472-523, 565-592). self_shadow=False: render_image
     with the phong renderer (renderer_helper.py:60-81, 106-190). Returns (B,S,S,3)."""
@@ -189,7 +194,9 @@ def render_rgb(verts, topo, params, cam, S, focal, self_shadow=True, light_posit
     if self_shadow:
         light_R, light_T, cam_R, cam_T = process_info_for_shadow(cam, light_positions, verts.mean(1), S, focal)
         _, ndc_l = P.world_to_ndc(verts, light_R, light_T, focal, pp, S)
-        _, zbuf_l, _, _ = P.rasterize_meshes(ndc_l, faces, S, 0.0, 1)                                # :344
+        rl = P.rasterize_meshes(ndc_l, faces, S, 0.0, 2 if flag_ambiguous else 1, return_ambiguous=flag_ambiguous, flag_slivers=False)   # :344 (K=1; K=2 only to see depth ties)
+        zbuf_l = rl[1][..., :1]
+        amb_l = (rl[4] | _depth_tie(rl[0], rl[1])) if flag_ambiguous else None
         amb = torch.sigmoid(params["amb_ratio"])                                                     # optimize_sequence.py:480
         ambient = amb * torch.ones(1, 3, dtype=dt)                                                   # :435-441
         diffuse_c = 1.0 - ambient
@@ -200,7 +207,9 @@ def render_rgb(verts, topo, params, cam, S, focal, self_shadow=True, light_posit
         diffuse_c = torch.full((1, 3), 0.4, dtype=dt)
         specular = torch.full((1, 3), 0.1, dtype=dt)   # shininess=0 -> pow(.,0)=1 -> constant
     _, ndc = P.world_to_ndc(verts, cam_R, cam_T, focal, pp, S)
-    p2f, zbuf, bary, dists = P.rasterize_meshes(ndc, faces, S, 0.0, 1)                               # :353
+    rc = P.rasterize_meshes(ndc, faces, S, 0.0, 2 if flag_ambiguous else 1, return_ambiguous=flag_ambiguous)     # :353
+    p2f, zbuf, bary, dists = rc[0][..., :1], rc[1][..., :1], rc[2][..., :1, :], rc[3][..., :1]
+    amb_c = (rc[4] | _depth_tie(rc[0], rc[1])) if flag_ambiguous else None
     pix_pos = P.interpolate_face_attributes(p2f, bary, fverts)                                       # :364 / :498
     if self_shadow:
         N_, H, W, Kk, _ = pix_pos.shape
@@ -217,11 +226,34 @@ def render_rgb(verts, topo, params, cam, S, focal, self_shadow=True, light_posit
                 aa = in_light.reshape(N_, H, W, Kk, 3)[..., 2] - 0.008
                 vis = vis + torch.sigmoid((d_at - aa) * 1000.0)
         vis = vis / 9.0                                                                              # :408
+        if flag_ambiguous:
+            # (test infrastructure) camera pixels whose colour is not decided at float32 precision: own coverage ambiguous, a shadow tap
+            # on a light-view pixel with ambiguous coverage, or a hit point within 2e-3 px of the .round() boundary of the tap index
+            fx, fy = xs.detach() - torch.floor(xs.detach()), ys.detach() - torch.floor(ys.detach())
+            amb = ((fx - 0.5).abs() < 2e-3) | ((fy - 0.5).abs() < 2e-3)
+            for ii in (-1, 0, 1):
+                for jj in (-1, 0, 1):
+                    amb = amb | amb_l[bk, (yk + ii).clamp(0, S - 1), (xk + jj).clamp(0, S - 1)].reshape(N_, -1)
+            amb_c = amb_c | amb.reshape(N_, H, W)
     texels = P.sample_textures_uv(texture, params["verts_uvs"], params["faces_uvs"], p2f, bary, Fn)  # :572
     pix_n = P.interpolate_face_attributes(p2f, bary, fnorm)                                          # :501-503
     nm = P.sample_textures_uv(nmap, params["verts_uvs"], params["faces_uvs"], p2f, bary, Fn)         # pbr_materials.py:110
+    if flag_ambiguous:
+        with torch.no_grad():
+            # branch of the tangent frame (pbr_materials.py:68: s = sign(z), z >= 0 -> +1) on the un-normalised interpolated normal
+            amb_c = amb_c | (pix_n[..., 0, 2].abs() < 1e-5 * pix_n[..., 0, :].norm(dim=-1).clamp(min=1e-12))
+            # texel boundary of the bilinear footprint: the texture VALUE is continuous there, its derivative w.r.t. uv (hence every
+            # geometry gradient of the photometric term) is not
+            puv = P.interpolate_face_attributes(p2f, bary, params["verts_uvs"][params["faces_uvs"]].repeat(B, 1, 1))[..., 0, :]
+            Ht, Wt = texture.shape[1:3]
+            tx, ty = puv[..., 0] * (Wt - 1), (1 - puv[..., 1]) * (Ht - 1)
+            amb_c = amb_c | ((tx - tx.round()).abs() < 1e-3) | ((ty - ty.round()).abs() < 1e-3)
     pix_n = apply_normal_map(pix_n, nm)                                                              # :505-511
     diff = P.point_light_diffuse(pix_pos, pix_n, light_positions[:, None, None, None, :], diffuse_c[:, None, None, None, :])
+    if flag_ambiguous:
+        with torch.no_grad():      # kink of relu(n^ . l^)
+            lh = F.normalize(light_positions[:, None, None, None, :] - pix_pos, dim=-1, eps=1e-6)
+            amb_c = amb_c | ((F.normalize(pix_n, dim=-1, eps=1e-6) * lh).sum(-1)[..., 0].abs() < 1e-5)
     amb_b = ambient[:, None, None, None, :]
     if self_shadow:
         colors = (amb_b + diff * vis[..., None]) * texels + specular[:, None, None, None, :]        # :517-518
@@ -230,6 +262,8 @@ def render_rgb(verts, topo, params, cam, S, focal, self_shadow=True, light_posit
     img = P.softmax_rgb_blend(colors, p2f, zbuf, dists)                                              # :589-591
     if return_aux:
         aux = {"pix_to_face": p2f, "zbuf": zbuf, "bary": bary}
+        if flag_ambiguous:
+            aux["ambiguous"] = amb_c
         if self_shadow:
             aux.update(zbuf_light=zbuf_l, vis=vis, light_R=light_R, light_T=light_T)
         return img[..., :3], aux

@@ -88,11 +88,16 @@ def pixel_centers(S, dtype):
 
 
 def rasterize_meshes(verts_ndc, faces, image_size, blur_radius=0.0, faces_per_pixel=1,
-                     perspective_correct=True, clip_barycentric_coords=None, cull_backfaces=False):
+                     perspective_correct=True, clip_barycentric_coords=None, cull_backfaces=False, return_ambiguous=False, amb_tol=3e-7, flag_slivers=True):
     """verts_ndc (B,V,3) = (x_ndc, y_ndc, z_view); faces (F,3) long shared by the batch.
 
     Returns pix_to_face (B,S,S,K) int64 packed (b*F+f, -1 empty), zbuf, bary (...,3), dists (signed,
     squared NDC); the float outputs are differentiable w.r.t. verts_ndc (== rasterize_meshes_backward).
+
+    return_ambiguous=True appends a (B,S,S) bool map of pixels whose COVERAGE by some face is not decided at float32 precision: the
+    pixel centre lies within `amb_tol` (relative to the edge's extent) of an edge line while being on the inside of the other edges.
+    Test infrastructure for fp32-vs-fp64 comparisons: such a pixel may legitimately land on either side in any fp32 implementation
+    (including the reference's own CUDA kernels), and in a K=1 pass the flip is a discontinuity of the image.
     """
     if clip_barycentric_coords is None:
         clip_barycentric_coords = blur_radius > 0.0
@@ -140,6 +145,19 @@ def rasterize_meshes(verts_ndc, faces, image_size, blur_radius=0.0, faces_per_pi
         out_bbox = (px > xmax.reshape(-1)[bf] + r) | (px < xmin.reshape(-1)[bf] - r) | \
                    (py > ymax.reshape(-1)[bf] + r) | (py < ymin.reshape(-1)[bf] - r) | (zmin < K_EPS)
         ok = ~((zmax < 0) | out_bbox | zero_area)
+        amb_map = None
+        if return_ambiguous:
+            sgn = torch.sign(face_area)
+            near_all, in_all = torch.zeros_like(ok), torch.ones_like(ok)
+            for (ax, ay, bx, by) in ((x1, y1, x2, y2), (x2, y2, x0, y0), (x0, y0, x1, y1)):
+                e = _edge_fn(px, py, ax, ay, bx, by)
+                near = e.abs() < amb_tol * ((bx - ax).abs() + (by - ay).abs() + (px - ax).abs() + (py - ay).abs())
+                near_all |= near
+                in_all &= near | (e * sgn > 0)
+            flag = ok & near_all & in_all
+            amb_map = torch.zeros(B * S * S, dtype=torch.bool)
+            amb_map[((bf // Fn) * (S * S) + yi * S + xi)[flag]] = True
+            amb_map = amb_map.view(B, S, S)
         if cull_backfaces:
             ok &= ~(face_area < 0)
         ok &= ~(pz < 0)
@@ -169,6 +187,18 @@ def rasterize_meshes(verts_ndc, faces, image_size, blur_radius=0.0, faces_per_pi
     dists = torch.full((B * S * S * K,), -1.0, dtype=dt).index_put((slot,), sd)
     baryo = torch.full((B * S * S * K, 3), -1.0, dtype=dt).index_put((slot,), bary)
     shp = (B, S, S, K)
+    if return_ambiguous:
+        # ... and pixels whose nearest face is a SLIVER in NDC: its barycentric gradients scale with 1/area, and the area of a triangle
+        # whose vertices are float32 numbers of magnitude ~0.5 (absolute uncertainty ~4e-8 each) is only known to ~4e-8 * perimeter
+        with torch.no_grad():
+            f2 = fvd.reshape(B * Fn, 3, 3)
+            ex = (f2[:, 1, :2] - f2[:, 0, :2]).abs().sum(-1) + (f2[:, 2, :2] - f2[:, 0, :2]).abs().sum(-1) + (f2[:, 2, :2] - f2[:, 1, :2]).abs().sum(-1)
+            area = _edge_fn(f2[:, 0, 0], f2[:, 0, 1], f2[:, 1, 0], f2[:, 1, 1], f2[:, 2, 0], f2[:, 2, 1]).abs()
+            sliver = (4e-8 * ex) > 3e-4 * area
+            p0 = pix_to_face.view(shp)[..., 0]
+            if flag_slivers:
+                amb_map = amb_map | ((p0 >= 0) & sliver[p0.clamp(min=0)])
+        return pix_to_face.view(shp), zbuf.view(shp), baryo.view(*shp, 3), dists.view(shp), amb_map
     return pix_to_face.view(shp), zbuf.view(shp), baryo.view(*shp, 3), dists.view(shp)
 
 

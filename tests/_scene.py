@@ -175,3 +175,37 @@ def engine_eval(case, fid, coarse=True, app=True, tfid=None):
     eng.forward_backward(coarse, app, B=n)
     torch.cuda.synchronize()
     return eng.losses()
+
+
+def mask_ambiguous_pixels(case):
+    """Take pixels whose colour is NOT DECIDED AT FLOAT32 PRECISION out of the photometric mask of every frame (for the HIP path and the
+    oracle alike).  HARP's K=1 passes are discontinuous where a pixel centre sits on a face edge — in the camera view, or in the light
+    view, where an uncovered texel reads depth -1 = "in shadow" for up to 9 camera pixels — and where a hit point projects onto the
+    .round() boundary of its shadow-tap index (renderer_helper.py:385): there any two float32 evaluations (ours, the oracle's in fp32, the
+    reference's CUDA kernels) may differ by a whole tap (1/9 of the diffuse term).  The same holds for the other branch points of the
+    path: depth ties between the two nearest faces, the sign branch of the tangent frame (pbr_materials.py:68), relu(n.l) at 0, the
+    texel boundaries of the bilinear footprint (the derivative w.r.t. uv jumps) and the kink of the L1 term (|y_pred - y_true| ~ 0: the
+    sign IS the gradient) — and for pixels on faces that are slivers in NDC, whose barycentric gradients (~1/area) amplify the float32
+    rounding of the NDC vertices themselves (measured: one such face, seen edge-on at the silhouette, carried the largest entries of
+    dL/d ndc with a 0.25 % error, 1e-2 after projection onto the pose parameters; position / normal / texture gradients of the same
+    launch agreed to 2e-6).  One such pixel moves a gradient by ~1/sqrt(#pixels) = 0.2-1 % in relative L2 at these image sizes.
+    The flags come from the oracle's float64 forward pass
+    alone (oracle/p3d_like.rasterize_meshes(return_ambiguous=True), oracle/harp_ref.render_rgb(flag_ambiguous=True)); the oracle's own
+    fp32-vs-fp64 image differences > 1e-3 all fall on flagged pixels.  Returns the fraction of covered pixels removed."""
+    eng = case["eng"]
+    P, model, targets = oracle_inputs(case, torch.float64)
+    fid = torch.arange(case["T"])
+    with torch.no_grad():
+        _, verts = H.prepare_mesh(P, fid, model, case["topo"], use_arm=case["kind"] == "arm")
+        _, aux = H.render_rgb(verts, case["topo"], P, P["cam"][fid], case["S"], case["focal"], self_shadow=eng.self_shadow, return_aux=True,
+                              flag_ambiguous=True)
+    img = _
+    # kink of the L1 photometric term: |y_pred - y_true| below what float32 resolves flips the sign of a channel's gradient
+    kink = ((img - targets["y_true"][fid]).abs() < 3e-4).any(-1)
+    amb = (aux["ambiguous"] | kink) & (aux["pix_to_face"][..., 0] >= 0)
+    cov = (aux["pix_to_face"][..., 0] >= 0).sum().item()
+    y_col = case["targets"]["y_sil_col"].clone()
+    y_col[amb] = 0.0
+    case["targets"]["y_sil_col"] = y_col
+    eng.set_targets(case["targets"]["y_true"], case["targets"]["y_sil"], y_col)
+    return amb.sum().item() / max(cov, 1)

@@ -19,8 +19,7 @@ def build(rank, world, T, S, B, seed=5):
     """the same case on every rank (same seed), then restricted to the rank's frames"""
     from tests._scene import make_fit_case
     case = make_fit_case("hand", T=T, S=S, B=B * world, seed=seed, device="cuda:0")     # global-batch engine (B x world frames): renders all targets
-    if world == 1:
-        return case, case["eng"]
+    # (also for world == 1: a FRESH engine, so that its texture-offset generator starts at the same counter as the ranks' of an N > 1 job)
     from harp_amd.engine import FitEngine
     from harp_amd import synth
     g = case["eng"]
