@@ -1,0 +1,488 @@
+// Backward pass of the fused shader for gfx950, wave-autonomous form (the one the fitting loop runs: harp_shade_bwd).
+// Same per-pixel arithmetic as shade_kernel<true> in shade.hip (the autograd of SoftPhongShaderShadow / SoftPhongShaderPBR,
+// renderer/renderer_helper.py:106-190, 472-523, 565-592; renderer/pbr_materials.py:58-124; fused torch.nn.L1Loss of
+// optimize_sequence.py:543) — what changed is how the gradients leave the lanes.
+//
+// Why: the first version shared three LDS accumulators (vertex hash, texel hash, shadow-tap window) among the four waves of a
+// 16x16-pixel tile.  That costs 17 workgroup barriers per tile (clears, window anchoring, block sums, the counting sort of the
+// texel flush) around ~2 000 instructions per wave; its SQ counters (profiles/r02_a_pmc_sq_*) show where the time went: waves
+// parked 56 % of their life (SQ_WAIT_ANY / SQ_WAVE_CYCLES), VALU busy 31 %, LDS busy 38 %, 2.6 waves per SIMD, ~39 k cycles of
+// lifetime per active wave for ~2 k instructions.  Nothing was saturated; the kernel waited on itself.
+//
+// Now every wave owns a private 9.5-KB slice of LDS for its 16x4-pixel strip and never meets the other waves of its tile again
+// after one barrier at the very start (the LDS tables must be cleared before use):
+//   * texel gradients (4 bilinear corners x 6 channels per pixel): a DIRECT-MAPPED table indexed by (x mod 32, y mod 7) with a tag
+//     per slot — neighbouring texels never collide, a second-chance slot half a table away catches chart seams, a real conflict
+//     falls through to memory-side atomics.  Accumulators are 32-bit FIXED POINT (ds_add_u32 is the fastest LDS atomic on gfx950:
+//     4.8 clk per wave instruction against 8.7 - 44 for ds_add_f64 and 193 for ds_add_f32) with a per-wave
+//     power-of-two scale taken from the wave's largest contribution: |sum| <= 64 lanes x max < 2^30, resolution 2^-23 of that
+//     maximum, i.e. float32-grade.  The table is flushed row-major, lanes = (texel, channel): consecutive addresses share memory
+//     requests (330 G atomics/s against 21 G/s for random addresses), without the counting sort the hash table needed.
+//   * vertex gradients (position, normal, NDC: 27 values per pixel): lanes on the same face are merged first (DPP / bpermute
+//     butterfly), the survivors add into a 32-slot double table.
+//   * shadow-map tap gradients: 16x16 fixed-point window anchored at the strip's smallest tap.
+//   * the 17 per-frame scalars (light colours, light position, light camera, loss): wave reductions -> LDS partials; the LAST
+//     wave of the tile to finish (LDS ticket, no barrier) issues one memory atomic per scalar, so the same-address traffic is what
+//     it was with one flush per tile.
+// LDS 39.4 KB per workgroup -> 4 workgroups per CU; __launch_bounds__(256, 4) keeps the kernel at <= 128 VGPRs (4 waves / SIMD).
+#include "shade_common.h"
+
+namespace {
+
+constexpr int kTW = 32, kTH = 7, kTSlots = kTW * kTH;     // texel table: (x & 31, y % 7)
+constexpr int kVSlots = 32;                               // vertex table
+constexpr int kZW = 16, kZH = 16;                         // shadow-tap window (light-view pixels)
+constexpr int kScalars = 17;                              // 0-8 colours, 9-11 light_pos, 12-14 light_R[:,2], 15 light_T.z, 16 loss
+
+struct WaveLds {
+  int tkey[kTSlots];
+  int tval[6][kTSlots];        // fixed point; 0-2 albedo, 3-5 normal map
+  int vkey[kVSlots];
+  double vval[9][kVSlots];     // 0-2 g_verts, 3-5 g_vnormals, 6-8 g_ndc
+  int zwin[kZW * kZH];         // fixed point
+};
+static_assert(sizeof(WaveLds) * 4 + 4 * 20 * sizeof(float) + 64 <= 40 * 1024, "4 workgroups per CU need <= 40 KB of LDS each");
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ int wave_min_i(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
+  return v;
+}
+// power-of-two scale s with |x| * s < 2^24 for every |x| <= m (so 64 such terms stay below 2^30); inv = 1 / s exactly
+__device__ __forceinline__ void fixed_scale(float m, float& s, float& inv) {
+  int e = ((__float_as_int(m) >> 23) & 0xff) - 126;          // m < 2^e
+  e = min(max(e, -100), 100);
+  s = __int_as_float((127 + 24 - e) << 23);
+  inv = __int_as_float((127 - 24 + e) << 23);
+}
+
+#ifndef SHADE_BWD_OCC
+#define SHADE_BWD_OCC 4
+#endif
+__global__ void __launch_bounds__(256, SHADE_BWD_OCC) shade_bwd_wave_kernel(const harp_shade_args A, const int32_t* __restrict__ order,
+                                                                const int32_t* __restrict__ nact, int nsx) {
+  __shared__ WaveLds s_w[4];
+  __shared__ float s_part[4][20];
+  __shared__ int s_ticket;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int S = A.S, V = A.V;
+  // g_rgb == NULL = FUSED-LOSS mode: the pass forms torch.nn.L1Loss(y_true * m, y_pred * m) and its gradient from the colour it
+  // recomputes anyway (no forward launch at all in a fitting step)
+  const bool fused = A.g_rgb == nullptr;
+  const int dbg = A.debug_skip >> 8;          // ablation switches (timing only, results WRONG): see harp_hip.h
+  int b, st, tx0, ty0, tsub;
+  const int kind = tile_decode(order, nact, A.B, nsx, S, b, st, tx0, ty0, tsub, fused);
+  if (kind == 0 || (dbg & 64)) return;
+  if (kind == 2) {
+    // super-tile without a face: no gradient; its part of the loss against the static targets is a table look-up
+    if (fused && tsub == 0 && threadIdx.x == 0) {
+      const float sum = A.l1_bg_sums[(size_t)A.l1_fid[b] * nsx * nsx + st];
+      if (sum != 0.f) atomicAdd(A.l1_loss, sum * A.l1_inv);
+    }
+    return;
+  }
+  WaveLds& L = s_w[w];
+  for (int i = lane; i < kTSlots; i += 64) {
+    L.tkey[i] = -1;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) L.tval[c][i] = 0;
+  }
+  if (lane < kVSlots) {
+    L.vkey[lane] = -1;
+#pragma unroll
+    for (int c = 0; c < 9; ++c) L.vval[c][lane] = 0.0;
+  }
+  for (int i = lane; i < kZW * kZH; i += 64) L.zwin[i] = 0;
+  if (threadIdx.x == 0) s_ticket = 0;
+  __syncthreads();                     // the only workgroup barrier: every wave is still at the top of the kernel
+
+  const int xi = tx0 + (lane & 15), yi = ty0 + w * 4 + (lane >> 4);
+  const bool in_img = xi < S && yi < S;
+  const size_t o = ((size_t)b * S + (in_img ? yi : 0)) * S + (in_img ? xi : 0);
+  const int f = in_img ? A.face_id[o] : -1;
+  bool act = f >= 0;
+  V3 gc = mk(0.f, 0.f, 0.f);
+  float l1_m = 0.f, loss_acc = 0.f;
+  size_t l1_to = 0;
+  if (fused) {
+    if (in_img) {
+      l1_to = ((size_t)A.l1_fid[b] * S + yi) * S + xi;
+      l1_m = A.l1_mask ? A.l1_mask[l1_to] : 1.f;
+      if (!act && l1_m != 0.f) {         // uncovered pixel inside the mask: background colour against the target, no gradient
+        const float* t = A.l1_target + l1_to * 3;
+        loss_acc = fabsf(A.bg[0] * l1_m - t[0] * l1_m) + fabsf(A.bg[1] * l1_m - t[1] * l1_m) + fabsf(A.bg[2] * l1_m - t[2] * l1_m);
+      }
+    }
+    act = act && (l1_m != 0.f);
+  } else {
+    if (act) gc = ld(A.g_rgb + o * 3);
+    act = act && (gc.x != 0.f || gc.y != 0.f || gc.z != 0.f);
+  }
+  if (dbg & 32) act = false;
+
+  float racc[kScalars];
+#pragma unroll
+  for (int k = 0; k < kScalars; ++k) racc[k] = 0.f;
+  racc[16] = loss_acc;
+  float vsc[27];          // gradient of the face's 3 vertices x (position, normal, ndc)
+  int vidx[3] = {0, 0, 0};
+  float zd[9];            // gradient of the 3x3 shadow-map taps (row-major)
+  int zix = -0x40000000, ziy = -0x40000000;
+  V3 g_tex = mk(0.f, 0.f, 0.f), g_m_keep = mk(0.f, 0.f, 0.f);
+  Bil bs;
+  bs.x0 = 0; bs.y0 = 0; bs.wx = 0.f; bs.wy = 0.f; bs.gxm = 0.f; bs.gym = 0.f;
+#pragma unroll
+  for (int c = 0; c < 27; ++c) vsc[c] = 0.f;
+#pragma unroll
+  for (int c = 0; c < 9; ++c) zd[c] = 0.f;
+
+  if (act) {
+    const float px = pix_to_ndc(xi, S), py = pix_to_ndc(yi, S);
+    const float* col = A.colors;               // amb(3) diff(3) spec(3)
+    Frag g;
+    g.t = load_tri(((const FaceRec*)A.recs) + (size_t)b * A.F + f);
+    g.br = bary_fwd(g.t, px, py);
+    const float b0 = g.br.b0, b1 = g.br.b1, b2 = g.br.b2;
+    g.i0 = A.faces[3 * f]; g.i1 = A.faces[3 * f + 1]; g.i2 = A.faces[3 * f + 2];
+    g.u0 = A.faces_uvs[3 * f]; g.u1 = A.faces_uvs[3 * f + 1]; g.u2 = A.faces_uvs[3 * f + 2];
+    const float* vb = A.verts + (size_t)b * V * 3;
+    const float* nb = A.vnormals + (size_t)b * V * 3;
+    const V3 v0 = ld(vb + 3 * g.i0), v1 = ld(vb + 3 * g.i1), v2 = ld(vb + 3 * g.i2);
+    const V3 n0 = ld(nb + 3 * g.i0), n1 = ld(nb + 3 * g.i1), n2 = ld(nb + 3 * g.i2);
+    const float uv0x = A.verts_uvs[2 * g.u0], uv0y = A.verts_uvs[2 * g.u0 + 1];
+    const float uv1x = A.verts_uvs[2 * g.u1], uv1y = A.verts_uvs[2 * g.u1 + 1];
+    const float uv2x = A.verts_uvs[2 * g.u2], uv2y = A.verts_uvs[2 * g.u2 + 1];
+    g.p = v0 * b0 + v1 * b1 + v2 * b2;
+    g.n = n0 * b0 + n1 * b1 + n2 * b2;
+    g.u = uv0x * b0 + uv1x * b1 + uv2x * b2;
+    g.v = uv0y * b0 + uv1y * b1 + uv2y * b2;
+    g.bs = bil_setup(g.u, g.v, A.Wt, A.Ht);
+    bs = g.bs;
+    V3 tdx, tdy, mdx = mk(0.f, 0.f, 0.f), mdy = mk(0.f, 0.f, 0.f);
+    const bool packed = A.texnm != nullptr && A.nmap != nullptr;
+    if (packed) bil_sample2((const float4*)A.texnm, g.bs, A.Wt, A.Ht, g.texel, g.m, &tdx, &tdy, &mdx, &mdy);
+    else g.texel = bil_sample(A.tex, g.bs, A.Wt, A.Ht, &tdx, &tdy);
+    // normal map (pbr_materials.py:58-124): n' = normalize(-u m.x - v m.y + n m.z)
+    V3 nfin = g.n;
+    if (A.nmap) {
+      if (!packed) g.m = bil_sample(A.nmap, g.bs, A.Wt, A.Ht, &mdx, &mdy);
+      g.s = (g.n.z >= 0.f) ? 1.f : -1.f;
+      g.a = -rcp(g.s + g.n.z);
+      const float bb = g.n.x * g.n.y * g.a;
+      g.tu = mk(1.f + g.s * g.n.x * g.n.x * g.a, g.s * bb, -g.s * g.n.x);
+      g.tv = mk(bb, g.s + g.n.y * g.n.y * g.a, -g.n.y);
+      g.nprime = g.tu * (-g.m.x) + g.tv * (-g.m.y) + g.n * g.m.z;
+      g.lnp = fsqrt(dot(g.nprime, g.nprime));
+      g.nhat = g.nprime * rcp(fmaxf(g.lnp, 1e-12f));
+      nfin = g.nhat;
+    }
+    // PointLights.diffuse: normalize(n, eps 1e-6) . normalize(L - p, eps 1e-6)
+    g.lnh = fsqrt(dot(nfin, nfin));
+    g.nn = nfin * rcp(fmaxf(g.lnh, 1e-6f));
+    g.ldir = ld(A.light_pos + 3 * b) - g.p;
+    g.llen = fsqrt(dot(g.ldir, g.ldir));
+    g.lhat = g.ldir * rcp(fmaxf(g.llen, 1e-6f));
+    g.cosr = dot(g.nn, g.lhat);
+    const float cosang = fmaxf(g.cosr, 0.f);
+    // shadow (renderer_helper.py:379-408)
+    g.vis = 1.f;
+    float sg[9];
+    const float half = 0.5f * (float)S;
+    if (A.zl) {
+      const float* R = A.light_R + 9 * b;
+      const float* T = A.light_T + 3 * b;
+      g.q = mk(g.p.x * R[0] + g.p.y * R[3] + g.p.z * R[6] + T[0], g.p.x * R[1] + g.p.y * R[4] + g.p.z * R[7] + T[1],
+               g.p.x * R[2] + g.p.y * R[5] + g.p.z * R[8] + T[2]);
+      const float rqz = rcp(g.q.z), rhalf = rcp(half);
+      const float xn = (A.focal * g.q.x * rqz - A.ppx + half) * rhalf, yn = (A.focal * g.q.y * rqz - A.ppy + half) * rhalf;
+      const float xs = half - half * xn, ys = half - half * yn;
+      g.ix = (int)rintf(fminf(fmaxf(xs, -1.0e6f), 1.0e6f));     // torch .round().long(): half-to-even
+      g.iy = (int)rintf(fminf(fmaxf(ys, -1.0e6f), 1.0e6f));
+      const float aa = g.q.z - 0.008f;
+      const float* zlb = A.zl + (size_t)b * S * S;
+      float acc = 0.f;
+      int k = 0;
+#pragma unroll
+      for (int ii = -1; ii <= 1; ++ii)
+#pragma unroll
+        for (int jj = -1; jj <= 1; ++jj, ++k) {
+          const int yy = min(max(g.iy + ii, 0), S - 1), xx = min(max(g.ix + jj, 0), S - 1);
+          sg[k] = sigmoidf((zlb[yy * S + xx] - aa) * 1000.0f);
+          acc += sg[k];
+        }
+      g.vis = acc * (1.0f / 9.0f);
+    }
+    const V3 amb = ld(col), dfc = ld(col + 3), spc = ld(col + 6);
+    const V3 lightc = mk(amb.x + dfc.x * cosang * g.vis, amb.y + dfc.y * cosang * g.vis, amb.z + dfc.z * cosang * g.vis);
+    const V3 c = mk(lightc.x * g.texel.x + spc.x, lightc.y * g.texel.y + spc.y, lightc.z * g.texel.z + spc.z);
+    // softmax_rgb_blend, K=1, blur=0 (Appendix A.4); prob in (0.5,1] is taken as 1 (error <= 2e-10)
+    const float zpix = b0 * g.t.z0 + b1 * g.t.z1 + b2 * g.t.z2;
+    const float zinv = (100.0f - zpix) * (1.0f / 99.0f);
+    const float zmax = fmaxf(zinv, 1e-10f);
+    const float wnum = __expf((zinv - zmax) * 1e4f);
+    const float delta = fmaxf(__expf((1e-10f - zmax) * 1e4f), 1e-10f);
+    const float rden = rcp(wnum + delta);
+    const float wk = wnum * rden;
+    if (fused) {
+      // the forward colour of this pixel, the L1 against the target and its gradient (same expressions as the forward kernel)
+      const float o3[3] = {(wnum * c.x + delta * A.bg[0]) * rden, (wnum * c.y + delta * A.bg[1]) * rden, (wnum * c.z + delta * A.bg[2]) * rden};
+      const float wl = A.l1_w[0] * A.l1_inv * l1_m;
+      float gq[3];
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch) {
+        const float d = o3[ch] * l1_m - A.l1_target[l1_to * 3 + ch] * l1_m;
+        racc[16] += fabsf(d);
+        gq[ch] = wl * (float)((d > 0.f) - (d < 0.f));
+      }
+      gc = mk(gq[0], gq[1], gq[2]);
+    }
+    const V3 g_c = gc * wk;
+    // c = lightc * texel + spec
+    g_tex = mk(g_c.x * lightc.x, g_c.y * lightc.y, g_c.z * lightc.z);
+    const V3 g_lc = mk(g_c.x * g.texel.x, g_c.y * g.texel.y, g_c.z * g.texel.z);
+    racc[0] = g_lc.x; racc[1] = g_lc.y; racc[2] = g_lc.z;                                     // amb
+    racc[3] = g_lc.x * cosang * g.vis; racc[4] = g_lc.y * cosang * g.vis; racc[5] = g_lc.z * cosang * g.vis;  // diff
+    racc[6] = g_c.x; racc[7] = g_c.y; racc[8] = g_c.z;                                        // spec
+    const float g_dv = g_lc.x * dfc.x + g_lc.y * dfc.y + g_lc.z * dfc.z;                      // d/d(cosang*vis)
+    const float g_vis = g_dv * cosang;
+    const float g_cos = (g.cosr > 0.f) ? g_dv * g.vis : 0.f;
+    float gu = dot(g_tex, tdx) * (float)(A.Wt - 1), gv = dot(g_tex, tdy) * -(float)(A.Ht - 1);   // d/d(u,v)
+    // cos = nn . lhat
+    const V3 g_nn = g.lhat * g_cos, g_lhat = g.nn * g_cos;
+    const V3 g_ldir = (g.llen > 1e-6f) ? (g_lhat - g.lhat * dot(g.lhat, g_lhat)) * rcp(g.llen) : g_lhat * 1e6f;
+    racc[9] = g_ldir.x; racc[10] = g_ldir.y; racc[11] = g_ldir.z;                             // light_pos
+    V3 g_p = mk(-g_ldir.x, -g_ldir.y, -g_ldir.z);
+    const V3 g_nfin = (g.lnh > 1e-6f) ? (g_nn - g.nn * dot(g.nn, g_nn)) * rcp(g.lnh) : g_nn * 1e6f;
+    V3 g_n = g_nfin;
+    if (A.nmap) {
+      const V3 g_np = (g.lnp > 1e-12f) ? (g_nfin - g.nhat * dot(g.nhat, g_nfin)) * rcp(g.lnp) : g_nfin * 1e12f;
+      const V3 g_m = mk(-dot(g.tu, g_np), -dot(g.tv, g_np), dot(g.n, g_np));
+      g_m_keep = g_m;
+      gu += dot(g_m, mdx) * (float)(A.Wt - 1);
+      gv += dot(g_m, mdy) * -(float)(A.Ht - 1);
+      const V3 g_tu = g_np * (-g.m.x), g_tv = g_np * (-g.m.y);
+      g_n = g_np * g.m.z;
+      const float x = g.n.x, y = g.n.y, s = g.s, a = g.a;
+      // tu = (1 + s x^2 a, s b, -s x), tv = (b, s + y^2 a, -y), b = x y a, a = -1/(s+z)
+      const float g_b = s * g_tu.y + g_tv.x;
+      const float g_a = s * x * x * g_tu.x + y * y * g_tv.y + g_b * x * y;
+      g_n.x += 2.f * s * x * a * g_tu.x - s * g_tu.z + g_b * y * a;
+      g_n.y += 2.f * y * a * g_tv.y - g_tv.z + g_b * x * a;
+      g_n.z += g_a * a * a;
+    }
+    // shadow
+    if (A.zl) {
+      float g_zq = 0.f;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) {
+        const float d = g_vis * (1.0f / 9.0f) * sg[k] * (1.0f - sg[k]) * 1000.0f;
+        zd[k] = d;
+        g_zq -= d;
+      }
+      zix = g.ix; ziy = g.iy;
+      const float* R = A.light_R + 9 * b;
+      g_p = g_p + mk(R[2], R[5], R[8]) * g_zq;
+      racc[12] = g.p.x * g_zq; racc[13] = g.p.y * g_zq; racc[14] = g.p.z * g_zq;             // light_R[:,2]
+      racc[15] = g_zq;                                                                        // light_T.z
+    }
+    // interpolation backward
+    const float gb0 = dot(v0, g_p) + dot(n0, g_n) + uv0x * gu + uv0y * gv;
+    const float gb1 = dot(v1, g_p) + dot(n1, g_n) + uv1x * gu + uv1y * gv;
+    const float gb2 = dot(v2, g_p) + dot(n2, g_n) + uv2x * gu + uv2y * gv;
+    float gnd[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    bary_bwd(g.t, px, py, g.br, gb0, gb1, gb2, gnd);
+    const float bw[3] = {b0, b1, b2};
+    vidx[0] = g.i0; vidx[1] = g.i1; vidx[2] = g.i2;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      vsc[9 * k + 0] = g_p.x * bw[k]; vsc[9 * k + 1] = g_p.y * bw[k]; vsc[9 * k + 2] = g_p.z * bw[k];
+      vsc[9 * k + 3] = g_n.x * bw[k]; vsc[9 * k + 4] = g_n.y * bw[k]; vsc[9 * k + 5] = g_n.z * bw[k];
+      vsc[9 * k + 6] = gnd[3 * k]; vsc[9 * k + 7] = gnd[3 * k + 1]; vsc[9 * k + 8] = gnd[3 * k + 2];
+    }
+  }
+
+  // ---- per-frame scalars: wave sums -> this wave's LDS partials (the last wave of the tile sends them on, below)
+#pragma unroll
+  for (int k = 0; k < kScalars; ++k) {
+    const float s = wave_sum(racc[k]);
+    if (lane == 0) s_part[w][k] = s;
+  }
+  const bool any_act = __any(act ? 1 : 0) != 0;
+
+  float* gvb = A.g_verts + (size_t)b * V * 3;
+  float* gnb = A.g_vnormals + (size_t)b * V * 3;
+  float* gdb = A.g_ndc + (size_t)b * V * 3;
+  if (any_act) {
+    if (!(dbg & 4)) {
+    // ---- vertex gradients: lanes on the same face add to the same three vertices: merge them first (xor distances 1, 2 = x
+    //      neighbours through DPP, 16 = the row below through ds_bpermute), the survivors add into the wave's double table
+    bool alive = act;
+    merge_same_face<27, 19>(vsc, act ? f : -1, alive, lane);
+    if (alive) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const int v = vidx[k];
+        unsigned h = ((unsigned)v * 2654435761u) >> 27;
+        int slot = -1;
+        for (int probe = 0; probe < 4; ++probe) {
+          const int old = atomicCAS(&L.vkey[h], -1, v);
+          if (old == -1 || old == v) { slot = (int)h; break; }
+          h = (h + 1) & (kVSlots - 1);
+        }
+        if (slot >= 0) {
+#pragma unroll
+          for (int c = 0; c < 9; ++c) atomicAdd(&L.vval[c][slot], (double)vsc[9 * k + c]);
+        } else {
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            atomicAdd(gvb + 3 * v + c, vsc[9 * k + c]); atomicAdd(gnb + 3 * v + c, vsc[9 * k + 3 + c]);
+            atomicAdd(gdb + 3 * v + c, vsc[9 * k + 6 + c]);
+          }
+        }
+      }
+    }
+
+    }
+    // ---- shadow-map tap gradients: fixed-point window anchored at the strip's smallest (clamped) tap column / row
+    if (A.zl && A.g_zl && !(dbg & 2)) {
+      const bool has = zix > -0x40000000;
+      const int x0 = wave_min_i(has ? min(max(zix - 1, 0), S - 1) : 0x7fffffff);
+      const int y0 = wave_min_i(has ? min(max(ziy - 1, 0), S - 1) : 0x7fffffff);
+      float zm = 0.f;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) zm = fmaxf(zm, fabsf(zd[k]));
+      zm = wave_max(zm);
+      if (zm > 0.f) {
+        float zs, zinv_s;
+        fixed_scale(zm * 16.0f, zs, zinv_s);           // up to 9 taps of 64 lanes on one light pixel: 4 more bits of head room
+        float* gz = A.g_zl + (size_t)b * S * S;
+        if (has) {
+#pragma unroll
+          for (int r = 0; r < 3; ++r) {
+            const int yy = min(max(ziy + r - 1, 0), S - 1);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+              const float d = zd[3 * r + c];
+              if (d == 0.f) continue;
+              const int xx = min(max(zix + c - 1, 0), S - 1);
+              const int wx = xx - x0, wy = yy - y0;
+              if (wx < kZW && wy < kZH) atomicAdd(&L.zwin[wy * kZW + wx], __float2int_rn(d * zs));
+              else atomicAdd(gz + (size_t)yy * S + xx, d);
+            }
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+#pragma unroll
+        for (int i = lane; i < kZW * kZH; i += 64) {
+          const int q = L.zwin[i];
+          if (q != 0) atomicAdd(gz + (size_t)(y0 + i / kZW) * S + x0 + (i % kZW), (float)q * zinv_s);
+        }
+      }
+    }
+
+    // ---- texture + normal-map gradients: 4 bilinear corners x 6 channels into the direct-mapped fixed-point table
+    if (!(dbg & 1)) {
+      const bool do_t = A.g_tex != nullptr, do_n = (A.nmap != nullptr) && (A.g_nmap != nullptr);
+      const float ma = wave_max(fmaxf(fabsf(g_tex.x), fmaxf(fabsf(g_tex.y), fabsf(g_tex.z))));
+      const float mm = wave_max(fmaxf(fabsf(g_m_keep.x), fmaxf(fabsf(g_m_keep.y), fabsf(g_m_keep.z))));
+      float sa, ia, sm, im;
+      fixed_scale(ma, sa, ia);
+      fixed_scale(mm, sm, im);
+      if (act) {
+        const float ax = 1.f - bs.wx, ay = 1.f - bs.wy;
+        const float cw[4] = {ax * ay, bs.wx * ay, ax * bs.wy, bs.wx * bs.wy};
+        int key[4], slot[4], old[4];
+        bool valid[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int cx = bs.x0 + (k & 1), cy = bs.y0 + (k >> 1);
+          valid[k] = cx < A.Wt && cy < A.Ht && cw[k] != 0.f;
+          key[k] = cy * A.Wt + cx;
+          slot[k] = (cx & (kTW - 1)) + kTW * (int)((unsigned)cy % (unsigned)kTH);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) old[k] = valid[k] ? atomicCAS(&L.tkey[slot[k]], -1, key[k]) : key[k];     // four independent LDS round trips
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          if (!valid[k]) continue;
+          bool ok = old[k] == -1 || old[k] == key[k];
+          if (!ok) {                      // taken by a texel >= 32 columns / 7 rows away (chart seam, strong minification): second chance
+            slot[k] = slot[k] >= kTSlots / 2 ? slot[k] - kTSlots / 2 : slot[k] + kTSlots / 2;
+            const int o2 = atomicCAS(&L.tkey[slot[k]], -1, key[k]);
+            ok = o2 == -1 || o2 == key[k];
+          }
+          const float va[3] = {g_tex.x * cw[k], g_tex.y * cw[k], g_tex.z * cw[k]};
+          const float vm[3] = {g_m_keep.x * cw[k], g_m_keep.y * cw[k], g_m_keep.z * cw[k]};
+          if (ok) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+              if (do_t) atomicAdd(&L.tval[c][slot[k]], __float2int_rn(va[c] * sa));
+              if (do_n) atomicAdd(&L.tval[3 + c][slot[k]], __float2int_rn(vm[c] * sm));
+            }
+          } else {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+              if (do_t) atomicAdd(A.g_tex + (size_t)key[k] * 3 + c, va[c]);
+              if (do_n) atomicAdd(A.g_nmap + (size_t)key[k] * 3 + c, vm[c]);
+            }
+          }
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      // flush, lanes = (slot, channel): a table row holds consecutive texels of one texture row -> consecutive addresses
+      if (!(dbg & 8)) for (int i = lane; i < kTSlots * 3; i += 64) {
+        const int sl = i / 3, c = i - 3 * sl;
+        const int key = L.tkey[sl];
+        if (key < 0) continue;
+        const int a0 = L.tval[c][sl], a1 = L.tval[3 + c][sl];
+        if (a0 != 0) atomicAdd(A.g_tex + (size_t)key * 3 + c, (float)a0 * ia);
+        if (a1 != 0) atomicAdd(A.g_nmap + (size_t)key * 3 + c, (float)a1 * im);
+      }
+    }
+
+    // ---- flush the vertex table, lanes = (slot, component)
+    if (!(dbg & 12)) for (int i = lane; i < kVSlots * 9; i += 64) {
+      const int sl = i / 9, c = i - 9 * sl;
+      const int v = L.vkey[sl];
+      if (v < 0) continue;
+      const float val = (float)L.vval[c][sl];
+      if (val == 0.f) continue;
+      float* dst = c < 3 ? gvb : (c < 6 ? gnb : gdb);
+      atomicAdd(dst + 3 * v + (c % 3), val);
+    }
+  }
+
+  // ---- the last wave of the tile to get here sends the tile's scalar sums on (one memory atomic per scalar per tile)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  int ticket = 0;
+  if (lane == 0) ticket = atomicAdd(&s_ticket, 1);
+  ticket = __shfl(ticket, 0, 64);
+  if (ticket == 3) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    if (lane < kScalars) {
+      const int k = lane;
+      const float s = s_part[0][k] + s_part[1][k] + s_part[2][k] + s_part[3][k];
+      if (s != 0.f) {
+        if (k < 9) { if (A.g_colors) atomicAdd(A.g_colors + k, s); }
+        else if (k < 12) { if (A.g_light_pos) atomicAdd(A.g_light_pos + 3 * b + (k - 9), s); }
+        else if (k < 15) { if (A.g_light_R) atomicAdd(A.g_light_R + 9 * b + 3 * (k - 12) + 2, s); }
+        else if (k == 15) { if (A.g_light_T) atomicAdd(A.g_light_T + 3 * b + 2, s); }
+        else if (fused) atomicAdd(A.l1_loss, s * A.l1_inv);
+      }
+    }
+  }
+}
+
+}  // namespace
+
+// launched by harp_shade_bwd (shade.hip)
+int harp_detail_shade_bwd_wave(const harp_shade_args& a, const int32_t* order, const int32_t* nact, int nsx, unsigned grid, hipStream_t stream) {
+  hipLaunchKernelGGL(shade_bwd_wave_kernel, dim3(grid), dim3(256), 0, stream, a, order, nact, nsx);
+  HARP_CHECK_LAUNCH();
+  return HARP_OK;
+}
