@@ -147,11 +147,54 @@ struct VertexAccum {
   __device__ __forceinline__ void add(int slot, int c, float x) { atomicAdd(&val[slot][c], (T)x); }
 };
 
-// value of lane (lane ^ bit): DPP quad permutes for 1 and 2, ds_bpermute otherwise
+// value of lane (lane ^ bit): DPP only for 1, 2 (quad permutes), 4 (half-row mirror, then quad reversal: i -> 7-i -> (7-i)^3 = i^4)
+// and 8 (row rotate by 8); ds_bpermute (an LDS round trip) otherwise
 __device__ __forceinline__ int lane_xor(int x, int bit) {
   if (bit == 1) return __builtin_amdgcn_mov_dpp(x, 0xB1, 0xF, 0xF, true);
   if (bit == 2) return __builtin_amdgcn_mov_dpp(x, 0x4E, 0xF, 0xF, true);
+  if (bit == 4) return __builtin_amdgcn_mov_dpp(__builtin_amdgcn_mov_dpp(x, 0x141, 0xF, 0xF, true), 0x1B, 0xF, 0xF, true);
+  if (bit == 8) return __builtin_amdgcn_mov_dpp(x, 0x128, 0xF, 0xF, true);
   return __shfl_xor(x, bit);
+}
+
+// Wave-wide reductions on the VALU only (no LDS round trips): DPP inclusive scan inside each row of 16 lanes (row_shr 1, 2, 4, 8),
+// then row_bcast15 / row_bcast31 carry the row totals forward; lane 63 holds the result, returned as a wave-uniform value.
+// (wave_sum above goes through ds_bpermute for the distances DPP cannot express: ~100 cycles per step instead of ~8.)
+#define HARP_DPP_STEP(OP, T_AS_INT, T_FROM_INT, ctrl, rmask, ident_is_self)                                              \
+  {                                                                                                                     \
+    const int self_ = T_AS_INT(v);                                                                                      \
+    const int oth_ = __builtin_amdgcn_update_dpp((ident_is_self) ? self_ : 0, self_, ctrl, rmask, 0xF, false);         \
+    v = OP(v, T_FROM_INT(oth_));                                                                                        \
+  }
+__device__ __forceinline__ float dpp_fadd_(float a, float b) { return a + b; }
+__device__ __forceinline__ int dpp_imin_(int a, int b) { return min(a, b); }
+__device__ __forceinline__ int dpp_ident_(int a) { return a; }
+__device__ __forceinline__ float wave_sum_u(float v) {
+  HARP_DPP_STEP(dpp_fadd_, __float_as_int, __int_as_float, 0x111, 0xF, false)
+  HARP_DPP_STEP(dpp_fadd_, __float_as_int, __int_as_float, 0x112, 0xF, false)
+  HARP_DPP_STEP(dpp_fadd_, __float_as_int, __int_as_float, 0x114, 0xF, false)
+  HARP_DPP_STEP(dpp_fadd_, __float_as_int, __int_as_float, 0x118, 0xF, false)
+  HARP_DPP_STEP(dpp_fadd_, __float_as_int, __int_as_float, 0x142, 0xA, false)
+  HARP_DPP_STEP(dpp_fadd_, __float_as_int, __int_as_float, 0x143, 0xC, false)
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+__device__ __forceinline__ float wave_max_u(float v) {
+  HARP_DPP_STEP(fmaxf, __float_as_int, __int_as_float, 0x111, 0xF, true)
+  HARP_DPP_STEP(fmaxf, __float_as_int, __int_as_float, 0x112, 0xF, true)
+  HARP_DPP_STEP(fmaxf, __float_as_int, __int_as_float, 0x114, 0xF, true)
+  HARP_DPP_STEP(fmaxf, __float_as_int, __int_as_float, 0x118, 0xF, true)
+  HARP_DPP_STEP(fmaxf, __float_as_int, __int_as_float, 0x142, 0xA, true)
+  HARP_DPP_STEP(fmaxf, __float_as_int, __int_as_float, 0x143, 0xC, true)
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+__device__ __forceinline__ int wave_min_u(int v) {
+  HARP_DPP_STEP(dpp_imin_, dpp_ident_, dpp_ident_, 0x111, 0xF, true)
+  HARP_DPP_STEP(dpp_imin_, dpp_ident_, dpp_ident_, 0x112, 0xF, true)
+  HARP_DPP_STEP(dpp_imin_, dpp_ident_, dpp_ident_, 0x114, 0xF, true)
+  HARP_DPP_STEP(dpp_imin_, dpp_ident_, dpp_ident_, 0x118, 0xF, true)
+  HARP_DPP_STEP(dpp_imin_, dpp_ident_, dpp_ident_, 0x142, 0xA, true)
+  HARP_DPP_STEP(dpp_imin_, dpp_ident_, dpp_ident_, 0x143, 0xC, true)
+  return __builtin_amdgcn_readlane(v, 63);
 }
 
 // Lanes of a 16x4-pixel wave that hit the same face add to the same vertices, and same-address LDS atomics serialise: merge such

@@ -9,27 +9,36 @@
 // parked 56 % of their life (SQ_WAIT_ANY / SQ_WAVE_CYCLES), VALU busy 31 %, LDS busy 38 %, 2.6 waves per SIMD, ~39 k cycles of
 // lifetime per active wave for ~2 k instructions.  Nothing was saturated; the kernel waited on itself.
 //
-// Now every wave owns a private 9.5-KB slice of LDS for its 16x4-pixel strip and never meets the other waves of its tile again
-// after one barrier at the very start (the LDS tables must be cleared before use):
-//   * texel gradients (4 bilinear corners x 6 channels per pixel): a DIRECT-MAPPED table indexed by (x mod 32, y mod 7) with a tag
-//     per slot — neighbouring texels never collide, a second-chance slot half a table away catches chart seams, a real conflict
-//     falls through to memory-side atomics.  Accumulators are 32-bit FIXED POINT (ds_add_u32 is the fastest LDS atomic on gfx950:
-//     4.8 clk per wave instruction against 8.7 - 44 for ds_add_f64 and 193 for ds_add_f32) with a per-wave
-//     power-of-two scale taken from the wave's largest contribution: |sum| <= 64 lanes x max < 2^30, resolution 2^-23 of that
-//     maximum, i.e. float32-grade.  The table is flushed row-major, lanes = (texel, channel): consecutive addresses share memory
-//     requests (330 G atomics/s against 21 G/s for random addresses), without the counting sort the hash table needed.
-//   * vertex gradients (position, normal, NDC: 27 values per pixel): lanes on the same face are merged first (DPP / bpermute
-//     butterfly), the survivors add into a 32-slot double table.
-//   * shadow-map tap gradients: 16x16 fixed-point window anchored at the strip's smallest tap.
-//   * the 17 per-frame scalars (light colours, light position, light camera, loss): wave reductions -> LDS partials; the LAST
-//     wave of the tile to finish (LDS ticket, no barrier) issues one memory atomic per scalar, so the same-address traffic is what
-//     it was with one flush per tile.
-// LDS 39.4 KB per workgroup -> 4 workgroups per CU; __launch_bounds__(256, 4) keeps the kernel at <= 128 VGPRs (4 waves / SIMD).
+// Removing the barriers alone (one private LDS slice per wave) changed almost nothing (0.355 -> 0.32 ms): the kernel is bound by
+// LATENCY x WAVE COUNT, not by any unit.  Every wave walks a chain of 7 dependent memory round trips (launch-order slot -> frame /
+// tile -> target row -> face id + mask -> face record + vertex ids -> vertex attributes -> texels -> shadow taps); a launch with
+// the shading switched off still took 0.09 of the 0.32 ms; and fewer than half of the lanes of a 16x4-pixel strip are active (the
+// photometric mask is the ERODED silhouette), so 58 k strips were shaded where 26 k waves' worth of pixels exist.  (A persistent
+// form — fixed grid, each wave looping over tiles — was built too: the loop keeps the ~40 pointers of harp_shade_args and the
+// loop state live, 120 VGPRs spill, and the shading part alone went from 0.19 to 0.30 ms.)
+//
+// Now, per 16x16 tile (one workgroup, dispatched heaviest-first):
+//   * every wave reads face id + mask of its 16x4 strip (coalesced rows); the ACTIVE pixels of the whole tile are compacted with
+//     ballots into one list in LDS (two barriers at the very top, when all four waves are still in step), and wave w shades
+//     entries [64 w, 64 w + 64) of it — typically one or two full waves per tile instead of four half-empty ones; the others leave.
+//   * after that the waves never meet again: gradients leave through WAVE-PRIVATE LDS tables:
+//       - texels (4 bilinear corners x 6 channels per pixel): a DIRECT-MAPPED table indexed by (x mod 32, y mod 8) with a tag per
+//         slot — neighbouring texels never collide, a second-chance slot half a table away catches chart seams, a real conflict
+//         falls through to memory-side atomics.  Accumulators are 32-bit FIXED POINT (ds_add_u32 is the fastest LDS atomic on
+//         gfx950: 4.8 clk per wave instruction against 8.7 - 44 for ds_add_f64 and 193 for ds_add_f32) with a
+//         per-wave power-of-two scale taken from the wave's largest contribution: |sum| <= 64 lanes x max < 2^30, resolution 2^-23
+//         of that maximum, i.e. float32-grade.  Flushed row-major, lanes = (texel, channel): consecutive addresses share memory
+//         requests (330 G atomics/s against 21 G/s for random addresses), without the counting sort the hash table needed.
+//       - vertices (position, normal, NDC: 27 values per pixel): lanes on the same face are merged first (DPP butterfly over the
+//         x neighbours of the compacted order), the survivors add into a 32-slot double table.
+//       - shadow-map taps: 16x16 fixed-point window anchored at the wave's smallest tap.
+//       - the 17 per-frame scalars (light colours, light position, light camera, loss): wave reductions -> LDS partials; the LAST
+//         wave of the tile to finish (LDS ticket, no barrier) issues one memory atomic per scalar.
 #include "shade_common.h"
 
 namespace {
 
-constexpr int kTW = 32, kTH = 7, kTSlots = kTW * kTH;     // texel table: (x & 31, y % 7)
+constexpr int kTW = 32, kTH = 8, kTSlots = kTW * kTH;     // texel table: (x & 31, y & 7)
 constexpr int kVSlots = 32;                               // vertex table
 constexpr int kZW = 16, kZH = 16;                         // shadow-tap window (light-view pixels)
 constexpr int kScalars = 17;                              // 0-8 colours, 9-11 light_pos, 12-14 light_R[:,2], 15 light_T.z, 16 loss
@@ -41,18 +50,8 @@ struct WaveLds {
   double vval[9][kVSlots];     // 0-2 g_verts, 3-5 g_vnormals, 6-8 g_ndc
   int zwin[kZW * kZH];         // fixed point
 };
-static_assert(sizeof(WaveLds) * 4 + 4 * 20 * sizeof(float) + 64 <= 40 * 1024, "4 workgroups per CU need <= 40 KB of LDS each");
+static_assert(sizeof(WaveLds) * 4 + 4 * 20 * sizeof(float) + 2 * 256 * 4 + 64 <= 53 * 1024, "3 workgroups per CU need <= 53 KB of LDS each");
 
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
-}
-__device__ __forceinline__ int wave_min_i(int v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
-  return v;
-}
 // power-of-two scale s with |x| * s < 2^24 for every |x| <= m (so 64 such terms stay below 2^30); inv = 1 / s exactly
 __device__ __forceinline__ void fixed_scale(float m, float& s, float& inv) {
   int e = ((__float_as_int(m) >> 23) & 0xff) - 126;          // m < 2^e
@@ -62,13 +61,16 @@ __device__ __forceinline__ void fixed_scale(float m, float& s, float& inv) {
 }
 
 #ifndef SHADE_BWD_OCC
-#define SHADE_BWD_OCC 4
+#define SHADE_BWD_OCC 3
 #endif
 __global__ void __launch_bounds__(256, SHADE_BWD_OCC) shade_bwd_wave_kernel(const harp_shade_args A, const int32_t* __restrict__ order,
                                                                 const int32_t* __restrict__ nact, int nsx) {
   __shared__ WaveLds s_w[4];
   __shared__ float s_part[4][20];
   __shared__ int s_ticket;
+  __shared__ int s_cnt[4];
+  __shared__ int s_list[256];          // compacted active pixels of the tile: face id | (pixel in tile) << 24
+  __shared__ float s_lmask[256];       // ... and their mask value
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int S = A.S, V = A.V;
   // g_rgb == NULL = FUSED-LOSS mode: the pass forms torch.nn.L1Loss(y_true * m, y_pred * m) and its gradient from the colour it
@@ -99,31 +101,56 @@ __global__ void __launch_bounds__(256, SHADE_BWD_OCC) shade_bwd_wave_kernel(cons
   }
   for (int i = lane; i < kZW * kZH; i += 64) L.zwin[i] = 0;
   if (threadIdx.x == 0) s_ticket = 0;
-  __syncthreads();                     // the only workgroup barrier: every wave is still at the top of the kernel
 
-  const int xi = tx0 + (lane & 15), yi = ty0 + w * 4 + (lane >> 4);
-  const bool in_img = xi < S && yi < S;
-  const size_t o = ((size_t)b * S + (in_img ? yi : 0)) * S + (in_img ? xi : 0);
-  const int f = in_img ? A.face_id[o] : -1;
-  bool act = f >= 0;
-  V3 gc = mk(0.f, 0.f, 0.f);
-  float l1_m = 0.f, loss_acc = 0.f;
-  size_t l1_to = 0;
-  if (fused) {
-    if (in_img) {
-      l1_to = ((size_t)A.l1_fid[b] * S + yi) * S + xi;
-      l1_m = A.l1_mask ? A.l1_mask[l1_to] : 1.f;
-      if (!act && l1_m != 0.f) {         // uncovered pixel inside the mask: background colour against the target, no gradient
-        const float* t = A.l1_target + l1_to * 3;
-        loss_acc = fabsf(A.bg[0] * l1_m - t[0] * l1_m) + fabsf(A.bg[1] * l1_m - t[1] * l1_m) + fabsf(A.bg[2] * l1_m - t[2] * l1_m);
+  // ---- own 16x4 strip: face id, mask -> active flag (coalesced rows)
+  float loss_acc = 0.f;
+  size_t tbase = 0;
+  {
+    const int xi = tx0 + (lane & 15), yi = ty0 + w * 4 + (lane >> 4);
+    const bool in_img = xi < S && yi < S;
+    const int f0 = in_img ? A.face_id[((size_t)b * S + yi) * S + xi] : -1;
+    bool act0 = f0 >= 0;
+    float m0 = 0.f;
+    if (fused) {
+      tbase = (size_t)A.l1_fid[b] * S * S;
+      if (in_img) {
+        const size_t to = tbase + (size_t)yi * S + xi;
+        m0 = A.l1_mask ? A.l1_mask[to] : 1.f;
+        if (!act0 && m0 != 0.f) {         // uncovered pixel inside the mask: background colour against the target, no gradient
+          const float* t = A.l1_target + to * 3;
+          loss_acc = fabsf(A.bg[0] * m0 - t[0] * m0) + fabsf(A.bg[1] * m0 - t[1] * m0) + fabsf(A.bg[2] * m0 - t[2] * m0);
+        }
       }
+      act0 = act0 && (m0 != 0.f);
     }
-    act = act && (l1_m != 0.f);
-  } else {
+    if (dbg & 32) act0 = false;
+    // ---- compaction of the tile's active pixels (row-major): wave w then shades entries [64 w, 64 w + 64)
+    const unsigned long long bal = __ballot(act0 ? 1 : 0);
+    if (lane == 0) s_cnt[w] = __popcll(bal);
+    __syncthreads();                     // every wave is still at the top of the kernel: cheap
+    int base = 0;
+    for (int i = 0; i < w; ++i) base += s_cnt[i];
+    if (act0) {
+      const int pos = base + __popcll(bal & ((1ull << lane) - 1ull));
+      s_list[pos] = f0 | (((w * 4 + (lane >> 4)) * 16 + (lane & 15)) << 24);
+      s_lmask[pos] = m0;
+    }
+    __syncthreads();
+  }
+  const int n_tile = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+  bool act = 64 * w + lane < n_tile;
+  const int ent = act ? s_list[64 * w + lane] : 0;
+  const int f = ent & 0x00ffffff;
+  const int pix = (int)((unsigned)ent >> 24);
+  const int xi = tx0 + (pix & 15), yi = ty0 + (pix >> 4);
+  const size_t o = ((size_t)b * S + yi) * S + xi;
+  const size_t l1_to = tbase + (size_t)yi * S + xi;
+  const float l1_m = act ? s_lmask[64 * w + lane] : 0.f;
+  V3 gc = mk(0.f, 0.f, 0.f);
+  if (!fused) {
     if (act) gc = ld(A.g_rgb + o * 3);
     act = act && (gc.x != 0.f || gc.y != 0.f || gc.z != 0.f);
   }
-  if (dbg & 32) act = false;
 
   float racc[kScalars];
 #pragma unroll
@@ -307,22 +334,28 @@ __global__ void __launch_bounds__(256, SHADE_BWD_OCC) shade_bwd_wave_kernel(cons
   }
 
   // ---- per-frame scalars: wave sums -> this wave's LDS partials (the last wave of the tile sends them on, below)
+  const bool working = 64 * w < n_tile;          // (wave-uniform) this wave has a share of the tile's active pixels
+  if (working) {
 #pragma unroll
-  for (int k = 0; k < kScalars; ++k) {
-    const float s = wave_sum(racc[k]);
-    if (lane == 0) s_part[w][k] = s;
+    for (int k = 0; k < kScalars; ++k) {
+      const float s = wave_sum_u(racc[k]);
+      if (lane == 0) s_part[w][k] = s;
+    }
+  } else {
+    const float s = wave_sum_u(loss_acc);
+    if (lane < kScalars) s_part[w][lane] = (lane == 16) ? s : 0.f;
   }
-  const bool any_act = __any(act ? 1 : 0) != 0;
+  const bool any_act = working && __any(act ? 1 : 0) != 0;
 
   float* gvb = A.g_verts + (size_t)b * V * 3;
   float* gnb = A.g_vnormals + (size_t)b * V * 3;
   float* gdb = A.g_ndc + (size_t)b * V * 3;
   if (any_act) {
     if (!(dbg & 4)) {
-    // ---- vertex gradients: lanes on the same face add to the same three vertices: merge them first (xor distances 1, 2 = x
-    //      neighbours through DPP, 16 = the row below through ds_bpermute), the survivors add into the wave's double table
+    // ---- vertex gradients: lanes on the same face add to the same three vertices: merge them first (xor distances 1, 2, 4 = x
+    //      neighbours in the compacted order), the survivors add into the wave's double table
     bool alive = act;
-    merge_same_face<27, 19>(vsc, act ? f : -1, alive, lane);
+    merge_same_face<27, 7>(vsc, act ? f : -1, alive, lane);
     if (alive) {
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
@@ -351,12 +384,12 @@ __global__ void __launch_bounds__(256, SHADE_BWD_OCC) shade_bwd_wave_kernel(cons
     // ---- shadow-map tap gradients: fixed-point window anchored at the strip's smallest (clamped) tap column / row
     if (A.zl && A.g_zl && !(dbg & 2)) {
       const bool has = zix > -0x40000000;
-      const int x0 = wave_min_i(has ? min(max(zix - 1, 0), S - 1) : 0x7fffffff);
-      const int y0 = wave_min_i(has ? min(max(ziy - 1, 0), S - 1) : 0x7fffffff);
+      const int x0 = wave_min_u(has ? min(max(zix - 1, 0), S - 1) : 0x7fffffff);
+      const int y0 = wave_min_u(has ? min(max(ziy - 1, 0), S - 1) : 0x7fffffff);
       float zm = 0.f;
 #pragma unroll
       for (int k = 0; k < 9; ++k) zm = fmaxf(zm, fabsf(zd[k]));
-      zm = wave_max(zm);
+      zm = wave_max_u(zm);
       if (zm > 0.f) {
         float zs, zinv_s;
         fixed_scale(zm * 16.0f, zs, zinv_s);           // up to 9 taps of 64 lanes on one light pixel: 4 more bits of head room
@@ -388,8 +421,8 @@ __global__ void __launch_bounds__(256, SHADE_BWD_OCC) shade_bwd_wave_kernel(cons
     // ---- texture + normal-map gradients: 4 bilinear corners x 6 channels into the direct-mapped fixed-point table
     if (!(dbg & 1)) {
       const bool do_t = A.g_tex != nullptr, do_n = (A.nmap != nullptr) && (A.g_nmap != nullptr);
-      const float ma = wave_max(fmaxf(fabsf(g_tex.x), fmaxf(fabsf(g_tex.y), fabsf(g_tex.z))));
-      const float mm = wave_max(fmaxf(fabsf(g_m_keep.x), fmaxf(fabsf(g_m_keep.y), fabsf(g_m_keep.z))));
+      const float ma = wave_max_u(fmaxf(fabsf(g_tex.x), fmaxf(fabsf(g_tex.y), fabsf(g_tex.z))));
+      const float mm = wave_max_u(fmaxf(fabsf(g_m_keep.x), fmaxf(fabsf(g_m_keep.y), fabsf(g_m_keep.z))));
       float sa, ia, sm, im;
       fixed_scale(ma, sa, ia);
       fixed_scale(mm, sm, im);
