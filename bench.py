@@ -39,14 +39,28 @@ def erode(mask, iters=2):
     return m[:, 0]
 
 
-def build_engine(rank, world, device, T=T_FRAMES, img=S, B=B_PER_GPU, seed=0):
-    tpl = synth.load_template("hand")
-    topo = synth.build_topology(tpl["faces0"], 778)
-    model = synth.make_mano_model(tpl, seed=seed)
-    seq, focal = synth.make_sequence(model, T, img, seed=seed)
+def build_engine(rank, world, device, T=T_FRAMES, img=S, B=B_PER_GPU, seed=0, kind="hand"):
+    """kind "hand": subdivided MANO hand (C2/C3/C4); "arm": SMPL-X right-arm mesh 4083 v / 8128 f with the kinematic-tree LBS (C5)"""
+    if kind == "hand":
+        tpl = synth.load_template("hand")
+        topo = synth.build_topology(tpl["faces0"], 778)
+        model = synth.make_mano_model(tpl, seed=seed)
+        seq, focal = synth.make_sequence(model, T, img, seed=seed)
+        kw = {}
+    else:
+        tpl = synth.load_template("arm")
+        topo = synth.build_topology(tpl["faces0"], 1026)
+        model = synth.make_smplx_arm_model(tpl, seed=seed)
+        focal = 1000.0 * img / 224.0
+        ga = torch.Generator().manual_seed(seed + 1)
+        c = model["v_template"].mean(0)
+        seq = dict(pose=torch.randn(T, 45, generator=ga) * 0.15, rot=torch.randn(T, 3, generator=ga) * 0.2, trans=torch.zeros(T, 3),
+                   shape=torch.randn(T, 10, generator=ga) * 0.3,
+                   cam=torch.tensor([[2 * focal / (img * 1.6), -float(c[0]), -float(c[1])]]).repeat(T, 1) + torch.randn(T, 3, generator=ga) * 0.005)
+        kw = dict(use_arm=True, opt_arm_pose=True)
     seq["joints"] = torch.zeros(T, 21, 3)
     eng = FitEngine(model, topo, tpl["verts_uvs"], tpl["faces_uvs"], tpl["uv_mask"].astype(np.float32) / 255.0, seq, img, focal, B,
-                    device=device, rank=rank, world_size=world, seed=seed)
+                    device=device, rank=rank, world_size=world, seed=seed, **kw)
     # ---- synthetic targets: render a perturbed "ground-truth" parameter set with the engine itself (SURVEY.md §8d)
     Tl = T // world
     lo = rank * Tl
@@ -61,7 +75,7 @@ def build_engine(rank, world, device, T=T_FRAMES, img=S, B=B_PER_GPU, seed=0):
         eng.params["texture"].copy_((0.35 + 0.5 * tex)[None].to(device))
     y_true = torch.empty(Tl, img, img, 3, device=device)
     y_sil = torch.empty(Tl, img, img, device=device)
-    joints = torch.empty(T, 21, 3, device=device)
+    joints = torch.empty(T, eng.n_joints, 3, device=device)
     eng.set_stage(False, True)
     eng.y_true, eng.y_sil, eng.y_sil_col = y_true, y_sil, y_sil      # placeholders (losses are ignored here)
     for s0 in range(0, T, B):
@@ -77,7 +91,7 @@ def build_engine(rank, world, device, T=T_FRAMES, img=S, B=B_PER_GPU, seed=0):
     with torch.no_grad():
         for k, v in saved.items():
             eng.params[k].copy_(v)
-    eng.init_joints = (joints + torch.randn(T, 21, 3, generator=g).to(device) * 2.0).contiguous()    # METRO-like noisy anchors (mm)
+    eng.init_joints = (joints[:, :21] + torch.randn(T, 21, 3, generator=g).to(device) * 2.0).contiguous()    # METRO-like noisy anchors (mm)
     eng.set_targets(y_true, y_sil, erode(y_sil), frame_offset=lo)
     eng.compute_reference_mesh()
     eng.g_buf.zero_()
@@ -96,9 +110,11 @@ def algorithmic_bytes(eng):
     return a_frame, a_step, dict(geom=geom, S2=S2, V=V, F=F)
 
 
-def kernel_roofline(eng, steps):
+def kernel_roofline(eng, steps, overlap=False):
     """Duration of the dominant kernel, measured with HIP events on the launch stream in an eager (non-graph) re-run of the
-    same steps right after the timed region; algorithmic bytes per launch from SURVEY.md §8(d)."""
+    same steps right after the timed region; algorithmic bytes per launch from SURVEY.md §8(d).
+    overlap=False: one stream, every event pair brackets exactly one kernel group running alone.  overlap=True: the step's real
+    two-stream schedule — the pair then measures the group IN SITU, next to whatever the second stream runs at that moment."""
     from harp_amd import _lib
     L = _lib.lib()
     names = ["harp_rasterize_fwd", "harp_rasterize_l1_fwd", "harp_shade_fwd", "harp_shade_bwd", "harp_silhouette_bwd", "harp_depth_bwd"]
@@ -123,7 +139,7 @@ def kernel_roofline(eng, steps):
         orig[n] = getattr(L, n)
         setattr(L, n, Timed(n, orig[n]))
     try:
-        eng.overlap = False          # one stream: event pairs then bracket exactly one kernel group each
+        eng.overlap = overlap        # False = one stream: event pairs then bracket exactly one kernel group each
         for i in range(steps):
             fid = (torch.arange(eng.B) + i * eng.B) % (eng.T // eng.world) + eng.target_offset
             eng.step(fid, True, True, use_graph=False)
@@ -137,6 +153,39 @@ def kernel_roofline(eng, steps):
     for n in names[2:]:
         if ms.get(n):
             out[n] = float(np.mean(ms[n]))
+    return out
+
+
+def extra_rates(eng, device, steps=12, warmup=4):
+    """Rates of the other BASELINE.json configurations and modes (not the headline `value`): the same step with the rendered image
+    materialised like the reference's y_pred (keep_image=True), C2 at the reference's batch size 18, and C5's per-GPU share (SMPL-X
+    arm mesh at 1024x1024, 32 frames / GPU).  Graph-replayed steps, barrier-free single GPU, synthetic targets rendered by the engine."""
+    def rate(e):
+        B, T = e.B, e.T
+        e.set_schedule(torch.stack([(torch.arange(B) + i * B) % T for i in range(warmup + steps)]).to(torch.int32))
+        for _ in range(warmup):
+            e.step(None, True, True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            e.step(None, True, True)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        return {"frames_per_s": B * steps / dt, "ms_per_step": dt / steps * 1e3, "frames_per_step": B, "steps": steps}
+    out = {}
+    eng.keep_image = True
+    out["C3_rendered_image_written(keep_image=True)"] = rate(eng)
+    eng.keep_image = False
+    e = build_engine(0, 1, device, T=72, img=S, B=18)[0]
+    e.keep_image = False
+    out["C2_reference_batch_18"] = rate(e)
+    del e
+    torch.cuda.empty_cache()
+    e = build_engine(0, 1, device, T=32, img=1024, B=32, kind="arm")[0]
+    e.keep_image = False
+    out["C5_arm_1024_per_gpu_share"] = dict(rate(e), mesh="SMPL-X right arm 4083v/8128f, kinematic-tree LBS")
+    del e
+    torch.cuda.empty_cache()
     return out
 
 
@@ -214,6 +263,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the rates of the other configurations (keep_image, B=18, C5 arm 1024)")
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -296,6 +346,7 @@ def main():
     if rank == 0 and world == 1:
         a_frame, a_step, parts = algorithmic_bytes(eng)
         kt = kernel_roofline(eng, 4)
+        kt_situ = kernel_roofline(eng, 4, overlap=True)
         # dominant kernel: the fused camera-view rasteriser (K=1 + soft silhouette); its algorithmic bytes per frame are the
         # rasteriser sub-figure of SURVEY.md §8(d): geom_pos + S^2*(4+4+12+4) for the K=1 fragment set + S^2*4 for alpha
         dom = max(kt, key=kt.get)
@@ -317,12 +368,18 @@ def main():
             tjson = json.load(open(tpath))
             traffic = tjson.get(dom)
         # the same figures for every timed kernel group (north_star asks for the rasteriser's fraction explicitly)
-        per_kernel = {k: {"avg_ms": kt[k], "algorithmic_bytes": alg[k], "achieved_GBps": alg[k] / (kt[k] * 1e-3) / 1e9,
+        per_kernel = {k: {"avg_ms": kt[k], "in_situ_ms": kt_situ.get(k), "algorithmic_bytes": alg[k], "achieved_GBps": alg[k] / (kt[k] * 1e-3) / 1e9,
                           "frac": alg[k] / (kt[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": tjson.get(k)} for k in kt}
         out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                           "traffic": traffic, "algorithmic_bytes_per_launch": alg[dom], "avg_ms": kt[dom],
+                           "traffic": traffic,
+                           "traffic_source": "NOT measured in this run (PMC counters cannot be read in-process): per-launch FETCH_SIZE / WRITE_SIZE of the last "
+                                             "committed rocprofv3 pass over this command, profiles/traffic_latest.json",
+                           "algorithmic_bytes_per_launch": alg[dom], "avg_ms": kt[dom], "in_situ_ms": kt_situ.get(dom),
+                           "in_situ_frac": alg[dom] / (kt_situ[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS if kt_situ.get(dom) else None,
                            "kernel_ms": kt, "per_kernel": per_kernel, "step_algorithmic_bytes": a_frame * eng.B + a_step,
                            "step_frac_of_hbm_roofline": (a_frame * eng.B + a_step) / (dt / args.steps) / 1e9 / HBM_PEAK_GBS}
+        if not args.no_extras:
+            out["extras"] = extra_rates(eng, device)
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
     if rank == 0:

@@ -167,3 +167,7 @@ SIGNATURES.update({
     "harp_allreduce_flat": (_i, [_vp, _vp, _sz, _vp]),
 })
 COMM_ID_BYTES = 128
+SIGNATURES.update({
+    "harp_rasterize_fragments_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "harp_rasterize_fragments_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _vp]),
+})

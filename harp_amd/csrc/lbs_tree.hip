@@ -14,7 +14,6 @@ namespace {
 
 constexpr int MAXJ = 64;          // joints
 constexpr int MAXB = 32;          // shape coefficients
-constexpr int FPB = 4;            // frames per workgroup in the skinning kernels
 
 // smplx.lbs.batch_rodrigues
 __device__ __forceinline__ void rod_fwd(const float r[3], float R[9]) {
@@ -78,17 +77,29 @@ __global__ void __launch_bounds__(64) tree_joints_kernel(const harp_tree_model M
     Jrest[(size_t)b * NJ * 3 + i] = acc;
   }
   __syncthreads();
-  if (l == 0) {
-    // batch_rigid_transform: chain[i] = chain[parent] @ [R_i | J_i - J_parent]   (sequential: 55 tiny products)
-    for (int k = 0; k < 9; ++k) sG[0][(k / 3) * 4 + (k % 3)] = sR[0][k];
-    for (int r = 0; r < 3; ++r) sG[0][r * 4 + 3] = sJ[0][r];
-    for (int j = 1; j < NJ; ++j) {
-      const int p = M.parents[j];
-      const float rel[3] = {sJ[j][0] - sJ[p][0], sJ[j][1] - sJ[p][1], sJ[j][2] - sJ[p][2]};
-      for (int r = 0; r < 3; ++r) {
-        for (int c = 0; c < 3; ++c)
-          sG[j][r * 4 + c] = sG[p][r * 4] * sR[j][c] + sG[p][r * 4 + 1] * sR[j][3 + c] + sG[p][r * 4 + 2] * sR[j][6 + c];
-        sG[j][r * 4 + 3] = sG[p][r * 4] * rel[0] + sG[p][r * 4 + 1] * rel[1] + sG[p][r * 4 + 2] * rel[2] + sG[p][r * 4 + 3];
+  // batch_rigid_transform: chain[i] = chain[parent] @ [R_i | J_i - J_parent].  Level-parallel: lane j waits until its parent's depth has
+  // been processed (the SMPL-X right-arm tree is 11 levels deep, 55 joints: 11 steps instead of 55 serial products on one lane)
+  {
+    const int j = l;
+    int depth = 0;
+    if (j < NJ) for (int q = M.parents[j]; q >= 0; q = M.parents[q]) ++depth;
+    int maxd = depth;
+#pragma unroll
+    for (int o2 = 32; o2 > 0; o2 >>= 1) maxd = max(maxd, __shfl_xor(maxd, o2, 64));
+    if (j == 0) {
+      for (int k = 0; k < 9; ++k) sG[0][(k / 3) * 4 + (k % 3)] = sR[0][k];
+      for (int r = 0; r < 3; ++r) sG[0][r * 4 + 3] = sJ[0][r];
+    }
+    for (int d = 1; d <= maxd; ++d) {
+      __syncthreads();                    // (one wave: orders the LDS traffic of the previous level)
+      if (j < NJ && depth == d) {
+        const int p = M.parents[j];
+        const float rel[3] = {sJ[j][0] - sJ[p][0], sJ[j][1] - sJ[p][1], sJ[j][2] - sJ[p][2]};
+        for (int r = 0; r < 3; ++r) {
+          for (int c = 0; c < 3; ++c)
+            sG[j][r * 4 + c] = sG[p][r * 4] * sR[j][c] + sG[p][r * 4 + 1] * sR[j][3 + c] + sG[p][r * 4 + 2] * sR[j][6 + c];
+          sG[j][r * 4 + 3] = sG[p][r * 4] * rel[0] + sG[p][r * 4 + 1] * rel[1] + sG[p][r * 4 + 2] * rel[2] + sG[p][r * 4 + 3];
+        }
       }
     }
   }
@@ -104,71 +115,96 @@ __global__ void __launch_bounds__(64) tree_joints_kernel(const harp_tree_model M
   }
 }
 
-// blockIdx.x: vertex chunk (256), blockIdx.y: frame chunk (FPB).  Forward: verts = ((T [vp;1]) - centre + transl) * 1000.
-// Backward: g_vp = T^T g, M = g (x) [vp;1] per vertex (g = g_verts * 1000).
+// ---- dense contractions on the matrix cores ------------------------------------------------------------------------------------
+// v_mfma_f32_16x16x4_f32 (f32 in, f32 accumulate: exact f32, an fmaf chain): D(16x16) += A(16x4) B(4x16) with lane l holding
+// A[l & 15][l >> 4], B[l >> 4][l & 15] and D[(l >> 4) * 4 + r][l & 15], r = 0..3.  These are the contractions BASELINE.json's
+// north_star reserves MFMA for; on the SMPL-X arm (C5) their VALU forms were 17 % of the step (profiles/r02_c5_kernel_stats.txt:
+// tree_skin 111 + 119 us, tree_gA 65 us, tree_gpm 63 us of 2.73 ms; tools/dev/micro/mfma_poseblend.hip: 39 -> 10 us for the blend).
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// v_posed(b, m) = v_template[m] + sum_k pose_map(b,k) posedirs_T[k][m] + sum_k betas(b,k) shapedirs_T[k][m]      (smplx.lbs, Appendix A.13)
+// workgroup = 16 frames x 16 columns of NV*3, its 4 waves split the K = NP + NB reduction, LDS sum, one store.
+__global__ void __launch_bounds__(256) tree_blend_mfma_kernel(const harp_tree_model M, const float* __restrict__ pose_map,
+                                                              const float* __restrict__ betas, int B, float* __restrict__ vp) {
+  __shared__ f32x4 s_acc[4][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int NV3 = M.NV * 3, NP = (M.NJ - 1) * 9, NB = M.NB, K = NP + NB;
+  const int col = blockIdx.x * 16 + (lane & 15), b0 = blockIdx.y * 16;
+  const bool col_ok = col < NV3;
+  const int row = b0 + (lane & 15);
+  const bool row_ok = row < B;
+  const int steps = (K + 3) / 4, per = (steps + 3) / 4;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+  for (int st = w * per; st < min(steps, (w + 1) * per); ++st) {
+    const int k = 4 * st + (lane >> 4);
+    float a = 0.f, bv = 0.f;
+    if (k < NP) {
+      if (row_ok) a = pose_map[(size_t)row * NP + k];
+      if (col_ok) bv = M.posedirs_T[(size_t)k * NV3 + col];
+    } else if (k < K) {
+      if (row_ok) a = betas[row * NB + (k - NP)];
+      if (col_ok) bv = M.shapedirs_T[(size_t)(k - NP) * NV3 + col];
+    }
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv, acc, 0, 0, 0);
+  }
+  s_acc[w][lane] = acc;
+  __syncthreads();
+  if (w == 0 && col_ok) {
+    const f32x4 t = s_acc[0][lane] + s_acc[1][lane] + s_acc[2][lane] + s_acc[3][lane];
+    const float base = M.v_template[col];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int bb = b0 + (lane >> 4) * 4 + r;
+      if (bb < B) vp[(size_t)bb * NV3 + col] = base + t[r];
+    }
+  }
+}
+
+// skinning: workgroup = 64 vertices x 4 frames; the weight rows of the 64 vertices (coalesced load, odd stride => conflict-free LDS
+// rows) and the 4 frames' joint transforms are staged in LDS.  Forward: verts = ((T [vp;1]) - centre + transl) * 1000.
+// Backward: g_vp = T^T g (g = g_verts * 1000); the outer products g (x) [vp;1] are contracted with the weights by tree_gA_mfma_kernel.
+constexpr int kSkinV = 64, kSkinF = 4;
 template <bool BWD>
-__global__ void __launch_bounds__(256) tree_skin_kernel(const harp_tree_model M, const float* __restrict__ betas,
-                                                        const float* __restrict__ transl, const float* __restrict__ pose_map,
+__global__ void __launch_bounds__(256) tree_skin_kernel(const harp_tree_model M, const float* __restrict__ transl, const float* __restrict__ vp,
                                                         const float* __restrict__ A, const float* __restrict__ G, int B,
-                                                        float* __restrict__ verts, const float* __restrict__ g_verts,
-                                                        float* __restrict__ g_vp, float* __restrict__ Mo) {
+                                                        float* __restrict__ verts, const float* __restrict__ g_verts, float* __restrict__ g_vp) {
   extern __shared__ float smem[];
-  const int NJ = M.NJ, NB = M.NB, NV = M.NV, NP = (NJ - 1) * 9;
-  float* s_pm = smem;                       // [FPB][NP]
-  float* s_beta = s_pm + FPB * NP;          // [FPB][NB]
-  float* s_A = s_beta + FPB * NB;           // [FPB][NJ*12]
-  float* s_c = s_A + FPB * NJ * 12;         // [FPB][3]  centre joint position
-  const int v = blockIdx.x * 256 + threadIdx.x;
-  const int b0 = blockIdx.y * FPB;
-  const int nb = min(FPB, B - b0);
-  for (int i = threadIdx.x; i < nb * NP; i += 256) s_pm[i] = pose_map[(size_t)b0 * NP + i];
-  for (int i = threadIdx.x; i < nb * NB; i += 256) s_beta[i] = betas[b0 * NB + i];
+  const int NJ = M.NJ, NV = M.NV;
+  float* s_W = smem;                        // [kSkinV][NJ]
+  float* s_A = s_W + kSkinV * NJ;           // [kSkinF][NJ*12]
+  float* s_c = s_A + kSkinF * NJ * 12;      // [kSkinF][3]  centre joint position
+  const int v0 = blockIdx.x * kSkinV, b0 = blockIdx.y * kSkinF;
+  const int nv = min(kSkinV, NV - v0), nb = min(kSkinF, B - b0);
+  for (int i = threadIdx.x; i < nv * NJ; i += 256) s_W[i] = M.weights[(size_t)v0 * NJ + i];
   for (int i = threadIdx.x; i < nb * NJ * 12; i += 256) s_A[i] = A[(size_t)b0 * NJ * 12 + i];
   for (int i = threadIdx.x; i < nb * 3; i += 256)
     s_c[i] = (M.center_joint >= 0) ? G[((size_t)(b0 + i / 3) * NJ + M.center_joint) * 12 + (i % 3) * 4 + 3] : 0.f;
   __syncthreads();
-  if (v >= NV) return;
-  float vp[FPB][3];
-  const float t0 = M.v_template[3 * v], t1 = M.v_template[3 * v + 1], t2 = M.v_template[3 * v + 2];
+  const int vl = threadIdx.x & (kSkinV - 1), f = threadIdx.x >> 6;
+  if (vl >= nv || f >= nb) return;
+  const int v = v0 + vl, b = b0 + f;
+  float T[12];
 #pragma unroll
-  for (int f = 0; f < FPB; ++f) { vp[f][0] = t0; vp[f][1] = t1; vp[f][2] = t2; }
-  const size_t row = (size_t)NV * 3;
-  for (int k = 0; k < NB; ++k) {
-    const float s0 = M.shapedirs_T[k * row + 3 * v], s1 = M.shapedirs_T[k * row + 3 * v + 1], s2 = M.shapedirs_T[k * row + 3 * v + 2];
+  for (int k = 0; k < 12; ++k) T[k] = 0.f;
+  for (int j = 0; j < NJ; ++j) {
+    const float wt = s_W[vl * NJ + j];
+    if (wt != 0.f) {
 #pragma unroll
-    for (int f = 0; f < FPB; ++f) { const float c = s_beta[f * NB + k]; vp[f][0] += s0 * c; vp[f][1] += s1 * c; vp[f][2] += s2 * c; }
-  }
-  for (int k = 0; k < NP; ++k) {
-    const float p0 = M.posedirs_T[k * row + 3 * v], p1 = M.posedirs_T[k * row + 3 * v + 1], p2 = M.posedirs_T[k * row + 3 * v + 2];
-#pragma unroll
-    for (int f = 0; f < FPB; ++f) { const float c = s_pm[f * NP + k]; vp[f][0] += p0 * c; vp[f][1] += p1 * c; vp[f][2] += p2 * c; }
-  }
-  for (int f = 0; f < nb; ++f) {
-    float T[12];
-#pragma unroll
-    for (int k = 0; k < 12; ++k) T[k] = 0.f;
-    for (int j = 0; j < NJ; ++j) {
-      const float w = M.weights[(size_t)v * NJ + j];
-      if (w != 0.f) {
-#pragma unroll
-        for (int k = 0; k < 12; ++k) T[k] += w * s_A[(f * NJ + j) * 12 + k];
-      }
+      for (int k = 0; k < 12; ++k) T[k] += wt * s_A[(f * NJ + j) * 12 + k];
     }
-    const int b = b0 + f;
-    if (!BWD) {
-      for (int r = 0; r < 3; ++r) {
-        const float o = T[r * 4] * vp[f][0] + T[r * 4 + 1] * vp[f][1] + T[r * 4 + 2] * vp[f][2] + T[r * 4 + 3];
-        verts[((size_t)b * NV + v) * 3 + r] = (o - s_c[f * 3 + r] + transl[3 * b + r]) * 1000.0f;
-      }
-    } else {
-      float g[3];
-      for (int r = 0; r < 3; ++r) g[r] = g_verts[((size_t)b * NV + v) * 3 + r] * 1000.0f;
-      for (int c = 0; c < 3; ++c) g_vp[((size_t)b * NV + v) * 3 + c] = T[c] * g[0] + T[4 + c] * g[1] + T[8 + c] * g[2];
-      float* mo = Mo + ((size_t)b * NV + v) * 12;
-      for (int r = 0; r < 3; ++r) {
-        mo[r * 4] = g[r] * vp[f][0]; mo[r * 4 + 1] = g[r] * vp[f][1]; mo[r * 4 + 2] = g[r] * vp[f][2]; mo[r * 4 + 3] = g[r];
-      }
+  }
+  if (!BWD) {
+    const float* p = vp + ((size_t)b * NV + v) * 3;
+    const float p0 = p[0], p1 = p[1], p2 = p[2];
+    for (int r = 0; r < 3; ++r) {
+      const float o = T[r * 4] * p0 + T[r * 4 + 1] * p1 + T[r * 4 + 2] * p2 + T[r * 4 + 3];
+      verts[((size_t)b * NV + v) * 3 + r] = (o - s_c[f * 3 + r] + transl[3 * b + r]) * 1000.0f;
     }
+  } else {
+    float g[3];
+    for (int r = 0; r < 3; ++r) g[r] = g_verts[((size_t)b * NV + v) * 3 + r] * 1000.0f;
+    for (int c = 0; c < 3; ++c) g_vp[((size_t)b * NV + v) * 3 + c] = T[c] * g[0] + T[4 + c] * g[1] + T[8 + c] * g[2];
   }
 }
 
@@ -215,40 +251,78 @@ __global__ void __launch_bounds__(256) tree_center_bwd_kernel(const harp_tree_mo
   }
 }
 
-// g_A[b][j][k] += sum_{v in chunk} w[v][j] M[b][v][k]   (g_A pre-zeroed)
-constexpr int kChunksA = 8;
-__global__ void __launch_bounds__(256) tree_gA_kernel(const harp_tree_model M, const float* __restrict__ Mo, float* __restrict__ g_A) {
-  const int b = blockIdx.x, NJ = M.NJ, NV = M.NV;
-  const int per = (NV + kChunksA - 1) / kChunksA, v0 = blockIdx.y * per, v1 = min(NV, v0 + per);
-  for (int o = threadIdx.x; o < NJ * 12; o += 256) {
-    const int j = o / 12, k = o % 12;
-    float acc = 0.f;
-    for (int v = v0; v < v1; ++v) {
-      const float w = M.weights[(size_t)v * NJ + j];
-      if (w != 0.f) acc += w * Mo[((size_t)b * NV + v) * 12 + k];
+// g_A(b, j, c) = sum_v W[v][j] * g(b,v,c/4) * [vp(b,v); 1](c%4)    (g = g_verts * 1000): per frame a (NJ x NV)(NV x 12) product.
+// workgroup = (16 joints, one frame); 4 waves split the NV reduction; the outer products are formed on the fly (no (B,NV,12) buffer).
+__global__ void __launch_bounds__(256) tree_gA_mfma_kernel(const harp_tree_model M, const float* __restrict__ g_verts, const float* __restrict__ vp,
+                                                           float* __restrict__ g_A) {
+  __shared__ f32x4 s_acc[4][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int NJ = M.NJ, NV = M.NV;
+  const int j0 = blockIdx.x * 16, b = blockIdx.y;
+  const int ja = j0 + (lane & 15);             // A operand: row = joint
+  const int cb = lane & 15;                    // B operand: column = c (12 used)
+  const int steps = (NV + 3) / 4, per = (steps + 3) / 4;
+  const float* gb = g_verts + (size_t)b * NV * 3;
+  const float* pb = vp + (size_t)b * NV * 3;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+  for (int st = w * per; st < min(steps, (w + 1) * per); ++st) {
+    const int v = 4 * st + (lane >> 4);
+    float a = 0.f, bv = 0.f;
+    if (v < NV) {
+      if (ja < NJ) a = M.weights[(size_t)v * NJ + ja];
+      if (cb < 12) bv = gb[3 * v + (cb >> 2)] * 1000.0f * (((cb & 3) < 3) ? pb[3 * v + (cb & 3)] : 1.0f);
     }
-    if (acc != 0.f) atomicAdd(&g_A[((size_t)b * NJ) * 12 + o], acc);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv, acc, 0, 0, 0);
+  }
+  s_acc[w][lane] = acc;
+  __syncthreads();
+  if (w == 0 && cb < 12) {
+    const f32x4 t = s_acc[0][lane] + s_acc[1][lane] + s_acc[2][lane] + s_acc[3][lane];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int j = j0 + (lane >> 4) * 4 + r;
+      if (j < NJ) g_A[((size_t)b * NJ + j) * 12 + cb] = t[r];
+    }
   }
 }
 
-// g_pose_map[b][k] += sum_{i in chunk} posedirs[i][k] g_vp[b][i]; g_beta likewise (both pre-zeroed)
-constexpr int kChunksP = 16;
-__global__ void __launch_bounds__(256) tree_gpm_kernel(const harp_tree_model M, const float* __restrict__ g_vp, float* __restrict__ g_pm,
-                                                       float* __restrict__ g_beta_b) {
-  const int b = blockIdx.x, NV3 = M.NV * 3, NP = (M.NJ - 1) * 9, NB = M.NB;
-  const int per = (NV3 + kChunksP - 1) / kChunksP, i0 = blockIdx.y * per, i1 = min(NV3, i0 + per);
-  const float* g = g_vp + (size_t)b * NV3;
-  for (int k = threadIdx.x; k < NP + NB; k += 256) {
-    float acc = 0.f;
-    if (k < NP) {
-#pragma unroll 4
-      for (int i = i0; i < i1; ++i) acc += M.posedirs[(size_t)i * NP + k] * g[i];
-      atomicAdd(&g_pm[(size_t)b * NP + k], acc);
-    } else {
-      const int kk = k - NP;
-#pragma unroll 4
-      for (int i = i0; i < i1; ++i) acc += M.shapedirs_T[(size_t)kk * NV3 + i] * g[i];
-      atomicAdd(&g_beta_b[b * NB + kk], acc);
+// g_pose_map(b, k) = sum_i g_vp(b,i) posedirs[i][k];  g_beta(b, k) += sum_i g_vp(b,i) shapedirs_T[k][i]    (i over NV*3)
+// workgroup = (16 frames, 16 output columns, one of kSplit slices of the NV*3 reduction); 4 waves split the slice; LDS sum; the slices
+// meet in memory with float atomics (g_pm / g_beta pre-zeroed).
+constexpr int kSplitP = 8;
+__global__ void __launch_bounds__(256) tree_gpm_mfma_kernel(const harp_tree_model M, const float* __restrict__ g_vp, int B, float* __restrict__ g_pm,
+                                                            float* __restrict__ g_beta_b) {
+  __shared__ f32x4 s_acc[4][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int NV3 = M.NV * 3, NP = (M.NJ - 1) * 9, NB = M.NB, K = NP + NB;
+  const int col = blockIdx.x * 16 + (lane & 15), b0 = blockIdx.y * 16;
+  const int row = b0 + (lane & 15);
+  const int steps = (NV3 + 3) / 4, per_wg = (steps + kSplitP - 1) / kSplitP, per = (per_wg + 3) / 4;
+  const int s_lo = blockIdx.z * per_wg + w * per, s_hi = min(min(steps, (int)(blockIdx.z + 1) * per_wg), s_lo + per);
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+  for (int st = s_lo; st < s_hi; ++st) {
+    const int i = 4 * st + (lane >> 4);
+    float a = 0.f, bv = 0.f;
+    if (i < NV3) {
+      if (row < B) a = g_vp[(size_t)row * NV3 + i];
+      if (col < NP) bv = M.posedirs[(size_t)i * NP + col];
+      else if (col < K) bv = M.shapedirs_T[(size_t)(col - NP) * NV3 + i];
+    }
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv, acc, 0, 0, 0);
+  }
+  s_acc[w][lane] = acc;
+  __syncthreads();
+  if (w == 0 && col < K) {
+    const f32x4 t = s_acc[0][lane] + s_acc[1][lane] + s_acc[2][lane] + s_acc[3][lane];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int bb = b0 + (lane >> 4) * 4 + r;
+      if (bb < B && t[r] != 0.f) {
+        if (col < NP) atomicAdd(&g_pm[(size_t)bb * NP + col], t[r]);
+        else atomicAdd(&g_beta_b[bb * NB + (col - NP)], t[r]);
+      }
     }
   }
 }
@@ -279,22 +353,36 @@ __global__ void __launch_bounds__(64) tree_chain_bwd_kernel(const harp_tree_mode
     for (int k = 0; k < 9; ++k) gRl[j][k] = (j > 0) ? g_pm[(size_t)b * NP + (j - 1) * 9 + k] : 0.f;
   }
   __syncthreads();
-  if (l == 0) {
-    for (int j = NJ - 1; j >= 1; --j) {
-      const int p = M.parents[j];
-      const float rel[3] = {Jb[j * 3] - Jb[p * 3], Jb[j * 3 + 1] - Jb[p * 3 + 1], Jb[j * 3 + 2] - Jb[p * 3 + 2]};
-      float gl[3];
-      for (int c = 0; c < 3; ++c) gl[c] = Gb[p * 12 + c] * gtG[j][0] + Gb[p * 12 + 4 + c] * gtG[j][1] + Gb[p * 12 + 8 + c] * gtG[j][2];
-      for (int r = 0; r < 3; ++r)
-        for (int c = 0; c < 3; ++c) {
-          gRl[j][r * 3 + c] += Gb[p * 12 + r] * gRG[j][c] + Gb[p * 12 + 4 + r] * gRG[j][3 + c] + Gb[p * 12 + 8 + r] * gRG[j][6 + c];
-          gRG[p][r * 3 + c] += gRG[j][r * 3] * Rb[j * 9 + c * 3] + gRG[j][r * 3 + 1] * Rb[j * 9 + c * 3 + 1] +
-                               gRG[j][r * 3 + 2] * Rb[j * 9 + c * 3 + 2] + gtG[j][r] * rel[c];
-        }
-      for (int c = 0; c < 3; ++c) { gtG[p][c] += gtG[j][c]; gJ[p][c] -= gl[c]; gJ[j][c] += gl[c]; }
+  // chain backward, level-parallel from the leaves up: lane j (depth d) is final once every deeper level has been folded into it;
+  // siblings add into their common parent with LDS atomics (a few dozen per frame)
+  {
+    const int j = l;
+    int depth = 0;
+    if (j < NJ) for (int q = M.parents[j]; q >= 0; q = M.parents[q]) ++depth;
+    int maxd = depth;
+#pragma unroll
+    for (int o2 = 32; o2 > 0; o2 >>= 1) maxd = max(maxd, __shfl_xor(maxd, o2, 64));
+    for (int d = maxd; d >= 1; --d) {
+      __syncthreads();
+      if (j < NJ && depth == d) {
+        const int p = M.parents[j];
+        const float rel[3] = {Jb[j * 3] - Jb[p * 3], Jb[j * 3 + 1] - Jb[p * 3 + 1], Jb[j * 3 + 2] - Jb[p * 3 + 2]};
+        float gl[3];
+        for (int c = 0; c < 3; ++c) gl[c] = Gb[p * 12 + c] * gtG[j][0] + Gb[p * 12 + 4 + c] * gtG[j][1] + Gb[p * 12 + 8 + c] * gtG[j][2];
+        for (int r = 0; r < 3; ++r)
+          for (int c = 0; c < 3; ++c) {
+            gRl[j][r * 3 + c] += Gb[p * 12 + r] * gRG[j][c] + Gb[p * 12 + 4 + r] * gRG[j][3 + c] + Gb[p * 12 + 8 + r] * gRG[j][6 + c];
+            atomicAdd(&gRG[p][r * 3 + c], gRG[j][r * 3] * Rb[j * 9 + c * 3] + gRG[j][r * 3 + 1] * Rb[j * 9 + c * 3 + 1] +
+                                              gRG[j][r * 3 + 2] * Rb[j * 9 + c * 3 + 2] + gtG[j][r] * rel[c]);
+          }
+        for (int c = 0; c < 3; ++c) { atomicAdd(&gtG[p][c], gtG[j][c]); atomicAdd(&gJ[p][c], -gl[c]); gJ[j][c] += gl[c]; }
+      }
     }
-    for (int k = 0; k < 9; ++k) gRl[0][k] += gRG[0][k];
-    for (int c = 0; c < 3; ++c) gJ[0][c] += gtG[0][c];
+    __syncthreads();
+    if (j == 0) {
+      for (int k = 0; k < 9; ++k) gRl[0][k] += gRG[0][k];
+      for (int c = 0; c < 3; ++c) gJ[0][c] += gtG[0][c];
+    }
   }
   __syncthreads();
   for (int j = l; j < NJ; j += 64) {
@@ -317,17 +405,17 @@ __global__ void zero_kernel(float* __restrict__ a, size_t n) {
   if (i < n) a[i] = 0.f;
 }
 
-struct TreeWs { float *pm, *A, *G, *Jrest, *Rloc, *g_vp, *Mo, *g_A, *g_pm, *g_Gt; };
+struct TreeWs { float *pm, *A, *G, *Jrest, *Rloc, *vp, *g_vp, *g_A, *g_pm, *g_Gt; };
 TreeWs tree_ws(const harp_tree_model* m, float* ws, int B) {
   const size_t NJ = m->NJ, NV = m->NV, NP = (NJ - 1) * 9;
   TreeWs w; float* p = ws;
   w.pm = p; p += B * NP; w.A = p; p += B * NJ * 12; w.G = p; p += B * NJ * 12; w.Jrest = p; p += B * NJ * 3; w.Rloc = p; p += B * NJ * 9;
-  w.g_vp = p; p += B * NV * 3; w.Mo = p; p += B * NV * 12;
-  w.g_A = p; p += B * NJ * 12; w.g_pm = p; p += B * NP; w.g_Gt = p;     // g_A | g_pm | g_Gt adjacent (zeroed together)
+  w.vp = p; p += B * NV * 3; w.g_vp = p; p += B * NV * 3;
+  w.g_A = p; p += B * NJ * 12; w.g_pm = p; p += B * NP; w.g_Gt = p;     // g_pm | g_Gt adjacent (zeroed together)
   return w;
 }
 
-size_t skin_smem(const harp_tree_model* m) { return sizeof(float) * (size_t)FPB * ((m->NJ - 1) * 9 + m->NB + m->NJ * 12 + 3); }
+size_t skin_smem(const harp_tree_model* m) { return sizeof(float) * ((size_t)kSkinV * m->NJ + (size_t)kSkinF * (m->NJ * 12 + 3)); }
 
 }  // namespace
 
@@ -335,7 +423,7 @@ extern "C" {
 
 size_t harp_lbs_tree_ws_floats(const harp_tree_model* m, int B) {
   const size_t NJ = m->NJ, NV = m->NV, NP = (NJ - 1) * 9;
-  return (size_t)B * (NP + NJ * 12 * 2 + NJ * 3 + NJ * 9 + NV * 3 + NV * 12 + NJ * 12 + NP + NJ * 3);
+  return (size_t)B * (NP + NJ * 12 * 2 + NJ * 3 + NJ * 9 + NV * 3 + NV * 3 + NJ * 12 + NP + NJ * 3);
 }
 
 int harp_lbs_tree_fwd(const harp_tree_model* m, const float* in_pose, const float* betas, const float* transl, int B, float* ws,
@@ -343,8 +431,9 @@ int harp_lbs_tree_fwd(const harp_tree_model* m, const float* in_pose, const floa
   if (!m || !in_pose || !betas || !transl || !ws || !verts || !joints || B <= 0 || m->NJ > MAXJ || m->NB > MAXB) return HARP_ERR_ARG;
   const TreeWs w = tree_ws(m, ws, B);
   hipLaunchKernelGGL(tree_joints_kernel, dim3(B), dim3(64), 0, stream, *m, in_pose, betas, w.pm, w.A, w.G, w.Jrest, w.Rloc);
-  hipLaunchKernelGGL(tree_skin_kernel<false>, dim3((m->NV + 255) / 256, (B + FPB - 1) / FPB), dim3(256), skin_smem(m), stream, *m, betas,
-                     transl, w.pm, w.A, w.G, B, verts, nullptr, nullptr, nullptr);
+  hipLaunchKernelGGL(tree_blend_mfma_kernel, dim3((m->NV * 3 + 15) / 16, (B + 15) / 16), dim3(256), 0, stream, *m, w.pm, betas, B, w.vp);
+  hipLaunchKernelGGL(tree_skin_kernel<false>, dim3((m->NV + kSkinV - 1) / kSkinV, (B + kSkinF - 1) / kSkinF), dim3(256), skin_smem(m), stream, *m,
+                     transl, w.vp, w.A, w.G, B, verts, nullptr, nullptr);
   hipLaunchKernelGGL(tree_joints_out_kernel, dim3((B * m->n_joints_out * 3 + 255) / 256), dim3(256), 0, stream, *m, w.G, verts, transl, B,
                      joints);
   HARP_CHECK_LAUNCH();
@@ -356,15 +445,16 @@ int harp_lbs_tree_bwd(const harp_tree_model* m, const float* in_pose, const floa
                       float* g_verts, const float* g_joints, float* g_in_pose, float* g_betas, float* g_transl, hipStream_t stream) {
   if (!m || !in_pose || !betas || !ws || !g_verts || !g_joints || !g_in_pose || !g_betas || !g_transl) return HARP_ERR_ARG;
   const TreeWs w = tree_ws(m, ws, B);
-  const size_t nz = (size_t)B * (m->NJ * 12 + (m->NJ - 1) * 9 + m->NJ * 3);
-  hipLaunchKernelGGL(zero_kernel, dim3((unsigned)((nz + 255) / 256)), dim3(256), 0, stream, w.g_A, nz);
+  const size_t nz = (size_t)B * ((m->NJ - 1) * 9 + m->NJ * 3);
+  hipLaunchKernelGGL(zero_kernel, dim3((unsigned)((nz + 255) / 256)), dim3(256), 0, stream, w.g_pm, nz);
   hipLaunchKernelGGL(zero_kernel, dim3((B * m->NB + 255) / 256), dim3(256), 0, stream, g_betas, (size_t)B * m->NB);
   hipLaunchKernelGGL(tree_joints_bwd_kernel, dim3((B * m->n_joints_out * 3 + 255) / 256), dim3(256), 0, stream, *m, g_joints, B, w.g_Gt, g_verts);
   hipLaunchKernelGGL(tree_center_bwd_kernel, dim3(B), dim3(256), 0, stream, *m, g_verts, w.g_Gt, g_transl);
-  hipLaunchKernelGGL(tree_skin_kernel<true>, dim3((m->NV + 255) / 256, (B + FPB - 1) / FPB), dim3(256), skin_smem(m), stream, *m, betas,
-                     transl, w.pm, w.A, w.G, B, nullptr, g_verts, w.g_vp, w.Mo);
-  hipLaunchKernelGGL(tree_gA_kernel, dim3(B, kChunksA), dim3(256), 0, stream, *m, w.Mo, w.g_A);
-  hipLaunchKernelGGL(tree_gpm_kernel, dim3(B, kChunksP), dim3(256), 0, stream, *m, w.g_vp, w.g_pm, g_betas);
+  hipLaunchKernelGGL(tree_skin_kernel<true>, dim3((m->NV + kSkinV - 1) / kSkinV, (B + kSkinF - 1) / kSkinF), dim3(256), skin_smem(m), stream, *m,
+                     transl, w.vp, w.A, w.G, B, nullptr, g_verts, w.g_vp);
+  hipLaunchKernelGGL(tree_gA_mfma_kernel, dim3((m->NJ + 15) / 16, B), dim3(256), 0, stream, *m, g_verts, w.vp, w.g_A);
+  const int ncol = (m->NJ - 1) * 9 + m->NB;
+  hipLaunchKernelGGL(tree_gpm_mfma_kernel, dim3((ncol + 15) / 16, (B + 15) / 16, kSplitP), dim3(256), 0, stream, *m, w.g_vp, B, w.g_pm, g_betas);
   hipLaunchKernelGGL(tree_chain_bwd_kernel, dim3(B), dim3(64), 0, stream, *m, in_pose, w.Rloc, w.G, w.Jrest, w.g_A, w.g_pm, w.g_Gt, g_in_pose,
                      g_betas);
   HARP_CHECK_LAUNCH();

@@ -506,6 +506,16 @@ __global__ void __launch_bounds__(256) raster_kernel(const FaceRec* __restrict__
 
 }  // namespace
 
+// per-face records with a bbox dilated by r, per-super-tile face lists (ascending), launch order: shared with csrc/fragments.hip
+int harp_detail_raster_setup(const float* ndc, const int32_t* faces, int B, int V, int F, int S, float r, void* ws, hipStream_t stream) {
+  const RasterWs W = raster_ws_split(ws, B, F, S);
+  hipLaunchKernelGGL(face_setup_kernel, dim3((F + 255) / 256, B), dim3(256), 0, stream, ndc, faces, V, F, r, W.recs, W.bbs);
+  hipLaunchKernelGGL(bin_faces_kernel, dim3((W.nsx * W.nsx + 3) / 4, B), dim3(256), 0, stream, W.bbs, F, S, W.nsx, W.bins, W.cnt);
+  hipLaunchKernelGGL(order_tiles_kernel, dim3(1), dim3(1024), 0, stream, W.cnt, B * W.nsx * W.nsx, W.order, W.nact);
+  HARP_CHECK_LAUNCH();
+  return HARP_OK;
+}
+
 extern "C" {
 
 size_t harp_rasterize_ws_bytes(int B, int F, int S) {

@@ -297,3 +297,54 @@ def shade(ndc, verts, vnormals, tex, nmap, light_pos, colors, face_id, ws, topo,
     pp = (S / 2.0, S / 2.0) if pp is None else pp
     return _Shade.apply(ndc, verts, vnormals, tex, nmap, light_pos, colors, zl, light_R, light_T, face_id, ws, topo, int(S), float(focal),
                         (float(pp[0]), float(pp[1])), tuple(float(x) for x in bg))
+
+
+# ------------------------------------------------------------------------------------------------------
+# fragment-level rasterisation (PyTorch3D's op pair; off the fitting loop's path)
+# ------------------------------------------------------------------------------------------------------
+class _RasterizeFragments(torch.autograd.Function):
+    """_C.rasterize_meshes / _C.rasterize_meshes_backward for a batch sharing one face table."""
+
+    @staticmethod
+    def forward(ctx, ndc, faces, S, blur_radius, K):
+        ndc = _f32(ndc)
+        B, V, _ = ndc.shape
+        F = faces.shape[0]
+        dev = ndc.device
+        ws = rasterize_workspace(B, F, S, dev)
+        p2f = torch.empty(B, S, S, K, dtype=torch.int32, device=dev)
+        zbuf = torch.empty(B, S, S, K, dtype=torch.float32, device=dev)
+        bary = torch.empty(B, S, S, K, 3, dtype=torch.float32, device=dev)
+        dists = torch.empty(B, S, S, K, dtype=torch.float32, device=dev)
+        _lib.check(_lib.lib().harp_rasterize_fragments_fwd(_lib.ptr(ndc), _lib.ptr(faces), B, V, F, S, float(blur_radius), int(K), _lib.ptr(ws),
+                                                           _lib.ptr(p2f), _lib.ptr(zbuf), _lib.ptr(bary), _lib.ptr(dists), _lib.stream()),
+                   "harp_rasterize_fragments_fwd")
+        ctx.save_for_backward(ndc, faces, p2f)
+        ctx.meta = (S, float(blur_radius), int(K))
+        ctx.mark_non_differentiable(p2f)
+        return p2f, zbuf, bary, dists
+
+    @staticmethod
+    def backward(ctx, _g_p2f, g_zbuf, g_bary, g_dists):
+        ndc, faces, p2f = ctx.saved_tensors
+        S, blur_radius, K = ctx.meta
+        B, V, _ = ndc.shape
+        g_ndc = torch.zeros_like(ndc)
+        c = lambda g: None if g is None else _f32(g)
+        gz, gb, gd = c(g_zbuf), c(g_bary), c(g_dists)
+        _lib.check(_lib.lib().harp_rasterize_fragments_bwd(_lib.ptr(ndc), _lib.ptr(faces), _lib.ptr(p2f), _lib.ptr(gz), _lib.ptr(gb), _lib.ptr(gd),
+                                                           B, V, faces.shape[0], S, blur_radius, K, _lib.ptr(g_ndc), _lib.stream()),
+                   "harp_rasterize_fragments_bwd")
+        return g_ndc, None, None, None, None
+
+
+def rasterize_fragments(ndc, faces, S, blur_radius=0.0, faces_per_pixel=1, packed=True):
+    """ndc (B,V,3) = (x_ndc, y_ndc, z_view), faces (F,3) int32 -> pix_to_face (B,S,S,K) int64 [PyTorch3D's packed index b*F + f when
+    `packed`, -1 empty], zbuf, bary (B,S,S,K,3), dists — the outputs of pytorch3d.renderer.mesh.rasterize_meshes, differentiable
+    w.r.t. ndc through zbuf / bary / dists.  faces_per_pixel caps the number of fragments kept per pixel (1..64)."""
+    p2f, zbuf, bary, dists = _RasterizeFragments.apply(ndc, faces, int(S), float(blur_radius), int(faces_per_pixel))
+    p2f = p2f.long()
+    if packed:
+        off = (torch.arange(ndc.shape[0], device=ndc.device) * faces.shape[0]).view(-1, 1, 1, 1)
+        p2f = torch.where(p2f >= 0, p2f + off, p2f)
+    return p2f, zbuf, bary, dists

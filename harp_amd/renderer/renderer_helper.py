@@ -41,13 +41,21 @@ class SilhouetteRenderer:
     def __init__(self, image_size, sigma, faces_per_pixel):
         self.image_size, self.sigma = image_size, sigma
         self.blur_radius = math.log(1.0 / 1e-4 - 1.0) * sigma                                       # renderer_helper.py:46
-        self.faces_per_pixel = faces_per_pixel      # K is not a buffer size here: every face within the blur radius contributes
+        # K is not a buffer size in the fused kernel: every face within the blur radius contributes.  The reference keeps the K nearest;
+        # for a hand mesh fewer than 50 faces ever overlap a pixel, so the cap never binds.  A caller that
+        # needs the cap enforced exactly (K smaller than the depth complexity) gets it from the fragment-level path below.
+        self.faces_per_pixel = faces_per_pixel
 
     def __call__(self, mesh, principal_point=None, focal_length=None, T=None, R=None, materials=None, image_size=None, **kw):
         S = _size(image_size) if image_size is not None else self.image_size
         dev = mesh.device
         ndc = ops.project(mesh.verts_padded(), R.to(dev), T.to(dev), _scalar(focal_length), S, _pp(principal_point))
-        alpha, _ = ops.soft_silhouette(ndc, mesh.topo.faces, S, self.blur_radius, self.sigma)
+        if self.faces_per_pixel < 50:                 # honour a binding cap: K nearest fragments -> sigmoid_alpha_blend (Appendix A.3)
+            p2f, _, _, dists = ops.rasterize_fragments(ndc, mesh.topo.faces, S, self.blur_radius, self.faces_per_pixel)
+            prob = torch.sigmoid(-dists / self.sigma) * (p2f >= 0).to(dists.dtype)
+            alpha = 1.0 - torch.prod(1.0 - prob, dim=-1)
+        else:
+            alpha, _ = ops.soft_silhouette(ndc, mesh.topo.faces, S, self.blur_radius, self.sigma)
         ones = torch.ones_like(alpha)
         return torch.stack([ones, ones, ones, alpha], -1)                                          # sigmoid_alpha_blend: RGB = 1, A = alpha
 
@@ -105,11 +113,80 @@ class MeshRendererShadow(_PhongBase):
         return self._shade(mesh, ndc_c, face_id, ws, materials, lp, colors, S, focal, pp, zl=zl, light_R=R.to(dev), light_T=T.to(dev))
 
 
+class Fragments:
+    """pytorch3d.renderer.mesh.rasterizer.Fragments: what MeshRasterizer.forward returns"""
+
+    def __init__(self, pix_to_face, zbuf, bary_coords, dists):
+        self.pix_to_face, self.zbuf, self.bary_coords, self.dists = pix_to_face, zbuf, bary_coords, dists
+
+    def __iter__(self):
+        return iter((self.pix_to_face, self.zbuf, self.bary_coords, self.dists))
+
+
+class MeshRasterizer:
+    """MeshRasterizer(cameras=PerspectiveCameras(in_ndc=False), raster_settings=RasterizationSettings(image_size, blur_radius,
+    faces_per_pixel)) (renderer_helper.py:33, 44-55, 62-79, 85-99) on the fragment-level HIP op (ops.rasterize_fragments): for callers
+    that bring their own PyTorch3D-style shader.  Returns Fragments with K = faces_per_pixel slots per pixel."""
+
+    def __init__(self, image_size, blur_radius=0.0, faces_per_pixel=1):
+        self.image_size, self.blur_radius, self.faces_per_pixel = image_size, float(blur_radius), int(faces_per_pixel)
+
+    def __call__(self, mesh, principal_point=None, focal_length=None, T=None, R=None, image_size=None, **kw):
+        S = _size(image_size) if image_size is not None else self.image_size
+        dev = mesh.device
+        pp = _pp(principal_point) if principal_point is not None else (S / 2.0, S / 2.0)
+        ndc = ops.project(mesh.verts_padded(), R.to(dev), T.to(dev), _scalar(focal_length), S, pp)
+        return Fragments(*ops.rasterize_fragments(ndc, mesh.topo.faces, S, self.blur_radius, self.faces_per_pixel))
+
+
+def interpolate_face_attributes(pix_to_face, bary, face_attrs):
+    """pytorch3d.ops.interpolate_face_attributes: (N,H,W,K) packed face ids, (N,H,W,K,3), (F_total,3,D) -> (N,H,W,K,D), zero where empty"""
+    mask = pix_to_face < 0
+    a = face_attrs[pix_to_face.clamp(min=0)]
+    return (bary[..., None] * a).sum(-2).masked_fill(mask[..., None], 0.0)
+
+
+def softmax_rgb_blend(colors, fragments, background=(1.0, 1.0, 1.0), sigma=1e-4, gamma=1e-4, znear=1.0, zfar=100.0):
+    """pytorch3d.renderer.blending.softmax_rgb_blend in torch ops: (N,H,W,K,3) -> (N,H,W,4)"""
+    eps = 1e-10
+    mask = (fragments.pix_to_face >= 0).to(colors.dtype)
+    prob = torch.sigmoid(-fragments.dists / sigma) * mask
+    alpha = torch.prod(1.0 - prob, dim=-1)
+    z_inv = (zfar - fragments.zbuf) / (zfar - znear) * mask
+    z_inv_max = torch.max(z_inv, dim=-1).values[..., None].clamp(min=eps)
+    wnum = prob * torch.exp((z_inv - z_inv_max) / gamma)
+    delta = torch.exp((eps - z_inv_max) / gamma).clamp(min=eps)
+    denom = wnum.sum(-1)[..., None] + delta
+    bg = torch.tensor(background, dtype=colors.dtype, device=colors.device)
+    rgb = ((wnum[..., None] * colors).sum(-2) + delta * bg) / denom
+    return torch.cat([rgb, (1.0 - alpha)[..., None]], -1)
+
+
+class NormalRenderer:
+    """MeshRenderer(MeshRasterizer(K=10, blur 0), SoftPhongNormalShader) (renderer_helper.py:82-101, 192-258): the interpolated vertex
+    normals (through the normal map when the materials carry one), y / z flipped, mapped to [0,1], softmax-blended over the K=10
+    fragments.  Visualisation only in the reference (`vis_normal`), hence plain torch ops over the fragment-level rasteriser."""
+
+    def __init__(self, image_size, faces_per_pixel=10):
+        self.rasterizer = MeshRasterizer(image_size, 0.0, faces_per_pixel)
+
+    def __call__(self, mesh, materials=None, **kw):
+        fr = self.rasterizer(mesh, **kw)
+        B = len(mesh)
+        faces = mesh.topo.faces.long()
+        vn = mesh.verts_normals_padded()
+        fn = vn[:, faces].reshape(B * faces.shape[0], 3, 3)
+        pix_n = interpolate_face_attributes(fr.pix_to_face, fr.bary_coords, fn)
+        if materials is not None and getattr(materials, "use_normal_map", False):
+            raise NotImplementedError("normal-map visualisation through the K=10 renderer: use the shading kernels' path (K=1)")
+        pix_n = pix_n * torch.tensor([1.0, -1.0, -1.0], device=pix_n.device)                    # renderer_helper.py:211-212
+        return softmax_rgb_blend((pix_n + 1.0) / 2.0, fr)                                          # :213, :255-257
+
+
 def get_renderers(image_size, light_posi=((1.0, 1.0, -5.0),), silh_sigma=1e-7, silh_gamma=1e-1, silh_faces_per_pixel=50, device="cuda"):
-    """renderer_helper.py:26-103 -> (phong_renderer, silhouette_renderer, normal_renderer).  silh_gamma is inert in the
-    reference too (SoftSilhouetteShader ignores it: SURVEY.md Appendix C.7); the normal-visualisation renderer is eval/debug
-    only (out of scope) and returned as None."""
-    return PhongRenderer(image_size, light_posi), SilhouetteRenderer(image_size, silh_sigma, silh_faces_per_pixel), None
+    """renderer_helper.py:26-103 -> (phong_renderer, silhouette_renderer, phong_normal_renderer).  silh_gamma is inert in the
+    reference too (SoftSilhouetteShader ignores it: SURVEY.md Appendix C.7)."""
+    return PhongRenderer(image_size, light_posi), SilhouetteRenderer(image_size, silh_sigma, silh_faces_per_pixel), NormalRenderer(image_size, 10)
 
 
 def get_shadow_renderers(image_size, light_posi=((1.0, 1.0, -5.0),), silh_sigma=1e-7, silh_gamma=1e-1, silh_faces_per_pixel=50,

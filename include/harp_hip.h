@@ -53,6 +53,22 @@ int harp_silhouette_bwd(const int32_t* faces, int B, int V, int F, int S, float 
 int harp_depth_bwd(const int32_t* face_id, const void* ws, const int32_t* faces, const float* g_z, int B, int V, int F, int S,
                    float* g_ndc, hipStream_t stream);
 
+/* ---- fragment-level rasterisation (the PyTorch3D op pair itself; NOT on the fitting loop's path) -----------------------------
+ * replaces _C.rasterize_meshes(face_verts, mesh_to_face_first_idx, num_faces_per_mesh, clipped_faces_neighbor_idx, image_size,
+ *   blur_radius, faces_per_pixel, bin_size, max_faces_per_bin, perspective_correct=True, clip_barycentric_coords=(blur_radius>0),
+ *   cull_backfaces=False) -> (pix_to_face, zbuf, bary, dists) and _C.rasterize_meshes_backward(face_verts, pix_to_face, grad_zbuf,
+ *   grad_bary, grad_dists, perspective_correct, clip_barycentric_coords) -> grad_face_verts, as reached through MeshRasterizer at
+ *   renderer/renderer_helper.py:52-55 (K=50, blur), :76-79 (K=1), :88-101 (K=10 normal renderer), :444-447.
+ * For callers that keep PyTorch3D-style shader classes.  K = faces_per_pixel is a CAP (1 <= K <= 64): the K nearest candidates are
+ * kept in ascending depth, ties keep the lower face index.  Outputs (B,S,S,K): pix_to_face int32 frame-local (-1 = empty slot; the
+ * PyTorch3D "packed" index is b*F + f), zbuf, bary (B,S,S,K,3), dists (signed squared NDC distance to the nearest edge); empty slots
+ * hold -1 everywhere.  ws: harp_rasterize_ws_bytes(B,F,S).  Backward: any of g_zbuf / g_bary / g_dists may be NULL; g_ndc (+=). */
+int harp_rasterize_fragments_fwd(const float* ndc, const int32_t* faces, int B, int V, int F, int S, float blur_radius, int K, void* ws,
+                                 int32_t* pix_to_face, float* zbuf, float* bary, float* dists, hipStream_t stream);
+int harp_rasterize_fragments_bwd(const float* ndc, const int32_t* faces, const int32_t* pix_to_face, const float* g_zbuf,
+                                 const float* g_bary, const float* g_dists, int B, int V, int F, int S, float blur_radius, int K,
+                                 float* g_ndc, hipStream_t stream);
+
 /* ---- shader --------------------------------------------------------------------------------------------------------
  * replaces SoftPhongShaderShadow.forward + phong_shading_with_shadow + the shadow-map test of
  * MeshRendererShadow.forward (renderer/renderer_helper.py:360-408, 472-523, 565-592), PBRMaterials.apply_normal_map

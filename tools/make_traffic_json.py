@@ -24,7 +24,7 @@ def per_launch(path, counter):
 
 
 GROUPS = {
-    "harp_shade_bwd": (("shade_kernel<true>", 1.0),),
+    "harp_shade_bwd": (("shade_bwd_wave_kernel", 1.0), ("shade_kernel<true>", 1.0)),
     "harp_shade_fwd": (("shade_kernel<false>", 1.0),),
     # face_setup / bin_faces / order_tiles run once per view: their per-launch averages are over both views already
     "raster_cam_fwd(setup+bin+raster)": (("raster_kernel<1>", 1.0), ("face_setup_kernel", 1.0), ("bin_faces_kernel", 1.0), ("order_tiles_kernel", 1.0)),

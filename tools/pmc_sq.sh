@@ -3,7 +3,7 @@
 set -u
 tag=${1:-rXX}; filt=${2:-shade_kernel}
 out=gpurun_out; mkdir -p $out; export TMPDIR=/tmp
-cmd="python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-graph"
+cmd="python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras --no-graph"
 p1="SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_SMEM"
 p2="SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"
 i=0
