@@ -161,6 +161,7 @@ class FitEngine:
         self.fused_loss = True           # loss-only mode: photometric L1 formed inside the shader backward (no forward shading launch)
         self.keep_image = True           # shader forward writes the rendered image s["rgb"] (False: loss + gradient only)
         self.mesh_terms_first = True     # key-point term + mesh regularisers run before the light raster (under the raster set-up) instead of after it
+        self.tail_side = False           # normal-map chain rule (+ early all-reduce) on the second stream: measured SLOWER (0.960 vs 0.948 ms: the extra cross-stream edge costs more than the 5-us kernel it moves)
         self.camera_first = True        # enqueue the camera-view raster chain (the longer one) before the light-view chain: +0.75 %
         self.frozen = ()                 # parameters kept out of the optimiser groups (known_appearance)
         self.disabled_terms = frozenset()   # loss terms left out of the objective altogether (set_disabled_terms)
@@ -438,12 +439,19 @@ class FitEngine:
         if app:
             self._ck(L.harp_shade_bwd(ctypes.byref(a), ST()), "shade_bwd")
             if shared_terms:
-                # the normal-map chain rule (and, for N > 1, the early all-reduce of the map gradients, which runs on RCCL's own stream and
-                # overlaps with the mesh / hand-layer backward) stays on the main stream: 6 us of kernel cost less than the cross-stream
-                # fork it used to ride on (1.027 -> 1.017 ms/step)
-                self._ck(L.harp_normalize3_bwd(p(self.params["normal_map"]), p(s["g_nmap_n"]), self.Ht * self.Wt, p(self.grads["normal_map"]), ST()),
-                         "normalize3_bwd")
-                self._allreduce_maps_early()
+                # the normal-map chain rule (and, for N > 1, the early all-reduce of the map gradients, which overlaps with the mesh /
+                # hand-layer backward) only feeds the optimiser: with `tail_side` it leaves the critical path for the second stream, which
+                # is idle once the silhouette backward is done (the join in front of the mesh-chain backward already exists)
+                def maps_tail():
+                    self._ck(L.harp_normalize3_bwd(p(self.params["normal_map"]), p(s["g_nmap_n"]), self.Ht * self.Wt, p(self.grads["normal_map"]), ST()),
+                             "normalize3_bwd")
+                    self._allreduce_maps_early()
+                if self.tail_side and self.overlap:
+                    side.wait_stream(cur)
+                    with torch.cuda.stream(side):
+                        maps_tail()
+                else:
+                    maps_tail()
             if self.self_shadow:
                 self._ck(L.harp_depth_bwd(p(s["face_l"]), p(s["ws_l"]), p(tp.faces), p(s["g_zl"]), B, V, F, S, p(s["g_ndc_l"]), ST()), "depth_bwd")
                 if not fused:
@@ -727,7 +735,7 @@ class FitEngine:
         # every switch the enqueued launch sequence depends on is part of the key: flipping one re-captures instead of replaying a
         # graph recorded for another configuration
         gkey = (coarse, app, scheduled, self.keep_image, self.fused_loss, self.self_shadow, tuple(self.frozen), self.overlap, self.early_terms,
-                self.packed_texels, self.auto_draw, self.mesh_terms_first, self.camera_first, self.fused_chain, dist_on, self.overlap_allreduce,
+                self.packed_texels, self.auto_draw, self.mesh_terms_first, self.camera_first, self.tail_side, self.fused_chain, dist_on, self.overlap_allreduce,
                 self.comm is not None)
         g = self._graphs.get(gkey)
         if g is None:
