@@ -292,6 +292,14 @@ def main():
     eng.force_allreduce = force_dist
     eng.keep_image = False                      # the step consumes the rendered image inside the shader (fused L1): it is not written out
     eng.graph_collectives = os.environ.get("HARP_GRAPH_COLLECTIVES", "0") == "1"
+    comm = None
+    if (world > 1 or force_dist) and backend == "nccl" and not shared_gpu and os.environ.get("HARP_NO_RCCL_COMM") != "1":
+        # production N > 1 path: RCCL called directly through the C ABI on the step's own streams (harp_allreduce_flat), so the
+        # collective is a node of the same hipGraph as the kernels; torch.distributed only carries the 128-byte communicator id
+        from harp_amd.dist import RcclComm
+        with _StdoutToStderr():
+            comm = RcclComm.from_process_group(device) if world > 1 else RcclComm.single()
+        eng.set_comm(comm)
     Tl = eng.T // world
 
     # the whole frame schedule lives on the device (the reference's DataLoader hands over host tensors every step)
@@ -334,7 +342,9 @@ def main():
                       "frames_per_gpu_per_step": eng.B, "global_batch": world * eng.B, "sequence_frames": eng.T,
                       "parallelism": f"dp{world} (frames sharded; flat gradient bucket of {eng.opt_span[1] * 4} B all-reduced over RCCL: the texture/normal-map "
                                      f"part overlapped with the mesh backward, the remainder before Adam)",
-                      "hipgraph": (not args.no_graph) and world == 1,
+                      "hipgraph": (not args.no_graph) and (world == 1 or comm is not None),
+                      "collective": ("harp_allreduce_flat (RCCL on the step's streams, captured into the hipGraph)" if comm is not None else
+                                     ("torch.distributed.all_reduce, eager steps" if world > 1 else None)),
                       "rendered_image": "not materialised: the shader backward recomputes the colour and forms the photometric L1 and its gradient "
                                         "itself, so the step has no forward shading launch (loss, gradients and the parameter update are its "
                                         "outputs; FitEngine.keep_image=True renders and writes y_pred like the reference)"},
@@ -384,6 +394,9 @@ def main():
             out["cpu_baseline"] = cpu_baseline()
     if rank == 0:
         print(json.dumps(out))
+    if comm is not None:
+        torch.cuda.synchronize()
+        comm.destroy()
     if world > 1 or force_dist:
         dist.destroy_process_group()
 

@@ -38,7 +38,13 @@
 
 namespace {
 
-constexpr int kTW = 32, kTH = 8, kTSlots = kTW * kTH;     // texel table: (x & 31, y & 7)
+#ifndef SHADE_BWD_OCC
+#define SHADE_BWD_OCC 3
+#endif
+#ifndef SHADE_BWD_TH
+#define SHADE_BWD_TH 7
+#endif
+constexpr int kTW = 32, kTH = SHADE_BWD_TH, kTSlots = kTW * kTH;     // texel table: (x & 31, y mod kTH)
 constexpr int kVSlots = 32;                               // vertex table
 constexpr int kZW = 16, kZH = 16;                         // shadow-tap window (light-view pixels)
 constexpr int kScalars = 17;                              // 0-8 colours, 9-11 light_pos, 12-14 light_R[:,2], 15 light_T.z, 16 loss
@@ -50,7 +56,7 @@ struct WaveLds {
   double vval[9][kVSlots];     // 0-2 g_verts, 3-5 g_vnormals, 6-8 g_ndc
   int zwin[kZW * kZH];         // fixed point
 };
-static_assert(sizeof(WaveLds) * 4 + 4 * 20 * sizeof(float) + 2 * 256 * 4 + 64 <= 53 * 1024, "3 workgroups per CU need <= 53 KB of LDS each");
+static_assert(sizeof(WaveLds) * 4 + 4 * 20 * sizeof(float) + 256 * 4 + 64 <= (160 / SHADE_BWD_OCC) * 1024, "LDS budget per workgroup");
 
 // power-of-two scale s with |x| * s < 2^24 for every |x| <= m (so 64 such terms stay below 2^30); inv = 1 / s exactly
 __device__ __forceinline__ void fixed_scale(float m, float& s, float& inv) {
@@ -60,9 +66,6 @@ __device__ __forceinline__ void fixed_scale(float m, float& s, float& inv) {
   inv = __int_as_float((127 - 24 + e) << 23);
 }
 
-#ifndef SHADE_BWD_OCC
-#define SHADE_BWD_OCC 3
-#endif
 __global__ void __launch_bounds__(256, SHADE_BWD_OCC) shade_bwd_wave_kernel(const harp_shade_args A, const int32_t* __restrict__ order,
                                                                 const int32_t* __restrict__ nact, int nsx) {
   __shared__ WaveLds s_w[4];
@@ -70,7 +73,6 @@ __global__ void __launch_bounds__(256, SHADE_BWD_OCC) shade_bwd_wave_kernel(cons
   __shared__ int s_ticket;
   __shared__ int s_cnt[4];
   __shared__ int s_list[256];          // compacted active pixels of the tile: face id | (pixel in tile) << 24
-  __shared__ float s_lmask[256];       // ... and their mask value
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int S = A.S, V = A.V;
   // g_rgb == NULL = FUSED-LOSS mode: the pass forms torch.nn.L1Loss(y_true * m, y_pred * m) and its gradient from the colour it
@@ -133,7 +135,6 @@ __global__ void __launch_bounds__(256, SHADE_BWD_OCC) shade_bwd_wave_kernel(cons
     if (act0) {
       const int pos = base + __popcll(bal & ((1ull << lane) - 1ull));
       s_list[pos] = f0 | (((w * 4 + (lane >> 4)) * 16 + (lane & 15)) << 24);
-      s_lmask[pos] = m0;
     }
     __syncthreads();
   }
@@ -145,7 +146,7 @@ __global__ void __launch_bounds__(256, SHADE_BWD_OCC) shade_bwd_wave_kernel(cons
   const int xi = tx0 + (pix & 15), yi = ty0 + (pix >> 4);
   const size_t o = ((size_t)b * S + yi) * S + xi;
   const size_t l1_to = tbase + (size_t)yi * S + xi;
-  const float l1_m = act ? s_lmask[64 * w + lane] : 0.f;
+  const float l1_m = (act && fused) ? (A.l1_mask ? A.l1_mask[l1_to] : 1.f) : 0.f;      // (re-read: L1 / L2 hit, one LDS kilobyte less)
   V3 gc = mk(0.f, 0.f, 0.f);
   if (!fused) {
     if (act) gc = ld(A.g_rgb + o * 3);

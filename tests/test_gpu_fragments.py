@@ -44,7 +44,7 @@ def test_fragments_match_oracle(geom, K, blur):
     m = same & (p2f_o >= 0)
     assert (z.cpu().double() - z_o)[m].abs().max() < 2e-6
     db = (b.cpu().double() - b_o)[m].abs()
-    assert db.max() < 2e-3 and (db > 1e-5).double().mean() < 1e-3      # (slivers: 1/area amplifies float32 rounding)
+    assert db.max() < 2e-3 and (db > 1e-4).double().mean() < 1e-3      # (sub-pixel faces at S = 96: 1/area amplifies float32 rounding)
     assert (d.cpu().double() - d_o)[m].abs().max() < 1e-7
     empty = p2f_o < 0
     assert (z.cpu()[empty & same] == -1).all() and (d.cpu()[empty & same] == -1).all() and (b.cpu()[empty & same] == -1).all()
