@@ -171,3 +171,4 @@ SIGNATURES.update({
     "harp_rasterize_fragments_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "harp_rasterize_fragments_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _vp]),
 })
+SIGNATURES["harp_shade_sil_bwd"] = (_i, [ctypes.POINTER(ShadeArgs), _f, _f, _vp, _vp, _vp])

@@ -52,11 +52,13 @@ inline unsigned tile_grid(int B, int nsx) { return (unsigned)(((B * nsx * nsx + 
 // so "empty" is slot >= *nact: one scalar load, no dependent trip through the bin counts.  3/4 of the workgroups of a launch are such
 // tiles and every one of them used to walk order -> bin count / face ids -> exit: with 5 workgroups per CU in flight that chain, not
 // the shading, was a third of the forward shader's time.  coords_if_empty = false: return 2 without touching `order`.
-__device__ __forceinline__ int tile_decode(const int32_t* __restrict__ order, const int32_t* __restrict__ nact, int B, int nsx, int S,
-                                           int& b, int& st, int& tx0, int& ty0, int& sub, bool coords_if_empty = true) {
+// (tile_decode_v: the same for an explicit index `bid` of that grid — a launch that interleaves two kinds of tiles passes a virtual index
+//  whose low 3 bits still equal the real workgroup id's, i.e. the XCD)
+__device__ __forceinline__ int tile_decode_v(unsigned bid, const int32_t* __restrict__ order, const int32_t* __restrict__ nact, int B, int nsx, int S,
+                                             int& b, int& st, int& tx0, int& ty0, int& sub, bool coords_if_empty = true) {
   constexpr int kTps = (kSuper / kTile) * (kSuper / kTile);
   const int nst = nsx * nsx;
-  const int xcd = blockIdx.x & 7, rr = blockIdx.x >> 3;
+  const int xcd = bid & 7, rr = bid >> 3;
   const int slot = (rr / kTps) * 8 + xcd;
   sub = rr % kTps;
   if (slot >= B * nst) return 0;
@@ -68,6 +70,10 @@ __device__ __forceinline__ int tile_decode(const int32_t* __restrict__ order, co
   ty0 = ((st / nsx) * (kSuper / kTile) + (sub >> 2)) * kTile;
   if (!(tx0 < S && ty0 < S)) return 0;
   return empty ? 2 : 1;
+}
+__device__ __forceinline__ int tile_decode(const int32_t* __restrict__ order, const int32_t* __restrict__ nact, int B, int nsx, int S,
+                                           int& b, int& st, int& tx0, int& ty0, int& sub, bool coords_if_empty = true) {
+  return tile_decode_v(blockIdx.x, order, nact, B, nsx, S, b, st, tx0, ty0, sub, coords_if_empty);
 }
 // Pixels of a whole 64x64 super-tile spread over a 256-thread workgroup (16 each, 64-wide coalesced rows): k = 0..15
 __device__ __forceinline__ void supertile_pixel(int k, int sx0, int sy0, int& xi, int& yi) {

@@ -1,0 +1,401 @@
+// Tile rasteriser body shared by csrc/raster.hip (its three launches) and csrc/shade_bwd.hip (the fused backward launch runs the
+// silhouette-backward tiles, MODE 2, interleaved with the shading tiles).  See raster.hip for the design notes.
+#pragma once
+#include "harp_common.h"
+#include "harp_hip.h"
+
+namespace rb {
+
+constexpr int kStage = 256;   // faces staged in LDS per round (17 KB)
+
+struct Tri {
+  float x0, y0, z0, x1, y1, z1, x2, y2, z2;
+};
+
+__device__ __forceinline__ Tri tri_from(const float4 a, const float4 b, const float4 c) {
+  Tri t;
+  t.x0 = a.x; t.y0 = a.y; t.z0 = a.z; t.x1 = a.w;
+  t.y1 = b.x; t.z1 = b.y; t.x2 = b.z; t.y2 = b.w;
+  t.z2 = c.x;
+  return t;
+}
+
+// BarycentricCoordsForward + BarycentricPerspectiveCorrectionForward; returns "inside" (all bary > 0).
+__device__ __forceinline__ bool tri_bary(const Tri& t, float px, float py, float& b0, float& b1, float& b2) {
+  const float area = edge_fn(t.x2, t.y2, t.x0, t.y0, t.x1, t.y1) + kEps;
+  const float w0 = edge_fn(px, py, t.x1, t.y1, t.x2, t.y2) / area;
+  const float w1 = edge_fn(px, py, t.x2, t.y2, t.x0, t.y0) / area;
+  const float w2 = edge_fn(px, py, t.x0, t.y0, t.x1, t.y1) / area;
+  const float t0 = w0 * t.z1 * t.z2, t1 = t.z0 * w1 * t.z2, t2 = t.z0 * t.z1 * w2;
+  const float den = fmaxf(t0 + t1 + t2, kEps);
+  b0 = t0 / den; b1 = t1 / den; b2 = t2 / den;
+  return b0 > 0.f && b1 > 0.f && b2 > 0.f;
+}
+
+// PointLineDistanceForward: squared distance to segment (a,b); also returns the clamped parameter t.
+__device__ __forceinline__ float seg_dist2(float px, float py, float ax, float ay, float bx, float by, float& tt) {
+  const float bax = bx - ax, bay = by - ay;
+  const float l2 = bax * bax + bay * bay;
+  if (l2 <= kEps) { tt = 1.f; return (px - bx) * (px - bx) + (py - by) * (py - by); }
+  float t = (bax * (px - ax) + bay * (py - ay)) * __builtin_amdgcn_rcpf(l2);      // <= 1.5 ulp from the IEEE quotient
+  t = fminf(fmaxf(t, 0.f), 1.f);
+  tt = t;
+  const float qx = ax + t * bax, qy = ay + t * bay;
+  return (px - qx) * (px - qx) + (py - qy) * (py - qy);
+}
+
+// Ascending-order compaction of `pred` across a 256-thread block. Returns this thread's slot (or -1) and
+// advances *running (uniform). lds_cnt: 4 ints.
+__device__ __forceinline__ int block_compact(bool pred, int running, int* lds_cnt, int& total) {
+  const unsigned long long m = __ballot(pred);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) lds_cnt[w] = __popcll(m);
+  __syncthreads();
+  int base = running;
+  for (int i = 0; i < w; ++i) base += lds_cnt[i];
+  total = lds_cnt[0] + lds_cnt[1] + lds_cnt[2] + lds_cnt[3];
+  const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+  __syncthreads();
+  return pred ? pos : -1;
+}
+
+// MODE 0: depth only (light view).  MODE 1: nearest face + silhouette product (camera view).
+// MODE 2: silhouette backward (rim pixels): scatter dL/d(ndc xy).
+__device__ __forceinline__ int nst_of(int nsx) { return nsx * nsx; }
+
+template <int MODE>
+struct RasterSmem {
+  float4 s_a[kStage], s_b[kStage], s_bb[kStage];
+  float s_z2[kStage];
+  float4 s_fc[MODE == 1 ? kStage : 1];      // per staged face: sign of the area, squared edge lengths l12, l20, l01
+  int32_t s_id[kStage];
+  int lds_cnt[4];
+  // MODE 2: per-staged-face gradient accumulators (x,y of 3 verts).  double: ds_add_f64 is ~20x faster than ds_add_f32 on gfx950
+  double s_g[MODE == 2 ? kStage : 1][6];
+  float red[4];
+};
+
+// One 16x16 tile; `vblock` = index in the 1-D heaviest-first tile grid (harp_common.h: tile_decode_v).  A __device__ function so that
+// the silhouette backward (MODE 2) can also run as part of the fused backward launch (shade_bwd.hip), interleaved with the shading tiles.
+template <int MODE>
+__device__ __forceinline__ void raster_tile(RasterSmem<MODE>& sm, unsigned vblock, const FaceRec* __restrict__ recs, const float4* __restrict__ bbs,
+                                                     const int32_t* __restrict__ bins,
+                                                     const int32_t* __restrict__ bin_count, const int32_t* __restrict__ order,
+                                                     const int32_t* __restrict__ nact, int B, int F, int S, int nsx,
+                                                     float blur, float sigma, int32_t* __restrict__ face_id,
+                                                     float* __restrict__ zbuf, float* __restrict__ alpha,
+                                                     const float* __restrict__ g_alpha, const int32_t* __restrict__ faces,
+                                                     int V, float* __restrict__ g_ndc, const float* __restrict__ l1_target,
+                                                     const int32_t* __restrict__ l1_fid, const float* __restrict__ l1_w,
+                                                     float* __restrict__ l1_loss, float* __restrict__ l1_grad, float l1_inv, int sparse,
+                                                     const float* __restrict__ l1_bg_sums) {
+  auto& s_a = sm.s_a; auto& s_b = sm.s_b; auto& s_bb = sm.s_bb; auto& s_z2 = sm.s_z2; auto& s_fc = sm.s_fc; auto& s_id = sm.s_id;
+  auto& s_g = sm.s_g;
+  int* lds_cnt = sm.lds_cnt;
+
+  int b, st, tx0, ty0, sub;
+  const int kind = tile_decode_v(vblock, order, nact, B, nsx, S, b, st, tx0, ty0, sub, MODE != 2);   // 1-D grid in heaviest-first order (harp_common.h)
+  if (kind == 0) return;
+  if (kind == 2) {
+    // super-tile without a single face.  Backward: nothing to do.  Forward: its first workgroup writes the empty-pixel outputs (and
+    // the fused silhouette L1 against alpha = 0) for all 64x64 pixels, the other 15 leave at once.
+    if (MODE == 2 || sub != 0) return;
+    if (MODE == 1 && sparse && l1_target && l1_bg_sums) {
+      // nothing to write, and the loss of an un-rendered super-tile against a static target is a constant: one table look-up
+      if (threadIdx.x == 0) {
+        const float sum = l1_bg_sums[(size_t)l1_fid[b] * nst_of(nsx) + st];
+        if (sum != 0.f) atomicAdd(l1_loss, sum * l1_inv);
+      }
+      return;
+    }
+    float acc = 0.f;
+    float tg[16];
+    const bool l1 = (MODE == 1) && l1_target != nullptr;
+    const float* trow = l1 ? l1_target + (size_t)l1_fid[b] * S * S : nullptr;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {            // all 16 target loads in flight before the first store
+      int xi, yi;
+      supertile_pixel(k, tx0, ty0, xi, yi);
+      tg[k] = (l1 && xi < S && yi < S) ? trow[(size_t)yi * S + xi] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      int xi, yi;
+      supertile_pixel(k, tx0, ty0, xi, yi);
+      if (xi < S && yi < S) {
+        const size_t o = ((size_t)b * S + yi) * S + xi;
+        if (l1) acc += fabsf(tg[k]);                       // |alpha - y| with alpha = 0
+        if (zbuf) zbuf[o] = -1.0f;                          // depth maps stay complete: shadow taps may land one pixel outside a face's super-tile
+        if (!sparse) {
+          face_id[o] = -1;
+          if (MODE == 1) {
+            alpha[o] = 0.f;
+            if (l1) l1_grad[o] = l1_w[0] * l1_inv * (float)((0.f > tg[k]) - (0.f < tg[k]));
+          }
+        }
+      }
+    }
+    if (MODE == 1 && l1_target) {
+      const float sum = block_sum_256(acc, sm.red);
+      if (threadIdx.x == 0 && sum != 0.f) atomicAdd(l1_loss, sum * l1_inv);
+    }
+    return;
+  }
+  const int nst = nsx * nsx;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int xi = tx0 + (lane & 15), yi = ty0 + w * 4 + (lane >> 4);
+  const bool in_img = (xi < S) && (yi < S);
+  const float px = pix_to_ndc(xi, S), py = pix_to_ndc(yi, S);
+  const int n = bin_count[b * nst + st];
+  const int32_t* list = bins + ((size_t)b * nst + st) * F;
+  const FaceRec* rb = recs + (size_t)b * F;
+  const float4* bbb = bbs + (size_t)b * F;
+
+  // tile and wave-strip bounds in NDC (conservative supersets of the per-pixel bbox test)
+  const float t_xhi = pix_to_ndc(tx0, S), t_xlo = pix_to_ndc(min(tx0 + kTile, S) - 1, S);
+  const float t_yhi = pix_to_ndc(ty0, S), t_ylo = pix_to_ndc(min(ty0 + kTile, S) - 1, S);
+  const float w_yhi = pix_to_ndc(ty0 + w * 4, S), w_ylo = pix_to_ndc(ty0 + w * 4 + 3, S);
+
+  const float strip_r = (MODE == 0) ? 0.f : sqrtf(blur);
+  float best_z = 3.0e38f;
+  int best_f = -1;
+  float prod = 1.0f;
+  float P = 0.f, ga = 0.f;
+  bool need = in_img;
+  if (MODE == 2) {
+    if (in_img) {
+      const size_t o = ((size_t)b * S + yi) * S + xi;
+      P = 1.0f - alpha[o];
+      ga = g_alpha[o];
+    }
+    need = in_img && (P != 0.f) && (ga != 0.f);
+    // whole tile saturated / no upstream gradient -> nothing to do
+    if (__syncthreads_or(need ? 1 : 0) == 0) return;
+  }
+
+  const float inv_sigma = 1.0f / sigma;
+  unsigned hq = 0u;
+  unsigned long long sq = 0ull;
+  int hn = 0, sn = 0;
+  // ---- phase 2: every lane pops its own queued faces (LDS gathers with per-lane addresses)
+  auto drain = [&]() {
+    if (MODE != 2) {
+      while (__any(hn > 0)) {
+        if (hn > 0) {
+          const int j = (int)(hq & 0xffu);
+          hq >>= 8; --hn;
+          const Tri t = tri_from(s_a[j], s_b[j], make_float4(s_z2[j], 0.f, 0.f, 0.f));
+          const float e0 = edge_fn(px, py, t.x1, t.y1, t.x2, t.y2);
+          const float e1 = edge_fn(px, py, t.x2, t.y2, t.x0, t.y0);
+          const float e2 = edge_fn(px, py, t.x0, t.y0, t.x1, t.y1);
+          const float area = edge_fn(t.x2, t.y2, t.x0, t.y0, t.x1, t.y1) + kEps;
+          // BarycentricCoordsForward + PerspectiveCorrection with reciprocals (<= 2 ulp from the IEEE-division form)
+          const float ra = __builtin_amdgcn_rcpf(area);
+          const float t0 = (e0 * ra) * t.z1 * t.z2, t1 = t.z0 * (e1 * ra) * t.z2, t2 = t.z0 * t.z1 * (e2 * ra);
+          const float rd = __builtin_amdgcn_rcpf(fmaxf(t0 + t1 + t2, kEps));
+          const float pz = (t0 * rd) * t.z0 + (t1 * rd) * t.z1 + (t2 * rd) * t.z2;
+          if (pz >= 0.f && pz < best_z) { best_z = pz; best_f = s_id[j]; }
+        }
+      }
+    }
+    if (MODE >= 1) {
+      while (__any(sn > 0)) {
+        if (sn > 0) {
+          const int j = (int)(sq & 0xffull);
+          sq >>= 8; --sn;
+          if (MODE == 2 || prod != 0.f) {
+            const Tri t = tri_from(s_a[j], s_b[j], make_float4(0.f, 0.f, 0.f, 0.f));
+            const float e0 = edge_fn(px, py, t.x1, t.y1, t.x2, t.y2);
+            const float e1 = edge_fn(px, py, t.x2, t.y2, t.x0, t.y0);
+            const float e2 = edge_fn(px, py, t.x0, t.y0, t.x1, t.y1);
+            const float area = edge_fn(t.x2, t.y2, t.x0, t.y0, t.x1, t.y1) + kEps;
+            const float sg = (area > 0.f) ? 1.f : ((area < 0.f) ? -1.f : 0.f);
+            const bool inside = (e0 * sg > 0.f) && (e1 * sg > 0.f) && (e2 * sg > 0.f);
+            float ta, tb, tc;
+            const float d01 = seg_dist2(px, py, t.x0, t.y0, t.x1, t.y1, ta);
+            const float d02 = seg_dist2(px, py, t.x0, t.y0, t.x2, t.y2, tb);
+            const float d12 = seg_dist2(px, py, t.x1, t.y1, t.x2, t.y2, tc);
+            const float dist = fminf(d01, fminf(d02, d12));
+            if (inside || dist < blur) {
+              const float sd = inside ? -dist : dist;
+              const float p = __builtin_amdgcn_rcpf(1.0f + __expf(sd * inv_sigma));   // sigmoid(-sd/sigma): fast exp + reciprocal (rel. error ~1e-6 at |x| ~ 18; image tolerance 1e-4)
+              if (MODE == 1) {
+                prod *= (1.0f - p);
+              } else {
+                // d alpha / d sd = -P * p / sigma  (P = prod over all faces)
+                const float g_sd = ga * (-P * p * inv_sigma);
+                const float gd = inside ? -g_sd : g_sd;     // d/d(dist^2)
+                // PointLineDistanceBackward on the argmin edge (t treated as constant)
+                int ia, ib; float ax, ay, bx, by, tt;
+                if (d01 <= d02 && d01 <= d12) { ia = 0; ib = 1; ax = t.x0; ay = t.y0; bx = t.x1; by = t.y1; tt = ta; }
+                else if (d02 <= d12)          { ia = 0; ib = 2; ax = t.x0; ay = t.y0; bx = t.x2; by = t.y2; tt = tb; }
+                else                          { ia = 1; ib = 2; ax = t.x1; ay = t.y1; bx = t.x2; by = t.y2; tt = tc; }
+                const float qx = ax + tt * (bx - ax), qy = ay + tt * (by - ay);
+                const float cx = gd * 2.f * (qx - px), cy = gd * 2.f * (qy - py);
+                atomicAdd(&s_g[j][2 * ia], (double)((1.f - tt) * cx));
+                atomicAdd(&s_g[j][2 * ia + 1], (double)((1.f - tt) * cy));
+                atomicAdd(&s_g[j][2 * ib], (double)(tt * cx));
+                atomicAdd(&s_g[j][2 * ib + 1], (double)(tt * cy));
+              }
+            }
+          }
+        }
+      }
+    }
+  };
+
+  for (int base = 0; base < n; base += kStage) {
+    // ---- stage: filter this round's list entries against the 16x16 tile, compact into LDS
+    const int e = base + threadIdx.x;
+    bool hit = false;
+    int id = 0;
+    float4 bb;
+    if (e < n) {
+      id = list[e];
+      bb = bbb[id];          // contiguous 16-B bbox array (4 per 64-B line) instead of the 64-B-strided records
+      hit = !(t_xlo > bb.y || t_xhi < bb.x || t_ylo > bb.w || t_yhi < bb.z);
+    }
+    int nl;
+    const int pos = block_compact(hit, 0, lds_cnt, nl);
+    if (pos >= 0) {
+      const FaceRec r = rb[id];
+      s_a[pos] = r.a; s_b[pos] = r.b; s_z2[pos] = r.c.x; s_bb[pos] = bb; s_id[pos] = id;
+      if (MODE == 1) {
+        // constants of the face that every (face, strip) classification below used to recompute on all 64 lanes
+        const Tri t = tri_from(r.a, r.b, make_float4(0.f, 0.f, 0.f, 0.f));
+        const float area = edge_fn(t.x2, t.y2, t.x0, t.y0, t.x1, t.y1) + kEps;
+        s_fc[pos] = make_float4((area > 0.f) ? 1.f : ((area < 0.f) ? -1.f : 0.f),
+                                (t.x2 - t.x1) * (t.x2 - t.x1) + (t.y2 - t.y1) * (t.y2 - t.y1),
+                                (t.x0 - t.x2) * (t.x0 - t.x2) + (t.y0 - t.y2) * (t.y0 - t.y2),
+                                (t.x1 - t.x0) * (t.x1 - t.x0) + (t.y1 - t.y0) * (t.y1 - t.y0));
+      }
+    }
+    if (MODE == 2) {
+#pragma unroll
+      for (int c = 0; c < 6; ++c) s_g[threadIdx.x][c] = 0.0;
+    }
+    __syncthreads();
+    // ---- walk: each wave ballots the staged faces against its 16x4 strip
+    for (int g = 0; g < nl; g += 64) {
+      const int i = g + lane;
+      bool whit = false;
+      if (i < nl) {
+        const float4 q = s_bb[i];
+        whit = !(t_xlo > q.y || t_xhi < q.x || w_ylo > q.w || w_yhi < q.z);
+        if (whit) {
+          // tighter than the bbox: the strip (a rectangle of pixel centres) is rejected when it lies entirely beyond one edge
+          // LINE of the face by more than the blur radius r (edge function = signed line distance * edge length).
+          const float4 fa = s_a[i], fb = s_b[i];
+          const float X0 = fa.x, Y0 = fa.y, X1 = fa.w, Y1 = fb.x, X2 = fb.z, Y2 = fb.w;
+          const float ar = edge_fn(X2, Y2, X0, Y0, X1, Y1) + kEps;
+          const float sgn = (ar > 0.f) ? 1.f : -1.f;
+          const float ex[3] = {X1, X2, X0}, ey[3] = {Y1, Y2, Y0}, fx[3] = {X2, X0, X1}, fy[3] = {Y2, Y0, Y1};
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            // e(p) = (px-ax)(by-ay) - (py-ay)(bx-ax), a = (ex,ey), b = (fx,fy); maximum of sgn*e over the 4 strip corners
+            const float dx = fx[k] - ex[k], dy = fy[k] - ey[k];
+            const float c00 = sgn * ((t_xlo - ex[k]) * dy - (w_ylo - ey[k]) * dx), c10 = sgn * ((t_xhi - ex[k]) * dy - (w_ylo - ey[k]) * dx);
+            const float c01 = sgn * ((t_xlo - ex[k]) * dy - (w_yhi - ey[k]) * dx), c11 = sgn * ((t_xhi - ex[k]) * dy - (w_yhi - ey[k]) * dx);
+            const float emax = fmaxf(fmaxf(c00, c10), fmaxf(c01, c11));
+            const float margin = strip_r * sqrtf(dx * dx + dy * dy) * 1.0001f + 1e-12f;
+            if (emax < -margin) whit = false;
+          }
+        }
+      }
+      // ---- phase 1: classify only.  The expensive parts (depth interpolation of a hit, the three segment distances + exp of a
+      // rim face) used to run for the whole wave whenever ANY lane needed them (~130 VALU instructions per face iteration); each lane
+      // now queues the staged-face indices it needs (hard: 4 x 8 bit, soft: 8 x 8 bit) and the queues are drained per lane, in
+      // ascending face order (same tie-break, same product order => bit-identical results), a handful of iterations per strip.
+      unsigned long long m = __ballot(whit);
+      while (m) {
+        const int j = g + __ffsll((unsigned long long)m) - 1;
+        m &= m - 1;
+        const float4 q = s_bb[j];
+        const bool inbox = in_img && !(px > q.y || px < q.x || py > q.w || py < q.z);
+        if (!__any(inbox && (MODE == 2 ? need : true))) continue;
+        const float4 fa = s_a[j], fb = s_b[j];
+        const Tri t = tri_from(fa, fb, make_float4(0.f, 0.f, 0.f, 0.f));
+        const float e0 = edge_fn(px, py, t.x1, t.y1, t.x2, t.y2);
+        const float e1 = edge_fn(px, py, t.x2, t.y2, t.x0, t.y0);
+        const float e2 = edge_fn(px, py, t.x0, t.y0, t.x1, t.y1);
+        float sg, l12 = 0.f, l20 = 0.f, l01 = 0.f;
+        if (MODE == 1) {
+          const float4 fc = s_fc[j];
+          sg = fc.x; l12 = fc.y; l20 = fc.z; l01 = fc.w;
+        } else {
+          const float area = edge_fn(t.x2, t.y2, t.x0, t.y0, t.x1, t.y1) + kEps;
+          sg = (area > 0.f) ? 1.f : ((area < 0.f) ? -1.f : 0.f);
+        }
+        const float e0s = e0 * sg, e1s = e1 * sg, e2s = e2 * sg;
+        const bool inside = (e0s > 0.f) && (e1s > 0.f) && (e2s > 0.f);
+        if (MODE != 2 && inside && inbox) { hq |= (unsigned)j << (8 * hn); ++hn; }
+        if (MODE >= 1) {
+          bool soft = (MODE == 1) ? (inbox && prod != 0.f) : (inbox && need);
+          if (soft) {
+            if (MODE == 2) {       // (few pairs get here in the backward pass: recomputing beats staging the constants, measured)
+              l12 = (t.x2 - t.x1) * (t.x2 - t.x1) + (t.y2 - t.y1) * (t.y2 - t.y1);
+              l20 = (t.x0 - t.x2) * (t.x0 - t.x2) + (t.y0 - t.y2) * (t.y0 - t.y2);
+              l01 = (t.x1 - t.x0) * (t.x1 - t.x0) + (t.y1 - t.y0) * (t.y1 - t.y0);
+            }
+            if (inside) {
+              // deeper than sqrt(18 sigma) inside every edge LINE (<= segment distance): sigmoid saturates to exactly 1 in
+              // fp32 (exp(-18) < 2^-24), so the factor (1-p) is exactly 0 — same result as the exact path, no div/exp.
+              const float K = 18.0f * sigma;
+              if (e0 * e0 > K * l12 && e1 * e1 > K * l20 && e2 * e2 > K * l01) {
+                if (MODE == 1) prod = 0.f;
+                soft = false;
+              }
+            } else {
+              // outside: the triangle lies beyond the line of any violated edge, so dist >= that line distance
+              const float Bf = blur * 1.00001f;
+              if ((e0s < 0.f && e0 * e0 >= Bf * l12) || (e1s < 0.f && e1 * e1 >= Bf * l20) || (e2s < 0.f && e2 * e2 >= Bf * l01)) soft = false;
+            }
+            if (soft) { sq |= (unsigned long long)j << (8 * sn); ++sn; }
+          }
+        }
+        if (__any(hn == 4 || sn == 8)) drain();
+      }
+    }
+    drain();            // staged indices are only valid within this round
+    __syncthreads();
+    if (MODE == 2 && (int)threadIdx.x < nl) {
+      // flush: one global atomic per (staged face, vertex, component) per workgroup
+      const int fid = s_id[threadIdx.x];
+      float* gb = g_ndc + (size_t)b * V * 3;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const float gx = (float)s_g[threadIdx.x][2 * k], gy = (float)s_g[threadIdx.x][2 * k + 1];
+        if (gx != 0.f || gy != 0.f) {
+          const int v = faces[3 * fid + k];
+          atomicAdd(gb + 3 * v, gx);
+          atomicAdd(gb + 3 * v + 1, gy);
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  float l1_acc = 0.f;
+  if (MODE != 2 && in_img) {
+    const size_t o = ((size_t)b * S + yi) * S + xi;
+    face_id[o] = best_f;
+    if (zbuf) zbuf[o] = (best_f >= 0) ? best_z : -1.0f;
+    if (MODE == 1) {
+      const float a = 1.0f - prod;
+      alpha[o] = a;
+      if (l1_target) {
+        // fused torch.nn.L1Loss(y_sil_true, y_sil_pred) (optimize_sequence.py:519) and its gradient w.r.t. alpha
+        const float d = a - l1_target[((size_t)l1_fid[b] * S + yi) * S + xi];
+        l1_acc = fabsf(d);
+        l1_grad[o] = l1_w[0] * l1_inv * ((d > 0.f) - (d < 0.f));
+      }
+    }
+  }
+  if (MODE == 1 && l1_target) {
+    const float sum = block_sum_256(l1_acc, sm.red);
+    if (threadIdx.x == 0 && sum != 0.f) atomicAdd(l1_loss, sum * l1_inv);
+  }
+}
+
+
+}  // namespace rb

@@ -647,6 +647,8 @@ __global__ void __launch_bounds__(256) depth_bwd_kernel(const int32_t* __restric
 }  // namespace
 
 int harp_detail_shade_bwd_wave(const harp_shade_args& a, const int32_t* order, const int32_t* nact, int nsx, unsigned grid, hipStream_t stream);
+int harp_detail_fused_bwd(const harp_shade_args& a, const void* ws, const int32_t* faces, float blur, float sigma, const float* alpha,
+                          const float* g_alpha, hipStream_t stream);
 
 extern "C" {
 
@@ -691,6 +693,20 @@ int harp_shade_bwd(const harp_shade_args* a, hipStream_t stream) {
   hipLaunchKernelGGL(shade_kernel<true>, dim3(tile_grid(a->B, W.nsx)), dim3(256), 0, stream, b, (const int32_t*)W.order, (const int32_t*)W.nact, W.nsx);
   HARP_CHECK_LAUNCH();
   return HARP_OK;
+}
+
+// harp_shade_bwd + harp_silhouette_bwd of the SAME camera-view rasterisation (a->recs) as one launch
+int harp_shade_sil_bwd(const harp_shade_args* a, float blur_radius, float sigma, const float* alpha, const float* g_alpha, hipStream_t stream) {
+  if (!a || !a->face_id || !a->recs || !a->faces || !a->g_verts || !a->g_vnormals || !a->g_ndc || !alpha || !g_alpha) return HARP_ERR_ARG;
+  harp_shade_args b = *a;
+  if (!b.g_rgb) {
+    if (!b.l1_target || !b.l1_fid || !b.l1_w || !b.l1_loss || !b.l1_bg_sums) return HARP_ERR_ARG;
+    b.l1_inv = 1.0f / ((float)b.B * (float)b.S * (float)b.S * 3.0f);
+  } else {
+    b.l1_target = nullptr;
+  }
+  b.debug_skip = 0;
+  return harp_detail_fused_bwd(b, a->recs, a->faces, blur_radius, sigma, alpha, g_alpha, stream);
 }
 
 // g_z (B,S,S) -> g_ndc (B,V,3) += ; ws = workspace of the harp_rasterize_fwd call that produced face_id

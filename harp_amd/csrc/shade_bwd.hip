@@ -34,6 +34,7 @@
 //       - shadow-map taps: 16x16 fixed-point window anchored at the wave's smallest tap.
 //       - the 17 per-frame scalars (light colours, light position, light camera, loss): wave reductions -> LDS partials; the LAST
 //         wave of the tile to finish (LDS ticket, no barrier) issues one memory atomic per scalar.
+#include "raster_body.h"
 #include "shade_common.h"
 
 namespace {
@@ -56,7 +57,6 @@ struct WaveLds {
   double vval[9][kVSlots];     // 0-2 g_verts, 3-5 g_vnormals, 6-8 g_ndc
   int zwin[kZW * kZH];         // fixed point
 };
-static_assert(sizeof(WaveLds) * 4 + 4 * 20 * sizeof(float) + 256 * 4 + 64 <= (160 / SHADE_BWD_OCC) * 1024, "LDS budget per workgroup");
 
 // power-of-two scale s with |x| * s < 2^24 for every |x| <= m (so 64 such terms stay below 2^30); inv = 1 / s exactly
 __device__ __forceinline__ void fixed_scale(float m, float& s, float& inv) {
@@ -66,13 +66,19 @@ __device__ __forceinline__ void fixed_scale(float m, float& s, float& inv) {
   inv = __int_as_float((127 - 24 + e) << 23);
 }
 
-__global__ void __launch_bounds__(256, SHADE_BWD_OCC) shade_bwd_wave_kernel(const harp_shade_args A, const int32_t* __restrict__ order,
-                                                                const int32_t* __restrict__ nact, int nsx) {
-  __shared__ WaveLds s_w[4];
-  __shared__ float s_part[4][20];
-  __shared__ int s_ticket;
-  __shared__ int s_cnt[4];
-  __shared__ int s_list[256];          // compacted active pixels of the tile: face id | (pixel in tile) << 24
+struct ShadeSmem {
+  WaveLds w[4];
+  float part[4][20];
+  int ticket;
+  int cnt[4];
+  int list[256];          // compacted active pixels of the tile: face id | (pixel in tile) << 24
+};
+static_assert(sizeof(ShadeSmem) <= (160 / SHADE_BWD_OCC) * 1024, "LDS budget per workgroup");
+
+// one 16x16 tile of the shading backward; `vblock` = index in the 1-D heaviest-first tile grid
+__device__ __forceinline__ void shade_bwd_tile(ShadeSmem& sm, unsigned vblock, const harp_shade_args& A, const int32_t* __restrict__ order,
+                                               const int32_t* __restrict__ nact, int nsx) {
+  auto& s_w = sm.w; auto& s_part = sm.part; int& s_ticket = sm.ticket; auto& s_cnt = sm.cnt; auto& s_list = sm.list;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int S = A.S, V = A.V;
   // g_rgb == NULL = FUSED-LOSS mode: the pass forms torch.nn.L1Loss(y_true * m, y_pred * m) and its gradient from the colour it
@@ -80,7 +86,7 @@ __global__ void __launch_bounds__(256, SHADE_BWD_OCC) shade_bwd_wave_kernel(cons
   const bool fused = A.g_rgb == nullptr;
   const int dbg = A.debug_skip >> 8;          // ablation switches (timing only, results WRONG): see harp_hip.h
   int b, st, tx0, ty0, tsub;
-  const int kind = tile_decode(order, nact, A.B, nsx, S, b, st, tx0, ty0, tsub, fused);
+  const int kind = tile_decode_v(vblock, order, nact, A.B, nsx, S, b, st, tx0, ty0, tsub, fused);
   if (kind == 0 || (dbg & 64)) return;
   if (kind == 2) {
     // super-tile without a face: no gradient; its part of the loss against the static targets is a table look-up
@@ -512,7 +518,53 @@ __global__ void __launch_bounds__(256, SHADE_BWD_OCC) shade_bwd_wave_kernel(cons
   }
 }
 
+__global__ void __launch_bounds__(256, SHADE_BWD_OCC) shade_bwd_wave_kernel(const harp_shade_args A, const int32_t* __restrict__ order,
+                                                                            const int32_t* __restrict__ nact, int nsx) {
+  __shared__ ShadeSmem sm;
+  shade_bwd_tile(sm, blockIdx.x, A, order, nact, nsx);
+}
+
+// FUSED BACKWARD LAUNCH: the shading backward and the silhouette backward (csrc/raster_body.h, MODE 2) as ONE grid.  As two kernels on
+// two streams they could not share a CU (3 x 168 VGPRs and 3 x 40 KB of LDS of the shader leave no room for a rasteriser workgroup), so
+// "concurrent" meant taking turns: 0.30 + 0.12 ms alone, 0.39 ms together — and the second stream cost a fork and a join (~10 us each).
+// In one grid the two kinds of workgroup co-reside, the rasteriser's waves issue while the shader's wait.  Workgroups alternate in
+// groups of 8 (one per XCD): ids 16 g + 0..7 = shading tiles 8 g + 0..7, ids 16 g + 8..15 = silhouette tiles 8 g + 0..7, so a tile's
+// XCD (real id & 7) is the same for both kinds and for the stand-alone launches.
+struct SilBwdArgs {
+  const FaceRec* recs; const float4* bbs; const int32_t* bins; const int32_t* cnt; const int32_t* faces;
+  const float* alpha; const float* g_alpha; float* g_ndc; int F; float blur, sigma;
+};
+union FusedSmem {
+  ShadeSmem sh;
+  rb::RasterSmem<2> rs;
+  __device__ FusedSmem() {}
+};
+__global__ void __launch_bounds__(256, SHADE_BWD_OCC) fused_bwd_kernel(const harp_shade_args A, const SilBwdArgs R, const int32_t* __restrict__ order,
+                                                                       const int32_t* __restrict__ nact, int nsx) {
+  __shared__ FusedSmem sm;
+  const unsigned g = blockIdx.x >> 4, r = blockIdx.x & 15;
+  const unsigned v = g * 8 + (r & 7);
+  if (r < 8) {
+    shade_bwd_tile(sm.sh, v, A, order, nact, nsx);
+  } else {
+    rb::raster_tile<2>(sm.rs, v, R.recs, R.bbs, R.bins, R.cnt, order, nact, A.B, R.F, A.S, nsx, R.blur, R.sigma, nullptr, nullptr, (float*)R.alpha,
+                       R.g_alpha, R.faces, A.V, R.g_ndc, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0, nullptr);
+  }
+}
+
 }  // namespace
+
+// harp_shade_sil_bwd (C ABI below): both backward passes of the camera view in one launch
+int harp_detail_fused_bwd(const harp_shade_args& a, const void* ws, const int32_t* faces, float blur, float sigma, const float* alpha,
+                          const float* g_alpha, hipStream_t stream) {
+  const RasterWs W = raster_ws_split((void*)ws, a.B, a.F, a.S);
+  SilBwdArgs R;
+  R.recs = W.recs; R.bbs = W.bbs; R.bins = W.bins; R.cnt = W.cnt; R.faces = faces; R.alpha = alpha; R.g_alpha = g_alpha; R.g_ndc = a.g_ndc;
+  R.F = a.F; R.blur = blur; R.sigma = sigma;
+  hipLaunchKernelGGL(fused_bwd_kernel, dim3(2 * tile_grid(a.B, W.nsx)), dim3(256), 0, stream, a, R, (const int32_t*)W.order, (const int32_t*)W.nact, W.nsx);
+  HARP_CHECK_LAUNCH();
+  return HARP_OK;
+}
 
 // launched by harp_shade_bwd (shade.hip)
 int harp_detail_shade_bwd_wave(const harp_shade_args& a, const int32_t* order, const int32_t* nact, int nsx, unsigned grid, hipStream_t stream) {

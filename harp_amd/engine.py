@@ -161,6 +161,7 @@ class FitEngine:
         self.fused_loss = True           # loss-only mode: photometric L1 formed inside the shader backward (no forward shading launch)
         self.keep_image = True           # shader forward writes the rendered image s["rgb"] (False: loss + gradient only)
         self.mesh_terms_first = True     # key-point term + mesh regularisers run before the light raster (under the raster set-up) instead of after it
+        self.fused_bwd = False           # shading + silhouette backward in ONE launch (harp_shade_sil_bwd): correct, measured SLOWER (1.05 vs 0.93 ms: the rasteriser tiles inherit 168 VGPRs / 3 waves per SIMD)
         self.tail_side = False           # normal-map chain rule (+ early all-reduce) on the second stream: measured SLOWER (0.960 vs 0.948 ms: the extra cross-stream edge costs more than the 5-us kernel it moves)
         self.camera_first = True        # enqueue the camera-view raster chain (the longer one) before the light-view chain: +0.75 %
         self.frozen = ()                 # parameters kept out of the optimiser groups (known_appearance)
@@ -412,9 +413,13 @@ class FitEngine:
             light_view()
             camera_view()
         cur.wait_stream(side)                           # join: light depth map, regulariser gradients, normalised normal map
-        if coarse:
+        # both backward passes of the camera view as ONE launch (harp_shade_sil_bwd): as two kernels on two streams they cannot share a CU
+        fuse_bwd = self.fused_bwd and coarse and app and self.perceptual is None
+        side_used = False
+        if coarse and not fuse_bwd:
             # the silhouette backward only needs g_alpha and the camera-view workspace: it overlaps with shading on the side stream
             side.wait_stream(cur)
+            side_used = True
             with torch.cuda.stream(side):
                 self._ck(L.harp_silhouette_bwd(p(tp.faces), B, V, F, S, ops.SIL_BLUR, ops.SIL_SIGMA, p(s["ws_c"]), p(s["alpha"]), p(s["g_alpha"]),
                                                p(s["g_ndc_c"]), ST()), "silhouette_bwd")
@@ -437,7 +442,10 @@ class FitEngine:
                 self._perceptual_term(B, ltfid, lloss)
         # ---- backward
         if app:
-            self._ck(L.harp_shade_bwd(ctypes.byref(a), ST()), "shade_bwd")
+            if fuse_bwd:
+                self._ck(L.harp_shade_sil_bwd(ctypes.byref(a), ops.SIL_BLUR, ops.SIL_SIGMA, p(s["alpha"]), p(s["g_alpha"]), ST()), "shade_sil_bwd")
+            else:
+                self._ck(L.harp_shade_bwd(ctypes.byref(a), ST()), "shade_bwd")
             if shared_terms:
                 # the normal-map chain rule (and, for N > 1, the early all-reduce of the map gradients, which overlaps with the mesh /
                 # hand-layer backward) only feeds the optimiser: with `tail_side` it leaves the critical path for the second stream, which
@@ -459,7 +467,8 @@ class FitEngine:
                                                 p(s["g_light_R"]), p(s["g_light_T"]), ST()), "project_bwd_l")
                     self._ck(L.harp_light_setup_bwd(p(s["centroid"]), p(s["light_pos"]), p(s["g_light_R"]), p(s["g_light_T"]), B, V, p(s["g_light_pos"]),
                                                     p(s["g_centroid"]), p(s["g_vd"]), ST()), "light_setup_bwd")
-        cur.wait_stream(side)                           # silhouette_bwd -> g_ndc_c, normalize3_bwd -> normal-map gradient complete
+        if side_used or (self.tail_side and self.overlap and app):
+            cur.wait_stream(side)                       # silhouette_bwd -> g_ndc_c (normal-map chain rule with tail_side)
         if fused:
             # projections, light camera, both vertex-normal passes, displacement, subdivision and the mm scaling: one launch
             self._ck(L.harp_mesh_chain_bwd(ctypes.byref(self._chain_struct(B, shadow, app)), ST()), "mesh_chain_bwd")
@@ -735,7 +744,7 @@ class FitEngine:
         # every switch the enqueued launch sequence depends on is part of the key: flipping one re-captures instead of replaying a
         # graph recorded for another configuration
         gkey = (coarse, app, scheduled, self.keep_image, self.fused_loss, self.self_shadow, tuple(self.frozen), self.overlap, self.early_terms,
-                self.packed_texels, self.auto_draw, self.mesh_terms_first, self.camera_first, self.tail_side, self.fused_chain, dist_on, self.overlap_allreduce,
+                self.packed_texels, self.auto_draw, self.mesh_terms_first, self.camera_first, self.tail_side, self.fused_bwd, self.fused_chain, dist_on, self.overlap_allreduce,
                 self.comm is not None)
         g = self._graphs.get(gkey)
         if g is None:

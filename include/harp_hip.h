@@ -139,6 +139,11 @@ int harp_shade_fwd(const harp_shade_args* a, hipStream_t stream);
  * l1_target / l1_fid / l1_w / l1_loss / l1_bg_sums): no harp_shade_fwd call is needed at all — the pass recomputes the colour anyway,
  * forms torch.nn.L1Loss(y_true * m, y_pred * m) (optimize_sequence.py:543) and its gradient itself and accumulates the loss value. */
 int harp_shade_bwd(const harp_shade_args* a, hipStream_t stream);
+/* harp_shade_bwd(a) and harp_silhouette_bwd(a->faces, ..., ws = a->recs, alpha, g_alpha, g_ndc = a->g_ndc) of the SAME camera-view
+ * rasterisation as ONE launch whose workgroups alternate between the two kinds of tile: as separate kernels on two streams they cannot
+ * share a CU (registers / LDS), in one grid the rasteriser's waves issue while the shader's wait on memory.  Same results. */
+int harp_shade_sil_bwd(const harp_shade_args* a, float blur_radius, float sigma, const float* alpha, const float* g_alpha,
+                       hipStream_t stream);
 
 /* ---- mesh preparation --------------------------------------------------------------------------------------------
  * replaces the PyTorch3D object churn of utils/visualize.py:prepare_mesh (:45-64): Meshes(...), SubdivideMeshes
