@@ -75,26 +75,6 @@ __device__ __forceinline__ int tile_decode(const int32_t* __restrict__ order, co
                                            int& b, int& st, int& tx0, int& ty0, int& sub, bool coords_if_empty = true) {
   return tile_decode_v(blockIdx.x, order, nact, B, nsx, S, b, st, tx0, ty0, sub, coords_if_empty);
 }
-// The same launch order for workgroups that own a 16x32-pixel DOUBLE tile (two vertically adjacent tiles; forward rasterisers with two
-// pixels per lane): 8 workgroups per super-tile, grid = tile_grid / 2.  (tx0, ty0) = top-left pixel of the double tile.
-inline unsigned tile_grid2(int B, int nsx) { return tile_grid(B, nsx) / 2; }
-__device__ __forceinline__ int tile_decode_v2(unsigned bid, const int32_t* __restrict__ order, const int32_t* __restrict__ nact, int B, int nsx, int S,
-                                              int& b, int& st, int& tx0, int& ty0, int& sub, bool coords_if_empty = true) {
-  constexpr int kTps = (kSuper / kTile) * (kSuper / kTile) / 2;
-  const int nst = nsx * nsx;
-  const int xcd = bid & 7, rr = bid >> 3;
-  const int slot = (rr / kTps) * 8 + xcd;
-  sub = rr % kTps;
-  if (slot >= B * nst) return 0;
-  const bool empty = slot >= nact[0];
-  if (empty && !coords_if_empty) return 2;
-  const int entry = order[slot];
-  b = entry / nst; st = entry - b * nst;
-  tx0 = ((st % nsx) * (kSuper / kTile) + (sub & 3)) * kTile;
-  ty0 = ((st / nsx) * (kSuper / kTile) + (sub >> 2) * 2) * kTile;
-  if (!(tx0 < S && ty0 < S)) return 0;
-  return empty ? 2 : 1;
-}
 // Pixels of a whole 64x64 super-tile spread over a 256-thread workgroup (16 each, 64-wide coalesced rows): k = 0..15
 __device__ __forceinline__ void supertile_pixel(int k, int sx0, int sy0, int& xi, int& yi) {
   const int idx = k * 256 + (int)threadIdx.x;

@@ -139,19 +139,6 @@ __global__ void __launch_bounds__(256) raster_kernel(const FaceRec* __restrict__
                         l1_target, l1_fid, l1_w, l1_loss, l1_grad, l1_inv, sparse, l1_bg_sums);
 }
 
-template <int MODE>
-__global__ void __launch_bounds__(256) raster2_kernel(const FaceRec* __restrict__ recs, const float4* __restrict__ bbs, const int32_t* __restrict__ bins,
-                                                      const int32_t* __restrict__ bin_count, const int32_t* __restrict__ order,
-                                                      const int32_t* __restrict__ nact, int B, int F, int S, int nsx, float blur, float sigma,
-                                                      int32_t* __restrict__ face_id, float* __restrict__ zbuf, float* __restrict__ alpha,
-                                                      const float* __restrict__ l1_target, const int32_t* __restrict__ l1_fid,
-                                                      const float* __restrict__ l1_w, float* __restrict__ l1_loss, float* __restrict__ l1_grad,
-                                                      float l1_inv, int sparse, const float* __restrict__ l1_bg_sums) {
-  __shared__ rb::RasterSmem<MODE> sm;
-  rb::raster_tile2<MODE>(sm, blockIdx.x, recs, bbs, bins, bin_count, order, nact, B, F, S, nsx, blur, sigma, face_id, zbuf, alpha, l1_target, l1_fid,
-                         l1_w, l1_loss, l1_grad, l1_inv, sparse, l1_bg_sums);
-}
-
 }  // namespace
 
 // per-face records with a bbox dilated by r, per-super-tile face lists (ascending), launch order: shared with csrc/fragments.hip
@@ -195,26 +182,14 @@ int harp_rasterize_l1_fwd(const float* ndc, const int32_t* faces, int B, int V, 
   hipLaunchKernelGGL(face_setup_kernel, dim3((F + 255) / 256, B), dim3(256), 0, stream, ndc, faces, V, F, r, recs, bbs);
   hipLaunchKernelGGL(bin_faces_kernel, dim3((nsx * nsx + 3) / 4, B), dim3(256), 0, stream, bbs, F, S, nsx, bins, cnt);
   hipLaunchKernelGGL(order_tiles_kernel, dim3(1), dim3(1024), 0, stream, cnt, B * nsx * nsx, order, W.nact);
-  // soft bit 2 (value 4): the first, one-pixel-per-lane tile kernels (A/B timing; same results)
-  if (soft & 4) {
-    const dim3 grid(tile_grid(B, nsx));
-    if (soft & 1)
-      hipLaunchKernelGGL(raster_kernel<1>, grid, dim3(256), 0, stream, recs, bbs, bins, cnt, order, W.nact, B, F, S, nsx, blur_radius, sigma,
-                         face_id, zbuf, alpha, nullptr, nullptr, 0, nullptr, l1_target, l1_fid, l1_w, l1_loss, l1_grad,
-                         1.0f / ((float)B * (float)S * (float)S), (soft & 2) ? 1 : 0, l1_bg_sums);
-    else
-      hipLaunchKernelGGL(raster_kernel<0>, grid, dim3(256), 0, stream, recs, bbs, bins, cnt, order, W.nact, B, F, S, nsx, 0.f, 1.f, face_id, zbuf,
-                         nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, (soft & 2) ? 1 : 0, nullptr);
-  } else {
-    const dim3 grid(tile_grid2(B, nsx));
-    if (soft & 1)
-      hipLaunchKernelGGL(raster2_kernel<1>, grid, dim3(256), 0, stream, recs, bbs, bins, cnt, order, W.nact, B, F, S, nsx, blur_radius, sigma,
-                         face_id, zbuf, alpha, l1_target, l1_fid, l1_w, l1_loss, l1_grad, 1.0f / ((float)B * (float)S * (float)S),
-                         (soft & 2) ? 1 : 0, l1_bg_sums);
-    else
-      hipLaunchKernelGGL(raster2_kernel<0>, grid, dim3(256), 0, stream, recs, bbs, bins, cnt, order, W.nact, B, F, S, nsx, 0.f, 1.f, face_id, zbuf,
-                         nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, (soft & 2) ? 1 : 0, nullptr);
-  }
+  const dim3 grid(tile_grid(B, nsx));
+  if (soft & 1)
+    hipLaunchKernelGGL(raster_kernel<1>, grid, dim3(256), 0, stream, recs, bbs, bins, cnt, order, W.nact, B, F, S, nsx, blur_radius, sigma,
+                       face_id, zbuf, alpha, nullptr, nullptr, 0, nullptr, l1_target, l1_fid, l1_w, l1_loss, l1_grad,
+                       1.0f / ((float)B * (float)S * (float)S), (soft & 2) ? 1 : 0, l1_bg_sums);
+  else
+    hipLaunchKernelGGL(raster_kernel<0>, grid, dim3(256), 0, stream, recs, bbs, bins, cnt, order, W.nact, B, F, S, nsx, 0.f, 1.f, face_id, zbuf,
+                       nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, (soft & 2) ? 1 : 0, nullptr);
   HARP_CHECK_LAUNCH();
   return HARP_OK;
 }

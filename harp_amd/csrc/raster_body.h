@@ -308,10 +308,7 @@ __device__ __forceinline__ void raster_tile(RasterSmem<MODE>& sm, unsigned vbloc
       // ascending face order (same tie-break, same product order => bit-identical results), a handful of iterations per strip.
       unsigned long long m = __ballot(whit);
 #if defined(RASTER_ABLATE) && (RASTER_ABLATE & 1)
-      m = 0;                 // ablation (timing only): no classification
-#endif
-#if defined(RASTER_ABLATE) && (RASTER_ABLATE & 4)
-      if (MODE != 2) m &= 0x1111111111111111ull;      // ablation (timing only): a quarter of the (face, strip) pairs
+      m = 0;                 // ablation (timing only, -DRASTER_ABLATE=1): no classification -> what staging, culls and epilogue cost
 #endif
       while (m) {
         const int j = g + __ffsll((unsigned long long)m) - 1;
@@ -362,11 +359,7 @@ __device__ __forceinline__ void raster_tile(RasterSmem<MODE>& sm, unsigned vbloc
         if (__any(hn == 4 || sn == 8)) drain();
       }
     }
-#if !(defined(RASTER_ABLATE) && (RASTER_ABLATE & 2))
     drain();            // staged indices are only valid within this round
-#else
-    hn = 0; sn = 0;
-#endif
     __syncthreads();
     if (MODE == 2 && (int)threadIdx.x < nl) {
       // flush: one global atomic per (staged face, vertex, component) per workgroup
@@ -408,278 +401,5 @@ __device__ __forceinline__ void raster_tile(RasterSmem<MODE>& sm, unsigned vbloc
 }
 
 
-// ---- forward rasterisation with TWO PIXELS PER LANE (MODE 0: light-view depth, MODE 1: camera view + soft silhouette) --------------
-// Why (profiles/r02_d_pmc_sq_raster_*, tools/dev ablations): the forward rasterisers are VALU-bound for real (95 % VALU-busy at 7 waves
-// per SIMD) and half of their time is NOT the per-face arithmetic: staging the super-tile's face list per 16x16 tile, the wave-level
-// culls and the loop bookkeeping cost 0.10 of the camera view's 0.24 ms with the classification switched off.  A workgroup now owns a
-// 16x32 DOUBLE tile and every lane two pixels of one column (rows y and y + 4; a wave = 16x8 pixels): one staging pass, one wave-level
-// cull and one trip through the hit loop serve twice the pixels; the column-dependent half of every edge function, (px - ax)(by - ay),
-// is computed once for both pixels, and the rest is written pair-wise so that the compiler emits packed-f32 instructions (v_pk_*).
-// Same visiting order (ascending face id) per pixel, same per-lane queues, same expressions: results are those of raster_tile.
-template <int MODE>
-__device__ __forceinline__ void raster_tile2(RasterSmem<MODE>& sm, unsigned vblock, const FaceRec* __restrict__ recs, const float4* __restrict__ bbs,
-                                             const int32_t* __restrict__ bins, const int32_t* __restrict__ bin_count,
-                                             const int32_t* __restrict__ order, const int32_t* __restrict__ nact, int B, int F, int S, int nsx,
-                                             float blur, float sigma, int32_t* __restrict__ face_id, float* __restrict__ zbuf,
-                                             float* __restrict__ alpha, const float* __restrict__ l1_target, const int32_t* __restrict__ l1_fid,
-                                             const float* __restrict__ l1_w, float* __restrict__ l1_loss, float* __restrict__ l1_grad, float l1_inv,
-                                             int sparse, const float* __restrict__ l1_bg_sums) {
-  static_assert(MODE == 0 || MODE == 1, "forward modes only");
-  auto& s_a = sm.s_a; auto& s_b = sm.s_b; auto& s_bb = sm.s_bb; auto& s_z2 = sm.s_z2; auto& s_fc = sm.s_fc; auto& s_id = sm.s_id;
-  int* lds_cnt = sm.lds_cnt;
-  int b, st, tx0, ty0, sub;
-  const int kind = tile_decode_v2(vblock, order, nact, B, nsx, S, b, st, tx0, ty0, sub, true);
-  if (kind == 0) return;
-  if (kind == 2) {
-    // super-tile without a single face: its first workgroup writes the empty-pixel outputs (and the fused silhouette L1 against
-    // alpha = 0) for all 64x64 pixels, the other 7 leave at once
-    if (sub != 0) return;
-    if (MODE == 1 && sparse && l1_target && l1_bg_sums) {
-      if (threadIdx.x == 0) {
-        const float sum = l1_bg_sums[(size_t)l1_fid[b] * nst_of(nsx) + st];
-        if (sum != 0.f) atomicAdd(l1_loss, sum * l1_inv);
-      }
-      return;
-    }
-    float acc = 0.f;
-    float tg[16];
-    const bool l1 = (MODE == 1) && l1_target != nullptr;
-    const float* trow = l1 ? l1_target + (size_t)l1_fid[b] * S * S : nullptr;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      int xi, yi;
-      supertile_pixel(k, tx0, ty0, xi, yi);
-      tg[k] = (l1 && xi < S && yi < S) ? trow[(size_t)yi * S + xi] : 0.f;
-    }
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      int xi, yi;
-      supertile_pixel(k, tx0, ty0, xi, yi);
-      if (xi < S && yi < S) {
-        const size_t o = ((size_t)b * S + yi) * S + xi;
-        if (l1) acc += fabsf(tg[k]);
-        if (zbuf) zbuf[o] = -1.0f;
-        if (!sparse) {
-          face_id[o] = -1;
-          if (MODE == 1) {
-            alpha[o] = 0.f;
-            if (l1) l1_grad[o] = l1_w[0] * l1_inv * (float)((0.f > tg[k]) - (0.f < tg[k]));
-          }
-        }
-      }
-    }
-    if (MODE == 1 && l1_target) {
-      const float sum = block_sum_256(acc, sm.red);
-      if (threadIdx.x == 0 && sum != 0.f) atomicAdd(l1_loss, sum * l1_inv);
-    }
-    return;
-  }
-  const int nst = nsx * nsx;
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int xi = tx0 + (lane & 15);
-  const int yi[2] = {ty0 + w * 8 + (lane >> 4), ty0 + w * 8 + (lane >> 4) + 4};
-  const bool in_img[2] = {(xi < S) && (yi[0] < S), (xi < S) && (yi[1] < S)};
-  const float px = pix_to_ndc(xi, S);
-  const float py[2] = {pix_to_ndc(yi[0], S), pix_to_ndc(yi[1], S)};
-  const int n = bin_count[b * nst + st];
-  const int32_t* list = bins + ((size_t)b * nst + st) * F;
-  const FaceRec* rb = recs + (size_t)b * F;
-  const float4* bbb = bbs + (size_t)b * F;
-  // double-tile and wave-block bounds in NDC (conservative supersets of the per-pixel bbox test)
-  const float t_xhi = pix_to_ndc(tx0, S), t_xlo = pix_to_ndc(min(tx0 + kTile, S) - 1, S);
-  const float t_yhi = pix_to_ndc(ty0, S), t_ylo = pix_to_ndc(min(ty0 + 2 * kTile, S) - 1, S);
-  const float w_yhi = pix_to_ndc(ty0 + w * 8, S), w_ylo = pix_to_ndc(ty0 + w * 8 + 7, S);
-  const float strip_r = (MODE == 0) ? 0.f : sqrtf(blur);
-  float best_z[2] = {3.0e38f, 3.0e38f};
-  int best_f[2] = {-1, -1};
-  float prod[2] = {1.0f, 1.0f};
-  const float inv_sigma = 1.0f / sigma;
-  unsigned hq[2] = {0u, 0u};
-  unsigned long long sq[2] = {0ull, 0ull};
-  int hn[2] = {0, 0}, sn[2] = {0, 0};
-  // ---- phase 2: every lane pops its own queued faces (LDS gathers with per-lane addresses); both pixels of the lane in one trip
-  auto drain = [&]() {
-    while (__any(hn[0] > 0 || hn[1] > 0)) {
-#pragma unroll
-      for (int p = 0; p < 2; ++p) {
-        if (hn[p] > 0) {
-          const int j = (int)(hq[p] & 0xffu);
-          hq[p] >>= 8; --hn[p];
-          const Tri t = tri_from(s_a[j], s_b[j], make_float4(s_z2[j], 0.f, 0.f, 0.f));
-          const float e0 = edge_fn(px, py[p], t.x1, t.y1, t.x2, t.y2);
-          const float e1 = edge_fn(px, py[p], t.x2, t.y2, t.x0, t.y0);
-          const float e2 = edge_fn(px, py[p], t.x0, t.y0, t.x1, t.y1);
-          const float area = edge_fn(t.x2, t.y2, t.x0, t.y0, t.x1, t.y1) + kEps;
-          const float ra = __builtin_amdgcn_rcpf(area);
-          const float t0 = (e0 * ra) * t.z1 * t.z2, t1 = t.z0 * (e1 * ra) * t.z2, t2 = t.z0 * t.z1 * (e2 * ra);
-          const float rd = __builtin_amdgcn_rcpf(fmaxf(t0 + t1 + t2, kEps));
-          const float pz = (t0 * rd) * t.z0 + (t1 * rd) * t.z1 + (t2 * rd) * t.z2;
-          if (pz >= 0.f && pz < best_z[p]) { best_z[p] = pz; best_f[p] = s_id[j]; }
-        }
-      }
-    }
-    if (MODE == 1) {
-      while (__any(sn[0] > 0 || sn[1] > 0)) {
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-          if (sn[p] > 0) {
-            const int j = (int)(sq[p] & 0xffull);
-            sq[p] >>= 8; --sn[p];
-            if (prod[p] != 0.f) {
-              const Tri t = tri_from(s_a[j], s_b[j], make_float4(0.f, 0.f, 0.f, 0.f));
-              const float e0 = edge_fn(px, py[p], t.x1, t.y1, t.x2, t.y2);
-              const float e1 = edge_fn(px, py[p], t.x2, t.y2, t.x0, t.y0);
-              const float e2 = edge_fn(px, py[p], t.x0, t.y0, t.x1, t.y1);
-              const float area = edge_fn(t.x2, t.y2, t.x0, t.y0, t.x1, t.y1) + kEps;
-              const float sg = (area > 0.f) ? 1.f : ((area < 0.f) ? -1.f : 0.f);
-              const bool inside = (e0 * sg > 0.f) && (e1 * sg > 0.f) && (e2 * sg > 0.f);
-              float ta, tb, tc;
-              const float d01 = seg_dist2(px, py[p], t.x0, t.y0, t.x1, t.y1, ta);
-              const float d02 = seg_dist2(px, py[p], t.x0, t.y0, t.x2, t.y2, tb);
-              const float d12 = seg_dist2(px, py[p], t.x1, t.y1, t.x2, t.y2, tc);
-              const float dist = fminf(d01, fminf(d02, d12));
-              if (inside || dist < blur) {
-                const float sd = inside ? -dist : dist;
-                const float pr = __builtin_amdgcn_rcpf(1.0f + __expf(sd * inv_sigma));
-                prod[p] *= (1.0f - pr);
-              }
-            }
-          }
-        }
-      }
-    }
-  };
-
-  for (int base = 0; base < n; base += kStage) {
-    // ---- stage: filter this round's list entries against the 16x32 double tile, compact into LDS
-    const int e = base + threadIdx.x;
-    bool hit = false;
-    int id = 0;
-    float4 bb;
-    if (e < n) {
-      id = list[e];
-      bb = bbb[id];
-      hit = !(t_xlo > bb.y || t_xhi < bb.x || t_ylo > bb.w || t_yhi < bb.z);
-    }
-    int nl;
-    const int pos = block_compact(hit, 0, lds_cnt, nl);
-    if (pos >= 0) {
-      const FaceRec r = rb[id];
-      s_a[pos] = r.a; s_b[pos] = r.b; s_z2[pos] = r.c.x; s_bb[pos] = bb; s_id[pos] = id;
-      if (MODE == 1) {
-        const Tri t = tri_from(r.a, r.b, make_float4(0.f, 0.f, 0.f, 0.f));
-        const float area = edge_fn(t.x2, t.y2, t.x0, t.y0, t.x1, t.y1) + kEps;
-        s_fc[pos] = make_float4((area > 0.f) ? 1.f : ((area < 0.f) ? -1.f : 0.f),
-                                (t.x2 - t.x1) * (t.x2 - t.x1) + (t.y2 - t.y1) * (t.y2 - t.y1),
-                                (t.x0 - t.x2) * (t.x0 - t.x2) + (t.y0 - t.y2) * (t.y0 - t.y2),
-                                (t.x1 - t.x0) * (t.x1 - t.x0) + (t.y1 - t.y0) * (t.y1 - t.y0));
-      }
-    }
-    __syncthreads();
-    // ---- walk: each wave ballots the staged faces against its 16x8 block
-    for (int g = 0; g < nl; g += 64) {
-      const int i = g + lane;
-      bool whit = false;
-      if (i < nl) {
-        const float4 q = s_bb[i];
-        whit = !(t_xlo > q.y || t_xhi < q.x || w_ylo > q.w || w_yhi < q.z);
-        if (whit) {
-          // tighter than the bbox: rejected when the block lies entirely beyond one edge LINE of the face by more than the blur radius
-          const float4 fa = s_a[i], fb = s_b[i];
-          const float X0 = fa.x, Y0 = fa.y, X1 = fa.w, Y1 = fb.x, X2 = fb.z, Y2 = fb.w;
-          const float ar = edge_fn(X2, Y2, X0, Y0, X1, Y1) + kEps;
-          const float sgn = (ar > 0.f) ? 1.f : -1.f;
-          const float ex[3] = {X1, X2, X0}, ey[3] = {Y1, Y2, Y0}, fx[3] = {X2, X0, X1}, fy[3] = {Y2, Y0, Y1};
-#pragma unroll
-          for (int k = 0; k < 3; ++k) {
-            const float dx = fx[k] - ex[k], dy = fy[k] - ey[k];
-            const float c00 = sgn * ((t_xlo - ex[k]) * dy - (w_ylo - ey[k]) * dx), c10 = sgn * ((t_xhi - ex[k]) * dy - (w_ylo - ey[k]) * dx);
-            const float c01 = sgn * ((t_xlo - ex[k]) * dy - (w_yhi - ey[k]) * dx), c11 = sgn * ((t_xhi - ex[k]) * dy - (w_yhi - ey[k]) * dx);
-            const float emax = fmaxf(fmaxf(c00, c10), fmaxf(c01, c11));
-            const float margin = strip_r * sqrtf(dx * dx + dy * dy) * 1.0001f + 1e-12f;
-            if (emax < -margin) whit = false;
-          }
-        }
-      }
-      // ---- phase 1: classify only; queue the staged-face indices each pixel needs (hard: 4 x 8 bit, soft: 8 x 8 bit per pixel)
-      unsigned long long m = __ballot(whit);
-      while (m) {
-        const int j = g + __ffsll((unsigned long long)m) - 1;
-        m &= m - 1;
-        const float4 q = s_bb[j];
-        const bool inx = !(px > q.y || px < q.x);
-        const bool inbox[2] = {in_img[0] && inx && !(py[0] > q.w || py[0] < q.z), in_img[1] && inx && !(py[1] > q.w || py[1] < q.z)};
-        if (!__any(inbox[0] || inbox[1])) continue;
-        const float4 fa = s_a[j], fb = s_b[j];
-        const Tri t = tri_from(fa, fb, make_float4(0.f, 0.f, 0.f, 0.f));
-        // e_k(p) = (px - ax)(by - ay) - (py - ay)(bx - ax): the first product is shared by the lane's two pixels
-        const float c0 = (px - t.x1) * (t.y2 - t.y1), c1 = (px - t.x2) * (t.y0 - t.y2), c2 = (px - t.x0) * (t.y1 - t.y0);
-        const float d0 = t.x2 - t.x1, d1 = t.x0 - t.x2, d2 = t.x1 - t.x0;
-        float e0[2], e1[2], e2[2];
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-          e0[p] = c0 - (py[p] - t.y1) * d0;
-          e1[p] = c1 - (py[p] - t.y2) * d1;
-          e2[p] = c2 - (py[p] - t.y0) * d2;
-        }
-        float sg, l12 = 0.f, l20 = 0.f, l01 = 0.f;
-        if (MODE == 1) {
-          const float4 fc = s_fc[j];
-          sg = fc.x; l12 = fc.y; l20 = fc.z; l01 = fc.w;
-        } else {
-          const float area = edge_fn(t.x2, t.y2, t.x0, t.y0, t.x1, t.y1) + kEps;
-          sg = (area > 0.f) ? 1.f : ((area < 0.f) ? -1.f : 0.f);
-        }
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-          const float e0s = e0[p] * sg, e1s = e1[p] * sg, e2s = e2[p] * sg;
-          const bool inside = (e0s > 0.f) && (e1s > 0.f) && (e2s > 0.f);
-          if (inside && inbox[p]) { hq[p] |= (unsigned)j << (8 * hn[p]); ++hn[p]; }
-          if (MODE == 1) {
-            bool soft = inbox[p] && prod[p] != 0.f;
-            if (soft) {
-              if (inside) {
-                // deeper than sqrt(18 sigma) inside every edge LINE: sigmoid saturates to exactly 1 in fp32, the factor (1-p) is exactly 0
-                const float K = 18.0f * sigma;
-                if (e0[p] * e0[p] > K * l12 && e1[p] * e1[p] > K * l20 && e2[p] * e2[p] > K * l01) { prod[p] = 0.f; soft = false; }
-              } else {
-                // outside: the triangle lies beyond the line of any violated edge, so dist >= that line distance
-                const float Bf = blur * 1.00001f;
-                if ((e0s < 0.f && e0[p] * e0[p] >= Bf * l12) || (e1s < 0.f && e1[p] * e1[p] >= Bf * l20) || (e2s < 0.f && e2[p] * e2[p] >= Bf * l01)) soft = false;
-              }
-              if (soft) { sq[p] |= (unsigned long long)j << (8 * sn[p]); ++sn[p]; }
-            }
-          }
-        }
-        if (__any(hn[0] == 4 || hn[1] == 4 || sn[0] == 8 || sn[1] == 8)) drain();
-      }
-    }
-    drain();            // staged indices are only valid within this round
-    __syncthreads();
-  }
-
-  float l1_acc = 0.f;
-#pragma unroll
-  for (int p = 0; p < 2; ++p) {
-    if (in_img[p]) {
-      const size_t o = ((size_t)b * S + yi[p]) * S + xi;
-      face_id[o] = best_f[p];
-      if (zbuf) zbuf[o] = (best_f[p] >= 0) ? best_z[p] : -1.0f;
-      if (MODE == 1) {
-        const float a = 1.0f - prod[p];
-        alpha[o] = a;
-        if (l1_target) {
-          const float d = a - l1_target[((size_t)l1_fid[b] * S + yi[p]) * S + xi];
-          l1_acc += fabsf(d);
-          l1_grad[o] = l1_w[0] * l1_inv * ((d > 0.f) - (d < 0.f));
-        }
-      }
-    }
-  }
-  if (MODE == 1 && l1_target) {
-    const float sum = block_sum_256(l1_acc, sm.red);
-    if (threadIdx.x == 0 && sum != 0.f) atomicAdd(l1_loss, sum * l1_inv);
-  }
-}
 
 }  // namespace rb
