@@ -172,3 +172,12 @@ SIGNATURES.update({
     "harp_rasterize_fragments_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _vp]),
 })
 SIGNATURES["harp_shade_sil_bwd"] = (_i, [ctypes.POINTER(ShadeArgs), _f, _f, _vp, _vp, _vp])
+
+
+class HandFront(ctypes.Structure):
+    """mirror of `harp_hand_front` (include/harp_hip.h)"""
+    _fields_ = ([("chain", MeshChain), ("mano", ManoModel), ("tables", FrameTables), ("fid", _vp)] +
+                [(n, _vp) for n in ("pose48", "betas", "trans_b", "cam_R", "cam_T", "light_pos", "colors", "lbs_ws")] + [("self_shadow", _i)])
+
+
+SIGNATURES["harp_hand_front_fwd"] = (_i, [ctypes.POINTER(HandFront), _vp])

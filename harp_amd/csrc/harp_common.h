@@ -32,7 +32,7 @@ struct FaceRec {
 // Layout of a rasteriser workspace (harp_rasterize_ws_bytes): face records | contiguous bboxes | per-super-tile face lists |
 // list lengths | heaviest-first launch order of the (frame, super-tile) pairs.
 struct RasterWs { FaceRec* recs; float4* bbs; int32_t* bins; int32_t* cnt; int32_t* order; int32_t* nact; int nsx; };
-inline RasterWs raster_ws_split(void* ws, int B, int F, int S) {
+__host__ __device__ inline RasterWs raster_ws_split(void* ws, int B, int F, int S) {
   RasterWs r;
   r.nsx = (S + kSuper - 1) / kSuper;
   char* p = (char*)ws;

@@ -26,92 +26,19 @@ __global__ void __launch_bounds__(256) face_setup_kernel(const float* __restrict
   const int f = blockIdx.x * blockDim.x + threadIdx.x;
   const int b = blockIdx.y;
   if (f >= F) return;
-  const int i0 = faces[3 * f], i1 = faces[3 * f + 1], i2 = faces[3 * f + 2];
-  const float* vb = ndc + (size_t)b * V * 3;
-  Tri t;
-  t.x0 = vb[3 * i0]; t.y0 = vb[3 * i0 + 1]; t.z0 = vb[3 * i0 + 2];
-  t.x1 = vb[3 * i1]; t.y1 = vb[3 * i1 + 1]; t.z1 = vb[3 * i1 + 2];
-  t.x2 = vb[3 * i2]; t.y2 = vb[3 * i2 + 1]; t.z2 = vb[3 * i2 + 2];
-  const float area = edge_fn(t.x0, t.y0, t.x1, t.y1, t.x2, t.y2);
-  const float zmax = fmaxf(t.z0, fmaxf(t.z1, t.z2)), zmin = fminf(t.z0, fminf(t.z1, t.z2));
-  // skipped for every pixel: behind camera, |area| <= eps, any vertex with z < eps (z_invalid), non-finite
-  const bool cull = (zmax < 0.f) || (area <= kEps && area >= -kEps) || (zmin < kEps) || !(area == area);
-  FaceRec rec;
-  rec.a = make_float4(t.x0, t.y0, t.z0, t.x1);
-  rec.b = make_float4(t.y1, t.z1, t.x2, t.y2);
-  rec.c = make_float4(t.z2, area, 0.f, 0.f);
-  if (cull) {
-    rec.bb = make_float4(3.0e38f, -3.0e38f, 3.0e38f, -3.0e38f);
-  } else {
-    rec.bb = make_float4(fminf(t.x0, fminf(t.x1, t.x2)) - r, fmaxf(t.x0, fmaxf(t.x1, t.x2)) + r,
-                         fminf(t.y0, fminf(t.y1, t.y2)) - r, fmaxf(t.y0, fmaxf(t.y1, t.y2)) + r);
-  }
+  const FaceRec rec = rb::face_rec(ndc + (size_t)b * V * 3, faces, f, r);
   recs[(size_t)b * F + f] = rec;
   bbs[(size_t)b * F + f] = rec.bb;      // contiguous copy: the binning pass streams it with fully coalesced 16-B loads
-}
-
-// Heaviest-first launch order of the (frame, super-tile) pairs: a counting sort of the bin counts by magnitude (33 buckets of
-// count leading zeros).  The raster grid is 1-D over this order, so the workgroups with real work are dispatched first and
-// densely (the natural (x, y, frame) order interleaves them with ~75 % empty tiles: measured average occupancy was < 3 of 8
-// waves per SIMD) and the longest ones do not end up in the tail.
-__device__ void order_tiles(const int32_t* __restrict__ bin_count, int total, int32_t* __restrict__ order, int32_t* __restrict__ nact,
-                            int* hist, int* base) {
-  if (threadIdx.x < 33) hist[threadIdx.x] = 0;
-  __syncthreads();
-  for (int i = threadIdx.x; i < total; i += blockDim.x) {
-    const int n = bin_count[i];
-    atomicAdd(&hist[n > 0 ? __clz(n) : 32], 1);
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    int run = 0;
-    for (int k = 0; k < 33; ++k) { base[k] = run; run += hist[k]; }
-    nact[0] = base[32];                      // bucket 32 = empty lists: everything before it has work
-  }
-  __syncthreads();
-  for (int i = threadIdx.x; i < total; i += blockDim.x) {
-    const int n = bin_count[i];
-    order[atomicAdd(&base[n > 0 ? __clz(n) : 32], 1)] = i;
-  }
 }
 
 // One WAVE per (frame, 64x64 super-tile): streams the frame's bboxes 64 at a time, ballot + popcount compaction,
 // no LDS, no barriers; the list comes out in ascending face order (== PyTorch3D's tie-break order).
 __global__ void __launch_bounds__(256) bin_faces_kernel(const float4* __restrict__ bbs, int F, int S, int nsx,
                                                         int32_t* __restrict__ bins, int32_t* __restrict__ bin_count) {
-  const int lane = threadIdx.x & 63;
   const int nst = nsx * nsx;
   const int st = blockIdx.x * 4 + (threadIdx.x >> 6), b = blockIdx.y;
   if (st >= nst) return;
-  const int sx = st % nsx, sy = st / nsx;
-  const int x_lo = sx * kSuper, x_hi = min(x_lo + kSuper, S) - 1;
-  const int y_lo = sy * kSuper, y_hi = min(y_lo + kSuper, S) - 1;
-  // NDC decreases with pixel index
-  const float nx_hi = pix_to_ndc(x_lo, S), nx_lo = pix_to_ndc(x_hi, S);
-  const float ny_hi = pix_to_ndc(y_lo, S), ny_lo = pix_to_ndc(y_hi, S);
-  const float4* bb = bbs + (size_t)b * F;
-  int32_t* out = bins + ((size_t)b * nst + st) * F;
-  int running = 0;
-  // the loop is a chain of dependent ballots but the loads are independent: issue kUnroll of them before the first use, otherwise
-  // every iteration pays a full L2 round trip (measured 50 us for 97 iterations at F = 6152; 2 waves per SIMD cannot hide it)
-  constexpr int kUnroll = 8;
-  for (int base = 0; base < F; base += 64 * kUnroll) {
-    float4 q[kUnroll];
-#pragma unroll
-    for (int u = 0; u < kUnroll; ++u) {
-      const int f = base + u * 64 + lane;
-      q[u] = (f < F) ? bb[f] : make_float4(3.0e38f, -3.0e38f, 3.0e38f, -3.0e38f);
-    }
-#pragma unroll
-    for (int u = 0; u < kUnroll; ++u) {
-      const int f = base + u * 64 + lane;
-      const bool hit = !(nx_lo > q[u].y || nx_hi < q[u].x || ny_lo > q[u].w || ny_hi < q[u].z);
-      const unsigned long long m = __ballot(hit);
-      if (hit) out[running + __popcll(m & ((1ull << lane) - 1ull))] = f;
-      running += __popcll(m);
-    }
-  }
-  if (lane == 0) bin_count[b * nst + st] = running;
+  rb::bin_super_tile(bbs + (size_t)b * F, F, S, nsx, st, bins + ((size_t)b * nst + st) * F, bin_count + b * nst + st);
 }
 
 // (Folding this into the binning pass with a "last workgroup done" ticket was measured: 512 same-address ticket atomics cost ~35 us,
@@ -119,7 +46,7 @@ __global__ void __launch_bounds__(256) bin_faces_kernel(const float4* __restrict
 __global__ void __launch_bounds__(1024) order_tiles_kernel(const int32_t* __restrict__ bin_count, int total, int32_t* __restrict__ order,
                                                            int32_t* __restrict__ nact) {
   __shared__ int s_hist[33], s_base[33];
-  order_tiles(bin_count, total, order, nact, s_hist, s_base);
+  rb::order_tiles(bin_count, total, order, nact, s_hist, s_base);
 }
 
 template <int MODE>
@@ -141,12 +68,16 @@ __global__ void __launch_bounds__(256) raster_kernel(const FaceRec* __restrict__
 
 }  // namespace
 
-// per-face records with a bbox dilated by r, per-super-tile face lists (ascending), launch order: shared with csrc/fragments.hip
-int harp_detail_raster_setup(const float* ndc, const int32_t* faces, int B, int V, int F, int S, float r, void* ws, hipStream_t stream) {
+static void raster_setup_any(const float* ndc, const int32_t* faces, int B, int V, int F, int S, float r, void* ws, hipStream_t stream) {
   const RasterWs W = raster_ws_split(ws, B, F, S);
   hipLaunchKernelGGL(face_setup_kernel, dim3((F + 255) / 256, B), dim3(256), 0, stream, ndc, faces, V, F, r, W.recs, W.bbs);
   hipLaunchKernelGGL(bin_faces_kernel, dim3((W.nsx * W.nsx + 3) / 4, B), dim3(256), 0, stream, W.bbs, F, S, W.nsx, W.bins, W.cnt);
   hipLaunchKernelGGL(order_tiles_kernel, dim3(1), dim3(1024), 0, stream, W.cnt, B * W.nsx * W.nsx, W.order, W.nact);
+}
+
+// per-face records with a bbox dilated by r, per-super-tile face lists (ascending), launch order: shared with csrc/fragments.hip
+int harp_detail_raster_setup(const float* ndc, const int32_t* faces, int B, int V, int F, int S, float r, void* ws, hipStream_t stream) {
+  raster_setup_any(ndc, faces, B, V, F, S, r, ws, stream);
   HARP_CHECK_LAUNCH();
   return HARP_OK;
 }
@@ -179,9 +110,7 @@ int harp_rasterize_l1_fwd(const float* ndc, const int32_t* faces, int B, int V, 
   FaceRec* recs = W.recs; int32_t *bins = W.bins, *cnt = W.cnt, *order = W.order; float4* bbs = W.bbs;
   const int nsx = W.nsx;
   const float r = (soft & 1) ? sqrtf(blur_radius) : 0.f;
-  hipLaunchKernelGGL(face_setup_kernel, dim3((F + 255) / 256, B), dim3(256), 0, stream, ndc, faces, V, F, r, recs, bbs);
-  hipLaunchKernelGGL(bin_faces_kernel, dim3((nsx * nsx + 3) / 4, B), dim3(256), 0, stream, bbs, F, S, nsx, bins, cnt);
-  hipLaunchKernelGGL(order_tiles_kernel, dim3(1), dim3(1024), 0, stream, cnt, B * nsx * nsx, order, W.nact);
+  raster_setup_any(ndc, faces, B, V, F, S, r, ws, stream);
   const dim3 grid(tile_grid(B, nsx));
   if (soft & 1)
     hipLaunchKernelGGL(raster_kernel<1>, grid, dim3(256), 0, stream, recs, bbs, bins, cnt, order, W.nact, B, F, S, nsx, blur_radius, sigma,

@@ -402,4 +402,94 @@ __device__ __forceinline__ void raster_tile(RasterSmem<MODE>& sm, unsigned vbloc
 
 
 
+__device__ __forceinline__ FaceRec face_rec(const float* vb, int i0, int i1, int i2, float r);
+__device__ __forceinline__ FaceRec face_rec(const float* vb, const int32_t* __restrict__ faces, int f, float r) {
+  return face_rec(vb, faces[3 * f], faces[3 * f + 1], faces[3 * f + 2], r);
+}
+
+// ---- set-up pieces (face records, super-tile binning, launch order): used by raster.hip's three set-up launches and, fused per
+//      frame, by hand_front.hip
+
+// per-face record with a bbox dilated by r; culled faces get an empty box.  vb: this frame's (V,3) NDC vertices (global or LDS)
+__device__ __forceinline__ FaceRec face_rec(const float* vb, int i0, int i1, int i2, float r) {
+  Tri t;
+  t.x0 = vb[3 * i0]; t.y0 = vb[3 * i0 + 1]; t.z0 = vb[3 * i0 + 2];
+  t.x1 = vb[3 * i1]; t.y1 = vb[3 * i1 + 1]; t.z1 = vb[3 * i1 + 2];
+  t.x2 = vb[3 * i2]; t.y2 = vb[3 * i2 + 1]; t.z2 = vb[3 * i2 + 2];
+  const float area = edge_fn(t.x0, t.y0, t.x1, t.y1, t.x2, t.y2);
+  const float zmax = fmaxf(t.z0, fmaxf(t.z1, t.z2)), zmin = fminf(t.z0, fminf(t.z1, t.z2));
+  // skipped for every pixel: behind camera, |area| <= eps, any vertex with z < eps (z_invalid), non-finite
+  const bool cull = (zmax < 0.f) || (area <= kEps && area >= -kEps) || (zmin < kEps) || !(area == area);
+  FaceRec rec;
+  rec.a = make_float4(t.x0, t.y0, t.z0, t.x1);
+  rec.b = make_float4(t.y1, t.z1, t.x2, t.y2);
+  rec.c = make_float4(t.z2, area, 0.f, 0.f);
+  if (cull) {
+    rec.bb = make_float4(3.0e38f, -3.0e38f, 3.0e38f, -3.0e38f);
+  } else {
+    rec.bb = make_float4(fminf(t.x0, fminf(t.x1, t.x2)) - r, fmaxf(t.x0, fmaxf(t.x1, t.x2)) + r,
+                         fminf(t.y0, fminf(t.y1, t.y2)) - r, fmaxf(t.y0, fmaxf(t.y1, t.y2)) + r);
+  }
+  return rec;
+}
+
+// One WAVE bins one (frame, 64x64 super-tile): streams the frame's bboxes `bb` (global or LDS) 64 at a time, ballot + popcount
+// compaction, no barriers; the list `out` comes out in ascending face order (== PyTorch3D's tie-break order).
+__device__ __forceinline__ void bin_super_tile(const float4* bb, int F, int S, int nsx, int st, int32_t* __restrict__ out,
+                                               int32_t* __restrict__ count) {
+  const int lane = threadIdx.x & 63;
+  const int sx = st % nsx, sy = st / nsx;
+  const int x_lo = sx * kSuper, x_hi = min(x_lo + kSuper, S) - 1;
+  const int y_lo = sy * kSuper, y_hi = min(y_lo + kSuper, S) - 1;
+  // NDC decreases with pixel index
+  const float nx_hi = pix_to_ndc(x_lo, S), nx_lo = pix_to_ndc(x_hi, S);
+  const float ny_hi = pix_to_ndc(y_lo, S), ny_lo = pix_to_ndc(y_hi, S);
+  int running = 0;
+  // the loop is a chain of dependent ballots but the loads are independent: issue kUnroll of them before the first use, otherwise
+  // every iteration pays a full L2 round trip (measured 50 us for 97 iterations at F = 6152; 2 waves per SIMD cannot hide it)
+  constexpr int kUnroll = 8;
+  for (int base = 0; base < F; base += 64 * kUnroll) {
+    float4 q[kUnroll];
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) {
+      const int f = base + u * 64 + lane;
+      q[u] = (f < F) ? bb[f] : make_float4(3.0e38f, -3.0e38f, 3.0e38f, -3.0e38f);
+    }
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) {
+      const int f = base + u * 64 + lane;
+      const bool hit = !(nx_lo > q[u].y || nx_hi < q[u].x || ny_lo > q[u].w || ny_hi < q[u].z);
+      const unsigned long long m = __ballot(hit);
+      if (hit) out[running + __popcll(m & ((1ull << lane) - 1ull))] = f;
+      running += __popcll(m);
+    }
+  }
+  if (lane == 0) count[0] = running;
+}
+
+// Heaviest-first launch order of the (frame, super-tile) pairs: a counting sort of the bin counts by magnitude (33 buckets of
+// count leading zeros).  The raster grid is 1-D over this order, so the workgroups with real work are dispatched first and
+// densely (the natural (x, y, frame) order interleaves them with ~75 % empty tiles: measured average occupancy was < 3 of 8
+// waves per SIMD) and the longest ones do not end up in the tail.   One workgroup; hist / base: 33 ints of LDS each.
+__device__ __forceinline__ void order_tiles(const int32_t* __restrict__ bin_count, int total, int32_t* __restrict__ order, int32_t* __restrict__ nact,
+                                            int* hist, int* base) {
+  if (threadIdx.x < 33) hist[threadIdx.x] = 0;
+  __syncthreads();
+  for (int i = threadIdx.x; i < total; i += blockDim.x) {
+    const int n = bin_count[i];
+    atomicAdd(&hist[n > 0 ? __clz(n) : 32], 1);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int run = 0;
+    for (int k = 0; k < 33; ++k) { base[k] = run; run += hist[k]; }
+    nact[0] = base[32];                      // bucket 32 = empty lists: everything before it has work
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < total; i += blockDim.x) {
+    const int n = bin_count[i];
+    order[atomicAdd(&base[n > 0 ? __clz(n) : 32], 1)] = i;
+  }
+}
+
 }  // namespace rb

@@ -149,6 +149,8 @@ class FitEngine:
         self._graphs = {}
         # per-frame fused mesh chain (csrc/chain.hip): 22 launches -> 2; needs the frame's mesh to fit its LDS staging
         self.fused_chain = self.topo.V <= _lib.lib().harp_mesh_chain_max_vertices()
+        # MANO path: frame set-up + hand layer + mesh chain + rasteriser set-up of both views as ONE launch (csrc/hand_front.hip)
+        self.fused_front = self.fused_chain and not self.use_arm and self.n_joints == 21
         # ---- switches (all on in production; tools/dev and bench.py flip some of them to measure their effect)
         self.overlap = True              # second HIP stream (light view, silhouette backward, parameter-only terms); False: one stream
         self.early_terms = True          # parameter-only terms / mesh regularisers scheduled on the second stream
@@ -261,10 +263,20 @@ class FitEngine:
         c.focal, c.shadow, c.has_normal_grad = self.focal, int(shadow), int(has_normal_grad)
         return c
 
-    def _mesh_forward(self, fid, B, shadow=False):
+    def _mesh_forward(self, fid, B, shadow=False, front=False):
         """frame_setup .. normals (and, fused, both projections + the light camera): fills the scratch geometry for the B frames in
-        `fid` (int32 device tensor).  Returns True when the fused chain ran (projections / light camera already done)."""
+        `fid` (int32 device tensor).  Returns True when the fused chain ran (projections / light camera already done).  front=True
+        allows the one-launch form of the whole front (MANO path, csrc/hand_front.hip)."""
         L, s, p, st, tp = _lib.lib(), self.s, _lib.ptr, _lib.stream(), self.topo
+        if front and self.fused_front and self.fused_chain:
+            h = _lib.HandFront()
+            h.chain, h.mano, h.tables = self._chain_struct(B, shadow, False), self.dm.struct, self.tables
+            for k, t in (("fid", fid), ("pose48", s["pose48"]), ("betas", s["betas"]), ("trans_b", s["trans_b"]), ("cam_R", s["cam_R"]),
+                         ("cam_T", s["cam_T"]), ("light_pos", s["light_pos"]), ("colors", s["colors"]), ("lbs_ws", s["lbs_ws"])):
+                setattr(h, k, p(t))
+            h.self_shadow = int(self.self_shadow)
+            self._ck(L.harp_hand_front_fwd(ctypes.byref(h), st), "hand_front_fwd")
+            return True
         self._ck(L.harp_frame_setup_fwd(ctypes.byref(self.tables), p(fid), B, self.S, self.focal, int(self.self_shadow), p(s["pose48"]),
                                         p(s["betas"]), p(s["trans_b"]), p(s["cam_R"]), p(s["cam_T"]), p(s["light_pos"]), p(s["colors"]), st),
                  "frame_setup_fwd")
@@ -369,7 +381,7 @@ class FitEngine:
             side.wait_stream(cur)
             with torch.cuda.stream(side):
                 param_terms()
-        fused = self._mesh_forward(lfid, B, shadow)      # fused chain: both projections and the light camera are done as well
+        fused = self._mesh_forward(lfid, B, shadow, front=True)      # fused chain: both projections and the light camera are done as well
         # ---- the light-view chain (centroid -> light camera -> projection -> K=1 raster) is independent of the camera-view chain:
         #      it runs on the second HIP stream so the two rasterisations overlap (fork / join is captured into the graph); the mesh
         #      regularisers and the key-point term follow it there (the light raster is the shorter of the two)
@@ -744,7 +756,7 @@ class FitEngine:
         # every switch the enqueued launch sequence depends on is part of the key: flipping one re-captures instead of replaying a
         # graph recorded for another configuration
         gkey = (coarse, app, scheduled, self.keep_image, self.fused_loss, self.self_shadow, tuple(self.frozen), self.overlap, self.early_terms,
-                self.packed_texels, self.auto_draw, self.mesh_terms_first, self.camera_first, self.tail_side, self.fused_bwd, self.fused_chain, dist_on, self.overlap_allreduce,
+                self.packed_texels, self.auto_draw, self.mesh_terms_first, self.camera_first, self.tail_side, self.fused_bwd, self.fused_chain, self.fused_front, dist_on, self.overlap_allreduce,
                 self.comm is not None)
         g = self._graphs.get(gkey)
         if g is None:

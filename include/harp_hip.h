@@ -347,6 +347,22 @@ int harp_frame_setup_fwd(const harp_frame_tables* t, const int32_t* fid, int B, 
 int harp_frame_setup_bwd(const harp_frame_tables* t, const int32_t* fid, int B, int S, float focal, int self_shadow,
                          const float* g_pose48, const float* g_betas, const float* g_trans_b, const float* g_cam_T,
                          const float* g_light_pos, const float* g_colors, hipStream_t stream);
+
+/* ---- fused per-frame front of a fitting step, MANO path (csrc/hand_front.hip) ------------------------------------------
+ * ONE launch = harp_frame_setup_fwd + harp_lbs_mano_fwd + harp_mesh_chain_fwd.  chain.verts_mm / chain.joints_mm are OUTPUTS
+ * here; chain.cam_R / cam_T / light_pos must alias cam_R / cam_T / light_pos below (written by this call).  tables.wrist_pose
+ * must be NULL (MANO rows), chain.V0 = 778, chain.NJ = 21. */
+typedef struct harp_hand_front {
+  harp_mesh_chain chain;
+  harp_mano_model mano;
+  harp_frame_tables tables;
+  const int32_t* fid;        /* (B,) frame of each batch row */
+  float *pose48, *betas, *trans_b, *cam_R, *cam_T, *light_pos, *colors;   /* as harp_frame_setup_fwd */
+  float* lbs_ws;             /* harp_lbs_mano_ws_floats(B) floats, kept for harp_lbs_mano_bwd */
+  int self_shadow;           /* colours from amb_ratio (shadow renderer) or the fixed Phong lights */
+} harp_hand_front;
+int harp_hand_front_fwd(const harp_hand_front* h, hipStream_t stream);
+
 int harp_light_setup_fwd(const float* centroid, const float* light_pos, int B, float* light_R, float* light_T, hipStream_t stream);
 int harp_light_setup_bwd(const float* centroid, const float* light_pos, const float* g_light_R, const float* g_light_T, int B, int V,
                          float* g_light_pos, float* g_centroid, float* g_verts, hipStream_t stream);

@@ -401,6 +401,7 @@ def test_fused_mesh_chain_matches_building_blocks(sc, coarse, app):
     eng.fid.copy_(fid); eng.tfid.copy_(fid)
     eng.auto_draw = False; eng.draw_texture_offsets(); eng.set_stage(coarse, app)
     assert eng.fused_chain
+    eng.fused_front = False                      # the chain kernels themselves (the one-launch front has its own test below)
     out = {}
     for fused in (False, True):
         eng.fused_chain = fused
@@ -417,6 +418,54 @@ def test_fused_mesh_chain_matches_building_blocks(sc, coarse, app):
         o, n = eng.arena.offsets[k][0], eng.arena.offsets[k][1]
         if g0[o:o + n].abs().max() > 0:
             assert rel(g1[o:o + n], g0[o:o + n]) < 5e-4, k       # atomics order + the conditioning of the silhouette-rim gradient
+
+
+@pytest.mark.parametrize("coarse,app", [(True, True), (True, False)])
+def test_fused_front_matches_building_blocks(sc, coarse, app):
+    """harp_hand_front_fwd (frame set-up + MANO layer + mesh chain in one launch, csrc/hand_front.hip) against harp_frame_setup_fwd +
+    harp_lbs_mano_fwd + harp_mesh_chain_fwd: same gathered rows (bit-exact), same geometry and LBS workspace to fp32 rounding (the
+    blend-shape sums run in a different order), same losses and gradients."""
+    from harp_amd.engine import FitEngine
+    tg = sc["targets"]
+    eng = FitEngine(sc["model_np"], sc["topo_np"], sc["tpl"]["verts_uvs"], sc["tpl"]["faces_uvs"], sc["uv_mask"].float(), sc["seq"], sc["S"],
+                    sc["focal"], 3, device=DEV, seed=1)
+    eng.set_targets(tg["y_true"], tg["y_sil"], tg["y_sil_col"])
+    with torch.no_grad():
+        eng.params["verts_disps"].copy_(torch.randn(3093, 1) * 0.001)
+        eng.params["pose"].add_(torch.randn_like(eng.params["pose"]) * 0.05)
+        eng.params["shape"].add_(torch.randn_like(eng.params["shape"]) * 0.3)
+    fid = torch.tensor([2, 0, 1], dtype=torch.int32, device=DEV)
+    eng.fid.copy_(fid); eng.tfid.copy_(fid)
+    eng.auto_draw = False; eng.draw_texture_offsets(); eng.set_stage(coarse, app)
+    assert eng.fused_front and eng.fused_chain
+    keys = ("pose48", "betas", "trans_b", "cam_R", "cam_T", "light_pos", "colors", "verts_mm", "joints_mm", "joints_m", "vs", "vd", "n1", "n2",
+            "ndc_c", "lbs_ws")
+    out = {}
+    for fused in (False, True):
+        eng.fused_front = fused
+        for k in keys:
+            eng.s[k].fill_(7.0)                      # every output must be (re)written by the path under test
+        eng.forward_backward(coarse, app)
+        torch.cuda.synchronize()
+        out[fused] = ({k: eng.s[k].clone() for k in keys}, eng.g_buf.clone().cpu(), eng.loss_vec.clone().cpu())
+    for k in ("pose48", "betas", "trans_b", "cam_R", "cam_T", "light_pos", "colors"):
+        assert torch.equal(out[True][0][k], out[False][0][k]), k
+    from harp_amd import _lib
+    ws_f = _lib.lib().harp_lbs_mano_ws_floats(3)
+    for k in keys[7:]:
+        a, b = out[True][0][k], out[False][0][k]
+        if k == "lbs_ws":                                # forward rows only (pose map .. G, posed vertices); the rest is backward scratch
+            fwd = 3 * (135 + 192 + 48 + 48 + 144 + 192)
+            a, b = torch.cat([a[:fwd], a[ws_f - 3 * 2334:ws_f]]), torch.cat([b[:fwd], b[ws_f - 3 * 2334:ws_f]])
+        assert (a - b).abs().max().item() <= 2e-6 * max(1.0, b.abs().max().item()) or k in ("n1", "n2"), k
+        if k in ("n1", "n2"):                            # unit normals of near-degenerate fans amplify the 1e-7 position differences
+            assert (a - b).abs().mean().item() < 5e-6 and (a - b).abs().max().item() < 2e-3, k      # = position rounding (1e-7 m) / edge length (mm)
+    assert rel(out[True][2], out[False][2]) < 1e-6
+    g1, g0 = out[True][1], out[False][1]
+    for k in ("pose", "cam", "verts_disps", "shape", "rot", "trans"):
+        o, n = eng.arena.offsets[k][0], eng.arena.offsets[k][1]
+        if g0[o:o + n].abs().max() > 0:
+            assert rel(g1[o:o + n], g0[o:o + n]) < 1e-3, k       # soft-rim conditioning: 1e-7 vertex moves flip a handful of pixels
 
 
 def test_rccl_path_on_one_rank(sc):
