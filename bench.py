@@ -156,7 +156,7 @@ def kernel_roofline(eng, steps, overlap=False):
     return out
 
 
-def extra_rates(eng, device, steps=12, warmup=4):
+def extra_rates(eng, device, steps=12, warmup=4, vgg_weights="random"):
     """Rates of the other BASELINE.json configurations and modes (not the headline `value`): the same step with the rendered image
     materialised like the reference's y_pred (keep_image=True), C2 at the reference's batch size 18, and C5's per-GPU share (SMPL-X
     arm mesh at 1024x1024, 32 frames / GPU).  Graph-replayed steps, barrier-free single GPU, synthetic targets rendered by the engine."""
@@ -186,7 +186,48 @@ def extra_rates(eng, device, steps=12, warmup=4):
     out["C5_arm_1024_per_gpu_share"] = dict(rate(e), mesh="SMPL-X right arm 4083v/8128f, kinematic-tree LBS")
     del e
     torch.cuda.empty_cache()
+    if vgg_weights is not None:
+        out["C3_with_perceptual_term"] = perceptual_rate(device, vgg_weights)
     return out
+
+
+# VGG16 features[0:23] at 512x512: 3x3 convolutions (Cin, Cout, H) -> 2 * 9 * Cin * Cout * H * H flop each
+_VGG_CONVS = ((3, 64, 512), (64, 64, 512), (64, 128, 256), (128, 128, 256), (128, 256, 128), (256, 256, 128), (256, 256, 128), (256, 512, 64),
+              (512, 512, 64), (512, 512, 64))
+
+
+def perceptual_rate(device, weights, steps=6, warmup=2):
+    """The same step with the reference's default VGG feature term on (optimize_sequence.py:404-405, 419, 546-547):
+    torch / MIOpen fp32 convolutions and their autograd, captured into the step's hipGraph next to the HIP launches.  Target features
+    are cached in HBM (the targets do not change during a fit), so a step is one VGG forward + one backward-data pass over the B
+    rendered images.  weights: "random" (seeded filters: the timing does not depend on the values) or the path of a torchvision vgg16
+    state dict.  The convolution rate is priced against the dense fp32 MFMA peak (157.3 TFLOP/s, MI355X_MICROARCH.md)."""
+    from harp_amd.model.vgg import Vgg16Features
+    e = build_engine(0, 1, device, T=B_PER_GPU, img=S, B=B_PER_GPU)[0]
+    e.keep_image = False
+    t0 = time.perf_counter()
+    e.set_perceptual(Vgg16Features(layers_weights=[1, 1 / 16, 1 / 8, 1 / 4, 1], weights=weights))
+    torch.cuda.synchronize()
+    t_set = time.perf_counter() - t0
+    e.set_schedule(torch.arange(B_PER_GPU).reshape(1, -1).to(torch.int32))
+    for _ in range(warmup):
+        e.step(None, True, True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        e.step(None, True, True)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    fwd = sum(2.0 * 9 * ci * co * h * h for ci, co, h in _VGG_CONVS) * B_PER_GPU
+    flop = 2.0 * fwd                                   # forward + backward-data (the filters are frozen: no weight gradients)
+    res = {"frames_per_s": B_PER_GPU / dt, "ms_per_step": dt * 1e3, "frames_per_step": B_PER_GPU, "steps": steps,
+           "filters": "random (seeded)" if weights == "random" else os.path.basename(str(weights)), "in_hipgraph": bool(e._graphs),
+           "conv_tflop_per_step": flop / 1e12, "conv_tflops": flop / dt / 1e12, "fp32_mfma_peak_tflops": 157.3,
+           "frac_of_fp32_mfma_peak": flop / dt / 157.3e12, "set_up_s(MIOpen search + target features)": t_set,
+           "vgg_loss": e.losses().get("vgg")}
+    del e
+    torch.cuda.empty_cache()
+    return res
 
 
 def cpu_baseline(seed=0):
@@ -264,6 +305,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the rates of the other configurations (keep_image, B=18, C5 arm 1024)")
+    ap.add_argument("--vgg-weights", default="random", help="filters of the perceptual-term entry of `extras`: 'random' (default, timing only), "
+                    "'none' (skip the entry) or the path of torchvision's vgg16 state dict (vgg16-397923af.pth)")
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -389,7 +432,7 @@ def main():
                            "kernel_ms": kt, "per_kernel": per_kernel, "step_algorithmic_bytes": a_frame * eng.B + a_step,
                            "step_frac_of_hbm_roofline": (a_frame * eng.B + a_step) / (dt / args.steps) / 1e9 / HBM_PEAK_GBS}
         if not args.no_extras:
-            out["extras"] = extra_rates(eng, device)
+            out["extras"] = extra_rates(eng, device, vgg_weights=None if args.vgg_weights == "none" else args.vgg_weights)
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
     if rank == 0:

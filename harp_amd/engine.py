@@ -173,6 +173,7 @@ class FitEngine:
         self._early_work = None
         self._loss_cleared = False
         self.perceptual = None           # optional VGG feature term of the appearance stage (set_perceptual)
+        self.graph_perceptual = True
         self.compute_reference_mesh()
 
     # ------------------------------------------------------------------------------------------------
@@ -506,12 +507,15 @@ class FitEngine:
     # ---- optional perceptual term (optimize_sequence.py:405, 546-547) -------------------------------
     def set_perceptual(self, vgg, weight=1.0, cache_bytes=64 << 30, autocast=None):
         """Add `weight * L1(vgg(y_pred * mask), vgg(y_true * mask))` to the appearance stage.  `vgg`: harp_amd.model.vgg.Vgg16Features
-        (None removes the term).  The convolutions are torch / MIOpen library calls with autograd, so steps run eagerly (no hipGraph)
-        while the term is on.  The target features do not change during a fit: when they fit `cache_bytes` for all resident frames
+        (None removes the term).  The convolutions are torch / MIOpen library calls with autograd; they are captured into the
+        step's hipGraph together with the HIP launches (`graph_perceptual = False` falls back to eager steps).  The target features do not change during a fit: when they fit `cache_bytes` for all resident frames
         (123 floats per pixel, 126 MB per 512x512 frame — 256 frames are 32 GB of the 288 GB) they are computed once and kept in
         HBM, which removes one of the step's two VGG forward passes.  autocast: e.g. torch.bfloat16 to run the convolutions on the
         bf16 MFMA path (default None = fp32 like the reference)."""
         self.perceptual = None if vgg is None else vgg.to(self.dev).eval()
+        # the torch / MIOpen part (convolutions, autograd) is captured into the step's hipGraph like the HIP launches: the capture runs
+        # after a warm-up pass, so MIOpen's solver search is done and every tensor comes from the graph's private pool
+        self.graph_perceptual = True
         self.perceptual_weight = float(weight)
         self._vgg_autocast = autocast
         self._vgg_cache = None
@@ -542,8 +546,6 @@ class FitEngine:
     def _perceptual_term(self, B, ltfid, lloss):
         """torch autograd through the VGG stack for d(term)/d(y_pred); the result joins the photometric gradient the shader backward
         consumes (that buffer is only defined at covered pixels — the fused L1 writes nothing elsewhere — hence the where)."""
-        if torch.cuda.is_current_stream_capturing():
-            raise RuntimeError("the perceptual term cannot be captured into a hipGraph; step(..., use_graph=False)")
         s = self.s
         idx = ltfid[:B].long()
         m = self.y_sil_col[idx].unsqueeze(-1)
@@ -748,7 +750,7 @@ class FitEngine:
         fb = (lambda: (self._schedule_next(), fb0())) if scheduled else fb0
         dist_on = self._dist_on()
         graph_ok = (not dist_on) or self.comm is not None or self.graph_collectives
-        if not use_graph or n != self.B or not graph_ok or (app and self.perceptual is not None):
+        if not use_graph or n != self.B or not graph_ok or (app and self.perceptual is not None and not self.graph_perceptual):
             fb()
             self.allreduce()
             self.adam(coarse, app, tick=False)
@@ -757,7 +759,7 @@ class FitEngine:
         # graph recorded for another configuration
         gkey = (coarse, app, scheduled, self.keep_image, self.fused_loss, self.self_shadow, tuple(self.frozen), self.overlap, self.early_terms,
                 self.packed_texels, self.auto_draw, self.mesh_terms_first, self.camera_first, self.tail_side, self.fused_bwd, self.fused_chain, self.fused_front, dist_on, self.overlap_allreduce,
-                self.comm is not None)
+                self.comm is not None, self.perceptual is not None and app)
         g = self._graphs.get(gkey)
         if g is None:
             # warm-up on a side stream, then capture (torch's documented recipe)

@@ -542,12 +542,24 @@ def test_perceptual_term_gradients(sc):
         # depends on the convolution's summation order (MIOpen vs the CPU), hence a looser bound than for the other terms
         for k in ("texture", "normal_map", "light_positions", "amb_ratio", "pose", "cam", "shape"):
             assert rel(eng.grads[k].cpu(), P[k].grad) < 2e-2, (cached, k, rel(eng.grads[k].cpu(), P[k].grad))
-    # a full step with the term on runs eagerly and moves the appearance parameters
-    before = eng.params["texture"].clone()
-    eng.step(fid, False, True)
-    torch.cuda.synchronize()
-    assert not eng._graphs and (eng.params["texture"] - before).abs().max() > 0
-    assert torch.isfinite(eng.p_buf).all()
+    # full steps with the term on: captured into the step's hipGraph (torch / MIOpen convolutions and their autograd included) — same
+    # parameters as eager steps from the same state
+    eng.set_stage(False, True)
+    state = [t.clone() for t in (eng.p_buf, eng.m_buf, eng.v_buf, eng.hyper, eng.draw_counter)]
+    res = {}
+    for graph in (False, True):
+        for t, s0 in zip((eng.p_buf, eng.m_buf, eng.v_buf, eng.hyper, eng.draw_counter), state):
+            t.copy_(s0)
+        eng.graph_perceptual = graph
+        eng._graphs = {}
+        for _ in range(3):
+            eng.step(fid, False, True)
+        torch.cuda.synchronize()
+        assert bool(eng._graphs) == graph
+        res[graph] = eng.p_buf.clone()
+    assert torch.isfinite(res[True]).all() and (res[True] - state[0]).abs().max() > 0
+    d = (res[True] - res[False]).abs()
+    assert d.mean().item() < 1e-6 and (d > 1e-3).float().mean().item() < 1e-4, (d.mean().item(), d.max().item())
 
 
 def test_loss_only_shading_matches_image_mode(sc):
