@@ -331,6 +331,9 @@ __device__ __forceinline__ void raster_tile(RasterSmem<MODE>& sm, unsigned vbloc
         }
         const float e0s = e0 * sg, e1s = e1 * sg, e2s = e2 * sg;
         const bool inside = (e0s > 0.f) && (e1s > 0.f) && (e2s > 0.f);
+#if defined(RASTER_ABLATE) && (RASTER_ABLATE & 4)
+        if (px == 12345.f)     // ablation (timing only, -DRASTER_ABLATE=4): classification runs, nothing is ever queued -> no drains
+#endif
         if (MODE != 2 && inside && inbox) { hq |= (unsigned)j << (8 * hn); ++hn; }
         if (MODE >= 1) {
           bool soft = (MODE == 1) ? (inbox && prod != 0.f) : (inbox && need);
@@ -353,6 +356,9 @@ __device__ __forceinline__ void raster_tile(RasterSmem<MODE>& sm, unsigned vbloc
               const float Bf = blur * 1.00001f;
               if ((e0s < 0.f && e0 * e0 >= Bf * l12) || (e1s < 0.f && e1 * e1 >= Bf * l20) || (e2s < 0.f && e2 * e2 >= Bf * l01)) soft = false;
             }
+#if defined(RASTER_ABLATE) && (RASTER_ABLATE & 4)
+            if (px == 12345.f)
+#endif
             if (soft) { sq |= (unsigned long long)j << (8 * sn); ++sn; }
           }
         }
