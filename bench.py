@@ -362,10 +362,39 @@ def main():
         eng.step(None, True, True, use_graph=not args.no_graph)
     sync()
     dt = time.perf_counter() - t0
+    dt_local = dt
     if world > 1 or force_dist:
         tmax = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+    per_rank_ms, allreduce = None, None
+    if world > 1 or force_dist:
+        tmax = torch.tensor([dt_local], device=device, dtype=torch.float64)
+        allt = [torch.zeros_like(tmax) for _ in range(world)]
+        dist.all_gather(allt, tmax)
+        per_rank_ms = [float(t.item()) / args.steps * 1e3 for t in allt]
+        # the collective on its own (outside the timed region): the flat gradient bucket, K back-to-back all-reduces on one stream
+        bucket = eng.g_buf[eng.opt_span[0]:eng.opt_span[0] + eng.opt_span[1]]
+        K = 20
+        def one():
+            if comm is not None:
+                comm.allreduce(bucket)
+            else:
+                dist.all_reduce(bucket)
+        for _ in range(3):
+            one()
+        sync()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(K):
+            one()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / K
+        nbytes = eng.opt_span[1] * 4
+        allreduce = {"ms": ms, "bytes": nbytes, "algbw_GBps": nbytes / ms / 1e6,
+                     "busbw_GBps": nbytes / ms / 1e6 * 2 * (world - 1) / world, "note": "flat gradient bucket alone, back to back; in the step "
+                     "the texture / normal-map part runs under the mesh + hand-layer backward"}
     losses = eng.losses()
     finite = all(np.isfinite(v) for v in losses.values())
     consistent = None
@@ -394,6 +423,9 @@ def main():
            "losses_finite": finite}
     if consistent is not None:
         out["ranks_consistent"] = consistent
+    if per_rank_ms is not None:
+        out["per_rank_ms_per_step"] = per_rank_ms
+        out["allreduce"] = allreduce
     if shared_gpu or backend != "nccl":
         out["invalid_timing"] = f"development run: backend={backend}, all ranks on one GPU={shared_gpu}"
     if rank == 0 and world == 1:
