@@ -70,6 +70,8 @@ struct RasterSmem {
   float4 s_fc[MODE == 1 ? kStage : 1];      // per staged face: sign of the area, squared edge lengths l12, l20, l01
   int32_t s_id[kStage];
   int lds_cnt[4];
+  unsigned long long zkey[MODE == 0 ? 256 : 1];   // face-scan walk (MODE 0): per pixel min over (depth bits << 32 | face id)
+  float ndc_x[kTile], ndc_y[kTile];               // pixel-centre NDC of the tile's columns / rows (pix_to_ndc holds an IEEE division)
   // MODE 2: per-staged-face gradient accumulators (x,y of 3 verts).  double: ds_add_f64 is ~20x faster than ds_add_f32 on gfx950
   double s_g[MODE == 2 ? kStage : 1][6];
   float red[4];
@@ -244,6 +246,16 @@ __device__ __forceinline__ void raster_tile(RasterSmem<MODE>& sm, unsigned vbloc
     }
   };
 
+#ifndef RASTER_NO_SCAN
+  constexpr bool kScan = (MODE == 0);
+#else
+  constexpr bool kScan = false;
+#endif
+  if (kScan) {                                  // (the first barrier of the staging below orders these before their first use)
+    sm.zkey[threadIdx.x] = ~0ull;
+    if (threadIdx.x < kTile) sm.ndc_x[threadIdx.x] = pix_to_ndc(tx0 + threadIdx.x, S);
+    else if (threadIdx.x < 2 * kTile) sm.ndc_y[threadIdx.x - kTile] = pix_to_ndc(ty0 + threadIdx.x - kTile, S);
+  }
   for (int base = 0; base < n; base += kStage) {
     // ---- stage: filter this round's list entries against the 16x16 tile, compact into LDS
     const int e = base + threadIdx.x;
@@ -275,6 +287,55 @@ __device__ __forceinline__ void raster_tile(RasterSmem<MODE>& sm, unsigned vbloc
       for (int c = 0; c < 6; ++c) s_g[threadIdx.x][c] = 0.0;
     }
     __syncthreads();
+    if constexpr (kScan) {
+      // ---- face scan (hard K = 1 pass): a 16-lane group owns one staged face at a time and visits only the pixels of its bbox, as
+      //      4x4 blocks; the nearest face of a pixel is a 64-bit LDS min over (depth bits, face id) — the same (pixel, face) pairs,
+      //      the same depth expression and the same tie-break (lower id) as the strip walk below, where every face of a strip's hit
+      //      list was classified by all 64 lanes of the strip (~8 % of them inside its bbox).
+      const int grp = threadIdx.x >> 4, gl = threadIdx.x & 15, lx = gl & 3, ly = gl >> 2;
+      const float hs = 0.5f * (float)S;
+      for (int k0 = 0; k0 < nl; k0 += 16) {
+        const int k = k0 + grp;
+        const bool valid = k < nl;
+        const int kk = valid ? k : 0;
+        const float4 q = s_bb[kk];
+        // pixel-centre columns / rows that can lie in the bbox (pixel coordinate of NDC n: (1 - n) S / 2 - 1/2; 1e-3 px of slack,
+        // the exact comparison below decides), clipped to the tile
+        const int x0 = max((int)ceilf((1.0f - q.y) * hs - 0.501f), tx0), x1 = min(min((int)floorf((1.0f - q.x) * hs - 0.499f), tx0 + kTile - 1), S - 1);
+        const int y0 = max((int)ceilf((1.0f - q.w) * hs - 0.501f), ty0), y1 = min(min((int)floorf((1.0f - q.z) * hs - 0.499f), ty0 + kTile - 1), S - 1);
+        bool more = valid && x0 <= x1 && y0 <= y1;
+        if (!__any(more)) continue;
+        const Tri t = tri_from(s_a[kk], s_b[kk], make_float4(s_z2[kk], 0.f, 0.f, 0.f));
+        const int fid = s_id[kk];
+        const float area = edge_fn(t.x2, t.y2, t.x0, t.y0, t.x1, t.y1) + kEps;
+        const float sg = (area > 0.f) ? 1.f : ((area < 0.f) ? -1.f : 0.f);
+        const float ra = __builtin_amdgcn_rcpf(area);
+        int bx = x0, by = y0;
+        while (__any(more)) {
+          if (more) {
+            const int xs = bx + lx, ys = by + ly;
+            if (xs <= x1 && ys <= y1) {
+              const float qx = sm.ndc_x[xs - tx0], qy = sm.ndc_y[ys - ty0];
+              const bool inbox = !(qx > q.y || qx < q.x || qy > q.w || qy < q.z);
+              const float e0 = edge_fn(qx, qy, t.x1, t.y1, t.x2, t.y2);
+              const float e1 = edge_fn(qx, qy, t.x2, t.y2, t.x0, t.y0);
+              const float e2 = edge_fn(qx, qy, t.x0, t.y0, t.x1, t.y1);
+              if (inbox && (e0 * sg > 0.f) && (e1 * sg > 0.f) && (e2 * sg > 0.f)) {
+                // BarycentricCoordsForward + PerspectiveCorrection with reciprocals (<= 2 ulp from the IEEE-division form)
+                const float t0 = (e0 * ra) * t.z1 * t.z2, t1 = t.z0 * (e1 * ra) * t.z2, t2 = t.z0 * t.z1 * (e2 * ra);
+                const float rd = __builtin_amdgcn_rcpf(fmaxf(t0 + t1 + t2, kEps));
+                const float pz = (t0 * rd) * t.z0 + (t1 * rd) * t.z1 + (t2 * rd) * t.z2;
+                if (pz >= 0.f && pz < 3.0e38f)
+                  atomicMin(&sm.zkey[(ys - ty0) * kTile + (xs - tx0)], ((unsigned long long)__float_as_uint(pz) << 32) | (unsigned)fid);
+              }
+            }
+            bx += 4;
+            if (bx > x1) { bx = x0; by += 4; }
+            more = by <= y1;
+          }
+        }
+      }
+    } else
     // ---- walk: each wave ballots the staged faces against its 16x4 strip
     for (int g = 0; g < nl; g += 64) {
       const int i = g + lane;
@@ -384,6 +445,11 @@ __device__ __forceinline__ void raster_tile(RasterSmem<MODE>& sm, unsigned vbloc
     __syncthreads();
   }
 
+  if constexpr (kScan) {
+    // (the last round ended with a barrier) pixel of this lane = tile-local index threadIdx.x
+    const unsigned long long key = sm.zkey[threadIdx.x];
+    if (key != ~0ull) { best_f = (int)(unsigned)(key & 0xffffffffull); best_z = __uint_as_float((unsigned)(key >> 32)); }
+  }
   float l1_acc = 0.f;
   if (MODE != 2 && in_img) {
     const size_t o = ((size_t)b * S + yi) * S + xi;

@@ -36,6 +36,34 @@ def rel(a, b):
     return ((a - b).norm() / (b.norm() + 1e-30)).item()
 
 
+def ambiguous_pixels(P, model, topo, S, focal, fid, y_true=None, use_arm=False, self_shadow=True):
+    """(len(fid),S,S) bool: covered pixels whose colour is NOT decided at float32 precision (see mask_ambiguous_pixels), flagged by the
+    oracle's float64 forward pass for the parameters P (any dtype; evaluated in float64)."""
+    f64 = lambda d: {k: (v.detach().double() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in d.items()}
+    P64, model64 = f64(P), f64(model)
+    fid = torch.as_tensor(fid)
+    with torch.no_grad():
+        _, verts = H.prepare_mesh(P64, fid, model64, topo, use_arm=use_arm)
+        img, aux = H.render_rgb(verts, topo, P64, P64["cam"][fid], S, focal, self_shadow=self_shadow, return_aux=True, flag_ambiguous=True)
+    amb = aux["ambiguous"]
+    if y_true is not None:      # kink of the L1 photometric term: |y_pred - y_true| below what float32 resolves flips the sign of a channel's gradient
+        amb = amb | ((img - y_true[fid].double()).abs() < 3e-4).any(-1)
+    return amb & (aux["pix_to_face"][..., 0] >= 0), aux
+
+
+def mask_scene_targets(sc, params, fid):
+    """make_scene targets with the ambiguous pixels of frames `fid` (under `params`) taken out of the photometric mask: returns a new
+    targets dict and the fraction of covered pixels removed"""
+    P = oracle_params(sc, params)
+    amb, aux = ambiguous_pixels(P, sc["model"], sc["topo"], sc["S"], sc["focal"], fid, sc["targets"]["y_true"])
+    tg = dict(sc["targets"])
+    col = tg["y_sil_col"].clone()
+    for i, f in enumerate(torch.as_tensor(fid).tolist()):
+        col[f][amb[i]] = 0.0
+    tg["y_sil_col"] = col
+    return tg, amb.sum().item() / max((aux["pix_to_face"][..., 0] >= 0).sum().item(), 1)
+
+
 # ----------------------------------------------------------------------------------------------------------------------
 # Fit cases at the BASELINE.json sizes: an engine on the GPU + everything the fp64 oracle needs for the same inputs.
 # ----------------------------------------------------------------------------------------------------------------------
@@ -195,14 +223,8 @@ def mask_ambiguous_pixels(case):
     eng = case["eng"]
     P, model, targets = oracle_inputs(case, torch.float64)
     fid = torch.arange(case["T"])
-    with torch.no_grad():
-        _, verts = H.prepare_mesh(P, fid, model, case["topo"], use_arm=case["kind"] == "arm")
-        _, aux = H.render_rgb(verts, case["topo"], P, P["cam"][fid], case["S"], case["focal"], self_shadow=eng.self_shadow, return_aux=True,
-                              flag_ambiguous=True)
-    img = _
-    # kink of the L1 photometric term: |y_pred - y_true| below what float32 resolves flips the sign of a channel's gradient
-    kink = ((img - targets["y_true"][fid]).abs() < 3e-4).any(-1)
-    amb = (aux["ambiguous"] | kink) & (aux["pix_to_face"][..., 0] >= 0)
+    amb, aux = ambiguous_pixels(P, model, case["topo"], case["S"], case["focal"], fid, targets["y_true"], use_arm=case["kind"] == "arm",
+                                self_shadow=eng.self_shadow)
     cov = (aux["pix_to_face"][..., 0] >= 0).sum().item()
     y_col = case["targets"]["y_sil_col"].clone()
     y_col[amb] = 0.0

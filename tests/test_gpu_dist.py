@@ -54,7 +54,7 @@ def test_two_ranks_equal_one_rank_global_batch(tmp_path):
             assert rel(a, b) < 1e-3, (k, rel(a, b))
     # loss values: rank 0 reports the mean over ITS frames for the image terms; the regularisers are rank-independent
     for i in (2, 7, 8):                                      # vert_disp_reg, albedo, normal_reg
-        assert abs(two["loss0"][i] - one["loss0"][i]) <= 1e-6 * abs(one["loss0"][i])
+        assert abs(two["loss0"][i] - one["loss0"][i]) <= 1e-5 * abs(one["loss0"][i])      # float32 sums of per-workgroup partials, atomics order
     # parameters after 3 steps (Adam's first steps are sign-like: bound the mean and the outlier fraction like the single-GPU tests)
     p2, p1 = two["params"].double(), one["params"].double()
     for k, (o, n) in two["offsets"].items():

@@ -29,6 +29,6 @@ else:
             if suf == ".sparse" and k in ("face_c", "alpha", "g_alpha", "face_l"):
                 continue                      # unwritten in empty super-tiles
             if x.dtype == torch.float32:
-                print(suf, "%-8s bit-identical %s  max|d| %.3e" % (k, torch.equal(x.view(torch.int32), y.view(torch.int32)), (x - y).abs().max().item()))
+                print(suf, "%-8s bit-identical %s  max|d| %.3e  differing %d of %d" % (k, torch.equal(x.view(torch.int32), y.view(torch.int32)), (x - y).abs().max().item(), (x != y).sum().item(), x.numel()))
             else:
-                print(suf, "%-8s identical %s" % (k, torch.equal(x, y)))
+                print(suf, "%-8s identical %s  mismatches %d of %d" % (k, torch.equal(x, y), (x != y).sum().item(), x.numel()))
