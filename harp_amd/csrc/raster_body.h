@@ -72,6 +72,10 @@ struct RasterSmem {
   int lds_cnt[4];
   unsigned long long zkey[MODE == 0 ? 256 : 1];   // face-scan walk (MODE 0): per pixel min over (depth bits << 32 | face id)
   float ndc_x[kTile], ndc_y[kTile];               // pixel-centre NDC of the tile's columns / rows (pix_to_ndc holds an IEEE division)
+  // pixel-centric pair walk (MODE 2): the tile's rim pixels (coordinates, P = 1 - alpha, upstream gradient), compacted, and the
+  // (rim pixel, staged face) pairs whose pixel lies in the face's bbox
+  float rp_x[MODE == 2 ? 256 : 1], rp_y[MODE == 2 ? 256 : 1], rp_P[MODE == 2 ? 256 : 1], rp_g[MODE == 2 ? 256 : 1];
+  unsigned short pairs[MODE == 2 ? 512 : 1];      // 4 waves x 128-entry ring
   // MODE 2: per-staged-face gradient accumulators (x,y of 3 verts).  double: ds_add_f64 is ~20x faster than ds_add_f32 on gfx950
   double s_g[MODE == 2 ? kStage : 1][6];
   float red[4];
@@ -173,6 +177,16 @@ __device__ __forceinline__ void raster_tile(RasterSmem<MODE>& sm, unsigned vbloc
     need = in_img && (P != 0.f) && (ga != 0.f);
     // whole tile saturated / no upstream gradient -> nothing to do
     if (__syncthreads_or(need ? 1 : 0) == 0) return;
+  }
+#ifndef RASTER_NO_SCAN
+  constexpr bool kPix = (MODE == 2);
+#else
+  constexpr bool kPix = false;
+#endif
+  int npx = 0;
+  if constexpr (kPix) {
+    const int slot = block_compact(need, 0, lds_cnt, npx);
+    if (slot >= 0) { sm.rp_x[slot] = px; sm.rp_y[slot] = py; sm.rp_P[slot] = P; sm.rp_g[slot] = ga; }
   }
 
   const float inv_sigma = 1.0f / sigma;
@@ -335,6 +349,86 @@ __device__ __forceinline__ void raster_tile(RasterSmem<MODE>& sm, unsigned vbloc
           }
         }
       }
+    } else if constexpr (kPix) {
+      // ---- pair walk (silhouette backward): only the tile's rim pixels (P != 0 and an upstream gradient: ~20 of 256) take part.
+      //      Phase 1 tests every (rim pixel, staged face) pair against the face's bbox, one pair per lane, and compacts the ~4 hits
+      //      per pixel into an LDS list; phase 2 does the distance / sigmoid / gradient arithmetic of the strip walk below on that
+      //      list, one pair per lane, every lane busy.  (The strip walk classified each face of a strip's hit list on all 64 lanes.)
+      const int npairs = npx * nl;
+      const float inv_nl = 1.0f / (float)nl;
+      // every wave walks its own quarter of the pairs and keeps its own hit list (a 128-entry ring in LDS, head / tail in SGPRs):
+      // no barrier and no atomic between the two phases — a wave only reads back what it wrote, and LDS operations of a wave are in order
+      unsigned short* wl = sm.pairs + w * 128;
+      const int per = (npairs + 3) >> 2, i_end = min(npairs, (w + 1) * per);
+      int head = 0, tail = 0;
+      auto process = [&](int nvalid) {
+        if (lane < nvalid) {
+          const int pr = wl[(head + lane) & 127], c = pr >> 8, j = pr & 255;
+          const float qx = sm.rp_x[c], qy = sm.rp_y[c], Pq = sm.rp_P[c], gq = sm.rp_g[c];
+          const Tri t = tri_from(s_a[j], s_b[j], make_float4(0.f, 0.f, 0.f, 0.f));
+          const float e0 = edge_fn(qx, qy, t.x1, t.y1, t.x2, t.y2);
+          const float e1 = edge_fn(qx, qy, t.x2, t.y2, t.x0, t.y0);
+          const float e2 = edge_fn(qx, qy, t.x0, t.y0, t.x1, t.y1);
+          const float area = edge_fn(t.x2, t.y2, t.x0, t.y0, t.x1, t.y1) + kEps;
+          const float sg = (area > 0.f) ? 1.f : ((area < 0.f) ? -1.f : 0.f);
+          const float e0s = e0 * sg, e1s = e1 * sg, e2s = e2 * sg;
+          const bool inside = (e0s > 0.f) && (e1s > 0.f) && (e2s > 0.f);
+          const float l12 = (t.x2 - t.x1) * (t.x2 - t.x1) + (t.y2 - t.y1) * (t.y2 - t.y1);
+          const float l20 = (t.x0 - t.x2) * (t.x0 - t.x2) + (t.y0 - t.y2) * (t.y0 - t.y2);
+          const float l01 = (t.x1 - t.x0) * (t.x1 - t.x0) + (t.y1 - t.y0) * (t.y1 - t.y0);
+          bool soft = true;
+          if (inside) {
+            const float K = 18.0f * sigma;               // saturated: the factor (1 - p) is exactly 0 and so is its gradient
+            if (e0 * e0 > K * l12 && e1 * e1 > K * l20 && e2 * e2 > K * l01) soft = false;
+          } else {
+            const float Bf = blur * 1.00001f;            // beyond the blur radius of a violated edge line
+            if ((e0s < 0.f && e0 * e0 >= Bf * l12) || (e1s < 0.f && e1 * e1 >= Bf * l20) || (e2s < 0.f && e2 * e2 >= Bf * l01)) soft = false;
+          }
+          if (soft) {
+            float ta, tb, tc;
+            const float d01 = seg_dist2(qx, qy, t.x0, t.y0, t.x1, t.y1, ta);
+            const float d02 = seg_dist2(qx, qy, t.x0, t.y0, t.x2, t.y2, tb);
+            const float d12 = seg_dist2(qx, qy, t.x1, t.y1, t.x2, t.y2, tc);
+            const float dist = fminf(d01, fminf(d02, d12));
+            if (inside || dist < blur) {
+              const float sd = inside ? -dist : dist;
+              const float p = __builtin_amdgcn_rcpf(1.0f + __expf(sd * inv_sigma));
+              // d alpha / d sd = -P * p / sigma  (P = prod over all faces)
+              const float g_sd = gq * (-Pq * p * inv_sigma);
+              const float gd = inside ? -g_sd : g_sd;     // d/d(dist^2)
+              // PointLineDistanceBackward on the argmin edge (t treated as constant)
+              int ia, ib; float ax, ay, bx, by, tt;
+              if (d01 <= d02 && d01 <= d12) { ia = 0; ib = 1; ax = t.x0; ay = t.y0; bx = t.x1; by = t.y1; tt = ta; }
+              else if (d02 <= d12)          { ia = 0; ib = 2; ax = t.x0; ay = t.y0; bx = t.x2; by = t.y2; tt = tb; }
+              else                          { ia = 1; ib = 2; ax = t.x1; ay = t.y1; bx = t.x2; by = t.y2; tt = tc; }
+              const float hx = ax + tt * (bx - ax), hy = ay + tt * (by - ay);
+              const float cx = gd * 2.f * (hx - qx), cy = gd * 2.f * (hy - qy);
+              atomicAdd(&s_g[j][2 * ia], (double)((1.f - tt) * cx));
+              atomicAdd(&s_g[j][2 * ia + 1], (double)((1.f - tt) * cy));
+              atomicAdd(&s_g[j][2 * ib], (double)(tt * cx));
+              atomicAdd(&s_g[j][2 * ib + 1], (double)(tt * cy));
+            }
+          }
+        }
+      };
+      for (int i0 = w * per; i0 < i_end; i0 += 64) {
+        const int i = i0 + lane;
+        bool pass = false;
+        int c = 0, k = 0;
+        if (i < i_end) {
+          c = (int)(((float)i + 0.5f) * inv_nl);
+          k = i - c * nl;
+          if (k < 0) { --c; k += nl; } else if (k >= nl) { ++c; k -= nl; }
+          const float4 q = s_bb[k];
+          const float qx = sm.rp_x[c], qy = sm.rp_y[c];
+          pass = !(qx > q.y || qx < q.x || qy > q.w || qy < q.z);
+        }
+        const unsigned long long m = __ballot(pass);
+        if (pass) wl[(tail + __popcll(m & ((1ull << lane) - 1ull))) & 127] = (unsigned short)((c << 8) | k);
+        tail += __popcll(m);
+        if (tail - head >= 64) { process(64); head += 64; }
+      }
+      if (tail > head) process(tail - head);
     } else
     // ---- walk: each wave ballots the staged faces against its 16x4 strip
     for (int g = 0; g < nl; g += 64) {
