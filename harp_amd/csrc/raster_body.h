@@ -67,15 +67,24 @@ template <int MODE>
 struct RasterSmem {
   float4 s_a[kStage], s_b[kStage], s_bb[kStage];
   float s_z2[kStage];
-  float4 s_fc[MODE == 1 ? kStage : 1];      // per staged face: sign of the area, squared edge lengths l12, l20, l01
+#ifndef RASTER_NO_SCAN
+  float4 s_fc[1];
+#else
+  float4 s_fc[MODE == 1 ? kStage : 1];      // (strip walk) per staged face: sign of the area, squared edge lengths l12, l20, l01
+#endif
   int32_t s_id[kStage];
   int lds_cnt[4];
-  unsigned long long zkey[MODE == 0 ? 256 : 1];   // face-scan walk (MODE 0): per pixel min over (depth bits << 32 | face id)
+  unsigned long long zkey[MODE <= 1 ? 256 : 1];   // face-scan walk (MODE 0 / 1): per pixel min over (depth bits << 32 | face id)
+  // MODE 1, soft silhouette: sat = some face covers the pixel deeper than the sigmoid's float32 range (alpha = 1 exactly);
+  // prodl = running product of (1 - p) over the other faces within the blur radius, in ascending face order; cand = pixels not (yet) saturated
+  int sat[MODE == 1 ? 256 : 1];
+  float prodl[MODE == 1 ? 256 : 1];
+  unsigned char cand[MODE == 1 ? 256 : 1];
   float ndc_x[kTile], ndc_y[kTile];               // pixel-centre NDC of the tile's columns / rows (pix_to_ndc holds an IEEE division)
   // pixel-centric pair walk (MODE 2): the tile's rim pixels (coordinates, P = 1 - alpha, upstream gradient), compacted, and the
   // (rim pixel, staged face) pairs whose pixel lies in the face's bbox
   float rp_x[MODE == 2 ? 256 : 1], rp_y[MODE == 2 ? 256 : 1], rp_P[MODE == 2 ? 256 : 1], rp_g[MODE == 2 ? 256 : 1];
-  unsigned short pairs[MODE == 2 ? 512 : 1];      // 4 waves x 128-entry ring
+  unsigned short pairs[MODE >= 1 ? 512 : 1];      // 4 waves x 128-entry ring of (pixel, staged face) pairs
   // MODE 2: per-staged-face gradient accumulators (x,y of 3 verts).  double: ds_add_f64 is ~20x faster than ds_add_f32 on gfx950
   double s_g[MODE == 2 ? kStage : 1][6];
   float red[4];
@@ -261,32 +270,21 @@ __device__ __forceinline__ void raster_tile(RasterSmem<MODE>& sm, unsigned vbloc
   };
 
 #ifndef RASTER_NO_SCAN
-  constexpr bool kScan = (MODE == 0);
+  constexpr bool kScan = (MODE <= 1);
 #else
   constexpr bool kScan = false;
 #endif
   if (kScan) {                                  // (the first barrier of the staging below orders these before their first use)
     sm.zkey[threadIdx.x] = ~0ull;
+    if (MODE == 1) { sm.sat[threadIdx.x] = 0; sm.prodl[threadIdx.x] = 1.0f; }
     if (threadIdx.x < kTile) sm.ndc_x[threadIdx.x] = pix_to_ndc(tx0 + threadIdx.x, S);
     else if (threadIdx.x < 2 * kTile) sm.ndc_y[threadIdx.x - kTile] = pix_to_ndc(ty0 + threadIdx.x - kTile, S);
   }
-  for (int base = 0; base < n; base += kStage) {
-    // ---- stage: filter this round's list entries against the 16x16 tile, compact into LDS
-    const int e = base + threadIdx.x;
-    bool hit = false;
-    int id = 0;
-    float4 bb;
-    if (e < n) {
-      id = list[e];
-      bb = bbb[id];          // contiguous 16-B bbox array (4 per 64-B line) instead of the 64-B-strided records
-      hit = !(t_xlo > bb.y || t_xhi < bb.x || t_ylo > bb.w || t_yhi < bb.z);
-    }
-    int nl;
-    const int pos = block_compact(hit, 0, lds_cnt, nl);
+  auto stage_write = [&](int pos, int id, const float4& bb) {
     if (pos >= 0) {
       const FaceRec r = rb[id];
       s_a[pos] = r.a; s_b[pos] = r.b; s_z2[pos] = r.c.x; s_bb[pos] = bb; s_id[pos] = id;
-      if (MODE == 1) {
+      if (MODE == 1 && !kScan) {
         // constants of the face that every (face, strip) classification below used to recompute on all 64 lanes
         const Tri t = tri_from(r.a, r.b, make_float4(0.f, 0.f, 0.f, 0.f));
         const float area = edge_fn(t.x2, t.y2, t.x0, t.y0, t.x1, t.y1) + kEps;
@@ -296,6 +294,37 @@ __device__ __forceinline__ void raster_tile(RasterSmem<MODE>& sm, unsigned vbloc
                                 (t.x1 - t.x0) * (t.x1 - t.x0) + (t.y1 - t.y0) * (t.y1 - t.y0));
       }
     }
+  };
+  // The super-tile's list is filtered against this 16x16 tile 256 entries at a time and the hits ACCUMULATE in the staging arrays:
+  // a walk runs when the next chunk would not fit, or at the end of the list — one walk per tile almost always (a tile sees 30 - 100
+  // of its super-tile's ~350 faces), instead of one per 256 list entries.
+  int staged = 0;
+  for (int base = 0; base < n || staged > 0;) {
+    bool flush = true;
+    if (base < n) {
+      // ---- stage: filter this chunk's list entries against the tile, compact into LDS behind what is already staged
+      const int e = base + threadIdx.x;
+      bool hit = false;
+      int id = 0;
+      float4 bb;
+      if (e < n) {
+        id = list[e];
+        bb = bbb[id];          // contiguous 16-B bbox array (4 per 64-B line) instead of the 64-B-strided records
+        hit = !(t_xlo > bb.y || t_xhi < bb.x || t_ylo > bb.w || t_yhi < bb.z);
+      }
+      int cnt;
+      const int pos = block_compact(hit, staged, lds_cnt, cnt);
+      if (staged + cnt <= kStage) {
+        stage_write(pos, id, bb);
+        staged += cnt;
+        base += kStage;
+        flush = base >= n;
+      }
+    }
+    if (!flush) continue;
+    const int nl = staged;
+    staged = 0;
+    if (nl == 0) continue;
     if (MODE == 2) {
 #pragma unroll
       for (int c = 0; c < 6; ++c) s_g[threadIdx.x][c] = 0.0;
@@ -324,6 +353,10 @@ __device__ __forceinline__ void raster_tile(RasterSmem<MODE>& sm, unsigned vbloc
         const float area = edge_fn(t.x2, t.y2, t.x0, t.y0, t.x1, t.y1) + kEps;
         const float sg = (area > 0.f) ? 1.f : ((area < 0.f) ? -1.f : 0.f);
         const float ra = __builtin_amdgcn_rcpf(area);
+        const float K18 = 18.0f * sigma;
+        const float l12 = (t.x2 - t.x1) * (t.x2 - t.x1) + (t.y2 - t.y1) * (t.y2 - t.y1);
+        const float l20 = (t.x0 - t.x2) * (t.x0 - t.x2) + (t.y0 - t.y2) * (t.y0 - t.y2);
+        const float l01 = (t.x1 - t.x0) * (t.x1 - t.x0) + (t.y1 - t.y0) * (t.y1 - t.y0);
         int bx = x0, by = y0;
         while (__any(more)) {
           if (more) {
@@ -339,14 +372,108 @@ __device__ __forceinline__ void raster_tile(RasterSmem<MODE>& sm, unsigned vbloc
                 const float t0 = (e0 * ra) * t.z1 * t.z2, t1 = t.z0 * (e1 * ra) * t.z2, t2 = t.z0 * t.z1 * (e2 * ra);
                 const float rd = __builtin_amdgcn_rcpf(fmaxf(t0 + t1 + t2, kEps));
                 const float pz = (t0 * rd) * t.z0 + (t1 * rd) * t.z1 + (t2 * rd) * t.z2;
-                if (pz >= 0.f && pz < 3.0e38f)
-                  atomicMin(&sm.zkey[(ys - ty0) * kTile + (xs - tx0)], ((unsigned long long)__float_as_uint(pz) << 32) | (unsigned)fid);
+                const int pix = (ys - ty0) * kTile + (xs - tx0);
+                if (pz >= 0.f && pz < 3.0e38f) atomicMin(&sm.zkey[pix], ((unsigned long long)__float_as_uint(pz) << 32) | (unsigned)fid);
+                if (MODE == 1) {
+                  // deeper than sqrt(18 sigma) inside every edge LINE (<= segment distance): sigmoid saturates to exactly 1 in
+                  // fp32 (exp(-18) < 2^-24), so the factor (1-p) is exactly 0 — the pixel's alpha is 1 whatever the other faces do
+                  if (e0 * e0 > K18 * l12 && e1 * e1 > K18 * l20 && e2 * e2 > K18 * l01) sm.sat[pix] = 1;
+                }
               }
             }
             bx += 4;
             if (bx > x1) { bx = x0; by += 4; }
             more = by <= y1;
           }
+        }
+      }
+      if constexpr (MODE == 1) {
+        // ---- soft silhouette of the pixels no face saturates: pair walk over (candidate pixel, staged face), as in the backward pass.
+        //      A wave owns a contiguous quarter of the candidates, so a pixel's pairs stay in one wave, in ascending face order:
+        //      the factors of a 64-pair batch are multiplied into the pixel's running product by the first lane of the pixel's run,
+        //      one after the other — the same sequence of float multiplications as a sequential walk over the faces.
+        __syncthreads();                                   // saturation flags of this round are complete
+        int ncand;
+        const int slot = block_compact(in_img && sm.sat[threadIdx.x] == 0, 0, lds_cnt, ncand);
+        if (slot >= 0) sm.cand[slot] = (unsigned char)threadIdx.x;
+        __syncthreads();
+        if (ncand > 0) {
+          unsigned short* wl = sm.pairs + w * 128;
+          const int cper = (ncand + 3) >> 2, c_lo = min(ncand, w * cper), c_hi = min(ncand, (w + 1) * cper);
+          const int i_lo = c_lo * nl, i_end = c_hi * nl;
+          const float inv_nl = 1.0f / (float)nl;
+          int head = 0, tail = 0;
+          auto process = [&](int nvalid) {
+            float f = 1.0f;
+            int c = -1 - lane;                             // (distinct keys for idle lanes)
+            if (lane < nvalid) {
+              const int pr = wl[(head + lane) & 127], j = pr & 255;
+              c = pr >> 8;
+              const float qx = sm.ndc_x[c & (kTile - 1)], qy = sm.ndc_y[c >> 4];
+              const Tri t = tri_from(s_a[j], s_b[j], make_float4(0.f, 0.f, 0.f, 0.f));
+              const float e0 = edge_fn(qx, qy, t.x1, t.y1, t.x2, t.y2);
+              const float e1 = edge_fn(qx, qy, t.x2, t.y2, t.x0, t.y0);
+              const float e2 = edge_fn(qx, qy, t.x0, t.y0, t.x1, t.y1);
+              const float area = edge_fn(t.x2, t.y2, t.x0, t.y0, t.x1, t.y1) + kEps;
+              const float sg = (area > 0.f) ? 1.f : ((area < 0.f) ? -1.f : 0.f);
+              const float e0s = e0 * sg, e1s = e1 * sg, e2s = e2 * sg;
+              const bool inside = (e0s > 0.f) && (e1s > 0.f) && (e2s > 0.f);
+              const float l12 = (t.x2 - t.x1) * (t.x2 - t.x1) + (t.y2 - t.y1) * (t.y2 - t.y1);
+              const float l20 = (t.x0 - t.x2) * (t.x0 - t.x2) + (t.y0 - t.y2) * (t.y0 - t.y2);
+              const float l01 = (t.x1 - t.x0) * (t.x1 - t.x0) + (t.y1 - t.y0) * (t.y1 - t.y0);
+              bool soft = true;
+              if (!inside) {                               // outside: the triangle lies beyond the line of any violated edge, so dist >= that line distance
+                const float Bf = blur * 1.00001f;
+                if ((e0s < 0.f && e0 * e0 >= Bf * l12) || (e1s < 0.f && e1 * e1 >= Bf * l20) || (e2s < 0.f && e2 * e2 >= Bf * l01)) soft = false;
+              }
+              if (soft) {
+                float ta, tb, tc;
+                const float d01 = seg_dist2(qx, qy, t.x0, t.y0, t.x1, t.y1, ta);
+                const float d02 = seg_dist2(qx, qy, t.x0, t.y0, t.x2, t.y2, tb);
+                const float d12 = seg_dist2(qx, qy, t.x1, t.y1, t.x2, t.y2, tc);
+                const float dist = fminf(d01, fminf(d02, d12));
+                if (inside || dist < blur) {
+                  const float sd = inside ? -dist : dist;
+                  const float p = __builtin_amdgcn_rcpf(1.0f + __expf(sd * inv_sigma));   // sigmoid(-sd/sigma): fast exp + reciprocal (rel. error ~1e-6 at |x| ~ 18; image tolerance 1e-4)
+                  f = 1.0f - p;
+                }
+              }
+            }
+            const int cprev = __shfl_up(c, 1);
+            const bool first = (lane < nvalid) && (lane == 0 || cprev != c);
+            const unsigned long long fm = __ballot((lane >= nvalid) || lane == 0 || cprev != c);      // run starts (idle lanes are runs of their own)
+            int len = 0;
+            float pacc = 1.0f;
+            if (first) {
+              const unsigned long long above = (lane == 63) ? 0ull : (fm >> (lane + 1));
+              len = above ? __ffsll((unsigned long long)above) : 64 - lane;
+              pacc = sm.prodl[c];
+            }
+            for (int r = 0; __any(r < len); ++r) {
+              const float fr = __shfl(f, (lane + r) & 63);
+              if (r < len) pacc *= fr;
+            }
+            if (first) sm.prodl[c] = pacc;
+          };
+          for (int i0 = i_lo; i0 < i_end; i0 += 64) {
+            const int i = i0 + lane;
+            bool pass = false;
+            int c = 0, k = 0;
+            if (i < i_end) {
+              int ci = (int)(((float)i + 0.5f) * inv_nl);
+              k = i - ci * nl;
+              if (k < 0) { --ci; k += nl; } else if (k >= nl) { ++ci; k -= nl; }
+              c = sm.cand[ci];
+              const float4 q = s_bb[k];
+              const float qx = sm.ndc_x[c & (kTile - 1)], qy = sm.ndc_y[c >> 4];
+              pass = !(qx > q.y || qx < q.x || qy > q.w || qy < q.z);
+            }
+            const unsigned long long m = __ballot(pass);
+            if (pass) wl[(tail + __popcll(m & ((1ull << lane) - 1ull))) & 127] = (unsigned short)((c << 8) | k);
+            tail += __popcll(m);
+            if (tail - head >= 64) { process(64); head += 64; }
+          }
+          if (tail > head) process(tail - head);
         }
       }
     } else if constexpr (kPix) {
@@ -543,6 +670,7 @@ __device__ __forceinline__ void raster_tile(RasterSmem<MODE>& sm, unsigned vbloc
     // (the last round ended with a barrier) pixel of this lane = tile-local index threadIdx.x
     const unsigned long long key = sm.zkey[threadIdx.x];
     if (key != ~0ull) { best_f = (int)(unsigned)(key & 0xffffffffull); best_z = __uint_as_float((unsigned)(key >> 32)); }
+    if (MODE == 1) prod = sm.sat[threadIdx.x] ? 0.f : sm.prodl[threadIdx.x];
   }
   float l1_acc = 0.f;
   if (MODE != 2 && in_img) {
