@@ -50,7 +50,7 @@ __global__ void __launch_bounds__(1024) order_tiles_kernel(const int32_t* __rest
 }
 
 template <int MODE>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) raster_kernel(const FaceRec* __restrict__ recs, const float4* __restrict__ bbs,
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == 2 ? 5 : 7, 8))) raster_kernel(const FaceRec* __restrict__ recs, const float4* __restrict__ bbs,
                                                      const int32_t* __restrict__ bins,
                                                      const int32_t* __restrict__ bin_count, const int32_t* __restrict__ order,
                                                      const int32_t* __restrict__ nact, int B, int F, int S, int nsx,
