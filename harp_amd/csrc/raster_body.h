@@ -347,6 +347,9 @@ __device__ __forceinline__ void raster_tile(RasterSmem<MODE>& sm, unsigned vbloc
         const int x0 = max((int)ceilf((1.0f - q.y) * hs - 0.501f), tx0), x1 = min(min((int)floorf((1.0f - q.x) * hs - 0.499f), tx0 + kTile - 1), S - 1);
         const int y0 = max((int)ceilf((1.0f - q.w) * hs - 0.501f), ty0), y1 = min(min((int)floorf((1.0f - q.z) * hs - 0.499f), ty0 + kTile - 1), S - 1);
         bool more = valid && x0 <= x1 && y0 <= y1;
+#if defined(RASTER_ABLATE) && (RASTER_ABLATE & 256)
+        more = false;              // ablation (timing only): per-face prologue up to the pixel range only
+#endif
         if (!__any(more)) continue;
         const Tri t = tri_from(s_a[kk], s_b[kk], make_float4(s_z2[kk], 0.f, 0.f, 0.f));
         const int fid = s_id[kk];
@@ -361,6 +364,9 @@ __device__ __forceinline__ void raster_tile(RasterSmem<MODE>& sm, unsigned vbloc
         while (__any(more)) {
           if (more) {
             const int xs = bx + lx, ys = by + ly;
+#if defined(RASTER_ABLATE) && (RASTER_ABLATE & 128)
+            if (xs == 123456)      // ablation (timing only): face prologue and block loop run, no pixel is tested
+#endif
             if (xs <= x1 && ys <= y1) {
               const float qx = sm.ndc_x[xs - tx0], qy = sm.ndc_y[ys - ty0];
               const bool inbox = !(qx > q.y || qx < q.x || qy > q.w || qy < q.z);
