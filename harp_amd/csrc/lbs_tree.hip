@@ -135,7 +135,6 @@ __global__ void __launch_bounds__(256) tree_blend_mfma_kernel(const harp_tree_mo
   const bool row_ok = row < B;
   const int steps = (K + 3) / 4, per = (steps + 3) / 4;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 8
   for (int st = w * per; st < min(steps, (w + 1) * per); ++st) {
     const int k = 4 * st + (lane >> 4);
     float a = 0.f, bv = 0.f;
@@ -265,7 +264,6 @@ __global__ void __launch_bounds__(256) tree_gA_mfma_kernel(const harp_tree_model
   const float* gb = g_verts + (size_t)b * NV * 3;
   const float* pb = vp + (size_t)b * NV * 3;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 8
   for (int st = w * per; st < min(steps, (w + 1) * per); ++st) {
     const int v = 4 * st + (lane >> 4);
     float a = 0.f, bv = 0.f;
@@ -301,7 +299,6 @@ __global__ void __launch_bounds__(256) tree_gpm_mfma_kernel(const harp_tree_mode
   const int steps = (NV3 + 3) / 4, per_wg = (steps + kSplitP - 1) / kSplitP, per = (per_wg + 3) / 4;
   const int s_lo = blockIdx.z * per_wg + w * per, s_hi = min(min(steps, (int)(blockIdx.z + 1) * per_wg), s_lo + per);
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 8
   for (int st = s_lo; st < s_hi; ++st) {
     const int i = 4 * st + (lane >> 4);
     float a = 0.f, bv = 0.f;
