@@ -600,17 +600,24 @@ __global__ void __launch_bounds__(256) depth_bwd_kernel(const int32_t* __restric
                                                         const int32_t* __restrict__ order, const int32_t* __restrict__ nact,
                                                         int B, int nsx) {
   __shared__ VertexAccum<256, 3> s_acc;
+  // capped grid: a workgroup strides over the tiles of the super-tiles that hold faces (launch order).  The full grid is 16 workgroups
+  // per (frame, super-tile) — 32 768 at 512^2, 131 072 at 1024^2 — of which a sixth have work here, and this small kernel was as long
+  // as their dispatch (0.7 ns each: 24 us at 512^2, 107 us at 1024^2).  (The rasterisers keep the full grid: their tiles differ too much
+  // in cost for a static assignment, measured.)
+  const unsigned limit = (unsigned)(((nact[0] + 7) / 8) * 8 * (kSuper / kTile) * (kSuper / kTile));
+  for (unsigned vb = blockIdx.x; vb < limit; vb += gridDim.x) {
+  if (vb != blockIdx.x) __syncthreads();                 // s_acc of the previous tile has been flushed
   int b, st, tx0, ty0, tsub;
-  if (tile_decode(order, nact, B, nsx, S, b, st, tx0, ty0, tsub, false) != 1) return;   // no tile / super-tile without a single face
+  if (tile_decode_v(vb, order, nact, B, nsx, S, b, st, tx0, ty0, tsub, false) != 1) continue;   // no tile / super-tile without a single face
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int xi = tx0 + (lane & 15), yi = ty0 + w * 4 + (lane >> 4);
   const bool in_img = xi < S && yi < S;
   const size_t o = ((size_t)b * S + (in_img ? yi : 0)) * S + (in_img ? xi : 0);
   const int f = in_img ? face_id[o] : -1;
-  if (__syncthreads_or(f >= 0 ? 1 : 0) == 0) return;          // tile without faces: do not even read the gradient image
+  if (__syncthreads_or(f >= 0 ? 1 : 0) == 0) continue;        // tile without faces: do not even read the gradient image
   const float g = (f >= 0) ? g_z[o] : 0.f;
   const bool act = f >= 0 && g != 0.f;
-  if (__syncthreads_or(act ? 1 : 0) == 0) return;
+  if (__syncthreads_or(act ? 1 : 0) == 0) continue;
   s_acc.clear();
   __syncthreads();
   float* gdb = g_ndc + (size_t)b * V * 3;
@@ -641,6 +648,7 @@ __global__ void __launch_bounds__(256) depth_bwd_kernel(const int32_t* __restric
     if (v < 0) continue;
 #pragma unroll
     for (int c = 0; c < 3; ++c) if (s_acc.val[i][c] != 0) atomicAdd(gdb + 3 * v + c, (float)s_acc.val[i][c]);
+  }
   }
 }
 
@@ -714,7 +722,7 @@ int harp_depth_bwd(const int32_t* face_id, const void* ws, const int32_t* faces,
                    float* g_ndc, hipStream_t stream) {
   if (!face_id || !ws || !faces || !g_z || !g_ndc) return HARP_ERR_ARG;
   const RasterWs W = raster_ws_split((void*)ws, B, F, S);
-  hipLaunchKernelGGL(depth_bwd_kernel, dim3(tile_grid(B, W.nsx)), dim3(256), 0, stream, face_id, (const FaceRec*)ws, faces, g_z, V, F, S, g_ndc,
+  hipLaunchKernelGGL(depth_bwd_kernel, dim3(min(tile_grid(B, W.nsx), 4096u)), dim3(256), 0, stream, face_id, (const FaceRec*)ws, faces, g_z, V, F, S, g_ndc,
                      (const int32_t*)W.order, (const int32_t*)W.nact, B, W.nsx);
   HARP_CHECK_LAUNCH();
   return HARP_OK;
