@@ -45,7 +45,7 @@ __host__ __device__ inline RasterWs raster_ws_split(void* ws, int B, int F, int 
   return r;
 }
 // workgroups of the 1-D tile grid: launch-order slots rounded up to a multiple of 8 (one per XCD) x 16 tiles per super-tile
-inline unsigned tile_grid(int B, int nsx) { return (unsigned)(((B * nsx * nsx + 7) / 8) * 8 * (kSuper / kTile) * (kSuper / kTile)); }
+__host__ __device__ inline unsigned tile_grid(int B, int nsx) { return (unsigned)(((B * nsx * nsx + 7) / 8) * 8 * (kSuper / kTile) * (kSuper / kTile)); }
 // Decode a workgroup id of that grid: consecutive ids go round-robin over the 8 XCDs, so the 16 tiles of one super-tile (same bin
 // list, same face records, neighbouring pixels) stay on one XCD / one L2; slots follow the heaviest-first order.
 // Returns 0: no tile; 1: tile of a super-tile that holds faces; 2: tile of an EMPTY super-tile.  The slots are ordered heaviest-first,

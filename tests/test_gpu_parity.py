@@ -307,6 +307,55 @@ def test_full_step_smplx_arm():
     assert torch.equal(eng.params["trans"], before["trans"])
 
 
+def test_rasterizer_striding_grid_matches_plain_grid(sc, monkeypatch):
+    """Launches above 64 k workgroups (1024^2 with more than 16 frames) run the rasteriser kernels with a capped grid whose workgroups
+    stride over the tile order (csrc/raster.hip).  HARP_RASTER_LOOP forces that variant with a small grid on a small image: the forward
+    outputs are bit-identical to the plain launch, the fused silhouette loss (incl. the background table of un-rendered super-tiles) and
+    the backward agree up to the order of the float atomics; and a whole engine step gives the same losses and gradients."""
+    from harp_amd import ops
+    from harp_amd.engine import FitEngine
+    from oracle import harp_ref as H, p3d_like as P
+    S, focal, topo = 256, sc["focal"] * 2, sc["topo"]
+    params = dict(pose=sc["seq"]["pose"], rot=sc["seq"]["rot"], trans=sc["seq"]["trans"], shape=sc["seq"]["shape"].mean(0),
+                  verts_disps=torch.zeros(3093, 1))
+    fid = torch.arange(3)
+    with torch.no_grad():
+        _, v = H.prepare_mesh(params, fid, sc["model"], topo)
+        R, T = H.camera_RT(sc["seq"]["cam"][fid], S, focal)
+        _, ndc = P.world_to_ndc(v, R, T, focal, (S / 2, S / 2), S)
+    faces_d = topo["faces"].int().to(DEV)
+    tgt = (torch.rand(3, S, S) > 0.5).float().to(DEV)
+    out = {}
+    for mode in ("0", "24"):
+        monkeypatch.setenv("HARP_RASTER_LOOP", mode)
+        ndc_d = ndc.detach().to(DEV).requires_grad_()
+        alpha, face_id = ops.soft_silhouette(ndc_d, faces_d, S)
+        (alpha - tgt).abs().mean().backward()
+        f2, z2, _, _ = ops.rasterize_fwd(ndc_d.detach(), faces_d, S, soft=False)
+        out[mode] = (alpha.detach().clone(), face_id.clone(), f2.clone(), z2.clone(), ndc_d.grad.clone())
+    a, b = out["0"], out["24"]
+    for i in range(4):
+        assert torch.equal(a[i], b[i]), i
+    assert rel(b[4].cpu(), a[4].cpu()) < 1e-5
+    # whole engine steps in the fitting loop's sparse-output mode (background loss from the per-super-tile table)
+    tg = sc["targets"]
+    res = {}
+    for mode in ("0", "24"):
+        monkeypatch.setenv("HARP_RASTER_LOOP", mode)
+        eng = FitEngine(sc["model_np"], sc["topo_np"], sc["tpl"]["verts_uvs"], sc["tpl"]["faces_uvs"], sc["uv_mask"].float(), sc["seq"], sc["S"],
+                        sc["focal"], 3, device=DEV, seed=1)
+        eng.set_targets(tg["y_true"], tg["y_sil"], tg["y_sil_col"])
+        eng.keep_image = False
+        f3 = torch.tensor([2, 0, 1], dtype=torch.int32, device=DEV)
+        eng.fid.copy_(f3); eng.tfid.copy_(f3)
+        eng.auto_draw = False; eng.draw_texture_offsets(); eng.set_stage(True, True)
+        eng.forward_backward(True, True)
+        torch.cuda.synchronize()
+        res[mode] = (eng.loss_vec.clone().cpu(), eng.g_buf.clone().cpu())
+    assert rel(res["24"][0], res["0"][0]) < 1e-6
+    assert rel(res["24"][1], res["0"][1]) < 1e-5
+
+
 @pytest.mark.parametrize("S,B", [(100, 1), (448, 1), (72, 3)])
 def test_rasterizer_odd_sizes(sc, S, B):
     """image sides that are not multiples of the 16-px tile / 64-px super-tile (448 is the reference's default img_size), ragged
