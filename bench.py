@@ -156,26 +156,27 @@ def kernel_roofline(eng, steps, overlap=False):
     return out
 
 
-def extra_rates(eng, device, steps=12, warmup=4, vgg_weights="random"):
+def _graph_rate(e, steps, warmup):
+    """frames/s of graph-replayed scheduled steps of engine `e` (single GPU, outside the timed region of the headline)"""
+    B, T = e.B, e.T
+    e.set_schedule(torch.stack([(torch.arange(B) + i * B) % T for i in range(warmup + steps)]).to(torch.int32))
+    for _ in range(warmup):
+        e.step(None, True, True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        e.step(None, True, True)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"frames_per_s": B * steps / dt, "ms_per_step": dt / steps * 1e3, "frames_per_step": B, "steps": steps}
+
+
+def extra_rates(eng, device, steps=40, warmup=6, vgg_weights="random"):
     """Rates of the other BASELINE.json configurations and modes (not the headline `value`): the same step with the rendered image
     materialised like the reference's y_pred (keep_image=True), C2 at the reference's batch size 18, and C5's per-GPU share (SMPL-X
     arm mesh at 1024x1024, 32 frames / GPU).  Graph-replayed steps, barrier-free single GPU, synthetic targets rendered by the engine."""
-    def rate(e):
-        B, T = e.B, e.T
-        e.set_schedule(torch.stack([(torch.arange(B) + i * B) % T for i in range(warmup + steps)]).to(torch.int32))
-        for _ in range(warmup):
-            e.step(None, True, True)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            e.step(None, True, True)
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        return {"frames_per_s": B * steps / dt, "ms_per_step": dt / steps * 1e3, "frames_per_step": B, "steps": steps}
+    rate = lambda e: _graph_rate(e, steps, warmup)
     out = {}
-    eng.keep_image = True
-    out["C3_rendered_image_written(keep_image=True)"] = rate(eng)
-    eng.keep_image = False
     e = build_engine(0, 1, device, T=72, img=S, B=18)[0]
     e.keep_image = False
     out["C2_reference_batch_18"] = rate(e)
@@ -230,9 +231,11 @@ def perceptual_rate(device, weights, steps=6, warmup=2):
     return res
 
 
-def cpu_baseline(seed=0):
-    """The CPU oracle (a restatement of the reference path: materialised (B,S,S,K) fragments, torch autograd,
-    torch.optim.Adam) timed on this box's host cores on a bounded sample: 1 frame of the same workload per step."""
+def cpu_baseline(seed=0, frames_per_step=4):
+    """The CPU oracle (a restatement of the reference path: materialised (B,S,S,K) fragments, torch autograd, torch.optim.Adam) timed
+    on this box's host cores on the bounded sample SURVEY.md §8(d) names: the C2/C3 step reduced to 4 frames per step at 512x512 (so
+    the dense Adam update over 1.58 M parameters and the frame-independent regularisers are shared by 4 frames, as they are shared by
+    18 / 32 in the real configurations), and config C1 in full (one 256x256 frame, raw 778-vertex MANO mesh, silhouette term only)."""
     from oracle import harp_ref as H
     # many-core hosts oversubscribe badly on these small ops (256 threads: 306 s/step vs 3.9 s with 8) -> cap at 16
     cores = min(os.cpu_count() or 1, 16)
@@ -242,7 +245,8 @@ def cpu_baseline(seed=0):
     model_np = synth.make_mano_model(tpl, seed=seed)
     model = {k: torch.from_numpy(v) for k, v in model_np.items()}
     topo = {k: torch.from_numpy(np.asarray(v)).long() if isinstance(v, np.ndarray) else v for k, v in topo_np.items()}
-    T = 2
+    n = int(frames_per_step)
+    T = 2 * n
     seq, focal = synth.make_sequence(model_np, T, S, seed=seed)
     P = dict(pose=seq["pose"], cam=seq["cam"], verts_disps=torch.zeros(3093, 1), shape=seq["shape"].mean(0),
              light_positions=torch.tensor(((-0.5, -0.5, -0.5),)).repeat(T, 1), amb_ratio=torch.tensor(0.4),
@@ -256,11 +260,12 @@ def cpu_baseline(seed=0):
     opt_a = torch.optim.Adam([P["light_positions"], P["amb_ratio"], P["texture"], P["normal_map"]], lr=1e-2)
     with torch.no_grad():
         _, rv = H.prepare_mesh(P, torch.tensor([0]), model, topo)
-    def timed_steps(n):
+
+    def timed_steps(k):
         times = []
-        for it in range(n):
+        for it in range(k):
             t0 = time.time()
-            fid = torch.tensor([it % T])
+            fid = (torch.arange(n) + it * n) % T
             da = torch.normal(0, 1.0, (512, 512, 2)).to(torch.int).long()
             dn = torch.normal(0, 2.0, (512, 512, 2)).to(torch.int).long()
             _, total, _ = H.step_losses(P, fid, model, topo, tg, S, focal, rv, da, dn)
@@ -270,14 +275,34 @@ def cpu_baseline(seed=0):
             times.append(time.time() - t0)
         return float(np.median(times[1:]))
 
-    sec = timed_steps(9)
+    sec = timed_steps(5)
     torch.set_num_threads(1)                             # also a single-core figure
-    sec1 = timed_steps(4)
+    sec1 = timed_steps(2)
     torch.set_num_threads(cores)
-    return {"value": 1.0 / sec, "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"oracle/harp_ref.step_losses + autograd + torch.optim.Adam, 1 frame/step at {S}x{S} (K=50 silhouette fragments "
-                      f"materialised), median of 8 steps after 1 warm-up (~10 s of CPU work), torch.set_num_threads({cores})",
-            "single_core": {"value": 1.0 / sec1, "unit": "frames/s", "cores": 1, "sample": "same step, median of 3 after 1 warm-up"}}
+    # ---- C1 in full: one 256x256 frame, the un-subdivided MANO mesh, silhouette L1 only, Adam over the coarse group
+    raw_np = synth.build_raw_topology(tpl["faces0"], 778)
+    raw = {k: torch.from_numpy(np.asarray(v)).long() if isinstance(v, np.ndarray) else v for k, v in raw_np.items()}
+    seq1, focal1 = synth.make_sequence(model_np, 1, 256, seed=seed)
+    Q = {k: seq1[k].clone().requires_grad_() for k in ("pose", "cam", "rot", "trans")}
+    Q.update(shape=seq1["shape"].mean(0).clone().requires_grad_(), verts_disps=torch.zeros(778, 1, requires_grad=True))
+    y1 = (torch.rand(1, 256, 256) > 0.5).float()
+    opt1 = torch.optim.Adam([{"params": [Q["pose"], Q["cam"]], "lr": 1e-3}, {"params": [Q["verts_disps"], Q["shape"]], "lr": 1e-3}])
+    t_c1 = []
+    for it in range(6):
+        t0 = time.time()
+        _, v1 = H.prepare_mesh(Q, torch.tensor([0]), model, raw)
+        loss = 7.0 * torch.nn.functional.l1_loss(y1, H.render_silhouette(v1, raw["faces"], Q["cam"][:1], 256, focal1))
+        opt1.zero_grad(); loss.backward(); opt1.step()
+        t_c1.append(time.time() - t0)
+    c1 = float(np.median(t_c1[1:]))
+    return {"value": n / sec, "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"oracle/harp_ref.step_losses + autograd + torch.optim.Adam on the C2/C3 step reduced to {n} frames/step at {S}x{S} (SURVEY.md §8d; K=50 "
+                      f"silhouette fragments materialised, all terms but VGG, dense Adam shared by the {n} frames), median of 4 steps after 1 warm-up "
+                      f"(~{5 * sec + 2 * sec1 + 6 * c1:.0f} s of CPU work in total), torch.set_num_threads({cores})",
+            "s_per_step": sec,
+            "single_core": {"value": n / sec1, "unit": "frames/s", "cores": 1, "sample": "same step, 1 timed after 1 warm-up"},
+            "C1": {"value": 1.0 / c1, "unit": "frames/s", "cores": cores,
+                   "sample": "config C1 in full: one 256x256 frame, raw MANO mesh 778v/1538f, silhouette L1 only, Adam; median of 5 steps after 1 warm-up"}}
 
 
 class _StdoutToStderr:
@@ -300,8 +325,8 @@ class _StdoutToStderr:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
-    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the rates of the other configurations (keep_image, B=18, C5 arm 1024)")
@@ -432,18 +457,23 @@ def main():
         a_frame, a_step, parts = algorithmic_bytes(eng)
         kt = kernel_roofline(eng, 4)
         kt_situ = kernel_roofline(eng, 4, overlap=True)
-        # dominant kernel: the fused camera-view rasteriser (K=1 + soft silhouette); its algorithmic bytes per frame are the
-        # rasteriser sub-figure of SURVEY.md §8(d): geom_pos + S^2*(4+4+12+4) for the K=1 fragment set + S^2*4 for alpha
-        dom = max(kt, key=kt.get)
+        dom = max(kt, key=kt.get)                    # dominant kernel group of the step by measured time
         fused = "harp_shade_fwd" not in kt           # loss-only mode: the photometric L1 is formed inside the shader backward
         geom_pos = parts["V"] * 12 + parts["F"] * 12
-        alg = {"raster_cam_fwd(setup+bin+raster)": (geom_pos + parts["S2"] * 24 + parts["S2"] * 4 + parts["S2"] * 8) * eng.B,   # + fused silhouette L1: mask in, g_alpha out
-               "raster_light_fwd(setup+bin+raster)": (geom_pos + parts["S2"] * 24) * eng.B,
-               "harp_shade_fwd": (parts["geom"] + parts["S2"] * (4 + (12 if eng.keep_image else 0) + 4 + 12 + 4 + 12)) * eng.B,   # + fused photometric L1: y_true, mask in, g_rgb out; the image itself only if kept
+        S2 = parts["S2"]
+        # algorithmic bytes per launch, SURVEY.md §8(d): rasteriser sub-figure geom_pos + S^2*(4+4+12+4) per K=1 pass (face id, z, bary, dist)
+        # + S^2*4 for the fused silhouette's alpha (+ mask in, g_alpha out for the fused L1)
+        alg = {"raster_cam_fwd(setup+bin+raster)": (geom_pos + S2 * 24 + S2 * 4 + S2 * 8) * eng.B,
+               "raster_light_fwd(setup+bin+raster)": (geom_pos + S2 * 24) * eng.B,
+               "harp_shade_fwd": (parts["geom"] + S2 * (4 + (12 if eng.keep_image else 0) + 4 + 12 + 4 + 12)) * eng.B,   # + fused photometric L1: y_true, mask in, g_rgb out; the image itself only if kept
                # (fused-loss mode: no forward launch; the backward pass reads target + mask instead of the gradient image)
-               "harp_shade_bwd": (parts["geom"] + parts["V"] * 36 + parts["S2"] * (4 + (12 + 4 if fused else 12) + 4 + 4)) * eng.B + 2 * eng.Ht * eng.Wt * 12,
-               "harp_silhouette_bwd": (geom_pos + parts["S2"] * 8 + parts["V"] * 12) * eng.B,
-               "harp_depth_bwd": (geom_pos + parts["S2"] * 8 + parts["V"] * 12) * eng.B}
+               "harp_shade_bwd": (parts["geom"] + parts["V"] * 36 + S2 * (4 + (12 + 4 if fused else 12) + 4 + 4)) * eng.B + 2 * eng.Ht * eng.Wt * 12,
+               "harp_silhouette_bwd": (geom_pos + S2 * 8 + parts["V"] * 12) * eng.B,
+               "harp_depth_bwd": (geom_pos + S2 * 8 + parts["V"] * 12) * eng.B}
+        # ... and the bytes the FUSED kernels really have to move (barycentrics / distances are never materialised): the rasteriser's
+        # fraction is reported against both figures
+        moved = {"raster_cam_fwd(setup+bin+raster)": (geom_pos + S2 * (4 + 4) + S2 * (4 + 4)) * eng.B,     # face id + alpha out; mask in, g_alpha out
+                 "raster_light_fwd(setup+bin+raster)": (geom_pos + S2 * (4 + 4)) * eng.B}                # face id + depth out
         ach = alg[dom] / (kt[dom] * 1e-3) / 1e9
         # HBM traffic per launch comes from PMC counters, which cannot be read in-process: the last rocprofv3 FETCH_SIZE / WRITE_SIZE
         # passes over this same command are committed as profiles/traffic_latest.json (see its _source field)
@@ -453,16 +483,37 @@ def main():
             tjson = json.load(open(tpath))
             traffic = tjson.get(dom)
         # the same figures for every timed kernel group (north_star asks for the rasteriser's fraction explicitly)
-        per_kernel = {k: {"avg_ms": kt[k], "in_situ_ms": kt_situ.get(k), "algorithmic_bytes": alg[k], "achieved_GBps": alg[k] / (kt[k] * 1e-3) / 1e9,
-                          "frac": alg[k] / (kt[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": tjson.get(k)} for k in kt}
+        per_kernel = {}
+        for k in kt:
+            e = {"avg_ms": kt[k], "in_situ_ms": kt_situ.get(k), "algorithmic_bytes": alg[k], "achieved_GBps": alg[k] / (kt[k] * 1e-3) / 1e9,
+                 "frac": alg[k] / (kt[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": tjson.get(k)}
+            if k in moved:
+                e["moved_bytes(fused kernel: no bary/dist images)"] = moved[k]
+                e["frac_of_moved_bytes"] = moved[k] / (kt[k] * 1e-3) / 1e9 / HBM_PEAK_GBS
+            if tjson.get(k):
+                e["frac_of_measured_traffic"] = tjson[k] / (kt[k] * 1e-3) / 1e9 / HBM_PEAK_GBS
+            per_kernel[k] = e
+        step_s = dt / args.steps
+        step_bytes = a_frame * eng.B + a_step
+        # loss-only mode writes no y_pred and reads no gradient image back: 2 * S^2 * 12 B per frame less than §8(d)'s A_frame
+        step_bytes_lean = step_bytes - 2 * S2 * 12 * eng.B
         out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                            "traffic": traffic,
                            "traffic_source": "NOT measured in this run (PMC counters cannot be read in-process): per-launch FETCH_SIZE / WRITE_SIZE of the last "
                                              "committed rocprofv3 pass over this command, profiles/traffic_latest.json",
                            "algorithmic_bytes_per_launch": alg[dom], "avg_ms": kt[dom], "in_situ_ms": kt_situ.get(dom),
                            "in_situ_frac": alg[dom] / (kt_situ[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS if kt_situ.get(dom) else None,
-                           "kernel_ms": kt, "per_kernel": per_kernel, "step_algorithmic_bytes": a_frame * eng.B + a_step,
-                           "step_frac_of_hbm_roofline": (a_frame * eng.B + a_step) / (dt / args.steps) / 1e9 / HBM_PEAK_GBS}
+                           "kernel_ms": kt, "per_kernel": per_kernel, "step_algorithmic_bytes": step_bytes,
+                           "step_frac_of_hbm_roofline": step_bytes / step_s / 1e9 / HBM_PEAK_GBS,
+                           "step_algorithmic_bytes_loss_only_mode": step_bytes_lean,
+                           "step_frac_of_hbm_roofline_loss_only_bytes": step_bytes_lean / step_s / 1e9 / HBM_PEAK_GBS}
+        # the like-for-like step that materialises y_pred as the reference does, next to the headline (always measured: 40 replays)
+        eng.keep_image = True
+        ki = _graph_rate(eng, 40, 6)
+        eng.keep_image = False
+        out["value_keep_image"] = ki["frames_per_s"]
+        out["ms_per_step_keep_image"] = ki["ms_per_step"]
+        out["roofline"]["step_frac_of_hbm_roofline_keep_image"] = step_bytes / (ki["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS
         if not args.no_extras:
             out["extras"] = extra_rates(eng, device, vgg_weights=None if args.vgg_weights == "none" else args.vgg_weights)
         if not args.no_cpu_baseline:

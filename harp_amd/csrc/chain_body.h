@@ -42,8 +42,12 @@ __device__ __forceinline__ void block_sum_n(const float* v, float* red, float* o
   __syncthreads();
 }
 
-// process_info_for_shadow + look_at_rotation (same arithmetic as glue.hip:light_setup_kernel)
-struct LightCam { V3 c, d, pos, x, y, z; float dl, s, lx, ly, lz; };
+// process_info_for_shadow (renderer_helper.py:454-468) + PyTorch3D look_at_rotation, shared by the fused chain
+// below and glue.hip:light_setup_kernel.  Includes look_at_rotation's REPLACEMENT branch: when every component of x = normalize(up x z)
+// is within 5e-3 of zero (torch.isclose(x, 0, atol=5e-3): the light sits within ~5e-8 rad of the vertical through the centroid, so
+// |up x z| < 1e-5 and the eps-clamped normalisation leaves a tiny vector), x is replaced by normalize(y x z), with y = normalize(z x x)
+// still formed from the tiny x — the same sequence of operations as the reference, forward and backward.
+struct LightCam { V3 c, d, pos, x, y, z, x0; float dl, s, lx, ly, lz, lx2; bool repl; };
 __device__ __forceinline__ LightCam light_cam(V3 c, V3 L) {
   LightCam k;
   k.c = c; k.d = L - c;
@@ -52,9 +56,43 @@ __device__ __forceinline__ LightCam light_cam(V3 c, V3 L) {
   k.pos = c + k.d * k.s;
   const V3 up = mk(0.f, 1.f, 0.f);
   k.z = normz(c - k.pos, 1e-5f, k.lz);
-  k.x = normz(cross(up, k.z), 1e-5f, k.lx);
-  k.y = normz(cross(k.z, k.x), 1e-5f, k.ly);
+  k.x0 = normz(cross(up, k.z), 1e-5f, k.lx);
+  k.y = normz(cross(k.z, k.x0), 1e-5f, k.ly);
+  k.repl = fabsf(k.x0.x) <= 5e-3f && fabsf(k.x0.y) <= 5e-3f && fabsf(k.x0.z) <= 5e-3f;
+  k.lx2 = 0.f;
+  k.x = k.repl ? normz(cross(k.y, k.z), 1e-5f, k.lx2) : k.x0;
   return k;
+}
+// rotation (row-major, columns x y z) and translation T = -R^T pos of the light camera
+__device__ __forceinline__ void light_cam_RT(const LightCam& k, float* R, float* T) {
+  R[0] = k.x.x; R[1] = k.y.x; R[2] = k.z.x; R[3] = k.x.y; R[4] = k.y.y; R[5] = k.z.y; R[6] = k.x.z; R[7] = k.y.z; R[8] = k.z.z;
+  T[0] = -dot(k.x, k.pos); T[1] = -dot(k.y, k.pos); T[2] = -dot(k.z, k.pos);
+}
+// dL/d(light_R) (9, row-major), dL/d(light_T) (3) -> dL/d(light position) `gd`, dL/d(centroid) `gc`
+__device__ __forceinline__ void light_cam_bwd(const LightCam& k, const float* gR, const float* gT, V3& gd, V3& gc) {
+  const V3 up = mk(0.f, 1.f, 0.f);
+  V3 gx = mk(gR[0], gR[3], gR[6]) - k.pos * gT[0];
+  V3 gy = mk(gR[1], gR[4], gR[7]) - k.pos * gT[1];
+  V3 gz = mk(gR[2], gR[5], gR[8]) - k.pos * gT[2];
+  V3 gpos = (k.x * gT[0] + k.y * gT[1] + k.z * gT[2]) * -1.0f;
+  V3 gx0 = gx;
+  if (k.repl) {                                   // x = normalize(y x z): g_y += z x g, g_z += g x y; the first x only feeds y
+    const V3 gq = normz_bwd(k.x, k.lx2, 1e-5f, gx);
+    gy = gy + cross(k.z, gq);
+    gz = gz + cross(gq, k.y);
+    gx0 = mk(0.f, 0.f, 0.f);
+  }
+  const V3 gyr = normz_bwd(k.y, k.ly, 1e-5f, gy);  // y = normalize(z x x0)
+  gz = gz + cross(k.x0, gyr);
+  gx0 = gx0 + cross(gyr, k.z);
+  const V3 gxr = normz_bwd(k.x0, k.lx, 1e-5f, gx0);   // x0 = normalize(up x z)
+  gz = gz + cross(gxr, up);
+  const V3 gzr = normz_bwd(k.z, k.lz, 1e-5f, gz);  // z = normalize(c - pos)
+  gc = gzr;
+  gpos = gpos - gzr;
+  gc = gc + gpos;
+  gd = gpos * k.s - k.d * (1.5f * dot(k.d, gpos) / (k.dl * k.dl * k.dl));      // pos = c + d * 1.5 / |d|
+  gc = gc - gd;
 }
 
 // area-weighted vertex normal of vertex i from positions `p` (LDS or global): N, n = N / max(|N|, 1e-6), inv = 1/|N| or 0 if clamped
@@ -162,9 +200,9 @@ __device__ __forceinline__ void mesh_chain_fwd_body(const harp_mesh_chain& A, fl
     const V3 c = mk(s_tot3[0] / V, s_tot3[1] / V, s_tot3[2] / V);
     const LightCam k = light_cam(c, ld(lpos));
     st(A.centroid + 3 * b, c);
-    const float R[9] = {k.x.x, k.y.x, k.z.x, k.x.y, k.y.y, k.z.y, k.x.z, k.y.z, k.z.z};
+    float R[9], T[3];
+    light_cam_RT(k, R, T);
     for (int q = 0; q < 9; ++q) { s_cam[q] = R[q]; A.light_R[9 * b + q] = R[q]; }
-    const float T[3] = {-dot(k.x, k.pos), -dot(k.y, k.pos), -dot(k.z, k.pos)};
     for (int q = 0; q < 3; ++q) { s_cam[9 + q] = T[q]; A.light_T[3 * b + q] = T[q]; }
   }
   __syncthreads();
@@ -247,22 +285,8 @@ __device__ __forceinline__ void mesh_chain_bwd_body(const harp_mesh_chain& A, fl
       for (int k = 0; k < 9; ++k) gR[k] = A.g_light_R[9 * b + k] + gs[k];
       for (int k = 0; k < 3; ++k) gT[k] = A.g_light_T[3 * b + k] + gs[9 + k];
       const LightCam k = light_cam(ld(A.centroid + 3 * b), ld(A.light_pos + 3 * b));
-      const V3 up = mk(0.f, 1.f, 0.f);
-      V3 gx = mk(gR[0], gR[3], gR[6]) - k.pos * gT[0];
-      V3 gy = mk(gR[1], gR[4], gR[7]) - k.pos * gT[1];
-      V3 gz = mk(gR[2], gR[5], gR[8]) - k.pos * gT[2];
-      V3 gpos = (k.x * gT[0] + k.y * gT[1] + k.z * gT[2]) * -1.0f;
-      const V3 gyr = normz_bwd(k.y, k.ly, 1e-5f, gy);
-      gz = gz + cross(k.x, gyr);
-      gx = gx + cross(gyr, k.z);
-      const V3 gxr = normz_bwd(k.x, k.lx, 1e-5f, gx);
-      gz = gz + cross(gxr, up);
-      const V3 gzr = normz_bwd(k.z, k.lz, 1e-5f, gz);
-      V3 gc = gzr;
-      gpos = gpos - gzr;
-      gc = gc + gpos;
-      const V3 gd = gpos * k.s - k.d * (1.5f * dot(k.d, gpos) / (k.dl * k.dl * k.dl));
-      gc = gc - gd;
+      V3 gd, gc;
+      light_cam_bwd(k, gR, gT, gd, gc);
       float* gl = A.g_light_pos + 3 * b;
       gl[0] += gd.x; gl[1] += gd.y; gl[2] += gd.z;
       const float inv = 1.0f / (float)V;

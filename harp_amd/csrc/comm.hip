@@ -8,6 +8,8 @@
 // would each open their own xGMI / IPC state).  Being a plain stream-ordered enqueue, the call can be captured into the step's
 // hipGraph like every other node (no host-side work object, no extra stream, no event round trip).
 #include <dlfcn.h>
+#include <functional>
+#include <mutex>
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 #include <stddef.h>
@@ -29,9 +31,7 @@ struct Rccl {
   bool ok = false;
 };
 
-Rccl& rccl() {
-  static Rccl r;
-  if (r.h) return r;
+void rccl_bind(Rccl& r) {
   // 1. whatever the process already mapped (PyTorch ships its own librccl.so); 2. the ROCm install
   const char* names[] = {"librccl.so", "librccl.so.1"};
   for (const char* n : names) {
@@ -45,13 +45,20 @@ Rccl& rccl() {
       if (r.h) break;
     }
   }
-  if (!r.h) return r;
+  if (!r.h) return;
   r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(r.h, "ncclGetUniqueId");
   r.CommInitRank = (decltype(r.CommInitRank))dlsym(r.h, "ncclCommInitRank");
   r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.h, "ncclCommDestroy");
   r.AllReduce = (decltype(r.AllReduce))dlsym(r.h, "ncclAllReduce");
   r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.h, "ncclGetErrorString");
   r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.AllReduce;
+}
+
+// bound once, thread-safe: two threads creating communicators at the same time must not race on the function table
+Rccl& rccl() {
+  static Rccl r;
+  static std::once_flag once;
+  std::call_once(once, rccl_bind, std::ref(r));
   return r;
 }
 

@@ -4,23 +4,11 @@
 // renderer_helper.py:435-441) and the light camera of process_info_for_shadow (renderer_helper.py:454-468, with
 // PyTorch3D look_at_rotation) — as one forward and one backward kernel each, one lane per frame.  The backward scatters
 // straight into the flat gradient arena of the parameter tables (dense-Adam semantics: untouched rows keep zero grad).
-#include "harp_common.h"
-#include "harp_hip.h"
+#include "chain_body.h"      // V3 helpers + the light camera (process_info_for_shadow / look_at_rotation), shared with the fused chain
 
 namespace {
 
-struct V3 { float x, y, z; };
-__device__ __forceinline__ V3 mk(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
-__device__ __forceinline__ V3 ld(const float* p) { return mk(p[0], p[1], p[2]); }
-__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
-__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
-__device__ __forceinline__ V3 operator*(V3 a, float s) { return mk(a.x * s, a.y * s, a.z * s); }
-__device__ __forceinline__ float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
-__device__ __forceinline__ V3 cross(V3 a, V3 b) { return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
-__device__ __forceinline__ V3 normz(V3 a, float eps, float& len) { len = sqrtf(dot(a, a)); return a * (1.0f / fmaxf(len, eps)); }
-__device__ __forceinline__ V3 normz_bwd(V3 n, float len, float eps, V3 g) {
-  return (len > eps) ? (g - n * dot(n, g)) * (1.0f / len) : g * (1.0f / eps);
-}
+using namespace cb;
 
 __global__ void frame_setup_fwd_kernel(const harp_frame_tables t, const int32_t* __restrict__ fid, int B, int S, float focal,
                                        int self_shadow, float* __restrict__ pose48, float* __restrict__ betas,
@@ -97,41 +85,12 @@ __global__ void light_setup_kernel(const float* __restrict__ centroid, const flo
                                    const float* __restrict__ g_T, float* __restrict__ g_light_pos, float* __restrict__ g_centroid) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
-  const V3 c = ld(centroid + 3 * b), L = ld(light_pos + 3 * b);
-  const V3 d = L - c;
-  const float dl = sqrtf(dot(d, d));
-  const float s = 1.5f / dl;
-  const V3 pos = c + d * s;
-  const V3 up = mk(0.f, 1.f, 0.f);
-  float lz, lx, ly;
-  const V3 zr = c - pos;
-  const V3 z = normz(zr, 1e-5f, lz);
-  const V3 xr = cross(up, z);
-  const V3 x = normz(xr, 1e-5f, lx);
-  const V3 yr = cross(z, x);
-  const V3 y = normz(yr, 1e-5f, ly);
+  const LightCam k = light_cam(ld(centroid + 3 * b), ld(light_pos + 3 * b));
   if (!BWD) {
-    float* R = light_R + 9 * b;
-    R[0] = x.x; R[1] = y.x; R[2] = z.x; R[3] = x.y; R[4] = y.y; R[5] = z.y; R[6] = x.z; R[7] = y.z; R[8] = z.z;
-    light_T[3 * b] = -dot(x, pos); light_T[3 * b + 1] = -dot(y, pos); light_T[3 * b + 2] = -dot(z, pos);
+    light_cam_RT(k, light_R + 9 * b, light_T + 3 * b);
   } else {
-    const float* gR = g_R + 9 * b;
-    const float* gT = g_T + 3 * b;
-    V3 gx = mk(gR[0], gR[3], gR[6]) - pos * gT[0];
-    V3 gy = mk(gR[1], gR[4], gR[7]) - pos * gT[1];
-    V3 gz = mk(gR[2], gR[5], gR[8]) - pos * gT[2];
-    V3 gpos = (x * gT[0] + y * gT[1] + z * gT[2]) * -1.0f;
-    const V3 gyr = normz_bwd(y, ly, 1e-5f, gy);
-    gz = gz + cross(x, gyr);
-    gx = gx + cross(gyr, z);
-    const V3 gxr = normz_bwd(x, lx, 1e-5f, gx);
-    gz = gz + cross(gxr, up);
-    const V3 gzr = normz_bwd(z, lz, 1e-5f, gz);
-    V3 gc = gzr;
-    gpos = gpos - gzr;
-    gc = gc + gpos;
-    const V3 gd = gpos * s - d * (1.5f * dot(d, gpos) / (dl * dl * dl));
-    gc = gc - gd;
+    V3 gd, gc;
+    light_cam_bwd(k, g_R + 9 * b, g_T + 3 * b, gd, gc);
     float* gl = g_light_pos + 3 * b;
     gl[0] += gd.x; gl[1] += gd.y; gl[2] += gd.z;
     float* gco = g_centroid + 3 * b;

@@ -85,8 +85,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE =
                           l1_target, l1_fid, l1_w, l1_loss, l1_grad, l1_inv, sparse, l1_bg_sums);
   }
   if (bg_table) {
+    // slots below `limit` (nact rounded up to 8) already went through raster_tile, whose sub == 0 workgroup adds the table value of an
+    // empty super-tile: start behind them, or up to 7 empty super-tiles are counted twice whenever nact % 8 != 0
     float acc = 0.f;
-    for (int slot = nact[0] + (int)(blockIdx.x * blockDim.x + threadIdx.x); slot < B * nst; slot += (int)(gridDim.x * blockDim.x)) {
+    const int first = min(B * nst, (nact[0] + 7) / 8 * 8);
+    for (int slot = first + (int)(blockIdx.x * blockDim.x + threadIdx.x); slot < B * nst; slot += (int)(gridDim.x * blockDim.x)) {
       const int entry = order[slot], b = entry / nst, st = entry - b * nst;
       acc += l1_bg_sums[(size_t)l1_fid[b] * nst + st];
     }

@@ -11,6 +11,7 @@ Two transports:
   * `torch.distributed.all_reduce` — used when no RcclComm exists (the gloo CPU tests, and N processes sharing one GPU, which RCCL
     refuses: "duplicate GPU")."""
 import ctypes
+import weakref
 
 import torch
 import torch.distributed as dist
@@ -48,6 +49,19 @@ class RcclComm:
         h = ctypes.c_void_p()
         _lib.check(_lib.lib().harp_comm_create(uid_bytes, int(rank), int(world), ctypes.byref(h)), "harp_comm_create")
         self.handle, self.rank, self.world = h, int(rank), int(world)
+        self._engines = weakref.WeakSet()      # FitEngines whose captured step graphs embed this communicator's raw ncclComm_t
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.destroy()
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
 
     @staticmethod
     def unique_id():
@@ -74,6 +88,8 @@ class RcclComm:
 
     def allreduce(self, t, stream=None):
         """in-place sum of a contiguous fp32 HIP tensor, enqueued on `stream` (default: torch's current stream)"""
+        if not self.handle:
+            raise RuntimeError("RcclComm was destroyed")
         if t.dtype != torch.float32:
             raise TypeError("harp_allreduce_flat reduces float32 buckets")
         _lib.check(_lib.lib().harp_allreduce_flat(self.handle, _lib.ptr(t), t.numel(), _lib.stream() if stream is None else stream),
@@ -81,6 +97,11 @@ class RcclComm:
         return t
 
     def destroy(self):
+        """idempotent; engines that captured this communicator into their step graphs drop those graphs (a replay would hand RCCL a
+        dangling ncclComm_t) and fall back to no communicator"""
         if self.handle:
-            _lib.lib().harp_comm_destroy(self.handle)
-            self.handle = ctypes.c_void_p()
+            for eng in list(self._engines):
+                if eng.comm is self:
+                    eng.set_comm(None)
+            h, self.handle = self.handle, ctypes.c_void_p()
+            _lib.lib().harp_comm_destroy(h)

@@ -587,6 +587,8 @@ class FitEngine:
         plain enqueue, captured into the step's hipGraph like every kernel — instead of through torch.distributed."""
         self.comm = comm
         self._graphs = {}
+        if comm is not None:
+            comm._engines.add(self)                      # RcclComm.destroy() un-sets itself here (captured graphs hold its raw handle)
 
     def _comm_stream(self):
         if getattr(self, "_cstream", None) is None:

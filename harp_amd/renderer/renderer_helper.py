@@ -42,8 +42,11 @@ class SilhouetteRenderer:
         self.image_size, self.sigma = image_size, sigma
         self.blur_radius = math.log(1.0 / 1e-4 - 1.0) * sigma                                       # renderer_helper.py:46
         # K is not a buffer size in the fused kernel: every face within the blur radius contributes.  The reference keeps the K nearest;
-        # for a hand mesh fewer than 50 faces ever overlap a pixel, so the cap never binds.  A caller that
-        # needs the cap enforced exactly (K smaller than the depth complexity) gets it from the fragment-level path below.
+        # ASSUMPTION (checked, not taken on faith: tests/test_gpu_fragments.py::test_depth_complexity_stays_below_the_silhouette_cap
+        # counts the fragments per pixel of the bench scenes — hand and arm — with the fragment-level op): fewer than 50 faces ever lie
+        # within the blur radius of one pixel of a hand / arm mesh, so a cap of 50 or more never binds and the fused kernel returns what
+        # the capped reference returns.  A cap that can bind (K < 50) is honoured exactly through the fragment-level path below, which
+        # holds up to 64 slots per pixel; K > 64 cannot bind either while the count stays below 50 and takes the fused kernel too.
         self.faces_per_pixel = faces_per_pixel
 
     def __call__(self, mesh, principal_point=None, focal_length=None, T=None, R=None, materials=None, image_size=None, **kw):
@@ -162,6 +165,37 @@ def softmax_rgb_blend(colors, fragments, background=(1.0, 1.0, 1.0), sigma=1e-4,
     return torch.cat([rgb, (1.0 - alpha)[..., None]], -1)
 
 
+def sample_textures_uv(tex, fragments, n_faces):
+    """pytorch3d TexturesUV.sample_textures for K >= 1 fragments in torch ops: per-pixel uv from the packed face
+    ids + barycentrics, bilinear grid_sample with align_corners=True, border padding, v axis flipped.  (N,H,W,K) -> (N,H,W,K,C)"""
+    maps = tex.maps_padded()
+    N, H, W, K = fragments.pix_to_face.shape
+    dev = maps.device
+    verts_uvs = torch.as_tensor(tex.verts_uvs, dtype=torch.float32, device=dev).reshape(-1, 2)
+    faces_uvs = torch.as_tensor(tex.faces_uvs, device=dev).long().reshape(-1, 3)
+    face_uv = verts_uvs[faces_uvs].repeat(N, 1, 1)                                                # packed (N*F,3,2): ids are b*F + f
+    assert face_uv.shape[0] == N * n_faces
+    uv = interpolate_face_attributes(fragments.pix_to_face, fragments.bary_coords, face_uv)       # (N,H,W,K,2)
+    grid = torch.stack((2.0 * uv[..., 0] - 1.0, 1.0 - 2.0 * uv[..., 1]), -1)                      # flipped maps + (uv*2-1)  ==  y -> -y
+    grid = grid.permute(0, 3, 1, 2, 4).reshape(N * K, H, W, 2)
+    m = maps.permute(0, 3, 1, 2)[:, None].expand(N, K, -1, -1, -1).reshape(N * K, maps.shape[3], maps.shape[1], maps.shape[2])
+    out = torch.nn.functional.grid_sample(m, grid, mode="bilinear", padding_mode="border", align_corners=True)
+    return out.reshape(N, K, -1, H, W).permute(0, 3, 4, 1, 2)
+
+
+def apply_normal_map(pixel_normals, nm):
+    """PBRMaterials.apply_normal_map / compute_tangent (renderer/pbr_materials.py:58-124) in torch ops, for the fragment-level
+    renderers (the K=1 shading path has it fused into csrc/shade.hip): n' = normalize(-u m.x - v m.y + n m.z)."""
+    x, y, z = pixel_normals.unbind(-1)
+    s = 2.0 * (z >= 0).to(z.dtype) - 1.0
+    a = -1.0 / (s + z)
+    b = x * y * a
+    u = torch.stack((1 + s * x * x * a, s * b, -s * x), -1)
+    v = torch.stack((b, s + y * y * a, -y), -1)
+    out = -u * nm[..., 0:1] - v * nm[..., 1:2] + pixel_normals * nm[..., 2:3]
+    return torch.nn.functional.normalize(out, dim=-1)
+
+
 class NormalRenderer:
     """MeshRenderer(MeshRasterizer(K=10, blur 0), SoftPhongNormalShader) (renderer_helper.py:82-101, 192-258): the interpolated vertex
     normals (through the normal map when the materials carry one), y / z flipped, mapped to [0,1], softmax-blended over the K=10
@@ -177,8 +211,8 @@ class NormalRenderer:
         vn = mesh.verts_normals_padded()
         fn = vn[:, faces].reshape(B * faces.shape[0], 3, 3)
         pix_n = interpolate_face_attributes(fr.pix_to_face, fr.bary_coords, fn)
-        if materials is not None and getattr(materials, "use_normal_map", False):
-            raise NotImplementedError("normal-map visualisation through the K=10 renderer: use the shading kernels' path (K=1)")
+        if materials is not None and getattr(materials, "use_normal_map", False):                  # renderer_helper.py:226-232 (`vis_normal`)
+            pix_n = apply_normal_map(pix_n, sample_textures_uv(materials.normal_maps, fr, faces.shape[0]))
         pix_n = pix_n * torch.tensor([1.0, -1.0, -1.0], device=pix_n.device)                    # renderer_helper.py:211-212
         return softmax_rgb_blend((pix_n + 1.0) / 2.0, fr)                                          # :213, :255-257
 

@@ -29,10 +29,14 @@ _RAW_TOPO = {}
 
 def raw_topology(mesh_faces, n_verts, device):
     """static tables of the UN-subdivided template (prepare_mesh with mesh_subdivider=None, utils/visualize.py:51-56), built once"""
-    f = torch.as_tensor(mesh_faces).detach().cpu().reshape(-1, 3)
-    key = (f.data_ptr() if torch.is_tensor(mesh_faces) and not mesh_faces.is_cuda else hash(f.numpy().tobytes()), int(n_verts), str(device))
+    import hashlib
+    f = torch.as_tensor(mesh_faces).detach().cpu().reshape(-1, 3).contiguous()
+    # keyed on the CONTENT of the face table (18 KB for MANO): an address can be reused by another tensor after this one is freed
+    key = (hashlib.sha1(f.numpy().tobytes()).hexdigest(), int(n_verts), str(device))
     if key not in _RAW_TOPO:
         from ..synth import build_raw_topology
+        if len(_RAW_TOPO) >= 8:                           # a handful of templates at most (hand, arm): bounded
+            _RAW_TOPO.pop(next(iter(_RAW_TOPO)))
         t = build_raw_topology(f.numpy(), int(n_verts))
         _RAW_TOPO[key] = ops.DeviceTopology(t, torch.zeros(1, 2), torch.zeros(t["faces"].shape[0], 3, dtype=torch.int32), device)
     return _RAW_TOPO[key]

@@ -23,13 +23,39 @@ def make_scene(T=3, S=128, seed=0):
                 targets=targets, T=T, S=S)
 
 
-def oracle_params(sc, source):
+def oracle_params(sc, source, dtype=torch.float32):
     """dict of leaf tensors (requires_grad) cloned from `source` (engine.params or any dict of tensors)."""
     keys = ("pose", "cam", "verts_disps", "shape", "light_positions", "amb_ratio", "texture", "normal_map", "rot", "trans")
-    P = {k: source[k].detach().cpu().clone().requires_grad_() for k in keys}
-    P.update(verts_uvs=torch.from_numpy(sc["tpl"]["verts_uvs"]), faces_uvs=torch.from_numpy(sc["tpl"]["faces_uvs"]).long(),
-             uv_mask=sc["uv_mask"], init_joints=sc["seq"]["joints"])
+    P = {k: source[k].detach().cpu().to(dtype).clone().requires_grad_() for k in keys}
+    P.update(verts_uvs=torch.from_numpy(sc["tpl"]["verts_uvs"]).to(dtype), faces_uvs=torch.from_numpy(sc["tpl"]["faces_uvs"]).long(),
+             uv_mask=sc["uv_mask"], init_joints=sc["seq"]["joints"].to(dtype))
     return P
+
+
+def scene_f64(sc, targets):
+    """(model, targets) of a make_scene() scene in float64 for the oracle"""
+    model = {k: (v.double() if v.is_floating_point() else v) for k, v in sc["model"].items()}
+    return model, {k: v.double() for k, v in targets.items()}
+
+
+# Fraction of the covered pixels the ambiguous-pixel mask removed, per test case, as MEASURED on MI355X (round 3; every caller prints
+# its value).  A case fails when its fraction exceeds 1.5 x the recorded one: the mask may not quietly grow to hide kernel errors.
+# Every masked comparison has an UNMASKED companion with a looser gradient bound (tests/test_gpu_baseline.py), so what the mask
+# removes is bounded, not ignored.
+AMBIGUOUS_FRACTION = {}
+
+
+def check_removed(tag, removed):
+    import json, os
+    print(f"[ambiguous-pixel mask] {tag}: {removed:.4f} of the covered pixels removed")
+    log = os.environ.get("HARP_MASK_LOG")
+    if log:
+        with open(log, "a") as f:
+            f.write(json.dumps({"tag": tag, "removed": removed}) + "\n")
+    rec = AMBIGUOUS_FRACTION.get(tag)
+    assert rec is not None, f"no recorded mask fraction for {tag!r} (measured now: {removed:.4f})"
+    assert removed <= 1.5 * rec + 1e-4, (tag, removed, rec)
+    return removed
 
 
 def rel(a, b):

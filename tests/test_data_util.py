@@ -85,3 +85,31 @@ def test_load_sample_sequence_split_and_resident_targets(tmp_path):
     y_true, y_sil, y_col = rt.tensors()
     assert y_true.shape == (2, 16, 16, 3) and y_sil.shape == (2, 16, 16) and y_col.shape == (2, 16, 16) and rt.fid.tolist() == [3, 1]
     assert torch.equal(y_true[1], ds[1][1]) and torch.equal(y_sil[0], ds[3][2][..., 0]) and (y_col <= y_sil + 1e-6).all()
+
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_committed_frames_fixture_pins_load_img_and_erosion():
+    """tests/golden/frames (6 JPEG frames + masks + METRO pickles in the reference's layout) against frames_expected.npz, the output of
+    the reference's load_img restated literally with cv2.erode written out as loops from the OpenCV documentation
+    (tests/golden/make_golden_frames.py): decode, /255 scaling, un-thresholded mask, 3x3 erosion x2, shapes and dtypes."""
+    exp = np.load(os.path.join(GOLDEN, "frames_expected.npz"))
+    root = os.path.join(GOLDEN, "frames")
+    mp, ds, _, _ = D.load_multiple_sequences(os.path.join(root, "metro"), os.path.join(root, "img"), train_list=["1"], val_list=[])
+    assert len(ds) == 6 and mp["pose"].shape == (6, 45) and mp["cam"].shape == (6, 3)
+    assert [os.path.basename(p) for p in ds.image_paths] == [f"{i:04d}.jpg" for i in range(1, 7)]
+    for i in range(6):
+        fid, rgb, mask, er = ds[i]
+        assert fid == i and rgb.dtype == mask.dtype == er.dtype == torch.float32
+        assert np.array_equal(rgb.numpy(), exp["rgb"][i]) and np.array_equal(mask.numpy(), exp["mask"][i])
+        assert np.array_equal(er.numpy(), exp["eroded"][i]), i
+    # the masks are JPEGs: values are NOT thresholded by the reference (utils/data_util.py:14) and neither here
+    frac = ((exp["mask"] > 0.02) & (exp["mask"] < 0.98)).mean()
+    assert 0.0 < frac < 0.2, frac
+    assert (exp["eroded"] <= exp["mask"][..., 0] + 1e-7).all() and exp["eroded"].sum() < 0.8 * exp["mask"].sum()
+    # frames 1, 3, 5 touch the top border: erosion keeps the border rows (out-of-image neighbours never win the minimum)
+    assert exp["eroded"][0][0, 15] > 0.9 and exp["eroded"][0][3, 15] < 0.5 + 0.5 * exp["eroded"][0][2, 15]
+    rt = D.ResidentTargets(ds)
+    assert np.array_equal(rt.y_true.numpy(), exp["rgb"]) and np.array_equal(rt.y_sil.numpy(), exp["mask"][..., 0])
+    assert np.array_equal(rt.y_sil_col.numpy(), exp["eroded"]) and rt.fid.tolist() == list(range(6))

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests._scene import make_scene, mask_scene_targets, oracle_params, rel
+from tests._scene import check_removed, make_scene, mask_scene_targets, oracle_params, rel
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -35,7 +35,7 @@ def test_loop_body_through_reference_api():
     B = 2
     # pixels whose colour is not decided at float32 precision (tests/_scene.mask_ambiguous_pixels) leave the photometric mask of both paths
     tg, removed = mask_scene_targets(sc, params, fid)
-    assert removed < 0.10
+    check_removed("api_loop_body_128", removed)
     P = oracle_params(sc, params)
     # ---- the loop body, reference call for call (optimize_sequence.py:453-553)
     with torch.no_grad():

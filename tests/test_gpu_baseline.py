@@ -16,7 +16,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests._scene import ORACLE_KEYS, engine_eval, make_fit_case, mask_ambiguous_pixels, oracle_inputs, oracle_step, rel
+from tests._scene import ORACLE_KEYS, check_removed, engine_eval, make_fit_case, mask_ambiguous_pixels, oracle_inputs, oracle_step, rel
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -38,6 +38,7 @@ def _check_grads(eng, P, keys, tol=GRAD_TOL, tag=""):
             continue
         worst[k] = rel(eng.grads[k].cpu().double(), ref)
     bad = {k: v for k, v in worst.items() if not v < tol}
+    print(f"[gradient rel-L2 vs fp64 oracle] {tag}: " + ", ".join(f"{k} {v:.1e}" for k, v in worst.items()))
     assert not bad, (tag, bad, worst)
     return worst
 
@@ -53,7 +54,7 @@ def _check_images(eng, aux, n):
 def test_c2_c3_hand_512_b2_vs_fp64_oracle(keep_image):
     case = make_fit_case("hand", T=2, S=512, B=2, seed=0, device=DEV)
     eng = case["eng"]
-    assert mask_ambiguous_pixels(case) < 0.10
+    check_removed("c2c3_hand_512_b2", mask_ambiguous_pixels(case))
     eng.keep_image = keep_image
     eng.draw_texture_offsets()
     fid = torch.tensor([1, 0])
@@ -68,11 +69,32 @@ def test_c2_c3_hand_512_b2_vs_fp64_oracle(keep_image):
     _check_grads(eng, P, keys, tag=f"512 hand keep_image={keep_image}")
 
 
+def test_c2_c3_hand_512_b2_unmasked_companion():
+    """The same inputs as test_c2_c3_hand_512_b2_vs_fp64_oracle with NO pixel taken out of the photometric mask: what the mask removes is
+    bounded, not ignored.  The image criterion is unchanged (|d| <= 1e-4 on >= 99.9 % of the pixels); losses
+    rel 1e-4 (one pixel whose shadow tap rounds the other way moves the photometric mean by ~1e-5 relative) and gradients rel-L2
+    <= 1e-2: a pixel float32 cannot decide moves a gradient by ~1/sqrt(#pixels) — the float32 ORACLE differs from the float64 one by
+    2e-3 on the same inputs — so an error CONFINED to edge / texel-boundary / tap-boundary pixels larger than that still fails here."""
+    case = make_fit_case("hand", T=2, S=512, B=2, seed=0, device=DEV)
+    eng = case["eng"]
+    eng.draw_texture_offsets()
+    fid = torch.tensor([1, 0])
+    P, loss, total, aux, _ = oracle_step(case, fid)
+    keys = [k for k in ORACLE_KEYS if k != "wrist_pose"]
+    for keep in (True, False):
+        eng.keep_image = keep
+        lv = engine_eval(case, fid)
+        _check_losses(lv, loss, tol=1e-4)
+        if keep:
+            _check_images(eng, aux, 2)
+        _check_grads(eng, P, keys, tol=1e-2, tag=f"512 hand UNMASKED keep_image={keep}")
+
+
 def test_c2_reference_batch_18():
     """B = 18 (the reference's DataLoader batch, optimize_sequence.py:396) incl. a partial last batch of 36 % 18 ... = here 7 frames"""
     case = make_fit_case("hand", T=25, S=128, B=18, seed=1, device=DEV)
     eng = case["eng"]
-    assert mask_ambiguous_pixels(case) < 0.10
+    check_removed("c2_hand_128_b18", mask_ambiguous_pixels(case))
     eng.keep_image = False
     eng.draw_texture_offsets()
     for fid in (torch.arange(18), torch.arange(18, 25)):          # full batch, then the ragged tail (runs with B = 7)
@@ -85,7 +107,7 @@ def test_c2_reference_batch_18():
 def test_c5_arm_1024_b1_vs_fp64_oracle():
     case = make_fit_case("arm", T=1, S=1024, B=1, seed=0, device=DEV)
     eng = case["eng"]
-    assert mask_ambiguous_pixels(case) < 0.10
+    check_removed("c5_arm_1024_b1", mask_ambiguous_pixels(case))
     eng.draw_texture_offsets()
     fid = torch.tensor([0])
     P, loss, total, aux, _ = oracle_step(case, fid)
@@ -97,6 +119,69 @@ def test_c5_arm_1024_b1_vs_fp64_oracle():
             _check_images(eng, aux, 1)
             assert 0.02 < (eng.s["face_c"][:1] >= 0).float().mean().item() < 0.9
         _check_grads(eng, P, ORACLE_KEYS, tag=f"1024 arm keep_image={keep}")
+
+
+def test_c5_arm_1024_b32_through_the_striding_kernels(monkeypatch):
+    """C5 at its real per-GPU batch: 32 frames of the SMPL-X arm mesh at 1024x1024 = 131 072 tile workgroups per launch, above the 64 k
+    limit where the rasteriser kernels switch to the capped, striding grid (csrc/raster.hip, raster_kernel<*, true>; depth backward).
+    (i) Oracle parity on 2 of the 32 frames: every loss term that reaches a per-frame parameter row (pose, cam, rot, trans, wrist_pose)
+    is a mean over the batch of per-frame terms, so row f of the batch gradient x 32 is the gradient of the ONE-frame step on frame f,
+    which the float64 oracle evaluates (rel-L2 <= 1e-3, the two frames' float32-undecidable pixels out of the mask as everywhere).
+    (ii) The whole batch against the same launch forced onto the plain 131 072-workgroup grid (HARP_RASTER_LOOP=0): losses and every
+    gradient agree up to the order of the float atomics.  (iii) Size-independent properties of all 32 frames."""
+    from tests._scene import ambiguous_pixels
+    T = B = 32
+    case = make_fit_case("arm", T=T, S=1024, B=B, seed=0, device=DEV)
+    eng = case["eng"]
+    assert B * (1024 // 64) ** 2 * 16 > 65536               # tile_grid(B, nsx): the striding kernels are what runs by default
+    frames = (3, 17)
+    P, model, targets = oracle_inputs(case, torch.float64)
+    y_col = case["targets"]["y_sil_col"].clone()
+    removed = []
+    for f in frames:
+        amb, aux = ambiguous_pixels(P, model, case["topo"], 1024, case["focal"], [f], targets["y_true"], use_arm=True)
+        y_col[f][amb[0]] = 0.0
+        removed.append(amb.sum().item() / max((aux["pix_to_face"][..., 0] >= 0).sum().item(), 1))
+    check_removed("c5_arm_1024_b32", max(removed))
+    case["targets"]["y_sil_col"] = y_col
+    eng.set_targets(case["targets"]["y_true"], case["targets"]["y_sil"], y_col)
+    eng.draw_texture_offsets()
+    fid = torch.arange(T)
+    res = {}
+    for mode in (None, "0"):
+        if mode is None:
+            monkeypatch.delenv("HARP_RASTER_LOOP", raising=False)
+        else:
+            monkeypatch.setenv("HARP_RASTER_LOOP", mode)
+        for keep in (True, False):
+            eng.keep_image = keep
+            lv = engine_eval(case, fid)
+            res[(mode, keep)] = (lv, eng.g_buf.clone())
+            if mode is None and keep:
+                a, fc, rgb = eng.s["alpha"], eng.s["face_c"], eng.s["rgb"]
+                assert (a >= 0).all() and (a <= 1).all() and (fc >= -1).all() and (fc < eng.topo.F).all()
+                cov = fc >= 0
+                assert 0.02 < cov.float().mean().item() < 0.9 and (a[cov] > 0.49).all() and (rgb[~cov] == 1.0).all()
+                assert torch.isfinite(rgb).all() and torch.isfinite(eng.g_buf).all() and all(np.isfinite(v) for v in lv.values())
+    monkeypatch.delenv("HARP_RASTER_LOOP", raising=False)
+    ref_l, ref_g = res[("0", True)]
+    for key, (lv, g) in res.items():
+        for k, v in ref_l.items():
+            assert abs(v - lv[k]) <= 2e-6 * abs(v) + 1e-12, (key, k, v, lv[k])
+        assert rel(g.cpu(), ref_g.cpu()) < 1e-5, key
+    # (i) per-frame rows against the float64 oracle's one-frame steps
+    eng.keep_image = False
+    engine_eval(case, fid)
+    rows = ("pose", "cam", "rot", "trans", "wrist_pose")
+    got = {k: eng.grads[k].detach().cpu().double().clone() for k in rows}
+    targets["y_sil_col"] = y_col.double()
+    for f in frames:
+        for k in ORACLE_KEYS:
+            P[k].grad = None
+        oracle_step(case, torch.tensor([f]), P=P, model=model, targets=targets)
+        worst = {k: rel(got[k][f] * B, P[k].grad[f]) for k in rows}
+        print(f"[gradient rel-L2 vs fp64 oracle] C5 B=32 frame {f}:", {k: f"{v:.1e}" for k, v in worst.items()})
+        assert all(v < GRAD_TOL for v in worst.values()), (f, worst)
 
 
 def test_c1_raw_mano_mesh_silhouette_only():
@@ -141,7 +226,7 @@ def test_appearance_only_stage_geometry_gradients():
     hidden under the 7x-weighted silhouette gradient here"""
     case = make_fit_case("hand", T=2, S=256, B=2, seed=3, device=DEV)
     eng = case["eng"]
-    assert mask_ambiguous_pixels(case) < 0.10
+    check_removed("app_only_hand_256_b2", mask_ambiguous_pixels(case))
     eng.draw_texture_offsets()
     fid = torch.tensor([0, 1])
     for keep in (True, False):
@@ -212,7 +297,7 @@ def test_ten_steps_gradient_parity_along_the_oracle_trajectory():
             for k in keys:
                 eng.params[k].copy_(P[k].detach().float().to(DEV))
         case["targets"]["y_sil_col"] = y_col0.clone()
-        assert mask_ambiguous_pixels(case) < 0.10         # the pixels float32 cannot decide, at THIS step's parameters
+        check_removed("ten_steps_hand_128", mask_ambiguous_pixels(case))     # the pixels float32 cannot decide, at THIS step's parameters
         targets["y_sil_col"] = case["targets"]["y_sil_col"].double()
         eng.draw_texture_offsets()
         lv = engine_eval(case, fid)

@@ -23,8 +23,8 @@ def _free_port():
     return p
 
 
-def _launch(world, out, steps):
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=ROOT)
+def _launch(world, out, steps, rccl=False):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=ROOT, HARP_WORKER_RCCL="1" if rccl else "0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "dist_worker.py"), out, str(steps), "4"]
     for attempt in range(2):          # the probed port can be taken between the probe and the rendezvous: one retry on another port
@@ -36,12 +36,7 @@ def _launch(world, out, steps):
     return torch.load(out)
 
 
-@pytest.mark.timeout(1800)
-def test_two_ranks_equal_one_rank_global_batch(tmp_path):
-    """2 ranks x 2 frames/step == 1 rank x 4 frames/step: mean-type terms average over ranks (grad_scale = 1/world), frame-independent
-    regularisers are counted once, texture offsets come from the same seed, targets are indexed through target_offset"""
-    two = _launch(2, str(tmp_path / "w2.pt"), 3)
-    one = _launch(1, str(tmp_path / "w1.pt"), 3)
+def _assert_equals_one_rank(two, one):
     assert two["consistent"]
     # the rank-0 batches of the 2-rank job are frames {0,1},{1,0},{0,1}..., rank 1 {2,3},{3,2}: the 1-rank job with B = 4 walks
     # (arange(4) + it) % 4 — the same SET of frames every step, so per-step gradients agree up to float atomics
@@ -61,6 +56,31 @@ def test_two_ranks_equal_one_rank_global_batch(tmp_path):
         o -= two["opt_lo"]
         d = (p2[o:o + n] - p1[o:o + n]).abs()
         assert d.mean() < 2e-5 and (d > 1e-3).double().mean() < max(2e-4, 4.0 / n), (k, d.mean().item(), d.max().item())
+
+
+@pytest.mark.timeout(1800)
+def test_two_ranks_equal_one_rank_global_batch(tmp_path):
+    """2 ranks x 2 frames/step == 1 rank x 4 frames/step: mean-type terms average over ranks (grad_scale = 1/world), frame-independent
+    regularisers are counted once, texture offsets come from the same seed, targets are indexed through target_offset"""
+    two = _launch(2, str(tmp_path / "w2.pt"), 3)
+    one = _launch(1, str(tmp_path / "w1.pt"), 3)
+    _assert_equals_one_rank(two, one)
+
+
+@pytest.mark.timeout(1800)
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs >= 2 GPUs: one RCCL rank per device (self-starting on the first multi-GPU box)")
+@pytest.mark.parametrize("world", [2, 4])
+def test_rccl_ranks_on_real_devices(tmp_path, world):
+    """The production N > 1 path on real devices, no edits needed when a multi-GPU box appears: one rank per GPU, RcclComm built from the
+    process group, `harp_allreduce_flat` captured into every rank's step hipGraph (early all-reduce of the map gradients on the
+    communication stream + remainder before Adam).  Same assertions as the shared-GPU gloo run: the all-reduced gradient equals the
+    1-rank global-batch gradient, regularisers counted once, parameters after 3 steps, all ranks bit-identical."""
+    if torch.cuda.device_count() < world:
+        pytest.skip(f"{world} ranks need {world} GPUs")
+    many = _launch(world, str(tmp_path / f"r{world}.pt"), 3, rccl=True)
+    one = _launch(1, str(tmp_path / "w1.pt"), 3)
+    assert many["transport"].startswith("rccl") and many["graph_captured"]
+    _assert_equals_one_rank(many, one)
 
 
 def test_rccl_allreduce_c_abi_and_graph_capture():
@@ -100,4 +120,9 @@ def test_rccl_allreduce_c_abi_and_graph_capture():
         assert (a.params[k] - b.params[k]).abs().max().item() < 2e-3, k
     d = (a.params["texture"] - b.params["texture"]).abs()
     assert d.mean().item() < 2e-5 and (d > 1e-3).float().mean().item() < 1e-3
+    assert a.comm is comm and a._graphs
     comm.destroy()
+    assert a.comm is None and not a._graphs and not comm.handle       # graphs holding the raw ncclComm_t are dropped with it
+    comm.destroy()                                                    # idempotent
+    with pytest.raises(RuntimeError):
+        comm.allreduce(y)

@@ -91,3 +91,52 @@ def test_normal_renderer_and_capped_silhouette(geom):
     p2, _, _, d2 = P.rasterize_meshes(ndc.double(), faces, S, ops.SIL_BLUR, 2)
     a_ref = P.sigmoid_alpha_blend(p2, d2, 1e-7)
     assert ((sil.cpu().double() - a_ref).abs() > 1e-4).float().mean() < 1e-3
+
+
+def test_normal_renderer_through_the_normal_map(geom):
+    """`vis_normal` with materials that carry a normal map (renderer_helper.py:226-232): K=10 fragments -> TexturesUV.sample_textures ->
+    PBRMaterials.apply_normal_map -> flip / [0,1] map -> softmax blend, against the oracle's restatement of the same chain"""
+    from harp_amd.renderer import renderer_helper as RH
+    from harp_amd.renderer.pbr_materials import PBRMaterials
+    from harp_amd.structures import Meshes, TexturesUV
+    from harp_amd.utils.visualize import MeshSubdivider
+    from oracle import harp_ref as H, p3d_like as P
+    sc, ndc, v, S, focal = geom
+    sub = MeshSubdivider(torch.from_numpy(sc["tpl"]["faces0"]), 778, DEV)
+    mesh = Meshes(v.float().to(DEV), sub.faces, None, sub.topo)
+    R, T = H.camera_RT(sc["seq"]["cam"][:2], S, focal)
+    g = torch.Generator().manual_seed(9)
+    nmap = torch.nn.functional.normalize(torch.tensor([0., 0., 1.]).repeat(1, 512, 512, 1) + torch.randn(1, 512, 512, 3, generator=g) * 0.2, dim=-1)
+    vuv, fuv = torch.from_numpy(sc["tpl"]["verts_uvs"]), torch.from_numpy(sc["tpl"]["faces_uvs"]).long()
+    mats = PBRMaterials(shininess=0.0, normal_maps=TexturesUV(maps=nmap.repeat(2, 1, 1, 1).to(DEV), faces_uvs=fuv, verts_uvs=vuv))
+    kw = dict(principal_point=torch.Tensor([(S / 2., S / 2.)]), focal_length=focal, T=T.to(DEV), R=R.to(DEV), image_size=torch.Tensor([(S, S)]))
+    img = RH.NormalRenderer(S, 10)(mesh, materials=mats, **kw)
+    faces = sc["topo"]["faces"]
+    p2f, z, b, d = P.rasterize_meshes(ndc.double(), faces, S, 0.0, 10)
+    vn = P.verts_normals(v.double(), faces)
+    pn = P.interpolate_face_attributes(p2f, b, vn[:, faces].reshape(-1, 3, 3))
+    nm = P.sample_textures_uv(nmap.double().repeat(2, 1, 1, 1), vuv.double(), fuv, p2f, b, faces.shape[0])
+    pn = H.apply_normal_map(pn, nm) * torch.tensor([1.0, -1.0, -1.0], dtype=torch.float64)
+    ref = P.softmax_rgb_blend((pn + 1.0) / 2.0, p2f, z, d)
+    dimg = (img.cpu().double() - ref).abs().max(-1).values
+    assert dimg.mean() < 2e-4 and (dimg > 5e-3).float().mean() < 1e-2, (dimg.mean().item(), (dimg > 5e-3).float().mean().item())
+    assert (img[..., :3].cpu() - RH.NormalRenderer(S, 10)(mesh, **kw)[..., :3].cpu()).abs().max() > 0.05      # the map really perturbs the normals
+
+
+@pytest.mark.parametrize("kind,S", [("hand", 512), ("arm", 1024)])
+def test_depth_complexity_stays_below_the_silhouette_cap(kind, S):
+    """The fused soft-silhouette kernel lets EVERY face within the blur radius of a pixel contribute, the reference keeps the 50 nearest
+    (renderer_helper.py:52-55).  Counting the fragments per pixel of the bench scenes (same generator as bench.py) with the
+    fragment-level op (64 slots): the count stays far below 50, so the cap cannot bind and both give the same alpha."""
+    import bench
+    from harp_amd import ops
+    eng, _ = bench.build_engine(0, 1, torch.device(DEV), T=8, img=S, B=8, kind=kind)
+    eng.fid.copy_(torch.arange(8, dtype=torch.int32, device=DEV)); eng.tfid.zero_()
+    eng.forward_backward(True, True)
+    torch.cuda.synchronize()
+    worst = 0
+    for b in range(8):
+        p2f, _, _, _ = ops.rasterize_fragments(eng.s["ndc_c"][b:b + 1].clone(), eng.topo.faces, S, ops.SIL_BLUR, 64)
+        worst = max(worst, int((p2f >= 0).sum(-1).max()))
+    print(f"[depth complexity] {kind} {S}x{S}: at most {worst} faces within the blur radius of one pixel (cap 50)")
+    assert 2 <= worst < 40, worst

@@ -1,14 +1,16 @@
 """-m gpu parity tests: HIP path (through the C ABI) vs the CPU oracle on the same seeded inputs.
 
-Tolerances (fp32): images |d| <= 1e-4 on >= 99.9 % of pixels, identical nearest-face ids except near-tie /
-on-edge pixels (<= 1e-4 of the pixels), scalar losses rel 1e-5, gradients rel-L2 <= 2e-3 (float atomics + the conditioning of
-the soft-silhouette gradient: the oracle's own fp32-vs-fp64 gradients differ by up to 1e-3), parameters after Adam steps
-abs 1e-3 (one Adam step moves a parameter by ~lr)."""
+Tolerances: images |d| <= 1e-4 on >= 99.9 % of pixels, identical nearest-face ids except near-tie /
+on-edge pixels (<= 1e-4 of the pixels), scalar losses rel 1e-5, gradients of the full step rel-L2 <= 1e-3 against the oracle
+evaluated in FLOAT64 with the float32-undecidable pixels out of the photometric mask (tests/_scene.py; the fraction removed is
+printed and bounded per case) — the stand-alone silhouette op, compared with the float32 oracle, keeps 2e-3 —, parameters after
+Adam steps abs 1e-3 (one Adam step moves a parameter by ~lr)."""
+GRAD_TOL = 1e-3
 import numpy as np
 import pytest
 import torch
 
-from tests._scene import make_scene, mask_scene_targets, oracle_params, rel
+from tests._scene import check_removed, make_scene, mask_scene_targets, oracle_params, rel, scene_f64
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -99,22 +101,24 @@ def test_full_step_losses_grads_and_adam(sc):
     T, S, B = sc["T"], sc["S"], 2
     eng = FitEngine(sc["model_np"], sc["topo_np"], sc["tpl"]["verts_uvs"], sc["tpl"]["faces_uvs"], sc["uv_mask"].float(), sc["seq"], S,
                     sc["focal"], B, device=DEV)
-    tg = sc["targets"]
-    eng.set_targets(tg["y_true"], tg["y_sil"], tg["y_sil_col"])
     with torch.no_grad():
         eng.params["verts_disps"].copy_(torch.randn(3093, 1) * 0.001)
         eng.params["texture"].copy_(torch.rand(1, 512, 512, 3) * 0.5 + 0.3)
         eng.params["normal_map"].copy_(torch.tensor([0., 0., 1.]).repeat(1, 512, 512, 1) + torch.randn(1, 512, 512, 3) * 0.1)
         eng.params["trans"].copy_(torch.randn(T, 3) * 0.01)
-    eng.compute_reference_mesh()
-    P = oracle_params(sc, eng.params)
     fid = torch.tensor([2, 0])
+    tg, removed = mask_scene_targets(sc, eng.params, fid)          # float32-undecidable pixels leave the photometric mask of BOTH sides
+    check_removed("parity_full_step_128", removed)
+    eng.set_targets(tg["y_true"], tg["y_sil"], tg["y_sil_col"])
+    eng.compute_reference_mesh()
+    P = oracle_params(sc, eng.params, torch.float64)               # the oracle runs in float64: the exact result, not another fp32 rounding
+    model64, tg64 = scene_f64(sc, tg)
     eng.fid.copy_(fid.int().to(DEV)); eng.tfid.copy_(fid.int().to(DEV))
     eng.auto_draw = False; eng.draw_texture_offsets(); eng.set_stage(True, True)
     with torch.no_grad():
-        _, rv = H.prepare_mesh(P, torch.tensor([0]), sc["model"], sc["topo"])
+        _, rv = H.prepare_mesh(P, torch.tensor([0]), model64, sc["topo"])
     assert (eng.ref_verts.cpu() - rv[0]).abs().max() < 1e-5
-    loss, total, aux = H.step_losses(P, fid, sc["model"], sc["topo"], tg, S, sc["focal"], rv, eng.dist_albedo.cpu().long(),
+    loss, total, aux = H.step_losses(P, fid, model64, sc["topo"], tg64, S, sc["focal"], rv, eng.dist_albedo.cpu().long(),
                                      eng.dist_normal.cpu().long())
     total.backward()
     eng.forward_backward(True, True)
@@ -124,9 +128,16 @@ def test_full_step_losses_grads_and_adam(sc):
         assert abs(lv[k] - loss[k].item()) <= 1e-5 * abs(loss[k].item()) + 1e-8, (k, lv[k], loss[k].item())
     assert ((eng.s["alpha"].cpu() - aux["y_sil_pred"]).abs() > 1e-4).float().mean() < 1e-3
     assert ((eng.s["rgb"].cpu() - aux["y_pred"]).abs().max(-1).values > 1e-4).float().mean() < 1e-3
-    for k in ("pose", "cam", "verts_disps", "shape", "light_positions", "amb_ratio", "texture", "normal_map", "rot", "trans"):
-        assert rel(eng.grads[k].cpu(), P[k].grad) < 2e-3, (k, rel(eng.grads[k].cpu(), P[k].grad))
-    # ---- 3 optimiser steps (eager, then hipGraph capture + replay) vs torch.optim.Adam on the oracle
+    worst = {k: rel(eng.grads[k].cpu().double(), P[k].grad) for k in ("pose", "cam", "verts_disps", "shape", "light_positions", "amb_ratio",
+                                                                      "texture", "normal_map", "rot", "trans")}
+    print("[gradient rel-L2 vs fp64 oracle] 128 full step:", {k: f"{v:.1e}" for k, v in worst.items()})
+    assert all(v < GRAD_TOL for v in worst.values()), worst
+    # ---- 3 optimiser steps (eager, then hipGraph capture + replay) vs torch.optim.Adam on the (float32) oracle
+    tg = sc["targets"]
+    eng.set_targets(tg["y_true"], tg["y_sil"], tg["y_sil_col"])
+    P = oracle_params(sc, eng.params)
+    with torch.no_grad():
+        _, rv = H.prepare_mesh(P, torch.tensor([0]), sc["model"], sc["topo"])
     opt_c = torch.optim.Adam([{"params": [P["pose"], P["cam"]], "lr": 1e-3}, {"params": [P["verts_disps"], P["shape"]], "lr": 1e-3}])
     opt_a = torch.optim.Adam([P["light_positions"], P["amb_ratio"], P["texture"], P["normal_map"]], lr=1e-2)
     eng.auto_draw = True                       # from here on every step draws fresh offsets itself (inside the graph)
@@ -152,19 +163,29 @@ def test_stage_gating_and_no_shadow(sc):
     """coarse-only / appearance-only stages (optimize_sequence.py:507-515) and the self_shadow=False renderer."""
     from harp_amd.engine import FitEngine
     from oracle import harp_ref as H
+    from tests._scene import ambiguous_pixels
     S, B = sc["S"], 2
-    tg = sc["targets"]
     for shadow, coarse, app in ((True, True, False), (True, False, True), (False, True, True)):
         eng = FitEngine(sc["model_np"], sc["topo_np"], sc["tpl"]["verts_uvs"], sc["tpl"]["faces_uvs"], sc["uv_mask"].float(), sc["seq"], S,
                         sc["focal"], B, device=DEV, self_shadow=shadow)
-        eng.set_targets(tg["y_true"], tg["y_sil"], tg["y_sil_col"])
-        P = oracle_params(sc, eng.params)
         fid = torch.tensor([1, 2])
+        P = oracle_params(sc, eng.params, torch.float64)
+        model64, _ = scene_f64(sc, sc["targets"])
+        tg = dict(sc["targets"])
+        if app:       # float32-undecidable pixels (of THIS renderer: with or without the shadow pass) leave the photometric mask
+            amb, aux = ambiguous_pixels(P, model64, sc["topo"], S, sc["focal"], fid, tg["y_true"], self_shadow=shadow)
+            col = tg["y_sil_col"].clone()
+            for i, f in enumerate(fid.tolist()):
+                col[f][amb[i]] = 0.0
+            tg["y_sil_col"] = col
+            check_removed(f"parity_stage_128_shadow{int(shadow)}", amb.sum().item() / max((aux["pix_to_face"][..., 0] >= 0).sum().item(), 1))
+        eng.set_targets(tg["y_true"], tg["y_sil"], tg["y_sil_col"])
+        tg64 = {k: v.double() for k, v in tg.items()}
         eng.fid.copy_(fid.int().to(DEV)); eng.tfid.copy_(fid.int().to(DEV))
         eng.auto_draw = False; eng.draw_texture_offsets(); eng.set_stage(coarse, app)
         with torch.no_grad():
-            _, rv = H.prepare_mesh(P, torch.tensor([0]), sc["model"], sc["topo"])
-        loss, total, _ = H.step_losses(P, fid, sc["model"], sc["topo"], tg, S, sc["focal"], rv, eng.dist_albedo.cpu().long(),
+            _, rv = H.prepare_mesh(P, torch.tensor([0]), model64, sc["topo"])
+        loss, total, _ = H.step_losses(P, fid, model64, sc["topo"], tg64, S, sc["focal"], rv, eng.dist_albedo.cpu().long(),
                                        eng.dist_normal.cpu().long(), coarse=coarse, app=app, self_shadow=shadow)
         total.backward()
         eng.forward_backward(coarse, app)
@@ -173,8 +194,9 @@ def test_stage_gating_and_no_shadow(sc):
         for k, v in loss.items():
             assert abs(lv[k] - v.item()) <= 1e-5 * abs(v.item()) + 1e-8, (shadow, coarse, app, k)
         keys = (["pose", "cam", "shape"] if coarse else []) + (["texture", "light_positions"] if app else [])
-        for k in keys:
-            assert rel(eng.grads[k].cpu(), P[k].grad) < 2e-3, (shadow, coarse, app, k, rel(eng.grads[k].cpu(), P[k].grad))
+        worst = {k: rel(eng.grads[k].cpu().double(), P[k].grad) for k in keys}
+        print(f"[gradient rel-L2 vs fp64 oracle] 128 stage shadow={shadow} coarse={coarse} app={app}:", {k: f"{v:.1e}" for k, v in worst.items()})
+        assert all(v < GRAD_TOL for v in worst.values()), (shadow, coarse, app, worst)
 
 
 def test_full_size_properties():
@@ -279,11 +301,20 @@ def test_full_step_smplx_arm():
             eng.params[k].copy_(P0[k])
     eng.compute_reference_mesh()
     tg = dict(y_true=torch.rand(T, S, S, 3), y_sil=(torch.rand(T, S, S) > 0.5).float(), y_sil_col=(torch.rand(T, S, S) > 0.4).float())
-    eng.set_targets(tg["y_true"], tg["y_sil"], tg["y_sil_col"])
     keys = ("pose", "cam", "verts_disps", "shape", "light_positions", "amb_ratio", "texture", "normal_map", "rot", "trans", "wrist_pose")
-    P = {k: eng.params[k].detach().cpu().clone().requires_grad_() for k in keys}
-    P.update(verts_uvs=torch.from_numpy(tpl["verts_uvs"]), faces_uvs=torch.from_numpy(tpl["faces_uvs"]).long(), uv_mask=uv_mask, init_joints=seq["joints"])
+    # the oracle runs in float64; pixels float32 cannot decide leave the photometric mask of both sides (tests/_scene.py)
+    from tests._scene import ambiguous_pixels
+    P = {k: eng.params[k].detach().cpu().double().clone().requires_grad_() for k in keys}
+    P.update(verts_uvs=torch.from_numpy(tpl["verts_uvs"]).double(), faces_uvs=torch.from_numpy(tpl["faces_uvs"]).long(), uv_mask=uv_mask,
+             init_joints=seq["joints"].double())
+    mt = {k: (v.double() if v.is_floating_point() else v) for k, v in mt.items()}
     fid = torch.tensor([2, 0])
+    amb, aux_a = ambiguous_pixels(P, mt, topo, S, focal, fid, tg["y_true"], use_arm=True)
+    for i, f in enumerate(fid.tolist()):
+        tg["y_sil_col"][f][amb[i]] = 0.0
+    check_removed("parity_arm_128", amb.sum().item() / max((aux_a["pix_to_face"][..., 0] >= 0).sum().item(), 1))
+    eng.set_targets(tg["y_true"], tg["y_sil"], tg["y_sil_col"])
+    tg = {k: v.double() for k, v in tg.items()}
     eng.fid.copy_(fid.int().to(DEV)); eng.tfid.copy_(fid.int().to(DEV))
     eng.auto_draw = False; eng.draw_texture_offsets(); eng.set_stage(True, True)
     with torch.no_grad():
@@ -296,8 +327,9 @@ def test_full_step_smplx_arm():
     assert 0.02 < (eng.s["face_c"] >= 0).float().mean() < 0.9
     for k in LOSS_NAMES:
         assert abs(lv[k] - loss[k].item()) <= 2e-5 * abs(loss[k].item()) + 1e-8, (k, lv[k], loss[k].item())
-    for k in keys:
-        assert rel(eng.grads[k].cpu(), P[k].grad) < 3e-3, (k, rel(eng.grads[k].cpu(), P[k].grad))
+    worst = {k: rel(eng.grads[k].cpu().double(), P[k].grad) for k in keys}
+    print("[gradient rel-L2 vs fp64 oracle] 128 arm full step:", {k: f"{v:.1e}" for k, v in worst.items()})
+    assert all(v < GRAD_TOL for v in worst.values()), worst
     # opt_arm_pose: rot and wrist_pose are inside the coarse Adam span and move; trans never does
     before = {k: eng.params[k].clone() for k in ("rot", "wrist_pose", "trans")}
     eng.auto_draw = True
@@ -560,22 +592,24 @@ def test_perceptual_term_gradients(sc):
     LW = [1, 1 / 16, 1 / 8, 1 / 4, 1]
     eng = FitEngine(sc["model_np"], sc["topo_np"], sc["tpl"]["verts_uvs"], sc["tpl"]["faces_uvs"], sc["uv_mask"].float(), sc["seq"], S,
                     sc["focal"], B, device=DEV)
-    tg = sc["targets"]
-    eng.set_targets(tg["y_true"], tg["y_sil"], tg["y_sil_col"])
     g = torch.Generator().manual_seed(5)
     with torch.no_grad():
         eng.params["texture"].copy_(torch.rand(1, 512, 512, 3, generator=g) * 0.5 + 0.3)
         eng.params["trans"].copy_(torch.randn(T, 3, generator=g) * 0.01)
+    fid = torch.tensor([1, 2])
+    # float32-undecidable pixels leave the mask of both sides (tests/_scene.py); the oracle (renderer AND VGG) runs in float64
+    tg, removed = mask_scene_targets(sc, eng.params, fid)
+    check_removed("parity_vgg_128", removed)
+    eng.set_targets(tg["y_true"], tg["y_sil"], tg["y_sil_col"])
     eng.compute_reference_mesh()
     vgg = Vgg16Features(layers_weights=LW, weights="random", seed=2)
     sd = {k: v.clone() for k, v in vgg.state_dict().items()}
-    filters = {int(k.split(".")[1]): (sd[k], sd[k.replace("weight", "bias")]) for k in sd if k.endswith("weight")}
-    P = oracle_params(sc, eng.params)
-    fid = torch.tensor([1, 2])
-    aux = {}
-    verts = H.prepare_mesh(P, fid, sc["model"], sc["topo"])[1]
+    filters = {int(k.split(".")[1]): (sd[k].double(), sd[k.replace("weight", "bias")].double()) for k in sd if k.endswith("weight")}
+    P = oracle_params(sc, eng.params, torch.float64)
+    model64, tg64 = scene_f64(sc, tg)
+    verts = H.prepare_mesh(P, fid, model64, sc["topo"])[1]
     y_pred = H.render_rgb(verts, sc["topo"], P, P["cam"][fid], S, sc["focal"], self_shadow=True)
-    ref = H.perceptual_loss(filters, LW, y_pred, tg["y_true"][fid], tg["y_sil_col"][fid])
+    ref = H.perceptual_loss(filters, LW, y_pred, tg64["y_true"][fid], tg64["y_sil_col"][fid])
     ref.backward()
     for cached in (True, False):
         eng.set_perceptual(vgg, weight=1.0, cache_bytes=(64 << 30) if cached else 0)
@@ -588,9 +622,10 @@ def test_perceptual_term_gradients(sc):
         lv = eng.losses()
         assert abs(lv["vgg"] - ref.item()) <= 2e-5 * abs(ref.item()), (lv["vgg"], ref.item())
         # L1 of feature differences: where a feature difference is at fp32-noise level its sign (= its whole gradient contribution)
-        # depends on the convolution's summation order (MIOpen vs the CPU), hence a looser bound than for the other terms
-        for k in ("texture", "normal_map", "light_positions", "amb_ratio", "pose", "cam", "shape"):
-            assert rel(eng.grads[k].cpu(), P[k].grad) < 2e-2, (cached, k, rel(eng.grads[k].cpu(), P[k].grad))
+        # depends on the convolution's summation order (MIOpen vs float64 on the CPU): 5e-3 instead of the 1e-3 of the other terms
+        worst = {k: rel(eng.grads[k].cpu().double(), P[k].grad) for k in ("texture", "normal_map", "light_positions", "amb_ratio", "pose", "cam", "shape")}
+        print(f"[gradient rel-L2 vs fp64 oracle] VGG term cached={cached}:", {k: f"{v:.1e}" for k, v in worst.items()})
+        assert all(v < 5e-3 for v in worst.values()), (cached, worst)
     # full steps with the term on: captured into the step's hipGraph (torch / MIOpen convolutions and their autograd included) — same
     # parameters as eager steps from the same state
     eng.set_stage(False, True)
@@ -660,7 +695,7 @@ def test_losses_with_empty_supertiles():
             eng.params["normal_map"].copy_(torch.tensor([0., 0., 1.]).repeat(1, 512, 512, 1) + torch.randn(1, 512, 512, 3, generator=g) * 0.1)
         if ref is None:     # pixels whose colour is not decided at float32 precision leave the photometric mask (tests/_scene.py)
             tg, removed = mask_scene_targets(sc, eng.params, fid)
-            assert removed < 0.10
+            check_removed("parity_empty_supertiles_256", removed)
         eng.set_targets(tg["y_true"], tg["y_sil"], tg["y_sil_col"])
         eng.keep_image = keep
         eng.fid.copy_(fid.int().to(DEV)); eng.tfid.copy_(fid.int().to(DEV))
@@ -724,3 +759,72 @@ def test_arm_engine_loss_only_mode():
         eng.step(None, True, True)
     torch.cuda.synchronize()
     assert torch.isfinite(eng.p_buf).all()
+
+
+def test_striding_grid_counts_empty_supertiles_once(monkeypatch):
+    """The capped, striding rasteriser grid (csrc/raster.hip, LOOP) rounds the number of super-tiles that hold faces up to a multiple
+    of 8 (one slot per XCD); the empty super-tiles in that round-up go through the tile path, which adds their entry of the static
+    background table to the fused silhouette L1 — the trailing table loop must not add them again (round-2 advisor finding: up to 7
+    empty super-tiles were counted twice whenever nact % 8 != 0; only the reported loss was wrong).  The targets here are non-zero in
+    super-tiles that hold no face, and at least one of the two batch sizes has nact % 8 != 0."""
+    from harp_amd.engine import FitEngine
+    sc = make_scene(T=2, S=256, seed=4)
+    tg = sc["targets"]
+    assert tg["y_sil"].mean() > 0.3                        # random targets: every super-tile has a non-zero background sum
+    odd = 0
+    for B in (1, 2):
+        res = {}
+        for mode in ("0", "8"):
+            monkeypatch.setenv("HARP_RASTER_LOOP", mode)
+            eng = FitEngine(sc["model_np"], sc["topo_np"], sc["tpl"]["verts_uvs"], sc["tpl"]["faces_uvs"], sc["uv_mask"].float(), sc["seq"], 256,
+                            sc["focal"], B, device=DEV)
+            eng.set_targets(tg["y_true"], tg["y_sil"], tg["y_sil_col"])
+            eng.keep_image = False                         # sparse outputs + background tables: the path with the trailing loop
+            fid = torch.arange(B, dtype=torch.int32, device=DEV)
+            eng.fid.copy_(fid); eng.tfid.copy_(fid)
+            eng.auto_draw = False; eng.draw_texture_offsets(); eng.set_stage(True, True)
+            eng.forward_backward(True, True)
+            torch.cuda.synchronize()
+            nact = int(eng.s["ws_c"][-256:].view(torch.int32)[0])
+            assert 0 < nact < B * 16, nact
+            res[mode] = (eng.losses(), eng.g_buf.clone().cpu())
+        odd += nact % 8 != 0
+        for k, v in res["0"][0].items():
+            assert abs(v - res["8"][0][k]) <= 2e-6 * abs(v) + 1e-12, (B, nact, k, v, res["8"][0][k])
+        assert rel(res["8"][1], res["0"][1]) < 1e-5
+    assert odd > 0, "neither batch size exercises the rounded-up slots"
+
+
+def test_light_camera_incl_look_at_replacement_branch():
+    """process_info_for_shadow + look_at_rotation (renderer_helper.py:454-468) of the HIP path — one device
+    function shared by harp_light_setup_fwd/bwd and the fused mesh chain (csrc/chain_body.h:light_cam) — against the float64 oracle,
+    forward and backward, for: a generic light, a light EXACTLY on the vertical through the centroid (x = y = 0, the reference's
+    result), one ~4e-8 rad off it (|up x z| below the 5e-3 isclose test: look_at_rotation's replacement branch x = normalize(y x z)),
+    and one 1e-6 off (eps-clamped normalisation, no replacement)."""
+    from harp_amd import _lib
+    from oracle import harp_ref as H
+    L, p = _lib.lib(), _lib.ptr
+    c = torch.tensor([[0.03, -0.02, 0.9], [0., 0., 0.], [0., 0., 0.], [0., 0., 0.]])
+    lp = torch.tensor([[-0.5, -0.5, -0.5], [0., 0.8, 0.], [3e-8, 0.8, 1e-8], [1e-6, -0.8, 0.]])
+    B = 4
+    cd, ld_ = c.double().requires_grad_(), lp.double().requires_grad_()
+    R_o, T_o, _, _ = H.process_info_for_shadow(torch.tensor([[1.0, 0.0, 0.0]]).double().repeat(B, 1), ld_, cd, 128, 500.0)
+    g = torch.Generator().manual_seed(0)
+    wR, wT = torch.randn(B, 3, 3, generator=g, dtype=torch.float64), torch.randn(B, 3, generator=g, dtype=torch.float64)
+    ((R_o * wR).sum() + (T_o * wT).sum()).backward()
+    cg, lg = c.to(DEV).contiguous(), lp.to(DEV).contiguous()
+    R, T = torch.empty(B, 9, device=DEV), torch.empty(B, 3, device=DEV)
+    _lib.check(L.harp_light_setup_fwd(p(cg), p(lg), B, p(R), p(T), _lib.stream()), "light_setup_fwd")
+    torch.cuda.synchronize()
+    assert (R.cpu().double().view(B, 3, 3) - R_o.detach()).abs().max() < 2e-6, (R.cpu().view(B, 3, 3), R_o)
+    assert (T.cpu().double() - T_o.detach()).abs().max() < 5e-6
+    assert R_o[1, :, 0].abs().max() == 0 and R_o[1, :, 1].abs().max() == 0                  # exactly degenerate: x = y = 0, like the reference
+    assert abs(R_o[2, :, 0].norm().item() - 1) < 1e-9 and abs(R_o[2, :, 1].norm().item() - 1) < 1e-9      # replacement branch: proper unit axes again
+    g_lp, g_c, g_v = torch.zeros(B, 3, device=DEV), torch.zeros(B, 3, device=DEV), torch.zeros(B, 1, 3, device=DEV)
+    _lib.check(L.harp_light_setup_bwd(p(cg), p(lg), p(wR.float().reshape(B, 9).contiguous().to(DEV)), p(wT.float().contiguous().to(DEV)), B, 1,
+                                      p(g_lp), p(g_c), p(g_v), _lib.stream()), "light_setup_bwd")
+    torch.cuda.synchronize()
+    for b in range(B):
+        for got, ref, name in ((g_lp[b], ld_.grad[b], "light_pos"), (g_c[b], cd.grad[b], "centroid"), (g_v[b, 0], cd.grad[b], "verts")):
+            err = (got.cpu().double() - ref).norm().item() / (ref.norm().item() + 1e-30)
+            assert err < (2e-4 if b == 0 else 1e-3), (b, name, err, got.cpu(), ref)

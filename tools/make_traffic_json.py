@@ -23,15 +23,21 @@ def per_launch(path, counter):
     return {k: (tot[k] / len(disp[k]), len(disp[k])) for k in tot}
 
 
+# group -> parts; a part = tuple of ALTERNATIVE substrings of the kernel name (at least one must match a profiled kernel, otherwise the
+# script fails: in round 2 the rasteriser kernels gained a second template argument, "raster_kernel<1>" silently stopped matching and
+# the committed traffic file lost its rasteriser counters).  OPTIONAL groups may be absent (no such launch in the profiled command).
 GROUPS = {
-    "harp_shade_bwd": (("shade_bwd_wave_kernel", 1.0), ("shade_kernel<true>", 1.0)),
-    "harp_shade_fwd": (("shade_kernel<false>", 1.0),),
+    "harp_shade_bwd": (("shade_bwd_wave_kernel", "shade_bwd_face_kernel", "shade_kernel<true>"),),
+    "harp_shade_fwd": (("shade_kernel<false>",),),
     # face_setup / bin_faces / order_tiles run once per view: their per-launch averages are over both views already
-    "raster_cam_fwd(setup+bin+raster)": (("raster_kernel<1>", 1.0), ("face_setup_kernel", 1.0), ("bin_faces_kernel", 1.0), ("order_tiles_kernel", 1.0)),
-    "raster_light_fwd(setup+bin+raster)": (("raster_kernel<0>", 1.0), ("face_setup_kernel", 1.0), ("bin_faces_kernel", 1.0), ("order_tiles_kernel", 1.0)),
-    "harp_silhouette_bwd": (("raster_kernel<2>", 1.0),),
-    "harp_depth_bwd": (("depth_bwd_kernel", 1.0),),
+    "raster_cam_fwd(setup+bin+raster)": (("raster_kernel<1,",), ("face_setup_kernel",), ("bin_faces_kernel",), ("order_tiles_kernel",)),
+    "raster_light_fwd(setup+bin+raster)": (("raster_kernel<0,",), ("face_setup_kernel",), ("bin_faces_kernel",), ("order_tiles_kernel",)),
+    "raster_cam_fwd(raster kernel only)": (("raster_kernel<1,",),),
+    "raster_light_fwd(raster kernel only)": (("raster_kernel<0,",),),
+    "harp_silhouette_bwd": (("raster_kernel<2,",),),
+    "harp_depth_bwd": (("depth_bwd_kernel",),),
 }
+OPTIONAL = {"harp_shade_fwd"}       # not launched in the fitting loop's fused-loss mode
 
 
 def main(fetch_db, write_db, cmd):
@@ -40,14 +46,21 @@ def main(fetch_db, write_db, cmd):
                       "HBM bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (gfx950: FETCH_SIZE under-reports coalesced reads by 2x, calibrated on "
                       "adam_dev_kernel; WRITE_SIZE calibrated on the raster outputs).  tools/make_traffic_json.py"}
     detail = {}
+    names = set(f) | set(w)
     for key, parts in GROUPS.items():
         b = 0.0
-        for sub, wgt in parts:
-            for name in set(f) | set(w):
-                if sub in name:
-                    fb, wb = f.get(name, (0, 0))[0], w.get(name, (0, 0))[0]
-                    b += wgt * (2 * fb * 1024 + wb * 1024)
-                    detail[name[:60]] = {"fetch_KiB": round(fb, 1), "write_KiB": round(wb, 1), "launches": f.get(name, (0, 0))[1]}
+        for alts in parts:
+            hits = [n for n in names if any(a in n for a in alts)]
+            if not hits:
+                if key in OPTIONAL:
+                    continue
+                sys.exit(f"make_traffic_json: no profiled kernel matches {alts} (group {key!r}); kernels seen: {sorted(n[:50] for n in names)}")
+            for name in hits:
+                fb, wb = f.get(name, (0, 0))[0], w.get(name, (0, 0))[0]
+                b += 2 * fb * 1024 + wb * 1024
+                detail[name[:60]] = {"fetch_KiB": round(fb, 1), "write_KiB": round(wb, 1), "launches": f.get(name, (0, 0))[1]}
+        if b == 0.0 and key not in OPTIONAL:
+            sys.exit(f"make_traffic_json: group {key!r} has zero bytes")
         out[key] = int(b)
     out["_per_kernel"] = detail
     print(json.dumps(out, indent=1))
