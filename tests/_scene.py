@@ -42,7 +42,22 @@ def scene_f64(sc, targets):
 # its value).  A case fails when its fraction exceeds 1.5 x the recorded one: the mask may not quietly grow to hide kernel errors.
 # Every masked comparison has an UNMASKED companion with a looser gradient bound (tests/test_gpu_baseline.py), so what the mask
 # removes is bounded, not ignored.
-AMBIGUOUS_FRACTION = {}
+AMBIGUOUS_FRACTION = {
+    "api_loop_body_128": 0.0535,
+    "app_only_hand_256_b2": 0.0618,
+    "c2_hand_128_b18": 0.0436,
+    "c2c3_hand_512_b2": 0.0602,
+    "c5_arm_1024_b1": 0.0262,
+    "c5_arm_1024_b32": 0.0311,
+    "parity_arm_128": 0.0245,
+    "parity_empty_supertiles_256": 0.0421,
+    "parity_full_step_128": 0.0841,
+    "parity_stage_128_shadow0": 0.0094,
+    "parity_stage_128_shadow1": 0.0572,
+    "parity_vgg_128": 0.0659,
+    "smoke_hand_256_b1": 0.0700,       # (provisional until measured by the next smoke run)
+    "ten_steps_hand_128": 0.0821,
+}
 
 
 def check_removed(tag, removed):
@@ -52,6 +67,8 @@ def check_removed(tag, removed):
     if log:
         with open(log, "a") as f:
             f.write(json.dumps({"tag": tag, "removed": removed}) + "\n")
+    if os.environ.get("HARP_MASK_RECORD") == "1":       # measuring run (fills AMBIGUOUS_FRACTION): log only
+        return removed
     rec = AMBIGUOUS_FRACTION.get(tag)
     assert rec is not None, f"no recorded mask fraction for {tag!r} (measured now: {removed:.4f})"
     assert removed <= 1.5 * rec + 1e-4, (tag, removed, rec)

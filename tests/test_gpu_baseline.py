@@ -73,8 +73,9 @@ def test_c2_c3_hand_512_b2_unmasked_companion():
     """The same inputs as test_c2_c3_hand_512_b2_vs_fp64_oracle with NO pixel taken out of the photometric mask: what the mask removes is
     bounded, not ignored.  The image criterion is unchanged (|d| <= 1e-4 on >= 99.9 % of the pixels); losses
     rel 1e-4 (one pixel whose shadow tap rounds the other way moves the photometric mean by ~1e-5 relative) and gradients rel-L2
-    <= 1e-2: a pixel float32 cannot decide moves a gradient by ~1/sqrt(#pixels) — the float32 ORACLE differs from the float64 one by
-    2e-3 on the same inputs — so an error CONFINED to edge / texel-boundary / tap-boundary pixels larger than that still fails here."""
+    <= 5e-3 (measured: <= 1.2e-3, texture; the masked run: <= 3e-4): a pixel float32 cannot decide moves a gradient by
+    ~1/sqrt(#pixels) — the float32 ORACLE differs from the float64 one by 2e-3 on the same inputs — so an error CONFINED to edge /
+    texel-boundary / tap-boundary pixels larger than that still fails here."""
     case = make_fit_case("hand", T=2, S=512, B=2, seed=0, device=DEV)
     eng = case["eng"]
     eng.draw_texture_offsets()
@@ -87,7 +88,7 @@ def test_c2_c3_hand_512_b2_unmasked_companion():
         _check_losses(lv, loss, tol=1e-4)
         if keep:
             _check_images(eng, aux, 2)
-        _check_grads(eng, P, keys, tol=1e-2, tag=f"512 hand UNMASKED keep_image={keep}")
+        _check_grads(eng, P, keys, tol=5e-3, tag=f"512 hand UNMASKED keep_image={keep}")
 
 
 def test_c2_reference_batch_18():
@@ -166,8 +167,8 @@ def test_c5_arm_1024_b32_through_the_striding_kernels(monkeypatch):
     monkeypatch.delenv("HARP_RASTER_LOOP", raising=False)
     ref_l, ref_g = res[("0", True)]
     for key, (lv, g) in res.items():
-        for k, v in ref_l.items():
-            assert abs(v - lv[k]) <= 2e-6 * abs(v) + 1e-12, (key, k, v, lv[k])
+        for k, v in ref_l.items():       # (float32 atomics over 131 072 workgroup partial sums in another order: LOSS_TOL, not bit-for-bit)
+            assert abs(v - lv[k]) <= LOSS_TOL * abs(v) + 1e-12, (key, k, v, lv[k])
         assert rel(g.cpu(), ref_g.cpu()) < 1e-5, key
     # (i) per-frame rows against the float64 oracle's one-frame steps
     eng.keep_image = False

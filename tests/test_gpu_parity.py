@@ -622,10 +622,34 @@ def test_perceptual_term_gradients(sc):
         lv = eng.losses()
         assert abs(lv["vgg"] - ref.item()) <= 2e-5 * abs(ref.item()), (lv["vgg"], ref.item())
         # L1 of feature differences: where a feature difference is at fp32-noise level its sign (= its whole gradient contribution)
-        # depends on the convolution's summation order (MIOpen vs float64 on the CPU): 5e-3 instead of the 1e-3 of the other terms
+        # depends on the convolution's summation order (MIOpen fp32 vs float64 on the CPU).  Measured against the float64 oracle with the
+        # undecidable pixels masked: 4e-3 ... 8e-3 — 1e-2 is enforced (the round-2 bound was 2e-2 against the float32 oracle); the per-layer
+        # break-down below shows the error is carried by the deep taps (relu3_3 / relu4_3: 256 / 512-channel sums of 2304 / 4608 products,
+        # whose float32 rounding noise decides the sign of more near-zero differences), not by the input term or the first tap
         worst = {k: rel(eng.grads[k].cpu().double(), P[k].grad) for k in ("texture", "normal_map", "light_positions", "amb_ratio", "pose", "cam", "shape")}
         print(f"[gradient rel-L2 vs fp64 oracle] VGG term cached={cached}:", {k: f"{v:.1e}" for k, v in worst.items()})
-        assert all(v < 5e-3 for v in worst.values()), (cached, worst)
+        assert all(v < 1e-2 for v in worst.values()), (cached, worst)
+    # per-layer break-down (informational + loose per-layer bounds): the term with ONE of its five rows switched on at a time
+    per_layer = {}
+    for li, name in enumerate(("input", "relu1_2", "relu2_2", "relu3_3", "relu4_3")):
+        lw = [0.0] * 5
+        lw[li] = LW[li]
+        vgg_l = Vgg16Features(layers_weights=lw, weights="random", seed=2)
+        for k in P:
+            if torch.is_tensor(P[k]) and P[k].requires_grad:
+                P[k].grad = None
+        verts = H.prepare_mesh(P, fid, model64, sc["topo"])[1]
+        y_pred = H.render_rgb(verts, sc["topo"], P, P["cam"][fid], S, sc["focal"], self_shadow=True)
+        H.perceptual_loss(filters, lw, y_pred, tg64["y_true"][fid], tg64["y_sil_col"][fid]).backward()
+        eng.set_perceptual(vgg_l, weight=1.0, cache_bytes=0)
+        eng.set_stage(False, True)
+        eng.w_vec.zero_()
+        eng.forward_backward(False, True)
+        torch.cuda.synchronize()
+        per_layer[name] = max(rel(eng.grads[k].cpu().double(), P[k].grad) for k in ("texture", "pose", "cam"))
+    print("[VGG term, gradient rel-L2 per feature row]", {k: f"{v:.1e}" for k, v in per_layer.items()})
+    assert per_layer["input"] < 1e-3 and max(per_layer.values()) < 2e-2, per_layer
+    eng.set_perceptual(vgg, weight=1.0)
     # full steps with the term on: captured into the step's hipGraph (torch / MIOpen convolutions and their autograd included) — same
     # parameters as eager steps from the same state
     eng.set_stage(False, True)
@@ -821,8 +845,8 @@ def test_light_camera_incl_look_at_replacement_branch():
     assert R_o[1, :, 0].abs().max() == 0 and R_o[1, :, 1].abs().max() == 0                  # exactly degenerate: x = y = 0, like the reference
     assert abs(R_o[2, :, 0].norm().item() - 1) < 1e-9 and abs(R_o[2, :, 1].norm().item() - 1) < 1e-9      # replacement branch: proper unit axes again
     g_lp, g_c, g_v = torch.zeros(B, 3, device=DEV), torch.zeros(B, 3, device=DEV), torch.zeros(B, 1, 3, device=DEV)
-    _lib.check(L.harp_light_setup_bwd(p(cg), p(lg), p(wR.float().reshape(B, 9).contiguous().to(DEV)), p(wT.float().contiguous().to(DEV)), B, 1,
-                                      p(g_lp), p(g_c), p(g_v), _lib.stream()), "light_setup_bwd")
+    gR, gT = wR.float().reshape(B, 9).contiguous().to(DEV), wT.float().contiguous().to(DEV)     # (kept alive: p() is a raw pointer)
+    _lib.check(L.harp_light_setup_bwd(p(cg), p(lg), p(gR), p(gT), B, 1, p(g_lp), p(g_c), p(g_v), _lib.stream()), "light_setup_bwd")
     torch.cuda.synchronize()
     for b in range(B):
         for got, ref, name in ((g_lp[b], ld_.grad[b], "light_pos"), (g_c[b], cd.grad[b], "centroid"), (g_v[b, 0], cd.grad[b], "verts")):
