@@ -15,6 +15,12 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-mun
          "-Wno-unused-result", "-DNDEBUG"] + os.environ.get("HARP_EXTRA_FLAGS", "").split()
 
 
+# per-file extra flags.  shade_bwd.hip: the SLP vectoriser pairs float operations into v_pk_* instructions, whose aligned register
+# pairs (and the moves that build them) cost the shader backward ~15 VGPRs; that kernel is bound by waves in flight, not by VALU issue
+# (155 -> 122 VGPRs together with the reload of the face data in its backward half: 3 -> 4 waves per SIMD, no scratch)
+FILE_FLAGS = {"shade_bwd.hip": ["-fno-slp-vectorize"]}
+
+
 def sources():
     return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
 
@@ -36,7 +42,8 @@ def build(force=False, verbose=True):
     for s in sources():
         o = s[:-4] + ".o"
         objs.append(o)
-        cmd = [hipcc, "-c", *[f for f in FLAGS if f != "-shared"], "-I", os.path.join(CSRC, "..", "..", "include"), s, "-o", o]
+        cmd = [hipcc, "-c", *[f for f in FLAGS if f != "-shared"], *FILE_FLAGS.get(os.path.basename(s), []), "-I",
+               os.path.join(CSRC, "..", "..", "include"), s, "-o", o]
         procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
     for s, p in procs:
         out = p.communicate()[0].decode()

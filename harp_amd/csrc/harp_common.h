@@ -65,9 +65,11 @@ __device__ __forceinline__ int tile_decode_v(unsigned bid, const int32_t* __rest
   const bool empty = slot >= nact[0];
   if (empty && !coords_if_empty) return 2;
   const int entry = order[slot];
-  b = entry / nst; st = entry - b * nst;
-  tx0 = ((st % nsx) * (kSuper / kTile) + (sub & 3)) * kTile;
-  ty0 = ((st / nsx) * (kSuper / kTile) + (sub >> 2)) * kTile;
+  // (integer division runs on the vector ALU: its wave-uniform results are moved back to scalar registers explicitly, so that every
+  //  address formed from the frame / tile stays a scalar base + per-lane 32-bit offset instead of a 64-bit address per lane)
+  b = __builtin_amdgcn_readfirstlane(entry / nst); st = entry - b * nst;
+  tx0 = __builtin_amdgcn_readfirstlane(((st % nsx) * (kSuper / kTile) + (sub & 3)) * kTile);
+  ty0 = __builtin_amdgcn_readfirstlane(((st / nsx) * (kSuper / kTile) + (sub >> 2)) * kTile);
   if (!(tx0 < S && ty0 < S)) return 0;
   return empty ? 2 : 1;
 }

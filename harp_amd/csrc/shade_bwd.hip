@@ -34,13 +34,14 @@
 //       - shadow-map taps: 16x16 fixed-point window anchored at the wave's smallest tap.
 //       - the 17 per-frame scalars (light colours, light position, light camera, loss): wave reductions -> LDS partials; the LAST
 //         wave of the tile to finish (LDS ticket, no barrier) issues one memory atomic per scalar.
+#include <stdlib.h>
 #include "raster_body.h"
 #include "shade_common.h"
 
 namespace {
 
 #ifndef SHADE_BWD_OCC
-#define SHADE_BWD_OCC 3
+#define SHADE_BWD_OCC 4
 #endif
 #ifndef SHADE_BWD_TH
 #define SHADE_BWD_TH 7
@@ -73,7 +74,9 @@ struct ShadeSmem {
   int cnt[4];
   int list[256];          // compacted active pixels of the tile: face id | (pixel in tile) << 24
 };
+#ifndef SHADE_SKIP_LDS_ASSERT
 static_assert(sizeof(ShadeSmem) <= (160 / SHADE_BWD_OCC) * 1024, "LDS budget per workgroup");
+#endif
 
 // one 16x16 tile of the shading backward; `vblock` = index in the 1-D heaviest-first tile grid
 __device__ __forceinline__ void shade_bwd_tile(ShadeSmem& sm, unsigned vblock, const harp_shade_args& A, const int32_t* __restrict__ order,
@@ -85,6 +88,9 @@ __device__ __forceinline__ void shade_bwd_tile(ShadeSmem& sm, unsigned vblock, c
   // recomputes anyway (no forward launch at all in a fitting step)
   const bool fused = A.g_rgb == nullptr;
   const int dbg = A.debug_skip >> 8;          // ablation switches (timing only, results WRONG): see harp_hip.h
+  // target rows of all frames of the batch, requested before anything else: the row of this tile's frame is then a lane read instead
+  // of one more dependent trip behind the launch-order entry
+  const int tf_all = (fused && lane < A.B) ? A.l1_fid[lane] : 0;
   int b, st, tx0, ty0, tsub;
   const int kind = tile_decode_v(vblock, order, nact, A.B, nsx, S, b, st, tx0, ty0, tsub, fused);
   if (kind == 0 || (dbg & 64)) return;
@@ -96,18 +102,8 @@ __device__ __forceinline__ void shade_bwd_tile(ShadeSmem& sm, unsigned vblock, c
     }
     return;
   }
+  const int tfid = !fused ? 0 : (A.B <= 64 ? __builtin_amdgcn_readlane(tf_all, b) : A.l1_fid[b]);
   WaveLds& L = s_w[w];
-  for (int i = lane; i < kTSlots; i += 64) {
-    L.tkey[i] = -1;
-#pragma unroll
-    for (int c = 0; c < 6; ++c) L.tval[c][i] = 0;
-  }
-  if (lane < kVSlots) {
-    L.vkey[lane] = -1;
-#pragma unroll
-    for (int c = 0; c < 9; ++c) L.vval[c][lane] = 0.0;
-  }
-  for (int i = lane; i < kZW * kZH; i += 64) L.zwin[i] = 0;
   if (threadIdx.x == 0) s_ticket = 0;
 
   // ---- own 16x4 strip: face id, mask -> active flag (coalesced rows)
@@ -116,16 +112,16 @@ __device__ __forceinline__ void shade_bwd_tile(ShadeSmem& sm, unsigned vblock, c
   {
     const int xi = tx0 + (lane & 15), yi = ty0 + w * 4 + (lane >> 4);
     const bool in_img = xi < S && yi < S;
-    const int f0 = in_img ? A.face_id[((size_t)b * S + yi) * S + xi] : -1;
+    const unsigned pix_o = (unsigned)(yi * S + xi);                  // (32-bit offsets from wave-uniform bases: scalar-base addressing)
+    const int f0 = in_img ? *at32(A.face_id + (size_t)b * S * S, pix_o) : -1;
     bool act0 = f0 >= 0;
     float m0 = 0.f;
     if (fused) {
-      tbase = (size_t)A.l1_fid[b] * S * S;
+      tbase = (size_t)tfid * S * S;
       if (in_img) {
-        const size_t to = tbase + (size_t)yi * S + xi;
-        m0 = A.l1_mask ? A.l1_mask[to] : 1.f;
+        m0 = A.l1_mask ? *at32(A.l1_mask + tbase, pix_o) : 1.f;
         if (!act0 && m0 != 0.f) {         // uncovered pixel inside the mask: background colour against the target, no gradient
-          const float* t = A.l1_target + to * 3;
+          const float* t = at32(A.l1_target + tbase * 3, 3u * pix_o);
           loss_acc = fabsf(A.bg[0] * m0 - t[0] * m0) + fabsf(A.bg[1] * m0 - t[1] * m0) + fabsf(A.bg[2] * m0 - t[2] * m0);
         }
       }
@@ -145,17 +141,31 @@ __device__ __forceinline__ void shade_bwd_tile(ShadeSmem& sm, unsigned vblock, c
     __syncthreads();
   }
   const int n_tile = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+  if (64 * w < n_tile) {                     // only waves that got a share of the tile's active pixels clear their tables
+    for (int i = lane; i < kTSlots; i += 64) {
+      L.tkey[i] = -1;
+#pragma unroll
+      for (int c = 0; c < 6; ++c) L.tval[c][i] = 0;
+    }
+    if (lane < kVSlots) {
+      L.vkey[lane] = -1;
+#pragma unroll
+      for (int c = 0; c < 9; ++c) L.vval[c][lane] = 0.0;
+    }
+    for (int i = lane; i < kZW * kZH; i += 64) L.zwin[i] = 0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  }
   bool act = 64 * w + lane < n_tile;
   const int ent = act ? s_list[64 * w + lane] : 0;
   const int f = ent & 0x00ffffff;
   const int pix = (int)((unsigned)ent >> 24);
   const int xi = tx0 + (pix & 15), yi = ty0 + (pix >> 4);
-  const size_t o = ((size_t)b * S + yi) * S + xi;
-  const size_t l1_to = tbase + (size_t)yi * S + xi;
-  const float l1_m = (act && fused) ? (A.l1_mask ? A.l1_mask[l1_to] : 1.f) : 0.f;      // (re-read: L1 / L2 hit, one LDS kilobyte less)
+  const unsigned po = (unsigned)(yi * S + xi);
+  const float* l1_trow = A.l1_target + tbase * 3;
+  const float l1_m = (act && fused) ? (A.l1_mask ? *at32(A.l1_mask + tbase, po) : 1.f) : 0.f;      // (re-read: L1 / L2 hit, one LDS kilobyte less)
   V3 gc = mk(0.f, 0.f, 0.f);
   if (!fused) {
-    if (act) gc = ld(A.g_rgb + o * 3);
+    if (act) gc = ld(at32(A.g_rgb + (size_t)b * S * S * 3, 3u * po));
     act = act && (gc.x != 0.f || gc.y != 0.f || gc.z != 0.f);
   }
 
@@ -179,18 +189,21 @@ __device__ __forceinline__ void shade_bwd_tile(ShadeSmem& sm, unsigned vblock, c
     const float px = pix_to_ndc(xi, S), py = pix_to_ndc(yi, S);
     const float* col = A.colors;               // amb(3) diff(3) spec(3)
     Frag g;
-    g.t = load_tri(((const FaceRec*)A.recs) + (size_t)b * A.F + f);
+    const unsigned uf = (unsigned)f;
+    g.t = load_tri(at32(((const FaceRec*)A.recs) + (size_t)b * A.F, uf));
     g.br = bary_fwd(g.t, px, py);
     const float b0 = g.br.b0, b1 = g.br.b1, b2 = g.br.b2;
-    g.i0 = A.faces[3 * f]; g.i1 = A.faces[3 * f + 1]; g.i2 = A.faces[3 * f + 2];
-    g.u0 = A.faces_uvs[3 * f]; g.u1 = A.faces_uvs[3 * f + 1]; g.u2 = A.faces_uvs[3 * f + 2];
+    { const int32_t* fi = at32(A.faces, 3u * uf); g.i0 = fi[0]; g.i1 = fi[1]; g.i2 = fi[2]; }
+    { const int32_t* fu = at32(A.faces_uvs, 3u * uf); g.u0 = fu[0]; g.u1 = fu[1]; g.u2 = fu[2]; }
     const float* vb = A.verts + (size_t)b * V * 3;
     const float* nb = A.vnormals + (size_t)b * V * 3;
-    const V3 v0 = ld(vb + 3 * g.i0), v1 = ld(vb + 3 * g.i1), v2 = ld(vb + 3 * g.i2);
-    const V3 n0 = ld(nb + 3 * g.i0), n1 = ld(nb + 3 * g.i1), n2 = ld(nb + 3 * g.i2);
-    const float uv0x = A.verts_uvs[2 * g.u0], uv0y = A.verts_uvs[2 * g.u0 + 1];
-    const float uv1x = A.verts_uvs[2 * g.u1], uv1y = A.verts_uvs[2 * g.u1 + 1];
-    const float uv2x = A.verts_uvs[2 * g.u2], uv2y = A.verts_uvs[2 * g.u2 + 1];
+    const unsigned j0 = 3u * (unsigned)g.i0, j1 = 3u * (unsigned)g.i1, j2 = 3u * (unsigned)g.i2;
+    const unsigned k0 = 2u * (unsigned)g.u0, k1 = 2u * (unsigned)g.u1, k2 = 2u * (unsigned)g.u2;
+    const V3 v0 = ld(at32(vb, j0)), v1 = ld(at32(vb, j1)), v2 = ld(at32(vb, j2));
+    const V3 n0 = ld(at32(nb, j0)), n1 = ld(at32(nb, j1)), n2 = ld(at32(nb, j2));
+    const float uv0x = at32(A.verts_uvs, k0)[0], uv0y = at32(A.verts_uvs, k0)[1];
+    const float uv1x = at32(A.verts_uvs, k1)[0], uv1y = at32(A.verts_uvs, k1)[1];
+    const float uv2x = at32(A.verts_uvs, k2)[0], uv2y = at32(A.verts_uvs, k2)[1];
     g.p = v0 * b0 + v1 * b1 + v2 * b2;
     g.n = n0 * b0 + n1 * b1 + n2 * b2;
     g.u = uv0x * b0 + uv1x * b1 + uv2x * b2;
@@ -246,7 +259,7 @@ __device__ __forceinline__ void shade_bwd_tile(ShadeSmem& sm, unsigned vblock, c
 #pragma unroll
         for (int jj = -1; jj <= 1; ++jj, ++k) {
           const int yy = min(max(g.iy + ii, 0), S - 1), xx = min(max(g.ix + jj, 0), S - 1);
-          sg[k] = sigmoidf((zlb[yy * S + xx] - aa) * 1000.0f);
+          sg[k] = sigmoidf((*at32(zlb, (unsigned)(yy * S + xx)) - aa) * 1000.0f);
           acc += sg[k];
         }
       g.vis = acc * (1.0f / 9.0f);
@@ -269,7 +282,7 @@ __device__ __forceinline__ void shade_bwd_tile(ShadeSmem& sm, unsigned vblock, c
       float gq[3];
 #pragma unroll
       for (int ch = 0; ch < 3; ++ch) {
-        const float d = o3[ch] * l1_m - A.l1_target[l1_to * 3 + ch] * l1_m;
+        const float d = o3[ch] * l1_m - at32(l1_trow, 3u * po)[ch] * l1_m;
         racc[16] += fabsf(d);
         gq[ch] = wl * (float)((d > 0.f) - (d < 0.f));
       }
@@ -324,12 +337,25 @@ __device__ __forceinline__ void shade_bwd_tile(ShadeSmem& sm, unsigned vblock, c
       racc[12] = g.p.x * g_zq; racc[13] = g.p.y * g_zq; racc[14] = g.p.z * g_zq;             // light_R[:,2]
       racc[15] = g_zq;                                                                        // light_T.z
     }
-    // interpolation backward
-    const float gb0 = dot(v0, g_p) + dot(n0, g_n) + uv0x * gu + uv0y * gv;
-    const float gb1 = dot(v1, g_p) + dot(n1, g_n) + uv1x * gu + uv1y * gv;
-    const float gb2 = dot(v2, g_p) + dot(n2, g_n) + uv2x * gu + uv2y * gv;
+    // interpolation backward.  The 33 per-face values (vertex positions, normals, uvs, NDC record) are LOADED AGAIN here (L1 / L2
+    // hits) instead of being held in registers across the texel fetch, the lighting and the shadow test: what keeps this kernel at
+    // 3 waves per SIMD is its register peak in that middle section, and its time goes with 1 / waves.  The base
+    // pointers pass through an empty asm so that the compiler cannot merge the second set of loads with the first.
     float gnd[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    bary_bwd(g.t, px, py, g.br, gb0, gb1, gb2, gnd);
+    {
+      const float* vb2 = vb; const float* nb2 = nb; const float* uvb2 = A.verts_uvs; const FaceRec* rec2 = ((const FaceRec*)A.recs) + (size_t)b * A.F;
+      asm volatile("" : "+s"(vb2), "+s"(nb2), "+s"(uvb2), "+s"(rec2));
+      const V3 w0 = ld(at32(vb2, j0)), w1 = ld(at32(vb2, j1)), w2 = ld(at32(vb2, j2));
+      const V3 m0 = ld(at32(nb2, j0)), m1 = ld(at32(nb2, j1)), m2 = ld(at32(nb2, j2));
+      const float q0x = at32(uvb2, k0)[0], q0y = at32(uvb2, k0)[1], q1x = at32(uvb2, k1)[0], q1y = at32(uvb2, k1)[1];
+      const float q2x = at32(uvb2, k2)[0], q2y = at32(uvb2, k2)[1];
+      const Tri t2 = load_tri(at32(rec2, uf));
+      const float gb0 = dot(w0, g_p) + dot(m0, g_n) + q0x * gu + q0y * gv;
+      const float gb1 = dot(w1, g_p) + dot(m1, g_n) + q1x * gu + q1y * gv;
+      const float gb2 = dot(w2, g_p) + dot(m2, g_n) + q2x * gu + q2y * gv;
+      const Bary br2 = bary_fwd(t2, px, py);            // (same values as in the forward half)
+      bary_bwd(t2, px, py, br2, gb0, gb1, gb2, gnd);
+    }
     const float bw[3] = {b0, b1, b2};
     vidx[0] = g.i0; vidx[1] = g.i1; vidx[2] = g.i2;
 #pragma unroll
@@ -380,8 +406,8 @@ __device__ __forceinline__ void shade_bwd_tile(ShadeSmem& sm, unsigned vblock, c
         } else {
 #pragma unroll
           for (int c = 0; c < 3; ++c) {
-            atomicAdd(gvb + 3 * v + c, vsc[9 * k + c]); atomicAdd(gnb + 3 * v + c, vsc[9 * k + 3 + c]);
-            atomicAdd(gdb + 3 * v + c, vsc[9 * k + 6 + c]);
+            atomicAdd(at32m(gvb, 3u * (unsigned)v + c), vsc[9 * k + c]); atomicAdd(at32m(gnb, 3u * (unsigned)v + c), vsc[9 * k + 3 + c]);
+            atomicAdd(at32m(gdb, 3u * (unsigned)v + c), vsc[9 * k + 6 + c]);
           }
         }
       }
@@ -412,7 +438,7 @@ __device__ __forceinline__ void shade_bwd_tile(ShadeSmem& sm, unsigned vblock, c
               const int xx = min(max(zix + c - 1, 0), S - 1);
               const int wx = xx - x0, wy = yy - y0;
               if (wx < kZW && wy < kZH) atomicAdd(&L.zwin[wy * kZW + wx], __float2int_rn(d * zs));
-              else atomicAdd(gz + (size_t)yy * S + xx, d);
+              else atomicAdd(at32m(gz, (unsigned)(yy * S + xx)), d);
             }
           }
         }
@@ -420,7 +446,7 @@ __device__ __forceinline__ void shade_bwd_tile(ShadeSmem& sm, unsigned vblock, c
 #pragma unroll
         for (int i = lane; i < kZW * kZH; i += 64) {
           const int q = L.zwin[i];
-          if (q != 0) atomicAdd(gz + (size_t)(y0 + i / kZW) * S + x0 + (i % kZW), (float)q * zinv_s);
+          if (q != 0) atomicAdd(at32m(gz, (unsigned)((y0 + i / kZW) * S + x0 + (i % kZW))), (float)q * zinv_s);
         }
       }
     }
@@ -467,8 +493,8 @@ __device__ __forceinline__ void shade_bwd_tile(ShadeSmem& sm, unsigned vblock, c
           } else {
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-              if (do_t) atomicAdd(A.g_tex + (size_t)key[k] * 3 + c, va[c]);
-              if (do_n) atomicAdd(A.g_nmap + (size_t)key[k] * 3 + c, vm[c]);
+              if (do_t) atomicAdd(at32m(A.g_tex, 3u * (unsigned)key[k] + c), va[c]);
+              if (do_n) atomicAdd(at32m(A.g_nmap, 3u * (unsigned)key[k] + c), vm[c]);
             }
           }
         }
@@ -480,8 +506,8 @@ __device__ __forceinline__ void shade_bwd_tile(ShadeSmem& sm, unsigned vblock, c
         const int key = L.tkey[sl];
         if (key < 0) continue;
         const int a0 = L.tval[c][sl], a1 = L.tval[3 + c][sl];
-        if (a0 != 0) atomicAdd(A.g_tex + (size_t)key * 3 + c, (float)a0 * ia);
-        if (a1 != 0) atomicAdd(A.g_nmap + (size_t)key * 3 + c, (float)a1 * im);
+        if (a0 != 0) atomicAdd(at32m(A.g_tex, 3u * (unsigned)key + c), (float)a0 * ia);
+        if (a1 != 0) atomicAdd(at32m(A.g_nmap, 3u * (unsigned)key + c), (float)a1 * im);
       }
     }
 
@@ -493,7 +519,7 @@ __device__ __forceinline__ void shade_bwd_tile(ShadeSmem& sm, unsigned vblock, c
       const float val = (float)L.vval[c][sl];
       if (val == 0.f) continue;
       float* dst = c < 3 ? gvb : (c < 6 ? gnb : gdb);
-      atomicAdd(dst + 3 * v + (c % 3), val);
+      atomicAdd(at32m(dst, 3u * (unsigned)v + (c % 3)), val);
     }
   }
 
@@ -568,7 +594,10 @@ int harp_detail_fused_bwd(const harp_shade_args& a, const void* ws, const int32_
 
 // launched by harp_shade_bwd (shade.hip)
 int harp_detail_shade_bwd_wave(const harp_shade_args& a, const int32_t* order, const int32_t* nact, int nsx, unsigned grid, hipStream_t stream) {
-  hipLaunchKernelGGL(shade_bwd_wave_kernel, dim3(grid), dim3(256), 0, stream, a, order, nact, nsx);
+  // HARP_SHADE_LDS_PAD=<bytes> (timing experiments only) adds dynamic LDS to the launch to LOWER the number of resident workgroups:
+  // how the kernel's time scales with occupancy (round 3: t = 0.134 + 0.454 / n ms for n workgroups per CU)
+  static const unsigned pad = [] { const char* e = getenv("HARP_SHADE_LDS_PAD"); return e ? (unsigned)atoi(e) : 0u; }();
+  hipLaunchKernelGGL(shade_bwd_wave_kernel, dim3(grid), dim3(256), pad, stream, a, order, nact, nsx);
   HARP_CHECK_LAUNCH();
   return HARP_OK;
 }

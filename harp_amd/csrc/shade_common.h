@@ -12,6 +12,19 @@ namespace {
 __device__ __forceinline__ float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ float fsqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 
+// element `i` of a wave-uniform array, addressed as scalar base + 32-bit BYTE offset per lane (global_load ... v_off, s[base:base+1]):
+// with the byte offset formed in 32 bits the compiler need not widen it, which it must for `base[i]` (i * sizeof(T) may exceed 32 bits
+// as far as it knows) — one VGPR and no 64-bit arithmetic per address instead of a register pair and a v_lshl_add_u64
+template <typename T>
+__device__ __forceinline__ const T* at32(const T* base, unsigned i) {
+  return (const T*)((const char*)base + i * (unsigned)sizeof(T));
+}
+
+template <typename T>
+__device__ __forceinline__ T* at32m(T* base, unsigned i) {
+  return (T*)((char*)base + i * (unsigned)sizeof(T));
+}
+
 struct V3 { float x, y, z; };
 __device__ __forceinline__ V3 mk(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
 __device__ __forceinline__ V3 ld(const float* p) { return mk(p[0], p[1], p[2]); }
@@ -112,10 +125,12 @@ __device__ __forceinline__ V3 bil_sample(const float* m, const Bil& s, int W, in
 __device__ __forceinline__ void bil_sample2(const float4* tn, const Bil& s, int W, int H, V3& alb, V3& nm, V3* adx, V3* ady, V3* mdx, V3* mdy) {
   const int x1 = min(s.x0 + 1, W - 1), y1 = min(s.y0 + 1, H - 1);
   const float k10 = (s.x0 + 1 < W) ? 1.f : 0.f, k01 = (s.y0 + 1 < H) ? 1.f : 0.f;
-  const float4* r0 = tn + ((size_t)s.y0 * W) * 2;
-  const float4* r1 = tn + ((size_t)y1 * W) * 2;
-  const float4 a00 = r0[2 * s.x0], b00 = r0[2 * s.x0 + 1], a10 = r0[2 * x1], b10 = r0[2 * x1 + 1];
-  const float4 a01 = r1[2 * s.x0], b01 = r1[2 * s.x0 + 1], a11 = r1[2 * x1], b11 = r1[2 * x1 + 1];
+  // unsigned 32-bit element offsets from the (wave-uniform) base: the loads take the scalar-base + 32-bit-offset form instead of a
+  // 64-bit address per lane and corner
+  const unsigned o00 = 2u * (unsigned)(s.y0 * W + s.x0), o10 = 2u * (unsigned)(s.y0 * W + x1);
+  const unsigned o01 = 2u * (unsigned)(y1 * W + s.x0), o11 = 2u * (unsigned)(y1 * W + x1);
+  const float4 a00 = *at32(tn, o00), b00 = *at32(tn, o00 + 1u), a10 = *at32(tn, o10), b10 = *at32(tn, o10 + 1u);
+  const float4 a01 = *at32(tn, o01), b01 = *at32(tn, o01 + 1u), a11 = *at32(tn, o11), b11 = *at32(tn, o11 + 1u);
   const V3 t00 = mk(a00.x, a00.y, a00.z), t10 = mk(a10.x, a10.y, a10.z) * k10, t01 = mk(a01.x, a01.y, a01.z) * k01,
            t11 = mk(a11.x, a11.y, a11.z) * (k10 * k01);
   const V3 m00 = mk(a00.w, b00.x, b00.y), m10 = mk(a10.w, b10.x, b10.y) * k10, m01 = mk(a01.w, b01.x, b01.y) * k01,

@@ -55,7 +55,7 @@ AMBIGUOUS_FRACTION = {
     "parity_stage_128_shadow0": 0.0094,
     "parity_stage_128_shadow1": 0.0572,
     "parity_vgg_128": 0.0659,
-    "smoke_hand_256_b1": 0.0700,       # (provisional until measured by the next smoke run)
+    "smoke_hand_256_b1": 0.0649,
     "ten_steps_hand_128": 0.0821,
 }
 
