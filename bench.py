@@ -330,6 +330,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the rates of the other configurations (keep_image, B=18, C5 arm 1024)")
+    ap.add_argument("--no-roofline", action="store_true", help="skip the per-kernel event timing and the keep_image rate (profiling runs: only the timed steps)")
     ap.add_argument("--vgg-weights", default="random", help="filters of the perceptual-term entry of `extras`: 'random' (default, timing only), "
                     "'none' (skip the entry) or the path of torchvision's vgg16 state dict (vgg16-397923af.pth)")
     args = ap.parse_args()
@@ -453,7 +454,7 @@ def main():
         out["allreduce"] = allreduce
     if shared_gpu or backend != "nccl":
         out["invalid_timing"] = f"development run: backend={backend}, all ranks on one GPU={shared_gpu}"
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.no_roofline:
         a_frame, a_step, parts = algorithmic_bytes(eng)
         kt = kernel_roofline(eng, 4)
         kt_situ = kernel_roofline(eng, 4, overlap=True)

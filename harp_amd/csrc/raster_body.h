@@ -75,6 +75,10 @@ struct RasterSmem {
   int32_t s_id[kStage];
   int lds_cnt[4];
   unsigned long long zkey[MODE <= 1 ? 256 : 1];   // face-scan walk (MODE 0 / 1): per pixel min over (depth bits << 32 | face id)
+  // face scan: staged faces ordered by the number of 4x4 blocks their bbox covers in this tile (counting sort, descending), so that the
+  // four 16-lane groups of a wave walk faces of (nearly) equal length; faces whose bbox holds no pixel centre drop out
+  unsigned char perm[MODE <= 1 ? kStage : 1];
+  int hist[MODE <= 1 ? 20 : 1];
   // MODE 1, soft silhouette: sat = some face covers the pixel deeper than the sigmoid's float32 range (alpha = 1 exactly);
   // prodl = running product of (1 - p) over the other faces within the blur radius, in ascending face order; cand = pixels not (yet) saturated
   int sat[MODE == 1 ? 256 : 1];
@@ -337,10 +341,33 @@ __device__ __forceinline__ void raster_tile(RasterSmem<MODE>& sm, unsigned vbloc
       //      list was classified by all 64 lanes of the strip (~8 % of them inside its bbox).
       const int grp = threadIdx.x >> 4, gl = threadIdx.x & 15, lx = gl & 3, ly = gl >> 2;
       const float hs = 0.5f * (float)S;
-      for (int k0 = 0; k0 < nl; k0 += 16) {
-        const int k = k0 + grp;
-        const bool valid = k < nl;
-        const int kk = valid ? k : 0;
+      // ---- order the staged faces by block count (descending): thread = staged face
+      int nscan = nl;
+      {
+        int nb = 0;
+        if ((int)threadIdx.x < nl) {
+          const float4 q = s_bb[threadIdx.x];
+          const int x0 = max((int)ceilf((1.0f - q.y) * hs - 0.501f), tx0), x1 = min(min((int)floorf((1.0f - q.x) * hs - 0.499f), tx0 + kTile - 1), S - 1);
+          const int y0 = max((int)ceilf((1.0f - q.w) * hs - 0.501f), ty0), y1 = min(min((int)floorf((1.0f - q.z) * hs - 0.499f), ty0 + kTile - 1), S - 1);
+          if (x0 <= x1 && y0 <= y1) nb = (((x1 - x0) >> 2) + 1) * (((y1 - y0) >> 2) + 1);      // 1 .. 16
+        }
+        if (threadIdx.x < 20) sm.hist[threadIdx.x] = 0;
+        __syncthreads();
+        int rank = 0;
+        if (nb > 0) rank = atomicAdd(&sm.hist[16 - nb], 1);
+        __syncthreads();
+        int base_b = 0;
+        for (int i = 0; i < 16 - nb; ++i) base_b += sm.hist[i];
+        if (nb > 0) sm.perm[base_b + rank] = (unsigned char)threadIdx.x;
+        int tot = 0;
+        for (int i = 0; i < 16; ++i) tot += sm.hist[i];
+        nscan = tot;
+        __syncthreads();
+      }
+      for (int k0 = 0; k0 < nscan; k0 += 16) {
+        const int ks = k0 + grp;
+        const bool valid = ks < nscan;
+        const int kk = valid ? (int)sm.perm[ks] : 0;
         const float4 q = s_bb[kk];
         // pixel-centre columns / rows that can lie in the bbox (pixel coordinate of NDC n: (1 - n) S / 2 - 1/2; 1e-3 px of slack,
         // the exact comparison below decides), clipped to the tile

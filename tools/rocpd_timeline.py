@@ -1,11 +1,12 @@
-"""Print the kernel timeline of the last full step in a rocprofv3 rocpd database: start offset, duration, gap to the previous
+"""Print the kernel timeline of one full step in a rocprofv3 rocpd database: start offset, duration, gap to the previous
 kernel's end, kernel name.  A step runs from one marker kernel (default: the schedule_next kernel that opens every step) to the
-next.   python tools/rocpd_timeline.py DB [marker-substring]"""
+next.   python tools/rocpd_timeline.py DB [marker-substring] [step-index]     (step-index: 0-based from the first marker; default
+the last full step — bench.py ends with keep_image steps, its timed loss-only steps are the indices warmup .. warmup+steps-1)"""
 import sqlite3
 import sys
 
 
-def main(path, marker="schedule_next"):
+def main(path, marker="schedule_next", step=None):
     db = sqlite3.connect(path)
     cur = db.cursor()
     cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
@@ -15,7 +16,7 @@ def main(path, marker="schedule_next"):
     marks = [i for i, r in enumerate(rows) if marker in r[0]]
     if len(marks) < 3:
         print("not enough steps"); return
-    lo, hi = marks[-2], marks[-1]
+    lo, hi = (marks[-2], marks[-1]) if step is None else (marks[int(step)], marks[int(step) + 1])
     seg = rows[lo:hi]
     t0 = seg[0][1]
     prev_end = t0
