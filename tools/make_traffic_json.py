@@ -8,19 +8,29 @@ import sys
 from collections import defaultdict
 
 
-def per_launch(path, counter):
+LAST = 4      # launches per kernel that belong to the profiled steps (bench.py --steps 3 --warmup 1): bench.py first renders its targets
+              # with the same kernels in other modes (dense outputs, gradient image instead of the fused loss) — those launches are left out
+
+
+def per_launch(path, counter, last=LAST):
     db = sqlite3.connect(path)
     cur = db.cursor()
     cols = [r[1] for r in cur.execute("pragma table_info(pmc_events)")]
     idx = {c: i for i, c in enumerate(cols)}
-    tot, disp = defaultdict(float), defaultdict(set)
+    per = defaultdict(lambda: defaultdict(float))
     for r in cur.execute("select * from pmc_events"):
         name = r[idx["name"]] if "name" in idx else r[idx["kernel_name"]]
         if r[idx["counter_name"]] != counter:
             continue
-        tot[name] += r[idx["value"] if "value" in idx else idx["counter_value"]]
-        disp[name].add(r[idx["dispatch_id"]])
-    return {k: (tot[k] / len(disp[k]), len(disp[k])) for k in tot}
+        per[name][r[idx["dispatch_id"]]] += r[idx["value"] if "value" in idx else idx["counter_value"]]
+    out = {}
+    for k, d in per.items():
+        ids = sorted(d)
+        # set-up kernels run once per view: keep the launches of the last `last` steps of both views
+        n = last * (2 if any(t in k for t in ("face_setup_kernel", "bin_faces_kernel", "order_tiles_kernel")) else 1)
+        keep = ids[-n:]
+        out[k] = (sum(d[i] for i in keep) / len(keep), len(keep))
+    return out
 
 
 # group -> parts; a part = tuple of ALTERNATIVE substrings of the kernel name (at least one must match a profiled kernel, otherwise the
@@ -42,7 +52,8 @@ OPTIONAL = {"harp_shade_fwd"}       # not launched in the fitting loop's fused-l
 
 def main(fetch_db, write_db, cmd):
     f, w = per_launch(fetch_db, "FETCH_SIZE"), per_launch(write_db, "WRITE_SIZE")
-    out = {"_source": f"rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes) -- {cmd}; per-launch averages; "
+    out = {"_source": f"rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes) -- {cmd}; per-launch averages over the LAST {LAST} "
+                      "launches of every kernel (= the profiled steps; the launches that render bench.py's targets are left out); "
                       "HBM bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (gfx950: FETCH_SIZE under-reports coalesced reads by 2x, calibrated on "
                       "adam_dev_kernel; WRITE_SIZE calibrated on the raster outputs).  tools/make_traffic_json.py"}
     detail = {}

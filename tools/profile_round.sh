@@ -9,14 +9,14 @@ out=gpurun_out
 mkdir -p $out
 export TMPDIR=/tmp
 python bench.py > $out/${tag}_bench.json 2> $out/${tag}_bench.err
-timeout 900 rocprofv3 --kernel-trace --stats -d $out/prof_$tag -o run -- python bench.py --steps 40 --warmup 8 --no-cpu-baseline --no-extras \
+timeout 900 rocprofv3 --kernel-trace --stats -d $out/prof_$tag -o run -- python bench.py --steps 40 --warmup 8 --no-cpu-baseline --no-extras --no-roofline \
     > $out/${tag}_bench_under_rocprof.json 2> $out/${tag}_prof.err
 db=$(find $out/prof_$tag -name "*.db" | head -1)
 python tools/rocpd_stats.py $db > $out/${tag}_kernel_stats_default_bench_graph.txt
 python tools/rocpd_timeline.py $db > $out/${tag}_timeline_one_step.txt
 rm -rf $out/prof_$tag
 # HBM traffic per kernel: two separate PMC passes (counters only with --kernel-trace, never with other trace domains)
-cmd="python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras --no-graph"
+cmd="python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras --no-roofline --no-graph"
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 600 rocprofv3 --kernel-trace --pmc $c -d $out/pmc_${tag}_$c -o run -- $cmd > /dev/null 2> $out/${tag}_pmc_$c.err
 done
