@@ -396,7 +396,9 @@ __device__ __forceinline__ void raster_tile(RasterSmem<MODE>& sm, unsigned vbloc
 #endif
             if (xs <= x1 && ys <= y1) {
               const float qx = sm.ndc_x[xs - tx0], qy = sm.ndc_y[ys - ty0];
-              const bool inbox = !(qx > q.y || qx < q.x || qy > q.w || qy < q.z);
+              // (same predicate as !(qx > q.y || qx < q.x || qy > q.w || qy < q.z) for finite operands, as two median-of-three
+              //  instructions + two compares instead of four compares and the mask arithmetic that joins them)
+              const bool inbox = __builtin_amdgcn_fmed3f(qx, q.x, q.y) == qx && __builtin_amdgcn_fmed3f(qy, q.z, q.w) == qy;
               const float e0 = edge_fn(qx, qy, t.x1, t.y1, t.x2, t.y2);
               const float e1 = edge_fn(qx, qy, t.x2, t.y2, t.x0, t.y0);
               const float e2 = edge_fn(qx, qy, t.x0, t.y0, t.x1, t.y1);
