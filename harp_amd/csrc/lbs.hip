@@ -199,11 +199,15 @@ constexpr int kChunksA = 8;
 constexpr int kChunksP = 64;      // short dependent load chains: 37 trips per lane instead of 146 (23 -> ~8 us)
 
 // one wave per frame: chain + Rodrigues backward. g_j16 (B,16,3): gradient on the 16 chain joint positions (metres).
+// SCATTER (harp_hand_back_bwd): instead of writing g_pose (B,48) / g_beta_b (B,10) for a later harp_frame_setup_bwd launch, add them
+// straight to the rows of the parameter tables' gradient arena (rot, pose rows of frame fid[b]; shape summed over the frames).
+template <bool SCATTER>
 __global__ void __launch_bounds__(64) lbs_chain_bwd_kernel(const harp_mano_model M, const float* __restrict__ pose,
                                                            const float* __restrict__ Rloc, const float* __restrict__ G,
                                                            const float* __restrict__ Jrest, const float* __restrict__ g_A,
                                                            const float* __restrict__ g_pm, const float* __restrict__ g_j16,
-                                                           float* __restrict__ g_pose, float* __restrict__ g_beta_b) {
+                                                           float* __restrict__ g_pose, float* __restrict__ g_beta_b,
+                                                           const harp_frame_tables T, const int32_t* __restrict__ fid) {
   __shared__ float gRG[NJ][9], gtG[NJ][3], gRl[NJ][9], gJ[NJ][3];
   const int b = blockIdx.x, l = threadIdx.x;
   const float* Gb = G + b * NJ * 12;
@@ -264,12 +268,21 @@ __global__ void __launch_bounds__(64) lbs_chain_bwd_kernel(const harp_mano_model
     }
     float gaa[3];
     rodrigues_bwd(aa, gRl[l], gaa);
-    for (int c = 0; c < 3; ++c) g_pose[b * 48 + 3 * l + c] = gaa[c];
+    if (SCATTER) {
+      const int f = fid[b];
+      for (int c = 0; c < 3; ++c) {
+        if (l == 0) { if (T.g_rot) atomicAdd(T.g_rot + f * 3 + c, gaa[c]); }
+        else if (T.g_pose) atomicAdd(T.g_pose + f * 45 + 3 * (l - 1) + c, gaa[c]);
+      }
+    } else {
+      for (int c = 0; c < 3; ++c) g_pose[b * 48 + 3 * l + c] = gaa[c];
+    }
   }
   if (l < NB) {
     float acc = g_beta_b[b * NB + l];
     for (int i = 0; i < NJ * 3; ++i) acc += M.J_dirs[i * NB + l] * gJ[i / 3][i % 3];
-    g_beta_b[b * NB + l] = acc;
+    if (SCATTER) { if (T.g_shape) atomicAdd(T.g_shape + l, acc); }
+    else g_beta_b[b * NB + l] = acc;
   }
 }
 
@@ -373,10 +386,22 @@ int harp_lbs_mano_bwd(const harp_mano_model* m, const float* pose, const float* 
   hipLaunchKernelGGL(lbs_skin_kernel<true>, dim3((NV + kSkinVerts - 1) / kSkinVerts, (B + FRAMES_PER_BLOCK - 1) / FRAMES_PER_BLOCK), dim3(256), 0, stream,
                      *m, betas, trans, w.pm, w.A, B, nullptr, g_verts, w.g_vp, w.Mo, w.vposed);
   hipLaunchKernelGGL(lbs_gA_gpm_kernel, dim3(B, kChunksA + kChunksP), dim3(192), 0, stream, *m, m->weights, w.Mo, w.g_A, w.g_vp, w.g_pm, g_betas);
-  hipLaunchKernelGGL(lbs_chain_bwd_kernel, dim3(B), dim3(64), 0, stream, *m, pose, w.Rloc, w.G, w.Jrest, w.g_A, w.g_pm, w.g_j16,
-                     g_pose, g_betas);
+  hipLaunchKernelGGL(lbs_chain_bwd_kernel<false>, dim3(B), dim3(64), 0, stream, *m, pose, w.Rloc, w.G, w.Jrest, w.g_A, w.g_pm, w.g_j16,
+                     g_pose, g_betas, harp_frame_tables{}, nullptr);
   HARP_CHECK_LAUNCH();
   return HARP_OK;
 }
 
 }  // extern "C"
+
+// second and third launch of harp_hand_back_bwd (csrc/hand_back.hip): the two reductions over the vertices (spread over 72 workgroups per
+// frame: throughput work), then the kinematic chain + Rodrigues backward with the scatter into the parameter tables' gradient rows
+int harp_detail_lbs_back_tail(const harp_mano_model& m, const float* pose, int B, float* ws, float* g_betas, const harp_frame_tables& tables,
+                              const int32_t* fid, hipStream_t stream) {
+  const LbsWs w = lbs_ws(ws, B);
+  hipLaunchKernelGGL(lbs_gA_gpm_kernel, dim3(B, kChunksA + kChunksP), dim3(192), 0, stream, m, m.weights, w.Mo, w.g_A, w.g_vp, w.g_pm, g_betas);
+  hipLaunchKernelGGL(lbs_chain_bwd_kernel<true>, dim3(B), dim3(64), 0, stream, m, pose, w.Rloc, w.G, w.Jrest, w.g_A, w.g_pm, w.g_j16,
+                     nullptr, g_betas, tables, fid);
+  HARP_CHECK_LAUNCH();
+  return HARP_OK;
+}

@@ -151,6 +151,7 @@ class FitEngine:
         self.fused_chain = self.topo.V <= _lib.lib().harp_mesh_chain_max_vertices()
         # MANO path: frame set-up + hand layer + mesh chain + rasteriser set-up of both views as ONE launch (csrc/hand_front.hip)
         self.fused_front = self.fused_chain and not self.use_arm and self.n_joints == 21
+        self.fused_back = True           # ... and the backward tail as three launches instead of six (csrc/hand_back.hip)
         # ---- switches (all on in production; tools/dev and bench.py flip some of them to measure their effect)
         self.overlap = True              # second HIP stream (light view, silhouette backward, parameter-only terms); False: one stream
         self.early_terms = True          # parameter-only terms / mesh regularisers scheduled on the second stream
@@ -264,19 +265,24 @@ class FitEngine:
         c.focal, c.shadow, c.has_normal_grad = self.focal, int(shadow), int(has_normal_grad)
         return c
 
+    def _hand_struct(self, fid, B, shadow, has_normal_grad):
+        """harp_hand_front over the active lane's scratch: the one-launch front (csrc/hand_front.hip) and the three-launch back (csrc/hand_back.hip)"""
+        s, p = self.s, _lib.ptr
+        h = _lib.HandFront()
+        h.chain, h.mano, h.tables = self._chain_struct(B, shadow, has_normal_grad), self.dm.struct, self.tables
+        for k, t in (("fid", fid), ("pose48", s["pose48"]), ("betas", s["betas"]), ("trans_b", s["trans_b"]), ("cam_R", s["cam_R"]),
+                     ("cam_T", s["cam_T"]), ("light_pos", s["light_pos"]), ("colors", s["colors"]), ("lbs_ws", s["lbs_ws"])):
+            setattr(h, k, p(t))
+        h.self_shadow = int(self.self_shadow)
+        return h
+
     def _mesh_forward(self, fid, B, shadow=False, front=False):
         """frame_setup .. normals (and, fused, both projections + the light camera): fills the scratch geometry for the B frames in
         `fid` (int32 device tensor).  Returns True when the fused chain ran (projections / light camera already done).  front=True
         allows the one-launch form of the whole front (MANO path, csrc/hand_front.hip)."""
         L, s, p, st, tp = _lib.lib(), self.s, _lib.ptr, _lib.stream(), self.topo
         if front and self.fused_front and self.fused_chain:
-            h = _lib.HandFront()
-            h.chain, h.mano, h.tables = self._chain_struct(B, shadow, False), self.dm.struct, self.tables
-            for k, t in (("fid", fid), ("pose48", s["pose48"]), ("betas", s["betas"]), ("trans_b", s["trans_b"]), ("cam_R", s["cam_R"]),
-                         ("cam_T", s["cam_T"]), ("light_pos", s["light_pos"]), ("colors", s["colors"]), ("lbs_ws", s["lbs_ws"])):
-                setattr(h, k, p(t))
-            h.self_shadow = int(self.self_shadow)
-            self._ck(L.harp_hand_front_fwd(ctypes.byref(h), st), "hand_front_fwd")
+            self._ck(L.harp_hand_front_fwd(ctypes.byref(self._hand_struct(fid, B, shadow, False)), st), "hand_front_fwd")
             return True
         self._ck(L.harp_frame_setup_fwd(ctypes.byref(self.tables), p(fid), B, self.S, self.focal, int(self.self_shadow), p(s["pose48"]),
                                         p(s["betas"]), p(s["trans_b"]), p(s["cam_R"]), p(s["cam_T"]), p(s["light_pos"]), p(s["colors"]), st),
@@ -482,6 +488,11 @@ class FitEngine:
                                                     p(s["g_centroid"]), p(s["g_vd"]), ST()), "light_setup_bwd")
         if side_used or (self.tail_side and self.overlap and app):
             cur.wait_stream(side)                       # silhouette_bwd -> g_ndc_c (normal-map chain rule with tail_side)
+        if fused and self.fused_front and self.fused_back:
+            # the whole backward tail — mesh chain, hand layer, scatter into the parameter tables' gradient rows — as three launches
+            self._ck(L.harp_hand_back_bwd(ctypes.byref(self._hand_struct(lfid, B, shadow, app)), p(s["g_colors"]) if app else None,
+                                          p(s["g_betas"]), ST()), "hand_back_bwd")
+            return
         if fused:
             # projections, light camera, both vertex-normal passes, displacement, subdivision and the mm scaling: one launch
             self._ck(L.harp_mesh_chain_bwd(ctypes.byref(self._chain_struct(B, shadow, app)), ST()), "mesh_chain_bwd")
@@ -760,7 +771,7 @@ class FitEngine:
         # every switch the enqueued launch sequence depends on is part of the key: flipping one re-captures instead of replaying a
         # graph recorded for another configuration
         gkey = (coarse, app, scheduled, self.keep_image, self.fused_loss, self.self_shadow, tuple(self.frozen), self.overlap, self.early_terms,
-                self.packed_texels, self.auto_draw, self.mesh_terms_first, self.camera_first, self.tail_side, self.fused_bwd, self.fused_chain, self.fused_front, dist_on, self.overlap_allreduce,
+                self.packed_texels, self.auto_draw, self.mesh_terms_first, self.camera_first, self.tail_side, self.fused_bwd, self.fused_chain, self.fused_front, self.fused_back, dist_on, self.overlap_allreduce,
                 self.comm is not None, self.perceptual is not None and app)
         g = self._graphs.get(gkey)
         if g is None:

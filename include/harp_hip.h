@@ -362,6 +362,14 @@ typedef struct harp_hand_front {
   int self_shadow;           /* colours from amb_ratio (shadow renderer) or the fixed Phong lights */
 } harp_hand_front;
 int harp_hand_front_fwd(const harp_hand_front* h, hipStream_t stream);
+/* The counterpart for the backward tail of a step (csrc/hand_back.hip): harp_mesh_chain_bwd + harp_lbs_mano_bwd + harp_frame_setup_bwd
+ * (autograd of utils/visualize.py:16-88 / manopth/manolayer.py:108-296 down to the rows params[...][fid]) as THREE launches instead of
+ * six: mesh chain + joint split + per-vertex skinning backward + trans / cam / light scatter per frame, the two vertex reductions, the
+ * kinematic chain backward with the pose / rot / shape scatter.  `h` as passed to harp_hand_front_fwd of the same step, with the chain's
+ * gradient inputs filled in (g_ndc_c, g_ndc_l, g_vd, g_n2, g_joints_m, g_light_R / g_light_T, has_normal_grad); gradients are ADDED to
+ * the rows tables.g_* (pose, rot, trans, cam, shape and — when g_colors is given, i.e. an appearance stage ran — light_positions,
+ * amb_ratio).  g_colors: 9 floats (dL/d colours) or NULL; g_betas_scratch: B*10 floats of scratch. */
+int harp_hand_back_bwd(const harp_hand_front* h, const float* g_colors, float* g_betas_scratch, hipStream_t stream);
 
 int harp_light_setup_fwd(const float* centroid, const float* light_pos, int B, float* light_R, float* light_T, hipStream_t stream);
 int harp_light_setup_bwd(const float* centroid, const float* light_pos, const float* g_light_R, const float* g_light_T, int B, int V,

@@ -549,6 +549,48 @@ def test_fused_front_matches_building_blocks(sc, coarse, app):
             assert rel(g1[o:o + n], g0[o:o + n]) < 1e-3, k       # soft-rim conditioning: 1e-7 vertex moves flip a handful of pixels
 
 
+@pytest.mark.parametrize("coarse,app", [(True, True), (True, False), (False, True)])
+def test_fused_back_matches_building_blocks(sc, coarse, app):
+    """harp_hand_back_bwd (csrc/hand_back.hip: mesh chain backward + joint split + skinning backward + trans / cam / light scatter in one
+    launch per frame, the vertex reductions, the kinematic-chain backward with the pose / rot / shape scatter: three launches) against
+    harp_mesh_chain_bwd + harp_lbs_mano_bwd + harp_frame_setup_bwd (six) on the SAME image-space gradients: every block of the gradient
+    arena agrees to float32 summation order; with a frame repeated inside the batch (legal: rows are summed) and a partial batch."""
+    from harp_amd.engine import FitEngine
+    tg = sc["targets"]
+    eng = FitEngine(sc["model_np"], sc["topo_np"], sc["tpl"]["verts_uvs"], sc["tpl"]["faces_uvs"], sc["uv_mask"].float(), sc["seq"], sc["S"],
+                    sc["focal"], 3, device=DEV, seed=1)
+    eng.set_targets(tg["y_true"], tg["y_sil"], tg["y_sil_col"])
+    g = torch.Generator().manual_seed(3)
+    with torch.no_grad():
+        eng.params["verts_disps"].copy_((torch.randn(3093, 1, generator=g) * 0.001).to(DEV))
+        eng.params["pose"].add_((torch.randn(eng.params["pose"].shape, generator=g) * 0.05).to(DEV))
+        eng.params["shape"].add_((torch.randn(10, generator=g) * 0.3).to(DEV))
+        eng.params["trans"].copy_((torch.randn(3, 3, generator=g) * 0.01).to(DEV))
+    assert eng.fused_front and eng.fused_chain and eng.fused_back
+    eng.auto_draw = False; eng.draw_texture_offsets(); eng.set_stage(coarse, app)
+    for frames in ([2, 0, 1], [1, 1, 0], [2, 0]):
+        fid = torch.tensor(frames, dtype=torch.int32, device=DEV)
+        n = len(frames)
+        eng.fid[:n].copy_(fid); eng.tfid[:n].copy_(fid)
+        out = {}
+        for fused in (False, True):
+            eng.fused_back = fused
+            eng.forward_backward(coarse, app, B=n)
+            torch.cuda.synchronize()
+            out[fused] = eng.g_buf.clone().cpu().double()
+        eng.fused_back = True
+        for k in ("pose", "cam", "verts_disps", "shape", "rot", "trans", "light_positions", "amb_ratio"):
+            o, m = eng.arena.offsets[k][0], eng.arena.offsets[k][1]
+            a, b = out[True][o:o + m], out[False][o:o + m]
+            # (amb_ratio: the difference of two nearly equal colour-gradient sums, each a float-atomics sum of the shader backward that
+            #  ran again for the second path: 1e-7 of noise on the sums is ~1e-2 on their difference)
+            tol = 5e-2 if k == "amb_ratio" else 2e-5
+            if b.abs().max() > 0:
+                assert rel(a, b) < tol, (frames, k, rel(a, b))
+            else:
+                assert a.abs().max() == 0, (frames, k)
+
+
 def test_rccl_path_on_one_rank(sc):
     """The N>1 step (eager forward/backward, early async all-reduce of the texture / normal-map gradients overlapped with the mesh
     backward, small remainder afterwards, Adam) on a 1-rank RCCL group: same parameters as the plain single-GPU step."""
