@@ -43,6 +43,12 @@ namespace {
 #ifndef SHADE_BWD_OCC
 #define SHADE_BWD_OCC 4
 #endif
+// xor distances of the same-face lane merge in front of the vertex table: 1, 2, 4 (x neighbours of the compacted order) and 16 (the row
+// below): measured 0.2453 (7) / 0.2502 (3) / 0.2526 (1) / 0.2478 (15) / 0.2414 (23) / 0.258 (31) ms — what the merge saves is same-address
+// ds_add_f64 conflicts, which cost more than the DPP / permute steps
+#ifndef SHADE_MERGE_MASK
+#define SHADE_MERGE_MASK 23
+#endif
 #ifndef SHADE_BWD_TH
 #define SHADE_BWD_TH 7
 #endif
@@ -388,7 +394,7 @@ __device__ __forceinline__ void shade_bwd_tile(ShadeSmem& sm, unsigned vblock, c
     // ---- vertex gradients: lanes on the same face add to the same three vertices: merge them first (xor distances 1, 2, 4 = x
     //      neighbours in the compacted order), the survivors add into the wave's double table
     bool alive = act;
-    merge_same_face<27, 7>(vsc, act ? f : -1, alive, lane);
+    merge_same_face<27, SHADE_MERGE_MASK>(vsc, act ? f : -1, alive, lane);
     if (alive) {
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
