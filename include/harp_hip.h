@@ -111,7 +111,7 @@ typedef struct harp_shade_args {
   float* g_light_T;         /* (B,3) (+=) or NULL */
   int debug_skip;           /* 0 in production (wave-autonomous backward kernel, csrc/shade_bwd.hip).  Non-zero selects the first,
                              * barrier-synchronised backward kernel: 64 = that kernel unmodified (A/B timing, same results); bits 0-5 are
-                             * its ablation switches (tools/dev/gpu_variant.py): 1/2 no texel adds, 4 no shadow-tap gradient, 8 no vertex
+                             * its ablation switches (tools/dev/gpu_shade_r3.py): 1/2 no texel adds, 4 no shadow-tap gradient, 8 no vertex
                              * adds, 16 no texel flush, 32 no vertex flush — results are then WRONG by design.  Bits 8-13 are the same kind of
                              * switches for the production kernel: 256 no texel phase, 512 no shadow window, 1024 no vertex phase, 2048 no table
                              * flushes, 8192 no shading at all (fixed cost of the launch) */
