@@ -38,6 +38,14 @@
 #include "raster_body.h"
 #include "shade_common.h"
 
+#ifdef SHADE_STAMPS
+// debug build only (tools/dev/gpu_shade_stamps.py): shader-clock stamps at the phase boundaries of a working wave, summed per phase
+__device__ unsigned long long g_shade_stamps[4096][16];
+#define STAMP(k) ts[k] = __builtin_readcyclecounter()
+#else
+#define STAMP(k)
+#endif
+
 namespace {
 
 #ifndef SHADE_BWD_OCC
@@ -98,6 +106,12 @@ __device__ __forceinline__ void shade_bwd_tile(ShadeSmem& sm, unsigned vblock, c
   // of one more dependent trip behind the launch-order entry
   const int tf_all = (fused && lane < A.B) ? A.l1_fid[lane] : 0;
   int b, st, tx0, ty0, tsub;
+#ifdef SHADE_STAMPS
+  unsigned long long ts[12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) ts[k] = 0;
+#endif
+  STAMP(0);
   const int kind = tile_decode_v(vblock, order, nact, A.B, nsx, S, b, st, tx0, ty0, tsub, fused);
   if (kind == 0 || (dbg & 64)) return;
   if (kind == 2) {
@@ -175,6 +189,7 @@ __device__ __forceinline__ void shade_bwd_tile(ShadeSmem& sm, unsigned vblock, c
     act = act && (gc.x != 0.f || gc.y != 0.f || gc.z != 0.f);
   }
 
+  STAMP(1);
   float racc[kScalars];
 #pragma unroll
   for (int k = 0; k < kScalars; ++k) racc[k] = 0.f;
@@ -216,6 +231,10 @@ __device__ __forceinline__ void shade_bwd_tile(ShadeSmem& sm, unsigned vblock, c
     g.v = uv0y * b0 + uv1y * b1 + uv2y * b2;
     g.bs = bil_setup(g.u, g.v, A.Wt, A.Ht);
     bs = g.bs;
+#ifdef SHADE_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)");
+#endif
+    STAMP(2);
     V3 tdx, tdy, mdx = mk(0.f, 0.f, 0.f), mdy = mk(0.f, 0.f, 0.f);
     const bool packed = A.texnm != nullptr && A.nmap != nullptr;
     if (packed) bil_sample2((const float4*)A.texnm, g.bs, A.Wt, A.Ht, g.texel, g.m, &tdx, &tdy, &mdx, &mdy);
@@ -234,6 +253,10 @@ __device__ __forceinline__ void shade_bwd_tile(ShadeSmem& sm, unsigned vblock, c
       g.nhat = g.nprime * rcp(fmaxf(g.lnp, 1e-12f));
       nfin = g.nhat;
     }
+#ifdef SHADE_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)");
+#endif
+    STAMP(3);
     // PointLights.diffuse: normalize(n, eps 1e-6) . normalize(L - p, eps 1e-6)
     g.lnh = fsqrt(dot(nfin, nfin));
     g.nn = nfin * rcp(fmaxf(g.lnh, 1e-6f));
@@ -270,6 +293,10 @@ __device__ __forceinline__ void shade_bwd_tile(ShadeSmem& sm, unsigned vblock, c
         }
       g.vis = acc * (1.0f / 9.0f);
     }
+#ifdef SHADE_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)");
+#endif
+    STAMP(4);
     const V3 amb = ld(col), dfc = ld(col + 3), spc = ld(col + 6);
     const V3 lightc = mk(amb.x + dfc.x * cosang * g.vis, amb.y + dfc.y * cosang * g.vis, amb.z + dfc.z * cosang * g.vis);
     const V3 c = mk(lightc.x * g.texel.x + spc.x, lightc.y * g.texel.y + spc.y, lightc.z * g.texel.z + spc.z);
@@ -372,6 +399,7 @@ __device__ __forceinline__ void shade_bwd_tile(ShadeSmem& sm, unsigned vblock, c
     }
   }
 
+  STAMP(5);
   // ---- per-frame scalars: wave sums -> this wave's LDS partials (the last wave of the tile sends them on, below)
   const bool working = 64 * w < n_tile;          // (wave-uniform) this wave has a share of the tile's active pixels
   if (working) {
@@ -385,6 +413,7 @@ __device__ __forceinline__ void shade_bwd_tile(ShadeSmem& sm, unsigned vblock, c
     if (lane < kScalars) s_part[w][lane] = (lane == 16) ? s : 0.f;
   }
   const bool any_act = working && __any(act ? 1 : 0) != 0;
+  STAMP(6);
 
   float* gvb = A.g_verts + (size_t)b * V * 3;
   float* gnb = A.g_vnormals + (size_t)b * V * 3;
@@ -420,6 +449,7 @@ __device__ __forceinline__ void shade_bwd_tile(ShadeSmem& sm, unsigned vblock, c
     }
 
     }
+    STAMP(7);
     // ---- shadow-map tap gradients: fixed-point window anchored at the strip's smallest (clamped) tap column / row
     if (A.zl && A.g_zl && !(dbg & 2)) {
       const bool has = zix > -0x40000000;
@@ -457,6 +487,7 @@ __device__ __forceinline__ void shade_bwd_tile(ShadeSmem& sm, unsigned vblock, c
       }
     }
 
+    STAMP(8);
     // ---- texture + normal-map gradients: 4 bilinear corners x 6 channels into the direct-mapped fixed-point table
     if (!(dbg & 1)) {
       const bool do_t = A.g_tex != nullptr, do_n = (A.nmap != nullptr) && (A.g_nmap != nullptr);
@@ -517,6 +548,7 @@ __device__ __forceinline__ void shade_bwd_tile(ShadeSmem& sm, unsigned vblock, c
       }
     }
 
+    STAMP(9);
     // ---- flush the vertex table, lanes = (slot, component)
     if (!(dbg & 12)) for (int i = lane; i < kVSlots * 9; i += 64) {
       const int sl = i / 9, c = i - 9 * sl;
@@ -529,6 +561,16 @@ __device__ __forceinline__ void shade_bwd_tile(ShadeSmem& sm, unsigned vblock, c
     }
   }
 
+#ifdef SHADE_STAMPS
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)");
+  STAMP(10);
+  if (any_act && lane == 0) {
+    unsigned long long* dst = g_shade_stamps[(blockIdx.x * 4 + w) & 4095];
+#pragma unroll
+    for (int k = 1; k <= 10; ++k) atomicAdd(&dst[k], ts[k] - ts[k - 1]);
+    atomicAdd(&dst[0], 1ull);
+  }
+#endif
   // ---- the last wave of the tile to get here sends the tile's scalar sums on (one memory atomic per scalar per tile)
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   int ticket = 0;
@@ -607,3 +649,14 @@ int harp_detail_shade_bwd_wave(const harp_shade_args& a, const int32_t* order, c
   HARP_CHECK_LAUNCH();
   return HARP_OK;
 }
+
+#ifdef SHADE_STAMPS
+extern "C" int harp_debug_shade_stamps(unsigned long long* host16) {
+  static unsigned long long all[4096][16];
+  if (hipMemcpyFromSymbol(all, HIP_SYMBOL(g_shade_stamps), sizeof(all)) != hipSuccess) return -1;
+  for (int k = 0; k < 16; ++k) { host16[k] = 0; for (int i = 0; i < 4096; ++i) host16[k] += all[i][k]; }
+  void* dev = nullptr;
+  if (hipGetSymbolAddress(&dev, HIP_SYMBOL(g_shade_stamps)) != hipSuccess) return -1;
+  return hipMemset(dev, 0, sizeof(all)) == hipSuccess ? 0 : -1;
+}
+#endif
