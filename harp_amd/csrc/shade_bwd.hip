@@ -65,7 +65,7 @@ constexpr int kVSlots = 32;                               // vertex table
 constexpr int kZW = 16, kZH = 16;                         // shadow-tap window (light-view pixels)
 constexpr int kScalars = 17;                              // 0-8 colours, 9-11 light_pos, 12-14 light_R[:,2], 15 light_T.z, 16 loss
 
-struct WaveLds {
+struct alignas(16) WaveLds {
   int tkey[kTSlots];
   int tval[6][kTSlots];        // fixed point; 0-2 albedo, 3-5 normal map
   int vkey[kVSlots];
@@ -162,17 +162,13 @@ __device__ __forceinline__ void shade_bwd_tile(ShadeSmem& sm, unsigned vblock, c
   }
   const int n_tile = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
   if (64 * w < n_tile) {                     // only waves that got a share of the tile's active pixels clear their tables
-    for (int i = lane; i < kTSlots; i += 64) {
-      L.tkey[i] = -1;
+    // (16-B stores over the whole 9.5-KB block, then the two key arrays: 14 LDS instructions instead of 43)
+    int4* L4 = reinterpret_cast<int4*>(&L);
 #pragma unroll
-      for (int c = 0; c < 6; ++c) L.tval[c][i] = 0;
-    }
-    if (lane < kVSlots) {
-      L.vkey[lane] = -1;
+    for (int i = lane; i < (int)(sizeof(WaveLds) / 16); i += 64) L4[i] = make_int4(0, 0, 0, 0);
 #pragma unroll
-      for (int c = 0; c < 9; ++c) L.vval[c][lane] = 0.0;
-    }
-    for (int i = lane; i < kZW * kZH; i += 64) L.zwin[i] = 0;
+    for (int i = lane; i < kTSlots; i += 64) L.tkey[i] = -1;
+    if (lane < kVSlots) L.vkey[lane] = -1;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   }
   bool act = 64 * w + lane < n_tile;
