@@ -93,6 +93,8 @@ static_assert(sizeof(ShadeSmem) <= (160 / SHADE_BWD_OCC) * 1024, "LDS budget per
 #endif
 
 // one 16x16 tile of the shading backward; `vblock` = index in the 1-D heaviest-first tile grid
+// IMG: the fused-loss pass also writes the colour it recomputes (a template flag: the loss-only kernel must not pay for the branch — 9 % measured)
+template <bool IMG>
 __device__ __forceinline__ void shade_bwd_tile(ShadeSmem& sm, unsigned vblock, const harp_shade_args& A, const int32_t* __restrict__ order,
                                                const int32_t* __restrict__ nact, int nsx) {
   auto& s_w = sm.w; auto& s_part = sm.part; int& s_ticket = sm.ticket; auto& s_cnt = sm.cnt; auto& s_list = sm.list;
@@ -114,8 +116,18 @@ __device__ __forceinline__ void shade_bwd_tile(ShadeSmem& sm, unsigned vblock, c
   STAMP(0);
   const int kind = tile_decode_v(vblock, order, nact, A.B, nsx, S, b, st, tx0, ty0, tsub, fused);
   if (kind == 0 || (dbg & 64)) return;
+  // fused-loss mode with an image pointer: the pass also WRITES the colour it recomputes (y_pred, every pixel of the frame) — the
+  // "keep the rendered image" step without a forward shading launch
+  const bool img = IMG && fused;
   if (kind == 2) {
     // super-tile without a face: no gradient; its part of the loss against the static targets is a table look-up
+    if (img) {
+      const int xi = tx0 + (lane & 15), yi = ty0 + w * 4 + (lane >> 4);
+      if (xi < S && yi < S) {
+        float* o = at32m(A.rgb + (size_t)b * S * S * 3, 3u * (unsigned)(yi * S + xi));
+        o[0] = A.bg[0]; o[1] = A.bg[1]; o[2] = A.bg[2];
+      }
+    }
     if (fused && tsub == 0 && threadIdx.x == 0) {
       const float sum = A.l1_bg_sums[(size_t)A.l1_fid[b] * nsx * nsx + st];
       if (sum != 0.f) atomicAdd(A.l1_loss, sum * A.l1_inv);
@@ -145,7 +157,11 @@ __device__ __forceinline__ void shade_bwd_tile(ShadeSmem& sm, unsigned vblock, c
           loss_acc = fabsf(A.bg[0] * m0 - t[0] * m0) + fabsf(A.bg[1] * m0 - t[1] * m0) + fabsf(A.bg[2] * m0 - t[2] * m0);
         }
       }
-      act0 = act0 && (m0 != 0.f);
+      if (img && in_img && f0 < 0) {
+        float* o = at32m(A.rgb + (size_t)b * S * S * 3, 3u * pix_o);
+        o[0] = A.bg[0]; o[1] = A.bg[1]; o[2] = A.bg[2];
+      }
+      act0 = act0 && (m0 != 0.f || img);       // (with an image, covered pixels outside the mask are shaded too: weight 0, colour kept)
     }
     if (dbg & 32) act0 = false;
     // ---- compaction of the tile's active pixels (row-major): wave w then shades entries [64 w, 64 w + 64)
@@ -307,6 +323,10 @@ __device__ __forceinline__ void shade_bwd_tile(ShadeSmem& sm, unsigned vblock, c
     if (fused) {
       // the forward colour of this pixel, the L1 against the target and its gradient (same expressions as the forward kernel)
       const float o3[3] = {(wnum * c.x + delta * A.bg[0]) * rden, (wnum * c.y + delta * A.bg[1]) * rden, (wnum * c.z + delta * A.bg[2]) * rden};
+      if (img) {
+        float* o = at32m(A.rgb + (size_t)b * S * S * 3, 3u * po);
+        o[0] = o3[0]; o[1] = o3[1]; o[2] = o3[2];
+      }
       const float wl = A.l1_w[0] * A.l1_inv * l1_m;
       float gq[3];
 #pragma unroll
@@ -588,10 +608,11 @@ __device__ __forceinline__ void shade_bwd_tile(ShadeSmem& sm, unsigned vblock, c
   }
 }
 
+template <bool IMG>
 __global__ void __launch_bounds__(256, SHADE_BWD_OCC) shade_bwd_wave_kernel(const harp_shade_args A, const int32_t* __restrict__ order,
                                                                             const int32_t* __restrict__ nact, int nsx) {
   __shared__ ShadeSmem sm;
-  shade_bwd_tile(sm, blockIdx.x, A, order, nact, nsx);
+  shade_bwd_tile<IMG>(sm, blockIdx.x, A, order, nact, nsx);
 }
 
 // FUSED BACKWARD LAUNCH: the shading backward and the silhouette backward (csrc/raster_body.h, MODE 2) as ONE grid.  As two kernels on
@@ -615,7 +636,7 @@ __global__ void __launch_bounds__(256, SHADE_BWD_OCC) fused_bwd_kernel(const har
   const unsigned g = blockIdx.x >> 4, r = blockIdx.x & 15;
   const unsigned v = g * 8 + (r & 7);
   if (r < 8) {
-    shade_bwd_tile(sm.sh, v, A, order, nact, nsx);
+    shade_bwd_tile<false>(sm.sh, v, A, order, nact, nsx);
   } else {
     rb::raster_tile<2>(sm.rs, v, R.recs, R.bbs, R.bins, R.cnt, order, nact, A.B, R.F, A.S, nsx, R.blur, R.sigma, nullptr, nullptr, (float*)R.alpha,
                        R.g_alpha, R.faces, A.V, R.g_ndc, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0, nullptr);
@@ -641,7 +662,8 @@ int harp_detail_shade_bwd_wave(const harp_shade_args& a, const int32_t* order, c
   // HARP_SHADE_LDS_PAD=<bytes> (timing experiments only) adds dynamic LDS to the launch to LOWER the number of resident workgroups:
   // how the kernel's time scales with occupancy (round 3: t = 0.134 + 0.454 / n ms for n workgroups per CU)
   static const unsigned pad = [] { const char* e = getenv("HARP_SHADE_LDS_PAD"); return e ? (unsigned)atoi(e) : 0u; }();
-  hipLaunchKernelGGL(shade_bwd_wave_kernel, dim3(grid), dim3(256), pad, stream, a, order, nact, nsx);
+  if (a.g_rgb == nullptr && a.rgb != nullptr) hipLaunchKernelGGL(shade_bwd_wave_kernel<true>, dim3(grid), dim3(256), pad, stream, a, order, nact, nsx);
+  else hipLaunchKernelGGL(shade_bwd_wave_kernel<false>, dim3(grid), dim3(256), pad, stream, a, order, nact, nsx);
   HARP_CHECK_LAUNCH();
   return HARP_OK;
 }

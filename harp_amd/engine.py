@@ -162,6 +162,7 @@ class FitEngine:
         self.comm = None                 # harp_amd.dist.RcclComm: direct RCCL all-reduce on the step's stream (graph node by default), set_comm()
         self.force_allreduce = False     # run the N > 1 code path on a single rank (tests, bench HARP_FORCE_DIST)
         self.fused_loss = True           # loss-only mode: photometric L1 formed inside the shader backward (no forward shading launch)
+        self.fused_keep = True           # keep_image with the fused loss: the shader backward also writes y_pred (no forward shading launch either)
         self.keep_image = True           # shader forward writes the rendered image s["rgb"] (False: loss + gradient only)
         self.mesh_terms_first = True     # key-point term + mesh regularisers run before the light raster (under the raster set-up) instead of after it
         self.fused_bwd = False           # shading + silhouette backward in ONE launch (harp_shade_sil_bwd): correct, measured SLOWER (1.05 vs 0.93 ms: the rasteriser tiles inherit 168 VGPRs / 3 waves per SIMD)
@@ -452,7 +453,7 @@ class FitEngine:
             a.l1_w, a.l1_loss, a.l1_grad = wp(6), lp(6), p(s["g_rgb"])
             # fitting loop (no image kept, no perceptual term): there is no forward shading launch — the backward pass recomputes the
             # colour anyway and forms the photometric L1 and its gradient itself (harp_shade_bwd with g_rgb == NULL)
-            fused_loss = self.fused_loss and not self.keep_image and self.perceptual is None and self.bg_photo is not None
+            fused_loss = self.fused_loss and (self.fused_keep or not self.keep_image) and self.perceptual is None and self.bg_photo is not None
             if fused_loss:
                 a.g_rgb = None
             else:
@@ -771,7 +772,7 @@ class FitEngine:
         # every switch the enqueued launch sequence depends on is part of the key: flipping one re-captures instead of replaying a
         # graph recorded for another configuration
         gkey = (coarse, app, scheduled, self.keep_image, self.fused_loss, self.self_shadow, tuple(self.frozen), self.overlap, self.early_terms,
-                self.packed_texels, self.auto_draw, self.mesh_terms_first, self.camera_first, self.tail_side, self.fused_bwd, self.fused_chain, self.fused_front, self.fused_back, dist_on, self.overlap_allreduce,
+                self.packed_texels, self.fused_keep, self.auto_draw, self.mesh_terms_first, self.camera_first, self.tail_side, self.fused_bwd, self.fused_chain, self.fused_front, self.fused_back, dist_on, self.overlap_allreduce,
                 self.comm is not None, self.perceptual is not None and app)
         g = self._graphs.get(gkey)
         if g is None:

@@ -137,7 +137,8 @@ int harp_pack_texels(const float* tex, const float* nmap, int n_texels, float* o
 int harp_shade_fwd(const harp_shade_args* a, hipStream_t stream);
 /* backward of the shading pass.  g_rgb != NULL: plain backward of an upstream gradient image.  g_rgb == NULL (FUSED-LOSS mode, needs
  * l1_target / l1_fid / l1_w / l1_loss / l1_bg_sums): no harp_shade_fwd call is needed at all — the pass recomputes the colour anyway,
- * forms torch.nn.L1Loss(y_true * m, y_pred * m) (optimize_sequence.py:543) and its gradient itself and accumulates the loss value. */
+ * forms torch.nn.L1Loss(y_true * m, y_pred * m) (optimize_sequence.py:543) and its gradient itself and accumulates the loss value;
+ * with a->rgb != NULL it also writes that colour, i.e. the whole rendered image y_pred (background included), as harp_shade_fwd would. */
 int harp_shade_bwd(const harp_shade_args* a, hipStream_t stream);
 /* harp_shade_bwd(a) and harp_silhouette_bwd(a->faces, ..., ws = a->recs, alpha, g_alpha, g_ndc = a->g_ndc) of the SAME camera-view
  * rasterisation as ONE launch whose workgroups alternate between the two kinds of tile: as separate kernels on two streams they cannot
