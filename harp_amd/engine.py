@@ -162,6 +162,7 @@ class FitEngine:
         self.comm = None                 # harp_amd.dist.RcclComm: direct RCCL all-reduce on the step's stream (graph node by default), set_comm()
         self.force_allreduce = False     # run the N > 1 code path on a single rank (tests, bench HARP_FORCE_DIST)
         self.fused_loss = True           # loss-only mode: photometric L1 formed inside the shader backward (no forward shading launch)
+        self.mesh_third = True           # key-point / mesh regularisers on a third stream (their own graph branch) instead of in front of the light view: 0.751 vs 0.760 ms / step
         self.fused_keep = True           # keep_image with the fused loss: the shader backward also writes y_pred (no forward shading launch either)
         self.keep_image = True           # shader forward writes the rendered image s["rgb"] (False: loss + gradient only)
         self.mesh_terms_first = True     # key-point term + mesh regularisers run before the light raster (under the raster set-up) instead of after it
@@ -398,8 +399,16 @@ class FitEngine:
                 side.wait_stream(cur)
             else:
                 side.wait_event(fork)
+            if sched_early and self.mesh_third:
+                third = self._third_stream()
+                if fork is None:
+                    third.wait_stream(cur)
+                else:
+                    third.wait_event(fork)
+                with torch.cuda.stream(third):
+                    mesh_terms()
             with torch.cuda.stream(side):
-                if sched_early and self.mesh_terms_first:
+                if sched_early and self.mesh_terms_first and not self.mesh_third:
                     mesh_terms()
                 if shadow:
                     if not fused:
@@ -410,7 +419,7 @@ class FitEngine:
                     self._ck(L.harp_rasterize_fwd(p(s["ndc_l"]), p(tp.faces), B, V, F, S, 0 if self.keep_image else 2, 0.0, 1.0, p(s["ws_l"]), p(s["face_l"]),
                                                   p(s["zl"]), None, ST()),
                              "raster_light")
-                if sched_early and not self.mesh_terms_first:
+                if sched_early and not self.mesh_terms_first and not self.mesh_third:
                     mesh_terms()
 
         def camera_view():
@@ -433,6 +442,8 @@ class FitEngine:
             light_view()
             camera_view()
         cur.wait_stream(side)                           # join: light depth map, regulariser gradients, normalised normal map
+        if sched_early and self.mesh_third:
+            cur.wait_stream(self._third_stream())
         # both backward passes of the camera view as ONE launch (harp_shade_sil_bwd): as two kernels on two streams they cannot share a CU
         fuse_bwd = self.fused_bwd and coarse and app and self.perceptual is None
         side_used = False
@@ -575,6 +586,12 @@ class FitEngine:
         lloss[9:10].copy_(loss.detach().reshape(1))
         covered = (s["face_c"][:B] >= 0).unsqueeze(-1)
         s["g_rgb"][:B] = torch.where(covered, s["g_rgb"][:B] + self.perceptual_weight * g, torch.zeros((), device=self.dev))
+
+    def _third_stream(self):
+        lane = self._lane
+        if lane.get("third") is None:
+            lane["third"] = torch.cuda.Stream(device=self.dev)
+        return lane["third"]
 
     def _side_stream(self):
         lane = self._lane
@@ -772,7 +789,7 @@ class FitEngine:
         # every switch the enqueued launch sequence depends on is part of the key: flipping one re-captures instead of replaying a
         # graph recorded for another configuration
         gkey = (coarse, app, scheduled, self.keep_image, self.fused_loss, self.self_shadow, tuple(self.frozen), self.overlap, self.early_terms,
-                self.packed_texels, self.fused_keep, self.auto_draw, self.mesh_terms_first, self.camera_first, self.tail_side, self.fused_bwd, self.fused_chain, self.fused_front, self.fused_back, dist_on, self.overlap_allreduce,
+                self.packed_texels, self.fused_keep, self.mesh_third, self.auto_draw, self.mesh_terms_first, self.camera_first, self.tail_side, self.fused_bwd, self.fused_chain, self.fused_front, self.fused_back, dist_on, self.overlap_allreduce,
                 self.comm is not None, self.perceptual is not None and app)
         g = self._graphs.get(gkey)
         if g is None:
