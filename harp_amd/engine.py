@@ -162,7 +162,7 @@ class FitEngine:
         self.comm = None                 # harp_amd.dist.RcclComm: direct RCCL all-reduce on the step's stream (graph node by default), set_comm()
         self.force_allreduce = False     # run the N > 1 code path on a single rank (tests, bench HARP_FORCE_DIST)
         self.fused_loss = True           # loss-only mode: photometric L1 formed inside the shader backward (no forward shading launch)
-        self.mesh_third = True           # key-point / mesh regularisers on a third stream (their own graph branch) instead of in front of the light view: 0.751 vs 0.760 ms / step
+        self.mesh_third = True           # key-point / mesh regularisers on a third stream (their own graph branch) instead of in front of the light view: 0.755 vs 0.766 ms / step (a fourth branch for the parameter-only terms: 0.803 vs 0.753)
         self.fused_keep = True           # keep_image with the fused loss: the shader backward also writes y_pred (no forward shading launch either)
         self.keep_image = True           # shader forward writes the rendered image s["rgb"] (False: loss + gradient only)
         self.mesh_terms_first = True     # key-point term + mesh regularisers run before the light raster (under the raster set-up) instead of after it
@@ -200,9 +200,9 @@ class FitEngine:
         s["alpha"], s["zl"], s["rgb"] = f(B, S, S), f(B, S, S), f(B, S, S, 3)
         s["nmap_n"] = self.nmap_n
         # gradients (zeroed every step in ONE memset: they are carved from one flat buffer)
-        gspec = [("g_alpha", (B, S, S)), ("g_rgb", (B, S, S, 3)), ("g_zl", (B, S, S)), ("g_vd", (B, V, 3)), ("g_n2", (B, V, 3)),
+        gspec = [("g_alpha", (B, S, S)), ("g_rgb", (B, S, S, 3)), ("g_zl", (B, S, S)), ("g_vd", (B, V, 3)), ("g_joints_m", (B, NJo, 3)), ("g_n2", (B, V, 3)),
                  ("g_ndc_c", (B, V, 3)), ("g_ndc_l", (B, V, 3)), ("g_n1", (B, V, 3)), ("g_vs", (B, V, 3)), ("g_tmp", (B, V, 3)),
-                 ("g_v0", (B, V0, 3)), ("g_joints_m", (B, NJo, 3)), ("g_joints_mm", (B, NJo, 3)), ("g_light_pos", (B, 3)), ("g_colors", (9,)),
+                 ("g_v0", (B, V0, 3)), ("g_joints_mm", (B, NJo, 3)), ("g_light_pos", (B, 3)), ("g_colors", (9,)),
                  ("g_light_R", (B, 9)), ("g_light_T", (B, 3)), ("g_cam_R", (B, 9)), ("g_cam_T", (B, 3)), ("g_centroid", (B, 3)),
                  ("g_pose48", (B, self.pose_stride)), ("g_betas", (B, self.n_betas)), ("g_trans_b", (B, 3))] + list(extra)
         garena = _Arena(gspec, dev)
@@ -214,13 +214,15 @@ class FitEngine:
         # g_alpha and g_rgb (the first two segments, 4/5 of the slab) are fully overwritten by harp_image_l1: only the rest is zeroed
         # ... and of the rest, g_zl (B*S*S floats, 9/10 of it) is first touched by the shader backward: it is cleared on the second
         # stream, off the head of the step; the small remainder is cleared first thing on the main stream
-        return dict(s=s, gs_zero=gs_buf[garena.offsets["g_vd"][0]:], gs_zero_late=s["g_zl"], B=B, lo=lo, fid=self.fid[lo:lo + B], tfid=self.tfid[lo:lo + B],
+        # ... and g_vd / g_joints_m, the two the key-point / mesh terms accumulate into, are a segment of their own: those terms run on a
+        # third stream, which clears the segment itself instead of depending on the clear of another branch
+        return dict(s=s, gs_zero=gs_buf[garena.offsets["g_n2"][0]:], gs_mesh=gs_buf[garena.offsets["g_vd"][0]:garena.offsets["g_n2"][0]], gs_zero_late=s["g_zl"], B=B, lo=lo, fid=self.fid[lo:lo + B], tfid=self.tfid[lo:lo + B],
                     loss_vec=torch.zeros(16, dtype=torch.float32, device=dev), w_vec=torch.zeros(16, dtype=torch.float32, device=dev),
                     stream=None, side=None)
 
     def _activate(self, lane):
         """point the step code at one lane's buffers (host-side bookkeeping only)"""
-        self.s, self.gs_zero, self.gs_zero_late, self._lane = lane["s"], lane["gs_zero"], lane["gs_zero_late"], lane
+        self.s, self.gs_zero, self.gs_mesh, self.gs_zero_late, self._lane = lane["s"], lane["gs_zero"], lane["gs_mesh"], lane["gs_zero_late"], lane
 
     def set_targets(self, y_true, y_sil, y_sil_col, frame_offset=0):
         """(Tl,S,S,3), (Tl,S,S), (Tl,S,S) fp32 for this rank's frames [frame_offset, frame_offset+Tl): kept resident in HBM
@@ -351,22 +353,30 @@ class FitEngine:
         # cleared it already, the big slab clear moves to the second stream, off the head of the step
         fill_side = self._loss_cleared and self.early_terms and self.overlap and bool(lane.get("owns_shared"))
         self._loss_cleared = False
+        # g_vd / g_joints_m: cleared by the third stream in front of the terms that accumulate into them (nothing else touches the two
+        # before the streams join), otherwise together with the rest of the slab
+        mesh_on_third = self.mesh_third and self.early_terms and self.overlap
         if fill_side:
             pass
         else:
             self.gs_zero.zero_()                         # main lane: one fill also covers g_buf, g_nmap_n and the loss vector
+            if not mesh_on_third:
+                self.gs_mesh.zero_()
             if not lane.get("owns_shared"):
                 lloss.zero_()
         shadow = app and self.self_shadow
         if not self.overlap:
             side = cur                                   # single-stream mode (used when individual kernels are timed with events)
         sched_early = self.early_terms
+        extra = lambda name: self._extra_stream(name) if self.overlap else cur      # further graph branches (hipGraph replays four concurrently here)
         off = self.disabled_terms
         # ---- terms that depend on the parameters only (normal-map normalisation, texture regularisers, displacement regulariser) go
         #      first on the second stream: they run under the LBS / mesh chain, which is a string of small latency-bound launches
         def param_terms():
             if fill_side:
                 self.gs_zero[:-16].zero_()               # everything but the loss vector (last 16 floats of the slab)
+                if not mesh_on_third:
+                    self.gs_mesh.zero_()
             self.gs_zero_late.zero_()
             if tick:
                 self._adam_tick(coarse, app)             # only touches the hyper-parameter block: off the serial tail of the step
@@ -399,16 +409,17 @@ class FitEngine:
                 side.wait_stream(cur)
             else:
                 side.wait_event(fork)
-            if sched_early and self.mesh_third:
-                third = self._third_stream()
+            if mesh_on_third:
+                third = extra("third")
                 if fork is None:
                     third.wait_stream(cur)
                 else:
                     third.wait_event(fork)
                 with torch.cuda.stream(third):
+                    self.gs_mesh.zero_()
                     mesh_terms()
             with torch.cuda.stream(side):
-                if sched_early and self.mesh_terms_first and not self.mesh_third:
+                if sched_early and self.mesh_terms_first and not mesh_on_third:
                     mesh_terms()
                 if shadow:
                     if not fused:
@@ -419,7 +430,7 @@ class FitEngine:
                     self._ck(L.harp_rasterize_fwd(p(s["ndc_l"]), p(tp.faces), B, V, F, S, 0 if self.keep_image else 2, 0.0, 1.0, p(s["ws_l"]), p(s["face_l"]),
                                                   p(s["zl"]), None, ST()),
                              "raster_light")
-                if sched_early and not self.mesh_terms_first and not self.mesh_third:
+                if sched_early and not self.mesh_terms_first and not mesh_on_third:
                     mesh_terms()
 
         def camera_view():
@@ -442,8 +453,8 @@ class FitEngine:
             light_view()
             camera_view()
         cur.wait_stream(side)                           # join: light depth map, regulariser gradients, normalised normal map
-        if sched_early and self.mesh_third:
-            cur.wait_stream(self._third_stream())
+        if mesh_on_third:
+            cur.wait_stream(extra("third"))
         # both backward passes of the camera view as ONE launch (harp_shade_sil_bwd): as two kernels on two streams they cannot share a CU
         fuse_bwd = self.fused_bwd and coarse and app and self.perceptual is None
         side_used = False
@@ -587,11 +598,12 @@ class FitEngine:
         covered = (s["face_c"][:B] >= 0).unsqueeze(-1)
         s["g_rgb"][:B] = torch.where(covered, s["g_rgb"][:B] + self.perceptual_weight * g, torch.zeros((), device=self.dev))
 
-    def _third_stream(self):
+    def _extra_stream(self, name):
         lane = self._lane
-        if lane.get("third") is None:
-            lane["third"] = torch.cuda.Stream(device=self.dev)
-        return lane["third"]
+        if lane.get(name) is None:
+            lane[name] = torch.cuda.Stream(device=self.dev)
+        return lane[name]
+
 
     def _side_stream(self):
         lane = self._lane
