@@ -1,7 +1,8 @@
 #!/bin/bash
-# SQ counter passes (counters only with --kernel-trace) over an eager 3-step bench run: tools/pmc_sq.sh TAG [kernel-substring]
+# SQ counter passes (counters only with --kernel-trace) over an eager 3-step bench run: tools/pmc_sq.sh TAG [kernel-substring] [name]
+#   -> gpurun_out/TAG_pmc_sq_NAME.txt (both passes + the derived figures of tools/pmc_sq_derive.py)
 set -u
-tag=${1:-rXX}; filt=${2:-shade_kernel}
+tag=${1:-rXX}; filt=${2:-shade_kernel}; name=${3:-kernel}
 out=gpurun_out; mkdir -p $out; export TMPDIR=/tmp
 cmd="python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras --no-roofline --no-graph"
 p1="SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_SMEM"
@@ -13,4 +14,6 @@ for p in "$p1" "$p2"; do
   python tools/pmc_summary.py $(find $out/pmcsq_${tag}_$i -name "*.db" | head -1) "$filt" 4 > $out/${tag}_pmc_sq_$i.txt
   rm -rf $out/pmcsq_${tag}_$i
 done
-cat $out/${tag}_pmc_sq_1.txt $out/${tag}_pmc_sq_2.txt
+cat $out/${tag}_pmc_sq_1.txt $out/${tag}_pmc_sq_2.txt > $out/${tag}_pmc_sq_${name}.txt
+python tools/pmc_sq_derive.py $out/${tag}_pmc_sq_${name}.txt > /dev/null
+cat $out/${tag}_pmc_sq_${name}.txt
