@@ -613,9 +613,10 @@ __global__ void __launch_bounds__(256) depth_bwd_kernel(const int32_t* __restric
   const int xi = tx0 + (lane & 15), yi = ty0 + w * 4 + (lane >> 4);
   const bool in_img = xi < S && yi < S;
   const size_t o = ((size_t)b * S + (in_img ? yi : 0)) * S + (in_img ? xi : 0);
+  // face id and gradient are requested together: one dependent round trip and one barrier per tile instead of two (the tile loop is a
+  // chain of such trips: 81 -> 70 us at 1024^2); the 4 bytes per pixel read for nothing in tiles without faces do not show
   const int f = in_img ? face_id[o] : -1;
-  if (__syncthreads_or(f >= 0 ? 1 : 0) == 0) continue;        // tile without faces: do not even read the gradient image
-  const float g = (f >= 0) ? g_z[o] : 0.f;
+  const float g = in_img ? g_z[o] : 0.f;
   const bool act = f >= 0 && g != 0.f;
   if (__syncthreads_or(act ? 1 : 0) == 0) continue;
   s_acc.clear();
