@@ -47,6 +47,7 @@ AMBIGUOUS_FRACTION = {
     "app_only_hand_256_b2": 0.0618,
     "c2_hand_128_b18": 0.0436,
     "c2c3_hand_512_b2": 0.0602,
+    "c3_hand_512_b32": 0.0515,
     "c5_arm_1024_b1": 0.0262,
     "c5_arm_1024_b32": 0.0311,
     "parity_arm_128": 0.0245,

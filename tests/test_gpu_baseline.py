@@ -185,6 +185,55 @@ def test_c5_arm_1024_b32_through_the_striding_kernels(monkeypatch):
         assert all(v < GRAD_TOL for v in worst.values()), (f, worst)
 
 
+def test_c3_hand_512_b32_per_frame_rows_vs_fp64_oracle():
+    """C3 at the batch the headline number is quoted on: 32 frames of the subdivided hand at 512x512 in one step (the bench workload).
+    Oracle parity on 2 of the 32 frames the same way as for C5: every loss term that reaches a per-frame parameter row (pose, cam, rot,
+    trans) is a mean over the batch of per-frame terms, so row f of the batch gradient x 32 is the gradient of the ONE-frame step on
+    frame f, which the float64 oracle evaluates (rel-L2 <= 1e-3, those frames' float32-undecidable pixels out of the mask) — in both image
+    modes, whose losses must agree; plus the size-independent properties of all 32 frames."""
+    from tests._scene import ambiguous_pixels
+    T = B = 32
+    case = make_fit_case("hand", T=T, S=512, B=B, seed=2, device=DEV)
+    eng = case["eng"]
+    frames = (5, 26)
+    P, model, targets = oracle_inputs(case, torch.float64)
+    y_col = case["targets"]["y_sil_col"].clone()
+    removed = []
+    for f in frames:
+        amb, aux = ambiguous_pixels(P, model, case["topo"], 512, case["focal"], [f], targets["y_true"])
+        y_col[f][amb[0]] = 0.0
+        removed.append(amb.sum().item() / max((aux["pix_to_face"][..., 0] >= 0).sum().item(), 1))
+    check_removed("c3_hand_512_b32", max(removed))
+    case["targets"]["y_sil_col"] = y_col
+    eng.set_targets(case["targets"]["y_true"], case["targets"]["y_sil"], y_col)
+    eng.draw_texture_offsets()
+    fid = torch.arange(T)
+    rows = ("pose", "cam", "rot", "trans")
+    got, lvs = {}, {}
+    for keep in (True, False):
+        eng.keep_image = keep
+        lvs[keep] = engine_eval(case, fid)
+        got[keep] = {k: eng.grads[k].detach().cpu().double().clone() for k in rows}
+        if keep:
+            a, fc, rgb = eng.s["alpha"], eng.s["face_c"], eng.s["rgb"]
+            cov = fc >= 0
+            assert (a >= 0).all() and (a <= 1).all() and (fc >= -1).all() and (fc < eng.topo.F).all()
+            assert 0.02 < cov.float().mean().item() < 0.9 and (a[cov] > 0.49).all() and (rgb[~cov] == 1.0).all()
+            assert torch.isfinite(rgb).all() and torch.isfinite(eng.g_buf).all()
+    for k, v in lvs[True].items():
+        assert abs(v - lvs[False][k]) <= LOSS_TOL * abs(v) + 1e-12, (k, v, lvs[False][k])
+    targets["y_sil_col"] = y_col.double()
+    for f in frames:
+        for k in ORACLE_KEYS:
+            if k in P:
+                P[k].grad = None
+        oracle_step(case, torch.tensor([f]), P=P, model=model, targets=targets)
+        for keep in (True, False):
+            worst = {k: rel(got[keep][k][f] * B, P[k].grad[f]) for k in rows}
+            print(f"[gradient rel-L2 vs fp64 oracle] C3 B=32 frame {f} keep_image={keep}:", {k: f"{v:.1e}" for k, v in worst.items()})
+            assert all(v < GRAD_TOL for v in worst.values()), (f, keep, worst)
+
+
 def test_c1_raw_mano_mesh_silhouette_only():
     """config C1: one 256x256 frame, the un-subdivided MANO mesh, silhouette loss only"""
     from harp_amd.engine import LOSS_NAMES
