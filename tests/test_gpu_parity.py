@@ -790,6 +790,36 @@ def test_losses_with_empty_supertiles():
             assert rel(eng.grads[k].cpu(), g) < 2e-3, (keep, k)
 
 
+def test_mesh_entirely_off_screen():
+    """Edge case of the tile kernels: NO face reaches any tile (the hand is moved 5 m to the side), i.e. zero super-tiles with work in the
+    camera view (launch-order count nact = 0).  The image terms are then the terms of the empty image — silhouette = mean |0 - y_sil|,
+    photometric = mean |bg * m - y_true * m| — in both image modes and in replayed graphs; nothing is covered, every gradient is finite
+    and the image terms send no gradient to the geometry."""
+    from tests._scene import make_fit_case, engine_eval
+    case = make_fit_case("hand", T=2, S=256, B=2, seed=4, device=DEV)
+    eng = case["eng"]
+    with torch.no_grad():
+        eng.params["trans"][:, 0] += 5.0
+    tg = case["targets"]
+    fid = torch.arange(2)
+    sil_ref = tg["y_sil"].float().abs().mean().item()
+    m = tg["y_sil_col"].float()[..., None]
+    photo_ref = (1.0 * m - tg["y_true"].float() * m).abs().mean().item()            # BG_COLOR = white
+    for keep in (True, False):
+        eng.keep_image = keep
+        lv = engine_eval(case, fid)
+        assert abs(lv["silhouette"] - sil_ref) <= 1e-5 * sil_ref and abs(lv["photo"] - photo_ref) <= 1e-5 * photo_ref, (keep, lv, sil_ref, photo_ref)
+        assert torch.isfinite(eng.g_buf).all()
+        if keep:
+            assert (eng.s["face_c"] < 0).all() and (eng.s["alpha"] == 0).all() and (eng.s["rgb"] == 1.0).all()
+        assert eng.grads["cam"].abs().max().item() == 0.0                         # only the image terms reach the camera
+    for _ in range(3):
+        eng.step(fid, True, True, use_graph=True)
+    torch.cuda.synchronize()
+    ls = eng.losses()
+    assert abs(ls["silhouette"] - sil_ref) <= 1e-5 * sil_ref and all(np.isfinite(v) for v in ls.values())
+
+
 def test_arm_engine_loss_only_mode():
     """SMPL-X arm mesh through the fitting loop's loss-only mode (no image, sparse raster outputs, static-target tables, photometric L1
     formed in the shader backward): same losses and gradients as the image mode"""
