@@ -95,6 +95,50 @@ def test_rasterizer_and_silhouette(sc):
     assert torch.allclose(g, 7.0 * torch.sign(d) / d.numel(), rtol=1e-6, atol=0)
 
 
+@pytest.mark.parametrize("shrink", [0.25, 0.1])
+def test_rasterizer_many_faces_per_tile(sc, shrink):
+    """Edge case of the staging loop: the whole subdivided hand (6152 faces) inside a handful of 16x16 tiles — hundreds to thousands of
+    faces per tile against 256 staging slots (several staging rounds per tile, each followed by its own scan and soft pass whose
+    per-pixel state carries over), triangles far below a pixel, dozens of faces per pixel.  Same checks as the regular-size test, against
+    the oracle's K = 50 / K = 1 rasterisation."""
+    from harp_amd import ops
+    from oracle import harp_ref as H, p3d_like as P
+    S, focal, topo = 128, sc["focal"] * shrink, sc["topo"]
+    params = dict(pose=sc["seq"]["pose"], rot=sc["seq"]["rot"], trans=sc["seq"]["trans"], shape=sc["seq"]["shape"].mean(0),
+                  verts_disps=torch.zeros(3093, 1))
+    fid = torch.arange(2)
+    with torch.no_grad():
+        _, v = H.prepare_mesh(params, fid, sc["model"], topo)
+        R, T = H.camera_RT(sc["seq"]["cam"][fid], S, sc["focal"])
+        _, ndc = P.world_to_ndc(v, R, T, focal, (S / 2, S / 2), S)
+    ndc = ndc.requires_grad_()
+    p2f, zb, bary, d = P.rasterize_meshes(ndc, topo["faces"], S, ops.SIL_BLUR, 50)
+    a_ref = P.sigmoid_alpha_blend(p2f, d, ops.SIL_SIGMA)
+    tgt = (torch.rand(2, S, S, generator=torch.Generator().manual_seed(5)) > 0.5).float()
+    (a_ref - tgt).abs().mean().backward()
+    p2f1, zb1, _, _ = P.rasterize_meshes(ndc.detach(), topo["faces"], S, 0.0, 1)
+    F = topo["faces"].shape[0]
+    fid_ref = torch.where(p2f1[..., 0] >= 0, p2f1[..., 0] % F, p2f1[..., 0]).int()
+    covered = (fid_ref >= 0).sum().item()
+    ndc_d = ndc.detach().to(DEV).requires_grad_()
+    faces_d = topo["faces"].int().to(DEV)
+    alpha, face_id = ops.soft_silhouette(ndc_d, faces_d, S)
+    (alpha - tgt.to(DEV)).abs().mean().backward()
+    f2, z2, _, _ = ops.rasterize_fwd(ndc_d.detach(), faces_d, S, soft=False)
+    tiles = ((fid_ref >= 0).view(2, S // 16, 16, S // 16, 16).sum((2, 4)) > 0).sum().item()
+    bad_a = ((alpha.cpu() - a_ref).abs() > 1e-4).sum().item()
+    bad_f = (f2.cpu() != fid_ref).sum().item()
+    m = (f2.cpu() == fid_ref) & (fid_ref >= 0)
+    zerr = (z2.cpu() - zb1[..., 0])[m].abs().max().item()
+    g = rel(ndc_d.grad.cpu(), ndc.grad)
+    print(f"[many faces per tile] shrink {shrink}: {covered} covered pixels in {tiles} tiles (~{2 * F // max(tiles, 1)} faces / tile), alpha mismatches {bad_a}, "
+          f"face-id mismatches {bad_f}, depth err {zerr:.1e}, gradient rel-L2 {g:.1e}")
+    assert covered > 50 and 2 * F / tiles > 256                      # really more faces per tile than staging slots
+    assert torch.equal(face_id, f2)
+    assert bad_a <= 1e-3 * 2 * S * S and bad_f <= max(2, 0.01 * covered) and zerr < 1e-5
+    assert g < 2e-3
+
+
 def test_full_step_losses_grads_and_adam(sc):
     from harp_amd.engine import FitEngine, LOSS_NAMES
     from oracle import harp_ref as H
