@@ -139,6 +139,60 @@ def test_rasterizer_many_faces_per_tile(sc, shrink):
     assert g < 2e-3
 
 
+def test_rasterizer_culled_degenerate_and_huge_faces(sc):
+    """Inputs the rasteriser must reject or survive the way PyTorch3D does: vertices behind the camera (every face that touches one is skipped:
+    z_invalid), faces with a repeated vertex (zero area), and vertices far outside the image (faces whose boxes span most of the frame and
+    reach every super-tile's list).  Forward (alpha, face ids, depth) and the silhouette gradient against the oracle."""
+    from harp_amd import ops
+    from oracle import harp_ref as H, p3d_like as P
+    S, focal, topo = 192, sc["focal"] * 1.5, sc["topo"]
+    params = dict(pose=sc["seq"]["pose"], rot=sc["seq"]["rot"], trans=sc["seq"]["trans"], shape=sc["seq"]["shape"].mean(0),
+                  verts_disps=torch.zeros(3093, 1))
+    fid = torch.arange(2)
+    with torch.no_grad():
+        _, v = H.prepare_mesh(params, fid, sc["model"], topo)
+        R, T = H.camera_RT(sc["seq"]["cam"][fid], S, focal)
+        _, ndc = P.world_to_ndc(v, R, T, focal, (S / 2, S / 2), S)
+    g = torch.Generator().manual_seed(9)
+    V = ndc.shape[1]
+    ndc = ndc.clone()
+    behind = torch.randperm(V, generator=g)[: V // 12]
+    ndc[:, behind, 2] *= -1.0                                        # behind the camera
+    far = torch.randperm(V, generator=g)[:6]
+    ndc[0, far[:3], 0] = 3.0                                         # far outside the image, frame 0 only
+    ndc[1, far[3:], 1] = -2.5
+    faces = topo["faces"].clone()
+    dup = torch.randperm(faces.shape[0], generator=g)[:40]
+    faces[dup, 1] = faces[dup, 0]                                    # zero-area faces
+    ndc = ndc.requires_grad_()
+    p2f, zb, bary, d = P.rasterize_meshes(ndc, faces, S, ops.SIL_BLUR, 50)
+    a_ref = P.sigmoid_alpha_blend(p2f, d, ops.SIL_SIGMA)
+    tgt = (torch.rand(2, S, S, generator=g) > 0.5).float()
+    (a_ref - tgt).abs().mean().backward()
+    p2f1, zb1, _, _ = P.rasterize_meshes(ndc.detach(), faces, S, 0.0, 1)
+    F = faces.shape[0]
+    fid_ref = torch.where(p2f1[..., 0] >= 0, p2f1[..., 0] % F, p2f1[..., 0]).int()
+    ndc_d = ndc.detach().to(DEV).requires_grad_()
+    faces_d = faces.int().to(DEV)
+    alpha, face_id = ops.soft_silhouette(ndc_d, faces_d, S)
+    (alpha - tgt.to(DEV)).abs().mean().backward()
+    f2, z2, _, _ = ops.rasterize_fwd(ndc_d.detach(), faces_d, S, soft=False)
+    covered = (fid_ref >= 0).sum().item()
+    culled = ((ndc.detach()[:, :, 2][:, faces] < 1e-8).any(-1)).sum().item()
+    bad_a = ((alpha.cpu() - a_ref).abs() > 1e-4).sum().item()
+    bad_f = (f2.cpu() != fid_ref).sum().item()
+    m = (f2.cpu() == fid_ref) & (fid_ref >= 0)
+    zerr = (z2.cpu() - zb1[..., 0])[m].abs().max().item()
+    gr = rel(ndc_d.grad.cpu(), ndc.grad)
+    print(f"[culled / degenerate / huge faces] {covered} covered pixels, {culled} (frame, face) pairs behind the camera, alpha mismatches {bad_a}, "
+          f"face-id mismatches {bad_f}, depth err {zerr:.1e}, gradient rel-L2 {gr:.1e}")
+    assert covered > 2000 and culled > 1000 and torch.equal(face_id, f2)
+    used = torch.unique(f2[f2 >= 0]).cpu()
+    assert not torch.isin(used, dup).any()                                          # no zero-area face is ever the nearest one
+    assert bad_a <= 1e-3 * 2 * S * S and bad_f <= 1e-4 * 2 * S * S + 2 and zerr < 1e-5 and gr < 2e-3
+    assert torch.isfinite(ndc_d.grad).all() and (ndc_d.grad[:, behind.to(DEV)] == 0).all()   # culled faces send no gradient
+
+
 def test_full_step_losses_grads_and_adam(sc):
     from harp_amd.engine import FitEngine, LOSS_NAMES
     from oracle import harp_ref as H
