@@ -180,9 +180,7 @@ __device__ __forceinline__ void shade_bwd_tile(ShadeSmem& sm, unsigned vblock, c
   if (64 * w < n_tile) {                     // only waves that got a share of the tile's active pixels clear their tables
     // (16-B stores over the whole 9.5-KB block, then the two key arrays: 14 LDS instructions instead of 43)
     int4* L4 = reinterpret_cast<int4*>(&L);
-#pragma unroll
     for (int i = lane; i < (int)(sizeof(WaveLds) / 16); i += 64) L4[i] = make_int4(0, 0, 0, 0);
-#pragma unroll
     for (int i = lane; i < kTSlots; i += 64) L.tkey[i] = -1;
     if (lane < kVSlots) L.vkey[lane] = -1;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
