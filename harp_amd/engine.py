@@ -162,6 +162,7 @@ class FitEngine:
         self.comm = None                 # harp_amd.dist.RcclComm: direct RCCL all-reduce on the step's stream (graph node by default), set_comm()
         self.force_allreduce = False     # run the N > 1 code path on a single rank (tests, bench HARP_FORCE_DIST)
         self.fused_loss = True           # loss-only mode: photometric L1 formed inside the shader backward (no forward shading launch)
+        self.graph_order = True
         self.mesh_third = True           # key-point / mesh regularisers on a third stream (their own graph branch) instead of in front of the light view: 0.755 vs 0.766 ms / step (a fourth branch for the parameter-only terms: 0.803 vs 0.753)
         self.fused_keep = True           # keep_image with the fused loss: the shader backward also writes y_pred (no forward shading launch either)
         self.keep_image = True           # shader forward writes the rendered image s["rgb"] (False: loss + gradient only)
@@ -396,11 +397,21 @@ class FitEngine:
             if coarse and not off.issuperset(("laplacian", "normal", "arap")):      # (individually disabled ones carry weight 0)
                 self._ck(L.harp_mesh_regularizers(p(s["vd"]), p(self.ref_verts), p(tp.nbr_off), p(tp.nbr_idx), p(tp.nc_pairs), p(tp.vp_off), p(tp.vp_idx), B, V,
                                                   tp.nc_pairs.shape[0], tp.E, wp(3), lp(3), p(s["g_vd"]), ST()), "mesh_reg")
-        if sched_early:
+        # Capture order matters to the replay: of the kernels that depend on one node, hipGraph keeps the FIRST-captured one on
+        # that node's stream (no gap) and gives the others the next streams (~11 us of cross-stream wait each).  `graph_order` captures the
+        # critical path first everywhere — hand layer before the second stream's fork, camera-view set-up before the light view's, the light
+        # view before the third stream, the shader backward before the silhouette backward — so that it replays as ONE in-order stream.
+        go = self.graph_order and sched_early and self.overlap and self.camera_first
+        if sched_early and not go:
             side.wait_stream(cur)
             with torch.cuda.stream(side):
                 param_terms()
+        ev0 = cur.record_event() if go else None
         fused = self._mesh_forward(lfid, B, shadow, front=True)      # fused chain: both projections and the light camera are done as well
+        if go:
+            side.wait_event(ev0)
+            with torch.cuda.stream(side):
+                param_terms()
         # ---- the light-view chain (centroid -> light camera -> projection -> K=1 raster) is independent of the camera-view chain:
         #      it runs on the second HIP stream so the two rasterisations overlap (fork / join is captured into the graph); the mesh
         #      regularisers and the key-point term follow it there (the light raster is the shorter of the two)
@@ -409,15 +420,18 @@ class FitEngine:
                 side.wait_stream(cur)
             else:
                 side.wait_event(fork)
-            if mesh_on_third:
-                third = extra("third")
-                if fork is None:
-                    third.wait_stream(cur)
-                else:
-                    third.wait_event(fork)
-                with torch.cuda.stream(third):
-                    self.gs_mesh.zero_()
-                    mesh_terms()
+            def third_branch():
+                if mesh_on_third:
+                    third = extra("third")
+                    if fork is None:
+                        third.wait_stream(cur)
+                    else:
+                        third.wait_event(fork)
+                    with torch.cuda.stream(third):
+                        self.gs_mesh.zero_()
+                        mesh_terms()
+            if not go:
+                third_branch()
             with torch.cuda.stream(side):
                 if sched_early and self.mesh_terms_first and not mesh_on_third:
                     mesh_terms()
@@ -432,6 +446,8 @@ class FitEngine:
                              "raster_light")
                 if sched_early and not self.mesh_terms_first and not mesh_on_third:
                     mesh_terms()
+            if go:
+                third_branch()
 
         def camera_view():
             # ---- camera view: projection + fused K=1 / soft-silhouette raster
@@ -458,13 +474,22 @@ class FitEngine:
         # both backward passes of the camera view as ONE launch (harp_shade_sil_bwd): as two kernels on two streams they cannot share a CU
         fuse_bwd = self.fused_bwd and coarse and app and self.perceptual is None
         side_used = False
-        if coarse and not fuse_bwd:
+        sil_after = None
+        def launch_sil(ev=None):
             # the silhouette backward only needs g_alpha and the camera-view workspace: it overlaps with shading on the side stream
-            side.wait_stream(cur)
-            side_used = True
+            if ev is None:
+                side.wait_stream(cur)
+            else:
+                side.wait_event(ev)
             with torch.cuda.stream(side):
                 self._ck(L.harp_silhouette_bwd(p(tp.faces), B, V, F, S, ops.SIL_BLUR, ops.SIL_SIGMA, p(s["ws_c"]), p(s["alpha"]), p(s["g_alpha"]),
                                                p(s["g_ndc_c"]), ST()), "silhouette_bwd")
+        if coarse and not fuse_bwd:
+            side_used = True
+            if go and app:
+                sil_after = cur.record_event()           # captured right behind the shader backward (which then stays on the camera raster's stream)
+            else:
+                launch_sil()
         if not sched_early:
             param_terms()
             mesh_terms()
@@ -488,6 +513,8 @@ class FitEngine:
                 self._ck(L.harp_shade_sil_bwd(ctypes.byref(a), ops.SIL_BLUR, ops.SIL_SIGMA, p(s["alpha"]), p(s["g_alpha"]), ST()), "shade_sil_bwd")
             else:
                 self._ck(L.harp_shade_bwd(ctypes.byref(a), ST()), "shade_bwd")
+            if sil_after is not None:
+                launch_sil(sil_after)
             if shared_terms:
                 # the normal-map chain rule (and, for N > 1, the early all-reduce of the map gradients, which overlaps with the mesh /
                 # hand-layer backward) only feeds the optimiser: with `tail_side` it leaves the critical path for the second stream, which
@@ -801,7 +828,7 @@ class FitEngine:
         # every switch the enqueued launch sequence depends on is part of the key: flipping one re-captures instead of replaying a
         # graph recorded for another configuration
         gkey = (coarse, app, scheduled, self.keep_image, self.fused_loss, self.self_shadow, tuple(self.frozen), self.overlap, self.early_terms,
-                self.packed_texels, self.fused_keep, self.mesh_third, self.auto_draw, self.mesh_terms_first, self.camera_first, self.tail_side, self.fused_bwd, self.fused_chain, self.fused_front, self.fused_back, dist_on, self.overlap_allreduce,
+                self.packed_texels, self.fused_keep, self.mesh_third, self.graph_order, self.auto_draw, self.mesh_terms_first, self.camera_first, self.tail_side, self.fused_bwd, self.fused_chain, self.fused_front, self.fused_back, dist_on, self.overlap_allreduce,
                 self.comm is not None, self.perceptual is not None and app)
         g = self._graphs.get(gkey)
         if g is None:
