@@ -3,12 +3,15 @@
 replayable as a hipGraph, with one RCCL all-reduce of the flat gradient arena between backward and Adam.
 
 What the reference does per step with ~600 torch/PyTorch3D kernel launches, >= 8 host syncs and CPU-resident
-parameters, this does with ~45 launches, no host sync and everything resident:
+parameters, this does with 32 launches (hand mesh; 44 for the SMPL-X arm), no host sync and everything resident:
 
-  frame_setup -> LBS -> subdivide -> normals+displace -> normals -> project(cam) -> centroid -> light_setup ->
-  project(light) -> raster(light, K=1) -> raster(cam, K=1 + soft silhouette) -> normalize(normal map) -> shade ->
-  losses(+their gradients) -> shade_bwd -> silhouette_bwd -> depth_bwd -> project_bwd x2 -> light_setup_bwd ->
-  normals_bwd x2 -> displace_bwd -> subdivide_bwd -> LBS_bwd -> frame_setup_bwd -> [all-reduce] -> Adam x2
+  schedule -> hand_front (frame set-up, LBS, subdivide, normals + displace, normals, both projections, light camera) ->
+  raster(cam, K=1 + soft silhouette + its L1) || raster(light, K=1) || parameter / mesh regularisers ->
+  shade_bwd (recomputes the colour, forms the photometric L1, writes y_pred when asked) || silhouette_bwd -> depth_bwd ->
+  hand_back (mesh chain + hand layer backward, 3 launches) -> [all-reduce] -> Adam
+
+(the building blocks behind the fused launches — frame_setup, LBS, subdivide, normals, project, centroid, light_setup, shade and
+their backward passes — are separate C-ABI entry points and stay reachable through the `fused_*` switches; tests compare the two).
 
 Parameters live in ONE flat fp32 arena (and one gradient / exp_avg / exp_avg_sq arena of the same layout); the
 reference's parameter dict (optimize_sequence.py:181-250) is exposed as views into it (`params`).
