@@ -475,9 +475,9 @@ def main():
                       "frames_per_gpu_per_step": eng.B, "global_batch": world * eng.B, "sequence_frames": eng.T,
                       "parallelism": f"dp{world} (frames sharded; flat gradient bucket of {eng.opt_span[1] * 4} B all-reduced over RCCL: the texture/normal-map "
                                      f"part overlapped with the mesh backward, the remainder before Adam)",
-                      "hipgraph": use_graph and (world == 1 or comm is not None or eng.graph_collectives),
+                      "hipgraph": bool(eng._graphs),
                       "collective": ("harp_allreduce_flat (RCCL on the step's streams, captured into the hipGraph)" if comm is not None else
-                                     ("torch.distributed.all_reduce, eager steps" if world > 1 else None)),
+                                     ("torch.distributed.all_reduce, eager steps" if (world > 1 or force_dist) else None)),
                       "rendered_image": "not materialised: the shader backward recomputes the colour and forms the photometric L1 and its gradient "
                                         "itself, so the step has no forward shading launch (loss, gradients and the parameter update are its "
                                         "outputs; FitEngine.keep_image=True renders and writes y_pred like the reference)"},
