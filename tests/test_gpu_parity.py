@@ -918,6 +918,34 @@ def test_mesh_entirely_off_screen():
     assert abs(ls["silhouette"] - sil_ref) <= 1e-5 * sil_ref and all(np.isfinite(v) for v in ls.values())
 
 
+@pytest.mark.parametrize("keep", [False, True])
+def test_graph_replays_see_the_same_state(keep):
+    """Race detector for the three-stream step graph: with both learning rates at 0 and a one-row schedule every replay starts from the same
+    state, so gradients and loss terms of every replay must equal the first one's up to the order of the float atomics; a missing
+    dependency between two streams (a clear racing with an accumulation, a reader ahead of its writer) shows as a large difference."""
+    from tests._scene import make_fit_case
+    case = make_fit_case("hand", T=4, S=256, B=4, seed=3, device=DEV)
+    eng = case["eng"]
+    eng.keep_image = keep
+    eng.auto_draw = False
+    eng.draw_texture_offsets()
+    eng.set_lr(0.0, 0.0)
+    eng.set_schedule(torch.arange(4).reshape(1, 4).int())
+    for _ in range(4):
+        eng.step(None, True, True)
+    torch.cuda.synchronize()
+    assert len(eng._graphs) == 1
+    g0, l0 = eng.g_buf.double().clone(), eng.loss_vec.double().clone()
+    worst_g = worst_l = 0.0
+    for i in range(120):
+        eng.step(None, True, True)
+        if i % 4 == 3:
+            torch.cuda.synchronize()
+            worst_g = max(worst_g, rel(eng.g_buf.double(), g0))
+            worst_l = max(worst_l, ((eng.loss_vec.double() - l0).abs() / l0.abs().clamp_min(1e-12)).max().item())
+    assert worst_g < 1e-5 and worst_l < 1e-4, (worst_g, worst_l)
+
+
 def test_arm_engine_loss_only_mode():
     """SMPL-X arm mesh through the fitting loop's loss-only mode (no image, sparse raster outputs, static-target tables, photometric L1
     formed in the shader backward): same losses and gradients as the image mode"""
