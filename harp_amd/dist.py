@@ -33,6 +33,51 @@ def batches(lo, hi, batch_size, step):
     return (torch.arange(batch_size) + step * batch_size) % n + lo
 
 
+def dist_env():
+    """(rank, world) of the default torch.distributed group; (0, 1) when none is initialised"""
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def epoch_batches(per, batch, gen):
+    """One epoch of a rank's shard: the `per` LOCAL item positions in a fresh random order, cut into batches of `batch` (the last one
+    may be shorter) — DataLoader(shuffle=True) (optimize_sequence.py:398) restricted to a shard.  `gen` is a torch.Generator seeded
+    identically on every rank, so all ranks draw the SAME within-shard order: every rank runs the same number of steps with the same
+    batch sizes (collectives stay matched), and the global batch of step s is the union over ranks r of `lo_r + order[s]` — which a
+    single process reproduces exactly with `shards=world` (tests/test_gpu_dist.py)."""
+    perm = torch.randperm(int(per), generator=gen)
+    return [perm[s0:s0 + batch] for s0 in range(0, int(per), int(batch))]
+
+
+def mean_over_ranks(value, device=None):
+    """Average a host-side scalar (or small tensor) over the ranks of the default group so that every rank continues with the SAME
+    number: the epoch loss that drives ReduceLROnPlateau (optimize_sequence.py:581-582) and the finite check must not diverge between
+    ranks, or the replicated Adam state does.  All-reduce(sum) hands every rank the identical result; no-op for a single process."""
+    rank, world = dist_env()
+    if world == 1:
+        return value
+    t = torch.as_tensor(value, dtype=torch.float64).clone()
+    if dist.get_backend() == "nccl":
+        t = t.to(device if device is not None else torch.device("cuda", torch.cuda.current_device()))
+    dist.all_reduce(t)
+    t = (t / world).cpu()
+    return t.item() if t.dim() == 0 else t
+
+
+def ranks_identical(t):
+    """True when the tensor is bit-identical on every rank (checksum max == min over the group)"""
+    rank, world = dist_env()
+    if world == 1:
+        return True
+    cs = torch.stack((t.double().sum(), t.double().abs().sum(), (t.double() * t.double()).sum())).reshape(3)
+    cs = cs if dist.get_backend() == "nccl" else cs.cpu()
+    hi, lo = cs.clone(), cs.clone()
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    return bool((hi == lo).all().item())
+
+
 def allreduce_flat(bucket, comm=None):
     """sum the flat gradient bucket over all ranks in one collective, in place (no-op for a single process without a communicator)"""
     if comm is not None:

@@ -86,11 +86,32 @@ def stage_flags(epoch_id, training_stage):
 
 def optimize_hand_sequence(configs, input_params, images_dataset, val_params, val_images_dataset, hand_layer,
                            VERTS_UVS=None, FACES_UVS=None, VERTS_COLOR=None, device="cuda", uv_mask=None, batch_size=18, log_fn=None,
-                           seed=0, vgg=None):
+                           seed=0, vgg=None, rank=None, world_size=None, shards=None, plateau_patience=40, plateau_threshold=1e-4):
     """Fit the sequence (optimize_sequence.py:313-596).  Returns the parameter dict in the reference's checkpoint layout.
-    `images_dataset[i]` -> (fid, y_true (S,S,3), y_sil (S,S,1), y_sil_eroded (S,S,1)) like utils/data_util.ImagesDataset."""
+    `images_dataset[i]` -> (fid, y_true (S,S,3), y_sil (S,S,1), y_sil_eroded (S,S,1)) like utils/data_util.ImagesDataset.
+
+    Data-parallel (the reference is single-device): launched under `torch.distributed.run` (or with rank / world_size given)
+    every rank calls this function with the SAME arguments.  The dataset's items are cut into `shards` (default: world) contiguous
+    shards, a rank decodes and keeps resident only its own (`ResidentTargets(frames=...)`), `batch_size` stays the GLOBAL batch of the
+    reference (each shard contributes batch_size / shards frames per step), the flat gradient bucket is summed over ranks before the
+    replicated dense Adam step (RCCL through `harp_allreduce_flat` inside the step's hipGraph when the process group is nccl = one
+    device per rank; torch.distributed otherwise), the per-epoch shuffle comes from the shared seed WITHIN each shard
+    (harp_amd.dist.epoch_batches), the epoch loss is averaged over ranks BEFORE ReduceLROnPlateau sees it (:581-582) so that every rank
+    takes the same learning-rate decision, the finite check runs on that averaged loss, and only rank 0 writes checkpoints.
+    `shards > world` makes one process walk several shards per step — a 1-rank job with shards = N visits the same global batches as an
+    N-rank job.  plateau_patience / plateau_threshold: ReduceLROnPlateau's arguments (reference: patience 40, default threshold)."""
+    from . import dist as hdist
     if configs["model_type"] != "harp":
         raise NotImplementedError("only model_type 'harp' (SURVEY.md §8: 'html' / 'nimble' are out of scope)")
+    env_rank, env_world = hdist.dist_env()
+    rank = env_rank if rank is None else int(rank)
+    world = env_world if world_size is None else int(world_size)
+    shards = world if shards is None else int(shards)
+    n_items = len(images_dataset)
+    if shards % world or n_items % shards or batch_size % shards:
+        raise ValueError(f"{n_items} dataset items / global batch {batch_size} do not split evenly over {shards} shards on {world} ranks")
+    k, per, b = shards // world, n_items // shards, batch_size // shards          # shards per rank, items per shard, frames per shard and step
+    lo = rank * k * per                                                           # this rank's items: [lo, lo + k * per)
     S, T = configs["img_size"], input_params["pose"].shape[0]
     use_arm = bool(configs["use_arm"])
     faces0 = np.asarray((hand_layer.right_arm_faces_tensor if use_arm else hand_layer.th_faces).detach().cpu())
@@ -98,13 +119,21 @@ def optimize_hand_sequence(configs, input_params, images_dataset, val_params, va
     if uv_mask is None:
         uv_mask = load_uv_mask(configs, (512, 512))
     eng = FitEngine(hand_layer._model_np, topo, torch.as_tensor(VERTS_UVS).reshape(-1, 2), torch.as_tensor(FACES_UVS).reshape(-1, 3),
-                    torch.as_tensor(uv_mask).float(), input_params, S, configs["focal_length"], batch_size, device=device,
+                    torch.as_tensor(uv_mask).float(), input_params, S, configs["focal_length"], b * k, device=device,
                     self_shadow=configs["self_shadow"], share_light_position=configs["share_light_position"], seed=seed,
-                    use_arm=use_arm, opt_arm_pose=bool(configs.get("opt_arm_pose", False)))
-    rt = ResidentTargets(images_dataset)                             # decoded once, resident in HBM (utils/data_util.py)
+                    use_arm=use_arm, opt_arm_pose=bool(configs.get("opt_arm_pose", False)), rank=rank, world_size=world)
+    rt = ResidentTargets(images_dataset, frames=range(lo, lo + k * per))         # decoded once, resident in HBM (utils/data_util.py)
     if int(rt.fid.min()) < 0 or int(rt.fid.max()) >= T:
         raise ValueError(f"dataset frame ids span [{int(rt.fid.min())}, {int(rt.fid.max())}] but the parameter tables hold {T} frames")
     eng.set_targets(*rt.tensors())
+    comm = None
+    if world > 1:
+        import torch.distributed as tdist
+        if not (tdist.is_available() and tdist.is_initialized()):
+            raise RuntimeError("world_size > 1 needs an initialised torch.distributed process group (torch.distributed.run)")
+        if tdist.get_backend() == "nccl":                                # one device per rank: RCCL straight from the step's hipGraph
+            comm = hdist.RcclComm.from_process_group(torch.device(device))
+            eng.set_comm(comm)
     # perceptual term (:404-405, :546-547): needs the pretrained VGG16 filters, which cannot be downloaded here — pass a ready module
     # (`vgg=`) or the path of torchvision's vgg16 state dict (configs["vgg_weights"]); without either the term is left out
     if vgg is None and configs.get("vgg_weights"):
@@ -122,35 +151,86 @@ def optimize_hand_sequence(configs, input_params, images_dataset, val_params, va
         eng.set_disabled_terms(("kps_anchor", "vert_disp_reg", "laplacian", "normal", "arap"))
     # ReduceLROnPlateau lives on the host; torch's own scheduler drives a dummy optimiser and the lr is mirrored to the device
     dummy = torch.optim.Adam([torch.nn.Parameter(torch.zeros(1))], lr=1e-3)
-    sched = torch.optim.lr_scheduler.ReduceLROnPlateau(dummy, patience=40)
-    gen = torch.Generator().manual_seed(seed)
+    sched = torch.optim.lr_scheduler.ReduceLROnPlateau(dummy, patience=plateau_patience, threshold=plateau_threshold)
+    gen = torch.Generator().manual_seed(seed)                        # the SAME stream of draws on every rank
     weights = torch.tensor([{"silhouette": 7.0, "kps_anchor": 10.0, "vert_disp_reg": 2.0, "laplacian": 4.0, "normal": 0.1, "arap": 0.2,
-                             "photo": 1.0, "albedo": 0.5, "normal_reg": 0.1}[k] for k in LOSS_NAMES], device=device)
-    for epoch_id in range(configs["total_epoch"]):
-        coarse, app = stage_flags(epoch_id, configs["training_stage"])
-        perm = torch.randperm(len(rt), generator=gen)                              # DataLoader(shuffle=True) over the DATASET's items, :399
-        epoch_loss = torch.zeros((), device=device)
-        nb = 0
-        for s0 in range(0, len(rt), batch_size):
-            item = perm[s0:s0 + batch_size]
-            eng.step(rt.fid[item], coarse, app, tfid=item)                         # parameter rows = the items' own fids (:446, :464)
-            active = (eng.w_vec[:9] > 0).float()
-            epoch_loss += (eng.loss_vec[:9] * weights * active).sum()              # stays on the device: no per-term .cpu() sync (:559)
-            if app and eng.perceptual is not None:
-                epoch_loss += eng.loss_vec[9] * eng.perceptual_weight
-            nb += 1
-        mean_loss = float(epoch_loss / nb)                                         # one sync per epoch
-        if not np.isfinite(mean_loss):
-            raise FloatingPointError(f"non-finite loss at epoch {epoch_id}")      # the reference drops into pdb (:525-527)
-        if coarse:
-            sched.step(mean_loss)                                                  # :581-582
-            eng.set_lr(lr_coarse=dummy.param_groups[0]["lr"])
-        if log_fn is not None:
-            log_fn(epoch_id, mean_loss, eng)
-        if epoch_id % 200 == 0 and epoch_id > 0:
-            file_utils.save_result(export_params(eng, input_params, VERTS_UVS, FACES_UVS, uv_mask, hand_layer), configs["base_output_dir"])
-    params = export_params(eng, input_params, VERTS_UVS, FACES_UVS, uv_mask, hand_layer)
-    file_utils.save_result(params, configs["base_output_dir"], test=configs["known_appearance"])     # :595-596
+                             "photo": 1.0, "albedo": 0.5, "normal_reg": 0.1}[k_] for k_ in LOSS_NAMES], device=device)
+    own = torch.arange(k) * per                                      # first local row of each of this rank's shards
+    try:
+        for epoch_id in range(configs["total_epoch"]):
+            coarse, app = stage_flags(epoch_id, configs["training_stage"])
+            epoch_loss = torch.zeros((), device=device)
+            nb = 0
+            for order in hdist.epoch_batches(per, b, gen):                             # DataLoader(shuffle=True) over the DATASET's items, :398
+                item = (own[:, None] + order[None, :]).reshape(-1)                     # local rows of the resident targets, shard by shard
+                eng.step(rt.fid[item], coarse, app, tfid=item)                         # parameter rows = the items' own fids (:446, :464)
+                active = (eng.w_vec[:9] > 0).float()
+                epoch_loss += (eng.loss_vec[:9] * weights * active).sum()              # stays on the device: no per-term .cpu() sync (:559)
+                if app and eng.perceptual is not None:
+                    epoch_loss += eng.loss_vec[9] * eng.perceptual_weight
+                nb += 1
+            # one sync per epoch; N > 1: the mean over ranks (image terms are means over a rank's frames, regularisers are identical),
+            # the same float on every rank
+            mean_loss = float(hdist.mean_over_ranks(float(epoch_loss / nb), device=eng.dev) if world > 1 else epoch_loss / nb)
+            if not np.isfinite(mean_loss):
+                raise FloatingPointError(f"non-finite loss at epoch {epoch_id}")      # the reference drops into pdb (:525-527); all ranks raise together
+            if coarse:
+                sched.step(mean_loss)                                                  # :581-582
+                eng.set_lr(lr_coarse=dummy.param_groups[0]["lr"])
+            if log_fn is not None:
+                log_fn(epoch_id, mean_loss, eng)
+            if epoch_id % 200 == 0 and epoch_id > 0 and rank == 0:
+                file_utils.save_result(export_params(eng, input_params, VERTS_UVS, FACES_UVS, uv_mask, hand_layer), configs["base_output_dir"],
+                                       test=configs["known_appearance"])               # :590-591
+        params = export_params(eng, input_params, VERTS_UVS, FACES_UVS, uv_mask, hand_layer)
+        if rank == 0:
+            file_utils.save_result(params, configs["base_output_dir"], test=configs["known_appearance"])     # :595-596
+    finally:
+        if comm is not None:
+            torch.cuda.synchronize(eng.dev)
+            comm.destroy()                                           # drops the step graphs that captured it
+    return params
+
+
+def main(argv=None):
+    """optimize_sequence.py:819-838 over this package's loaders — and the data-parallel launch:
+
+        python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 -m harp_amd.optimize_sequence --config cfg.yaml
+
+    one rank per GPU (LOCAL_RANK), nccl (= RCCL) process group; HARP_ALL_ON_GPU0=1 puts every rank on cuda:0 over gloo (one-GPU boxes)."""
+    import argparse
+    import os
+    import yaml
+    import torch.distributed as tdist
+    from .utils import hand_model_utils
+    from .utils.config_utils import get_config
+    from .utils.data_util import load_multiple_sequences
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", required=True, help="yaml with the keys of utils/config_utils.get_config")
+    ap.add_argument("--batch-size", type=int, default=18)
+    args = ap.parse_args(argv)
+    with open(args.config) as f:
+        configs = get_config(write_yaml=False, **yaml.safe_load(f))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    shared = os.environ.get("HARP_ALL_ON_GPU0") == "1"
+    device = "cuda:0" if shared else f"cuda:{local}"
+    torch.cuda.set_device(device)
+    if world > 1:
+        if shared:
+            tdist.init_process_group("gloo")
+        else:
+            tdist.init_process_group("nccl", device_id=torch.device(device))
+    configs["device"] = device
+    hand_layer, VERTS_UVS, FACES_UVS, VERTS_COLOR = hand_model_utils.load_hand_model(configs)
+    mano_params, images_dataset, val_mano_params, val_images_dataset = load_multiple_sequences(
+        configs["metro_output_dir"], configs["image_dir"], train_list=configs["train_list"], val_list=configs["val_list"],
+        average_cam_sequence=configs["average_cam_sequence"], use_smooth_seq=configs["use_smooth_seq"], model_type=configs["model_type"])
+    params = optimize_hand_sequence(configs, mano_params, images_dataset, val_mano_params, val_images_dataset, hand_layer, VERTS_UVS, FACES_UVS,
+                                    VERTS_COLOR, device=device, batch_size=args.batch_size)
+    if world > 1:
+        tdist.barrier()
+        tdist.destroy_process_group()
     return params
 
 
@@ -189,3 +269,7 @@ def export_params(eng, input_params, VERTS_UVS, FACES_UVS, uv_mask, hand_layer):
     out.update(init_joints=input_params["joints"], verts_rgb=torch.ones(778, 3), verts_uvs=VERTS_UVS, faces_uvs=FACES_UVS,
                uv_mask=torch.as_tensor(uv_mask), mesh_faces=getattr(hand_layer, "right_arm_faces_tensor", getattr(hand_layer, "th_faces", None)))
     return out
+
+
+if __name__ == "__main__":
+    main()

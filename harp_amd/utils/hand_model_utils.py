@@ -1,0 +1,42 @@
+"""load_hand_model (utils/hand_model_utils.py:11-82) for the model types on the hot path: the UV layout from the template OBJ
+(`pytorch3d.io.load_obj(...).verts_uvs / faces.textures_idx`, :58-60) and the hand layer — METRO-compatible MANO (:74) or the
+SMPL-X arm (:66-70).  'html' / 'nimble' are out of scope."""
+import numpy as np
+import torch
+
+
+def load_obj_uvs(path):
+    """(verts_uvs (Nt,2) float32, faces_uvs (F,3) int64) of a triangulated OBJ: the `vt` lines and the second index of every `f` corner
+    — what pytorch3d.io.load_obj returns as properties.verts_uvs and faces.textures_idx"""
+    vt, ft = [], []
+    with open(path) as f:
+        for line in f:
+            p = line.split()
+            if not p:
+                continue
+            if p[0] == "vt":
+                vt.append([float(x) for x in p[1:3]])
+            elif p[0] == "f":
+                if len(p) != 4:
+                    raise ValueError(f"{path}: only triangulated OBJ templates are supported")
+                ft.append([int(q.split("/")[1]) - 1 for q in p[1:4]])
+    return torch.tensor(np.asarray(vt, np.float32)), torch.tensor(np.asarray(ft, np.int64))
+
+
+def load_hand_model(config_dict):
+    """-> (hand_layer, VERTS_UVS (1,Nt,2), FACES_UVS (1,F,3), VERTS_COLOR) like the reference"""
+    device = config_dict.get("device", "cuda")
+    if config_dict["model_type"] != "harp":
+        raise NotImplementedError("model_type 'html' / 'nimble' are out of scope (SURVEY.md §2)")
+    verts_uvs, faces_uvs = load_obj_uvs(config_dict["MANO_TEMPLATE"])
+    VERTS_COLOR = None
+    if config_dict["use_arm"]:
+        from ..hand_models_harp import body_models
+        hand_layer = body_models.create(config_dict.get("smplx_model_folder", "hand_models/smplx/models/"), model_type="smplxarm",
+                                        num_betas=10, num_expression_coeffs=10, device=device)
+    else:
+        from ..manopth.manolayer import ManoLayer
+        from .opt_utils import get_mano_vert_colors
+        hand_layer = ManoLayer(mano_root=config_dict.get("mano_root", "mano/models"), flat_hand_mean=False, use_pca=False, device=device)
+        VERTS_COLOR = get_mano_vert_colors(hand_layer)
+    return hand_layer, verts_uvs.unsqueeze(0), faces_uvs.unsqueeze(0), VERTS_COLOR

@@ -85,3 +85,52 @@ def test_two_rank_allreduce_equals_full_batch():
     ref = _grads(sc, torch.tensor([0, 1, 2, 3]), P, dists)      # one process, global batch = union of the two shards
     assert (got - ref).norm() <= 2e-4 * ref.norm(), ((got - ref).norm() / ref.norm()).item()
     # frame-independent regularisers are counted once, not `world` times: check the texture block against albedo-only grads
+
+
+def _sched_worker(rank, world, port, out):
+    """two ranks with DIFFERENT local epoch losses: after mean_over_ranks both feed ReduceLROnPlateau the same float, so the learning
+    rates stay identical (the replicated-Adam invariant of the data-parallel fit, harp_amd/optimize_sequence.py)"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from harp_amd.dist import dist_env, epoch_batches, mean_over_ranks, ranks_identical
+    assert dist_env() == (rank, world)
+    dummy = torch.optim.Adam([torch.nn.Parameter(torch.zeros(1))], lr=1e-3)
+    sched = torch.optim.lr_scheduler.ReduceLROnPlateau(dummy, patience=1)
+    # rank 0 alone would see a plateau from epoch 2 on, rank 1 alone a steady decrease: the mean decides for both
+    local = [[1.0, 0.9, 0.9, 0.9, 0.9, 0.9], [1.0, 0.8, 0.6, 0.6, 0.6, 0.6]][rank]
+    seen, lrs = [], []
+    for v in local:
+        m = mean_over_ranks(v)
+        seen.append(m)
+        sched.step(m)
+        lrs.append(dummy.param_groups[0]["lr"])
+    gen = torch.Generator().manual_seed(11)
+    order = [b.tolist() for b in epoch_batches(6, 4, gen)]
+    same = ranks_identical(torch.tensor(lrs)) and ranks_identical(torch.tensor(sum(order, [])).float())
+    differ = ranks_identical(torch.tensor([float(rank)]))
+    if rank == 0:
+        out.put((seen, lrs, order, same, differ))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_epoch_loss_is_averaged_before_the_plateau_scheduler():
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sched_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    seen, lrs, order, same, differ = out.get(timeout=200)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert seen == pytest.approx([1.0, 0.85, 0.75, 0.75, 0.75, 0.75])
+    assert lrs[:4] == [1e-3] * 4 and lrs[4] == pytest.approx(1e-4)       # two bad epochs (3, 4) > patience 1 -> one decay, on BOTH ranks
+    assert same and not differ
+    assert sorted(sum(order, [])) == list(range(6)) and [len(b) for b in order] == [4, 2]      # a shuffled shard, ragged last batch
+
+
+def test_single_process_helpers_are_no_ops():
+    from harp_amd.dist import dist_env, mean_over_ranks, ranks_identical
+    assert dist_env() == (0, 1) and mean_over_ranks(0.25) == 0.25 and ranks_identical(torch.ones(3))
