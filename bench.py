@@ -156,6 +156,105 @@ def kernel_roofline(eng, steps, overlap=False):
     return out
 
 
+# kernel-name substrings of the event-timed groups (the in-graph durations of a group = the sum over its kernels; the three set-up kernels
+# run once per view, their per-launch averages are over both views)
+_GROUP_KERNELS = {"raster_cam_fwd(setup+bin+raster)": ("raster_kernel<1,", "face_setup_kernel", "bin_faces_kernel", "order_tiles_kernel"),
+                  "raster_light_fwd(setup+bin+raster)": ("raster_kernel<0,", "face_setup_kernel", "bin_faces_kernel", "order_tiles_kernel"),
+                  "harp_shade_fwd": ("shade_kernel<false>",), "harp_shade_bwd": ("shade_bwd_wave_kernel",),
+                  "harp_silhouette_bwd": ("raster_kernel<2,",), "harp_depth_bwd": ("depth_bwd_kernel",)}
+
+
+def _child(cmd_tail, prof_args, out_dir, timeout=600):
+    """one `rocprofv3 <prof_args> -- python bench.py <cmd_tail>` child (outside the timed region); returns the rocpd database path or None"""
+    import glob
+    import shutil
+    import subprocess
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return None
+    env = dict(os.environ, HARP_BENCH_CHILD="1", TMPDIR="/tmp")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [exe, *prof_args, "-d", out_dir, "-o", "run", "--", sys.executable, os.path.join(ROOT, "bench.py"), *cmd_tail]
+    try:
+        r = subprocess.run(cmd, env=env, cwd="/tmp", capture_output=True, text=True, timeout=timeout)
+    except Exception as e:                                       # noqa: BLE001
+        print(f"[bench] profiling child failed: {type(e).__name__}: {e}", file=sys.stderr)
+        return None
+    dbs = glob.glob(os.path.join(out_dir, "**", "*.db"), recursive=True)
+    if r.returncode != 0 or not dbs:
+        print(f"[bench] profiling child rc={r.returncode}: {r.stderr[-400:]}", file=sys.stderr)
+        return None
+    return dbs[0]
+
+
+def profiled_in_graph(steps=40, warmup=8):
+    """In-graph kernel durations of THIS command, the way profiles/ records them: a child `rocprofv3 --kernel-trace -- python bench.py
+    --steps 40 --warmup 8 --no-cpu-baseline --no-extras --no-roofline` (graph replays, three streams), average over the last `steps`
+    launches of every kernel (= the timed replays; the launches that render the targets come first) -> {kernel name: (avg_us, launches)},
+    or None when rocprofv3 is not available / the child fails."""
+    import shutil
+    import sqlite3
+    import tempfile
+    out_dir = tempfile.mkdtemp(prefix="harp_prof_", dir="/tmp")
+    try:
+        db = _child(["--steps", str(steps), "--warmup", str(warmup), "--no-cpu-baseline", "--no-extras", "--no-roofline"], ["--kernel-trace"], out_dir)
+        if db is None:
+            return None
+        cur = sqlite3.connect(db).cursor()
+        cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
+        name = "name" if "name" in cols else [c for c in cols if "name" in c][0]
+        per = {}
+        for n, t0, t1 in cur.execute(f"select {name}, start, end from kernels order by start"):
+            per.setdefault(n, []).append((t1 - t0) / 1e3)
+        out = {}
+        for n, d in per.items():
+            k = steps * (2 if any(t in n for t in ("face_setup_kernel", "bin_faces_kernel", "order_tiles_kernel")) else 1)
+            keep = d[-k:]
+            out[n] = (float(np.mean(keep)), len(keep))
+        return out
+    except Exception as e:                                       # noqa: BLE001
+        print(f"[bench] kernel-trace pass unusable: {type(e).__name__}: {e}", file=sys.stderr)
+        return None
+    finally:
+        shutil.rmtree(out_dir, ignore_errors=True)
+
+
+def profiled_traffic():
+    """HBM bytes per launch of the kernel groups from two separate PMC passes over this command (FETCH_SIZE, WRITE_SIZE; counters only
+    with --kernel-trace, 3 eager steps each; units and the gfx950 2x FETCH correction as in tools/make_traffic_json.py, which this
+    reuses) -> dict like profiles/traffic_latest.json, or None."""
+    import contextlib
+    import io
+    import shutil
+    import tempfile
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        import make_traffic_json as mt
+    except Exception:                                            # noqa: BLE001
+        return None
+    tail = ["--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-extras", "--no-roofline", "--no-graph"]
+    dirs, dbs = [], []
+    try:
+        for c in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = tempfile.mkdtemp(prefix=f"harp_pmc_{c}_", dir="/tmp")
+            dirs.append(d)
+            db = _child(tail, ["--kernel-trace", "--pmc", c], d)
+            if db is None:
+                return None
+            dbs.append(db)
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            mt.main(dbs[0], dbs[1], "python bench.py " + " ".join(tail))
+        return json.loads(buf.getvalue())
+    except (Exception, SystemExit) as e:                         # noqa: BLE001
+        print(f"[bench] PMC passes unusable: {type(e).__name__}: {e}", file=sys.stderr)
+        return None
+    finally:
+        for d in dirs:
+            shutil.rmtree(d, ignore_errors=True)
+
+
 def _graph_rate(e, steps, warmup):
     """frames/s of graph-replayed scheduled steps of engine `e` (single GPU, outside the timed region of the headline)"""
     B, T = e.B, e.T
@@ -331,6 +430,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the rates of the other configurations (keep_image, B=18, C5 arm 1024)")
     ap.add_argument("--no-roofline", action="store_true", help="skip the per-kernel event timing and the keep_image rate (profiling runs: only the timed steps)")
+    ap.add_argument("--no-profile", action="store_true", help="do not start rocprofv3 children for the in-graph kernel durations / HBM traffic of the "
+                    "roofline entry (they run outside the timed region; without them the entry falls back to HIP-event timing and the committed traffic file)")
     ap.add_argument("--vgg-weights", default="random", help="filters of the perceptual-term entry of `extras`: 'random' (default, timing only), "
                     "'none' (skip the entry) or the path of torchvision's vgg16 state dict (vgg16-397923af.pth)")
     args = ap.parse_args()
@@ -367,8 +468,24 @@ def main():
         # collective is a node of the same hipGraph as the kernels; torch.distributed only carries the 128-byte communicator id
         from harp_amd.dist import RcclComm
         # never exercised on more than one rank in the build environment (1-GPU boxes only): if the communicator cannot be built on ANY
-        # rank, every rank falls back to torch.distributed's all-reduce with eager steps, and the line says so ("collective")
+        # rank, every rank falls back to torch.distributed's all-reduce with eager steps, and the line says so ("collective").
+        # BEST EFFORT: the agreement below needs every rank to reach it.  What can fail on ONE rank without the others blocking inside a
+        # collective is checked first and agreed on (pre-flight: the C-ABI library resolves RCCL's symbols — dlopen + dlsym, no
+        # communication); a rank that dies INSIDE ncclCommInitRank or inside a captured all-reduce still hangs its peers until the
+        # launcher's timeout — that is RCCL's own failure mode, not something a fallback on top of it can repair.
+        pre = 1
         try:
+            RcclComm.unique_id()                                # dlopen(librccl) + symbol resolution + ncclGetUniqueId: local, no peers involved
+        except Exception as e:                                  # noqa: BLE001
+            print(f"[bench] rank {rank}: RCCL pre-flight failed ({type(e).__name__}: {e})", file=sys.stderr)
+            pre = 0
+        if world > 1:
+            flag = torch.tensor([pre], device=device, dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            pre = int(flag.item())
+        try:
+            if not pre:
+                raise RuntimeError("RCCL pre-flight failed on some rank")
             with _StdoutToStderr():
                 comm = RcclComm.from_process_group(device) if world > 1 else RcclComm.single()
             ok = 1
@@ -413,6 +530,9 @@ def main():
         if not use_graph:
             raise RuntimeError(f"warm-up steps failed: {graph_fallback}")
         print(f"[bench] rank {rank}: graph-replayed steps failed ({graph_fallback}); eager steps", file=sys.stderr)
+        # (`torch.cuda.graph`'s context manager ends a capture that failed half-way on its way out; the partial graph is dropped with the
+        # engine's graph table below) — drain the device before the eager steps use the same streams
+        torch.cuda.synchronize()
         use_graph, eng._graphs = False, {}
         graph_fallback = graph_fallback or "another rank failed"
         for i in range(args.warmup):
@@ -493,9 +613,24 @@ def main():
         out["invalid_timing"] = f"development run: backend={backend}, all ranks on one GPU={shared_gpu}"
     if rank == 0 and world == 1 and not args.no_roofline:
         a_frame, a_step, parts = algorithmic_bytes(eng)
-        kt = kernel_roofline(eng, 4)
-        kt_situ = kernel_roofline(eng, 4, overlap=True)
-        dom = max(kt, key=kt.get)                    # dominant kernel group of the step by measured time
+        kt = kernel_roofline(eng, 4)                    # stand-alone: one stream, the group runs alone (HIP events)
+        kt_situ = kernel_roofline(eng, 4, overlap=True)   # eager two-stream re-run, events around the C-ABI call
+        # ... and the number profiles/ records: the kernel's average duration INSIDE the replayed graph, from a rocprofv3 --kernel-trace
+        # child over this same command (events cannot bracket one node of a replayed graph).  `frac` / `achieved` are computed from it;
+        # the event timings stay as secondary keys.  Children run outside the timed region; a profiling child never starts children itself.
+        child = os.environ.get("HARP_BENCH_CHILD") == "1"
+        prof = None if (args.no_profile or child) else profiled_in_graph()
+        kg = {}
+        if prof:
+            for grp, subs in _GROUP_KERNELS.items():
+                hit = [avg for name, (avg, n) in prof.items() if any(t in name for t in subs)]
+                if hit and grp in kt:
+                    kg[grp] = sum(hit) / 1e3
+        timing = kg if all(k in kg for k in kt) else kt_situ
+        timing_source = ("rocprofv3 --kernel-trace child over `python bench.py --steps 40 --warmup 8 --no-cpu-baseline --no-extras --no-roofline`: average "
+                         "duration over the 40 timed graph replays (in the graph, next to the other streams' kernels)" if timing is kg else
+                         "HIP events around the C-ABI call in an eager two-stream re-run of the steps (no rocprofv3 child: --no-profile, not on PATH, or failed)")
+        dom = max(timing, key=timing.get)            # dominant kernel group of the step by measured time
         fused = "harp_shade_fwd" not in kt           # loss-only mode: the photometric L1 is formed inside the shader backward
         geom_pos = parts["V"] * 12 + parts["F"] * 12
         S2 = parts["S2"]
@@ -508,43 +643,54 @@ def main():
                "harp_shade_bwd": (parts["geom"] + parts["V"] * 36 + S2 * (4 + (12 + 4 if fused else 12) + 4 + 4)) * eng.B + 2 * eng.Ht * eng.Wt * 12,
                "harp_silhouette_bwd": (geom_pos + S2 * 8 + parts["V"] * 12) * eng.B,
                "harp_depth_bwd": (geom_pos + S2 * 8 + parts["V"] * 12) * eng.B}
-        # ... and the bytes the FUSED kernels really have to move (barycentrics / distances are never materialised): the rasteriser's
-        # fraction is reported against both figures
+        # ... and the bytes the FUSED rasteriser kernels really have to move (barycentrics / distances are never materialised): their
+        # `frac` is against THIS figure; the one against §8(d)'s formula is kept as `frac_survey_8d`
         moved = {"raster_cam_fwd(setup+bin+raster)": (geom_pos + S2 * (4 + 4) + S2 * (4 + 4)) * eng.B,     # face id + alpha out; mask in, g_alpha out
                  "raster_light_fwd(setup+bin+raster)": (geom_pos + S2 * (4 + 4)) * eng.B}                # face id + depth out
-        ach = alg[dom] / (kt[dom] * 1e-3) / 1e9
-        # HBM traffic per launch comes from PMC counters, which cannot be read in-process: the last rocprofv3 FETCH_SIZE / WRITE_SIZE
-        # passes over this same command are committed as profiles/traffic_latest.json (see its _source field)
-        traffic, tjson = None, {}
-        tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        if os.path.exists(tpath):
-            tjson = json.load(open(tpath))
-            traffic = tjson.get(dom)
+        ach = alg[dom] / (timing[dom] * 1e-3) / 1e9
+        # HBM traffic per launch: two PMC passes (FETCH_SIZE, WRITE_SIZE) over this command, run now as children when rocprofv3 is there;
+        # otherwise the last committed passes (profiles/traffic_latest.json, stamped with the commit they were taken at)
+        tjson = None if (args.no_profile or child) else profiled_traffic()
+        if tjson is not None:
+            traffic_source = "measured in this run: " + tjson.get("_source", "")
+        else:
+            tjson = {}
+            tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+            if os.path.exists(tpath):
+                tjson = json.load(open(tpath))
+            traffic_source = ("NOT measured in this run: per-launch FETCH_SIZE / WRITE_SIZE of the last committed rocprofv3 passes over this command, "
+                              f"profiles/traffic_latest.json (taken at commit {tjson.get('_head', 'unknown')})")
+        traffic = tjson.get(dom)
         # the same figures for every timed kernel group (north_star asks for the rasteriser's fraction explicitly)
         per_kernel = {}
         for k in kt:
-            e = {"avg_ms": kt[k], "in_situ_ms": kt_situ.get(k), "algorithmic_bytes": alg[k], "achieved_GBps": alg[k] / (kt[k] * 1e-3) / 1e9,
-                 "frac": alg[k] / (kt[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": tjson.get(k)}
+            byts = moved.get(k, alg[k])
+            e = {"ms": timing[k], "in_graph_ms": kg.get(k), "standalone_event_ms": kt[k], "in_situ_event_ms": kt_situ.get(k),
+                 "bytes": byts, "bytes_kind": ("moved by the fused kernel (no bary / dist images)" if k in moved else "algorithmic, SURVEY.md 8(d)"),
+                 "achieved_GBps": byts / (timing[k] * 1e-3) / 1e9, "frac": byts / (timing[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": tjson.get(k)}
             if k in moved:
-                e["moved_bytes(fused kernel: no bary/dist images)"] = moved[k]
-                e["frac_of_moved_bytes"] = moved[k] / (kt[k] * 1e-3) / 1e9 / HBM_PEAK_GBS
+                e["bytes_survey_8d"] = alg[k]
+                e["frac_survey_8d"] = alg[k] / (timing[k] * 1e-3) / 1e9 / HBM_PEAK_GBS
             if tjson.get(k):
-                e["frac_of_measured_traffic"] = tjson[k] / (kt[k] * 1e-3) / 1e9 / HBM_PEAK_GBS
+                e["frac_of_measured_traffic"] = tjson[k] / (timing[k] * 1e-3) / 1e9 / HBM_PEAK_GBS
             per_kernel[k] = e
         step_s = dt / args.steps
         step_bytes = a_frame * eng.B + a_step
         # loss-only mode writes no y_pred and reads no gradient image back: 2 * S^2 * 12 B per frame less than §8(d)'s A_frame
         step_bytes_lean = step_bytes - 2 * S2 * 12 * eng.B
         out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                           "traffic": traffic,
-                           "traffic_source": "NOT measured in this run (PMC counters cannot be read in-process): per-launch FETCH_SIZE / WRITE_SIZE of the last "
-                                             "committed rocprofv3 pass over this command, profiles/traffic_latest.json",
-                           "algorithmic_bytes_per_launch": alg[dom], "avg_ms": kt[dom], "in_situ_ms": kt_situ.get(dom),
-                           "in_situ_frac": alg[dom] / (kt_situ[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS if kt_situ.get(dom) else None,
-                           "kernel_ms": kt, "per_kernel": per_kernel, "step_algorithmic_bytes": step_bytes,
+                           "traffic": traffic, "traffic_source": traffic_source,
+                           "algorithmic_bytes_per_launch": alg[dom], "avg_ms": timing[dom], "timing_source": timing_source,
+                           "standalone_event_ms": kt[dom], "in_situ_event_ms": kt_situ.get(dom),
+                           "standalone_frac": alg[dom] / (kt[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                           "kernel_ms": timing, "per_kernel": per_kernel, "step_algorithmic_bytes": step_bytes,
                            "step_frac_of_hbm_roofline": step_bytes / step_s / 1e9 / HBM_PEAK_GBS,
                            "step_algorithmic_bytes_loss_only_mode": step_bytes_lean,
                            "step_frac_of_hbm_roofline_loss_only_bytes": step_bytes_lean / step_s / 1e9 / HBM_PEAK_GBS}
+        if prof:
+            short = lambda n: n.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
+            out["roofline"]["kernels_in_graph_us"] = {short(n): round(a, 2) for n, (a, c) in sorted(prof.items(), key=lambda kv: -kv[1][0] * kv[1][1])
+                                                      if c >= 40 and "at::native" not in n and "Cijk" not in n}
         # the like-for-like step that materialises y_pred as the reference does, next to the headline (always measured: 40 replays)
         eng.keep_image = True
         ki = _graph_rate(eng, 40, 6)

@@ -53,12 +53,9 @@ int harp_mesh_chain_bwd(const harp_mesh_chain* a, hipStream_t stream) {
                      !a->g_light_pos)))
     return HARP_ERR_ARG;
   const size_t lds = (size_t)(a->V0 + a->E0) * 9 * sizeof(float);
-  static size_t attr_lds = 0;      // dynamic LDS above 64 KB has to be requested (3 buffers of V*12 B: 111 KB hand, 147 KB arm)
-  if (lds > attr_lds) {
-    if (hipFuncSetAttribute((const void*)mesh_chain_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-      return HARP_ERR_ARG;
-    attr_lds = lds;
-  }
+  // dynamic LDS above 64 KB has to be requested (3 buffers of V*12 B: 111 KB hand, 147 KB arm); per-device attribute, set on every call
+  if (hipFuncSetAttribute((const void*)mesh_chain_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return HARP_ERR_ARG;
   hipLaunchKernelGGL(mesh_chain_bwd_kernel, dim3(a->B), dim3(kChainThreads), lds, stream, *a);
   HARP_CHECK_LAUNCH();
   return HARP_OK;

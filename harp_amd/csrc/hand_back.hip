@@ -129,11 +129,9 @@ int harp_hand_back_bwd(const harp_hand_front* h, const float* g_colors, float* g
     return HARP_ERR_ARG;
   if (!h->fid || !h->pose48 || !h->lbs_ws || h->tables.wrist_pose) return HARP_ERR_ARG;
   const size_t lds = (size_t)(a->V0 + a->E0) * 9 * sizeof(float);
-  static size_t attr_lds = 0;      // dynamic LDS above 64 KB has to be requested
-  if (lds > attr_lds) {
-    if (hipFuncSetAttribute((const void*)hand_back_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return HARP_ERR_ARG;
-    attr_lds = lds;
-  }
+  // dynamic LDS above 64 KB has to be requested; the attribute is per DEVICE, so it is set on every call (cheap) rather than cached in a
+  // process-wide static that a second device or a concurrent first call would defeat
+  if (hipFuncSetAttribute((const void*)hand_back_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return HARP_ERR_ARG;
   hipLaunchKernelGGL(hand_back_kernel, dim3(a->B), dim3(kChainThreads), lds, stream, *h, g_colors, g_betas_scratch);
   HARP_CHECK_LAUNCH();
   return harp_detail_lbs_back_tail(h->mano, h->pose48, a->B, h->lbs_ws, g_betas_scratch, h->tables, h->fid, stream);

@@ -216,6 +216,7 @@ __device__ __forceinline__ void shade_bwd_tile(ShadeSmem& sm, unsigned vblock, c
 #pragma unroll
   for (int c = 0; c < 9; ++c) zd[c] = 0.f;
 
+  bool dead = false;      // IMG mode: covered pixel outside the L1 mask — its colour is written, it stays out of the table phases
   if (act) {
     const float px = pix_to_ndc(xi, S), py = pix_to_ndc(yi, S);
     const float* col = A.colors;               // amb(3) diff(3) spec(3)
@@ -325,13 +326,16 @@ __device__ __forceinline__ void shade_bwd_tile(ShadeSmem& sm, unsigned vblock, c
         float* o = at32m(A.rgb + (size_t)b * S * S * 3, 3u * po);
         o[0] = o3[0]; o[1] = o3[1]; o[2] = o3[2];
       }
+      dead = IMG && l1_m == 0.f;       // (no table traffic, no zero-valued atomics, no 0 * inf in the sums for such a pixel)
       const float wl = A.l1_w[0] * A.l1_inv * l1_m;
-      float gq[3];
+      float gq[3] = {0.f, 0.f, 0.f};
+      if (!dead) {
 #pragma unroll
-      for (int ch = 0; ch < 3; ++ch) {
-        const float d = o3[ch] * l1_m - at32(l1_trow, 3u * po)[ch] * l1_m;
-        racc[16] += fabsf(d);
-        gq[ch] = wl * (float)((d > 0.f) - (d < 0.f));
+        for (int ch = 0; ch < 3; ++ch) {
+          const float d = o3[ch] * l1_m - at32(l1_trow, 3u * po)[ch] * l1_m;
+          racc[16] += fabsf(d);
+          gq[ch] = wl * (float)((d > 0.f) - (d < 0.f));
+        }
       }
       gc = mk(gq[0], gq[1], gq[2]);
     }
@@ -411,6 +415,13 @@ __device__ __forceinline__ void shade_bwd_tile(ShadeSmem& sm, unsigned vblock, c
       vsc[9 * k + 3] = g_n.x * bw[k]; vsc[9 * k + 4] = g_n.y * bw[k]; vsc[9 * k + 5] = g_n.z * bw[k];
       vsc[9 * k + 6] = gnd[3 * k]; vsc[9 * k + 7] = gnd[3 * k + 1]; vsc[9 * k + 8] = gnd[3 * k + 2];
     }
+  }
+  if (IMG && dead) {
+    // its gradient section ran with weight 0 (every product is an exact zero unless a colour overflowed: clear the sums anyway); the
+    // lane takes no part in the table phases below
+    act = false;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) racc[k] = 0.f;
   }
 
   STAMP(5);
@@ -628,7 +639,11 @@ union FusedSmem {
   rb::RasterSmem<2> rs;
   __device__ FusedSmem() {}
 };
-__global__ void __launch_bounds__(256, SHADE_BWD_OCC) fused_bwd_kernel(const harp_shade_args A, const SilBwdArgs R, const int32_t* __restrict__ order,
+// (its own occupancy target: the rasteriser tiles it hosts want 168 VGPRs; under the shader's 4-waves-per-SIMD cap of 128 they would spill)
+#ifndef FUSED_BWD_OCC
+#define FUSED_BWD_OCC 3
+#endif
+__global__ void __launch_bounds__(256, FUSED_BWD_OCC) fused_bwd_kernel(const harp_shade_args A, const SilBwdArgs R, const int32_t* __restrict__ order,
                                                                        const int32_t* __restrict__ nact, int nsx) {
   __shared__ FusedSmem sm;
   const unsigned g = blockIdx.x >> 4, r = blockIdx.x & 15;

@@ -503,7 +503,10 @@ class FitEngine:
             a.l1_w, a.l1_loss, a.l1_grad = wp(6), lp(6), p(s["g_rgb"])
             # fitting loop (no image kept, no perceptual term): there is no forward shading launch — the backward pass recomputes the
             # colour anyway and forms the photometric L1 and its gradient itself (harp_shade_bwd with g_rgb == NULL)
-            fused_loss = self.fused_loss and (self.fused_keep or not self.keep_image) and self.perceptual is None and self.bg_photo is not None
+            # (the one-launch backward pair, `fused_bwd`, instantiates the loss-only shader tile: it cannot write y_pred, so a kept
+            # image goes through the forward shader there)
+            fused_loss = (self.fused_loss and (not self.keep_image or (self.fused_keep and not fuse_bwd)) and self.perceptual is None
+                          and self.bg_photo is not None)
             if fused_loss:
                 a.g_rgb = None
             else:

@@ -4,9 +4,10 @@
 
 A 6-frame synthetic sequence in the reference's directory layout (utils/data_util.py:76-195):
     frames/img/1/unscreen_cropped/000N.jpg, frames/img/1/mask/000N_mask.jpg, frames/metro/1/metro_mano/000N_mano.pkl
-and the tensors the reference's `ImagesDataset.__getitem__` (utils/data_util.py:32-51) produces for them, computed HERE by a literal
-restatement of `load_img` (utils/data_util.py:11-30) in which the one call the build image cannot make, `cv2.erode(img, np.ones((3,3),
-np.uint8), iterations=2)`, is written out in plain NumPy loops from the OpenCV documentation of `erode`:
+and the tensors the reference's `load_multiple_sequences` -> `ImagesDataset.__getitem__` (utils/data_util.py:32-51, 76-195) produce for
+them: the reference's own module is IMPORTED from /root/reference (round 4; rounds 1-3 restated `load_img`) with a stub `cv2` whose
+`erode` — the one call the build image cannot make, `cv2.erode(img, np.ones((3,3), np.uint8), iterations=2)` — is written out in plain
+NumPy loops from the OpenCV documentation of `erode`:
     dst(x, y) = min over (x', y') in the 3x3 neighbourhood anchored at its centre of src(x + x', y + y'), applied `iterations` times;
     default borderType = BORDER_CONSTANT with borderValue = morphologyDefaultBorderValue(), which for erosion means +DBL_MAX: pixels
     outside the image never win the minimum.  (Replicating the border pixels — BORDER_REPLICATE — gives the same result for a 3x3
@@ -46,19 +47,38 @@ def erode_3x3_loops(src, iterations, border):
     return a
 
 
-def reference_load_img(path, load_mask=False, erode=False, downsample_factor=1):
-    """utils/data_util.py:11-30, statement for statement (torch_tensor=True only wraps the array in torch.Tensor = float32)"""
-    if load_mask:
-        img = np.asarray(Image.open(path).convert("L")) / 255
-        img = img[::downsample_factor, ::downsample_factor, None]
-        if erode:
-            a = erode_3x3_loops(img[..., 0], 2, "constant_max")      # cv2.erode returns (H,W) for an (H,W,1) input
-            assert np.array_equal(a, erode_3x3_loops(img[..., 0], 2, "replicate"))
-            img = a
-    else:
-        img = np.asarray(Image.open(path).convert("RGB")) / 255
-        img = img[::downsample_factor, ::downsample_factor, 0:3]
-    return img.astype(np.float32)
+def import_reference_data_util():
+    """The reference's OWN utils/data_util.py, imported from /root/reference (build container only) with a stub `cv2` module whose `erode`
+    is the documented loop above — the one call the build image cannot make.  Decode, /255 scaling, channel order, down-sampling, the
+    un-thresholded mask, what is eroded and how often, the METRO pickle reading and the dataset ordering are then the reference's own
+    statements (utils/data_util.py:11-51, 54-73, 76-195)."""
+    import importlib.util
+    import sys
+    import types
+    cv2 = types.ModuleType("cv2")
+
+    def erode(src, kernel, iterations=1):
+        k = np.asarray(kernel)
+        assert k.shape == (3, 3) and (k == 1).all(), "the stub implements the 3x3 all-ones kernel the reference passes"
+        a = np.asarray(src)
+        assert a.ndim == 2 or (a.ndim == 3 and a.shape[2] == 1)
+        a2 = a[..., 0] if a.ndim == 3 else a                 # cv2.erode returns (H,W) for an (H,W,1) input
+        out = erode_3x3_loops(a2, iterations, "constant_max")
+        assert np.array_equal(out, erode_3x3_loops(a2, iterations, "replicate"))
+        return out
+    cv2.erode = erode
+    had = sys.modules.get("cv2")
+    sys.modules["cv2"] = cv2
+    try:
+        spec = importlib.util.spec_from_file_location("ref_data_util", "/root/reference/utils/data_util.py")
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+    finally:
+        if had is None:
+            del sys.modules["cv2"]
+        else:
+            sys.modules["cv2"] = had
+    return mod
 
 
 def main():
@@ -86,13 +106,26 @@ def main():
                  "cam": np.asarray((0.9 + 0.01 * i, 0.02 * i, -0.03), np.float32)}
         with open(os.path.join(root, "metro/1/metro_mano", name + "_mano.pkl"), "wb") as f:
             pickle.dump(frame, f, protocol=2)
-        img_p = os.path.join(root, "img/1/unscreen_cropped", name + ".jpg")
-        msk_p = os.path.join(root, "img/1/mask", name + "_mask.jpg")
-        exp["rgb"].append(reference_load_img(img_p))
-        exp["mask"].append(reference_load_img(msk_p, load_mask=True))
-        exp["eroded"].append(reference_load_img(msk_p, load_mask=True, erode=True))
-    np.savez_compressed(os.path.join(HERE, "frames_expected.npz"), **{k: np.stack(v) for k, v in exp.items()})
-    print("wrote", root, {k: np.stack(v).shape for k, v in exp.items()})
+    # ---- expected tensors: the reference's loader run on the tree just written
+    R = import_reference_data_util()
+    mano, ds, val_mano, val_ds = R.load_multiple_sequences(os.path.join(root, "metro") + "/", os.path.join(root, "img") + "/", train_list=["1"],
+                                                           val_list=[], average_cam_sequence=False, use_smooth_seq=False, model_type="harp")
+    assert len(ds) == N
+    for i in range(N):
+        fid, col, mask, eroded = ds[i]
+        assert fid == i
+        exp["rgb"].append(col.numpy()); exp["mask"].append(mask.numpy()); exp["eroded"].append(eroded.numpy())
+    out = {k: np.stack(v) for k, v in exp.items()}
+    out["image_paths"] = np.asarray([os.path.relpath(p, root) for p in ds.image_paths])      # dataset order = the reference's
+    for k in ("pose", "rot", "trans", "shape", "cam", "joints"):
+        out["mano_" + k] = np.asarray(mano[k])
+    old_path = os.path.join(HERE, "frames_expected.npz")
+    if os.path.exists(old_path):
+        old = np.load(old_path)
+        for k in ("rgb", "mask", "eroded"):
+            print(f"{k}: identical to the committed fixture = {np.array_equal(old[k], out[k])}")
+    np.savez_compressed(old_path, **out)
+    print("wrote", root, {k: v.shape for k, v in out.items()})
 
 
 if __name__ == "__main__":

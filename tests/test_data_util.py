@@ -92,13 +92,17 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 def test_committed_frames_fixture_pins_load_img_and_erosion():
     """tests/golden/frames (6 JPEG frames + masks + METRO pickles in the reference's layout) against frames_expected.npz, the output of
-    the reference's load_img restated literally with cv2.erode written out as loops from the OpenCV documentation
-    (tests/golden/make_golden_frames.py): decode, /255 scaling, un-thresholded mask, 3x3 erosion x2, shapes and dtypes."""
+    the REFERENCE's own utils/data_util.py (load_multiple_sequences -> ImagesDataset) imported by tests/golden/make_golden_frames.py
+    with a stub cv2 whose erode is written out as loops from the OpenCV documentation: decode, /255 scaling, channel order,
+    un-thresholded mask, 3x3 erosion x2, shapes and dtypes, dataset order and the stacked METRO parameters."""
     exp = np.load(os.path.join(GOLDEN, "frames_expected.npz"))
     root = os.path.join(GOLDEN, "frames")
     mp, ds, _, _ = D.load_multiple_sequences(os.path.join(root, "metro"), os.path.join(root, "img"), train_list=["1"], val_list=[])
     assert len(ds) == 6 and mp["pose"].shape == (6, 45) and mp["cam"].shape == (6, 3)
     assert [os.path.basename(p) for p in ds.image_paths] == [f"{i:04d}.jpg" for i in range(1, 7)]
+    assert [os.path.relpath(p, root) for p in ds.image_paths] == exp["image_paths"].tolist()            # the reference's dataset order
+    for k in ("pose", "rot", "trans", "shape", "cam", "joints"):                                         # combine_dict_to_batch, :54-73
+        assert mp[k].dtype == torch.float32 and np.array_equal(mp[k].numpy(), exp["mano_" + k]), k
     for i in range(6):
         fid, rgb, mask, er = ds[i]
         assert fid == i and rgb.dtype == mask.dtype == er.dtype == torch.float32

@@ -185,35 +185,36 @@ def test_c5_arm_1024_b32_through_the_striding_kernels(monkeypatch):
         assert all(v < GRAD_TOL for v in worst.values()), (f, worst)
 
 
-def test_c3_hand_512_b32_per_frame_rows_vs_fp64_oracle():
-    """C3 at the batch the headline number is quoted on: 32 frames of the subdivided hand at 512x512 in one step (the bench workload).
-    Oracle parity on 2 of the 32 frames the same way as for C5: every loss term that reaches a per-frame parameter row (pose, cam, rot,
-    trans) is a mean over the batch of per-frame terms, so row f of the batch gradient x 32 is the gradient of the ONE-frame step on
-    frame f, which the float64 oracle evaluates (rel-L2 <= 1e-3, those frames' float32-undecidable pixels out of the mask) — in both image
-    modes, whose losses must agree; plus the size-independent properties of all 32 frames."""
+def test_c3_hand_512_b32_all_gradients_vs_fp64_oracle():
+    """C3 at the batch the headline number is quoted on: 32 frames of the subdivided hand at 512x512 in ONE step (the bench workload),
+    EVERY gradient against the float64 oracle — the per-frame rows (pose, cam, rot, trans) and the shared parameters on which 32 frames'
+    atomics land (texture, normal_map, verts_disps, shape, light_positions, amb_ratio) — in both image modes.  The oracle is linear in
+    the frames: every image / mesh term is a mean over the batch of per-frame terms and the regularisers do not depend on the frames, so
+    the batch objective is the average of the 32 one-frame objectives; it is evaluated frame by frame (K=50 fragments of ONE 512x512
+    frame at a time) and the gradients accumulate.  Float32-undecidable pixels of all 32 frames are out of the mask (both sides)."""
     from tests._scene import ambiguous_pixels
     T = B = 32
     case = make_fit_case("hand", T=T, S=512, B=B, seed=2, device=DEV)
     eng = case["eng"]
-    frames = (5, 26)
     P, model, targets = oracle_inputs(case, torch.float64)
     y_col = case["targets"]["y_sil_col"].clone()
-    removed = []
-    for f in frames:
+    n_amb = n_cov = 0
+    for f in range(T):
         amb, aux = ambiguous_pixels(P, model, case["topo"], 512, case["focal"], [f], targets["y_true"])
         y_col[f][amb[0]] = 0.0
-        removed.append(amb.sum().item() / max((aux["pix_to_face"][..., 0] >= 0).sum().item(), 1))
-    check_removed("c3_hand_512_b32", max(removed))
+        n_amb += amb.sum().item()
+        n_cov += (aux["pix_to_face"][..., 0] >= 0).sum().item()
+    check_removed("c3_hand_512_b32", n_amb / max(n_cov, 1))
     case["targets"]["y_sil_col"] = y_col
     eng.set_targets(case["targets"]["y_true"], case["targets"]["y_sil"], y_col)
     eng.draw_texture_offsets()
     fid = torch.arange(T)
-    rows = ("pose", "cam", "rot", "trans")
+    keys = [k for k in ORACLE_KEYS if k != "wrist_pose"]
     got, lvs = {}, {}
     for keep in (True, False):
         eng.keep_image = keep
         lvs[keep] = engine_eval(case, fid)
-        got[keep] = {k: eng.grads[k].detach().cpu().double().clone() for k in rows}
+        got[keep] = {k: eng.grads[k].detach().cpu().double().clone() for k in keys}
         if keep:
             a, fc, rgb = eng.s["alpha"], eng.s["face_c"], eng.s["rgb"]
             cov = fc >= 0
@@ -223,15 +224,70 @@ def test_c3_hand_512_b32_per_frame_rows_vs_fp64_oracle():
     for k, v in lvs[True].items():
         assert abs(v - lvs[False][k]) <= LOSS_TOL * abs(v) + 1e-12, (k, v, lvs[False][k])
     targets["y_sil_col"] = y_col.double()
-    for f in frames:
-        for k in ORACLE_KEYS:
-            if k in P:
-                P[k].grad = None
-        oracle_step(case, torch.tensor([f]), P=P, model=model, targets=targets)
+    loss_sum = {}
+    for f in range(T):                                            # .grad accumulates over the 32 one-frame steps
+        _, loss, _, _, _ = oracle_step(case, torch.tensor([f]), P=P, model=model, targets=targets)
+        for k, v in loss.items():
+            loss_sum[k] = loss_sum.get(k, 0.0) + v.item()
+    for keep in (True, False):
+        for k, v in loss_sum.items():
+            assert abs(lvs[keep][k] - v / T) <= LOSS_TOL * abs(v / T) + 1e-9, (k, keep, lvs[keep][k], v / T)
+        worst = {}
+        for k in keys:
+            if P[k].grad is None or P[k].grad.abs().max() == 0:
+                assert got[keep][k].abs().max().item() == 0, (k, "expected an exactly zero gradient")
+                continue
+            worst[k] = rel(got[keep][k], P[k].grad / T)
+        print(f"[gradient rel-L2 vs fp64 oracle] C3 B=32 512x512, all parameters, keep_image={keep}:", {k: f"{v:.1e}" for k, v in worst.items()})
+        assert all(v < GRAD_TOL for v in worst.values()), (keep, worst)
+        assert all(k in worst for k in ("pose", "cam", "verts_disps", "shape", "light_positions", "amb_ratio", "texture", "normal_map", "rot", "trans"))
+        # per-frame rows frame by frame (a wrong frame index would average out of the whole-table norm above)
+        for k in ("pose", "cam", "rot", "trans"):
+            rows = torch.stack([(got[keep][k][f] - P[k].grad[f] / T).norm() / (P[k].grad[f] / T).norm().clamp_min(1e-30) for f in range(T)])
+            assert rows.max().item() < 2 * GRAD_TOL, (k, keep, rows.max().item(), int(rows.argmax()))
+
+
+def test_unmasked_companions_c5_arm_1024_and_appearance_only_stage():
+    """Companions of test_c5_arm_1024_b1_vs_fp64_oracle and test_appearance_only_stage_geometry_gradients with NO pixel taken out of the
+    photometric mask (like test_c2_c3_hand_512_b2_unmasked_companion): image criterion unchanged, losses rel 1e-4, gradients rel-L2
+    <= 5e-3 (the appearance-only stage's geometry gradients: against the float32 oracle's own distance from the float64 result, see
+    below) — what the ambiguous-pixel mask removes in those two cases is bounded, not ignored."""
+    for tag, kind, S, coarse, keys in (("C5 arm 1024 B=1", "arm", 1024, True, ORACLE_KEYS),
+                                       ("app-only hand 256 B=2", "hand", 256, False, [k for k in ORACLE_KEYS if k != "wrist_pose"])):
+        n = 1 if kind == "arm" else 2
+        case = make_fit_case(kind, T=n, S=S, B=n, seed=0 if kind == "arm" else 3, device=DEV)
+        eng = case["eng"]
+        eng.draw_texture_offsets()
+        fid = torch.arange(n)
+        P, loss, total, aux, _ = oracle_step(case, fid, coarse=coarse, app=True)
+        o32 = None
         for keep in (True, False):
-            worst = {k: rel(got[keep][k][f] * B, P[k].grad[f]) for k in rows}
-            print(f"[gradient rel-L2 vs fp64 oracle] C3 B=32 frame {f} keep_image={keep}:", {k: f"{v:.1e}" for k, v in worst.items()})
-            assert all(v < GRAD_TOL for v in worst.values()), (f, keep, worst)
+            eng.keep_image = keep
+            lv = engine_eval(case, fid, coarse=coarse, app=True)
+            _check_losses(lv, loss, tol=1e-4)
+            if keep and coarse:
+                _check_images(eng, aux, n)
+            elif keep:
+                rgb = eng.s["rgb"][:n].cpu().double()
+                assert ((rgb - aux["y_pred"]).abs().max(-1).values > 1e-4).float().mean() < 1e-3
+            if coarse:
+                _check_grads(eng, P, keys, tol=5e-3, tag=f"{tag} UNMASKED keep_image={keep}")
+                continue
+            # appearance-only stage: the geometry gradients exist ONLY through the photometric term's barycentric / shadow path, i.e. they
+            # are made of exactly the pixels float32 cannot decide (sliver faces seen edge-on: d bary ~ 1/area amplifies the rounding of
+            # the float32 NDC vertices; measured unmasked: pose 2.8e-2, shape 1.4e-2, cam / rot 1.1e-2 — appearance parameters <= 2e-4).
+            # The yardstick is the ORACLE ITSELF evaluated in float32 on the same inputs: the HIP path may not be further from the
+            # float64 result than 3 x the float32 oracle is (and never more than 5e-2); where float32 is decisive, 5e-3 holds.
+            if o32 is None:
+                P32, _, _, _, _ = oracle_step(case, fid, dtype=torch.float32, coarse=False, app=True)
+                o32 = {k: rel(P32[k].grad.double(), P[k].grad) for k in keys if P[k].grad is not None and P[k].grad.abs().max() > 0}
+                print(f"[gradient rel-L2 of the float32 ORACLE vs the float64 oracle] {tag} UNMASKED: " + ", ".join(f"{k} {v:.1e}" for k, v in o32.items()))
+            got = {k: rel(eng.grads[k].cpu().double(), P[k].grad) for k in o32}
+            print(f"[gradient rel-L2 vs fp64 oracle] {tag} UNMASKED keep_image={keep}: " + ", ".join(f"{k} {v:.1e}" for k, v in got.items()))
+            for k, v in got.items():
+                assert v < min(5e-2, max(5e-3, 3.0 * o32[k])), (tag, keep, k, v, o32[k])
+        del case, eng
+        torch.cuda.empty_cache()
 
 
 def test_c1_raw_mano_mesh_silhouette_only():

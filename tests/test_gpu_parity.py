@@ -1051,3 +1051,65 @@ def test_light_camera_incl_look_at_replacement_branch():
         for got, ref, name in ((g_lp[b], ld_.grad[b], "light_pos"), (g_c[b], cd.grad[b], "centroid"), (g_v[b, 0], cd.grad[b], "verts")):
             err = (got.cpu().double() - ref).norm().item() / (ref.norm().item() + 1e-30)
             assert err < (2e-4 if b == 0 else 1e-3), (b, name, err, got.cpu(), ref)
+
+
+@pytest.mark.parametrize("switches", [dict(graph_order=False), dict(mesh_third=False), dict(camera_first=False), dict(overlap=False),
+                                      dict(graph_order=False, mesh_third=False), dict(mesh_third=False, camera_first=False),
+                                      dict(graph_order=False, mesh_third=False, camera_first=False), dict(early_terms=False),
+                                      dict(mesh_terms_first=False, mesh_third=False), dict(tail_side=True)])
+def test_schedule_switches_give_the_default_schedules_result(switches):
+    """The stream / capture-order switches of FitEngine (graph_order, mesh_third, camera_first, overlap, early_terms, mesh_terms_first,
+    tail_side) only move launches between streams: losses and the whole gradient arena of every non-default combination must equal the
+    default schedule's up to the order of the float atomics — eagerly AND graph-replayed (lr = 0, one-row schedule: every replay starts
+    from the same state).  A missing join or a clear that no longer covers a segment (gs_mesh, gs_zero_late) in a non-default
+    combination shows up here."""
+    from tests._scene import make_fit_case
+    case = make_fit_case("hand", T=3, S=128, B=3, seed=4, device=DEV)
+    eng = case["eng"]
+    eng.keep_image = False
+    eng.auto_draw = False
+    eng.draw_texture_offsets()
+    eng.set_lr(0.0, 0.0)
+    eng.set_schedule(torch.arange(3).reshape(1, 3).int())
+
+    def run(graph):
+        for _ in range(3 if graph else 1):
+            eng.step(None, True, True, use_graph=graph)
+        torch.cuda.synchronize()
+        return eng.g_buf.double().clone(), eng.loss_vec[:9].double().clone()
+    ref = {g: run(g) for g in (False, True)}
+    defaults = {k: getattr(eng, k) for k in switches}
+    for k, v in switches.items():
+        setattr(eng, k, v)
+    try:
+        for graph in (False, True):
+            g, l = run(graph)
+            assert rel(g, ref[graph][0]) < 1e-5, (switches, graph, rel(g, ref[graph][0]))
+            assert ((l - ref[graph][1]).abs() <= 1e-5 * ref[graph][1].abs() + 1e-9).all(), (switches, graph, l, ref[graph][1])
+            for k in ("pose", "cam", "verts_disps", "shape", "light_positions", "texture", "normal_map"):
+                a, b = eng.arena.view(g, k), eng.arena.view(ref[graph][0], k)
+                assert rel(a, b) < 1e-4, (switches, graph, k, rel(a, b))
+    finally:
+        for k, v in defaults.items():
+            setattr(eng, k, v)
+
+
+def test_one_launch_backward_pair_with_a_kept_image():
+    """`fused_bwd` (shading + silhouette backward in one launch) instantiates the loss-only shader tile, which cannot write y_pred: with
+    keep_image the step must go through the forward shader, so that s["rgb"] is this step's image and not a stale one"""
+    from tests._scene import make_fit_case
+    case = make_fit_case("hand", T=2, S=128, B=2, seed=5, device=DEV)
+    eng = case["eng"]
+    eng.auto_draw = False
+    eng.draw_texture_offsets()
+    eng.keep_image = True
+    fid = torch.tensor([0, 1])
+    engine_eval = __import__("tests._scene", fromlist=["engine_eval"]).engine_eval
+    lv0 = engine_eval(case, fid)
+    rgb0, g0 = eng.s["rgb"].clone(), eng.g_buf.double().clone()
+    eng.s["rgb"].fill_(-7.0)                                   # a stale image would survive the next pass
+    eng.fused_bwd = True
+    lv1 = engine_eval(case, fid)
+    eng.fused_bwd = False
+    assert (eng.s["rgb"] - rgb0).abs().max().item() < 1e-4      # forward shader vs the colour the backward pass recomputes: 2e-5 measured
+    assert rel(eng.g_buf.double(), g0) < 1e-5 and abs(lv1["photo"] - lv0["photo"]) <= 1e-5 * abs(lv0["photo"])

@@ -41,7 +41,7 @@ if not os.environ.get("R3_NOCHECK"):
     # gradient agreement with the round-1 barrier-synchronised kernel (debug_skip = 64): one launch of each into cleared buffers
     def grads(flags):
         a.debug_skip = flags
-        eng.gs_zero.zero_(); eng.gs_zero_late.zero_()
+        eng.gs_zero.zero_(); eng.gs_zero_late.zero_(); eng.gs_mesh.zero_()      # (g_vd / g_joints_m are a segment of their own since the third stream)
         L.harp_shade_bwd(ctypes.byref(a), _lib.stream()); torch.cuda.synchronize()
         return {k: eng.s[k].clone() for k in ("g_vd", "g_n2", "g_ndc_c", "g_zl", "g_light_pos", "g_colors", "g_light_R", "g_light_T", "g_nmap_n")} | \
                {"g_tex": eng.grads["texture"].clone(), "loss": eng.loss_vec.clone()}

@@ -56,6 +56,13 @@ def main(fetch_db, write_db, cmd):
                       "launches of every kernel (= the profiled steps; the launches that render bench.py's targets are left out); "
                       "HBM bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (gfx950: FETCH_SIZE under-reports coalesced reads by 2x, calibrated on "
                       "adam_dev_kernel; WRITE_SIZE calibrated on the raster outputs).  tools/make_traffic_json.py"}
+    try:
+        import os
+        import subprocess
+        out["_head"] = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True, timeout=10,
+                                      cwd=os.path.dirname(os.path.abspath(__file__))).stdout.strip() or "unknown (no git on this box)"
+    except Exception:
+        out["_head"] = "unknown"
     detail = {}
     names = set(f) | set(w)
     for key, parts in GROUPS.items():
