@@ -158,8 +158,8 @@ def kernel_roofline(eng, steps, overlap=False):
 
 # kernel-name substrings of the event-timed groups (the in-graph durations of a group = the sum over its kernels; the three set-up kernels
 # run once per view, their per-launch averages are over both views)
-_GROUP_KERNELS = {"raster_cam_fwd(setup+bin+raster)": ("raster_kernel<1,", "face_setup_kernel", "bin_faces_kernel", "order_tiles_kernel"),
-                  "raster_light_fwd(setup+bin+raster)": ("raster_kernel<0,", "face_setup_kernel", "bin_faces_kernel", "order_tiles_kernel"),
+_GROUP_KERNELS = {"raster_cam_fwd(setup+bin+raster)": ("raster_kernel<1,", "face_setup_kernel", "bin_faces_kernel", "expand_bits_kernel", "order_tiles_kernel"),
+                  "raster_light_fwd(setup+bin+raster)": ("raster_kernel<0,", "face_setup_kernel", "bin_faces_kernel", "expand_bits_kernel", "order_tiles_kernel"),
                   "harp_shade_fwd": ("shade_kernel<false>",), "harp_shade_bwd": ("shade_bwd_wave_kernel",),
                   "harp_silhouette_bwd": ("raster_kernel<2,",), "harp_depth_bwd": ("depth_bwd_kernel",)}
 
@@ -209,7 +209,7 @@ def profiled_in_graph(steps=40, warmup=8):
             per.setdefault(n, []).append((t1 - t0) / 1e3)
         out = {}
         for n, d in per.items():
-            k = steps * (2 if any(t in n for t in ("face_setup_kernel", "bin_faces_kernel", "order_tiles_kernel")) else 1)
+            k = steps * (2 if any(t in n for t in ("face_setup_kernel", "bin_faces_kernel", "expand_bits_kernel", "order_tiles_kernel")) else 1)
             keep = d[-k:]
             out[n] = (float(np.mean(keep)), len(keep))
         return out

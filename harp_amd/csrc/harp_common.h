@@ -31,7 +31,8 @@ struct FaceRec {
 
 // Layout of a rasteriser workspace (harp_rasterize_ws_bytes): face records | contiguous bboxes | per-super-tile face lists |
 // list lengths | heaviest-first launch order of the (frame, super-tile) pairs.
-struct RasterWs { FaceRec* recs; float4* bbs; int32_t* bins; int32_t* cnt; int32_t* order; int32_t* nact; int nsx; };
+// ... | hit bitmaps: one bit per (frame, super-tile, face), 64 faces per word (written whole by the face set-up pass, expanded into the lists)
+struct RasterWs { FaceRec* recs; float4* bbs; int32_t* bins; int32_t* cnt; int32_t* order; int32_t* nact; int nsx; unsigned long long* bits; int W64; };
 __host__ __device__ inline RasterWs raster_ws_split(void* ws, int B, int F, int S) {
   RasterWs r;
   r.nsx = (S + kSuper - 1) / kSuper;
@@ -41,7 +42,9 @@ __host__ __device__ inline RasterWs raster_ws_split(void* ws, int B, int F, int 
   r.bins = (int32_t*)p;   p += (size_t)B * r.nsx * r.nsx * F * sizeof(int32_t);
   r.cnt = (int32_t*)p;    p += (((size_t)B * r.nsx * r.nsx * sizeof(int32_t)) + 255) / 256 * 256;
   r.order = (int32_t*)p;  p += (((size_t)B * r.nsx * r.nsx * sizeof(int32_t)) + 255) / 256 * 256;
-  r.nact = (int32_t*)p;   // one int: number of super-tiles that hold faces = number of leading launch-order slots with work
+  r.nact = (int32_t*)p;   p += 256;   // one int: number of super-tiles that hold faces = number of leading launch-order slots with work
+  r.bits = (unsigned long long*)p;
+  r.W64 = (F + 63) / 64;
   return r;
 }
 // workgroups of the 1-D tile grid: launch-order slots rounded up to a multiple of 8 (one per XCD) x 16 tiles per super-tile

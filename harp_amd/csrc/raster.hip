@@ -21,25 +21,85 @@ namespace {
 
 using rb::Tri;
 
+// BITS: the pass also writes the super-tile hit bitmaps (round 4).  A wave owns 64 consecutive faces = exactly one 64-bit word of every
+// (frame, super-tile) bitmap, so the words are plain stores — no atomics, nothing to clear, every word is rewritten by every call.  The hit
+// test of the binning pass is separable in x and y: nsx + nsx ballots per wave give the column masks and the row masks, lane l then forms
+// the word of super-tile l as (column mask) & (row mask).  Same comparison, same floats as rb::bin_super_tile -> identical lists.
+template <bool BITS>
 __global__ void __launch_bounds__(256) face_setup_kernel(const float* __restrict__ ndc, const int32_t* __restrict__ faces,
                                                          int V, int F, float r, FaceRec* __restrict__ recs,
-                                                         float4* __restrict__ bbs) {
+                                                         float4* __restrict__ bbs, int S, int nsx, unsigned long long* __restrict__ bits, int W64) {
   const int f = blockIdx.x * blockDim.x + threadIdx.x;
   const int b = blockIdx.y;
-  if (f >= F) return;
-  const FaceRec rec = rb::face_rec(ndc + (size_t)b * V * 3, faces, f, r);
-  recs[(size_t)b * F + f] = rec;
-  bbs[(size_t)b * F + f] = rec.bb;      // contiguous copy: the binning pass streams it with fully coalesced 16-B loads
+  float4 bb = make_float4(3.0e38f, -3.0e38f, 3.0e38f, -3.0e38f);
+  if (f < F) {
+    const FaceRec rec = rb::face_rec(ndc + (size_t)b * V * 3, faces, f, r);
+    recs[(size_t)b * F + f] = rec;
+    bbs[(size_t)b * F + f] = rec.bb;      // contiguous copy: the tile kernels' staging streams it with fully coalesced 16-B loads
+    bb = rec.bb;
+  }
+  if constexpr (BITS) {
+    const int lane = threadIdx.x & 63;
+    const int chunk = f >> 6;             // wave-uniform: blockDim.x is a multiple of 64
+    if (chunk >= W64) return;
+    unsigned long long kx = 0ull, ky = 0ull;
+    for (int s = 0; s < nsx; ++s) {
+      const int lo = s * kSuper, hi = min(lo + kSuper, S) - 1;
+      const float n_hi = pix_to_ndc(lo, S), n_lo = pix_to_ndc(hi, S);       // NDC decreases with the pixel index
+      const unsigned long long mx = __ballot(!(n_lo > bb.y || n_hi < bb.x));
+      const unsigned long long my = __ballot(!(n_lo > bb.w || n_hi < bb.z));
+      if (lane == s) { kx = mx; ky = my; }
+    }
+    const int nst = nsx * nsx;
+    for (int g = 0; g < nst; g += 64) {
+      const int st = g + lane;
+      const int sx = st % nsx, sy = min(st / nsx, nsx - 1);
+      const unsigned xl = __shfl((unsigned)kx, sx, 64), xh = __shfl((unsigned)(kx >> 32), sx, 64);
+      const unsigned yl = __shfl((unsigned)ky, sy, 64), yh = __shfl((unsigned)(ky >> 32), sy, 64);
+      if (st < nst) bits[((size_t)b * nst + st) * W64 + chunk] = ((unsigned long long)(xh & yh) << 32) | (unsigned long long)(xl & yl);
+    }
+  }
 }
 
 // One WAVE per (frame, 64x64 super-tile): streams the frame's bboxes 64 at a time, ballot + popcount compaction,
 // no LDS, no barriers; the list comes out in ascending face order (== PyTorch3D's tie-break order).
+// (rounds 1-3; since round 4 only for images above 4096 pixels a side, whose super-tile columns no longer fit the lanes of a wave)
 __global__ void __launch_bounds__(256) bin_faces_kernel(const float4* __restrict__ bbs, int F, int S, int nsx,
                                                         int32_t* __restrict__ bins, int32_t* __restrict__ bin_count) {
   const int nst = nsx * nsx;
   const int st = blockIdx.x * 4 + (threadIdx.x >> 6), b = blockIdx.y;
   if (st >= nst) return;
   rb::bin_super_tile(bbs + (size_t)b * F, F, S, nsx, st, bins + ((size_t)b * nst + st) * F, bin_count + b * nst + st);
+}
+
+// Round 4: the lists from the hit bitmaps.  One wave per (frame, super-tile) reads its W64 words (coalesced, ONE round trip for up to
+// 4096 faces instead of the 13 dependent trips of the bbox scan), prefix-sums the popcounts and writes the set bits in ascending order.
+// The scan took 32 us of the 51 us between the end of the hand layer and the first raster workgroup (profiles/r04_a_timeline_one_step.txt).
+__global__ void __launch_bounds__(256) expand_bits_kernel(const unsigned long long* __restrict__ bits, int F, int W64, int nst,
+                                                          int32_t* __restrict__ bins, int32_t* __restrict__ bin_count) {
+  const int st = blockIdx.x * 4 + (threadIdx.x >> 6), b = blockIdx.y, lane = threadIdx.x & 63;
+  if (st >= nst) return;
+  const unsigned long long* src = bits + ((size_t)b * nst + st) * W64;
+  int32_t* out = bins + ((size_t)b * nst + st) * F;
+  int total = 0;
+  for (int base = 0; base < W64; base += 64) {
+    unsigned long long w = (base + lane < W64) ? src[base + lane] : 0ull;
+    const int c = __popcll(w);
+    int incl = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int t = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += t;
+    }
+    int pos = total + incl - c;
+    const int f0 = (base + lane) * 64;
+    while (w) {
+      out[pos++] = f0 + (int)__builtin_ctzll(w);
+      w &= w - 1ull;
+    }
+    total += __shfl(incl, 63, 64);
+  }
+  if (lane == 0) bin_count[b * nst + st] = total;
 }
 
 // (Folding this into the binning pass with a "last workgroup done" ticket was measured: 512 same-address ticket atomics cost ~35 us,
@@ -101,8 +161,14 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE =
 
 static void raster_setup_any(const float* ndc, const int32_t* faces, int B, int V, int F, int S, float r, void* ws, hipStream_t stream) {
   const RasterWs W = raster_ws_split(ws, B, F, S);
-  hipLaunchKernelGGL(face_setup_kernel, dim3((F + 255) / 256, B), dim3(256), 0, stream, ndc, faces, V, F, r, W.recs, W.bbs);
-  hipLaunchKernelGGL(bin_faces_kernel, dim3((W.nsx * W.nsx + 3) / 4, B), dim3(256), 0, stream, W.bbs, F, S, W.nsx, W.bins, W.cnt);
+  static const bool old_bins = [] { const char* e = getenv("HARP_BIN_SCAN"); return e && atoi(e) != 0; }();     // A/B: the bbox scan of rounds 1-3
+  if (W.nsx <= 64 && !old_bins) {
+    hipLaunchKernelGGL(face_setup_kernel<true>, dim3((F + 255) / 256, B), dim3(256), 0, stream, ndc, faces, V, F, r, W.recs, W.bbs, S, W.nsx, W.bits, W.W64);
+    hipLaunchKernelGGL(expand_bits_kernel, dim3((W.nsx * W.nsx + 3) / 4, B), dim3(256), 0, stream, W.bits, F, W.W64, W.nsx * W.nsx, W.bins, W.cnt);
+  } else {
+    hipLaunchKernelGGL(face_setup_kernel<false>, dim3((F + 255) / 256, B), dim3(256), 0, stream, ndc, faces, V, F, r, W.recs, W.bbs, S, W.nsx, nullptr, 0);
+    hipLaunchKernelGGL(bin_faces_kernel, dim3((W.nsx * W.nsx + 3) / 4, B), dim3(256), 0, stream, W.bbs, F, S, W.nsx, W.bins, W.cnt);
+  }
   hipLaunchKernelGGL(order_tiles_kernel, dim3(1), dim3(1024), 0, stream, W.cnt, B * W.nsx * W.nsx, W.order, W.nact);
 }
 
@@ -133,7 +199,8 @@ size_t harp_rasterize_ws_bytes(int B, int F, int S) {
   size_t bbs = (size_t)B * F * sizeof(float4);
   size_t bins = (size_t)B * nsx * nsx * F * sizeof(int32_t);
   size_t cnt = (((size_t)B * nsx * nsx * sizeof(int32_t)) + 255) / 256 * 256;
-  return recs + bbs + bins + 2 * cnt + 256;      // counts + launch order + number of non-empty super-tiles
+  size_t bits = (size_t)B * nsx * nsx * ((F + 63) / 64) * sizeof(unsigned long long);
+  return recs + bbs + bins + 2 * cnt + 256 + bits;      // counts + launch order + number of non-empty super-tiles + hit bitmaps
 }
 
 // Forward rasterisation of B frames sharing one face table.

@@ -370,7 +370,11 @@ class FitEngine:
                 lloss.zero_()
         shadow = app and self.self_shadow
         if not self.overlap:
-            side = cur                                   # single-stream mode (used when individual kernels are timed with events)
+            side = cur                                   # single-stream mode (kernels timed with events; the lanes of a pipelined step)
+        # (single-stream mode enqueues no waits at all: a stream waiting for itself is legal but has crashed hipStreamEndCapture)
+        one = not self.overlap
+        wait_s = lambda a, b: None if one else a.wait_stream(b)
+        wait_e = lambda a, e: None if one else a.wait_event(e)
         sched_early = self.early_terms
         extra = lambda name: self._extra_stream(name) if self.overlap else cur      # further graph branches (hipGraph replays four concurrently here)
         off = self.disabled_terms
@@ -406,13 +410,13 @@ class FitEngine:
         # view before the third stream, the shader backward before the silhouette backward — so that it replays as ONE in-order stream.
         go = self.graph_order and sched_early and self.overlap and self.camera_first
         if sched_early and not go:
-            side.wait_stream(cur)
+            wait_s(side, cur)
             with torch.cuda.stream(side):
                 param_terms()
         ev0 = cur.record_event() if go else None
         fused = self._mesh_forward(lfid, B, shadow, front=True)      # fused chain: both projections and the light camera are done as well
         if go:
-            side.wait_event(ev0)
+            wait_e(side, ev0)
             with torch.cuda.stream(side):
                 param_terms()
         # ---- the light-view chain (centroid -> light camera -> projection -> K=1 raster) is independent of the camera-view chain:
@@ -420,16 +424,16 @@ class FitEngine:
         #      regularisers and the key-point term follow it there (the light raster is the shorter of the two)
         def light_view(fork=None):
             if fork is None:
-                side.wait_stream(cur)
+                wait_s(side, cur)
             else:
-                side.wait_event(fork)
+                wait_e(side, fork)
             def third_branch():
                 if mesh_on_third:
                     third = extra("third")
                     if fork is None:
-                        third.wait_stream(cur)
+                        wait_s(third, cur)
                     else:
-                        third.wait_event(fork)
+                        wait_e(third, fork)
                     with torch.cuda.stream(third):
                         self.gs_mesh.zero_()
                         mesh_terms()
@@ -471,9 +475,9 @@ class FitEngine:
         else:
             light_view()
             camera_view()
-        cur.wait_stream(side)                           # join: light depth map, regulariser gradients, normalised normal map
+        wait_s(cur, side)                           # join: light depth map, regulariser gradients, normalised normal map
         if mesh_on_third:
-            cur.wait_stream(extra("third"))
+            wait_s(cur, extra("third"))
         # both backward passes of the camera view as ONE launch (harp_shade_sil_bwd): as two kernels on two streams they cannot share a CU
         fuse_bwd = self.fused_bwd and coarse and app and self.perceptual is None
         side_used = False
@@ -481,9 +485,9 @@ class FitEngine:
         def launch_sil(ev=None):
             # the silhouette backward only needs g_alpha and the camera-view workspace: it overlaps with shading on the side stream
             if ev is None:
-                side.wait_stream(cur)
+                wait_s(side, cur)
             else:
-                side.wait_event(ev)
+                wait_e(side, ev)
             with torch.cuda.stream(side):
                 self._ck(L.harp_silhouette_bwd(p(tp.faces), B, V, F, S, ops.SIL_BLUR, ops.SIL_SIGMA, p(s["ws_c"]), p(s["alpha"]), p(s["g_alpha"]),
                                                p(s["g_ndc_c"]), ST()), "silhouette_bwd")
@@ -530,7 +534,7 @@ class FitEngine:
                              "normalize3_bwd")
                     self._allreduce_maps_early()
                 if self.tail_side and self.overlap:
-                    side.wait_stream(cur)
+                    wait_s(side, cur)
                     with torch.cuda.stream(side):
                         maps_tail()
                 else:
@@ -543,7 +547,7 @@ class FitEngine:
                     self._ck(L.harp_light_setup_bwd(p(s["centroid"]), p(s["light_pos"]), p(s["g_light_R"]), p(s["g_light_T"]), B, V, p(s["g_light_pos"]),
                                                     p(s["g_centroid"]), p(s["g_vd"]), ST()), "light_setup_bwd")
         if side_used or (self.tail_side and self.overlap and app):
-            cur.wait_stream(side)                       # silhouette_bwd -> g_ndc_c (normal-map chain rule with tail_side)
+            wait_s(cur, side)                       # silhouette_bwd -> g_ndc_c (normal-map chain rule with tail_side)
         if fused and self.fused_front and self.fused_back:
             # the whole backward tail — mesh chain, hand layer, scatter into the parameter tables' gradient rows — as three launches
             self._ck(L.harp_hand_back_bwd(ctypes.byref(self._hand_struct(lfid, B, shadow, app)), p(s["g_colors"]) if app else None,

@@ -20,6 +20,14 @@ def rasterize_workspace(B, F, S, device):
     return torch.empty(n, dtype=torch.uint8, device=device)
 
 
+def rasterize_ws_nact(ws, B, F, S):
+    """number of (frame, 64x64 super-tile) pairs that hold faces, read back from a rasteriser workspace (csrc/harp_common.h:
+    raster_ws_split — ... | nact (256 B) | hit bitmaps at the tail); debugging / tests: one D2H copy"""
+    nst = ((S + 63) // 64) ** 2
+    bits = B * nst * ((F + 63) // 64) * 8
+    return int(ws[-(256 + bits):][:4].view(torch.int32)[0])
+
+
 def rasterize_fwd(ndc, faces, S, soft=False, blur_radius=0.0, sigma=1.0, want_zbuf=True, ws=None):
     """ndc (B,V,3) f32, faces (F,3) i32 -> face_id (B,S,S) i32, zbuf (B,S,S)|None, alpha (B,S,S)|None, ws."""
     B, V, _ = ndc.shape

@@ -333,7 +333,7 @@ def test_full_size_properties():
     for k, v in full[0].items():
         assert abs(v - lean[0][k]) <= 2e-6 * abs(v) + 1e-12, (k, v, lean[0][k])
     assert rel(lean[1].cpu(), full[1].cpu()) < 1e-5
-    nact = int(eng.s["ws_c"][-256:].view(torch.int32)[0])
+    nact = ops.rasterize_ws_nact(eng.s["ws_c"], eng.B, eng.topo.F, eng.S)
     assert 0 < nact < 32 * 64 // 2                      # most 64x64 super-tiles of a hand image are background
 
 
@@ -867,7 +867,8 @@ def test_losses_with_empty_supertiles():
         eng.auto_draw = False; eng.draw_texture_offsets(); eng.set_stage(True, True)
         eng.forward_backward(True, True)
         torch.cuda.synchronize()
-        nact = int(eng.s["ws_c"][-256:].view(torch.int32)[0])
+        from harp_amd import ops as _ops
+        nact = _ops.rasterize_ws_nact(eng.s["ws_c"], eng.B, eng.topo.F, eng.S)
         assert 0 < nact < B * 16, nact                    # some super-tiles hold faces, some do not
         if ref is None:
             P = oracle_params(sc, eng.params)
@@ -1008,7 +1009,8 @@ def test_striding_grid_counts_empty_supertiles_once(monkeypatch):
             eng.auto_draw = False; eng.draw_texture_offsets(); eng.set_stage(True, True)
             eng.forward_backward(True, True)
             torch.cuda.synchronize()
-            nact = int(eng.s["ws_c"][-256:].view(torch.int32)[0])
+            from harp_amd import ops as _ops
+            nact = _ops.rasterize_ws_nact(eng.s["ws_c"], eng.B, eng.topo.F, eng.S)
             assert 0 < nact < B * 16, nact
             res[mode] = (eng.losses(), eng.g_buf.clone().cpu())
         odd += nact % 8 != 0

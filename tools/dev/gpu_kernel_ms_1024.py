@@ -12,4 +12,4 @@ for _ in range(3): eng.step(None, True, True)
 torch.cuda.synchronize(); t = time.perf_counter()
 for _ in range(30): eng.step(None, True, True)
 torch.cuda.synchronize(); print("step %.3f ms" % ((time.perf_counter() - t) / 30 * 1e3))
-nact = int(eng.s["ws_c"][-256:].view(torch.int32)[0]); print("active super-tiles", nact, "of", 32 * 256)
+nact = __import__("harp_amd.ops", fromlist=["x"]).rasterize_ws_nact(eng.s["ws_c"], eng.B, eng.topo.F, eng.S); print("active super-tiles", nact, "of", 32 * 256)

@@ -1,0 +1,10 @@
+"""graph replays of the bench workload with FitEngine attributes set from HARP_ENG (e.g. "pipelined=1,mesh_third=0"): for rocprofv3 timelines"""
+import sys, os; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
+import torch, bench
+eng, focal = bench.build_engine(0, 1, torch.device('cuda'))
+eng.keep_image = False
+for kv in filter(None, os.environ.get("HARP_ENG", "").split(",")):
+    k, v = kv.split("="); setattr(eng, k, type(getattr(eng, k))(int(v)))
+eng.set_schedule(torch.arange(256).reshape(-1, 32).int())
+for _ in range(30): eng.step(None, True, True)
+torch.cuda.synchronize()

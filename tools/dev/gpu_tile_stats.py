@@ -6,7 +6,7 @@ fid = torch.arange(32)
 eng.step(fid, True, True, use_graph=False); torch.cuda.synchronize()
 f = eng.s["face_c"]; m = eng.y_sil_col[:32]
 cov = f >= 0; act = cov & (m != 0)
-print("nact", int(eng.s["ws_c"][-256:].view(torch.int32)[0]), "of", 32 * 64)
+print("nact", __import__("harp_amd.ops", fromlist=["x"]).rasterize_ws_nact(eng.s["ws_c"], eng.B, eng.topo.F, eng.S), "of", 32 * 64)
 print("covered px", cov.sum().item(), "active px", act.sum().item(), "of", f.numel())
 t = act.view(32, 32, 16, 32, 16).permute(0, 1, 3, 2, 4).reshape(32, 32, 32, 256)     # tiles
 per_tile = t.sum(-1)

@@ -27,7 +27,7 @@ def per_launch(path, counter, last=LAST):
     for k, d in per.items():
         ids = sorted(d)
         # set-up kernels run once per view: keep the launches of the last `last` steps of both views
-        n = last * (2 if any(t in k for t in ("face_setup_kernel", "bin_faces_kernel", "order_tiles_kernel")) else 1)
+        n = last * (2 if any(t in k for t in ("face_setup_kernel", "bin_faces_kernel", "expand_bits_kernel", "order_tiles_kernel")) else 1)
         keep = ids[-n:]
         out[k] = (sum(d[i] for i in keep) / len(keep), len(keep))
     return out
@@ -40,8 +40,8 @@ GROUPS = {
     "harp_shade_bwd": (("shade_bwd_wave_kernel", "shade_bwd_face_kernel", "shade_kernel<true>"),),
     "harp_shade_fwd": (("shade_kernel<false>",),),
     # face_setup / bin_faces / order_tiles run once per view: their per-launch averages are over both views already
-    "raster_cam_fwd(setup+bin+raster)": (("raster_kernel<1,",), ("face_setup_kernel",), ("bin_faces_kernel",), ("order_tiles_kernel",)),
-    "raster_light_fwd(setup+bin+raster)": (("raster_kernel<0,",), ("face_setup_kernel",), ("bin_faces_kernel",), ("order_tiles_kernel",)),
+    "raster_cam_fwd(setup+bin+raster)": (("raster_kernel<1,",), ("face_setup_kernel",), ("bin_faces_kernel", "expand_bits_kernel"), ("order_tiles_kernel",)),
+    "raster_light_fwd(setup+bin+raster)": (("raster_kernel<0,",), ("face_setup_kernel",), ("bin_faces_kernel", "expand_bits_kernel"), ("order_tiles_kernel",)),
     "raster_cam_fwd(raster kernel only)": (("raster_kernel<1,",),),
     "raster_light_fwd(raster kernel only)": (("raster_kernel<0,",),),
     "harp_silhouette_bwd": (("raster_kernel<2,",),),
