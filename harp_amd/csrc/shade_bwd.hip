@@ -504,10 +504,13 @@ __device__ __forceinline__ void shade_bwd_tile(ShadeSmem& sm, unsigned vblock, c
           }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        int zq[kZW * kZH / 64];
 #pragma unroll
-        for (int i = lane; i < kZW * kZH; i += 64) {
-          const int q = L.zwin[i];
-          if (q != 0) atomicAdd(at32m(gz, (unsigned)((y0 + i / kZW) * S + x0 + (i % kZW))), (float)q * zinv_s);
+        for (int j = 0; j < kZW * kZH / 64; ++j) zq[j] = L.zwin[lane + 64 * j];
+#pragma unroll
+        for (int j = 0; j < kZW * kZH / 64; ++j) {
+          const int i = lane + 64 * j;
+          if (zq[j] != 0) atomicAdd(at32m(gz, (unsigned)((y0 + i / kZW) * S + x0 + (i % kZW))), (float)zq[j] * zinv_s);
         }
       }
     }
@@ -563,6 +566,27 @@ __device__ __forceinline__ void shade_bwd_tile(ShadeSmem& sm, unsigned vblock, c
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       // flush, lanes = (slot, channel): a table row holds consecutive texels of one texture row -> consecutive addresses
+#ifndef SHADE_FLUSH_SERIAL
+      if (!(dbg & 8)) {
+        // all LDS reads of the flush in flight at once (3 x 11 per lane), then the memory atomics: the loop form paid two dependent
+        // LDS round trips per pass, 21 in a row
+        constexpr int kP = (kTSlots * 3 + 63) / 64;
+        int key[kP], a0[kP], a1[kP];
+#pragma unroll
+        for (int j = 0; j < kP; ++j) {
+          const int i = min(lane + 64 * j, kTSlots * 3 - 1), sl = i / 3, c = i - 3 * sl;
+          key[j] = L.tkey[sl]; a0[j] = L.tval[c][sl]; a1[j] = L.tval[3 + c][sl];
+        }
+#pragma unroll
+        for (int j = 0; j < kP; ++j) {
+          const int i = lane + 64 * j, c = i % 3;
+          if (i < kTSlots * 3 && key[j] >= 0) {
+            if (a0[j] != 0) atomicAdd(at32m(A.g_tex, 3u * (unsigned)key[j] + c), (float)a0[j] * ia);
+            if (a1[j] != 0) atomicAdd(at32m(A.g_nmap, 3u * (unsigned)key[j] + c), (float)a1[j] * im);
+          }
+        }
+      }
+#else
       if (!(dbg & 8)) for (int i = lane; i < kTSlots * 3; i += 64) {
         const int sl = i / 3, c = i - 3 * sl;
         const int key = L.tkey[sl];
@@ -571,10 +595,30 @@ __device__ __forceinline__ void shade_bwd_tile(ShadeSmem& sm, unsigned vblock, c
         if (a0 != 0) atomicAdd(at32m(A.g_tex, 3u * (unsigned)key + c), (float)a0 * ia);
         if (a1 != 0) atomicAdd(at32m(A.g_nmap, 3u * (unsigned)key + c), (float)a1 * im);
       }
+#endif
     }
 
     STAMP(9);
     // ---- flush the vertex table, lanes = (slot, component)
+#ifndef SHADE_FLUSH_SERIAL
+    if (!(dbg & 12)) {
+      constexpr int kQ = (kVSlots * 9 + 63) / 64;
+      int vk[kQ]; float vv[kQ];
+#pragma unroll
+      for (int j = 0; j < kQ; ++j) {
+        const int i = min(lane + 64 * j, kVSlots * 9 - 1), sl = i / 9, c = i - 9 * sl;
+        vk[j] = L.vkey[sl]; vv[j] = (float)L.vval[c][sl];
+      }
+#pragma unroll
+      for (int j = 0; j < kQ; ++j) {
+        const int i = lane + 64 * j, c = i % 9;
+        if (i < kVSlots * 9 && vk[j] >= 0 && vv[j] != 0.f) {
+          float* dst = c < 3 ? gvb : (c < 6 ? gnb : gdb);
+          atomicAdd(at32m(dst, 3u * (unsigned)vk[j] + (c % 3)), vv[j]);
+        }
+      }
+    }
+#else
     if (!(dbg & 12)) for (int i = lane; i < kVSlots * 9; i += 64) {
       const int sl = i / 9, c = i - 9 * sl;
       const int v = L.vkey[sl];
@@ -584,6 +628,7 @@ __device__ __forceinline__ void shade_bwd_tile(ShadeSmem& sm, unsigned vblock, c
       float* dst = c < 3 ? gvb : (c < 6 ? gnb : gdb);
       atomicAdd(at32m(dst, 3u * (unsigned)v + (c % 3)), val);
     }
+#endif
   }
 
 #ifdef SHADE_STAMPS
