@@ -164,7 +164,7 @@ _GROUP_KERNELS = {"raster_cam_fwd(setup+bin+raster)": ("raster_kernel<1,", "face
                   "harp_silhouette_bwd": ("raster_kernel<2,",), "harp_depth_bwd": ("depth_bwd_kernel",)}
 
 
-def _child(cmd_tail, prof_args, out_dir, timeout=600):
+def _child(cmd_tail, prof_args, out_dir, timeout=240):
     """one `rocprofv3 <prof_args> -- python bench.py <cmd_tail>` child (outside the timed region); returns the rocpd database path or None"""
     import glob
     import shutil
@@ -650,7 +650,8 @@ def main():
         ach = alg[dom] / (timing[dom] * 1e-3) / 1e9
         # HBM traffic per launch: two PMC passes (FETCH_SIZE, WRITE_SIZE) over this command, run now as children when rocprofv3 is there;
         # otherwise the last committed passes (profiles/traffic_latest.json, stamped with the commit they were taken at)
-        tjson = None if (args.no_profile or child) else profiled_traffic()
+        # (skipped when the kernel-trace child did not come back: a profiler that is broken on this box must not cost the run three time-outs)
+        tjson = None if (args.no_profile or child or prof is None) else profiled_traffic()
         if tjson is not None:
             traffic_source = "measured in this run: " + tjson.get("_source", "")
         else:
