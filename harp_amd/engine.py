@@ -857,7 +857,9 @@ class FitEngine:
                 self.schedule_row.copy_(row)             # ... nor consume a schedule row
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            # N > 1: other threads of the process (RCCL's proxy, torch's process-group watchdog) make HIP calls of their own while this
+            # thread captures; only this thread's calls belong to the capture
+            with torch.cuda.graph(g, capture_error_mode="thread_local" if dist_on else "global"):
                 fb()
                 self.allreduce()                         # no-op for a single rank; RCCL all-reduce is captured into the graph otherwise
                 self.adam(coarse, app, tick=False)
