@@ -117,3 +117,19 @@ def test_committed_frames_fixture_pins_load_img_and_erosion():
     rt = D.ResidentTargets(ds)
     assert np.array_equal(rt.y_true.numpy(), exp["rgb"]) and np.array_equal(rt.y_sil.numpy(), exp["mask"][..., 0])
     assert np.array_equal(rt.y_sil_col.numpy(), exp["eroded"]) and rt.fid.tolist() == list(range(6))
+
+
+def test_load_obj_uvs_reads_what_pytorch3d_load_obj_returns(tmp_path):
+    """utils/hand_model_utils.load_obj_uvs: `vt` lines -> verts_uvs, second index of every face corner -> faces.textures_idx
+    (what utils/hand_model_utils.py:58-60 takes from pytorch3d.io.load_obj); the template assets were built from the same fields"""
+    from harp_amd.utils.hand_model_utils import load_obj_uvs
+    p = tmp_path / "t.obj"
+    p.write_text("# tiny\nv 0 0 0\nv 1 0 0\nv 0 1 0\nv 1 1 0\nvt 0.0 0.0\nvt 1.0 0.0\nvt 0.0 1.0\nvt 1.0 1.0\nvt 0.5 0.5\n"
+                 "f 1/1 2/2 3/3\nf 2/2/1 4/5/1 3/3/1\n")
+    uv, f = load_obj_uvs(str(p))
+    assert uv.shape == (5, 2) and uv.dtype == torch.float32 and f.dtype == torch.int64
+    assert f.tolist() == [[0, 1, 2], [1, 4, 2]] and uv[4].tolist() == [0.5, 0.5]
+    (tmp_path / "q.obj").write_text("v 0 0 0\nvt 0 0\nf 1/1 1/1 1/1 1/1\n")
+    import pytest
+    with pytest.raises(ValueError):
+        load_obj_uvs(str(tmp_path / "q.obj"))

@@ -134,3 +134,17 @@ def test_epoch_loss_is_averaged_before_the_plateau_scheduler():
 def test_single_process_helpers_are_no_ops():
     from harp_amd.dist import dist_env, mean_over_ranks, ranks_identical
     assert dist_env() == (0, 1) and mean_over_ranks(0.25) == 0.25 and ranks_identical(torch.ones(3))
+
+
+def test_fit_entry_point_rejects_uneven_shards():
+    """optimize_hand_sequence validates the split before anything touches a device: items and the global batch must divide over the shards,
+    the shards over the ranks"""
+    from harp_amd.optimize_sequence import optimize_hand_sequence
+    cfg = {"model_type": "harp"}
+    ds = [None] * 8
+    for kw in (dict(world_size=3, rank=0), dict(world_size=2, rank=0, shards=3), dict(world_size=1, rank=0, shards=2, batch_size=3)):
+        kw.setdefault("batch_size", 4)
+        with pytest.raises(ValueError):
+            optimize_hand_sequence(cfg, {"pose": torch.zeros(8, 45)}, ds, None, None, None, **kw)
+    with pytest.raises(NotImplementedError):
+        optimize_hand_sequence({"model_type": "nimble"}, {}, ds, None, None, None)
