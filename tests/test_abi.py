@@ -47,7 +47,8 @@ def test_no_cpu_fallback(lib):
     from harp_amd import ops
     with pytest.raises(RuntimeError, match="no CPU path"):
         ops.rasterize_fwd(torch.zeros(1, 3, 3), torch.zeros(1, 3, dtype=torch.int32), 8)
-    assert lib.harp_rasterize_ws_bytes(2, 10, 64) == 2 * 10 * 64 + 2 * 10 * 16 + 2 * 1 * 10 * 4 + 3 * 256      # pure host arithmetic
+    # records | bboxes | lists | counts, order, nact (256 B each) | hit bitmaps (one 64-bit word per frame, super-tile and 64 faces)
+    assert lib.harp_rasterize_ws_bytes(2, 10, 64) == 2 * 10 * 64 + 2 * 10 * 16 + 2 * 1 * 10 * 4 + 3 * 256 + 2 * 1 * 1 * 8      # pure host arithmetic
     assert lib.harp_rasterize_fwd(None, None, 1, 1, 1, 8, 0, 0.0, 1.0, None, None, None, None, None) == 1   # HARP_ERR_ARG, no launch
 
 
