@@ -181,6 +181,4 @@ class HandFront(ctypes.Structure):
 
 
 SIGNATURES["harp_hand_front_fwd"] = (_i, [ctypes.POINTER(HandFront), _vp])
-SIGNATURES["harp_hand_front_head"] = (_i, [ctypes.POINTER(HandFront), _vp])
-SIGNATURES["harp_hand_front_tail"] = (_i, [ctypes.POINTER(HandFront), _vp])
 SIGNATURES["harp_hand_back_bwd"] = (_i, [ctypes.POINTER(HandFront), _vp, _vp, _vp])

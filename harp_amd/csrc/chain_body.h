@@ -135,10 +135,6 @@ __device__ __forceinline__ V3 project(V3 p, const float* r, const float* T, floa
 // Forward chain of frame b by one 1024-thread workgroup.  s_p: V*3 floats of LDS (first the subdivided mesh, then the displaced one).
 // verts_ready: s_p[0, V0*3) already holds the hand-layer vertices in metres and joints_m is written (fused front kernel);
 // cR / cT / lpos: this frame's camera rotation (9), translation (3) and light position (3) — global or LDS.
-// PHASE 0: everything.  PHASE 1: up to the displaced vertices and the camera-view projection (all the camera-view raster chain waits for).
-// PHASE 2: the rest — normals of the displaced mesh, centroid, light camera, light-view projection — for a workgroup that finds the
-// displaced vertices in global memory (hand_front.hip: the tail runs on the light view's stream, next to the camera-view set-up).
-template <int PHASE = 0>
 __device__ __forceinline__ void mesh_chain_fwd_body(const harp_mesh_chain& A, float* s_p, int b, bool verts_ready, const float* cR,
                                                     const float* cT, const float* lpos) {
   __shared__ float s_red3[16 * 3], s_tot3[3];
@@ -146,8 +142,6 @@ __device__ __forceinline__ void mesh_chain_fwd_body(const harp_mesh_chain& A, fl
   const int tid = threadIdx.x;
   const int V0 = A.V0, V = A.V0 + A.E0;
   const float half = 0.5f * (float)A.S;
-  V3 vd[kMaxPerThread];
-  if constexpr (PHASE != 2) {
   // ---- metres + SubdivideMeshes (edge midpoints appended after the originals)
   if (!verts_ready) {
     const float* src = A.verts_mm + (size_t)b * V0 * 3;
@@ -163,6 +157,7 @@ __device__ __forceinline__ void mesh_chain_fwd_body(const harp_mesh_chain& A, fl
   float* vs = A.vs + (size_t)b * V * 3;
   for (int i = tid; i < V * 3; i += kChainThreads) vs[i] = s_p[i];
   // ---- normals of the subdivided mesh + displacement along them (kept in registers until every thread has read its neighbours)
+  V3 vd[kMaxPerThread];
 #pragma unroll
   for (int j = 0; j < kMaxPerThread; ++j) {
     const int i = tid + j * kChainThreads;
@@ -174,10 +169,8 @@ __device__ __forceinline__ void mesh_chain_fwd_body(const harp_mesh_chain& A, fl
       A.il1[o] = inv;
       vd[j] = ld(s_p + 3 * i) + n * A.disp[i];
       st(A.vd + o * 3, vd[j]);
-      if (PHASE == 1) st(A.ndc_c + o * 3, project(vd[j], cR, cT, A.focal, half, half));
     }
   }
-  if constexpr (PHASE == 1) return;
   __syncthreads();
 #pragma unroll
   for (int j = 0; j < kMaxPerThread; ++j) {
@@ -185,16 +178,6 @@ __device__ __forceinline__ void mesh_chain_fwd_body(const harp_mesh_chain& A, fl
     if (i < V) st(s_p + 3 * i, vd[j]);
   }
   __syncthreads();
-  } else {
-    // PHASE 2: the displaced vertices come from global memory (written by the head kernel)
-    const float* src = A.vd + (size_t)b * V * 3;
-#pragma unroll
-    for (int j = 0; j < kMaxPerThread; ++j) {
-      const int i = tid + j * kChainThreads;
-      if (i < V) { vd[j] = ld(src + 3 * i); st(s_p + 3 * i, vd[j]); }
-    }
-    __syncthreads();
-  }
   // ---- normals of the displaced mesh, camera-view projection, centroid
   V3 csum = mk(0.f, 0.f, 0.f);
 #pragma unroll
@@ -206,7 +189,7 @@ __device__ __forceinline__ void mesh_chain_fwd_body(const harp_mesh_chain& A, fl
       const size_t o = (size_t)b * V + i;
       st(A.n2 + o * 3, n);
       A.il2[o] = inv;
-      if (PHASE == 0) st(A.ndc_c + o * 3, project(vd[j], cR, cT, A.focal, half, half));
+      st(A.ndc_c + o * 3, project(vd[j], cR, cT, A.focal, half, half));
       csum = csum + vd[j];
     }
   }

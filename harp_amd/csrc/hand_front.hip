@@ -19,9 +19,6 @@ namespace {
 using namespace lb;
 using cb::kChainThreads;
 
-// HEAD = true: stops after the displaced vertices and the camera-view projection (the camera-view raster chain starts then); the tail
-// kernel below (normals of the displaced mesh, centroid, light camera, light-view projection) runs on the light view's stream.
-template <bool HEAD>
 __global__ void __launch_bounds__(kChainThreads) hand_front_kernel(const harp_hand_front H) {
   extern __shared__ float s_dyn[];             // V*3 positions
   __shared__ float s_pose[48], s_beta[NB], s_tr[3], s_pm[NP], s_A[NJ * 12], s_cam[12], s_lpos[3];
@@ -183,22 +180,14 @@ __global__ void __launch_bounds__(kChainThreads) hand_front_kernel(const harp_ha
     A.joints_m[(size_t)b * 63 + tid] = jm * 1e-3f;
   }
   // ---- mesh chain (chain_body.h); its first statement after the (skipped) load is a barrier
-  if constexpr (HEAD) cb::mesh_chain_fwd_body<1>(A, s_p, b, true, s_cam, s_cam + 9, s_lpos);
-  else cb::mesh_chain_fwd_body<0>(A, s_p, b, true, s_cam, s_cam + 9, s_lpos);
-}
-
-__global__ void __launch_bounds__(kChainThreads) hand_front_tail_kernel(const harp_hand_front H) {
-  extern __shared__ float s_dyn[];             // V*3 displaced positions
-  const harp_mesh_chain& A = H.chain;
-  const int b = blockIdx.x;
-  cb::mesh_chain_fwd_body<2>(A, s_dyn, b, true, H.cam_R + 9 * b, H.cam_T + 3 * b, H.light_pos + 3 * b);
+  cb::mesh_chain_fwd_body(A, s_p, b, true, s_cam, s_cam + 9, s_lpos);
 }
 
 }  // namespace
 
 extern "C" {
 
-static int hand_front_check(const harp_hand_front* h) {
+int harp_hand_front_fwd(const harp_hand_front* h, hipStream_t stream) {
   if (!h) return HARP_ERR_ARG;
   const harp_mesh_chain& a = h->chain;
   if (!a.edges0 || !a.vf_off || !a.vf_tri || !a.disp || a.B <= 0 || a.V0 != NV || a.E0 < 0 || a.NJ != 21 ||
@@ -208,32 +197,8 @@ static int hand_front_check(const harp_hand_front* h) {
   if (!h->fid || !h->pose48 || !h->betas || !h->trans_b || !h->cam_R || !h->cam_T || !h->light_pos || !h->colors || !h->lbs_ws ||
       h->tables.wrist_pose)
     return HARP_ERR_ARG;
-  return HARP_OK;
-}
-
-int harp_hand_front_fwd(const harp_hand_front* h, hipStream_t stream) {
-  if (const int rc = hand_front_check(h)) return rc;
-  const harp_mesh_chain& a = h->chain;
   const size_t lds = (size_t)(a.V0 + a.E0) * 3 * sizeof(float);          // <= 48 KB (harp_mesh_chain_max_vertices)
-  hipLaunchKernelGGL(hand_front_kernel<false>, dim3(a.B), dim3(kChainThreads), lds, stream, *h);
-  HARP_CHECK_LAUNCH();
-  return HARP_OK;
-}
-
-int harp_hand_front_head(const harp_hand_front* h, hipStream_t stream) {
-  if (const int rc = hand_front_check(h)) return rc;
-  const harp_mesh_chain& a = h->chain;
-  const size_t lds = (size_t)(a.V0 + a.E0) * 3 * sizeof(float);
-  hipLaunchKernelGGL(hand_front_kernel<true>, dim3(a.B), dim3(kChainThreads), lds, stream, *h);
-  HARP_CHECK_LAUNCH();
-  return HARP_OK;
-}
-
-int harp_hand_front_tail(const harp_hand_front* h, hipStream_t stream) {
-  if (const int rc = hand_front_check(h)) return rc;
-  const harp_mesh_chain& a = h->chain;
-  const size_t lds = (size_t)(a.V0 + a.E0) * 3 * sizeof(float);
-  hipLaunchKernelGGL(hand_front_tail_kernel, dim3(a.B), dim3(kChainThreads), lds, stream, *h);
+  hipLaunchKernelGGL(hand_front_kernel, dim3(a.B), dim3(kChainThreads), lds, stream, *h);
   HARP_CHECK_LAUNCH();
   return HARP_OK;
 }

@@ -167,8 +167,6 @@ class FitEngine:
         self.fused_loss = True           # loss-only mode: photometric L1 formed inside the shader backward (no forward shading launch)
         self.graph_order = True
         self.mesh_third = True           # key-point / mesh regularisers on a third stream (their own graph branch) instead of in front of the light view: 0.755 vs 0.766 ms / step (a fourth branch for the parameter-only terms: 0.803 vs 0.753)
-        self.split_front = True          # hand_front as head (-> vd, camera projection) + tail (n2, centroid, light camera, light projection) on the light view's stream
-        self._front_tail = None
         self.fused_keep = True           # keep_image with the fused loss: the shader backward also writes y_pred (no forward shading launch either)
         self.keep_image = True           # shader forward writes the rendered image s["rgb"] (False: loss + gradient only)
         self.mesh_terms_first = True     # key-point term + mesh regularisers run before the light raster (under the raster set-up) instead of after it
@@ -292,13 +290,7 @@ class FitEngine:
         allows the one-launch form of the whole front (MANO path, csrc/hand_front.hip)."""
         L, s, p, st, tp = _lib.lib(), self.s, _lib.ptr, _lib.stream(), self.topo
         if front and self.fused_front and self.fused_chain:
-            if self.split_front:
-                # head only: the camera-view raster chain starts after the displaced vertices + camera projection; the tail (normals of
-                # the displaced mesh, centroid, light camera, light projection) is enqueued by the light view on ITS stream
-                self._front_tail = self._hand_struct(fid, B, shadow, False)
-                self._ck(L.harp_hand_front_head(ctypes.byref(self._front_tail), st), "hand_front_head")
-            else:
-                self._ck(L.harp_hand_front_fwd(ctypes.byref(self._hand_struct(fid, B, shadow, False)), st), "hand_front_fwd")
+            self._ck(L.harp_hand_front_fwd(ctypes.byref(self._hand_struct(fid, B, shadow, False)), st), "hand_front_fwd")
             return True
         self._ck(L.harp_frame_setup_fwd(ctypes.byref(self.tables), p(fid), B, self.S, self.focal, int(self.self_shadow), p(s["pose48"]),
                                         p(s["betas"]), p(s["trans_b"]), p(s["cam_R"]), p(s["cam_T"]), p(s["light_pos"]), p(s["colors"]), st),
@@ -448,9 +440,6 @@ class FitEngine:
             if not go:
                 third_branch()
             with torch.cuda.stream(side):
-                if self._front_tail is not None:
-                    self._ck(L.harp_hand_front_tail(ctypes.byref(self._front_tail), ST()), "hand_front_tail")
-                    self._front_tail = None
                 if sched_early and self.mesh_terms_first and not mesh_on_third:
                     mesh_terms()
                 if shadow:
@@ -849,7 +838,7 @@ class FitEngine:
         # every switch the enqueued launch sequence depends on is part of the key: flipping one re-captures instead of replaying a
         # graph recorded for another configuration
         gkey = (coarse, app, scheduled, self.keep_image, self.fused_loss, self.self_shadow, tuple(self.frozen), self.overlap, self.early_terms,
-                self.packed_texels, self.fused_keep, self.mesh_third, self.graph_order, self.auto_draw, self.mesh_terms_first, self.camera_first, self.tail_side, self.fused_bwd, self.fused_chain, self.fused_front, self.fused_back, self.split_front, dist_on, self.overlap_allreduce,
+                self.packed_texels, self.fused_keep, self.mesh_third, self.graph_order, self.auto_draw, self.mesh_terms_first, self.camera_first, self.tail_side, self.fused_bwd, self.fused_chain, self.fused_front, self.fused_back, dist_on, self.overlap_allreduce,
                 self.comm is not None, self.perceptual is not None and app)
         g = self._graphs.get(gkey)
         if g is None:

@@ -363,13 +363,6 @@ typedef struct harp_hand_front {
   int self_shadow;           /* colours from amb_ratio (shadow renderer) or the fixed Phong lights */
 } harp_hand_front;
 int harp_hand_front_fwd(const harp_hand_front* h, hipStream_t stream);
-/* The same as TWO launches for callers that overlap the two views (round 4): _head = everything up to the displaced vertices chain.vd and
- * the camera-view projection chain.ndc_c — what the camera-view rasteriser set-up (renderer_helper.py:353) waits for; _tail = the rest
- * (vertex normals of the displaced mesh chain.n2 / il2 for the shader, centroid, light camera, light-view projection chain.ndc_l:
- * renderer_helper.py:344, 454-468, 495), which reads chain.vd back and may run on another stream, e.g. the light view's.
- * _head followed by _tail writes exactly what harp_hand_front_fwd writes. */
-int harp_hand_front_head(const harp_hand_front* h, hipStream_t stream);
-int harp_hand_front_tail(const harp_hand_front* h, hipStream_t stream);
 /* The counterpart for the backward tail of a step (csrc/hand_back.hip): harp_mesh_chain_bwd + harp_lbs_mano_bwd + harp_frame_setup_bwd
  * (autograd of utils/visualize.py:16-88 / manopth/manolayer.py:108-296 down to the rows params[...][fid]) as THREE launches instead of
  * six: mesh chain + joint split + per-vertex skinning backward + trans / cam / light scatter per frame, the two vertex reductions, the
