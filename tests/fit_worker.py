@@ -18,6 +18,7 @@ sys.path.insert(0, ROOT)
 
 def main():
     out, shards = sys.argv[1], int(sys.argv[2])
+    batch = int(sys.argv[3]) if len(sys.argv) > 3 else 4
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     rccl = os.environ.get("HARP_WORKER_RCCL") == "1"
     local = int(os.environ.get("LOCAL_RANK", "0")) if rccl else 0
@@ -51,7 +52,7 @@ def main():
     # global batch 4 = 2 frames of each of the 2 shards per step, 2 steps per epoch; patience 0 + a threshold no epoch can meet: the
     # coarse learning rate decays after the second epoch — driven by the epoch loss every rank must agree on
     params = optimize_hand_sequence(cfg, sc["seq"], ds, None, None, layer, torch.from_numpy(sc["tpl"]["verts_uvs"])[None],
-                                    torch.from_numpy(sc["tpl"]["faces_uvs"])[None], device=device, uv_mask=sc["uv_mask"], batch_size=4,
+                                    torch.from_numpy(sc["tpl"]["faces_uvs"])[None], device=device, uv_mask=sc["uv_mask"], batch_size=batch,
                                     log_fn=log, shards=shards, plateau_patience=0, plateau_threshold=0.5)
     eng = engs[0]
     o, n = eng.opt_span

@@ -128,11 +128,11 @@ def test_rccl_allreduce_c_abi_and_graph_capture():
         comm.allreduce(y)
 
 
-def _assert_fit_equals_global_batch(two, one):
+def _assert_fit_equals_global_batch(two, one, batch=4):
     """parameters of the N-rank fit against the 1-rank fit that walks the same global batches (shards = N)"""
     assert two["identical"], "parameters / Adam moments differ between ranks"
     assert two["wrote_by_rank"] == [True] + [False] * (two["world"] - 1)            # rank-0 checkpoint only
-    assert two["batch"] * two["world"] == one["batch"] == 4 and two["rows"] * two["world"] == one["rows"] == 8      # a rank keeps only its shard resident
+    assert two["batch"] * two["world"] == one["batch"] == batch and two["rows"] * two["world"] == one["rows"] == 8      # a rank keeps only its shard resident
     h2, h1 = two["hist"], one["hist"]
     assert [h[0] for h in h2] == [0, 1, 2, 3]
     assert [h[2:] for h in h2] == [h[2:] for h in h1]                               # the same learning rates after every epoch ...
@@ -146,6 +146,9 @@ def _assert_fit_equals_global_batch(two, one):
         d = (p2[o:o + n] - p1[o:o + n]).abs()
         worst[k] = (d.mean().item(), d.max().item(), (d > 1e-3).double().mean().item())
         # 8 Adam steps (first steps are sign-like): bound the mean and the outlier fraction like the single-GPU tests
+        if n < 64:      # a few scalars (amb_ratio, the shared light position: differences of nearly equal gradient sums, so their first Adam steps follow a noisy sign)
+            assert d.max() < 1e-3, (k, worst[k])
+            continue
         assert d.mean() < 1e-5 and (d > 1e-3).double().mean() < max(2e-4, 4.0 / n), (k, worst[k])      # measured on MI355X: mean <= 2e-7, outliers <= 2e-5
     print("data-parallel fit vs global-batch fit, |dp| mean / max / fraction > 1e-3:", worst)
 
@@ -158,6 +161,15 @@ def test_data_parallel_fit_two_ranks_equal_global_batch_fit(tmp_path):
     one = _launch(1, str(tmp_path / "f1.pt"), 0, worker="fit_worker.py", args=[2])
     assert two["transport"] == "gloo" and two["comm"] == "NoneType" and one["graphs"] >= 3
     _assert_fit_equals_global_batch(two, one)
+
+
+@pytest.mark.timeout(1800)
+def test_data_parallel_fit_with_a_ragged_last_batch(tmp_path):
+    """global batch 6 over 8 items in 2 shards: every epoch is a full step (3 frames per shard) and a ragged one (1 frame per shard, eager
+    on every rank) — ranks stay in lock-step (same number of steps, same batch sizes) and equal the 1-rank fit over the same global batches"""
+    two = _launch(2, str(tmp_path / "g2.pt"), 0, worker="fit_worker.py", args=[2, 6])
+    one = _launch(1, str(tmp_path / "g1.pt"), 0, worker="fit_worker.py", args=[2, 6])
+    _assert_fit_equals_global_batch(two, one, batch=6)
 
 
 @pytest.mark.timeout(1800)
