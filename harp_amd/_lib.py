@@ -67,6 +67,7 @@ class ShadeArgs(ctypes.Structure):
 
 SIGNATURES.update({
     "harp_depth_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "harp_depth_bwd_consume": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "harp_shade_fwd": (_i, [ctypes.POINTER(ShadeArgs), _vp]),
     "harp_shade_bwd": (_i, [ctypes.POINTER(ShadeArgs), _vp]),
     "harp_pack_texels": (_i, [_vp, _vp, _i, _vp, _vp]),

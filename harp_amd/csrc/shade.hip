@@ -594,8 +594,13 @@ __global__ void pack_texels_kernel(const float* __restrict__ tex, const float* _
 
 // zbuf backward of a K=1 pass (used for the light-view depth map the shadow test gathers from):
 // zbuf = sum_i bary_i z_i  ->  g on the face's NDC vertices (rasterize_meshes_backward, grad_zbuf path).
+// CONSUME: the pass also CLEARS every non-zero entry of g_z it reads.  In a fitting step g_z is the shadow-map gradient image the shader
+// backward scatters into: non-zero only at light-view pixels that hold a face (an empty texel reads depth -1, whose shadow-test sigmoid
+// and gradient are exactly 0), i.e. only inside the tiles this kernel visits — so the image is all-zero again when the kernel is done and
+// the 33.5-MB clear of every step (B x 512 x 512 floats) goes away.
+template <bool CONSUME>
 __global__ void __launch_bounds__(256) depth_bwd_kernel(const int32_t* __restrict__ face_id, const FaceRec* __restrict__ recs,
-                                                        const int32_t* __restrict__ faces, const float* __restrict__ g_z,
+                                                        const int32_t* __restrict__ faces, float* __restrict__ g_z,
                                                         int V, int F, int S, float* __restrict__ g_ndc,
                                                         const int32_t* __restrict__ order, const int32_t* __restrict__ nact,
                                                         int B, int nsx) {
@@ -617,6 +622,7 @@ __global__ void __launch_bounds__(256) depth_bwd_kernel(const int32_t* __restric
   // chain of such trips: 81 -> 70 us at 1024^2); the 4 bytes per pixel read for nothing in tiles without faces do not show
   const int f = in_img ? face_id[o] : -1;
   const float g = in_img ? g_z[o] : 0.f;
+  if (CONSUME && g != 0.f) g_z[o] = 0.f;
   const bool act = f >= 0 && g != 0.f;
   if (__syncthreads_or(act ? 1 : 0) == 0) continue;
   s_acc.clear();
@@ -723,7 +729,18 @@ int harp_depth_bwd(const int32_t* face_id, const void* ws, const int32_t* faces,
                    float* g_ndc, hipStream_t stream) {
   if (!face_id || !ws || !faces || !g_z || !g_ndc) return HARP_ERR_ARG;
   const RasterWs W = raster_ws_split((void*)ws, B, F, S);
-  hipLaunchKernelGGL(depth_bwd_kernel, dim3(min(tile_grid(B, W.nsx), 4096u)), dim3(256), 0, stream, face_id, (const FaceRec*)ws, faces, g_z, V, F, S, g_ndc,
+  hipLaunchKernelGGL(depth_bwd_kernel<false>, dim3(min(tile_grid(B, W.nsx), 4096u)), dim3(256), 0, stream, face_id, (const FaceRec*)ws, faces, (float*)g_z, V, F, S,
+                     g_ndc, (const int32_t*)W.order, (const int32_t*)W.nact, B, W.nsx);
+  HARP_CHECK_LAUNCH();
+  return HARP_OK;
+}
+
+// the same, and g_z is all-zero again afterwards (see depth_bwd_kernel<CONSUME>): for callers that keep ONE gradient image across steps
+int harp_depth_bwd_consume(const int32_t* face_id, const void* ws, const int32_t* faces, float* g_z, int B, int V, int F, int S,
+                           float* g_ndc, hipStream_t stream) {
+  if (!face_id || !ws || !faces || !g_z || !g_ndc) return HARP_ERR_ARG;
+  const RasterWs W = raster_ws_split((void*)ws, B, F, S);
+  hipLaunchKernelGGL(depth_bwd_kernel<true>, dim3(min(tile_grid(B, W.nsx), 4096u)), dim3(256), 0, stream, face_id, (const FaceRec*)ws, faces, g_z, V, F, S, g_ndc,
                      (const int32_t*)W.order, (const int32_t*)W.nact, B, W.nsx);
   HARP_CHECK_LAUNCH();
   return HARP_OK;

@@ -167,6 +167,7 @@ class FitEngine:
         self.fused_loss = True           # loss-only mode: photometric L1 formed inside the shader backward (no forward shading launch)
         self.graph_order = True
         self.mesh_third = True           # key-point / mesh regularisers on a third stream (their own graph branch) instead of in front of the light view: 0.755 vs 0.766 ms / step (a fourth branch for the parameter-only terms: 0.803 vs 0.753)
+        self.consume_gzl = True          # the depth backward clears the shadow-map gradient entries it consumes: no per-step clear of that image (33.5 MB at B = 32, 512^2)
         self.fused_keep = True           # keep_image with the fused loss: the shader backward also writes y_pred (no forward shading launch either)
         self.keep_image = True           # shader forward writes the rendered image s["rgb"] (False: loss + gradient only)
         self.mesh_terms_first = True     # key-point term + mesh regularisers run before the light raster (under the raster set-up) instead of after it
@@ -385,7 +386,8 @@ class FitEngine:
                 self.gs_zero[:-16].zero_()               # everything but the loss vector (last 16 floats of the slab)
                 if not mesh_on_third:
                     self.gs_mesh.zero_()
-            self.gs_zero_late.zero_()
+            if not self.consume_gzl:
+                self.gs_zero_late.zero_()
             if tick:
                 self._adam_tick(coarse, app)             # only touches the hyper-parameter block: off the serial tail of the step
             if app and shared_terms:
@@ -540,7 +542,8 @@ class FitEngine:
                 else:
                     maps_tail()
             if self.self_shadow:
-                self._ck(L.harp_depth_bwd(p(s["face_l"]), p(s["ws_l"]), p(tp.faces), p(s["g_zl"]), B, V, F, S, p(s["g_ndc_l"]), ST()), "depth_bwd")
+                depth_bwd = L.harp_depth_bwd_consume if self.consume_gzl else L.harp_depth_bwd
+                self._ck(depth_bwd(p(s["face_l"]), p(s["ws_l"]), p(tp.faces), p(s["g_zl"]), B, V, F, S, p(s["g_ndc_l"]), ST()), "depth_bwd")
                 if not fused:
                     self._ck(L.harp_project_bwd(p(s["vd"]), p(s["light_R"]), p(s["light_T"]), p(s["g_ndc_l"]), B, V, self.focal, S, p(s["g_vd"]),
                                                 p(s["g_light_R"]), p(s["g_light_T"]), ST()), "project_bwd_l")
@@ -838,7 +841,7 @@ class FitEngine:
         # every switch the enqueued launch sequence depends on is part of the key: flipping one re-captures instead of replaying a
         # graph recorded for another configuration
         gkey = (coarse, app, scheduled, self.keep_image, self.fused_loss, self.self_shadow, tuple(self.frozen), self.overlap, self.early_terms,
-                self.packed_texels, self.fused_keep, self.mesh_third, self.graph_order, self.auto_draw, self.mesh_terms_first, self.camera_first, self.tail_side, self.fused_bwd, self.fused_chain, self.fused_front, self.fused_back, dist_on, self.overlap_allreduce,
+                self.packed_texels, self.fused_keep, self.mesh_third, self.graph_order, self.auto_draw, self.mesh_terms_first, self.camera_first, self.tail_side, self.fused_bwd, self.fused_chain, self.fused_front, self.fused_back, self.consume_gzl, dist_on, self.overlap_allreduce,
                 self.comm is not None, self.perceptual is not None and app)
         g = self._graphs.get(gkey)
         if g is None:

@@ -52,6 +52,12 @@ int harp_silhouette_bwd(const int32_t* faces, int B, int V, int F, int S, float 
 /* replaces _C.rasterize_meshes_backward (grad_zbuf path) for a K=1 pass: g_z (B,S,S) -> g_ndc (B,V,3) (+=) */
 int harp_depth_bwd(const int32_t* face_id, const void* ws, const int32_t* faces, const float* g_z, int B, int V, int F, int S,
                    float* g_ndc, hipStream_t stream);
+/* the same for a caller that keeps ONE gradient image g_z across steps (the fitting loop: harp_shade_bwd scatters the shadow test's tap
+ * gradients of renderer_helper.py:385-408 into it): every non-zero entry read is also cleared.  The shader only ever writes at light-view
+ * pixels that hold a face (an empty texel's depth -1 gives a shadow-test sigmoid of exactly 0), all of which this pass visits, so an
+ * image that was all-zero before the step's harp_shade_bwd is all-zero again after this call and needs no per-step clear. */
+int harp_depth_bwd_consume(const int32_t* face_id, const void* ws, const int32_t* faces, float* g_z, int B, int V, int F, int S,
+                           float* g_ndc, hipStream_t stream);
 
 /* ---- fragment-level rasterisation (the PyTorch3D op pair itself; NOT on the fitting loop's path) -----------------------------
  * replaces _C.rasterize_meshes(face_verts, mesh_to_face_first_idx, num_faces_per_mesh, clipped_faces_neighbor_idx, image_size,

@@ -1058,7 +1058,7 @@ def test_light_camera_incl_look_at_replacement_branch():
 @pytest.mark.parametrize("switches", [dict(graph_order=False), dict(mesh_third=False), dict(camera_first=False), dict(overlap=False),
                                       dict(graph_order=False, mesh_third=False), dict(mesh_third=False, camera_first=False),
                                       dict(graph_order=False, mesh_third=False, camera_first=False), dict(early_terms=False),
-                                      dict(mesh_terms_first=False, mesh_third=False), dict(tail_side=True)])
+                                      dict(mesh_terms_first=False, mesh_third=False), dict(tail_side=True), dict(consume_gzl=False)])
 def test_schedule_switches_give_the_default_schedules_result(switches):
     """The stream / capture-order switches of FitEngine (graph_order, mesh_third, camera_first, overlap, early_terms, mesh_terms_first,
     tail_side) only move launches between streams: losses and the whole gradient arena of every non-default combination must equal the
@@ -1080,6 +1080,9 @@ def test_schedule_switches_give_the_default_schedules_result(switches):
         torch.cuda.synchronize()
         return eng.g_buf.double().clone(), eng.loss_vec[:9].double().clone()
     ref = {g: run(g) for g in (False, True)}
+    # the shadow-map gradient image is all-zero again after a step: the depth backward clears what it consumes (harp_depth_bwd_consume),
+    # which is what lets the default schedule go without the per-step clear of that image
+    assert eng.consume_gzl and eng.s["g_zl"].abs().max().item() == 0.0
     defaults = {k: getattr(eng, k) for k in switches}
     for k, v in switches.items():
         setattr(eng, k, v)
