@@ -158,6 +158,7 @@ SIGNATURES["harp_mesh_chain_max_vertices"] = (_i, [])
 SIGNATURES["harp_mesh_chain_fwd"] = (_i, [ctypes.POINTER(MeshChain), _vp])
 SIGNATURES["harp_mesh_chain_bwd"] = (_i, [ctypes.POINTER(MeshChain), _vp])
 SIGNATURES["harp_draw_texture_offsets"] = (_i, [ctypes.c_uint, _vp, _i, _i, _f, _vp, _f, _vp, _vp])
+SIGNATURES["harp_rasterize_fwd_keep"] = (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp])
 SIGNATURES["harp_rasterize_l1_fwd"] = (_i, [_vp, _vp, _i, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp])
 
 # data-parallel exchange (csrc/comm.hip): RCCL bound at run time, all-reduce enqueued on the caller's stream

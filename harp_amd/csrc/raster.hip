@@ -123,11 +123,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE =
                                                      int V, float* __restrict__ g_ndc, const float* __restrict__ l1_target,
                                                      const int32_t* __restrict__ l1_fid, const float* __restrict__ l1_w,
                                                      float* __restrict__ l1_loss, float* __restrict__ l1_grad, float l1_inv, int sparse,
-                                                     const float* __restrict__ l1_bg_sums) {
+                                                     const float* __restrict__ l1_bg_sums, int32_t* __restrict__ st_state) {
   __shared__ rb::RasterSmem<MODE> sm;
   if constexpr (!LOOP) {
     rb::raster_tile<MODE>(sm, blockIdx.x, recs, bbs, bins, bin_count, order, nact, B, F, S, nsx, blur, sigma, face_id, zbuf, alpha, g_alpha, faces, V, g_ndc,
-                          l1_target, l1_fid, l1_w, l1_loss, l1_grad, l1_inv, sparse, l1_bg_sums);
+                          l1_target, l1_fid, l1_w, l1_loss, l1_grad, l1_inv, sparse, l1_bg_sums, st_state);
     return;
   }
   // LOOP (grids above 64 k workgroups, i.e. 1024^2 and up): the grid is capped at kRasterGrid workgroups (a multiple of 8, so a workgroup's tiles stay on its XCD) and a workgroup strides over
@@ -142,7 +142,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE =
   for (unsigned v = blockIdx.x; v < limit; v += gridDim.x) {
     if (v != blockIdx.x) __syncthreads();                 // LDS of the previous tile
     rb::raster_tile<MODE>(sm, v, recs, bbs, bins, bin_count, order, nact, B, F, S, nsx, blur, sigma, face_id, zbuf, alpha, g_alpha, faces, V, g_ndc,
-                          l1_target, l1_fid, l1_w, l1_loss, l1_grad, l1_inv, sparse, l1_bg_sums);
+                          l1_target, l1_fid, l1_w, l1_loss, l1_grad, l1_inv, sparse, l1_bg_sums, st_state);
   }
   if (bg_table) {
     // slots below `limit` (nact rounded up to 8) already went through raster_tile, whose sub == 0 workgroup adds the table value of an
@@ -210,10 +210,10 @@ size_t harp_rasterize_ws_bytes(int B, int F, int S) {
 //   ws: harp_rasterize_ws_bytes() bytes, 256-B aligned; must stay untouched until the matching backward ran.
 // Same, with the silhouette L1 loss fused into the camera-view raster epilogue (soft != 0): loss (+=) mean |alpha - y_sil[fid]|,
 // g_alpha = w * d loss / d alpha.  y_sil == NULL: plain rasterisation.
-int harp_rasterize_l1_fwd(const float* ndc, const int32_t* faces, int B, int V, int F, int S, int soft, float blur_radius,
+static int rasterize_impl(const float* ndc, const int32_t* faces, int B, int V, int F, int S, int soft, float blur_radius,
                           float sigma, void* ws, int32_t* face_id, float* zbuf, float* alpha, const float* l1_target,
                           const int32_t* l1_fid, const float* l1_w, float* l1_loss, float* l1_grad, const float* l1_bg_sums,
-                          hipStream_t stream) {
+                          int32_t* st_state, hipStream_t stream) {
   if (!ndc || !faces || !ws || !face_id || B <= 0 || F <= 0 || S <= 0 || ((soft & 1) && !alpha)) return HARP_ERR_ARG;
   if (l1_target && (!(soft & 1) || !l1_fid || !l1_w || !l1_loss || !l1_grad)) return HARP_ERR_ARG;
   const RasterWs W = raster_ws_split(ws, B, F, S);
@@ -229,23 +229,41 @@ int harp_rasterize_l1_fwd(const float* ndc, const int32_t* faces, int B, int V, 
 #define HARP_RASTER_LAUNCH(MODE, LOOP, ...) hipLaunchKernelGGL((raster_kernel<MODE, LOOP>), grid, dim3(256), 0, stream, __VA_ARGS__)
   if (soft & 1) {
     if (loop) HARP_RASTER_LAUNCH(1, true, recs, bbs, bins, cnt, order, W.nact, B, F, S, nsx, blur_radius, sigma, face_id, zbuf, alpha, nullptr, nullptr, 0, nullptr,
-                                 l1_target, l1_fid, l1_w, l1_loss, l1_grad, l1_inv, sp, l1_bg_sums);
+                                 l1_target, l1_fid, l1_w, l1_loss, l1_grad, l1_inv, sp, l1_bg_sums, nullptr);
     else HARP_RASTER_LAUNCH(1, false, recs, bbs, bins, cnt, order, W.nact, B, F, S, nsx, blur_radius, sigma, face_id, zbuf, alpha, nullptr, nullptr, 0, nullptr,
-                            l1_target, l1_fid, l1_w, l1_loss, l1_grad, l1_inv, sp, l1_bg_sums);
+                            l1_target, l1_fid, l1_w, l1_loss, l1_grad, l1_inv, sp, l1_bg_sums, nullptr);
   } else {
     if (loop) HARP_RASTER_LAUNCH(0, true, recs, bbs, bins, cnt, order, W.nact, B, F, S, nsx, 0.f, 1.f, face_id, zbuf, nullptr, nullptr, nullptr, 0, nullptr, nullptr,
-                                 nullptr, nullptr, nullptr, nullptr, 0.f, sp, nullptr);
+                                 nullptr, nullptr, nullptr, nullptr, 0.f, sp, nullptr, st_state);
     else HARP_RASTER_LAUNCH(0, false, recs, bbs, bins, cnt, order, W.nact, B, F, S, nsx, 0.f, 1.f, face_id, zbuf, nullptr, nullptr, nullptr, 0, nullptr, nullptr,
-                            nullptr, nullptr, nullptr, nullptr, 0.f, sp, nullptr);
+                            nullptr, nullptr, nullptr, nullptr, 0.f, sp, nullptr, st_state);
   }
   HARP_CHECK_LAUNCH();
   return HARP_OK;
 }
 
+int harp_rasterize_l1_fwd(const float* ndc, const int32_t* faces, int B, int V, int F, int S, int soft, float blur_radius,
+                          float sigma, void* ws, int32_t* face_id, float* zbuf, float* alpha, const float* l1_target,
+                          const int32_t* l1_fid, const float* l1_w, float* l1_loss, float* l1_grad, const float* l1_bg_sums,
+                          hipStream_t stream) {
+  return rasterize_impl(ndc, faces, B, V, F, S, soft, blur_radius, sigma, ws, face_id, zbuf, alpha, l1_target, l1_fid, l1_w, l1_loss, l1_grad,
+                        l1_bg_sums, nullptr, stream);
+}
+
 int harp_rasterize_fwd(const float* ndc, const int32_t* faces, int B, int V, int F, int S, int soft, float blur_radius,
                        float sigma, void* ws, int32_t* face_id, float* zbuf, float* alpha, hipStream_t stream) {
-  return harp_rasterize_l1_fwd(ndc, faces, B, V, F, S, soft, blur_radius, sigma, ws, face_id, zbuf, alpha, nullptr, nullptr, nullptr,
-                               nullptr, nullptr, nullptr, stream);
+  return rasterize_impl(ndc, faces, B, V, F, S, soft, blur_radius, sigma, ws, face_id, zbuf, alpha, nullptr, nullptr, nullptr,
+                        nullptr, nullptr, nullptr, nullptr, stream);
+}
+
+// K = 1 depth pass into a depth map the caller KEEPS between calls: st_state (B * nsx * nsx ints, zero before the first call, owned by
+// the library afterwards) records which super-tiles hold -1 everywhere; with sparse outputs (sparse != 0: face ids of empty super-tiles
+// are not written) a super-tile that is empty AGAIN is then not touched at all.  zbuf must not be written by anyone else between calls.
+int harp_rasterize_fwd_keep(const float* ndc, const int32_t* faces, int B, int V, int F, int S, int sparse, void* ws, int32_t* face_id,
+                            float* zbuf, int32_t* st_state, hipStream_t stream) {
+  if (!zbuf || !st_state) return HARP_ERR_ARG;
+  return rasterize_impl(ndc, faces, B, V, F, S, sparse ? 2 : 0, 0.f, 1.f, ws, face_id, zbuf, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                        nullptr, st_state, stream);
 }
 
 // Soft-silhouette backward: g_alpha (B,S,S) -> accumulates (atomicAdd) into g_ndc (B,V,3) (x,y components).
@@ -260,9 +278,9 @@ int harp_silhouette_bwd(const int32_t* faces, int B, int V, int F, int S, float 
   const bool loop = lgrid != 0u;
   const dim3 grid(loop ? lgrid : tile_grid(B, nsx));
   if (loop) HARP_RASTER_LAUNCH(2, true, recs, bbs, bins, cnt, order, W.nact, B, F, S, nsx, blur_radius, sigma, nullptr, nullptr, (float*)alpha, g_alpha, faces, V, g_ndc,
-                               nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0, nullptr);
+                               nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0, nullptr, nullptr);
   else HARP_RASTER_LAUNCH(2, false, recs, bbs, bins, cnt, order, W.nact, B, F, S, nsx, blur_radius, sigma, nullptr, nullptr, (float*)alpha, g_alpha, faces, V, g_ndc,
-                          nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0, nullptr);
+                          nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0, nullptr, nullptr);
   HARP_CHECK_LAUNCH();
   return HARP_OK;
 }

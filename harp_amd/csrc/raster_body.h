@@ -107,7 +107,7 @@ __device__ __forceinline__ void raster_tile(RasterSmem<MODE>& sm, unsigned vbloc
                                                      int V, float* __restrict__ g_ndc, const float* __restrict__ l1_target,
                                                      const int32_t* __restrict__ l1_fid, const float* __restrict__ l1_w,
                                                      float* __restrict__ l1_loss, float* __restrict__ l1_grad, float l1_inv, int sparse,
-                                                     const float* __restrict__ l1_bg_sums) {
+                                                     const float* __restrict__ l1_bg_sums, int32_t* __restrict__ st_state = nullptr) {
   auto& s_a = sm.s_a; auto& s_b = sm.s_b; auto& s_bb = sm.s_bb; auto& s_z2 = sm.s_z2; auto& s_fc = sm.s_fc; auto& s_id = sm.s_id;
   auto& s_g = sm.s_g;
   int* lds_cnt = sm.lds_cnt;
@@ -119,6 +119,9 @@ __device__ __forceinline__ void raster_tile(RasterSmem<MODE>& sm, unsigned vbloc
     // super-tile without a single face.  Backward: nothing to do.  Forward: its first workgroup writes the empty-pixel outputs (and
     // the fused silhouette L1 against alpha = 0) for all 64x64 pixels, the other 15 leave at once.
     if (MODE == 2 || sub != 0) return;
+    // depth pass of a caller that keeps ONE depth map across calls (st_state, harp_rasterize_fwd_keep): a super-tile that was empty — and
+    // therefore filled with -1 — the last time as well is left alone; 3/4 of the map are such super-tiles (25 MB of writes per step)
+    if (MODE == 0 && sparse && st_state && st_state[b * nst_of(nsx) + st] == 1) return;
     if (MODE == 1 && sparse && l1_target && l1_bg_sums) {
       // nothing to write, and the loss of an un-rendered super-tile against a static target is a constant: one table look-up
       if (threadIdx.x == 0) {
@@ -158,9 +161,11 @@ __device__ __forceinline__ void raster_tile(RasterSmem<MODE>& sm, unsigned vbloc
       const float sum = block_sum_256(acc, sm.red);
       if (threadIdx.x == 0 && sum != 0.f) atomicAdd(l1_loss, sum * l1_inv);
     }
+    if (MODE == 0 && st_state && threadIdx.x == 0) st_state[b * nst_of(nsx) + st] = 1;               // all -1 from now on
     return;
   }
   const int nst = nsx * nsx;
+  if (MODE == 0 && st_state && sub == 0 && threadIdx.x == 0) st_state[b * nst + st] = 0;               // holds depths: to be cleared when it empties
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int xi = tx0 + (lane & 15), yi = ty0 + w * 4 + (lane >> 4);
   const bool in_img = (xi < S) && (yi < S);

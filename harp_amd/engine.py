@@ -167,6 +167,7 @@ class FitEngine:
         self.fused_loss = True           # loss-only mode: photometric L1 formed inside the shader backward (no forward shading launch)
         self.graph_order = True
         self.mesh_third = True           # key-point / mesh regularisers on a third stream (their own graph branch) instead of in front of the light view: 0.755 vs 0.766 ms / step (a fourth branch for the parameter-only terms: 0.803 vs 0.753)
+        self.keep_depth = True           # light-view depth map kept across steps (harp_rasterize_fwd_keep): empty super-tiles are filled with -1 once, not every step (25 MB)
         self.consume_gzl = True          # the depth backward clears the shadow-map gradient entries it consumes: no per-step clear of that image (33.5 MB at B = 32, 512^2)
         self.fused_keep = True           # keep_image with the fused loss: the shader backward also writes y_pred (no forward shading launch either)
         self.keep_image = True           # shader forward writes the rendered image s["rgb"] (False: loss + gradient only)
@@ -203,6 +204,7 @@ class FitEngine:
         s["face_c"] = torch.empty(B, S, S, dtype=torch.int32, device=dev)
         s["face_l"] = torch.empty(B, S, S, dtype=torch.int32, device=dev)
         s["alpha"], s["zl"], s["rgb"] = f(B, S, S), f(B, S, S), f(B, S, S, 3)
+        s["zl_state"] = torch.zeros(B * ((S + 63) // 64) ** 2, dtype=torch.int32, device=dev)     # harp_rasterize_fwd_keep: which super-tiles of zl are all -1
         s["nmap_n"] = self.nmap_n
         # gradients (zeroed every step in ONE memset: they are carved from one flat buffer)
         gspec = [("g_alpha", (B, S, S)), ("g_rgb", (B, S, S, 3)), ("g_zl", (B, S, S)), ("g_vd", (B, V, 3)), ("g_joints_m", (B, NJo, 3)), ("g_n2", (B, V, 3)),
@@ -450,9 +452,13 @@ class FitEngine:
                         self._ck(L.harp_light_setup_fwd(p(s["centroid"]), p(s["light_pos"]), B, p(s["light_R"]), p(s["light_T"]), ST()), "light_setup")
                         self._ck(L.harp_project_fwd(p(s["vd"]), p(s["light_R"]), p(s["light_T"]), B, V, self.focal, S / 2.0, S / 2.0, S, p(s["ndc_l"]), ST()),
                                  "project_l")
-                    self._ck(L.harp_rasterize_fwd(p(s["ndc_l"]), p(tp.faces), B, V, F, S, 0 if self.keep_image else 2, 0.0, 1.0, p(s["ws_l"]), p(s["face_l"]),
-                                                  p(s["zl"]), None, ST()),
-                             "raster_light")
+                    if self.keep_depth:      # the light depth map lives across steps: super-tiles that stay empty are not filled with -1 again
+                        self._ck(L.harp_rasterize_fwd_keep(p(s["ndc_l"]), p(tp.faces), B, V, F, S, 0 if self.keep_image else 1, p(s["ws_l"]), p(s["face_l"]),
+                                                           p(s["zl"]), p(s["zl_state"]), ST()), "raster_light")
+                    else:
+                        self._ck(L.harp_rasterize_fwd(p(s["ndc_l"]), p(tp.faces), B, V, F, S, 0 if self.keep_image else 2, 0.0, 1.0, p(s["ws_l"]), p(s["face_l"]),
+                                                      p(s["zl"]), None, ST()),
+                                 "raster_light")
                 if sched_early and not self.mesh_terms_first and not mesh_on_third:
                     mesh_terms()
             if go:
@@ -841,7 +847,7 @@ class FitEngine:
         # every switch the enqueued launch sequence depends on is part of the key: flipping one re-captures instead of replaying a
         # graph recorded for another configuration
         gkey = (coarse, app, scheduled, self.keep_image, self.fused_loss, self.self_shadow, tuple(self.frozen), self.overlap, self.early_terms,
-                self.packed_texels, self.fused_keep, self.mesh_third, self.graph_order, self.auto_draw, self.mesh_terms_first, self.camera_first, self.tail_side, self.fused_bwd, self.fused_chain, self.fused_front, self.fused_back, self.consume_gzl, dist_on, self.overlap_allreduce,
+                self.packed_texels, self.fused_keep, self.mesh_third, self.graph_order, self.auto_draw, self.mesh_terms_first, self.camera_first, self.tail_side, self.fused_bwd, self.fused_chain, self.fused_front, self.fused_back, self.consume_gzl, self.keep_depth, dist_on, self.overlap_allreduce,
                 self.comm is not None, self.perceptual is not None and app)
         g = self._graphs.get(gkey)
         if g is None:

@@ -34,6 +34,12 @@ typedef struct ihipStream_t* hipStream_t;
 size_t harp_rasterize_ws_bytes(int B, int F, int S);
 int harp_rasterize_fwd(const float* ndc, const int32_t* faces, int B, int V, int F, int S, int soft, float blur_radius,
                        float sigma, void* ws, int32_t* face_id, float* zbuf, float* alpha, hipStream_t stream);
+/* K = 1 depth pass (the light view, renderer_helper.py:344) into a depth map zbuf that the caller KEEPS between calls.  st_state:
+ * B * ceil(S/64)^2 ints, zero before the first call and owned by the library afterwards — which 64x64 super-tiles of zbuf hold -1
+ * everywhere.  With sparse != 0 (face ids of super-tiles without a face are not written, as with soft bit 1 of harp_rasterize_fwd) a
+ * super-tile that is empty again is not filled again: in a fitting step that is 3/4 of the map.  Nobody else may write zbuf between calls. */
+int harp_rasterize_fwd_keep(const float* ndc, const int32_t* faces, int B, int V, int F, int S, int sparse, void* ws, int32_t* face_id,
+                            float* zbuf, int32_t* st_state, hipStream_t stream);
 /* the same with torch.nn.L1Loss(y_sil_true, y_sil_pred) (optimize_sequence.py:519) fused into the raster epilogue: l1_target (T,S,S)
  * indexed by l1_fid (B,), *l1_loss (+=) the mean, l1_grad (B,S,S) = l1_w[0] * d loss / d alpha.  l1_target == NULL: plain rasterisation. */
 /* soft bit 0: soft silhouette on.  soft bit 1 (value 2): SPARSE outputs — face_id / alpha / l1_grad are left unwritten in 64x64

@@ -1058,7 +1058,7 @@ def test_light_camera_incl_look_at_replacement_branch():
 @pytest.mark.parametrize("switches", [dict(graph_order=False), dict(mesh_third=False), dict(camera_first=False), dict(overlap=False),
                                       dict(graph_order=False, mesh_third=False), dict(mesh_third=False, camera_first=False),
                                       dict(graph_order=False, mesh_third=False, camera_first=False), dict(early_terms=False),
-                                      dict(mesh_terms_first=False, mesh_third=False), dict(tail_side=True), dict(consume_gzl=False)])
+                                      dict(mesh_terms_first=False, mesh_third=False), dict(tail_side=True), dict(consume_gzl=False), dict(keep_depth=False)])
 def test_schedule_switches_give_the_default_schedules_result(switches):
     """The stream / capture-order switches of FitEngine (graph_order, mesh_third, camera_first, overlap, early_terms, mesh_terms_first,
     tail_side) only move launches between streams: losses and the whole gradient arena of every non-default combination must equal the
@@ -1118,3 +1118,36 @@ def test_one_launch_backward_pair_with_a_kept_image():
     eng.fused_bwd = False
     assert (eng.s["rgb"] - rgb0).abs().max().item() < 1e-4      # forward shader vs the colour the backward pass recomputes: 2e-5 measured
     assert rel(eng.g_buf.double(), g0) < 1e-5 and abs(lv1["photo"] - lv0["photo"]) <= 1e-5 * abs(lv0["photo"])
+
+
+def test_kept_light_depth_map_equals_a_freshly_filled_one():
+    """harp_rasterize_fwd_keep: the light-view depth map lives across steps and super-tiles that are empty AGAIN are not filled with -1
+    again.  Frames whose hand sits in different corners of the image take turns in the same batch rows, so super-tiles keep switching
+    between holding faces and holding none; after every pass the kept map must equal, bit for bit, the map of an engine that fills
+    every empty super-tile every time — in both image modes (sparse and dense face ids) and across a switch between them."""
+    from tests._scene import make_fit_case
+    cases = [make_fit_case("hand", T=6, S=256, B=2, seed=7, device=DEV) for _ in range(2)]
+    g = torch.Generator().manual_seed(1)
+    shift = (torch.rand(6, 2, generator=g) - 0.5) * 0.16            # metres in the camera plane: up to +- 130 px at this focal length
+    for c in cases:
+        with torch.no_grad():
+            c["eng"].params["cam"][:, 1:].add_(shift.to(DEV))
+        c["eng"].auto_draw = False
+        c["eng"].draw_texture_offsets()
+        c["eng"].set_stage(True, True)
+    a, b = cases[0]["eng"], cases[1]["eng"]
+    assert a.keep_depth
+    b.keep_depth = False
+    empties = []
+    for it, (pair, keep) in enumerate([((0, 1), False), ((2, 3), False), ((4, 5), False), ((1, 4), True), ((3, 0), True), ((5, 2), False), ((0, 1), False)]):
+        for e in (a, b):
+            e.keep_image = keep
+            fid = torch.tensor(pair, dtype=torch.int32, device=DEV)
+            e.fid.copy_(fid); e.tfid.copy_(fid)
+            e.forward_backward(True, True)
+        torch.cuda.synchronize()
+        assert torch.equal(a.s["zl"], b.s["zl"]), (it, pair, keep, (a.s["zl"] != b.s["zl"]).sum().item())
+        assert rel(a.g_buf.double(), b.g_buf.double()) < 1e-5
+        st = a.s["zl_state"].view(2, -1)
+        empties.append(st.sum(1).tolist())
+    assert len({tuple(e) for e in empties}) > 1, empties            # the set of empty super-tiles did change between passes
