@@ -1,3 +1,4 @@
+#include <stdlib.h>
 // Loss terms of the HARP fitting loop (optimize_sequence.py:517-553) with their gradients, texture-map helpers and
 // the fused Adam update, for gfx950.  Each kernel evaluates a term AND, when a device weight array is given, its
 // gradient (weight = d total / d term, i.e. the loss weight of optimize_sequence.py:411-422 in the fused engine or
@@ -70,19 +71,32 @@ __global__ void __launch_bounds__(64) kps_kernel(const float* __restrict__ gt, c
 // static CSR tables, and owns g_verts[b, u, :].  w[0..2] = weights of (laplacian, normal, arap); loss[0..2] accumulate.
 // STAGE: the frame's vertices are first copied to LDS (V*12 B, dynamic) and every neighbour / pair gather reads from there: a lane
 // walks ~100 dependent gathers and with only ~1.5 waves per SIMD in flight the L2 round trips were the whole cost (53 -> 15 us).
-template <bool STAGE>
-__global__ void __launch_bounds__(256) mesh_reg_kernel(const float* __restrict__ verts, const float* __restrict__ ref_verts,
+// BS: workgroup size.  A workgroup stages the whole frame (V * 12 B) for BS vertices' worth of gathers: 256 threads = 13 workgroups per
+// (frame, term) for the hand mesh, each copying 37 KB; 1024 threads = 4.
+template <int BS>
+__device__ __forceinline__ float block_sum_bs(float v, float* red16) {
+  v = wave_sum(v);
+  if ((threadIdx.x & 63) == 0) red16[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float r = 0.f;
+  if (threadIdx.x == 0)
+    for (int i = 0; i < BS / 64; ++i) r += red16[i];
+  __syncthreads();
+  return r;
+}
+template <bool STAGE, int BS = 256>
+__global__ void __launch_bounds__(BS) mesh_reg_kernel(const float* __restrict__ verts, const float* __restrict__ ref_verts,
                                                        const int32_t* __restrict__ nbr_off, const int32_t* __restrict__ nbr_idx,
                                                        const int32_t* __restrict__ pairs, const int32_t* __restrict__ vp_off,
                                                        const int32_t* __restrict__ vp_idx, int B, int V, int P, int E,
                                                        const float* __restrict__ w, float* __restrict__ loss,
                                                        float* __restrict__ g_verts) {
-  __shared__ float red[4];
+  __shared__ float red[16];
   extern __shared__ float s_verts[];
-  const int b = blockIdx.y, u = blockIdx.x * 256 + threadIdx.x;
+  const int b = blockIdx.y, u = blockIdx.x * BS + threadIdx.x;
   const float* vb = verts + (size_t)b * V * 3;
   if (STAGE) {
-    for (int i = threadIdx.x; i < V * 3; i += 256) s_verts[i] = vb[i];
+    for (int i = threadIdx.x; i < V * 3; i += BS) s_verts[i] = vb[i];
     __syncthreads();
     vb = s_verts;
   }
@@ -175,7 +189,7 @@ __global__ void __launch_bounds__(256) mesh_reg_kernel(const float* __restrict__
       atomicAdd(o, g[0]); atomicAdd(o + 1, g[1]); atomicAdd(o + 2, g[2]);
     }
   }
-  const float s0 = block_sum_256(l_lap, red), s1 = block_sum_256(l_nc, red), s2 = block_sum_256(l_ar, red);
+  const float s0 = block_sum_bs<BS>(l_lap, red), s1 = block_sum_bs<BS>(l_nc, red), s2 = block_sum_bs<BS>(l_ar, red);
   if (threadIdx.x == 0) {
     if (s0 != 0.f) atomicAdd(loss, s0);
     if (s1 != 0.f) atomicAdd(loss + 1, s1);
@@ -422,8 +436,10 @@ int harp_mesh_regularizers(const float* verts, const float* ref_verts, const int
                            const float* w, float* loss, float* g_verts, hipStream_t stream) {
   if (!verts || !nbr_off || !nbr_idx || !nc_pairs || !vp_off || !vp_idx || !loss) return HARP_ERR_ARG;
   const size_t lds = (size_t)V * 3 * sizeof(float);
+  // 512 threads per workgroup: a workgroup stages the whole frame (V * 12 B) whatever its size — 7 stagings per (frame, term) instead of the
+  // 13 of 256-thread workgroups (40 -> 30 us, and 9 us off the step: the kernel runs next to the camera-view set-up); 1024 threads: 41 us
   if (lds <= 60 * 1024)
-    hipLaunchKernelGGL(mesh_reg_kernel<true>, dim3((V + 255) / 256, B, 3), dim3(256), lds, stream, verts, ref_verts, nbr_off, nbr_idx, nc_pairs,
+    hipLaunchKernelGGL((mesh_reg_kernel<true, 512>), dim3((V + 511) / 512, B, 3), dim3(512), lds, stream, verts, ref_verts, nbr_off, nbr_idx, nc_pairs,
                        vp_off, vp_idx, B, V, P, E, w, loss, g_verts);
   else
     hipLaunchKernelGGL(mesh_reg_kernel<false>, dim3((V + 255) / 256, B, 3), dim3(256), 0, stream, verts, ref_verts, nbr_off, nbr_idx, nc_pairs,
