@@ -117,7 +117,9 @@ def kernel_roofline(eng, steps, overlap=False):
     two-stream schedule — the pair then measures the group IN SITU, next to whatever the second stream runs at that moment."""
     from harp_amd import _lib
     L = _lib.lib()
-    names = ["harp_rasterize_fwd", "harp_rasterize_l1_fwd", "harp_shade_fwd", "harp_shade_bwd", "harp_silhouette_bwd", "harp_depth_bwd"]
+    # (the fitting loop calls the light-view pass and its backward through the variants that keep their images across steps)
+    alias = {"harp_rasterize_fwd_keep": "raster_light", "harp_depth_bwd_consume": "harp_depth_bwd"}
+    names = ["harp_rasterize_fwd", "harp_rasterize_l1_fwd", "harp_shade_fwd", "harp_shade_bwd", "harp_silhouette_bwd", "harp_depth_bwd"] + list(alias)
     rec = {n: [] for n in names}
     orig = {}
 
@@ -131,7 +133,7 @@ def kernel_roofline(eng, steps, overlap=False):
             r = self.fn(*a)
             e1.record()
             # harp_rasterize_fwd: argument 6 is `soft` (bit 0 = camera view with the fused soft silhouette, else the light-view depth pass)
-            key = self.name if "rasterize" not in self.name else ("raster_cam" if (a[6] & 1) else "raster_light")
+            key = alias.get(self.name) or (self.name if "rasterize" not in self.name else ("raster_cam" if (a[6] & 1) else "raster_light"))
             rec.setdefault(key, []).append((e0, e1))
             return r
 
@@ -150,7 +152,7 @@ def kernel_roofline(eng, steps, overlap=False):
             setattr(L, n, orig[n])
     ms = {n: [a.elapsed_time(b) for a, b in v] for n, v in rec.items()}
     out = {"raster_cam_fwd(setup+bin+raster)": float(np.mean(ms["raster_cam"])), "raster_light_fwd(setup+bin+raster)": float(np.mean(ms["raster_light"]))}
-    for n in names[2:]:
+    for n in names[2:6]:
         if ms.get(n):
             out[n] = float(np.mean(ms[n]))
     return out
