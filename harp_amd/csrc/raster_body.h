@@ -63,16 +63,24 @@ __device__ __forceinline__ int block_compact(bool pred, int running, int* lds_cn
 // MODE 2: silhouette backward (rim pixels): scatter dL/d(ndc xy).
 __device__ __forceinline__ int nst_of(int nsx) { return nsx * nsx; }
 
+// staging capacity per round.  The silhouette backward (MODE 2) stages 128 faces at a time (a tile sees 30 - 100 of its super-tile's faces,
+// so one round almost always): with 256 slots its accumulators made the workgroup 32 KB of LDS = 5 workgroups per CU, and the kernel is a
+// chain of dependent round trips per tile (alpha -> list -> bbox -> record, ~15 us) whose only cover is other workgroups.
+#ifndef RASTER_CAP2
+#define RASTER_CAP2 128
+#endif
+template <int MODE> constexpr int stage_cap() { return MODE == 2 ? RASTER_CAP2 : kStage; }
 template <int MODE>
 struct RasterSmem {
-  float4 s_a[kStage], s_b[kStage], s_bb[kStage];
-  float s_z2[kStage];
+  static constexpr int kCap = stage_cap<MODE>();
+  float4 s_a[kCap], s_b[kCap], s_bb[kCap];
+  float s_z2[MODE == 2 ? 1 : kCap];
 #ifndef RASTER_NO_SCAN
   float4 s_fc[1];
 #else
   float4 s_fc[MODE == 1 ? kStage : 1];      // (strip walk) per staged face: sign of the area, squared edge lengths l12, l20, l01
 #endif
-  int32_t s_id[kStage];
+  int32_t s_id[kCap];
   int lds_cnt[4];
   unsigned long long zkey[MODE <= 1 ? 256 : 1];   // face-scan walk (MODE 0 / 1): per pixel min over (depth bits << 32 | face id)
   // face scan: staged faces ordered by the number of 4x4 blocks their bbox covers in this tile (counting sort, descending), so that the
@@ -90,7 +98,7 @@ struct RasterSmem {
   float rp_x[MODE == 2 ? 256 : 1], rp_y[MODE == 2 ? 256 : 1], rp_P[MODE == 2 ? 256 : 1], rp_g[MODE == 2 ? 256 : 1];
   unsigned short pairs[MODE >= 1 ? 512 : 1];      // 4 waves x 128-entry ring of (pixel, staged face) pairs
   // MODE 2: per-staged-face gradient accumulators (x,y of 3 verts).  double: ds_add_f64 is ~20x faster than ds_add_f32 on gfx950
-  double s_g[MODE == 2 ? kStage : 1][6];
+  double s_g[MODE == 2 ? kCap : 1][6];
   float red[4];
 };
 
@@ -296,7 +304,8 @@ __device__ __forceinline__ void raster_tile(RasterSmem<MODE>& sm, unsigned vbloc
   auto stage_write = [&](int pos, int id, const float4& bb) {
     if (pos >= 0) {
       const FaceRec r = rb[id];
-      s_a[pos] = r.a; s_b[pos] = r.b; s_z2[pos] = r.c.x; s_bb[pos] = bb; s_id[pos] = id;
+      s_a[pos] = r.a; s_b[pos] = r.b; s_bb[pos] = bb; s_id[pos] = id;
+      if (MODE != 2) s_z2[pos] = r.c.x;
       if (MODE == 1 && !kScan) {
         // constants of the face that every (face, strip) classification below used to recompute on all 64 lanes
         const Tri t = tri_from(r.a, r.b, make_float4(0.f, 0.f, 0.f, 0.f));
@@ -311,7 +320,7 @@ __device__ __forceinline__ void raster_tile(RasterSmem<MODE>& sm, unsigned vbloc
   // The super-tile's list is filtered against this 16x16 tile 256 entries at a time and the hits ACCUMULATE in the staging arrays:
   // a walk runs when the next chunk would not fit, or at the end of the list — one walk per tile almost always (a tile sees 30 - 100
   // of its super-tile's ~350 faces), instead of one per 256 list entries.
-  int staged = 0;
+  int staged = 0, skip = 0;                    // skip: hits of the current chunk staged in an earlier round (a chunk with more hits than a round holds)
   for (int base = 0; base < n || staged > 0;) {
     bool flush = true;
     if (base < n) {
@@ -326,12 +335,20 @@ __device__ __forceinline__ void raster_tile(RasterSmem<MODE>& sm, unsigned vbloc
         hit = !(t_xlo > bb.y || t_xhi < bb.x || t_ylo > bb.w || t_yhi < bb.z);
       }
       int cnt;
-      const int pos = block_compact(hit, staged, lds_cnt, cnt);
-      if (staged + cnt <= kStage) {
-        stage_write(pos, id, bb);
-        staged += cnt;
+      const int posc = block_compact(hit, 0, lds_cnt, cnt);       // rank among this chunk's hits
+      const int rem = cnt - skip, room = stage_cap<MODE>() - staged;
+      if (rem <= room) {
+        stage_write((posc >= skip) ? staged + posc - skip : -1, id, bb);
+        staged += rem;
+        skip = 0;
         base += kStage;
         flush = base >= n;
+      } else if (staged == 0) {
+        // more hits in one chunk than a round holds (only with the 128-slot rounds of MODE 2, on tiles with > 128 faces): take what
+        // fits, walk, come back to the same chunk for the rest
+        stage_write((posc >= skip && posc < skip + room) ? posc - skip : -1, id, bb);
+        staged = room;
+        skip += room;
       }
     }
     if (!flush) continue;
@@ -340,7 +357,8 @@ __device__ __forceinline__ void raster_tile(RasterSmem<MODE>& sm, unsigned vbloc
     if (nl == 0) continue;
     if (MODE == 2) {
 #pragma unroll
-      for (int c = 0; c < 6; ++c) s_g[threadIdx.x][c] = 0.0;
+      for (int c = 0; c < 6; ++c)
+        if ((int)threadIdx.x < stage_cap<MODE>()) s_g[threadIdx.x][c] = 0.0;
     }
     __syncthreads();
     if constexpr (kScan) {
