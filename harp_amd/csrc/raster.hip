@@ -110,10 +110,16 @@ __global__ void __launch_bounds__(1024) order_tiles_kernel(const int32_t* __rest
   rb::order_tiles(bin_count, total, order, nact, s_hist, s_base);
 }
 
+#ifndef RASTER_OCC0
+#define RASTER_OCC0 7
+#endif
+#ifndef RASTER_OCC2
+#define RASTER_OCC2 8   // silhouette backward: 64 VGPRs, 8 waves per SIMD (18 KB of LDS per workgroup): 53 -> 51 us, step -3 us (5: the round-3 setting for its 32-KB form)
+#endif
 constexpr unsigned kRasterGrid = 16384;
 
 template <int MODE, bool LOOP>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == 2 ? 5 : 7, 8))) raster_kernel(const FaceRec* __restrict__ recs, const float4* __restrict__ bbs,
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == 2 ? RASTER_OCC2 : (MODE == 0 ? RASTER_OCC0 : 7), 8))) raster_kernel(const FaceRec* __restrict__ recs, const float4* __restrict__ bbs,
                                                      const int32_t* __restrict__ bins,
                                                      const int32_t* __restrict__ bin_count, const int32_t* __restrict__ order,
                                                      const int32_t* __restrict__ nact, int B, int F, int S, int nsx,
