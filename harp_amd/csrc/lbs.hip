@@ -194,7 +194,7 @@ __global__ void __launch_bounds__(256) lbs_skin_kernel(const harp_mano_model M, 
 }
 
 // g_A[b][j][k] += sum_{v in chunk} w[v][j] M[b][v][k]   (192 lanes per frame x kChunksA vertex chunks; g_A pre-zeroed)
-constexpr int kChunksA = 8;
+constexpr int kChunksA = 16;     // (round 4: 8 -> 16 chunks, a lane walks 49 vertices instead of 98: the launch 15.5 -> 13.7 us; 32: 14.2)
 // g_pose_map[b][k] += sum_{vc in chunk} posedirs[vc][k] g_vp[b][vc];  g_beta_part[b][k] likewise with shapedirs (k<10)
 constexpr int kChunksP = 64;      // short dependent load chains: 37 trips per lane instead of 146 (23 -> ~8 us)
 
