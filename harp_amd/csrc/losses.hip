@@ -363,6 +363,31 @@ __global__ void adam_dev_kernel(float* __restrict__ p, const float* __restrict__
 // [o0, o0 + n0), the rest to [o1, o1 + n1) of the same four arenas
 __global__ void adam_dev2_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                  size_t o0, size_t n0, size_t o1, size_t n1, const harp_adam_hyper* __restrict__ hs) {
+  // four elements per lane (16-B loads / stores of all four arenas) when both spans are whole quads — the engine's arena segments are
+  // 64-float aligned —, same per-element arithmetic
+  if (((o0 | n0 | o1 | n1) & 3) == 0) {
+    for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; 4 * q < n0 + n1; q += (size_t)gridDim.x * blockDim.x) {
+      const size_t k = 4 * q;
+      const bool first = k < n0;
+      const harp_adam_hyper* h = hs + (first ? 0 : 1);
+      const size_t i = first ? o0 + k : o1 + (k - n0);
+      const float beta1 = h->beta1, beta2 = h->beta2, gs = h->grad_scale, ss = h->step_size, isb = h->inv_sqrt_bc2, eps = h->eps;
+      const float4 G = *reinterpret_cast<const float4*>(g + i);
+      float4 M = *reinterpret_cast<float4*>(m + i), Vv = *reinterpret_cast<float4*>(v + i), P = *reinterpret_cast<float4*>(p + i);
+      const float gq[4] = {G.x * gs, G.y * gs, G.z * gs, G.w * gs};
+      float mq[4] = {M.x, M.y, M.z, M.w}, vq[4] = {Vv.x, Vv.y, Vv.z, Vv.w}, pq[4] = {P.x, P.y, P.z, P.w};
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        mq[c] = mq[c] + (gq[c] - mq[c]) * (1.0f - beta1);
+        vq[c] = vq[c] * beta2 + (1.0f - beta2) * gq[c] * gq[c];
+        pq[c] -= ss * (mq[c] / (sqrtf(vq[c]) * isb + eps));
+      }
+      *reinterpret_cast<float4*>(m + i) = make_float4(mq[0], mq[1], mq[2], mq[3]);
+      *reinterpret_cast<float4*>(v + i) = make_float4(vq[0], vq[1], vq[2], vq[3]);
+      *reinterpret_cast<float4*>(p + i) = make_float4(pq[0], pq[1], pq[2], pq[3]);
+    }
+    return;
+  }
   for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < n0 + n1; k += (size_t)gridDim.x * blockDim.x) {
     const bool first = k < n0;
     const harp_adam_hyper* h = hs + (first ? 0 : 1);
@@ -407,7 +432,7 @@ int harp_adam_apply(float* p, const float* g, float* m, float* v, size_t n, cons
 int harp_adam_apply2(float* p, const float* g, float* m, float* v, size_t o0, size_t n0, size_t o1, size_t n1, const harp_adam_hyper* h2,
                      hipStream_t stream) {
   if (!p || !g || !m || !v || !h2 || n0 + n1 == 0) return HARP_ERR_ARG;
-  const int blocks = (int)min((size_t)2048, (n0 + n1 + 255) / 256);
+  const int blocks = (int)min((size_t)2048, ((n0 + n1) / 4 + 255) / 256 + 1);
   hipLaunchKernelGGL(adam_dev2_kernel, dim3(blocks), dim3(256), 0, stream, p, g, m, v, o0, n0, o1, n1, h2);
   HARP_CHECK_LAUNCH();
   return HARP_OK;
