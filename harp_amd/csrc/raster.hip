@@ -110,6 +110,9 @@ __global__ void __launch_bounds__(1024) order_tiles_kernel(const int32_t* __rest
   rb::order_tiles(bin_count, total, order, nact, s_hist, s_base);
 }
 
+#ifndef RASTER_OCC1
+#define RASTER_OCC1 7
+#endif
 #ifndef RASTER_OCC0
 #define RASTER_OCC0 7
 #endif
@@ -119,7 +122,7 @@ __global__ void __launch_bounds__(1024) order_tiles_kernel(const int32_t* __rest
 constexpr unsigned kRasterGrid = 16384;
 
 template <int MODE, bool LOOP>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == 2 ? RASTER_OCC2 : (MODE == 0 ? RASTER_OCC0 : 7), 8))) raster_kernel(const FaceRec* __restrict__ recs, const float4* __restrict__ bbs,
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == 2 ? RASTER_OCC2 : (MODE == 0 ? RASTER_OCC0 : RASTER_OCC1), 8))) raster_kernel(const FaceRec* __restrict__ recs, const float4* __restrict__ bbs,
                                                      const int32_t* __restrict__ bins,
                                                      const int32_t* __restrict__ bin_count, const int32_t* __restrict__ order,
                                                      const int32_t* __restrict__ nact, int B, int F, int S, int nsx,
