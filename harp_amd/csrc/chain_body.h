@@ -29,7 +29,11 @@ __device__ __forceinline__ void block_sum_n(const float* v, float* red, float* o
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 #pragma unroll
   for (int k = 0; k < N; ++k) {
+#ifdef CHAIN_SLOW_SUM
     const float s = wave_sum(v[k]);
+#else
+    const float s = wave_sum_u(v[k]);     // DPP reduction (~8 cycles a step; the shuffle form goes through ds_bpermute, ~100)
+#endif
     if (lane == 0) red[w * N + k] = s;
   }
   __syncthreads();
