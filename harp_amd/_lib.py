@@ -71,6 +71,8 @@ SIGNATURES.update({
     "harp_shade_fwd": (_i, [ctypes.POINTER(ShadeArgs), _vp]),
     "harp_shade_bwd": (_i, [ctypes.POINTER(ShadeArgs), _vp]),
     "harp_pack_texels": (_i, [_vp, _vp, _i, _vp, _vp]),
+    "harp_normalize3_pack": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
+    "harp_depth_nmap_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp]),
     "harp_subdivide_fwd": (_i, [_vp, _vp, _i, _i, _i, _f, _vp, _vp]),
     "harp_subdivide_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _vp, _vp]),
     "harp_vertex_normals_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
@@ -98,6 +100,8 @@ SIGNATURES.update({
     "harp_sum_squares": (_i, [_vp, _i, _vp, _vp, _vp, _vp]),
     "harp_mse": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
     "harp_texture_smooth_reg": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
+    "harp_mesh_kps_terms": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
+    "harp_texture_terms": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "harp_close_to_z_reg": (_i, [_vp, _i, _i, _f, _vp, _vp, _vp, _vp]),
     "harp_normalize3_fwd": (_i, [_vp, _i, _vp, _vp]),
     "harp_normalize3_bwd": (_i, [_vp, _vp, _i, _vp, _vp]),
@@ -124,6 +128,7 @@ SIGNATURES.update({
 
 SIGNATURES.update({
     "harp_adam_tick": (_i, [_vp, _i, _vp]),
+    "harp_step_prologue": (_i, [_vp, _sz, _vp, _i, ctypes.c_uint, _vp, _i, _i, _f, _vp, _f, _vp, _vp]),
     "harp_adam_apply": (_i, [_vp, _vp, _vp, _vp, _sz, _vp, _vp]),
     "harp_adam_apply2": (_i, [_vp, _vp, _vp, _vp, _sz, _sz, _sz, _sz, _vp, _vp]),
 })
@@ -176,10 +181,17 @@ SIGNATURES.update({
 SIGNATURES["harp_shade_sil_bwd"] = (_i, [ctypes.POINTER(ShadeArgs), _f, _f, _vp, _vp, _vp])
 
 
+class StepFrame(ctypes.Structure):
+    """mirror of `harp_step_frame` (include/harp_hip.h)"""
+    _fields_ = [("schedule", _vp), ("sched_row", _vp), ("n_rows", _i), ("target_offset", _i), ("tfid_out", _vp), ("clear_mesh_grads", _i),
+                ("loss", _vp), ("loss_out", _vp), ("n_loss", _i), ("draw_counter", _vp)]
+
+
 class HandFront(ctypes.Structure):
     """mirror of `harp_hand_front` (include/harp_hip.h)"""
     _fields_ = ([("chain", MeshChain), ("mano", ManoModel), ("tables", FrameTables), ("fid", _vp)] +
-                [(n, _vp) for n in ("pose48", "betas", "trans_b", "cam_R", "cam_T", "light_pos", "colors", "lbs_ws")] + [("self_shadow", _i)])
+                [(n, _vp) for n in ("pose48", "betas", "trans_b", "cam_R", "cam_T", "light_pos", "colors", "lbs_ws")] + [("self_shadow", _i),
+                 ("step", StepFrame)])
 
 
 SIGNATURES["harp_hand_front_fwd"] = (_i, [ctypes.POINTER(HandFront), _vp])

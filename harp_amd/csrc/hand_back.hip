@@ -111,6 +111,20 @@ __global__ void __launch_bounds__(kChainThreads) hand_back_kernel(const harp_han
     const float g_amb = (g_colors[0] + g_colors[1] + g_colors[2]) - (g_colors[3] + g_colors[4] + g_colors[5]);
     atomicAdd(T.g_amb_ratio, g_amb * amb * (1.0f - amb));
   }
+  // ---- optional step epilogue (harp_step_frame): every kernel that reads the schedule row, adds to the loss vector or reads the draw
+  //      counter is an EARLIER launch of the step (stream order / joins), so one workgroup can turn the three over for the next step
+  if (b == 0) {
+    const harp_step_frame& E = H.step;
+    if (tid >= 128 && tid < 128 + E.n_loss && E.loss) {
+      const int k = tid - 128;
+      if (E.loss_out) E.loss_out[k] = E.loss[k];
+      E.loss[k] = 0.f;
+    } else if (tid == 192 && E.schedule) {
+      E.sched_row[0] = (int)((unsigned)E.sched_row[0] % (unsigned)E.n_rows) + 1;
+    } else if (tid == 193 && E.draw_counter) {
+      E.draw_counter[0] += 1;
+    }
+  }
 }
 
 }  // namespace
@@ -128,6 +142,8 @@ int harp_hand_back_bwd(const harp_hand_front* h, const float* g_colors, float* g
                      !a->g_light_pos)))
     return HARP_ERR_ARG;
   if (!h->fid || !h->pose48 || !h->lbs_ws || h->tables.wrist_pose) return HARP_ERR_ARG;
+  if ((h->step.schedule && (!h->step.sched_row || h->step.n_rows <= 0)) || (h->step.loss && (h->step.n_loss < 0 || h->step.n_loss > 64)))
+    return HARP_ERR_ARG;
   const size_t lds = (size_t)(a->V0 + a->E0) * 9 * sizeof(float);
   // dynamic LDS above 64 KB has to be requested; the attribute is per DEVICE, so it is set on every call (cheap) rather than cached in a
   // process-wide static that a second device or a concurrent first call would defeat

@@ -45,8 +45,26 @@ __global__ void __launch_bounds__(kChainThreads) hand_front_kernel(const harp_ha
     for (int i = 0; i < kPer; ++i) warm += t[i];
     warm += u;
   }
+  // ---- optional step prologue (harp_step_frame): this workgroup's frame from the device schedule — what schedule_next_kernel did as a
+  //      launch of its own in front of this one (6 us + a node gap on the critical path) —, and the clear of the frame's slice of the two
+  //      gradient segments the key-point / mesh terms accumulate into (they start after this kernel)
+  int f;
+  if (H.step.schedule) {
+    const int row = (int)((unsigned)H.step.sched_row[0] % (unsigned)H.step.n_rows);     // bumped by hand_back_kernel, a later launch
+    f = H.step.schedule[(size_t)row * B + b];
+    if (tid == 0) {
+      const_cast<int32_t*>(H.fid)[b] = f;
+      if (H.step.tfid_out) H.step.tfid_out[b] = f - H.step.target_offset;
+    }
+  } else {
+    f = H.fid[b];
+  }
+  if (H.step.clear_mesh_grads) {
+    float* gv = const_cast<float*>(A.g_vd) + (size_t)b * V * 3;          // (inputs of the backward launch of the same struct)
+    for (int i = tid; i < V * 3; i += kChainThreads) gv[i] = 0.f;
+    if (tid < A.NJ * 3) const_cast<float*>(A.g_joints_m)[(size_t)b * A.NJ * 3 + tid] = 0.f;
+  }
   // ---- frame set-up (glue.hip: frame_setup_fwd_kernel)
-  const int f = H.fid[b];
   if (tid < 48) {
     const float p = (tid < 3) ? T.rot[f * 3 + tid] : T.pose[f * 45 + tid - 3];
     s_pose[tid] = p; H.pose48[b * 48 + tid] = p;
@@ -196,6 +214,8 @@ int harp_hand_front_fwd(const harp_hand_front* h, hipStream_t stream) {
     return HARP_ERR_ARG;
   if (!h->fid || !h->pose48 || !h->betas || !h->trans_b || !h->cam_R || !h->cam_T || !h->light_pos || !h->colors || !h->lbs_ws ||
       h->tables.wrist_pose)
+    return HARP_ERR_ARG;
+  if ((h->step.schedule && (!h->step.sched_row || h->step.n_rows <= 0)) || (h->step.clear_mesh_grads && (!a.g_vd || !a.g_joints_m)))
     return HARP_ERR_ARG;
   const size_t lds = (size_t)(a.V0 + a.E0) * 3 * sizeof(float);          // <= 48 KB (harp_mesh_chain_max_vertices)
   hipLaunchKernelGGL(hand_front_kernel, dim3(a.B), dim3(kChainThreads), lds, stream, *h);

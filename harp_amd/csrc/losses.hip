@@ -35,10 +35,9 @@ __global__ void __launch_bounds__(256) image_l1_kernel(const float* __restrict__
 }
 
 // kps_loss (loss/kps_loss.py:4-17): mean_{b,j} (|| (gt-gt0) - 1000 (pred-pred0) ||/100)^2 over the first 21 joints.
-__global__ void __launch_bounds__(64) kps_kernel(const float* __restrict__ gt, const int32_t* __restrict__ fid,
-                                                 const float* __restrict__ pred, int B, int NJp, const float* __restrict__ w,
-                                                 float* __restrict__ loss, float* __restrict__ g_pred) {
-  const int b = blockIdx.x, j = threadIdx.x;
+__device__ __forceinline__ void kps_body(const float* __restrict__ gt, const int32_t* __restrict__ fid, const float* __restrict__ pred,
+                                         int b, int j, int B, int NJp, const float* __restrict__ w, float* __restrict__ loss,
+                                         float* __restrict__ g_pred) {
   const float* g = gt + (size_t)(fid ? fid[b] : b) * 63;
   const float* p = pred + (size_t)b * NJp * 3;
   float d[3] = {0.f, 0.f, 0.f}, l = 0.f;
@@ -64,6 +63,13 @@ __global__ void __launch_bounds__(64) kps_kernel(const float* __restrict__ gt, c
     }
   }
 }
+__global__ void __launch_bounds__(64) kps_kernel(const float* __restrict__ gt, const int32_t* __restrict__ fid,
+                                                 const float* __restrict__ pred, int B, int NJp, const float* __restrict__ w,
+                                                 float* __restrict__ loss, float* __restrict__ g_pred) {
+  kps_body(gt, fid, pred, blockIdx.x, threadIdx.x, B, NJp, w, loss, g_pred);
+}
+// the key-point term riding in the mesh regularisers' launch (grid slice z == 3: one wave per frame) instead of a launch of its own
+struct KpsArgs { const float* gt; const int32_t* fid; const float* pred; int NJp; const float* w; float* loss; float* g_pred; };
 
 // laplacian (uniform, Appendix A.11) | normal consistency (A.12) | ARAP (loss/arap.py:45-57); blockIdx.y = frame.
 // GATHER formulation, one lane per (frame, vertex), no atomics on the gradient: every lane re-derives the terms its vertex
@@ -90,9 +96,13 @@ __global__ void __launch_bounds__(BS) mesh_reg_kernel(const float* __restrict__ 
                                                        const int32_t* __restrict__ pairs, const int32_t* __restrict__ vp_off,
                                                        const int32_t* __restrict__ vp_idx, int B, int V, int P, int E,
                                                        const float* __restrict__ w, float* __restrict__ loss,
-                                                       float* __restrict__ g_verts) {
+                                                       float* __restrict__ g_verts, const KpsArgs K) {
   __shared__ float red[16];
   extern __shared__ float s_verts[];
+  if (blockIdx.z == 3) {                      // (only launched when K.gt is set)
+    if (blockIdx.x == 0 && threadIdx.x < 64) kps_body(K.gt, K.fid, K.pred, blockIdx.y, threadIdx.x, B, K.NJp, K.w, K.loss, K.g_pred);
+    return;
+  }
   const int b = blockIdx.y, u = blockIdx.x * BS + threadIdx.x;
   const float* vb = verts + (size_t)b * V * 3;
   if (STAGE) {
@@ -198,16 +208,20 @@ __global__ void __launch_bounds__(BS) mesh_reg_kernel(const float* __restrict__ 
 }
 
 // sum(d^2) (optimize_sequence.py:533)
-__global__ void __launch_bounds__(256) sumsq_kernel(const float* __restrict__ d, int n, const float* __restrict__ w,
-                                                    float* __restrict__ loss, float* __restrict__ g) {
-  __shared__ float red[4];
+__device__ __forceinline__ void sumsq_body(int bid, int nb, const float* __restrict__ d, int n, const float* __restrict__ w,
+                                           float* __restrict__ loss, float* __restrict__ g, float* red) {
   float acc = 0.f;
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+  for (int i = bid * 256 + threadIdx.x; i < n; i += nb * 256) {
     acc += d[i] * d[i];
     if (w && g) atomicAdd(&g[i], 2.0f * w[0] * d[i]);
   }
   const float s = block_sum_256(acc, red);
   if (threadIdx.x == 0) atomicAdd(loss, s);
+}
+__global__ void __launch_bounds__(256) sumsq_kernel(const float* __restrict__ d, int n, const float* __restrict__ w,
+                                                    float* __restrict__ loss, float* __restrict__ g) {
+  __shared__ float red[4];
+  sumsq_body(blockIdx.x, gridDim.x, d, n, w, loss, g, red);
 }
 
 // torch.nn.MSELoss()(x, y) and its gradient w.r.t. x (metro_modifications/hand_utils.py:71-87): the per-iteration objective of the
@@ -227,12 +241,11 @@ __global__ void __launch_bounds__(256) mse_kernel(const float* __restrict__ x, c
 }
 
 // albedo_reg / smooth_texture_reg (loss/texture_reg.py:5-30, 48-66): mean_xy( ||t[x,y]-t[x+dx,y+dy]||_1 / 3 * mask )
-__global__ void __launch_bounds__(256) tex_smooth_kernel(const float* __restrict__ t, const int32_t* __restrict__ dist,
-                                                         const float* __restrict__ mask, int H, int W, const float* __restrict__ w,
-                                                         float* __restrict__ loss, float* __restrict__ g) {
-  __shared__ float red[4];
+__device__ __forceinline__ void tex_smooth_body(int bid, int nb, const float* __restrict__ t, const int32_t* __restrict__ dist,
+                                                const float* __restrict__ mask, int H, int W, const float* __restrict__ w,
+                                                float* __restrict__ loss, float* __restrict__ g, float* red) {
   float acc = 0.f;
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < H * W; i += gridDim.x * 256) {
+  for (int i = bid * 256 + threadIdx.x; i < H * W; i += nb * 256) {
     const int x = i / W, y = i % W;                    // reference names: x = row, y = column
     const int tx = min(max(x + dist[2 * i], 0), H - 1), ty = min(max(y + dist[2 * i + 1], 0), W - 1);
     const int j = tx * W + ty;
@@ -250,14 +263,20 @@ __global__ void __launch_bounds__(256) tex_smooth_kernel(const float* __restrict
   const float s = block_sum_256(acc, red);
   if (threadIdx.x == 0) atomicAdd(loss, s / (float)(H * W));
 }
+__global__ void __launch_bounds__(256) tex_smooth_kernel(const float* __restrict__ t, const int32_t* __restrict__ dist,
+                                                         const float* __restrict__ mask, int H, int W, const float* __restrict__ w,
+                                                         float* __restrict__ loss, float* __restrict__ g) {
+  __shared__ float red[4];
+  tex_smooth_body(blockIdx.x, gridDim.x, t, dist, mask, H, W, w, loss, g, red);
+}
 
 // close_to_z_reg (loss/texture_reg.py:40-45) as the reference computes it: L2 norm over the WIDTH axis of
 // (nm - (0,0,1)) for every (row, channel), /3, mean over rows x channels. One block per row.
-__global__ void __launch_bounds__(256) close_to_z_kernel(const float* __restrict__ nm, int H, int W, const float* __restrict__ w,
-                                                         float scale, float* __restrict__ loss, float* __restrict__ g) {
-  __shared__ float red[4];
-  __shared__ float s_norm[3];
-  const int h = blockIdx.x;
+// ATOMIC: the gradient is added with atomics (the fused launch below runs this term next to the smoothness term, which scatters into
+// the same gradient image)
+template <bool ATOMIC>
+__device__ __forceinline__ void close_to_z_body(int h, const float* __restrict__ nm, int H, int W, const float* __restrict__ w, float scale,
+                                                float* __restrict__ loss, float* __restrict__ g, float* red, float* s_norm) {
   float a[3] = {0.f, 0.f, 0.f};
   for (int x = threadIdx.x; x < W; x += 256)
     for (int c = 0; c < 3; ++c) { const float d = nm[((size_t)h * W + x) * 3 + c] - (c == 2 ? 1.f : 0.f); a[c] += d * d; }
@@ -272,8 +291,44 @@ __global__ void __launch_bounds__(256) close_to_z_kernel(const float* __restrict
     const float k = w[0] * scale * inv;
     for (int x = threadIdx.x; x < W; x += 256)
       for (int c = 0; c < 3; ++c)
-        if (s_norm[c] > 0.f) g[((size_t)h * W + x) * 3 + c] += k * (nm[((size_t)h * W + x) * 3 + c] - (c == 2 ? 1.f : 0.f)) / s_norm[c];
+        if (s_norm[c] > 0.f) {
+          const float v = k * (nm[((size_t)h * W + x) * 3 + c] - (c == 2 ? 1.f : 0.f)) / s_norm[c];
+          if (ATOMIC) atomicAdd(g + ((size_t)h * W + x) * 3 + c, v);
+          else g[((size_t)h * W + x) * 3 + c] += v;
+        }
   }
+}
+__global__ void __launch_bounds__(256) close_to_z_kernel(const float* __restrict__ nm, int H, int W, const float* __restrict__ w,
+                                                         float scale, float* __restrict__ loss, float* __restrict__ g) {
+  __shared__ float red[4];
+  __shared__ float s_norm[3];
+  close_to_z_body<false>(blockIdx.x, nm, H, W, w, scale, loss, g, red, s_norm);
+}
+
+// The parameter-only regularisers of an appearance + geometry step in ONE launch (they were four: albedo smoothness, close-to-z, normal-map
+// smoothness, displacement sum of squares — 15 + 16 + 18 + 5 us of mostly launch latency on the second stream of a step): the grid is cut
+// into four block ranges, one per term, each running the body of its stand-alone kernel.
+struct TexTerms {
+  const float *tex, *nmap, *mask, *disp;
+  const int32_t *dist_a, *dist_n;
+  int H, W, n_disp;
+  float z_scale;
+  const float *w_a, *w_n, *w_d;        // device weights (albedo | close-to-z and normal smoothness share one | displacement)
+  float *l_a, *l_n, *l_d;
+  float *g_tex, *g_nmap, *g_disp;
+  int nb_smooth, nb_disp;
+};
+__global__ void __launch_bounds__(256) texture_terms_kernel(const TexTerms A) {
+  __shared__ float red[4];
+  __shared__ float s_norm[3];
+  int bid = blockIdx.x;
+  if (bid < A.nb_smooth) { tex_smooth_body(bid, A.nb_smooth, A.tex, A.dist_a, A.mask, A.H, A.W, A.w_a, A.l_a, A.g_tex, red); return; }
+  bid -= A.nb_smooth;
+  if (bid < A.nb_smooth) { tex_smooth_body(bid, A.nb_smooth, A.nmap, A.dist_n, A.mask, A.H, A.W, A.w_n, A.l_n, A.g_nmap, red); return; }
+  bid -= A.nb_smooth;
+  if (bid < A.H) { close_to_z_body<true>(bid, A.nmap, A.H, A.W, A.w_n, A.z_scale, A.l_n, A.g_nmap, red, s_norm); return; }
+  bid -= A.H;
+  if (A.disp) sumsq_body(bid, A.nb_disp, A.disp, A.n_disp, A.w_d, A.l_d, A.g_disp, red);
 }
 
 // F.normalize(normal_map, dim=-1) per texel (utils/visualize.py:99), eps 1e-12
@@ -286,16 +341,7 @@ __global__ void normalize3_fwd_kernel(const float* __restrict__ x, int n, float*
 }
 __global__ void normalize3_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gy, int n, float* __restrict__ gx) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const float a = x[3 * i], b = x[3 * i + 1], c = x[3 * i + 2];
-  const float l = sqrtf(a * a + b * b + c * c);
-  const float g0 = gy[3 * i], g1 = gy[3 * i + 1], g2 = gy[3 * i + 2];
-  if (l > 1e-12f) {
-    const float inv = 1.0f / l, na = a * inv, nb = b * inv, nc = c * inv, d = na * g0 + nb * g1 + nc * g2;
-    gx[3 * i] += (g0 - na * d) * inv; gx[3 * i + 1] += (g1 - nb * d) * inv; gx[3 * i + 2] += (g2 - nc * d) * inv;
-  } else {
-    gx[3 * i] += g0 * 1e12f; gx[3 * i + 1] += g1 * 1e12f; gx[3 * i + 2] += g2 * 1e12f;
-  }
+  if (i < n) normalize3_bwd_texel(x, gy, gx, (size_t)i);
 }
 
 // torch.optim.Adam (betas, eps, no weight decay, no amsgrad) on a flat segment; bias corrections computed on the host.
@@ -359,6 +405,38 @@ __global__ void adam_dev_kernel(float* __restrict__ p, const float* __restrict__
   }
 }
 
+// The head of a step's second stream in ONE launch (it was a fill, adam_tick, draw_offsets and bump_counter: four launches of ~5 us each in
+// front of the texture terms): clear the gradient slab, advance the optimisers' hyper-parameter structs, draw the texture offsets for the
+// current value of the draw counter (which is advanced elsewhere: harp_step_frame's epilogue).
+__global__ void __launch_bounds__(256) step_prologue_kernel(float* __restrict__ zero, size_t n_zero, harp_adam_hyper* hs, int n_hyper,
+                                                            uint32_t seed, const int* __restrict__ counter, int n_draw, float std,
+                                                            int32_t* __restrict__ out, float std2, int32_t* __restrict__ out2) {
+  const size_t tid = (size_t)blockIdx.x * 256 + threadIdx.x, nth = (size_t)gridDim.x * 256;
+  if (zero) {
+    const size_t head = min(n_zero, (size_t)((16 - ((uintptr_t)zero & 15)) & 15) / 4);       // floats up to the first 16-B boundary
+    float4* z4 = reinterpret_cast<float4*>(zero + head);
+    const size_t n4 = (n_zero - head) / 4;
+    for (size_t i = tid; i < n4; i += nth) z4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (tid < head) zero[tid] = 0.f;
+    const size_t tail = head + 4 * n4;
+    if (tid < n_zero - tail) zero[tail + tid] = 0.f;
+  }
+  if (blockIdx.x == 0 && (int)threadIdx.x < n_hyper) {
+    harp_adam_hyper* h = hs + threadIdx.x;
+    h->step += 1;
+    const double bc1 = 1.0 - pow((double)h->beta1, (double)h->step), bc2 = 1.0 - pow((double)h->beta2, (double)h->step);
+    h->step_size = (float)((double)h->lr / bc1);
+    h->inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+  }
+  if (out) {
+    const uint32_t c = (uint32_t)counter[0];
+    for (size_t i = tid; i < (size_t)n_draw; i += nth) {
+      draw_pair(seed, c, (int)i, std, out);
+      if (out2) draw_pair(seed ^ 0x5bd1e995U, c + 0x632BE5ABU, (int)i, std2, out2);
+    }
+  }
+}
+
 // two parameter groups (their own hyper-parameter structs, adjacent in memory) in ONE launch: elements [0, n0) of the grid map to
 // [o0, o0 + n0), the rest to [o1, o1 + n1) of the same four arenas
 __global__ void adam_dev2_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
@@ -414,6 +492,18 @@ int harp_draw_texture_offsets(unsigned seed, int* counter_dev, int H, int W, flo
   return HARP_OK;
 }
 
+int harp_step_prologue(float* zero, size_t n_zero, harp_adam_hyper* hyper, int n_hyper, unsigned seed, const int* draw_counter, int H, int W,
+                       float std, int32_t* dist, float std2, int32_t* dist2, hipStream_t stream) {
+  if ((n_zero && !zero) || (n_hyper && !hyper) || n_hyper < 0 || n_hyper > 64 || (dist && (!draw_counter || H <= 0 || W <= 0)) || (dist2 && !dist))
+    return HARP_ERR_ARG;
+  const size_t work = max(n_zero / 4, dist ? (size_t)H * W : (size_t)0);
+  const int blocks = (int)max((size_t)1, min((size_t)2048, (work + 255) / 256));
+  hipLaunchKernelGGL(step_prologue_kernel, dim3(blocks), dim3(256), 0, stream, n_zero ? zero : nullptr, n_zero, hyper, n_hyper, seed,
+                     draw_counter, dist ? H * W : 0, std, dist, std2, dist2);
+  HARP_CHECK_LAUNCH();
+  return HARP_OK;
+}
+
 int harp_adam_tick(harp_adam_hyper* h, int count, hipStream_t stream) {
   if (!h || count < 1 || count > 64) return HARP_ERR_ARG;
   hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(64), 0, stream, h, count);
@@ -456,19 +546,53 @@ int harp_kps_loss(const float* gt, const int32_t* fid, const float* pred, int B,
   return HARP_OK;
 }
 
-int harp_mesh_regularizers(const float* verts, const float* ref_verts, const int32_t* nbr_off, const int32_t* nbr_idx,
-                           const int32_t* nc_pairs, const int32_t* vp_off, const int32_t* vp_idx, int B, int V, int P, int E,
-                           const float* w, float* loss, float* g_verts, hipStream_t stream) {
+static int mesh_terms_launch(const float* verts, const float* ref_verts, const int32_t* nbr_off, const int32_t* nbr_idx,
+                             const int32_t* nc_pairs, const int32_t* vp_off, const int32_t* vp_idx, int B, int V, int P, int E,
+                             const float* w, float* loss, float* g_verts, const KpsArgs& K, hipStream_t stream) {
   if (!verts || !nbr_off || !nbr_idx || !nc_pairs || !vp_off || !vp_idx || !loss) return HARP_ERR_ARG;
+  const int nz = K.gt ? 4 : 3;
   const size_t lds = (size_t)V * 3 * sizeof(float);
   // 512 threads per workgroup: a workgroup stages the whole frame (V * 12 B) whatever its size — 7 stagings per (frame, term) instead of the
   // 13 of 256-thread workgroups (40 -> 30 us, and 9 us off the step: the kernel runs next to the camera-view set-up); 1024 threads: 41 us
   if (lds <= 60 * 1024)
-    hipLaunchKernelGGL((mesh_reg_kernel<true, 512>), dim3((V + 511) / 512, B, 3), dim3(512), lds, stream, verts, ref_verts, nbr_off, nbr_idx, nc_pairs,
-                       vp_off, vp_idx, B, V, P, E, w, loss, g_verts);
+    hipLaunchKernelGGL((mesh_reg_kernel<true, 512>), dim3((V + 511) / 512, B, nz), dim3(512), lds, stream, verts, ref_verts, nbr_off, nbr_idx, nc_pairs,
+                       vp_off, vp_idx, B, V, P, E, w, loss, g_verts, K);
   else
-    hipLaunchKernelGGL(mesh_reg_kernel<false>, dim3((V + 255) / 256, B, 3), dim3(256), 0, stream, verts, ref_verts, nbr_off, nbr_idx, nc_pairs,
-                       vp_off, vp_idx, B, V, P, E, w, loss, g_verts);
+    hipLaunchKernelGGL(mesh_reg_kernel<false>, dim3((V + 255) / 256, B, nz), dim3(256), 0, stream, verts, ref_verts, nbr_off, nbr_idx, nc_pairs,
+                       vp_off, vp_idx, B, V, P, E, w, loss, g_verts, K);
+  HARP_CHECK_LAUNCH();
+  return HARP_OK;
+}
+
+int harp_mesh_regularizers(const float* verts, const float* ref_verts, const int32_t* nbr_off, const int32_t* nbr_idx,
+                           const int32_t* nc_pairs, const int32_t* vp_off, const int32_t* vp_idx, int B, int V, int P, int E,
+                           const float* w, float* loss, float* g_verts, hipStream_t stream) {
+  return mesh_terms_launch(verts, ref_verts, nbr_off, nbr_idx, nc_pairs, vp_off, vp_idx, B, V, P, E, w, loss, g_verts, KpsArgs{}, stream);
+}
+
+int harp_mesh_kps_terms(const float* verts, const float* ref_verts, const int32_t* nbr_off, const int32_t* nbr_idx,
+                        const int32_t* nc_pairs, const int32_t* vp_off, const int32_t* vp_idx, int B, int V, int P, int E,
+                        const float* w, float* loss, float* g_verts, const float* kps_gt, const int32_t* fid, const float* kps_pred,
+                        int n_joints_pred, const float* w_kps, float* loss_kps, float* g_kps_pred, hipStream_t stream) {
+  if (!kps_gt || !kps_pred || !loss_kps || n_joints_pred < 21) return HARP_ERR_ARG;
+  const KpsArgs K{kps_gt, fid, kps_pred, n_joints_pred, w_kps, loss_kps, g_kps_pred};
+  return mesh_terms_launch(verts, ref_verts, nbr_off, nbr_idx, nc_pairs, vp_off, vp_idx, B, V, P, E, w, loss, g_verts, K, stream);
+}
+
+int harp_texture_terms(const float* tex, const float* nmap, const float* mask, const int32_t* dist_albedo, const int32_t* dist_normal,
+                       int H, int W, float z_scale, const float* w_albedo, float* loss_albedo, float* g_tex, const float* w_normal,
+                       float* loss_normal, float* g_nmap, const float* disp, int n_disp, const float* w_disp, float* loss_disp,
+                       float* g_disp, hipStream_t stream) {
+  if (!tex || !nmap || !dist_albedo || !dist_normal || !loss_albedo || !loss_normal || H <= 0 || W <= 0 || (disp && (!loss_disp || n_disp <= 0)))
+    return HARP_ERR_ARG;
+  TexTerms A;
+  A.tex = tex; A.nmap = nmap; A.mask = mask; A.disp = disp; A.dist_a = dist_albedo; A.dist_n = dist_normal;
+  A.H = H; A.W = W; A.n_disp = n_disp; A.z_scale = z_scale;
+  A.w_a = w_albedo; A.w_n = w_normal; A.w_d = w_disp; A.l_a = loss_albedo; A.l_n = loss_normal; A.l_d = loss_disp;
+  A.g_tex = g_tex; A.g_nmap = g_nmap; A.g_disp = g_disp;
+  A.nb_smooth = min((H * W + 255) / 256, 512);
+  A.nb_disp = disp ? min((n_disp + 255) / 256, 64) : 0;
+  hipLaunchKernelGGL(texture_terms_kernel, dim3(2 * A.nb_smooth + H + A.nb_disp), dim3(256), 0, stream, A);
   HARP_CHECK_LAUNCH();
   return HARP_OK;
 }

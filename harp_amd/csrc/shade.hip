@@ -591,6 +591,20 @@ __global__ void pack_texels_kernel(const float* __restrict__ tex, const float* _
   out[2 * i] = make_float4(tex[3 * i], tex[3 * i + 1], tex[3 * i + 2], nmap[3 * i]);
   out[2 * i + 1] = make_float4(nmap[3 * i + 1], nmap[3 * i + 2], 0.f, 0.f);
 }
+// F.normalize of the raw normal map (losses.hip: normalize3_fwd_kernel, same expression) and the packing above in one launch
+__global__ void normalize_pack_kernel(const float* __restrict__ tex, const float* __restrict__ nmap_raw, int n, float* __restrict__ nmap_n,
+                                      float4* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float a = nmap_raw[3 * i], b = nmap_raw[3 * i + 1], c = nmap_raw[3 * i + 2];
+  const float inv = 1.0f / fmaxf(sqrtf(a * a + b * b + c * c), 1e-12f);
+  const float n0 = a * inv, n1 = b * inv, n2 = c * inv;
+  nmap_n[3 * i] = n0; nmap_n[3 * i + 1] = n1; nmap_n[3 * i + 2] = n2;
+  if (out) {
+    out[2 * i] = make_float4(tex[3 * i], tex[3 * i + 1], tex[3 * i + 2], n0);
+    out[2 * i + 1] = make_float4(n1, n2, 0.f, 0.f);
+  }
+}
 
 // zbuf backward of a K=1 pass (used for the light-view depth map the shadow test gathers from):
 // zbuf = sum_i bary_i z_i  ->  g on the face's NDC vertices (rasterize_meshes_backward, grad_zbuf path).
@@ -598,19 +612,29 @@ __global__ void pack_texels_kernel(const float* __restrict__ tex, const float* _
 // backward scatters into: non-zero only at light-view pixels that hold a face (an empty texel reads depth -1, whose shadow-test sigmoid
 // and gradient are exactly 0), i.e. only inside the tiles this kernel visits — so the image is all-zero again when the kernel is done and
 // the 33.5-MB clear of every step (B x 512 x 512 floats) goes away.
-template <bool CONSUME>
+// NMAP: the launch carries `M.blocks` more workgroups behind the tile workgroups, which apply the chain rule of the normal-map
+// normalisation (losses.hip: normalize3_bwd_kernel) — the other small kernel between the shader backward and the per-frame backward
+// tail; both only need the shader backward's output and neither reads what the other writes.
+struct NmapBwd { const float* x; const float* gy; float* gx; int n; int blocks; };
+template <bool CONSUME, bool NMAP = false>
 __global__ void __launch_bounds__(256) depth_bwd_kernel(const int32_t* __restrict__ face_id, const FaceRec* __restrict__ recs,
                                                         const int32_t* __restrict__ faces, float* __restrict__ g_z,
                                                         int V, int F, int S, float* __restrict__ g_ndc,
                                                         const int32_t* __restrict__ order, const int32_t* __restrict__ nact,
-                                                        int B, int nsx) {
+                                                        int B, int nsx, const NmapBwd M) {
   __shared__ VertexAccum<256, 3> s_acc;
+  const unsigned tile_blocks = NMAP ? gridDim.x - (unsigned)M.blocks : gridDim.x;
+  if (NMAP && blockIdx.x >= tile_blocks) {
+    for (size_t i = (size_t)(blockIdx.x - tile_blocks) * 256 + threadIdx.x; i < (size_t)M.n; i += (size_t)M.blocks * 256)
+      normalize3_bwd_texel(M.x, M.gy, M.gx, i);
+    return;
+  }
   // capped grid: a workgroup strides over the tiles of the super-tiles that hold faces (launch order).  The full grid is 16 workgroups
   // per (frame, super-tile) — 32 768 at 512^2, 131 072 at 1024^2 — of which a sixth have work here, and this small kernel was as long
   // as their dispatch (0.7 ns each: 24 us at 512^2, 107 us at 1024^2).  (The rasterisers keep the full grid: their tiles differ too much
   // in cost for a static assignment, measured.)
   const unsigned limit = (unsigned)(((nact[0] + 7) / 8) * 8 * (kSuper / kTile) * (kSuper / kTile));
-  for (unsigned vb = blockIdx.x; vb < limit; vb += gridDim.x) {
+  for (unsigned vb = blockIdx.x; vb < limit; vb += tile_blocks) {
   if (vb != blockIdx.x) __syncthreads();                 // s_acc of the previous tile has been flushed
   int b, st, tx0, ty0, tsub;
   if (tile_decode_v(vb, order, nact, B, nsx, S, b, st, tx0, ty0, tsub, false) != 1) continue;   // no tile / super-tile without a single face
@@ -730,7 +754,7 @@ int harp_depth_bwd(const int32_t* face_id, const void* ws, const int32_t* faces,
   if (!face_id || !ws || !faces || !g_z || !g_ndc) return HARP_ERR_ARG;
   const RasterWs W = raster_ws_split((void*)ws, B, F, S);
   hipLaunchKernelGGL(depth_bwd_kernel<false>, dim3(min(tile_grid(B, W.nsx), 4096u)), dim3(256), 0, stream, face_id, (const FaceRec*)ws, faces, (float*)g_z, V, F, S,
-                     g_ndc, (const int32_t*)W.order, (const int32_t*)W.nact, B, W.nsx);
+                     g_ndc, (const int32_t*)W.order, (const int32_t*)W.nact, B, W.nsx, NmapBwd{});
   HARP_CHECK_LAUNCH();
   return HARP_OK;
 }
@@ -741,7 +765,26 @@ int harp_depth_bwd_consume(const int32_t* face_id, const void* ws, const int32_t
   if (!face_id || !ws || !faces || !g_z || !g_ndc) return HARP_ERR_ARG;
   const RasterWs W = raster_ws_split((void*)ws, B, F, S);
   hipLaunchKernelGGL(depth_bwd_kernel<true>, dim3(min(tile_grid(B, W.nsx), 4096u)), dim3(256), 0, stream, face_id, (const FaceRec*)ws, faces, g_z, V, F, S, g_ndc,
-                     (const int32_t*)W.order, (const int32_t*)W.nact, B, W.nsx);
+                     (const int32_t*)W.order, (const int32_t*)W.nact, B, W.nsx, NmapBwd{});
+  HARP_CHECK_LAUNCH();
+  return HARP_OK;
+}
+
+// harp_depth_bwd_consume + harp_normalize3_bwd(nmap, g_nmap_n, n_texels, g_nmap) as ONE launch
+int harp_depth_nmap_bwd(const int32_t* face_id, const void* ws, const int32_t* faces, float* g_z, int B, int V, int F, int S, float* g_ndc,
+                        const float* nmap, const float* g_nmap_n, int n_texels, float* g_nmap, hipStream_t stream) {
+  if (!face_id || !ws || !faces || !g_z || !g_ndc || !nmap || !g_nmap_n || !g_nmap || n_texels <= 0) return HARP_ERR_ARG;
+  const RasterWs W = raster_ws_split((void*)ws, B, F, S);
+  const NmapBwd M{nmap, g_nmap_n, g_nmap, n_texels, min((n_texels + 255) / 256, 1024)};
+  hipLaunchKernelGGL((depth_bwd_kernel<true, true>), dim3(min(tile_grid(B, W.nsx), 4096u) + (unsigned)M.blocks), dim3(256), 0, stream, face_id,
+                     (const FaceRec*)ws, faces, g_z, V, F, S, g_ndc, (const int32_t*)W.order, (const int32_t*)W.nact, B, W.nsx, M);
+  HARP_CHECK_LAUNCH();
+  return HARP_OK;
+}
+
+int harp_normalize3_pack(const float* tex, const float* nmap_raw, int n_texels, float* nmap_n, float* packed, hipStream_t stream) {
+  if (!nmap_raw || !nmap_n || n_texels <= 0 || (packed && !tex)) return HARP_ERR_ARG;
+  hipLaunchKernelGGL(normalize_pack_kernel, dim3((n_texels + 255) / 256), dim3(256), 0, stream, tex, nmap_raw, n_texels, nmap_n, (float4*)packed);
   HARP_CHECK_LAUNCH();
   return HARP_OK;
 }

@@ -142,6 +142,7 @@ class FitEngine:
         self.target_offset = 0
         self.w_vec = torch.zeros(16, dtype=torch.float32, device=self.dev)
         self._main["loss_vec"], self._main["w_vec"] = self.loss_vec, self.w_vec
+        self.loss_acc = torch.zeros(16, dtype=torch.float32, device=self.dev)      # fold_step: the terms accumulate here, hand_back moves them to loss_vec and clears
         self._main["owns_shared"] = True               # its zero slab also covers g_buf / g_nmap_n / loss_vec
         self._activate(self._main)
         self.dist_albedo = torch.zeros(tex_size, tex_size, 2, dtype=torch.int32, device=self.dev)
@@ -175,6 +176,8 @@ class FitEngine:
         self.fused_bwd = False           # shading + silhouette backward in ONE launch (harp_shade_sil_bwd): correct, measured SLOWER (1.05 vs 0.93 ms: the rasteriser tiles inherit 168 VGPRs / 3 waves per SIMD)
         self.tail_side = False           # normal-map chain rule (+ early all-reduce) on the second stream: measured SLOWER (0.960 vs 0.948 ms: the extra cross-stream edge costs more than the 5-us kernel it moves)
         self.camera_first = True        # enqueue the camera-view raster chain (the longer one) before the light-view chain: +0.75 %
+        self.fold_step = True            # scheduled steps: the batch row is fetched by hand_front itself, the loss vector / schedule row / draw counter are turned over by hand_back, the slab clear + Adam tick + offset draw are ONE launch (harp_step_frame, harp_step_prologue): 31 -> 23 kernels per step, no schedule kernel in front of the hand layer
+        self.fused_terms = True          # normalise + pack, the four parameter-only regularisers, key-point + mesh terms, depth backward + normal-map chain rule: one launch each (were 2 + 4 + 2 + 2)
         self.frozen = ()                 # parameters kept out of the optimiser groups (known_appearance)
         self.disabled_terms = frozenset()   # loss terms left out of the objective altogether (set_disabled_terms)
         self.schedule = None
@@ -276,10 +279,12 @@ class FitEngine:
         c.focal, c.shadow, c.has_normal_grad = self.focal, int(shadow), int(has_normal_grad)
         return c
 
-    def _hand_struct(self, fid, B, shadow, has_normal_grad):
+    def _hand_struct(self, fid, B, shadow, has_normal_grad, step=None):
         """harp_hand_front over the active lane's scratch: the one-launch front (csrc/hand_front.hip) and the three-launch back (csrc/hand_back.hip)"""
         s, p = self.s, _lib.ptr
         h = _lib.HandFront()
+        if step is not None:
+            h.step = step
         h.chain, h.mano, h.tables = self._chain_struct(B, shadow, has_normal_grad), self.dm.struct, self.tables
         for k, t in (("fid", fid), ("pose48", s["pose48"]), ("betas", s["betas"]), ("trans_b", s["trans_b"]), ("cam_R", s["cam_R"]),
                      ("cam_T", s["cam_T"]), ("light_pos", s["light_pos"]), ("colors", s["colors"]), ("lbs_ws", s["lbs_ws"])):
@@ -287,14 +292,16 @@ class FitEngine:
         h.self_shadow = int(self.self_shadow)
         return h
 
-    def _mesh_forward(self, fid, B, shadow=False, front=False):
+    def _mesh_forward(self, fid, B, shadow=False, front=False, step=None):
         """frame_setup .. normals (and, fused, both projections + the light camera): fills the scratch geometry for the B frames in
         `fid` (int32 device tensor).  Returns True when the fused chain ran (projections / light camera already done).  front=True
         allows the one-launch form of the whole front (MANO path, csrc/hand_front.hip)."""
         L, s, p, st, tp = _lib.lib(), self.s, _lib.ptr, _lib.stream(), self.topo
         if front and self.fused_front and self.fused_chain:
-            self._ck(L.harp_hand_front_fwd(ctypes.byref(self._hand_struct(fid, B, shadow, False)), st), "hand_front_fwd")
+            self._ck(L.harp_hand_front_fwd(ctypes.byref(self._hand_struct(fid, B, shadow, False, step)), st), "hand_front_fwd")
             return True
+        if step is not None:
+            raise RuntimeError("a folded step needs the one-launch front (fused_front)")
         self._ck(L.harp_frame_setup_fwd(ctypes.byref(self.tables), p(fid), B, self.S, self.focal, int(self.self_shadow), p(s["pose48"]),
                                         p(s["betas"]), p(s["trans_b"]), p(s["cam_R"]), p(s["cam_T"]), p(s["light_pos"]), p(s["colors"]), st),
                  "frame_setup_fwd")
@@ -340,13 +347,35 @@ class FitEngine:
             setattr(a, k, _lib.ptr(t))
         return a
 
-    def forward_backward(self, coarse=True, app=True, B=None, shared_terms=True, tick=False):
+    def _can_fold(self):
+        """the step's book-keeping rides in hand_front / hand_back / harp_step_prologue (`fold_step`) when those launches exist"""
+        return bool(self.fold_step and self.fused_front and self.fused_chain and self.fused_back and self.overlap and self.early_terms
+                    and self.schedule is not None and self._lane.get("owns_shared"))
+
+    def forward_backward(self, coarse=True, app=True, B=None, shared_terms=True, tick=False, sched=False):
         """Enqueue forward + losses + backward for the first B (default: the lane's size) frames of the active lane; gradients land
         in self.g_buf, loss terms in loss_vec[:9] (unweighted, order LOSS_NAMES).  shared_terms=False skips everything that does not
         depend on the frames (gradient-arena zeroing, offset draw, normal-map normalisation, displacement / texture regularisers)."""
         lane = self._lane
         B = lane["B"] if B is None else int(B)
         lfid, ltfid, lloss = lane["fid"], lane["tfid"], lane["loss_vec"]
+        # sched: take the next row of the device schedule INSIDE this step's launches (step() passes it when _can_fold()): hand_front fetches
+        # the row, the terms accumulate into loss_acc (always clean between steps), hand_back moves them to the lane's loss vector, clears
+        # loss_acc and advances the schedule row and the draw counter
+        fold = bool(sched)
+        frame = None
+        if fold:
+            if B != lane["B"] or not shared_terms or not self._can_fold():
+                raise RuntimeError("forward_backward(sched=True) needs the full batch, the shared terms and _can_fold()")
+            frame = _lib.StepFrame()
+            frame.schedule, frame.sched_row = _lib.ptr(self.schedule), _lib.ptr(self.schedule_row)
+            frame.n_rows, frame.target_offset = int(self.schedule.shape[0]), int(self.target_offset)
+            frame.tfid_out, frame.clear_mesh_grads = _lib.ptr(ltfid), 1
+            frame.loss, frame.loss_out, frame.n_loss = _lib.ptr(self.loss_acc), _lib.ptr(lloss), 16
+            if app and self.auto_draw:
+                frame.draw_counter = _lib.ptr(self.draw_counter)
+            lloss = self.loss_acc
+            self._loss_cleared = True
         L, s, p, ST, tp, S = _lib.lib(), self.s, _lib.ptr, _lib.stream, self.topo, self.S
         cur, side = torch.cuda.current_stream(), self._side_stream()
         V, F = tp.V, tp.F
@@ -367,7 +396,7 @@ class FitEngine:
             pass
         else:
             self.gs_zero.zero_()                         # main lane: one fill also covers g_buf, g_nmap_n and the loss vector
-            if not mesh_on_third:
+            if not mesh_on_third and not fold:
                 self.gs_mesh.zero_()
             if not lane.get("owns_shared"):
                 lloss.zero_()
@@ -384,28 +413,56 @@ class FitEngine:
         # ---- terms that depend on the parameters only (normal-map normalisation, texture regularisers, displacement regulariser) go
         #      first on the second stream: they run under the LBS / mesh chain, which is a string of small latency-bound launches
         def param_terms():
-            if fill_side:
-                self.gs_zero[:-16].zero_()               # everything but the loss vector (last 16 floats of the slab)
-                if not mesh_on_third:
-                    self.gs_mesh.zero_()
+            if fold:
+                # slab clear + Adam tick + offset draw: ONE launch (the draw counter is advanced by hand_back at the end of the step)
+                zero = self.gs_zero[:-16] if fill_side else None
+                hy, nh = (None, 0)
+                if tick and (coarse or app):
+                    hy, nh = (self.hyper.data_ptr(), 2) if (coarse and app) else (self.hyper.data_ptr() + (0 if coarse else 1) * self._hyper_stride, 1)
+                draw = app and self.auto_draw
+                self._ck(L.harp_step_prologue(p(zero) if zero is not None else None, zero.numel() if zero is not None else 0, hy, nh, self.seed,
+                                              p(self.draw_counter), self.Ht, self.Wt, 1.0, p(self.dist_albedo) if draw else None, 2.0,
+                                              p(self.dist_normal) if draw else None, ST()), "step_prologue")
+            else:
+                if fill_side:
+                    self.gs_zero[:-16].zero_()               # everything but the loss vector (last 16 floats of the slab)
+                    if not mesh_on_third:
+                        self.gs_mesh.zero_()
+                if tick:
+                    self._adam_tick(coarse, app)             # only touches the hyper-parameter block: off the serial tail of the step
             if not self.consume_gzl:
                 self.gs_zero_late.zero_()
-            if tick:
-                self._adam_tick(coarse, app)             # only touches the hyper-parameter block: off the serial tail of the step
+            disp_reg = coarse and shared_terms and "vert_disp_reg" not in off
             if app and shared_terms:
-                if self.auto_draw:
+                if self.auto_draw and not fold:
                     self.draw_texture_offsets()
-                self._ck(L.harp_normalize3_fwd(p(self.params["normal_map"]), self.Ht * self.Wt, p(s["nmap_n"]), ST()), "normalize3")
-                if self.packed_texels:
-                    self._ck(L.harp_pack_texels(p(self.params["texture"]), p(s["nmap_n"]), self.Ht * self.Wt, p(self.texnm), ST()), "pack_texels")
-                self._texture_terms(wp, lp)
-            if coarse and shared_terms and "vert_disp_reg" not in off:
+                nt = self.Ht * self.Wt
+                if self.fused_terms:
+                    self._ck(L.harp_normalize3_pack(p(self.params["texture"]), p(self.params["normal_map"]), nt, p(s["nmap_n"]),
+                                                    p(self.texnm) if self.packed_texels else None, ST()), "normalize3_pack")
+                    self._ck(L.harp_texture_terms(p(self.params["texture"]), p(self.params["normal_map"]), p(self.uv_mask), p(self.dist_albedo),
+                                                  p(self.dist_normal), self.Ht, self.Wt, 0.2, wp(7), lp(7), p(self.grads["texture"]), wp(8), lp(8),
+                                                  p(self.grads["normal_map"]), p(self.params["verts_disps"]) if disp_reg else None, V, wp(2), lp(2),
+                                                  p(self.grads["verts_disps"]), ST()), "texture_terms")
+                    disp_reg = False
+                else:
+                    self._ck(L.harp_normalize3_fwd(p(self.params["normal_map"]), nt, p(s["nmap_n"]), ST()), "normalize3")
+                    if self.packed_texels:
+                        self._ck(L.harp_pack_texels(p(self.params["texture"]), p(s["nmap_n"]), nt, p(self.texnm), ST()), "pack_texels")
+                    self._texture_terms(wp, lp)
+            if disp_reg:
                 self._ck(L.harp_sum_squares(p(self.params["verts_disps"]), V, wp(2), lp(2), p(self.grads["verts_disps"]), ST()), "disp_reg")
 
         def mesh_terms():
-            if coarse and "kps_anchor" not in off:
+            kps_on, reg_on = coarse and "kps_anchor" not in off, coarse and not off.issuperset(("laplacian", "normal", "arap"))
+            if kps_on and reg_on and self.fused_terms:
+                self._ck(L.harp_mesh_kps_terms(p(s["vd"]), p(self.ref_verts), p(tp.nbr_off), p(tp.nbr_idx), p(tp.nc_pairs), p(tp.vp_off), p(tp.vp_idx), B, V,
+                                               tp.nc_pairs.shape[0], tp.E, wp(3), lp(3), p(s["g_vd"]), p(self.init_joints), p(lfid), p(s["joints_m"]),
+                                               self.n_joints, wp(1), lp(1), p(s["g_joints_m"]), ST()), "mesh_kps_terms")
+                return
+            if kps_on:
                 self._ck(L.harp_kps_loss(p(self.init_joints), p(lfid), p(s["joints_m"]), B, self.n_joints, wp(1), lp(1), p(s["g_joints_m"]), ST()), "kps")
-            if coarse and not off.issuperset(("laplacian", "normal", "arap")):      # (individually disabled ones carry weight 0)
+            if reg_on:      # (individually disabled ones carry weight 0)
                 self._ck(L.harp_mesh_regularizers(p(s["vd"]), p(self.ref_verts), p(tp.nbr_off), p(tp.nbr_idx), p(tp.nc_pairs), p(tp.vp_off), p(tp.vp_idx), B, V,
                                                   tp.nc_pairs.shape[0], tp.E, wp(3), lp(3), p(s["g_vd"]), ST()), "mesh_reg")
         # Capture order matters to the replay: of the kernels that depend on one node, hipGraph keeps the FIRST-captured one on
@@ -418,7 +475,7 @@ class FitEngine:
             with torch.cuda.stream(side):
                 param_terms()
         ev0 = cur.record_event() if go else None
-        fused = self._mesh_forward(lfid, B, shadow, front=True)      # fused chain: both projections and the light camera are done as well
+        fused = self._mesh_forward(lfid, B, shadow, front=True, step=frame)      # fused chain: both projections and the light camera are done as well
         if go:
             wait_e(side, ev0)
             with torch.cuda.stream(side):
@@ -439,7 +496,8 @@ class FitEngine:
                     else:
                         wait_e(third, fork)
                     with torch.cuda.stream(third):
-                        self.gs_mesh.zero_()
+                        if not fold:                     # (a folded step: hand_front cleared its frames' slices)
+                            self.gs_mesh.zero_()
                         mesh_terms()
             if not go:
                 third_branch()
@@ -541,15 +599,25 @@ class FitEngine:
                     self._ck(L.harp_normalize3_bwd(p(self.params["normal_map"]), p(s["g_nmap_n"]), self.Ht * self.Wt, p(self.grads["normal_map"]), ST()),
                              "normalize3_bwd")
                     self._allreduce_maps_early()
-                if self.tail_side and self.overlap:
+                # the chain rule of the normal map rides in the depth backward's launch when both exist (harp_depth_nmap_bwd)
+                nmap_in_depth = self.fused_terms and self.self_shadow and self.consume_gzl and not (self.tail_side and self.overlap)
+                if nmap_in_depth:
+                    self._ck(L.harp_depth_nmap_bwd(p(s["face_l"]), p(s["ws_l"]), p(tp.faces), p(s["g_zl"]), B, V, F, S, p(s["g_ndc_l"]),
+                                                   p(self.params["normal_map"]), p(s["g_nmap_n"]), self.Ht * self.Wt, p(self.grads["normal_map"]), ST()),
+                             "depth_nmap_bwd")
+                    self._allreduce_maps_early()
+                elif self.tail_side and self.overlap:
                     wait_s(side, cur)
                     with torch.cuda.stream(side):
                         maps_tail()
                 else:
                     maps_tail()
+            else:
+                nmap_in_depth = False
             if self.self_shadow:
-                depth_bwd = L.harp_depth_bwd_consume if self.consume_gzl else L.harp_depth_bwd
-                self._ck(depth_bwd(p(s["face_l"]), p(s["ws_l"]), p(tp.faces), p(s["g_zl"]), B, V, F, S, p(s["g_ndc_l"]), ST()), "depth_bwd")
+                if not nmap_in_depth:
+                    depth_bwd = L.harp_depth_bwd_consume if self.consume_gzl else L.harp_depth_bwd
+                    self._ck(depth_bwd(p(s["face_l"]), p(s["ws_l"]), p(tp.faces), p(s["g_zl"]), B, V, F, S, p(s["g_ndc_l"]), ST()), "depth_bwd")
                 if not fused:
                     self._ck(L.harp_project_bwd(p(s["vd"]), p(s["light_R"]), p(s["light_T"]), p(s["g_ndc_l"]), B, V, self.focal, S, p(s["g_vd"]),
                                                 p(s["g_light_R"]), p(s["g_light_T"]), ST()), "project_bwd_l")
@@ -559,9 +627,11 @@ class FitEngine:
             wait_s(cur, side)                       # silhouette_bwd -> g_ndc_c (normal-map chain rule with tail_side)
         if fused and self.fused_front and self.fused_back:
             # the whole backward tail — mesh chain, hand layer, scatter into the parameter tables' gradient rows — as three launches
-            self._ck(L.harp_hand_back_bwd(ctypes.byref(self._hand_struct(lfid, B, shadow, app)), p(s["g_colors"]) if app else None,
+            self._ck(L.harp_hand_back_bwd(ctypes.byref(self._hand_struct(lfid, B, shadow, app, frame)), p(s["g_colors"]) if app else None,
                                           p(s["g_betas"]), ST()), "hand_back_bwd")
             return
+        if fold:
+            raise RuntimeError("a folded step needs the fused backward tail (fused_back)")
         if fused:
             # projections, light camera, both vertex-normal passes, displacement, subdivision and the mm scaling: one launch
             self._ck(L.harp_mesh_chain_bwd(ctypes.byref(self._chain_struct(B, shadow, app)), ST()), "mesh_chain_bwd")
@@ -835,8 +905,9 @@ class FitEngine:
         if self._stage != key:
             self.set_stage(coarse, app)
             self._stage = key
-        fb0 = lambda: self.forward_backward(coarse, app, B=n, tick=True)
-        fb = (lambda: (self._schedule_next(), fb0())) if scheduled else fb0
+        fold = scheduled and self._can_fold()
+        fb0 = lambda: self.forward_backward(coarse, app, B=n, tick=True, sched=fold)
+        fb = (lambda: (self._schedule_next(), fb0())) if (scheduled and not fold) else fb0
         dist_on = self._dist_on()
         graph_ok = (not dist_on) or self.comm is not None or self.graph_collectives
         if not use_graph or n != self.B or not graph_ok or (app and self.perceptual is not None and not self.graph_perceptual):
@@ -847,7 +918,7 @@ class FitEngine:
         # every switch the enqueued launch sequence depends on is part of the key: flipping one re-captures instead of replaying a
         # graph recorded for another configuration
         gkey = (coarse, app, scheduled, self.keep_image, self.fused_loss, self.self_shadow, tuple(self.frozen), self.overlap, self.early_terms,
-                self.packed_texels, self.fused_keep, self.mesh_third, self.graph_order, self.auto_draw, self.mesh_terms_first, self.camera_first, self.tail_side, self.fused_bwd, self.fused_chain, self.fused_front, self.fused_back, self.consume_gzl, self.keep_depth, dist_on, self.overlap_allreduce,
+                self.packed_texels, self.fused_keep, self.mesh_third, self.graph_order, fold, self.fused_terms, self.auto_draw, self.mesh_terms_first, self.camera_first, self.tail_side, self.fused_bwd, self.fused_chain, self.fused_front, self.fused_back, self.consume_gzl, self.keep_depth, dist_on, self.overlap_allreduce,
                 self.comm is not None, self.perceptual is not None and app)
         g = self._graphs.get(gkey)
         if g is None:

@@ -64,6 +64,10 @@ int harp_depth_bwd(const int32_t* face_id, const void* ws, const int32_t* faces,
  * image that was all-zero before the step's harp_shade_bwd is all-zero again after this call and needs no per-step clear. */
 int harp_depth_bwd_consume(const int32_t* face_id, const void* ws, const int32_t* faces, float* g_z, int B, int V, int F, int S,
                            float* g_ndc, hipStream_t stream);
+/* harp_depth_bwd_consume + harp_normalize3_bwd(nmap, g_nmap_n, n_texels, g_nmap) as ONE launch: the two small passes between the shader
+ * backward and the per-frame backward tail of a fitting step (neither reads what the other writes) */
+int harp_depth_nmap_bwd(const int32_t* face_id, const void* ws, const int32_t* faces, float* g_z, int B, int V, int F, int S, float* g_ndc,
+                        const float* nmap, const float* g_nmap_n, int n_texels, float* g_nmap, hipStream_t stream);
 
 /* ---- fragment-level rasterisation (the PyTorch3D op pair itself; NOT on the fitting loop's path) -----------------------------
  * replaces _C.rasterize_meshes(face_verts, mesh_to_face_first_idx, num_faces_per_mesh, clipped_faces_neighbor_idx, image_size,
@@ -146,6 +150,8 @@ typedef struct harp_shade_args {
 } harp_shade_args;
 /* interleaves albedo (Ht*Wt,3) and the normalised normal map (Ht*Wt,3) into out (Ht*Wt,8): [r g b nx | ny nz 0 0], 16-B aligned */
 int harp_pack_texels(const float* tex, const float* nmap, int n_texels, float* out, hipStream_t stream);
+/* harp_normalize3_fwd(nmap_raw) -> nmap_n and harp_pack_texels(tex, nmap_n) -> packed (may be NULL) in ONE launch */
+int harp_normalize3_pack(const float* tex, const float* nmap_raw, int n_texels, float* nmap_n, float* packed, hipStream_t stream);
 int harp_shade_fwd(const harp_shade_args* a, hipStream_t stream);
 /* backward of the shading pass.  g_rgb != NULL: plain backward of an upstream gradient image.  g_rgb == NULL (FUSED-LOSS mode, needs
  * l1_target / l1_fid / l1_w / l1_loss / l1_bg_sums): no harp_shade_fwd call is needed at all — the pass recomputes the colour anyway,
@@ -301,6 +307,12 @@ int harp_kps_loss(const float* gt, const int32_t* fid, const float* pred, int B,
 int harp_mesh_regularizers(const float* verts, const float* ref_verts, const int32_t* nbr_off, const int32_t* nbr_idx,
                            const int32_t* nc_pairs, const int32_t* vp_off, const int32_t* vp_idx, int B, int V, int P, int E,
                            const float* w, float* loss, float* g_verts, hipStream_t stream);
+/* harp_mesh_regularizers + harp_kps_loss (kps_gt, fid, kps_pred, n_joints_pred, w_kps, loss_kps, g_kps_pred as there) in ONE launch:
+ * both run between the hand layer and the backward pass of a fitting step and depend on nothing else (optimize_sequence.py:523-537) */
+int harp_mesh_kps_terms(const float* verts, const float* ref_verts, const int32_t* nbr_off, const int32_t* nbr_idx,
+                        const int32_t* nc_pairs, const int32_t* vp_off, const int32_t* vp_idx, int B, int V, int P, int E,
+                        const float* w, float* loss, float* g_verts, const float* kps_gt, const int32_t* fid, const float* kps_pred,
+                        int n_joints_pred, const float* w_kps, float* loss_kps, float* g_kps_pred, hipStream_t stream);
 /* torch.sum(verts_disps ** 2) (optimize_sequence.py:533) */
 int harp_sum_squares(const float* x, int n, const float* w, float* loss, float* g, hipStream_t stream);
 /* torch.nn.MSELoss()(x, y) over n elements, ACCUMULATED into *loss (zero it first), and d/dx written to g_x (may be NULL): the
@@ -314,6 +326,14 @@ int harp_texture_smooth_reg(const float* tex, const int32_t* dist, const float* 
  * *counter_dev (one int, device memory) is advanced on the device after the draw, so graph replays draw fresh offsets. */
 int harp_draw_texture_offsets(unsigned seed, int* counter_dev, int H, int W, float std, int32_t* dist, float std2, int32_t* dist2,
                               hipStream_t stream);
+/* The parameter-only regularisers of a step in ONE launch (optimize_sequence.py:533, 549-551): harp_texture_smooth_reg(tex, dist_albedo)
+ * -> loss_albedo / g_tex, harp_close_to_z_reg(nmap, z_scale) + harp_texture_smooth_reg(nmap, dist_normal) -> loss_normal / g_nmap (one
+ * weight, as the reference adds the two into one term), and — when disp != NULL — harp_sum_squares(disp, n_disp) -> loss_disp / g_disp.
+ * Same per-element arithmetic as the stand-alone calls; the gradient images are accumulated with atomics. */
+int harp_texture_terms(const float* tex, const float* nmap, const float* mask, const int32_t* dist_albedo, const int32_t* dist_normal,
+                       int H, int W, float z_scale, const float* w_albedo, float* loss_albedo, float* g_tex, const float* w_normal,
+                       float* loss_normal, float* g_nmap, const float* disp, int n_disp, const float* w_disp, float* loss_disp,
+                       float* g_disp, hipStream_t stream);
 /* scale * close_to_z_reg (loss/texture_reg.py:40-45) */
 int harp_close_to_z_reg(const float* nm, int H, int W, float scale, const float* w, float* loss, float* g_nm, hipStream_t stream);
 /* F.normalize(normal_map, dim=-1) (utils/visualize.py:99); n = number of texels */
@@ -336,6 +356,11 @@ int harp_adam_apply(float* p, const float* g, float* m, float* v, size_t n, cons
  * arenas step with h2_dev[0], elements [o1, o1+n1) with h2_dev[1] */
 int harp_adam_apply2(float* p, const float* g, float* m, float* v, size_t o0, size_t n0, size_t o1, size_t n1,
                      const harp_adam_hyper* h2_dev, hipStream_t stream);
+/* The head of a fitting step's parameter-only work in ONE launch (any part optional): zero[0..n_zero) = 0 (the step's gradient slab),
+ * harp_adam_tick(hyper, n_hyper), and the draw of harp_draw_texture_offsets for the CURRENT value of *draw_counter — which is NOT
+ * advanced here (harp_step_frame.draw_counter: the epilogue of the same step advances it). */
+int harp_step_prologue(float* zero, size_t n_zero, harp_adam_hyper* hyper_dev, int n_hyper, unsigned seed, const int* draw_counter,
+                       int H, int W, float std, int32_t* dist, float std2, int32_t* dist2, hipStream_t stream);
 
 /* ---- per-frame glue of the fitting loop ---------------------------------------------------------------------------
  * replaces the row gathers params[k][fid] of utils/visualize.py:26-27,38-39 / optimize_sequence.py:464, the camera
@@ -365,6 +390,26 @@ int harp_frame_setup_bwd(const harp_frame_tables* t, const int32_t* fid, int B, 
  * ONE launch = harp_frame_setup_fwd + harp_lbs_mano_fwd + harp_mesh_chain_fwd.  chain.verts_mm / chain.joints_mm are OUTPUTS
  * here; chain.cam_R / cam_T / light_pos must alias cam_R / cam_T / light_pos below (written by this call).  tables.wrist_pose
  * must be NULL (MANO rows), chain.V0 = 778, chain.NJ = 21. */
+/* Optional book-keeping of a fitting step carried by the two per-frame launches instead of kernels of their own (all NULL / 0: none).
+ * Front (harp_hand_front_fwd): with `schedule` set, workgroup b takes its frame from row (sched_row[0] mod n_rows) of the (n_rows,B)
+ * device schedule and WRITES it to fid[b] (fid is then an output) and fid - target_offset to tfid_out[b] — the DataLoader's batch
+ * (optimize_sequence.py:396-399, :446), what harp_schedule_next does as a launch; clear_mesh_grads: chain.g_vd / chain.g_joints_m of
+ * the frame are zeroed (the two gradient segments the key-point / mesh terms accumulate into).
+ * Back (harp_hand_back_bwd; every kernel that adds to the loss vector has finished by then): sched_row[0] = row + 1;
+ * loss_out[0..n_loss) = loss[0..n_loss) and loss[..] = 0 (the terms of the NEXT step accumulate into a clean vector, no clear at the
+ * head of a step); draw_counter[0] += 1 (harp_draw_texture_offsets_at of the next step draws fresh offsets). */
+typedef struct harp_step_frame {
+  const int32_t* schedule;
+  int32_t* sched_row;
+  int n_rows, target_offset;
+  int32_t* tfid_out;
+  int clear_mesh_grads;
+  float* loss;
+  float* loss_out;
+  int n_loss;
+  int32_t* draw_counter;
+} harp_step_frame;
+
 typedef struct harp_hand_front {
   harp_mesh_chain chain;
   harp_mano_model mano;
@@ -373,6 +418,7 @@ typedef struct harp_hand_front {
   float *pose48, *betas, *trans_b, *cam_R, *cam_T, *light_pos, *colors;   /* as harp_frame_setup_fwd */
   float* lbs_ws;             /* harp_lbs_mano_ws_floats(B) floats, kept for harp_lbs_mano_bwd */
   int self_shadow;           /* colours from amb_ratio (shadow renderer) or the fixed Phong lights */
+  harp_step_frame step;      /* optional prologue / epilogue of a fitting step (zero-initialised: none) */
 } harp_hand_front;
 int harp_hand_front_fwd(const harp_hand_front* h, hipStream_t stream);
 /* The counterpart for the backward tail of a step (csrc/hand_back.hip): harp_mesh_chain_bwd + harp_lbs_mano_bwd + harp_frame_setup_bwd

@@ -1058,7 +1058,9 @@ def test_light_camera_incl_look_at_replacement_branch():
 @pytest.mark.parametrize("switches", [dict(graph_order=False), dict(mesh_third=False), dict(camera_first=False), dict(overlap=False),
                                       dict(graph_order=False, mesh_third=False), dict(mesh_third=False, camera_first=False),
                                       dict(graph_order=False, mesh_third=False, camera_first=False), dict(early_terms=False),
-                                      dict(mesh_terms_first=False, mesh_third=False), dict(tail_side=True), dict(consume_gzl=False), dict(keep_depth=False)])
+                                      dict(mesh_terms_first=False, mesh_third=False), dict(tail_side=True), dict(consume_gzl=False), dict(keep_depth=False),
+                                      dict(fold_step=False), dict(fused_terms=False), dict(fold_step=False, fused_terms=False),
+                                      dict(fold_step=False, mesh_third=False), dict(fused_terms=False, consume_gzl=False)])
 def test_schedule_switches_give_the_default_schedules_result(switches):
     """The stream / capture-order switches of FitEngine (graph_order, mesh_third, camera_first, overlap, early_terms, mesh_terms_first,
     tail_side) only move launches between streams: losses and the whole gradient arena of every non-default combination must equal the
@@ -1097,6 +1099,78 @@ def test_schedule_switches_give_the_default_schedules_result(switches):
     finally:
         for k, v in defaults.items():
             setattr(eng, k, v)
+
+
+def test_folded_step_bookkeeping_equals_the_separate_kernels():
+    """`fold_step`: the batch row fetched by hand_front, loss vector / schedule row / draw counter turned over by hand_back, slab clear +
+    Adam tick + offset draw in ONE launch (harp_step_frame, harp_step_prologue) — against an identical engine that runs harp_schedule_next,
+    the fills, harp_adam_tick, harp_draw_texture_offsets and the un-fused terms as launches of their own.  Several steps over a
+    multi-row schedule with fresh offset draws and a non-zero learning rate, eagerly and graph-replayed: the same frames, the same draws,
+    the same optimiser state after every step."""
+    from tests._scene import make_fit_case
+    cases = [make_fit_case("hand", T=6, S=128, B=3, seed=9, device=DEV) for _ in range(2)]
+    sched = torch.tensor([[0, 1, 2], [3, 4, 5], [5, 0, 3], [2, 2, 4]]).int()          # (a frame may repeat inside a batch)
+    for c, fold in zip(cases, (True, False)):
+        eng = c["eng"]
+        eng.keep_image = False
+        eng.fold_step = eng.fused_terms = fold
+        eng.set_schedule(sched)
+    a, b = cases[0]["eng"], cases[1]["eng"]
+    assert a._can_fold() and not b._can_fold()
+    step, draws0 = 0, a.draw_counter.item()
+    for graph in (False, True):
+        for _ in range(5):
+            for c in cases:
+                c["eng"].step(None, True, True, use_graph=graph)
+            torch.cuda.synchronize()
+            step += 1
+            assert torch.equal(a.fid, b.fid) and torch.equal(a.tfid, b.tfid), (step, a.fid, b.fid)
+            assert a.schedule_row.item() == b.schedule_row.item() and a.draw_counter.item() == b.draw_counter.item() == draws0 + step
+            assert torch.equal(a.dist_albedo, b.dist_albedo) and torch.equal(a.dist_normal, b.dist_normal)
+            assert torch.equal(a.hyper, b.hyper)                                            # step counts and bias corrections
+            la, lb = a.loss_vec[:9].double(), b.loss_vec[:9].double()
+            assert ((la - lb).abs() <= 1e-5 * lb.abs() + 1e-9).all(), (step, la, lb)
+            assert a.loss_acc.abs().max().item() == 0.0                                     # clean for the next step
+            assert rel(a.g_buf.double(), b.g_buf.double()) < 1e-4, (step, rel(a.g_buf.double(), b.g_buf.double()))
+            d = (a.p_buf - b.p_buf).abs()
+            assert d.mean().item() < 1e-6 and (d > 1e-3).float().mean().item() < 1e-4, (step, d.mean().item(), d.max().item())
+            # teacher forcing: Adam turns the order noise of the float atomics into sign flips of near-zero updates, which would compound
+            for k in ("p_buf", "m_buf", "v_buf"):
+                getattr(b, k).copy_(getattr(a, k))
+    assert a.losses().keys() == b.losses().keys()
+
+
+def test_step_prologue_equals_fill_tick_and_draw():
+    """harp_step_prologue against torch's fill, harp_adam_tick and harp_draw_texture_offsets — with a slab that starts and ends off a
+    16-byte boundary, and with parts left out"""
+    from harp_amd import _lib
+    L, p = _lib.lib(), _lib.ptr
+    H = W = 96
+    for off, n in ((0, 4096), (1, 4099), (3, 5), (2, 1), (0, 0)):
+        buf = torch.full((n + 8,), 7.0, device=DEV)
+        hy = torch.zeros(2 * 8, dtype=torch.float32, device=DEV)
+        hv = hy.view(2, 8)
+        hv[:, 0], hv[:, 1], hv[:, 2], hv[:, 3], hv[:, 4] = torch.tensor([1e-3, 1e-2], device=DEV), 0.9, 0.999, 1e-8, 1.0
+        hy2 = hy.clone()
+        cnt = torch.tensor([5], dtype=torch.int32, device=DEV)
+        cnt2 = cnt.clone()
+        d1, d2 = (torch.zeros(H, W, 2, dtype=torch.int32, device=DEV) for _ in range(2))
+        e1, e2 = d1.clone(), d2.clone()
+        for _ in range(3):                                                                   # three ticks; the counter stays (no bump)
+            _lib.check(L.harp_step_prologue(p(buf) + 4 * off, n, p(hy), 2, 123, p(cnt), H, W, 1.0, p(d1), 2.0, p(d2), _lib.stream()), "prologue")
+            _lib.check(L.harp_adam_tick(p(hy2), 2, _lib.stream()), "tick")
+        _lib.check(L.harp_draw_texture_offsets(123, p(cnt2), H, W, 1.0, p(e1), 2.0, p(e2), _lib.stream()), "draw")
+        torch.cuda.synchronize()
+        assert (buf[off:off + n] == 0).all() and (buf[:off] == 7).all() and (buf[off + n:] == 7).all(), (off, n)
+        assert torch.equal(hy.view(torch.int32), hy2.view(torch.int32))
+        assert cnt.item() == 5 and cnt2.item() == 6
+        assert torch.equal(d1, e1) and torch.equal(d2, e2) and d1.abs().max().item() > 0
+    # parts left out: nothing else is touched
+    buf = torch.full((64,), 7.0, device=DEV)
+    _lib.check(L.harp_step_prologue(p(buf), 64, None, 0, 0, None, 0, 0, 0.0, None, 0.0, None, _lib.stream()), "prologue")
+    torch.cuda.synchronize()
+    assert (buf == 0).all()
+    assert L.harp_step_prologue(None, 4, None, 0, 0, None, 0, 0, 0.0, None, 0.0, None, None) == 1          # HARP_ERR_ARG
 
 
 def test_one_launch_backward_pair_with_a_kept_image():

@@ -1,6 +1,6 @@
 """Print the kernel timeline of one full step in a rocprofv3 rocpd database: start offset, duration, gap to the previous
-kernel's end, kernel name.  A step runs from one marker kernel (default: the schedule_next kernel that opens every step) to the
-next.   python tools/rocpd_timeline.py DB [marker-substring] [step-index]     (step-index: 0-based from the first marker; default
+kernel's end, kernel name.  A step runs from one marker kernel (default: the schedule_next kernel that opens every step; without one, the kernel
+that follows an Adam launch) to the next.   python tools/rocpd_timeline.py DB [marker-substring] [step-index]     (step-index: 0-based from the first marker; default
 the last full step — bench.py ends with keep_image steps, its timed loss-only steps are the indices warmup .. warmup+steps-1)"""
 import sqlite3
 import sys
@@ -14,6 +14,10 @@ def main(path, marker="schedule_next", step=None):
     extra = ", stream_id" if "stream_id" in cols else (", queue_id" if "queue_id" in cols else "")
     rows = cur.execute(f"select {name}, start, end{extra} from kernels order by start").fetchall()
     marks = [i for i, r in enumerate(rows) if marker in r[0]]
+    if len(marks) < 3 and marker == "schedule_next":
+        # folded steps (FitEngine.fold_step) have no schedule kernel: a step then runs from the kernel after one Adam launch (the last
+        # kernel of every step) through the next Adam launch
+        marks = [i + 1 for i, r in enumerate(rows) if "adam_dev" in r[0] and i + 1 < len(rows)]
     if len(marks) < 3:
         print("not enough steps"); return
     lo, hi = (marks[-2], marks[-1]) if step is None else (marks[int(step)], marks[int(step) + 1])
