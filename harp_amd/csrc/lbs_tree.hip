@@ -57,9 +57,13 @@ __device__ __forceinline__ void rod_bwd(const float r[3], const float g[9], floa
 __global__ void __launch_bounds__(64) tree_joints_kernel(const harp_tree_model M, const float* __restrict__ in_pose,
                                                          const float* __restrict__ betas, float* __restrict__ pose_map,
                                                          float* __restrict__ A, float* __restrict__ G, float* __restrict__ Jrest,
-                                                         float* __restrict__ Rloc) {
+                                                         float* __restrict__ Rloc, float* __restrict__ z_pm, float* __restrict__ z_Gt) {
   __shared__ float sR[MAXJ][9], sJ[MAXJ][3], sG[MAXJ][12];
   const int b = blockIdx.x, l = threadIdx.x, NJ = M.NJ, NB = M.NB, NP = (NJ - 1) * 9;
+  // the backward pass accumulates into g_pm / g_Gt with atomics: cleared here, off the backward tail (the chain backward clears what it
+  // consumes, so a second backward call on the same workspace starts from zero as well)
+  for (int k = l; k < NP; k += 64) z_pm[(size_t)b * NP + k] = 0.f;
+  for (int k = l; k < NJ * 3; k += 64) z_Gt[(size_t)b * NJ * 3 + k] = 0.f;
   for (int j = l; j < NJ; j += 64) {
     float aa[3];
     const int src = M.pose_src[j];
@@ -223,8 +227,9 @@ __global__ void tree_joints_out_kernel(const harp_tree_model M, const float* __r
 
 // g_joints -> g_Gt (B,NJ,3) chain-joint translation gradients [metres] (zero-initialised by the caller) and tip part into g_verts
 __global__ void tree_joints_bwd_kernel(const harp_tree_model M, const float* __restrict__ g_joints, int B, float* __restrict__ g_Gt,
-                                       float* __restrict__ g_verts) {
+                                       float* __restrict__ g_verts, float* __restrict__ z_betas) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x, no = M.n_joints_out;
+  if (i < B * M.NB) z_betas[i] = 0.f;                    // (the shape gradient is accumulated with atomics by a later launch)
   if (i >= B * no * 3) return;
   const int b = i / (no * 3), k = (i / 3) % no, c = i % 3, src = M.joint_src[k];
   if (src >= 0) atomicAdd(&g_Gt[((size_t)b * M.NJ + src) * 3 + c], g_joints[i] * 1000.0f);
@@ -328,7 +333,7 @@ __global__ void __launch_bounds__(256) tree_gpm_mfma_kernel(const harp_tree_mode
 __global__ void __launch_bounds__(64) tree_chain_bwd_kernel(const harp_tree_model M, const float* __restrict__ in_pose,
                                                             const float* __restrict__ Rloc, const float* __restrict__ G,
                                                             const float* __restrict__ Jrest, const float* __restrict__ g_A,
-                                                            const float* __restrict__ g_pm, const float* __restrict__ g_Gt,
+                                                            float* __restrict__ g_pm, float* __restrict__ g_Gt,
                                                             float* __restrict__ g_in_pose, float* __restrict__ g_beta_b) {
   __shared__ float gRG[MAXJ][9], gtG[MAXJ][3], gRl[MAXJ][9], gJ[MAXJ][3];
   const int b = blockIdx.x, l = threadIdx.x, NJ = M.NJ, NB = M.NB, NP = (NJ - 1) * 9;
@@ -341,13 +346,17 @@ __global__ void __launch_bounds__(64) tree_chain_bwd_kernel(const harp_tree_mode
       const float gt = ga[r * 4 + 3];
       for (int c = 0; c < 3; ++c) gRG[j][r * 3 + c] = ga[r * 4 + c] - gt * Jb[j * 3 + c];
       gtG[j][r] = gt + g_Gt[((size_t)b * NJ + j) * 3 + r];
+      g_Gt[((size_t)b * NJ + j) * 3 + r] = 0.f;          // consumed: the two accumulators are all-zero again for the next backward call
     }
     for (int c = 0; c < 3; ++c) {
       float acc = 0.f;
       for (int r = 0; r < 3; ++r) acc -= Gb[j * 12 + r * 4 + c] * ga[r * 4 + 3];
       gJ[j][c] = acc;
     }
-    for (int k = 0; k < 9; ++k) gRl[j][k] = (j > 0) ? g_pm[(size_t)b * NP + (j - 1) * 9 + k] : 0.f;
+    for (int k = 0; k < 9; ++k) {
+      gRl[j][k] = (j > 0) ? g_pm[(size_t)b * NP + (j - 1) * 9 + k] : 0.f;
+      if (j > 0) g_pm[(size_t)b * NP + (j - 1) * 9 + k] = 0.f;
+    }
   }
   __syncthreads();
   // chain backward, level-parallel from the leaves up: lane j (depth d) is final once every deeper level has been folded into it;
@@ -397,10 +406,6 @@ __global__ void __launch_bounds__(64) tree_chain_bwd_kernel(const harp_tree_mode
   }
 }
 
-__global__ void zero_kernel(float* __restrict__ a, size_t n) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) a[i] = 0.f;
-}
 
 struct TreeWs { float *pm, *A, *G, *Jrest, *Rloc, *vp, *g_vp, *g_A, *g_pm, *g_Gt; };
 TreeWs tree_ws(const harp_tree_model* m, float* ws, int B) {
@@ -427,7 +432,7 @@ int harp_lbs_tree_fwd(const harp_tree_model* m, const float* in_pose, const floa
                       float* verts, float* joints, hipStream_t stream) {
   if (!m || !in_pose || !betas || !transl || !ws || !verts || !joints || B <= 0 || m->NJ > MAXJ || m->NB > MAXB) return HARP_ERR_ARG;
   const TreeWs w = tree_ws(m, ws, B);
-  hipLaunchKernelGGL(tree_joints_kernel, dim3(B), dim3(64), 0, stream, *m, in_pose, betas, w.pm, w.A, w.G, w.Jrest, w.Rloc);
+  hipLaunchKernelGGL(tree_joints_kernel, dim3(B), dim3(64), 0, stream, *m, in_pose, betas, w.pm, w.A, w.G, w.Jrest, w.Rloc, w.g_pm, w.g_Gt);
   hipLaunchKernelGGL(tree_blend_mfma_kernel, dim3((m->NV * 3 + 15) / 16, (B + 15) / 16), dim3(256), 0, stream, *m, w.pm, betas, B, w.vp);
   hipLaunchKernelGGL(tree_skin_kernel<false>, dim3((m->NV + kSkinV - 1) / kSkinV, (B + kSkinF - 1) / kSkinF), dim3(256), skin_smem(m), stream, *m,
                      transl, w.vp, w.A, w.G, B, verts, nullptr, nullptr);
@@ -442,10 +447,9 @@ int harp_lbs_tree_bwd(const harp_tree_model* m, const float* in_pose, const floa
                       float* g_verts, const float* g_joints, float* g_in_pose, float* g_betas, float* g_transl, hipStream_t stream) {
   if (!m || !in_pose || !betas || !ws || !g_verts || !g_joints || !g_in_pose || !g_betas || !g_transl) return HARP_ERR_ARG;
   const TreeWs w = tree_ws(m, ws, B);
-  const size_t nz = (size_t)B * ((m->NJ - 1) * 9 + m->NJ * 3);
-  hipLaunchKernelGGL(zero_kernel, dim3((unsigned)((nz + 255) / 256)), dim3(256), 0, stream, w.g_pm, nz);
-  hipLaunchKernelGGL(zero_kernel, dim3((B * m->NB + 255) / 256), dim3(256), 0, stream, g_betas, (size_t)B * m->NB);
-  hipLaunchKernelGGL(tree_joints_bwd_kernel, dim3((B * m->n_joints_out * 3 + 255) / 256), dim3(256), 0, stream, *m, g_joints, B, w.g_Gt, g_verts);
+  // (g_pm / g_Gt were cleared by harp_lbs_tree_fwd on this workspace, and again by the last backward call that consumed them)
+  const int nth = max(B * m->n_joints_out * 3, B * m->NB);
+  hipLaunchKernelGGL(tree_joints_bwd_kernel, dim3((nth + 255) / 256), dim3(256), 0, stream, *m, g_joints, B, w.g_Gt, g_verts, g_betas);
   hipLaunchKernelGGL(tree_center_bwd_kernel, dim3(B), dim3(256), 0, stream, *m, g_verts, w.g_Gt, g_transl);
   hipLaunchKernelGGL(tree_skin_kernel<true>, dim3((m->NV + kSkinV - 1) / kSkinV, (B + kSkinF - 1) / kSkinF), dim3(256), skin_smem(m), stream, *m,
                      transl, w.vp, w.A, w.G, B, nullptr, g_verts, w.g_vp);

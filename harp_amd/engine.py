@@ -437,13 +437,15 @@ class FitEngine:
                 if self.auto_draw and not fold:
                     self.draw_texture_offsets()
                 nt = self.Ht * self.Wt
+                def tex_terms(dr):
+                    self._ck(L.harp_texture_terms(p(self.params["texture"]), p(self.params["normal_map"]), p(self.uv_mask), p(self.dist_albedo),
+                                                  p(self.dist_normal), self.Ht, self.Wt, 0.2, wp(7), lp(7), p(self.grads["texture"]), wp(8), lp(8),
+                                                  p(self.grads["normal_map"]), p(self.params["verts_disps"]) if dr else None, V, wp(2), lp(2),
+                                                  p(self.grads["verts_disps"]), ST()), "texture_terms")
                 if self.fused_terms:
                     self._ck(L.harp_normalize3_pack(p(self.params["texture"]), p(self.params["normal_map"]), nt, p(s["nmap_n"]),
                                                     p(self.texnm) if self.packed_texels else None, ST()), "normalize3_pack")
-                    self._ck(L.harp_texture_terms(p(self.params["texture"]), p(self.params["normal_map"]), p(self.uv_mask), p(self.dist_albedo),
-                                                  p(self.dist_normal), self.Ht, self.Wt, 0.2, wp(7), lp(7), p(self.grads["texture"]), wp(8), lp(8),
-                                                  p(self.grads["normal_map"]), p(self.params["verts_disps"]) if disp_reg else None, V, wp(2), lp(2),
-                                                  p(self.grads["verts_disps"]), ST()), "texture_terms")
+                    tex_terms(disp_reg)
                     disp_reg = False
                 else:
                     self._ck(L.harp_normalize3_fwd(p(self.params["normal_map"]), nt, p(s["nmap_n"]), ST()), "normalize3")

@@ -232,6 +232,8 @@ size_t harp_lbs_tree_ws_floats(const harp_tree_model* m, int B);
 /* verts (B,NV,3) mm, joints (B,n_joints_out,3) mm */
 int harp_lbs_tree_fwd(const harp_tree_model* m, const float* in_pose, const float* betas, const float* transl, int B, float* ws,
                       float* verts, float* joints, hipStream_t stream);
+/* ws: the workspace harp_lbs_tree_fwd filled for the same inputs (it also clears the accumulators this call adds to; the call leaves
+ * them cleared again, so it may be repeated on one forward pass) */
 int harp_lbs_tree_bwd(const harp_tree_model* m, const float* in_pose, const float* betas, const float* transl, int B, float* ws,
                       float* g_verts, const float* g_joints, float* g_in_pose, float* g_betas, float* g_transl, hipStream_t stream);
 

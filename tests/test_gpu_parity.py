@@ -358,9 +358,17 @@ def test_smplx_arm_lbs_vs_oracle():
     v, j = layer(betas=dev[0], global_orient=dev[1], transl=dev[2], right_hand_pose=dev[3], right_wrist_pose=dev[4], return_type="mano_w_arm")
     assert v.shape == (B, 1026, 3) and j.shape == (B, 22, 3)
     assert torch.allclose(v.cpu(), v_ref.detach(), atol=5e-3) and torch.allclose(j.cpu(), j_ref.detach(), atol=5e-3)      # mm
-    ((v * wv.to(DEV)).sum() + (j * wj.to(DEV)).sum()).backward()
+    obj = (v * wv.to(DEV)).sum() + (j * wj.to(DEV)).sum()
+    obj.backward(retain_graph=True)
     for a, b, name in zip(dev, cpu, ("betas", "global_orient", "transl", "right_hand_pose", "right_wrist_pose")):
         assert rel(a.grad.cpu(), b.grad) < 2e-4, (name, rel(a.grad.cpu(), b.grad))
+    # a second backward call on the same forward workspace: the atomically accumulated buffers were left cleared by the first one
+    first = [a.grad.clone() for a in dev]
+    for a in dev:
+        a.grad = None
+    obj.backward()
+    for a, f, name in zip(dev, first, ("betas", "global_orient", "transl", "right_hand_pose", "right_wrist_pose")):
+        assert rel(a.grad, f) < 1e-5, (name, rel(a.grad, f))
     vm, jm = layer(betas=dev[0].detach(), global_orient=dev[1].detach(), transl=dev[2].detach(), right_hand_pose=dev[3].detach(),
                    right_wrist_pose=dev[4].detach(), return_type="mano")
     assert vm.shape == (B, 778, 3) and jm.shape == (B, 21, 3)

@@ -6,7 +6,8 @@ args = sys.argv[1:]
 if args and "=" not in args[0]:
     args = ["%s=%s" % (args[0], v) for v in args[1:]]
 cfgs = [dict((kv.split("=")[0], int(kv.split("=")[1])) for kv in a.split(",") if kv) for a in args]
-eng, focal = bench.build_engine(0, 1, torch.device('cuda'))
+kind, img = os.environ.get("HARP_TL_KIND", "hand"), int(os.environ.get("HARP_TL_IMG", "512"))      # C5: HARP_TL_KIND=arm HARP_TL_IMG=1024
+eng, focal = bench.build_engine(0, 1, torch.device('cuda'), kind=kind, img=img)
 eng.keep_image = False
 eng.set_schedule(torch.arange(256).reshape(-1, 32).int())
 defaults = {k: getattr(eng, k) for c in cfgs for k in c}
