@@ -62,7 +62,7 @@ class ShadeArgs(ctypes.Structure):
                 [(n, _f) for n in ("focal", "ppx", "ppy")] + [("bg", _f * 3)] +
                 [(n, _vp) for n in ("rgb", "g_rgb", "g_tex", "g_nmap", "g_verts", "g_vnormals", "g_ndc", "g_zl", "g_light_pos",
                                     "g_colors", "g_light_R", "g_light_T")] + [("debug_skip", _i)] +
-                [(n, _vp) for n in ("l1_target", "l1_mask", "l1_fid", "l1_w", "l1_loss", "l1_grad")] + [("l1_inv", _f), ("texnm", _vp), ("l1_bg_sums", _vp)])
+                [(n, _vp) for n in ("l1_target", "l1_mask", "l1_fid", "l1_w", "l1_loss", "l1_grad")] + [("l1_inv", _f), ("texnm", _vp), ("l1_bg_sums", _vp), ("g_zl_tiles", _vp)])
 
 
 SIGNATURES.update({
@@ -72,7 +72,8 @@ SIGNATURES.update({
     "harp_shade_bwd": (_i, [ctypes.POINTER(ShadeArgs), _vp]),
     "harp_pack_texels": (_i, [_vp, _vp, _i, _vp, _vp]),
     "harp_normalize3_pack": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
-    "harp_depth_nmap_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp]),
+    "harp_depth_nmap_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
+    "harp_depth_bwd_tiles": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "harp_subdivide_fwd": (_i, [_vp, _vp, _i, _i, _i, _f, _vp, _vp]),
     "harp_subdivide_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _vp, _vp]),
     "harp_vertex_normals_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
@@ -101,7 +102,7 @@ SIGNATURES.update({
     "harp_mse": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
     "harp_texture_smooth_reg": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
     "harp_mesh_kps_terms": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
-    "harp_texture_terms": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
+    "harp_texture_terms": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "harp_close_to_z_reg": (_i, [_vp, _i, _i, _f, _vp, _vp, _vp, _vp]),
     "harp_normalize3_fwd": (_i, [_vp, _i, _vp, _vp]),
     "harp_normalize3_bwd": (_i, [_vp, _vp, _i, _vp, _vp]),

@@ -317,11 +317,13 @@ struct TexTerms {
   float *l_a, *l_n, *l_d;
   float *g_tex, *g_nmap, *g_disp;
   int nb_smooth, nb_disp;
+  int* bump;                           // optional: the draw counter the offsets were drawn for (advanced here: the offsets are consumed)
 };
 __global__ void __launch_bounds__(256) texture_terms_kernel(const TexTerms A) {
   __shared__ float red[4];
   __shared__ float s_norm[3];
   int bid = blockIdx.x;
+  if (A.bump && bid == 0 && threadIdx.x == 0) A.bump[0] += 1;      // (harp_step_prologue, an earlier launch, drew with the old value)
   if (bid < A.nb_smooth) { tex_smooth_body(bid, A.nb_smooth, A.tex, A.dist_a, A.mask, A.H, A.W, A.w_a, A.l_a, A.g_tex, red); return; }
   bid -= A.nb_smooth;
   if (bid < A.nb_smooth) { tex_smooth_body(bid, A.nb_smooth, A.nmap, A.dist_n, A.mask, A.H, A.W, A.w_n, A.l_n, A.g_nmap, red); return; }
@@ -582,14 +584,14 @@ int harp_mesh_kps_terms(const float* verts, const float* ref_verts, const int32_
 int harp_texture_terms(const float* tex, const float* nmap, const float* mask, const int32_t* dist_albedo, const int32_t* dist_normal,
                        int H, int W, float z_scale, const float* w_albedo, float* loss_albedo, float* g_tex, const float* w_normal,
                        float* loss_normal, float* g_nmap, const float* disp, int n_disp, const float* w_disp, float* loss_disp,
-                       float* g_disp, hipStream_t stream) {
+                       float* g_disp, int* draw_counter_bump, hipStream_t stream) {
   if (!tex || !nmap || !dist_albedo || !dist_normal || !loss_albedo || !loss_normal || H <= 0 || W <= 0 || (disp && (!loss_disp || n_disp <= 0)))
     return HARP_ERR_ARG;
   TexTerms A;
   A.tex = tex; A.nmap = nmap; A.mask = mask; A.disp = disp; A.dist_a = dist_albedo; A.dist_n = dist_normal;
   A.H = H; A.W = W; A.n_disp = n_disp; A.z_scale = z_scale;
   A.w_a = w_albedo; A.w_n = w_normal; A.w_d = w_disp; A.l_a = loss_albedo; A.l_n = loss_normal; A.l_d = loss_disp;
-  A.g_tex = g_tex; A.g_nmap = g_nmap; A.g_disp = g_disp;
+  A.g_tex = g_tex; A.g_nmap = g_nmap; A.g_disp = g_disp; A.bump = draw_counter_bump;
   A.nb_smooth = min((H * W + 255) / 256, 512);
   A.nb_disp = disp ? min((n_disp + 255) / 256, 64) : 0;
   hipLaunchKernelGGL(texture_terms_kernel, dim3(2 * A.nb_smooth + H + A.nb_disp), dim3(256), 0, stream, A);

@@ -437,6 +437,7 @@ __global__ void __launch_bounds__(256, SHADE_OCC) shade_kernel(const harp_shade_
     __syncthreads();
     const int x0 = s_zbox[0], y0 = s_zbox[1];
     float* gz = A.g_zl + (size_t)b * S * S;
+    const int znt = (S + 15) >> 4;
     if (has) {
 #pragma unroll
       for (int r = 0; r < 3; ++r) {
@@ -448,7 +449,10 @@ __global__ void __launch_bounds__(256, SHADE_OCC) shade_kernel(const harp_shade_
           const int xx = min(max(zix + c - 1, 0), S - 1);
           const int wx = xx - x0, wy = yy - y0;
           if (wx < kZlW && wy < kZlH) atomicAdd(&s_zwin[wy * kZlW + wx], (double)d);
-          else atomicAdd(gz + yy * S + xx, d);
+          else {
+            atomicAdd(gz + yy * S + xx, d);
+            if (A.g_zl_tiles) A.g_zl_tiles[((size_t)b * znt + (yy >> 4)) * znt + (xx >> 4)] = 1;
+          }
         }
       }
     }
@@ -456,7 +460,10 @@ __global__ void __launch_bounds__(256, SHADE_OCC) shade_kernel(const harp_shade_
     if (x0 != 0x7fffffff) {
       for (int i = threadIdx.x; i < kZlW * kZlH; i += 256) {
         const double v = s_zwin[i];
-        if (v != 0.0) atomicAdd(gz + (size_t)(y0 + i / kZlW) * S + x0 + (i % kZlW), (float)v);
+        if (v != 0.0) {
+          atomicAdd(gz + (size_t)(y0 + i / kZlW) * S + x0 + (i % kZlW), (float)v);
+          if (A.g_zl_tiles) A.g_zl_tiles[((size_t)b * znt + ((y0 + i / kZlW) >> 4)) * znt + ((x0 + i % kZlW) >> 4)] = 1;
+        }
       }
     }
   }
@@ -621,7 +628,7 @@ __global__ void __launch_bounds__(256) depth_bwd_kernel(const int32_t* __restric
                                                         const int32_t* __restrict__ faces, float* __restrict__ g_z,
                                                         int V, int F, int S, float* __restrict__ g_ndc,
                                                         const int32_t* __restrict__ order, const int32_t* __restrict__ nact,
-                                                        int B, int nsx, const NmapBwd M) {
+                                                        int B, int nsx, const NmapBwd M, unsigned char* __restrict__ tiles) {
   __shared__ VertexAccum<256, 3> s_acc;
   const unsigned tile_blocks = NMAP ? gridDim.x - (unsigned)M.blocks : gridDim.x;
   if (NMAP && blockIdx.x >= tile_blocks) {
@@ -638,6 +645,13 @@ __global__ void __launch_bounds__(256) depth_bwd_kernel(const int32_t* __restric
   if (vb != blockIdx.x) __syncthreads();                 // s_acc of the previous tile has been flushed
   int b, st, tx0, ty0, tsub;
   if (tile_decode_v(vb, order, nact, B, nsx, S, b, st, tx0, ty0, tsub, false) != 1) continue;   // no tile / super-tile without a single face
+  if (tiles) {                                           // the shader backward flags the tiles it adds to (about half of the ones visited here)
+    const int znt = (S + 15) >> 4;
+    unsigned char* fl = tiles + ((size_t)b * znt + (ty0 >> 4)) * znt + (tx0 >> 4);
+    if (*fl == 0) continue;                              // (uniform: no barrier is skipped by part of the workgroup)
+    __syncthreads();                                     // every wave has read the flag
+    if (threadIdx.x == 0) *fl = 0;
+  }
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int xi = tx0 + (lane & 15), yi = ty0 + w * 4 + (lane >> 4);
   const bool in_img = xi < S && yi < S;
@@ -754,7 +768,7 @@ int harp_depth_bwd(const int32_t* face_id, const void* ws, const int32_t* faces,
   if (!face_id || !ws || !faces || !g_z || !g_ndc) return HARP_ERR_ARG;
   const RasterWs W = raster_ws_split((void*)ws, B, F, S);
   hipLaunchKernelGGL(depth_bwd_kernel<false>, dim3(min(tile_grid(B, W.nsx), 4096u)), dim3(256), 0, stream, face_id, (const FaceRec*)ws, faces, (float*)g_z, V, F, S,
-                     g_ndc, (const int32_t*)W.order, (const int32_t*)W.nact, B, W.nsx, NmapBwd{});
+                     g_ndc, (const int32_t*)W.order, (const int32_t*)W.nact, B, W.nsx, NmapBwd{}, nullptr);
   HARP_CHECK_LAUNCH();
   return HARP_OK;
 }
@@ -765,19 +779,29 @@ int harp_depth_bwd_consume(const int32_t* face_id, const void* ws, const int32_t
   if (!face_id || !ws || !faces || !g_z || !g_ndc) return HARP_ERR_ARG;
   const RasterWs W = raster_ws_split((void*)ws, B, F, S);
   hipLaunchKernelGGL(depth_bwd_kernel<true>, dim3(min(tile_grid(B, W.nsx), 4096u)), dim3(256), 0, stream, face_id, (const FaceRec*)ws, faces, g_z, V, F, S, g_ndc,
-                     (const int32_t*)W.order, (const int32_t*)W.nact, B, W.nsx, NmapBwd{});
+                     (const int32_t*)W.order, (const int32_t*)W.nact, B, W.nsx, NmapBwd{}, nullptr);
+  HARP_CHECK_LAUNCH();
+  return HARP_OK;
+}
+
+int harp_depth_bwd_tiles(const int32_t* face_id, const void* ws, const int32_t* faces, float* g_z, int B, int V, int F, int S,
+                         float* g_ndc, unsigned char* g_z_tiles, hipStream_t stream) {
+  if (!face_id || !ws || !faces || !g_z || !g_ndc) return HARP_ERR_ARG;
+  const RasterWs W = raster_ws_split((void*)ws, B, F, S);
+  hipLaunchKernelGGL(depth_bwd_kernel<true>, dim3(min(tile_grid(B, W.nsx), 4096u)), dim3(256), 0, stream, face_id, (const FaceRec*)ws, faces, g_z, V, F, S, g_ndc,
+                     (const int32_t*)W.order, (const int32_t*)W.nact, B, W.nsx, NmapBwd{}, g_z_tiles);
   HARP_CHECK_LAUNCH();
   return HARP_OK;
 }
 
 // harp_depth_bwd_consume + harp_normalize3_bwd(nmap, g_nmap_n, n_texels, g_nmap) as ONE launch
 int harp_depth_nmap_bwd(const int32_t* face_id, const void* ws, const int32_t* faces, float* g_z, int B, int V, int F, int S, float* g_ndc,
-                        const float* nmap, const float* g_nmap_n, int n_texels, float* g_nmap, hipStream_t stream) {
+                        const float* nmap, const float* g_nmap_n, int n_texels, float* g_nmap, unsigned char* g_z_tiles, hipStream_t stream) {
   if (!face_id || !ws || !faces || !g_z || !g_ndc || !nmap || !g_nmap_n || !g_nmap || n_texels <= 0) return HARP_ERR_ARG;
   const RasterWs W = raster_ws_split((void*)ws, B, F, S);
   const NmapBwd M{nmap, g_nmap_n, g_nmap, n_texels, min((n_texels + 255) / 256, 1024)};
   hipLaunchKernelGGL((depth_bwd_kernel<true, true>), dim3(min(tile_grid(B, W.nsx), 4096u) + (unsigned)M.blocks), dim3(256), 0, stream, face_id,
-                     (const FaceRec*)ws, faces, g_z, V, F, S, g_ndc, (const int32_t*)W.order, (const int32_t*)W.nact, B, W.nsx, M);
+                     (const FaceRec*)ws, faces, g_z, V, F, S, g_ndc, (const int32_t*)W.order, (const int32_t*)W.nact, B, W.nsx, M, g_z_tiles);
   HARP_CHECK_LAUNCH();
   return HARP_OK;
 }

@@ -488,6 +488,7 @@ __device__ __forceinline__ void shade_bwd_tile(ShadeSmem& sm, unsigned vblock, c
         float zs, zinv_s;
         fixed_scale(zm * 16.0f, zs, zinv_s);           // up to 9 taps of 64 lanes on one light pixel: 4 more bits of head room
         float* gz = A.g_zl + (size_t)b * S * S;
+        const int znt = (S + 15) >> 4;
         if (has) {
 #pragma unroll
           for (int r = 0; r < 3; ++r) {
@@ -499,7 +500,10 @@ __device__ __forceinline__ void shade_bwd_tile(ShadeSmem& sm, unsigned vblock, c
               const int xx = min(max(zix + c - 1, 0), S - 1);
               const int wx = xx - x0, wy = yy - y0;
               if (wx < kZW && wy < kZH) atomicAdd(&L.zwin[wy * kZW + wx], __float2int_rn(d * zs));
-              else atomicAdd(at32m(gz, (unsigned)(yy * S + xx)), d);
+              else {
+                atomicAdd(at32m(gz, (unsigned)(yy * S + xx)), d);
+                if (A.g_zl_tiles) A.g_zl_tiles[((size_t)b * znt + (yy >> 4)) * znt + (xx >> 4)] = 1;
+              }
             }
           }
         }
@@ -510,7 +514,11 @@ __device__ __forceinline__ void shade_bwd_tile(ShadeSmem& sm, unsigned vblock, c
 #pragma unroll
         for (int j = 0; j < kZW * kZH / 64; ++j) {
           const int i = lane + 64 * j;
-          if (zq[j] != 0) atomicAdd(at32m(gz, (unsigned)((y0 + i / kZW) * S + x0 + (i % kZW))), (float)zq[j] * zinv_s);
+          if (zq[j] != 0) {
+            atomicAdd(at32m(gz, (unsigned)((y0 + i / kZW) * S + x0 + (i % kZW))), (float)zq[j] * zinv_s);
+            // the light-view tile now holds a gradient (plain byte stores of the same value: no ordering needed)
+            if (A.g_zl_tiles) A.g_zl_tiles[((size_t)b * znt + ((y0 + i / kZW) >> 4)) * znt + ((x0 + i % kZW) >> 4)] = 1;
+          }
         }
       }
     }

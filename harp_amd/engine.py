@@ -176,6 +176,11 @@ class FitEngine:
         self.fused_bwd = False           # shading + silhouette backward in ONE launch (harp_shade_sil_bwd): correct, measured SLOWER (1.05 vs 0.93 ms: the rasteriser tiles inherit 168 VGPRs / 3 waves per SIMD)
         self.tail_side = False           # normal-map chain rule (+ early all-reduce) on the second stream: measured SLOWER (0.960 vs 0.948 ms: the extra cross-stream edge costs more than the 5-us kernel it moves)
         self.camera_first = True        # enqueue the camera-view raster chain (the longer one) before the light-view chain: +0.75 %
+        # the shader backward flags the light-view tiles it adds a shadow-tap gradient to and the depth backward reads only those (42 % of the
+        # tiles it visits at 512^2, 51 % at 1024^2 on the arm).  The flag is one more dependent load per tile: at 512^2, where a workgroup of
+        # the depth backward walks <= 2 tiles, it costs what it saves (0.704 vs 0.701 ms / step); at 1024^2 (8 tiles per workgroup) it wins
+        # (1.777 vs 1.788 ms / step on the arm) — on from 1024 px.
+        self.zl_tile_flags = self.S >= 1024
         self.fold_step = True            # scheduled steps: the batch row is fetched by hand_front itself, the loss vector / schedule row / draw counter are turned over by hand_back, the slab clear + Adam tick + offset draw are ONE launch (harp_step_frame, harp_step_prologue): 31 -> 23 kernels per step, no schedule kernel in front of the hand layer
         self.fused_terms = True          # normalise + pack, the four parameter-only regularisers, key-point + mesh terms, depth backward + normal-map chain rule: one launch each (were 2 + 4 + 2 + 2)
         self.frozen = ()                 # parameters kept out of the optimiser groups (known_appearance)
@@ -207,6 +212,7 @@ class FitEngine:
         s["face_c"] = torch.empty(B, S, S, dtype=torch.int32, device=dev)
         s["face_l"] = torch.empty(B, S, S, dtype=torch.int32, device=dev)
         s["alpha"], s["zl"], s["rgb"] = f(B, S, S), f(B, S, S), f(B, S, S, 3)
+        s["zl_tiles"] = torch.zeros(B * ((S + 15) // 16) ** 2, dtype=torch.uint8, device=dev)     # harp_shade_args.g_zl_tiles: all-zero between steps
         s["zl_state"] = torch.zeros(B * ((S + 63) // 64) ** 2, dtype=torch.int32, device=dev)     # harp_rasterize_fwd_keep: which super-tiles of zl are all -1
         s["nmap_n"] = self.nmap_n
         # gradients (zeroed every step in ONE memset: they are carved from one flat buffer)
@@ -345,6 +351,8 @@ class FitEngine:
                      ("g_light_pos", s["g_light_pos"]), ("g_colors", s["g_colors"]),
                      ("g_light_R", s["g_light_R"] if self.self_shadow else None), ("g_light_T", s["g_light_T"] if self.self_shadow else None)):
             setattr(a, k, _lib.ptr(t))
+        # light-view tiles that receive a shadow-tap gradient are flagged for the depth backward (which clears what it consumes)
+        a.g_zl_tiles = _lib.ptr(s["zl_tiles"]) if (self.self_shadow and self.consume_gzl and self.zl_tile_flags) else None
         return a
 
     def _can_fold(self):
@@ -413,16 +421,20 @@ class FitEngine:
         # ---- terms that depend on the parameters only (normal-map normalisation, texture regularisers, displacement regulariser) go
         #      first on the second stream: they run under the LBS / mesh chain, which is a string of small latency-bound launches
         def param_terms():
-            if fold:
-                # slab clear + Adam tick + offset draw: ONE launch (the draw counter is advanced by hand_back at the end of the step)
+            # slab clear + Adam tick + offset draw as ONE launch (harp_step_prologue); the draw counter is advanced at the end of the step by
+            # hand_back (folded step) or by the launch that consumes the offsets (harp_texture_terms)
+            pro = fold or (fill_side and self.fused_terms)
+            draw = app and shared_terms and self.auto_draw
+            if pro:
                 zero = self.gs_zero[:-16] if fill_side else None
                 hy, nh = (None, 0)
                 if tick and (coarse or app):
                     hy, nh = (self.hyper.data_ptr(), 2) if (coarse and app) else (self.hyper.data_ptr() + (0 if coarse else 1) * self._hyper_stride, 1)
-                draw = app and self.auto_draw
                 self._ck(L.harp_step_prologue(p(zero) if zero is not None else None, zero.numel() if zero is not None else 0, hy, nh, self.seed,
                                               p(self.draw_counter), self.Ht, self.Wt, 1.0, p(self.dist_albedo) if draw else None, 2.0,
                                               p(self.dist_normal) if draw else None, ST()), "step_prologue")
+                if fill_side and not mesh_on_third and not fold:
+                    self.gs_mesh.zero_()
             else:
                 if fill_side:
                     self.gs_zero[:-16].zero_()               # everything but the loss vector (last 16 floats of the slab)
@@ -434,18 +446,17 @@ class FitEngine:
                 self.gs_zero_late.zero_()
             disp_reg = coarse and shared_terms and "vert_disp_reg" not in off
             if app and shared_terms:
-                if self.auto_draw and not fold:
+                if draw and not pro:
                     self.draw_texture_offsets()
                 nt = self.Ht * self.Wt
-                def tex_terms(dr):
-                    self._ck(L.harp_texture_terms(p(self.params["texture"]), p(self.params["normal_map"]), p(self.uv_mask), p(self.dist_albedo),
-                                                  p(self.dist_normal), self.Ht, self.Wt, 0.2, wp(7), lp(7), p(self.grads["texture"]), wp(8), lp(8),
-                                                  p(self.grads["normal_map"]), p(self.params["verts_disps"]) if dr else None, V, wp(2), lp(2),
-                                                  p(self.grads["verts_disps"]), ST()), "texture_terms")
                 if self.fused_terms:
                     self._ck(L.harp_normalize3_pack(p(self.params["texture"]), p(self.params["normal_map"]), nt, p(s["nmap_n"]),
                                                     p(self.texnm) if self.packed_texels else None, ST()), "normalize3_pack")
-                    tex_terms(disp_reg)
+                    self._ck(L.harp_texture_terms(p(self.params["texture"]), p(self.params["normal_map"]), p(self.uv_mask), p(self.dist_albedo),
+                                                  p(self.dist_normal), self.Ht, self.Wt, 0.2, wp(7), lp(7), p(self.grads["texture"]), wp(8), lp(8),
+                                                  p(self.grads["normal_map"]), p(self.params["verts_disps"]) if disp_reg else None, V, wp(2), lp(2),
+                                                  p(self.grads["verts_disps"]), p(self.draw_counter) if (draw and pro and not fold) else None, ST()),
+                             "texture_terms")
                     disp_reg = False
                 else:
                     self._ck(L.harp_normalize3_fwd(p(self.params["normal_map"]), nt, p(s["nmap_n"]), ST()), "normalize3")
@@ -605,8 +616,8 @@ class FitEngine:
                 nmap_in_depth = self.fused_terms and self.self_shadow and self.consume_gzl and not (self.tail_side and self.overlap)
                 if nmap_in_depth:
                     self._ck(L.harp_depth_nmap_bwd(p(s["face_l"]), p(s["ws_l"]), p(tp.faces), p(s["g_zl"]), B, V, F, S, p(s["g_ndc_l"]),
-                                                   p(self.params["normal_map"]), p(s["g_nmap_n"]), self.Ht * self.Wt, p(self.grads["normal_map"]), ST()),
-                             "depth_nmap_bwd")
+                                                   p(self.params["normal_map"]), p(s["g_nmap_n"]), self.Ht * self.Wt, p(self.grads["normal_map"]),
+                                                   p(s["zl_tiles"]) if self.zl_tile_flags else None, ST()), "depth_nmap_bwd")
                     self._allreduce_maps_early()
                 elif self.tail_side and self.overlap:
                     wait_s(side, cur)
@@ -618,8 +629,12 @@ class FitEngine:
                 nmap_in_depth = False
             if self.self_shadow:
                 if not nmap_in_depth:
-                    depth_bwd = L.harp_depth_bwd_consume if self.consume_gzl else L.harp_depth_bwd
-                    self._ck(depth_bwd(p(s["face_l"]), p(s["ws_l"]), p(tp.faces), p(s["g_zl"]), B, V, F, S, p(s["g_ndc_l"]), ST()), "depth_bwd")
+                    if self.consume_gzl and self.zl_tile_flags:
+                        self._ck(L.harp_depth_bwd_tiles(p(s["face_l"]), p(s["ws_l"]), p(tp.faces), p(s["g_zl"]), B, V, F, S, p(s["g_ndc_l"]), p(s["zl_tiles"]),
+                                                        ST()), "depth_bwd")
+                    else:
+                        depth_bwd = L.harp_depth_bwd_consume if self.consume_gzl else L.harp_depth_bwd
+                        self._ck(depth_bwd(p(s["face_l"]), p(s["ws_l"]), p(tp.faces), p(s["g_zl"]), B, V, F, S, p(s["g_ndc_l"]), ST()), "depth_bwd")
                 if not fused:
                     self._ck(L.harp_project_bwd(p(s["vd"]), p(s["light_R"]), p(s["light_T"]), p(s["g_ndc_l"]), B, V, self.focal, S, p(s["g_vd"]),
                                                 p(s["g_light_R"]), p(s["g_light_T"]), ST()), "project_bwd_l")
@@ -920,7 +935,7 @@ class FitEngine:
         # every switch the enqueued launch sequence depends on is part of the key: flipping one re-captures instead of replaying a
         # graph recorded for another configuration
         gkey = (coarse, app, scheduled, self.keep_image, self.fused_loss, self.self_shadow, tuple(self.frozen), self.overlap, self.early_terms,
-                self.packed_texels, self.fused_keep, self.mesh_third, self.graph_order, fold, self.fused_terms, self.auto_draw, self.mesh_terms_first, self.camera_first, self.tail_side, self.fused_bwd, self.fused_chain, self.fused_front, self.fused_back, self.consume_gzl, self.keep_depth, dist_on, self.overlap_allreduce,
+                self.packed_texels, self.fused_keep, self.mesh_third, self.graph_order, fold, self.fused_terms, self.zl_tile_flags, self.auto_draw, self.mesh_terms_first, self.camera_first, self.tail_side, self.fused_bwd, self.fused_chain, self.fused_front, self.fused_back, self.consume_gzl, self.keep_depth, dist_on, self.overlap_allreduce,
                 self.comm is not None, self.perceptual is not None and app)
         g = self._graphs.get(gkey)
         if g is None:

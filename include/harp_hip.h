@@ -67,7 +67,11 @@ int harp_depth_bwd_consume(const int32_t* face_id, const void* ws, const int32_t
 /* harp_depth_bwd_consume + harp_normalize3_bwd(nmap, g_nmap_n, n_texels, g_nmap) as ONE launch: the two small passes between the shader
  * backward and the per-frame backward tail of a fitting step (neither reads what the other writes) */
 int harp_depth_nmap_bwd(const int32_t* face_id, const void* ws, const int32_t* faces, float* g_z, int B, int V, int F, int S, float* g_ndc,
-                        const float* nmap, const float* g_nmap_n, int n_texels, float* g_nmap, hipStream_t stream);
+                        const float* nmap, const float* g_nmap_n, int n_texels, float* g_nmap, unsigned char* g_z_tiles, hipStream_t stream);
+/* harp_depth_bwd_consume restricted to the tiles flagged in g_z_tiles (harp_shade_args.g_zl_tiles of the backward that filled g_z; NULL:
+ * every tile); the flags of the tiles visited are cleared */
+int harp_depth_bwd_tiles(const int32_t* face_id, const void* ws, const int32_t* faces, float* g_z, int B, int V, int F, int S,
+                         float* g_ndc, unsigned char* g_z_tiles, hipStream_t stream);
 
 /* ---- fragment-level rasterisation (the PyTorch3D op pair itself; NOT on the fitting loop's path) -----------------------------
  * replaces _C.rasterize_meshes(face_verts, mesh_to_face_first_idx, num_faces_per_mesh, clipped_faces_neighbor_idx, image_size,
@@ -120,7 +124,7 @@ typedef struct harp_shade_args {
   float* g_verts;           /* (B,V,3) (+=) */
   float* g_vnormals;        /* (B,V,3) (+=) */
   float* g_ndc;             /* (B,V,3) (+=) camera-view NDC vertices */
-  float* g_zl;              /* (B,S,S) (+=) or NULL */
+  float* g_zl;              /* (B,S,S) (+=) or NULL; see g_zl_tiles at the end of the struct */
   float* g_light_pos;       /* (B,3) (+=) or NULL */
   float* g_colors;          /* 9 (+=) or NULL */
   float* g_light_R;         /* (B,9) (+=) or NULL */
@@ -147,6 +151,10 @@ typedef struct harp_shade_args {
    * |bg_c - y_c| * mask — the photometric term of a super-tile that holds no face (static targets: a table instead of reading mask
    * and target of 3/4 of the image every step) */
   const float* l1_bg_sums;
+  /* optional (backward): (B, ceil(S/16), ceil(S/16)) bytes; the byte of every 16x16 light-view tile in which the backward adds to g_zl
+   * is set to 1.  harp_depth_bwd_tiles / harp_depth_nmap_bwd read them to leave out the tiles without a gradient (about half of the
+   * tiles they would otherwise read) and clear the ones they consume. */
+  unsigned char* g_zl_tiles;
 } harp_shade_args;
 /* interleaves albedo (Ht*Wt,3) and the normalised normal map (Ht*Wt,3) into out (Ht*Wt,8): [r g b nx | ny nz 0 0], 16-B aligned */
 int harp_pack_texels(const float* tex, const float* nmap, int n_texels, float* out, hipStream_t stream);
@@ -331,11 +339,12 @@ int harp_draw_texture_offsets(unsigned seed, int* counter_dev, int H, int W, flo
 /* The parameter-only regularisers of a step in ONE launch (optimize_sequence.py:533, 549-551): harp_texture_smooth_reg(tex, dist_albedo)
  * -> loss_albedo / g_tex, harp_close_to_z_reg(nmap, z_scale) + harp_texture_smooth_reg(nmap, dist_normal) -> loss_normal / g_nmap (one
  * weight, as the reference adds the two into one term), and — when disp != NULL — harp_sum_squares(disp, n_disp) -> loss_disp / g_disp.
- * Same per-element arithmetic as the stand-alone calls; the gradient images are accumulated with atomics. */
+ * Same per-element arithmetic as the stand-alone calls; the gradient images are accumulated with atomics.  draw_counter_bump (optional):
+ * *draw_counter_bump += 1 — the counter harp_step_prologue drew dist_albedo / dist_normal for, advanced by the launch that consumes them. */
 int harp_texture_terms(const float* tex, const float* nmap, const float* mask, const int32_t* dist_albedo, const int32_t* dist_normal,
                        int H, int W, float z_scale, const float* w_albedo, float* loss_albedo, float* g_tex, const float* w_normal,
                        float* loss_normal, float* g_nmap, const float* disp, int n_disp, const float* w_disp, float* loss_disp,
-                       float* g_disp, hipStream_t stream);
+                       float* g_disp, int* draw_counter_bump, hipStream_t stream);
 /* scale * close_to_z_reg (loss/texture_reg.py:40-45) */
 int harp_close_to_z_reg(const float* nm, int H, int W, float scale, const float* w, float* loss, float* g_nm, hipStream_t stream);
 /* F.normalize(normal_map, dim=-1) (utils/visualize.py:99); n = number of texels */

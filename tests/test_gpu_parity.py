@@ -1068,7 +1068,8 @@ def test_light_camera_incl_look_at_replacement_branch():
                                       dict(graph_order=False, mesh_third=False, camera_first=False), dict(early_terms=False),
                                       dict(mesh_terms_first=False, mesh_third=False), dict(tail_side=True), dict(consume_gzl=False), dict(keep_depth=False),
                                       dict(fold_step=False), dict(fused_terms=False), dict(fold_step=False, fused_terms=False),
-                                      dict(fold_step=False, mesh_third=False), dict(fused_terms=False, consume_gzl=False)])
+                                      dict(fold_step=False, mesh_third=False), dict(fused_terms=False, consume_gzl=False), dict(zl_tile_flags=True),
+                                      dict(fused_terms=False, zl_tile_flags=True)])
 def test_schedule_switches_give_the_default_schedules_result(switches):
     """The stream / capture-order switches of FitEngine (graph_order, mesh_third, camera_first, overlap, early_terms, mesh_terms_first,
     tail_side) only move launches between streams: losses and the whole gradient arena of every non-default combination must equal the
@@ -1093,6 +1094,7 @@ def test_schedule_switches_give_the_default_schedules_result(switches):
     # the shadow-map gradient image is all-zero again after a step: the depth backward clears what it consumes (harp_depth_bwd_consume),
     # which is what lets the default schedule go without the per-step clear of that image
     assert eng.consume_gzl and eng.s["g_zl"].abs().max().item() == 0.0
+    assert eng.s["zl_tiles"].max().item() == 0                                # ... and so are the tile flags (on from 1024 px; forced on below)
     defaults = {k: getattr(eng, k) for k in switches}
     for k, v in switches.items():
         setattr(eng, k, v)
@@ -1111,20 +1113,21 @@ def test_schedule_switches_give_the_default_schedules_result(switches):
 
 def test_folded_step_bookkeeping_equals_the_separate_kernels():
     """`fold_step`: the batch row fetched by hand_front, loss vector / schedule row / draw counter turned over by hand_back, slab clear +
-    Adam tick + offset draw in ONE launch (harp_step_frame, harp_step_prologue) — against an identical engine that runs harp_schedule_next,
-    the fills, harp_adam_tick, harp_draw_texture_offsets and the un-fused terms as launches of their own.  Several steps over a
-    multi-row schedule with fresh offset draws and a non-zero learning rate, eagerly and graph-replayed: the same frames, the same draws,
-    the same optimiser state after every step."""
+    Adam tick + offset draw in ONE launch (harp_step_frame, harp_step_prologue) — and the same prologue without the fold, the counter then
+    advanced by harp_texture_terms — against an identical engine that runs harp_schedule_next, the fills, harp_adam_tick,
+    harp_draw_texture_offsets and the un-fused terms as launches of their own.  Several steps over a multi-row schedule with fresh offset
+    draws and a non-zero learning rate, eagerly and graph-replayed: the same frames, the same draws, the same optimiser state after
+    every step."""
     from tests._scene import make_fit_case
-    cases = [make_fit_case("hand", T=6, S=128, B=3, seed=9, device=DEV) for _ in range(2)]
+    cases = [make_fit_case("hand", T=6, S=128, B=3, seed=9, device=DEV) for _ in range(3)]
     sched = torch.tensor([[0, 1, 2], [3, 4, 5], [5, 0, 3], [2, 2, 4]]).int()          # (a frame may repeat inside a batch)
-    for c, fold in zip(cases, (True, False)):
+    for c, (fold, fused) in zip(cases, ((True, True), (False, False), (False, True))):
         eng = c["eng"]
         eng.keep_image = False
-        eng.fold_step = eng.fused_terms = fold
+        eng.fold_step, eng.fused_terms = fold, fused
         eng.set_schedule(sched)
-    a, b = cases[0]["eng"], cases[1]["eng"]
-    assert a._can_fold() and not b._can_fold()
+    a, b, c3 = (c["eng"] for c in cases)
+    assert a._can_fold() and not b._can_fold() and not c3._can_fold()
     step, draws0 = 0, a.draw_counter.item()
     for graph in (False, True):
         for _ in range(5):
@@ -1132,20 +1135,56 @@ def test_folded_step_bookkeeping_equals_the_separate_kernels():
                 c["eng"].step(None, True, True, use_graph=graph)
             torch.cuda.synchronize()
             step += 1
-            assert torch.equal(a.fid, b.fid) and torch.equal(a.tfid, b.tfid), (step, a.fid, b.fid)
-            assert a.schedule_row.item() == b.schedule_row.item() and a.draw_counter.item() == b.draw_counter.item() == draws0 + step
-            assert torch.equal(a.dist_albedo, b.dist_albedo) and torch.equal(a.dist_normal, b.dist_normal)
-            assert torch.equal(a.hyper, b.hyper)                                            # step counts and bias corrections
-            la, lb = a.loss_vec[:9].double(), b.loss_vec[:9].double()
-            assert ((la - lb).abs() <= 1e-5 * lb.abs() + 1e-9).all(), (step, la, lb)
+            for e in (a, c3):
+                assert torch.equal(e.fid, b.fid) and torch.equal(e.tfid, b.tfid), (step, e.fid, b.fid)
+                assert e.schedule_row.item() == b.schedule_row.item() and e.draw_counter.item() == b.draw_counter.item() == draws0 + step
+                assert torch.equal(e.dist_albedo, b.dist_albedo) and torch.equal(e.dist_normal, b.dist_normal)
+                assert torch.equal(e.hyper, b.hyper)                                            # step counts and bias corrections
+                la, lb = e.loss_vec[:9].double(), b.loss_vec[:9].double()
+                assert ((la - lb).abs() <= 1e-5 * lb.abs() + 1e-9).all(), (step, la, lb)
+                assert rel(e.g_buf.double(), b.g_buf.double()) < 1e-4, (step, rel(e.g_buf.double(), b.g_buf.double()))
+                d = (e.p_buf - b.p_buf).abs()
+                assert d.mean().item() < 1e-6 and (d > 1e-3).float().mean().item() < 1e-4, (step, d.mean().item(), d.max().item())
             assert a.loss_acc.abs().max().item() == 0.0                                     # clean for the next step
-            assert rel(a.g_buf.double(), b.g_buf.double()) < 1e-4, (step, rel(a.g_buf.double(), b.g_buf.double()))
-            d = (a.p_buf - b.p_buf).abs()
-            assert d.mean().item() < 1e-6 and (d > 1e-3).float().mean().item() < 1e-4, (step, d.mean().item(), d.max().item())
             # teacher forcing: Adam turns the order noise of the float atomics into sign flips of near-zero updates, which would compound
-            for k in ("p_buf", "m_buf", "v_buf"):
-                getattr(b, k).copy_(getattr(a, k))
+            for e in (a, c3):
+                for k in ("p_buf", "m_buf", "v_buf"):
+                    getattr(e, k).copy_(getattr(b, k))
     assert a.losses().keys() == b.losses().keys()
+
+
+def test_light_view_tile_flags_cover_the_shadow_map_gradient():
+    """harp_shade_args.g_zl_tiles: when the shader backward is done, every 16x16 light-view tile that holds a non-zero entry of the
+    shadow-map gradient image is flagged (the depth backward reads flagged tiles only); when the depth backward is done, image and flags
+    are all-zero again."""
+    from tests._scene import make_fit_case
+    from harp_amd import _lib
+    case = make_fit_case("hand", T=3, S=128, B=3, seed=11, device=DEV)
+    eng = case["eng"]
+    eng.keep_image = False
+    eng.zl_tile_flags = True
+    eng.set_stage(True, True)
+    L = _lib.lib()
+    seen = {}
+    orig = L.harp_depth_nmap_bwd
+
+    def spy(*a):
+        torch.cuda.synchronize()
+        seen["g"], seen["t"] = eng.s["g_zl"].clone(), eng.s["zl_tiles"].clone()
+        return orig(*a)
+    L.harp_depth_nmap_bwd = spy
+    try:
+        eng.fid.copy_(torch.arange(3, dtype=torch.int32)); eng.tfid.copy_(torch.arange(3, dtype=torch.int32))
+        eng.forward_backward(True, True)
+        torch.cuda.synchronize()
+    finally:
+        L.harp_depth_nmap_bwd = orig
+    S, nt = 128, 8
+    nz = (seen["g"].view(3, nt, 16, nt, 16) != 0).any(dim=4).any(dim=2)
+    fl = seen["t"].view(3, nt, nt) != 0
+    assert nz.sum().item() > 10 and (fl | ~nz).all(), (nz.sum().item(), fl.sum().item())      # flagged is a superset of non-zero
+    assert fl.sum().item() <= nz.sum().item() + 8                                              # ... and not much more (fixed-point roundings to 0)
+    assert eng.s["g_zl"].abs().max().item() == 0.0 and eng.s["zl_tiles"].max().item() == 0
 
 
 def test_step_prologue_equals_fill_tick_and_draw():
