@@ -272,10 +272,13 @@ def _graph_rate(e, steps, warmup):
     return {"frames_per_s": B * steps / dt, "ms_per_step": dt / steps * 1e3, "frames_per_step": B, "steps": steps}
 
 
-def extra_rates(eng, device, steps=40, warmup=6, vgg_weights="random"):
+def extra_rates(eng, device, steps=100, warmup=30, vgg_weights="random"):
     """Rates of the other BASELINE.json configurations and modes (not the headline `value`): the same step with the rendered image
     materialised like the reference's y_pred (keep_image=True), C2 at the reference's batch size 18, and C5's per-GPU share (SMPL-X
-    arm mesh at 1024x1024, 32 frames / GPU).  Graph-replayed steps, barrier-free single GPU, synthetic targets rendered by the engine."""
+    arm mesh at 1024x1024, 32 frames / GPU).  Graph-replayed steps, barrier-free single GPU, synthetic targets rendered by the engine.
+    (30 warm-up steps: the first ~50 ms after an engine is built run 5 % slower — the device idles while the host renders the targets
+    — and a 6-step warm-up put that ramp into the 40 timed steps: 1.886 ms / step against 1.79 for every later measurement of the same
+    engine, tools/dev/gpu_c5_rate.py in round 4.)"""
     rate = lambda e: _graph_rate(e, steps, warmup)
     out = {}
     e = build_engine(0, 1, device, T=72, img=S, B=18)[0]
