@@ -125,6 +125,7 @@ SIGNATURES.update({
     "harp_light_setup_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
     "harp_scale": (_i, [_vp, _f, _i, _vp, _vp]),
     "harp_schedule_next": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp]),
+    "harp_schedule_next_rows": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp]),
 })
 
 SIGNATURES.update({
@@ -184,8 +185,8 @@ SIGNATURES["harp_shade_sil_bwd"] = (_i, [ctypes.POINTER(ShadeArgs), _f, _f, _vp,
 
 class StepFrame(ctypes.Structure):
     """mirror of `harp_step_frame` (include/harp_hip.h)"""
-    _fields_ = [("schedule", _vp), ("sched_row", _vp), ("n_rows", _i), ("target_offset", _i), ("tfid_out", _vp), ("clear_mesh_grads", _i),
-                ("loss", _vp), ("loss_out", _vp), ("n_loss", _i), ("draw_counter", _vp)]
+    _fields_ = [("schedule", _vp), ("tschedule", _vp), ("sched_row", _vp), ("n_rows", _i), ("target_offset", _i), ("tfid_out", _vp), ("clear_mesh_grads", _i),
+                ("loss", _vp), ("loss_out", _vp), ("n_loss", _i), ("draw_counter", _vp), ("loss_w", _vp), ("loss_total", _vp)]
 
 
 class HandFront(ctypes.Structure):

@@ -114,7 +114,7 @@ __global__ void scale_kernel(const float* __restrict__ x, float s, int n, float*
 
 // One row of a device-resident batch schedule -> the step's frame ids (and target-local ids); bumps the row counter.  Lives inside
 // the step's hipGraph so that a replay needs no host-side copy at all.
-__global__ void schedule_next_kernel(const int32_t* __restrict__ sched, int n_rows, int B, int target_offset,
+__global__ void schedule_next_kernel(const int32_t* __restrict__ sched, const int32_t* __restrict__ tsched, int n_rows, int B, int target_offset,
                                      int32_t* __restrict__ counter, int32_t* __restrict__ fid, int32_t* __restrict__ tfid,
                                      float* __restrict__ zero, int n_zero) {
   for (int i = threadIdx.x; i < n_zero; i += blockDim.x) zero[i] = 0.f;      // (the step's loss vector: no launch of its own)
@@ -122,7 +122,7 @@ __global__ void schedule_next_kernel(const int32_t* __restrict__ sched, int n_ro
   for (int i = threadIdx.x; i < B; i += blockDim.x) {
     const int f = sched[(size_t)row * B + i];
     fid[i] = f;
-    tfid[i] = f - target_offset;
+    tfid[i] = tsched ? tsched[(size_t)row * B + i] : f - target_offset;
   }
   __syncthreads();
   if (threadIdx.x == 0) counter[0] = row + 1;
@@ -178,13 +178,18 @@ int harp_scale(const float* x, float s, int n, float* y, hipStream_t stream) {
   return HARP_OK;
 }
 
-int harp_schedule_next(const int32_t* schedule, int n_rows, int B, int target_offset, int32_t* counter, int32_t* fid, int32_t* tfid,
-                       float* zero, int n_zero, hipStream_t stream) {
+int harp_schedule_next_rows(const int32_t* schedule, const int32_t* tschedule, int n_rows, int B, int target_offset, int32_t* counter,
+                            int32_t* fid, int32_t* tfid, float* zero, int n_zero, hipStream_t stream) {
   if (!schedule || !counter || !fid || !tfid || n_rows <= 0 || B <= 0 || (n_zero > 0 && !zero)) return HARP_ERR_ARG;
-  hipLaunchKernelGGL(schedule_next_kernel, dim3(1), dim3(256), 0, stream, schedule, n_rows, B, target_offset, counter, fid, tfid, zero,
+  hipLaunchKernelGGL(schedule_next_kernel, dim3(1), dim3(256), 0, stream, schedule, tschedule, n_rows, B, target_offset, counter, fid, tfid, zero,
                      zero ? n_zero : 0);
   HARP_CHECK_LAUNCH();
   return HARP_OK;
+}
+
+int harp_schedule_next(const int32_t* schedule, int n_rows, int B, int target_offset, int32_t* counter, int32_t* fid, int32_t* tfid,
+                       float* zero, int n_zero, hipStream_t stream) {
+  return harp_schedule_next_rows(schedule, nullptr, n_rows, B, target_offset, counter, fid, tfid, zero, n_zero, stream);
 }
 
 }  // extern "C"

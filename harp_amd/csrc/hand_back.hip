@@ -115,10 +115,18 @@ __global__ void __launch_bounds__(kChainThreads) hand_back_kernel(const harp_han
   //      counter is an EARLIER launch of the step (stream order / joins), so one workgroup can turn the three over for the next step
   if (b == 0) {
     const harp_step_frame& E = H.step;
-    if (tid >= 128 && tid < 128 + E.n_loss && E.loss) {
+    if ((tid >> 6) == 2) {                          // wave 2 (lanes 128 .. 191), whole: the wave sum below needs every lane
       const int k = tid - 128;
-      if (E.loss_out) E.loss_out[k] = E.loss[k];
-      E.loss[k] = 0.f;
+      const bool on = E.loss && k < E.n_loss;       // n_loss <= 64 (checked by the launcher)
+      const float v = on ? E.loss[k] : 0.f;
+      if (on) {
+        if (E.loss_out) E.loss_out[k] = v;
+        E.loss[k] = 0.f;
+      }
+      if (E.loss_w && E.loss_total) {
+        const float tot = wave_sum_u(on ? E.loss_w[k] * v : 0.f);
+        if (k == 0) E.loss_total[0] += tot;
+      }
     } else if (tid == 192 && E.schedule) {
       E.sched_row[0] = (int)((unsigned)E.sched_row[0] % (unsigned)E.n_rows) + 1;
     } else if (tid == 193 && E.draw_counter) {

@@ -54,7 +54,7 @@ __global__ void __launch_bounds__(kChainThreads) hand_front_kernel(const harp_ha
     f = H.step.schedule[(size_t)row * B + b];
     if (tid == 0) {
       const_cast<int32_t*>(H.fid)[b] = f;
-      if (H.step.tfid_out) H.step.tfid_out[b] = f - H.step.target_offset;
+      if (H.step.tfid_out) H.step.tfid_out[b] = H.step.tschedule ? H.step.tschedule[(size_t)row * B + b] : f - H.step.target_offset;
     }
   } else {
     f = H.fid[b];

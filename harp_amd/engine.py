@@ -142,6 +142,11 @@ class FitEngine:
         self.target_offset = 0
         self.w_vec = torch.zeros(16, dtype=torch.float32, device=self.dev)
         self._main["loss_vec"], self._main["w_vec"] = self.loss_vec, self.w_vec
+        # accumulate_loss: loss_total += sum_k w_k loss_k after every step — the reference's per-step `sum_loss` added up over an epoch
+        # (optimize_sequence.py:553-559, :581) — by hand_back itself in a folded step, by two small torch kernels otherwise
+        self.accumulate_loss = False
+        self.loss_total = torch.zeros(1, dtype=torch.float32, device=self.dev)
+        self.w_total = torch.zeros(16, dtype=torch.float32, device=self.dev)
         self.loss_acc = torch.zeros(16, dtype=torch.float32, device=self.dev)      # fold_step: the terms accumulate here, hand_back moves them to loss_vec and clears
         self._main["owns_shared"] = True               # its zero slab also covers g_buf / g_nmap_n / loss_vec
         self._activate(self._main)
@@ -185,7 +190,7 @@ class FitEngine:
         self.fused_terms = True          # normalise + pack, the four parameter-only regularisers, key-point + mesh terms, depth backward + normal-map chain rule: one launch each (were 2 + 4 + 2 + 2)
         self.frozen = ()                 # parameters kept out of the optimiser groups (known_appearance)
         self.disabled_terms = frozenset()   # loss terms left out of the objective altogether (set_disabled_terms)
-        self.schedule = None
+        self.schedule = self.tschedule = None
         self._stage = None
         self._early_work = None
         self._loss_cleared = False
@@ -377,9 +382,12 @@ class FitEngine:
                 raise RuntimeError("forward_backward(sched=True) needs the full batch, the shared terms and _can_fold()")
             frame = _lib.StepFrame()
             frame.schedule, frame.sched_row = _lib.ptr(self.schedule), _lib.ptr(self.schedule_row)
+            frame.tschedule = _lib.ptr(self.tschedule) if self.tschedule is not None else None
             frame.n_rows, frame.target_offset = int(self.schedule.shape[0]), int(self.target_offset)
             frame.tfid_out, frame.clear_mesh_grads = _lib.ptr(ltfid), 1
             frame.loss, frame.loss_out, frame.n_loss = _lib.ptr(self.loss_acc), _lib.ptr(lloss), 16
+            if self.accumulate_loss:
+                frame.loss_w, frame.loss_total = _lib.ptr(self.w_total), _lib.ptr(self.loss_total)
             if app and self.auto_draw:
                 frame.draw_counter = _lib.ptr(self.draw_counter)
             lloss = self.loss_acc
@@ -847,6 +855,10 @@ class FitEngine:
             if ((coarse and k in COARSE_TERMS) or (app and k in APP_TERMS)) and k not in self.disabled_terms:
                 w[i] = LOSS_WEIGHTS[k]
         self.w_vec.copy_(w.to(self.dev))
+        # the weights of the step's sum_loss (optimize_sequence.py:553-559): the same, plus the perceptual term's in slot 9
+        if app and self.perceptual is not None:
+            w[9] = self.perceptual_weight
+        self.w_total.copy_(w.to(self.dev))
 
     def set_disabled_terms(self, names):
         """Leave loss terms out of the objective: weight 0, kernels not launched, loss value reported as 0.  The reference fits a test
@@ -862,12 +874,17 @@ class FitEngine:
 
     def set_lr(self, lr_coarse=None, lr_app=None):
         """host -> device hyper block (ReduceLROnPlateau lives on the host, optimize_sequence.py:309, 581-582)"""
+        new = (None if lr_coarse is None else float(lr_coarse), None if lr_app is None else float(lr_app))
+        last = getattr(self, "_lr_set", (None, None))
+        if all(n is None or n == l for n, l in zip(new, last)):
+            return                                       # unchanged since the last call (every epoch without a plateau): no D2H + H2D round trip
         h = self.hyper.cpu().numpy().view(self.hyper_np.dtype)
         if lr_coarse is not None:
             h["lr"][0] = lr_coarse
         if lr_app is not None:
             h["lr"][1] = lr_app
         self.hyper.copy_(torch.from_numpy(h.view(np.uint8)).to(self.dev))
+        self._lr_set = tuple(n if n is not None else l for n, l in zip(new, last))
 
     def draw_texture_offsets(self):
         """the random neighbour offsets of albedo_reg (std 1) / smooth_texture_reg (std 2), loss/texture_reg.py:15, 51 — drawn on the
@@ -876,22 +893,38 @@ class FitEngine:
         self._ck(L.harp_draw_texture_offsets(self.seed, p(self.draw_counter), self.Ht, self.Wt, 1.0, p(self.dist_albedo), 2.0, p(self.dist_normal), st),
                  "draw_offsets")
 
-    def set_schedule(self, schedule):
+    def set_schedule(self, schedule, tschedule=None):
         """(n_rows, batch_size) global frame ids, kept on the device: `step(None, ...)` then takes the next row (wrapping around)
         inside the step's hipGraph, so a replay needs no host-side copy at all (the reference's DataLoader hands a host tensor over
-        every step, optimize_sequence.py:399, :446)."""
+        every step, optimize_sequence.py:399, :446).  tschedule: the rows of the resident targets these frames compare against, same
+        shape (default fid - target_offset, i.e. targets stored in frame order) — for a dataset that holds a subset / another order of
+        the frames.  A schedule of the SAME shape as the current one is written into the buffers the captured step graphs already read
+        (a new epoch's shuffle costs two small copies, no re-capture); the row counter starts at 0 again."""
         sch = torch.as_tensor(schedule).to(torch.int32).to(self.dev).contiguous()
         if sch.dim() != 2 or sch.shape[1] != self.B:
             raise ValueError(f"schedule must be (n_rows, {self.B}), got {tuple(sch.shape)}")
-        self.schedule = sch
+        tsch = None
+        if tschedule is not None:
+            tsch = torch.as_tensor(tschedule).to(torch.int32).to(self.dev).contiguous()
+            if tsch.shape != sch.shape:
+                raise ValueError(f"tschedule must have the schedule's shape {tuple(sch.shape)}, got {tuple(tsch.shape)}")
+        same = (self.schedule is not None and self.schedule.shape == sch.shape and (self.tschedule is None) == (tsch is None))
+        if same:
+            self.schedule.copy_(sch)
+            if tsch is not None:
+                self.tschedule.copy_(tsch)
+            self.schedule_row.zero_()
+            return
+        self.schedule, self.tschedule = sch, tsch
         self.schedule_row = torch.zeros(1, dtype=torch.int32, device=self.dev)
         self._graphs = {}                               # graphs captured against an older schedule buffer are stale
 
     def _schedule_next(self):
         # the same launch clears the loss vector: with it gone from the slab clear, that one runs on the second stream (forward_backward)
-        self._ck(_lib.lib().harp_schedule_next(_lib.ptr(self.schedule), int(self.schedule.shape[0]), self.B, self.target_offset,
-                                               _lib.ptr(self.schedule_row), _lib.ptr(self.fid), _lib.ptr(self.tfid), _lib.ptr(self.loss_vec), 16,
-                                               _lib.stream()), "schedule_next")
+        self._ck(_lib.lib().harp_schedule_next_rows(_lib.ptr(self.schedule), _lib.ptr(self.tschedule) if self.tschedule is not None else None,
+                                                    int(self.schedule.shape[0]), self.B, self.target_offset, _lib.ptr(self.schedule_row),
+                                                    _lib.ptr(self.fid), _lib.ptr(self.tfid), _lib.ptr(self.loss_vec), 16, _lib.stream()),
+                 "schedule_next")
         self._loss_cleared = True
 
     def step(self, fid, coarse=True, app=True, use_graph=True, tfid=None):
@@ -931,11 +964,13 @@ class FitEngine:
             fb()
             self.allreduce()
             self.adam(coarse, app, tick=False)
+            if self.accumulate_loss and not fold:
+                self.loss_total.add_(torch.dot(self.loss_vec, self.w_total))
             return
         # every switch the enqueued launch sequence depends on is part of the key: flipping one re-captures instead of replaying a
         # graph recorded for another configuration
         gkey = (coarse, app, scheduled, self.keep_image, self.fused_loss, self.self_shadow, tuple(self.frozen), self.overlap, self.early_terms,
-                self.packed_texels, self.fused_keep, self.mesh_third, self.graph_order, fold, self.fused_terms, self.zl_tile_flags, self.auto_draw, self.mesh_terms_first, self.camera_first, self.tail_side, self.fused_bwd, self.fused_chain, self.fused_front, self.fused_back, self.consume_gzl, self.keep_depth, dist_on, self.overlap_allreduce,
+                self.packed_texels, self.fused_keep, self.mesh_third, self.graph_order, fold, self.fused_terms, self.zl_tile_flags, self.accumulate_loss, self.auto_draw, self.mesh_terms_first, self.camera_first, self.tail_side, self.fused_bwd, self.fused_chain, self.fused_front, self.fused_back, self.consume_gzl, self.keep_depth, dist_on, self.overlap_allreduce,
                 self.comm is not None, self.perceptual is not None and app)
         g = self._graphs.get(gkey)
         if g is None:
@@ -943,13 +978,14 @@ class FitEngine:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             row = self.schedule_row.clone() if scheduled else None
-            hyper, draws = self.hyper.clone(), self.draw_counter.clone()
+            hyper, draws, ltot = self.hyper.clone(), self.draw_counter.clone(), self.loss_total.clone()
             with torch.cuda.stream(side):
                 fb()
                 self.allreduce()                         # completes (and clears) the early all-reduce the warm-up pass started
             torch.cuda.current_stream().wait_stream(side)
             self.hyper.copy_(hyper)                      # the warm-up pass must not advance the optimiser's step count ...
             self.draw_counter.copy_(draws)               # ... nor the texture-offset generator (same draws as an eager run with this seed)
+            self.loss_total.copy_(ltot)                  # ... nor count its losses into the epoch's sum (accumulate_loss)
             if scheduled:
                 self.schedule_row.copy_(row)             # ... nor consume a schedule row
             torch.cuda.synchronize()
@@ -963,6 +999,8 @@ class FitEngine:
             self._graphs[gkey] = g
             # the capture itself does not execute; fall through to the first replay
         g.replay()
+        if self.accumulate_loss and not fold:
+            self.loss_total.add_(torch.dot(self.loss_vec, self.w_total))
 
     def losses(self):
         """dict of the last step's unweighted loss terms (one D2H copy; call sparingly)."""

@@ -86,7 +86,7 @@ def stage_flags(epoch_id, training_stage):
 
 def optimize_hand_sequence(configs, input_params, images_dataset, val_params, val_images_dataset, hand_layer,
                            VERTS_UVS=None, FACES_UVS=None, VERTS_COLOR=None, device="cuda", uv_mask=None, batch_size=18, log_fn=None,
-                           seed=0, vgg=None, rank=None, world_size=None, shards=None, plateau_patience=40, plateau_threshold=1e-4):
+                           seed=0, vgg=None, rank=None, world_size=None, shards=None, plateau_patience=40, plateau_threshold=1e-4, device_schedule=True):
     """Fit the sequence (optimize_sequence.py:313-596).  Returns the parameter dict in the reference's checkpoint layout.
     `images_dataset[i]` -> (fid, y_true (S,S,3), y_sil (S,S,1), y_sil_eroded (S,S,1)) like utils/data_util.ImagesDataset.
 
@@ -142,6 +142,7 @@ def optimize_hand_sequence(configs, input_params, images_dataset, val_params, va
     if vgg is not None:
         eng.set_perceptual(vgg, weight=1.0)
     eng.keep_image = False                                           # the fused L1 consumes y_pred in the shader; nothing reads the image back
+    eng.accumulate_loss = True
     if configs["start_from"]:
         restore_checkpoint(eng, configs, input_params)
     if configs["known_appearance"]:
@@ -153,25 +154,31 @@ def optimize_hand_sequence(configs, input_params, images_dataset, val_params, va
     dummy = torch.optim.Adam([torch.nn.Parameter(torch.zeros(1))], lr=1e-3)
     sched = torch.optim.lr_scheduler.ReduceLROnPlateau(dummy, patience=plateau_patience, threshold=plateau_threshold)
     gen = torch.Generator().manual_seed(seed)                        # the SAME stream of draws on every rank
-    weights = torch.tensor([{"silhouette": 7.0, "kps_anchor": 10.0, "vert_disp_reg": 2.0, "laplacian": 4.0, "normal": 0.1, "arap": 0.2,
-                             "photo": 1.0, "albedo": 0.5, "normal_reg": 0.1}[k_] for k_ in LOSS_NAMES], device=device)
+    # (the loss weights of :411-422 are the engine's LOSS_WEIGHTS: its kernels scale the gradients with them and its step epilogue forms sum_loss)
     own = torch.arange(k) * per                                      # first local row of each of this rank's shards
     try:
         for epoch_id in range(configs["total_epoch"]):
             coarse, app = stage_flags(epoch_id, configs["training_stage"])
-            epoch_loss = torch.zeros((), device=device)
-            nb = 0
-            for order in hdist.epoch_batches(per, b, gen):                             # DataLoader(shuffle=True) over the DATASET's items, :398
-                item = (own[:, None] + order[None, :]).reshape(-1)                     # local rows of the resident targets, shard by shard
-                eng.step(rt.fid[item], coarse, app, tfid=item)                         # parameter rows = the items' own fids (:446, :464)
-                active = (eng.w_vec[:9] > 0).float()
-                epoch_loss += (eng.loss_vec[:9] * weights * active).sum()              # stays on the device: no per-term .cpu() sync (:559)
-                if app and eng.perceptual is not None:
-                    epoch_loss += eng.loss_vec[9] * eng.perceptual_weight
-                nb += 1
+            eng.loss_total.zero_()            # the engine adds every step's sum_loss (:553-559) to it on the device: no per-step host arithmetic, no sync
+            batches = hdist.epoch_batches(per, b, gen)                                 # DataLoader(shuffle=True) over the DATASET's items, :398
+            items = [(own[:, None] + order[None, :]).reshape(-1) for order in batches]  # local rows of the resident targets, shard by shard
+            # the epoch's full batches go to the device as ONE schedule (parameter rows = the items' own fids, :446, :464; target rows = the
+            # items): every such step is then a bare graph replay that fetches its own row — no host tensor per step like the DataLoader's
+            # (:399).  Same shape every epoch: the captured step graphs keep reading the same two buffers.
+            full = [it for it in items if it.numel() == eng.B] if device_schedule else []
+            if full:
+                rows = torch.stack(full)
+                eng.set_schedule(rt.fid[rows], tschedule=rows)
+            for item in items:
+                if item.numel() == eng.B and device_schedule:
+                    eng.step(None, coarse, app)
+                else:
+                    eng.step(rt.fid[item], coarse, app, tfid=item)                     # the last, partial batch runs eagerly (:396-399)
+            nb = len(items)
             # one sync per epoch; N > 1: the mean over ranks (image terms are means over a rank's frames, regularisers are identical),
             # the same float on every rank
-            mean_loss = float(hdist.mean_over_ranks(float(epoch_loss / nb), device=eng.dev) if world > 1 else epoch_loss / nb)
+            epoch_loss = float(eng.loss_total.item()) / nb
+            mean_loss = float(hdist.mean_over_ranks(epoch_loss, device=eng.dev)) if world > 1 else epoch_loss
             if not np.isfinite(mean_loss):
                 raise FloatingPointError(f"non-finite loss at epoch {epoch_id}")      # the reference drops into pdb (:525-527); all ranks raise together
             if coarse:

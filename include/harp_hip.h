@@ -408,9 +408,11 @@ int harp_frame_setup_bwd(const harp_frame_tables* t, const int32_t* fid, int B, 
  * the frame are zeroed (the two gradient segments the key-point / mesh terms accumulate into).
  * Back (harp_hand_back_bwd; every kernel that adds to the loss vector has finished by then): sched_row[0] = row + 1;
  * loss_out[0..n_loss) = loss[0..n_loss) and loss[..] = 0 (the terms of the NEXT step accumulate into a clean vector, no clear at the
- * head of a step); draw_counter[0] += 1 (harp_draw_texture_offsets_at of the next step draws fresh offsets). */
+ * head of a step), loss_total[0] += loss_w . loss when both are given; draw_counter[0] += 1 (harp_draw_texture_offsets_at of the next step draws fresh offsets). */
 typedef struct harp_step_frame {
   const int32_t* schedule;
+  const int32_t* tschedule;   /* optional (n_rows,B): rows of the resident targets (a dataset that holds a subset / another order of the frames);
+                               * NULL: tfid = fid - target_offset */
   int32_t* sched_row;
   int n_rows, target_offset;
   int32_t* tfid_out;
@@ -419,6 +421,8 @@ typedef struct harp_step_frame {
   float* loss_out;
   int n_loss;
   int32_t* draw_counter;
+  const float* loss_w;        /* optional (n_loss,): back: loss_total[0] += sum_k loss_w[k] * loss[k] — the step's sum_loss */
+  float* loss_total;          /*   (optimize_sequence.py:553-559) accumulated over an epoch on the device, no per-step host arithmetic */
 } harp_step_frame;
 
 typedef struct harp_hand_front {
@@ -449,6 +453,9 @@ int harp_scale(const float* x, float s, int n, float* y, hipStream_t stream);
  * (n_rows,B) int32 schedule -> fid (B,), tfid = fid - target_offset; then counter[0] = row + 1.  Graph-replayable. */
 int harp_schedule_next(const int32_t* schedule, int n_rows, int B, int target_offset, int32_t* counter, int32_t* fid, int32_t* tfid,
                        float* zero, int n_zero, hipStream_t stream);   /* zero (optional): n_zero floats cleared in the same launch (loss vector) */
+/* the same with the target rows given by a second (n_rows,B) table instead of fid - target_offset (tschedule == NULL: as above) */
+int harp_schedule_next_rows(const int32_t* schedule, const int32_t* tschedule, int n_rows, int B, int target_offset, int32_t* counter,
+                            int32_t* fid, int32_t* tfid, float* zero, int n_zero, hipStream_t stream);
 
 /* ---- data-parallel exchange (RCCL over xGMI) -------------------------------------------------------------------------
  * New capability: the reference is single-device.  Frames of a sequence are sharded over the GPUs of a node; between

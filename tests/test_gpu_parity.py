@@ -571,6 +571,51 @@ def test_device_schedule_matches_explicit_batches(sc):
                   sc["focal"], 2, device=DEV).step(None)
 
 
+@pytest.mark.parametrize("fold", [True, False])
+def test_device_schedule_with_target_rows_and_in_place_update(sc, fold):
+    """set_schedule(rows, tschedule=...): the resident targets are stored in REVERSED frame order and the schedule carries their rows, in the
+    folded step (hand_front fetches both) and through harp_schedule_next_rows; a second schedule of the same shape is written into the
+    buffers the captured graphs read (no re-capture) and restarts at row 0.  Against explicit step(fid, tfid=...) calls."""
+    from harp_amd.engine import FitEngine
+    tg = sc["targets"]
+    T = tg["y_true"].shape[0]
+    rows1 = torch.tensor([[2, 0], [1, 2]], dtype=torch.int32)
+    rows2 = torch.tensor([[0, 1], [2, 1]], dtype=torch.int32)
+
+    def run(scheduled):
+        eng = FitEngine(sc["model_np"], sc["topo_np"], sc["tpl"]["verts_uvs"], sc["tpl"]["faces_uvs"], sc["uv_mask"].float(), sc["seq"], sc["S"],
+                        sc["focal"], 2, device=DEV, seed=3)
+        eng.fold_step = fold
+        eng.set_targets(tg["y_true"].flip(0), tg["y_sil"].flip(0), tg["y_sil_col"].flip(0))
+        graphs = None
+        for rows in (rows1, rows2):
+            trows = (T - 1) - rows
+            if scheduled:
+                eng.set_schedule(rows, tschedule=trows)
+                assert eng._can_fold() == fold
+            for i in range(3):                       # 3 steps over 2 rows: wraps around
+                if scheduled:
+                    eng.step(None, True, True)
+                else:
+                    eng.step(rows[i % 2].to(DEV), True, True, tfid=trows[i % 2].to(DEV))
+            if scheduled and graphs is None:
+                graphs = dict(eng._graphs)
+        torch.cuda.synchronize()
+        if scheduled:
+            assert eng._graphs == graphs and len(graphs) == 1          # the second schedule re-used the captured graph
+            assert torch.equal(eng.fid.cpu(), rows2[0]) and torch.equal(eng.tfid.cpu(), (T - 1) - rows2[0]) and int(eng.schedule_row.item()) == 1
+        return eng
+    a, b = run(True), run(False)
+    for k in ("pose", "cam", "verts_disps", "shape", "light_positions"):
+        assert (a.params[k] - b.params[k]).abs().max().item() < 2e-3, k
+    d = (a.params["texture"] - b.params["texture"]).abs()
+    assert d.mean().item() < 4e-5 and (d > 1e-3).float().mean().item() < 5e-3      # (6 Adam steps at lr 1e-2: texels whose gradient is order noise flip sign)
+    la, lb = a.loss_vec[:9].double(), b.loss_vec[:9].double()
+    assert ((la - lb).abs() <= 1e-3 * lb.abs() + 1e-9).all(), (la, lb)      # (after 6 Adam steps each)
+    with pytest.raises(ValueError):
+        a.set_schedule(rows1, tschedule=rows1[:1])
+
+
 @pytest.mark.parametrize("coarse,app", [(True, True), (True, False), (False, True)])
 def test_fused_mesh_chain_matches_building_blocks(sc, coarse, app):
     """harp_mesh_chain_fwd/bwd (one workgroup per frame, mesh staged in LDS) against the stand-alone subdivide / normals / displace /
@@ -1125,16 +1170,22 @@ def test_folded_step_bookkeeping_equals_the_separate_kernels():
         eng = c["eng"]
         eng.keep_image = False
         eng.fold_step, eng.fused_terms = fold, fused
+        eng.accumulate_loss = True
         eng.set_schedule(sched)
     a, b, c3 = (c["eng"] for c in cases)
     assert a._can_fold() and not b._can_fold() and not c3._can_fold()
     step, draws0 = 0, a.draw_counter.item()
+    total = 0.0
     for graph in (False, True):
         for _ in range(5):
             for c in cases:
                 c["eng"].step(None, True, True, use_graph=graph)
             torch.cuda.synchronize()
             step += 1
+            # accumulate_loss: every engine's running sum of the steps' sum_loss (the first replay's warm-up pass must not be counted)
+            total += float(torch.dot(b.loss_vec.double(), b.w_total.double()))
+            for e in (a, b, c3):
+                assert abs(e.loss_total.item() - total) <= 1e-4 * abs(total), (step, e.loss_total.item(), total)
             for e in (a, c3):
                 assert torch.equal(e.fid, b.fid) and torch.equal(e.tfid, b.tfid), (step, e.fid, b.fid)
                 assert e.schedule_row.item() == b.schedule_row.item() and e.draw_counter.item() == b.draw_counter.item() == draws0 + step
