@@ -157,18 +157,22 @@ def optimize_hand_sequence(configs, input_params, images_dataset, val_params, va
     # (the loss weights of :411-422 are the engine's LOSS_WEIGHTS: its kernels scale the gradients with them and its step epilogue forms sum_loss)
     own = torch.arange(k) * per                                      # first local row of each of this rank's shards
     try:
+        def draw_epoch():
+            """the next epoch's batches (DataLoader(shuffle=True) over the DATASET's items, :398) and — its full batches as ONE device schedule
+            (parameter rows = the items' own fids, :446, :464; target rows = the items): every such step is a bare graph replay that fetches
+            its own row, no host tensor per step like the DataLoader's (:399); same shape every epoch, so the captured step graphs keep
+            reading the same two buffers — the schedule to hand to eng.set_schedule"""
+            batches = hdist.epoch_batches(per, b, gen)
+            items = [(own[:, None] + order[None, :]).reshape(-1) for order in batches]  # local rows of the resident targets, shard by shard
+            full = [it for it in items if it.numel() == eng.B] if device_schedule else []
+            rows = torch.stack(full) if full else None
+            return items, (None if rows is None else (rt.fid[rows], rows))
+        items, sch = draw_epoch()
+        if sch is not None:
+            eng.set_schedule(sch[0], tschedule=sch[1])
+        eng.loss_total.zero_()            # the engine adds every step's sum_loss (:553-559) to it on the device: no per-step host arithmetic, no sync
         for epoch_id in range(configs["total_epoch"]):
             coarse, app = stage_flags(epoch_id, configs["training_stage"])
-            eng.loss_total.zero_()            # the engine adds every step's sum_loss (:553-559) to it on the device: no per-step host arithmetic, no sync
-            batches = hdist.epoch_batches(per, b, gen)                                 # DataLoader(shuffle=True) over the DATASET's items, :398
-            items = [(own[:, None] + order[None, :]).reshape(-1) for order in batches]  # local rows of the resident targets, shard by shard
-            # the epoch's full batches go to the device as ONE schedule (parameter rows = the items' own fids, :446, :464; target rows = the
-            # items): every such step is then a bare graph replay that fetches its own row — no host tensor per step like the DataLoader's
-            # (:399).  Same shape every epoch: the captured step graphs keep reading the same two buffers.
-            full = [it for it in items if it.numel() == eng.B] if device_schedule else []
-            if full:
-                rows = torch.stack(full)
-                eng.set_schedule(rt.fid[rows], tschedule=rows)
             for item in items:
                 if item.numel() == eng.B and device_schedule:
                     eng.step(None, coarse, app)
@@ -177,7 +181,15 @@ def optimize_hand_sequence(configs, input_params, images_dataset, val_params, va
             nb = len(items)
             # one sync per epoch; N > 1: the mean over ranks (image terms are means over a rank's frames, regularisers are identical),
             # the same float on every rank
-            epoch_loss = float(eng.loss_total.item()) / nb
+            # ... and everything of the NEXT epoch that does not depend on this epoch's loss — its shuffle, its schedule (stream-ordered behind
+            # the steps above) — is enqueued before that sync, so the device goes from this epoch's last step to the next one's first
+            total = eng.loss_total.clone()
+            eng.loss_total.zero_()
+            if epoch_id + 1 < configs["total_epoch"]:
+                items, sch = draw_epoch()
+                if sch is not None:
+                    eng.set_schedule(sch[0], tschedule=sch[1])
+            epoch_loss = float(total.item()) / nb
             mean_loss = float(hdist.mean_over_ranks(epoch_loss, device=eng.dev)) if world > 1 else epoch_loss
             if not np.isfinite(mean_loss):
                 raise FloatingPointError(f"non-finite loss at epoch {epoch_id}")      # the reference drops into pdb (:525-527); all ranks raise together
