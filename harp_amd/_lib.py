@@ -154,7 +154,7 @@ SIGNATURES.update({
 class MeshChain(ctypes.Structure):
     """mirror of `harp_mesh_chain` (include/harp_hip.h)"""
     _fields_ = ([(n, _vp) for n in ("edges0", "vf_off", "vf_tri", "sub_off", "sub_idx", "disp")] +
-                [(n, _i) for n in ("B", "V0", "E0", "NJ", "S")] + [("focal", _f), ("shadow", _i), ("has_normal_grad", _i)] +
+                [(n, _i) for n in ("B", "V0", "E0", "NJ", "S")] + [("focal", _f), ("shadow", _i), ("has_normal_grad", _i), ("light_only", _i)] +
                 [(n, _vp) for n in ("verts_mm", "joints_mm", "cam_R", "cam_T", "light_pos",
                                     "joints_m", "vs", "n1", "il1", "vd", "n2", "il2", "ndc_c", "centroid", "light_R", "light_T", "ndc_l",
                                     "g_ndc_c", "g_ndc_l", "g_n2", "g_joints_m", "g_vd", "g_light_R", "g_light_T",

@@ -261,6 +261,31 @@ __device__ __forceinline__ void mesh_chain_bwd_body(const harp_mesh_chain& A, fl
   __shared__ float s_gc[3];
   const int tid = threadIdx.x;
   const int V0 = A.V0, V = A.V0 + A.E0;
+  if (A.light_only) {
+    // appearance-only stage: the light position is the only optimised parameter this chain feeds — projection backward of the light view
+    // (its 12 camera sums; the vertex gradients it would also produce are not wanted), light camera backward
+    if (!A.shadow) return;
+    const float half = 0.5f * (float)A.S;
+    const size_t fo = (size_t)b * V * 3;
+    float gr[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) gr[k] = 0.f;
+    const float* lR = A.light_R + 9 * b;
+    const float* lT = A.light_T + 3 * b;
+    for (int i = tid; i < V; i += kChainThreads) project_bwd(ld(A.vd + fo + 3 * i), ld(A.g_ndc_l + fo + 3 * i), lR, lT, A.focal, half, gr);
+    block_sum_n<12>(gr, s_red12, s_tot);
+    if (tid == 0) {
+      float gR[9], gT[3];
+      for (int k = 0; k < 9; ++k) gR[k] = A.g_light_R[9 * b + k] + s_tot[k];
+      for (int k = 0; k < 3; ++k) gT[k] = A.g_light_T[3 * b + k] + s_tot[9 + k];
+      const LightCam k = light_cam(ld(A.centroid + 3 * b), ld(A.light_pos + 3 * b));
+      V3 gd, gc;
+      light_cam_bwd(k, gR, gT, gd, gc);
+      float* gl = A.g_light_pos + 3 * b;
+      gl[0] += gd.x; gl[1] += gd.y; gl[2] += gd.z;
+    }
+    return;
+  }
   float* s_p = s_mem;
   float* s_gN = s_mem + (size_t)V * 3;
   float* s_g = s_mem + (size_t)V * 6;

@@ -30,13 +30,17 @@ __global__ void __launch_bounds__(kChainThreads) hand_back_kernel(const harp_han
   const harp_frame_tables& T = H.tables;
   const int b = blockIdx.x, tid = threadIdx.x, B = A.B;
   const LbsWs Wl = lbs_ws(H.lbs_ws, B);
-  // the reduction buffers of the next launch (g_A | g_pm adjacent in the workspace, g_betas) are cleared by all workgroups together
-  for (int k = b * kChainThreads + tid; k < B * (192 + 135); k += gridDim.x * kChainThreads) Wl.g_A[k] = 0.f;
-  for (int k = b * kChainThreads + tid; k < B * NB; k += gridDim.x * kChainThreads) g_betas[k] = 0.f;
+  const bool lean = A.light_only != 0;         // appearance-only stage: light-view part, light / ambient scatter and the step epilogue only
+  if (!lean) {
+    // the reduction buffers of the next launch (g_A | g_pm adjacent in the workspace, g_betas) are cleared by all workgroups together
+    for (int k = b * kChainThreads + tid; k < B * (192 + 135); k += gridDim.x * kChainThreads) Wl.g_A[k] = 0.f;
+    for (int k = b * kChainThreads + tid; k < B * NB; k += gridDim.x * kChainThreads) g_betas[k] = 0.f;
+  }
 
   cb::mesh_chain_bwd_body(A, s_mem, b);        // ... -> g_v0 (this frame's 778 x 3), g_cam_T, g_light_pos, g_disp
   __threadfence_block();
   __syncthreads();
+  if (!lean) {
 
   // ---- joint gradients (lbs_joints_bwd): chain joints -> g_j16 [metres], finger tips -> their vertices; stage this frame's A
   if (tid < 63) {
@@ -87,13 +91,14 @@ __global__ void __launch_bounds__(kChainThreads) hand_back_kernel(const harp_han
     for (int c = 0; c < 3; ++c) gt3[c] = s_gj16[tid - 800][c];               // g_trans also collects the chain joints
   }
   cb::block_sum_n<3>(gt3, s_red, s_tot);
+  }
   // ---- scatter what is final by now into the gradient rows of the parameter tables (frame_setup_bwd_kernel's trans / cam / light part);
   //      duplicates of a frame in one batch are legal and the shared light is summed over the frames -> atomics
   const int f = H.fid[b];
   if (tid < 3) {
     const int k = tid;
-    if (T.g_trans) atomicAdd(T.g_trans + f * 3 + k, s_tot[k]);
-    if (T.g_cam) {
+    if (T.g_trans && !lean) atomicAdd(T.g_trans + f * 3 + k, s_tot[k]);
+    if (T.g_cam && !lean) {
       if (k == 0) {
         const float c0 = T.cam[f * 3];
         const float den = (float)A.S * c0 + 1e-9f;
@@ -158,6 +163,7 @@ int harp_hand_back_bwd(const harp_hand_front* h, const float* g_colors, float* g
   if (hipFuncSetAttribute((const void*)hand_back_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return HARP_ERR_ARG;
   hipLaunchKernelGGL(hand_back_kernel, dim3(a->B), dim3(kChainThreads), lds, stream, *h, g_colors, g_betas_scratch);
   HARP_CHECK_LAUNCH();
+  if (a->light_only) return HARP_OK;           // no hand-layer backward: nothing of it reaches the appearance optimiser's parameters
   return harp_detail_lbs_back_tail(h->mano, h->pose48, a->B, h->lbs_ws, g_betas_scratch, h->tables, h->fid, stream);
 }
 

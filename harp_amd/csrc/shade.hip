@@ -729,7 +729,10 @@ int harp_shade_fwd(const harp_shade_args* a, hipStream_t stream) {
 }
 
 int harp_shade_bwd(const harp_shade_args* a, hipStream_t stream) {
-  if (!a || !a->face_id || !a->recs || !a->g_verts || !a->g_vnormals || !a->g_ndc) return HARP_ERR_ARG;
+  if (!a || !a->face_id || !a->recs) return HARP_ERR_ARG;
+  // all three geometry gradients, or none of them (appearance-only stage: production kernel only)
+  const bool geom = a->g_verts && a->g_vnormals && a->g_ndc;
+  if (!geom && (a->g_verts || a->g_vnormals || a->g_ndc || (a->debug_skip & 0xff))) return HARP_ERR_ARG;
   harp_shade_args b = *a;
   if (!b.g_rgb) {
     // fused-loss mode (no harp_shade_fwd call at all): the photometric L1 and its gradient are formed here; the background part of

@@ -104,6 +104,9 @@ __device__ __forceinline__ void shade_bwd_tile(ShadeSmem& sm, unsigned vblock, c
   // recomputes anyway (no forward launch at all in a fitting step)
   const bool fused = A.g_rgb == nullptr;
   const int dbg = A.debug_skip >> 8;          // ablation switches (timing only, results WRONG): see harp_hip.h
+  // g_verts == NULL (with g_vnormals, g_ndc): the caller wants no geometry gradients — the appearance-only stage of a fit, whose optimiser
+  // holds texture, normal map, light and ambient ratio only: no second set of face loads, no barycentric backward, no vertex table
+  const bool geom = A.g_verts != nullptr;
   // target rows of all frames of the batch, requested before anything else: the row of this tile's frame is then a lane read instead
   // of one more dependent trip behind the launch-order entry
   const int tf_all = (fused && lane < A.B) ? A.l1_fid[lane] : 0;
@@ -393,7 +396,7 @@ __device__ __forceinline__ void shade_bwd_tile(ShadeSmem& sm, unsigned vblock, c
     // 3 waves per SIMD is its register peak in that middle section, and its time goes with 1 / waves.  The base
     // pointers pass through an empty asm so that the compiler cannot merge the second set of loads with the first.
     float gnd[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    {
+    if (geom) {
       const float* vb2 = vb; const float* nb2 = nb; const float* uvb2 = A.verts_uvs; const FaceRec* rec2 = ((const FaceRec*)A.recs) + (size_t)b * A.F;
       asm volatile("" : "+s"(vb2), "+s"(nb2), "+s"(uvb2), "+s"(rec2));
       const V3 w0 = ld(at32(vb2, j0)), w1 = ld(at32(vb2, j1)), w2 = ld(at32(vb2, j2));
@@ -406,14 +409,14 @@ __device__ __forceinline__ void shade_bwd_tile(ShadeSmem& sm, unsigned vblock, c
       const float gb2 = dot(w2, g_p) + dot(m2, g_n) + q2x * gu + q2y * gv;
       const Bary br2 = bary_fwd(t2, px, py);            // (same values as in the forward half)
       bary_bwd(t2, px, py, br2, gb0, gb1, gb2, gnd);
-    }
-    const float bw[3] = {b0, b1, b2};
-    vidx[0] = g.i0; vidx[1] = g.i1; vidx[2] = g.i2;
+      const float bw[3] = {b0, b1, b2};
+      vidx[0] = g.i0; vidx[1] = g.i1; vidx[2] = g.i2;
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      vsc[9 * k + 0] = g_p.x * bw[k]; vsc[9 * k + 1] = g_p.y * bw[k]; vsc[9 * k + 2] = g_p.z * bw[k];
-      vsc[9 * k + 3] = g_n.x * bw[k]; vsc[9 * k + 4] = g_n.y * bw[k]; vsc[9 * k + 5] = g_n.z * bw[k];
-      vsc[9 * k + 6] = gnd[3 * k]; vsc[9 * k + 7] = gnd[3 * k + 1]; vsc[9 * k + 8] = gnd[3 * k + 2];
+      for (int k = 0; k < 3; ++k) {
+        vsc[9 * k + 0] = g_p.x * bw[k]; vsc[9 * k + 1] = g_p.y * bw[k]; vsc[9 * k + 2] = g_p.z * bw[k];
+        vsc[9 * k + 3] = g_n.x * bw[k]; vsc[9 * k + 4] = g_n.y * bw[k]; vsc[9 * k + 5] = g_n.z * bw[k];
+        vsc[9 * k + 6] = gnd[3 * k]; vsc[9 * k + 7] = gnd[3 * k + 1]; vsc[9 * k + 8] = gnd[3 * k + 2];
+      }
     }
   }
   if (IMG && dead) {
@@ -444,7 +447,7 @@ __device__ __forceinline__ void shade_bwd_tile(ShadeSmem& sm, unsigned vblock, c
   float* gnb = A.g_vnormals + (size_t)b * V * 3;
   float* gdb = A.g_ndc + (size_t)b * V * 3;
   if (any_act) {
-    if (!(dbg & 4)) {
+    if (!(dbg & 4) && geom) {
     // ---- vertex gradients: lanes on the same face add to the same three vertices: merge them first (xor distances 1, 2, 4 = x
     //      neighbours in the compacted order), the survivors add into the wave's double table
     bool alive = act;
@@ -609,7 +612,7 @@ __device__ __forceinline__ void shade_bwd_tile(ShadeSmem& sm, unsigned vblock, c
     STAMP(9);
     // ---- flush the vertex table, lanes = (slot, component)
 #ifndef SHADE_FLUSH_SERIAL
-    if (!(dbg & 12)) {
+    if (!(dbg & 12) && geom) {
       constexpr int kQ = (kVSlots * 9 + 63) / 64;
       int vk[kQ]; float vv[kQ];
 #pragma unroll
@@ -627,7 +630,7 @@ __device__ __forceinline__ void shade_bwd_tile(ShadeSmem& sm, unsigned vblock, c
       }
     }
 #else
-    if (!(dbg & 12)) for (int i = lane; i < kVSlots * 9; i += 64) {
+    if (!(dbg & 12) && geom) for (int i = lane; i < kVSlots * 9; i += 64) {
       const int sl = i / 9, c = i - 9 * sl;
       const int v = L.vkey[sl];
       if (v < 0) continue;

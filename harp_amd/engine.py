@@ -186,6 +186,8 @@ class FitEngine:
         # the depth backward walks <= 2 tiles, it costs what it saves (0.704 vs 0.701 ms / step); at 1024^2 (8 tiles per workgroup) it wins
         # (1.777 vs 1.788 ms / step on the arm) — on from 1024 px.
         self.zl_tile_flags = self.S >= 1024
+        self.lean_app_stage = False      # appearance-only stage without the geometry gradients nothing reads (set by optimize_hand_sequence; off by default: g_buf then holds what autograd would)
+        self._lean_now = False
         self.fold_step = True            # scheduled steps: the batch row is fetched by hand_front itself, the loss vector / schedule row / draw counter are turned over by hand_back, the slab clear + Adam tick + offset draw are ONE launch (harp_step_frame, harp_step_prologue): 31 -> 23 kernels per step, no schedule kernel in front of the hand layer
         self.fused_terms = True          # normalise + pack, the four parameter-only regularisers, key-point + mesh terms, depth backward + normal-map chain rule: one launch each (were 2 + 4 + 2 + 2)
         self.frozen = ()                 # parameters kept out of the optimiser groups (known_appearance)
@@ -288,6 +290,7 @@ class FitEngine:
             setattr(c, k, p(t))
         c.B, c.V0, c.E0, c.NJ, c.S = B, tp.V0, tp.E0, self.n_joints, self.S
         c.focal, c.shadow, c.has_normal_grad = self.focal, int(shadow), int(has_normal_grad)
+        c.light_only = int(getattr(self, "_lean_now", False))
         return c
 
     def _hand_struct(self, fid, B, shadow, has_normal_grad, step=None):
@@ -356,6 +359,8 @@ class FitEngine:
                      ("g_light_pos", s["g_light_pos"]), ("g_colors", s["g_colors"]),
                      ("g_light_R", s["g_light_R"] if self.self_shadow else None), ("g_light_T", s["g_light_T"] if self.self_shadow else None)):
             setattr(a, k, _lib.ptr(t))
+        if getattr(self, "_lean_now", False):            # appearance-only stage: no geometry gradients out of the shader backward
+            a.g_verts = a.g_vnormals = a.g_ndc = None
         # light-view tiles that receive a shadow-tap gradient are flagged for the depth backward (which clears what it consumes)
         a.g_zl_tiles = _lib.ptr(s["zl_tiles"]) if (self.self_shadow and self.consume_gzl and self.zl_tile_flags) else None
         return a
@@ -377,6 +382,11 @@ class FitEngine:
         # loss_acc and advances the schedule row and the draw counter
         fold = bool(sched)
         frame = None
+        # `lean_app_stage`: in the appearance-only stage the optimiser holds texture, normal map, light position and ambient ratio
+        # (optimize_sequence.py:264-310) — the reference's autograd still differentiates through the whole mesh chain and hand layer and
+        # throws those gradients away.  Lean: the shader backward forms no vertex gradients, the chain backward only its light-view part
+        # (-> light position), no hand-layer backward.  Same parameters after the step; g_buf's geometry segments stay zero.
+        self._lean_now = bool(self.lean_app_stage and app and not coarse and shared_terms and self.fused_chain and self.perceptual is None)
         if fold:
             if B != lane["B"] or not shared_terms or not self._can_fold():
                 raise RuntimeError("forward_backward(sched=True) needs the full batch, the shared terms and _can_fold()")
@@ -673,8 +683,9 @@ class FitEngine:
             self._ck(L.harp_subdivide_bwd(p(s["g_vd"]), p(tp.sub_off), p(tp.sub_idx), B, tp.V0, V, 1e-3, p(s["g_v0"]), ST()), "subdivide_bwd")
             self._ck(L.harp_scale(p(s["g_joints_m"]), 1e-3, B * self.n_joints * 3, p(s["g_joints_mm"]), ST()), "scale_bwd")
         lbs_bwd = L.harp_lbs_tree_bwd if self.use_arm else L.harp_lbs_mano_bwd
-        self._ck(lbs_bwd(ctypes.byref(self.dm.struct), p(s["pose48"]), p(s["betas"]), p(s["trans_b"]), B, p(s["lbs_ws"]),
-                         p(s["g_v0"]), p(s["g_joints_mm"]), p(s["g_pose48"]), p(s["g_betas"]), p(s["g_trans_b"]), ST()), "lbs_bwd")
+        if not self._lean_now:                          # (lean: g_pose48 / g_betas / g_trans_b stay the zeros of the slab clear)
+            self._ck(lbs_bwd(ctypes.byref(self.dm.struct), p(s["pose48"]), p(s["betas"]), p(s["trans_b"]), B, p(s["lbs_ws"]),
+                             p(s["g_v0"]), p(s["g_joints_mm"]), p(s["g_pose48"]), p(s["g_betas"]), p(s["g_trans_b"]), ST()), "lbs_bwd")
         self._ck(L.harp_frame_setup_bwd(ctypes.byref(self.tables), p(lfid), B, S, self.focal, int(self.self_shadow), p(s["g_pose48"]),
                                         p(s["g_betas"]), p(s["g_trans_b"]), p(s["g_cam_T"]), p(s["g_light_pos"]) if app else None,
                                         p(s["g_colors"]) if app else None, ST()), "frame_setup_bwd")
@@ -970,7 +981,7 @@ class FitEngine:
         # every switch the enqueued launch sequence depends on is part of the key: flipping one re-captures instead of replaying a
         # graph recorded for another configuration
         gkey = (coarse, app, scheduled, self.keep_image, self.fused_loss, self.self_shadow, tuple(self.frozen), self.overlap, self.early_terms,
-                self.packed_texels, self.fused_keep, self.mesh_third, self.graph_order, fold, self.fused_terms, self.zl_tile_flags, self.accumulate_loss, self.auto_draw, self.mesh_terms_first, self.camera_first, self.tail_side, self.fused_bwd, self.fused_chain, self.fused_front, self.fused_back, self.consume_gzl, self.keep_depth, dist_on, self.overlap_allreduce,
+                self.packed_texels, self.fused_keep, self.mesh_third, self.graph_order, fold, self.fused_terms, self.zl_tile_flags, self.accumulate_loss, self.lean_app_stage, self.auto_draw, self.mesh_terms_first, self.camera_first, self.tail_side, self.fused_bwd, self.fused_chain, self.fused_front, self.fused_back, self.consume_gzl, self.keep_depth, dist_on, self.overlap_allreduce,
                 self.comm is not None, self.perceptual is not None and app)
         g = self._graphs.get(gkey)
         if g is None:

@@ -143,6 +143,7 @@ def optimize_hand_sequence(configs, input_params, images_dataset, val_params, va
         eng.set_perceptual(vgg, weight=1.0)
     eng.keep_image = False                                           # the fused L1 consumes y_pred in the shader; nothing reads the image back
     eng.accumulate_loss = True
+    eng.lean_app_stage = True                                        # the appearance-only stage steps opt_app alone (:264-310, :567-573): no geometry gradients are formed for it
     if configs["start_from"]:
         restore_checkpoint(eng, configs, input_params)
     if configs["known_appearance"]:

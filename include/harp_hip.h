@@ -123,7 +123,8 @@ typedef struct harp_shade_args {
   float* g_nmap;            /* (Ht,Wt,3) (+=) or NULL */
   float* g_verts;           /* (B,V,3) (+=) */
   float* g_vnormals;        /* (B,V,3) (+=) */
-  float* g_ndc;             /* (B,V,3) (+=) camera-view NDC vertices */
+  float* g_ndc;             /* (B,V,3) (+=) camera-view NDC vertices.  harp_shade_bwd: all three NULL = no geometry gradients (the
+                             * appearance-only stage, optimize_sequence.py:264-310: opt_app holds texture, normal map, light, ambient ratio) */
   float* g_zl;              /* (B,S,S) (+=) or NULL; see g_zl_tiles at the end of the struct */
   float* g_light_pos;       /* (B,3) (+=) or NULL */
   float* g_colors;          /* 9 (+=) or NULL */
@@ -264,6 +265,10 @@ typedef struct harp_mesh_chain {
   float focal;
   int shadow;               /* light-view outputs / gradients wanted */
   int has_normal_grad;      /* backward: g_n2 is given (appearance stage) */
+  int light_only;           /* backward: ONLY the light-view part — projection backward of g_ndc_l, light camera backward -> g_light_pos (+=);
+                             * everything else (camera view, both normal passes, displacement, subdivision, g_v0 / g_joints_mm / g_cam_T /
+                             * g_disp) is left out and not written.  The appearance-only stage of a fit: its optimiser holds no geometry
+                             * (optimize_sequence.py:264-310), the light position is the one parameter of it this chain feeds. */
   /* forward in */
   const float* verts_mm;    /* (B,V0,3) hand-layer vertices, millimetres */
   const float* joints_mm;   /* (B,NJ,3) */

@@ -1204,6 +1204,43 @@ def test_folded_step_bookkeeping_equals_the_separate_kernels():
     assert a.losses().keys() == b.losses().keys()
 
 
+@pytest.mark.parametrize("kind", ["hand", "arm"])
+def test_lean_appearance_stage_equals_full_on_the_optimised_parameters(kind):
+    """`lean_app_stage`: the appearance-only stage (optimize_sequence.py:264-310: opt_app = light position, ambient ratio, texture, normal
+    map) without the geometry gradients the reference's autograd forms and nobody reads — no vertex gradients out of the shader backward,
+    only the light-view part of the chain backward, no hand-layer backward.  Against the full backward of the same stage: the same losses,
+    the same gradients of the four optimised groups, the same parameters after Adam steps (eager and graph-replayed); the geometry segments
+    of the gradient arena stay zero."""
+    from tests._scene import make_fit_case
+    cases = [make_fit_case(kind, T=3, S=128, B=3, seed=13, device=DEV) for _ in range(2)]
+    full, lean = (c["eng"] for c in cases)
+    for e in (full, lean):
+        e.keep_image = False
+        e.auto_draw = False
+        e.draw_texture_offsets()
+        e.set_schedule(torch.tensor([[0, 1, 2], [2, 0, 1]]).int())
+    lean.lean_app_stage = True
+    for graph in (False, True):
+        for _ in range(3):
+            for e in (full, lean):
+                e.step(None, False, True, use_graph=graph)
+            torch.cuda.synchronize()
+            lf, ll = full.loss_vec[:9].double(), lean.loss_vec[:9].double()
+            assert ((lf - ll).abs() <= 1e-5 * lf.abs() + 1e-9).all(), (lf, ll)
+            for k in ("light_positions", "amb_ratio", "texture", "normal_map"):
+                a, b = lean.arena.view(lean.g_buf, k).double(), full.arena.view(full.g_buf, k).double()
+                assert b.abs().max().item() > 0 and rel(a, b) < 1e-4, (k, rel(a, b))
+            for k in ("pose", "cam", "verts_disps", "shape", "rot"):
+                assert lean.arena.view(lean.g_buf, k).abs().max().item() == 0.0, k
+                assert full.arena.view(full.g_buf, k).abs().max().item() > 0.0, k          # (what the lean step leaves out)
+            o, n = full.app_span
+            d = (lean.p_buf[o:o + n] - full.p_buf[o:o + n]).abs()
+            assert d.mean().item() < 1e-6 and (d > 1e-3).float().mean().item() < 1e-4, (d.mean().item(), d.max().item())
+            assert torch.equal(lean.p_buf[:o], full.p_buf[:o])                              # geometry parameters: untouched by both
+            for k in ("p_buf", "m_buf", "v_buf"):                                           # teacher forcing (Adam amplifies atomics-order noise)
+                getattr(lean, k).copy_(getattr(full, k))
+
+
 def test_light_view_tile_flags_cover_the_shadow_map_gradient():
     """harp_shade_args.g_zl_tiles: when the shader backward is done, every 16x16 light-view tile that holds a non-zero entry of the
     shadow-map gradient image is flagged (the depth backward reads flagged tiles only); when the depth backward is done, image and flags

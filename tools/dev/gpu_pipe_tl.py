@@ -7,5 +7,6 @@ eng.keep_image = False
 for kv in filter(None, os.environ.get("HARP_ENG", "").split(",")):
     k, v = kv.split("="); setattr(eng, k, type(getattr(eng, k))(int(v)))
 eng.set_schedule(torch.arange(256).reshape(-1, 32).int())
-for _ in range(30): eng.step(None, True, True)
+c, a = (os.environ.get("HARP_TL_STAGE", "11")[0] == "1"), (os.environ.get("HARP_TL_STAGE", "11")[1] == "1")      # HARP_TL_STAGE=10: geometry only, 01: appearance only
+for _ in range(30): eng.step(None, c, a)
 torch.cuda.synchronize()
