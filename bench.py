@@ -257,16 +257,16 @@ def profiled_traffic():
             shutil.rmtree(d, ignore_errors=True)
 
 
-def _graph_rate(e, steps, warmup):
+def _graph_rate(e, steps, warmup, coarse=True, app=True):
     """frames/s of graph-replayed scheduled steps of engine `e` (single GPU, outside the timed region of the headline)"""
     B, T = e.B, e.T
     e.set_schedule(torch.stack([(torch.arange(B) + i * B) % T for i in range(warmup + steps)]).to(torch.int32))
     for _ in range(warmup):
-        e.step(None, True, True)
+        e.step(None, coarse, app)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
-        e.step(None, True, True)
+        e.step(None, coarse, app)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     return {"frames_per_s": B * steps / dt, "ms_per_step": dt / steps * 1e3, "frames_per_step": B, "steps": steps}
@@ -281,6 +281,16 @@ def extra_rates(eng, device, steps=100, warmup=30, vgg_weights="random"):
     engine, tools/dev/gpu_c5_rate.py in round 4.)"""
     rate = lambda e: _graph_rate(e, steps, warmup)
     out = {}
+    # the other two stages of the reference's schedule (configs["training_stage"], optimize_sequence.py:426-441) on the headline's engine and
+    # scene: geometry only (silhouette, key points, mesh regularisers -> opt_coarse) and appearance only (photometric + texture regularisers
+    # -> opt_app) — the latter also as the fitting API runs it (`lean_app_stage`: without the geometry gradients nothing reads)
+    keep = (eng.keep_image, eng.lean_app_stage)
+    eng.keep_image = False
+    out["C3_stage_geometry_only"] = _graph_rate(eng, steps, warmup, True, False)
+    out["C3_stage_appearance_only"] = _graph_rate(eng, steps, warmup, False, True)
+    eng.lean_app_stage = True
+    out["C3_stage_appearance_only_lean"] = _graph_rate(eng, steps, warmup, False, True)
+    eng.keep_image, eng.lean_app_stage = keep
     e = build_engine(0, 1, device, T=72, img=S, B=18)[0]
     e.keep_image = False
     out["C2_reference_batch_18"] = rate(e)

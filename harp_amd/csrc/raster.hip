@@ -223,7 +223,8 @@ static int rasterize_impl(const float* ndc, const int32_t* faces, int B, int V, 
                           float sigma, void* ws, int32_t* face_id, float* zbuf, float* alpha, const float* l1_target,
                           const int32_t* l1_fid, const float* l1_w, float* l1_loss, float* l1_grad, const float* l1_bg_sums,
                           int32_t* st_state, hipStream_t stream) {
-  if (!ndc || !faces || !ws || !face_id || B <= 0 || F <= 0 || S <= 0 || ((soft & 1) && !alpha)) return HARP_ERR_ARG;
+  // face_id == NULL: silhouette only (camera view of a geometry-only step: nothing reads the nearest face) — soft pass, no depth map
+  if (!ndc || !faces || !ws || (!face_id && (!(soft & 1) || zbuf)) || B <= 0 || F <= 0 || S <= 0 || ((soft & 1) && !alpha)) return HARP_ERR_ARG;
   if (l1_target && (!(soft & 1) || !l1_fid || !l1_w || !l1_loss || !l1_grad)) return HARP_ERR_ARG;
   const RasterWs W = raster_ws_split(ws, B, F, S);
   FaceRec* recs = W.recs; int32_t *bins = W.bins, *cnt = W.cnt, *order = W.order; float4* bbs = W.bbs;

@@ -157,7 +157,7 @@ __device__ __forceinline__ void raster_tile(RasterSmem<MODE>& sm, unsigned vbloc
         if (l1) acc += fabsf(tg[k]);                       // |alpha - y| with alpha = 0
         if (zbuf) zbuf[o] = -1.0f;                          // depth maps stay complete: shadow taps may land one pixel outside a face's super-tile
         if (!sparse) {
-          face_id[o] = -1;
+          if (face_id) face_id[o] = -1;
           if (MODE == 1) {
             alpha[o] = 0.f;
             if (l1) l1_grad[o] = l1_w[0] * l1_inv * (float)((0.f > tg[k]) - (0.f < tg[k]));
@@ -431,11 +431,13 @@ __device__ __forceinline__ void raster_tile(RasterSmem<MODE>& sm, unsigned vbloc
               const float e2 = edge_fn(qx, qy, t.x0, t.y0, t.x1, t.y1);
               if (inbox && (e0 * sg > 0.f) && (e1 * sg > 0.f) && (e2 * sg > 0.f)) {
                 // BarycentricCoordsForward + PerspectiveCorrection with reciprocals (<= 2 ulp from the IEEE-division form)
-                const float t0 = (e0 * ra) * t.z1 * t.z2, t1 = t.z0 * (e1 * ra) * t.z2, t2 = t.z0 * t.z1 * (e2 * ra);
-                const float rd = __builtin_amdgcn_rcpf(fmaxf(t0 + t1 + t2, kEps));
-                const float pz = (t0 * rd) * t.z0 + (t1 * rd) * t.z1 + (t2 * rd) * t.z2;
                 const int pix = (ys - ty0) * kTile + (xs - tx0);
-                if (pz >= 0.f && pz < 3.0e38f) atomicMin(&sm.zkey[pix], ((unsigned long long)__float_as_uint(pz) << 32) | (unsigned)fid);
+                if (MODE != 1 || face_id) {        // (camera view without face ids — the geometry-only stage: the silhouette needs no nearest face)
+                  const float t0 = (e0 * ra) * t.z1 * t.z2, t1 = t.z0 * (e1 * ra) * t.z2, t2 = t.z0 * t.z1 * (e2 * ra);
+                  const float rd = __builtin_amdgcn_rcpf(fmaxf(t0 + t1 + t2, kEps));
+                  const float pz = (t0 * rd) * t.z0 + (t1 * rd) * t.z1 + (t2 * rd) * t.z2;
+                  if (pz >= 0.f && pz < 3.0e38f) atomicMin(&sm.zkey[pix], ((unsigned long long)__float_as_uint(pz) << 32) | (unsigned)fid);
+                }
                 if (MODE == 1) {
                   // deeper than sqrt(18 sigma) inside every edge LINE (<= segment distance): sigmoid saturates to exactly 1 in
                   // fp32 (exp(-18) < 2^-24), so the factor (1-p) is exactly 0 — the pixel's alpha is 1 whatever the other faces do
@@ -737,7 +739,7 @@ __device__ __forceinline__ void raster_tile(RasterSmem<MODE>& sm, unsigned vbloc
   float l1_acc = 0.f;
   if (MODE != 2 && in_img) {
     const size_t o = ((size_t)b * S + yi) * S + xi;
-    face_id[o] = best_f;
+    if (face_id) face_id[o] = best_f;
     if (zbuf) zbuf[o] = (best_f >= 0) ? best_z : -1.0f;
     if (MODE == 1) {
       const float a = 1.0f - prod;

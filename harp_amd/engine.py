@@ -188,6 +188,7 @@ class FitEngine:
         self.zl_tile_flags = self.S >= 1024
         self.lean_app_stage = False      # appearance-only stage without the geometry gradients nothing reads (set by optimize_hand_sequence; off by default: g_buf then holds what autograd would)
         self._lean_now = False
+        self.sil_only_raster = True      # geometry-only steps without a kept image: the camera raster forms no nearest-face ids (harp_rasterize_l1_fwd with face_id == NULL)
         self.fold_step = True            # scheduled steps: the batch row is fetched by hand_front itself, the loss vector / schedule row / draw counter are turned over by hand_back, the slab clear + Adam tick + offset draw are ONE launch (harp_step_frame, harp_step_prologue): 31 -> 23 kernels per step, no schedule kernel in front of the hand layer
         self.fused_terms = True          # normalise + pack, the four parameter-only regularisers, key-point + mesh terms, depth backward + normal-map chain rule: one launch each (were 2 + 4 + 2 + 2)
         self.frozen = ()                 # parameters kept out of the optimiser groups (known_appearance)
@@ -561,7 +562,9 @@ class FitEngine:
             # without keep_image nothing reads face ids / alpha / g_alpha in super-tiles that hold no face (shaders and the silhouette
             # backward skip them): soft = 3 leaves those 3/4 of the three images unwritten
             sparse = 0 if (self.keep_image or self.perceptual is not None) else 2
-            self._ck(L.harp_rasterize_l1_fwd(p(s["ndc_c"]), p(tp.faces), B, V, F, S, 1 | sparse, ops.SIL_BLUR, ops.SIL_SIGMA, p(s["ws_c"]), p(s["face_c"]),
+            # (geometry-only stage in the loss-only image mode: nothing reads the camera view's face ids — silhouette only)
+            face_c = p(s["face_c"]) if (app or self.keep_image or not self.sil_only_raster) else None
+            self._ck(L.harp_rasterize_l1_fwd(p(s["ndc_c"]), p(tp.faces), B, V, F, S, 1 | sparse, ops.SIL_BLUR, ops.SIL_SIGMA, p(s["ws_c"]), face_c,
                                              None, p(s["alpha"]), p(self.y_sil) if coarse else None, p(ltfid), wp(0), lp(0), p(s["g_alpha"]),
                                              p(self.bg_sil) if sparse else None, ST()),
                      "raster_cam")
@@ -589,11 +592,17 @@ class FitEngine:
                 self._ck(L.harp_silhouette_bwd(p(tp.faces), B, V, F, S, ops.SIL_BLUR, ops.SIL_SIGMA, p(s["ws_c"]), p(s["alpha"]), p(s["g_alpha"]),
                                                p(s["g_ndc_c"]), ST()), "silhouette_bwd")
         if coarse and not fuse_bwd:
-            side_used = True
-            if go and app:
-                sil_after = cur.record_event()           # captured right behind the shader backward (which then stays on the camera raster's stream)
+            if not app and self.overlap:
+                # geometry-only stage: there is no shader backward to run next to — the silhouette backward stays on the critical stream
+                # (two cross-stream edges, ~6 us each, off the step)
+                self._ck(L.harp_silhouette_bwd(p(tp.faces), B, V, F, S, ops.SIL_BLUR, ops.SIL_SIGMA, p(s["ws_c"]), p(s["alpha"]), p(s["g_alpha"]),
+                                               p(s["g_ndc_c"]), ST()), "silhouette_bwd")
             else:
-                launch_sil()
+                side_used = True
+                if go and app:
+                    sil_after = cur.record_event()       # captured right behind the shader backward (which then stays on the camera raster's stream)
+                else:
+                    launch_sil()
         if not sched_early:
             param_terms()
             mesh_terms()
@@ -981,7 +990,7 @@ class FitEngine:
         # every switch the enqueued launch sequence depends on is part of the key: flipping one re-captures instead of replaying a
         # graph recorded for another configuration
         gkey = (coarse, app, scheduled, self.keep_image, self.fused_loss, self.self_shadow, tuple(self.frozen), self.overlap, self.early_terms,
-                self.packed_texels, self.fused_keep, self.mesh_third, self.graph_order, fold, self.fused_terms, self.zl_tile_flags, self.accumulate_loss, self.lean_app_stage, self.auto_draw, self.mesh_terms_first, self.camera_first, self.tail_side, self.fused_bwd, self.fused_chain, self.fused_front, self.fused_back, self.consume_gzl, self.keep_depth, dist_on, self.overlap_allreduce,
+                self.packed_texels, self.fused_keep, self.mesh_third, self.graph_order, fold, self.fused_terms, self.zl_tile_flags, self.accumulate_loss, self.lean_app_stage, self.sil_only_raster, self.auto_draw, self.mesh_terms_first, self.camera_first, self.tail_side, self.fused_bwd, self.fused_chain, self.fused_front, self.fused_back, self.consume_gzl, self.keep_depth, dist_on, self.overlap_allreduce,
                 self.comm is not None, self.perceptual is not None and app)
         g = self._graphs.get(gkey)
         if g is None:

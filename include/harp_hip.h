@@ -48,6 +48,8 @@ int harp_rasterize_fwd_keep(const float* ndc, const int32_t* faces, int B, int V
 /* l1_bg_sums (optional, used with sparse outputs): (T, nsx*nsx) per target frame and 64x64 super-tile, the term's sum over the
  * super-tile when nothing is rendered there (sum of y_sil) — targets are static during a fit, so the background part of the loss is
  * a table look-up instead of a pass over 3/4 of the target image every step. */
+/* face_id == NULL (with the soft silhouette on and zbuf == NULL): silhouette only — the nearest face per pixel is neither formed nor
+ * written (the geometry-only stage of a fit reads alpha alone). */
 int harp_rasterize_l1_fwd(const float* ndc, const int32_t* faces, int B, int V, int F, int S, int soft, float blur_radius,
                           float sigma, void* ws, int32_t* face_id, float* zbuf, float* alpha, const float* l1_target,
                           const int32_t* l1_fid, const float* l1_w, float* l1_loss, float* l1_grad, const float* l1_bg_sums,

@@ -1241,6 +1241,35 @@ def test_lean_appearance_stage_equals_full_on_the_optimised_parameters(kind):
                 getattr(lean, k).copy_(getattr(full, k))
 
 
+def test_geometry_only_stage_without_face_ids_and_with_the_silhouette_backward_in_stream():
+    """Geometry-only steps (coarse stage, loss-only image mode): the camera raster forms no nearest-face ids (harp_rasterize_l1_fwd with
+    face_id == NULL) and the silhouette backward stays on the critical stream — against the same step with face ids: bit-identical alpha,
+    the same losses and gradient arena, eagerly and graph-replayed."""
+    from tests._scene import make_fit_case
+    case = make_fit_case("hand", T=3, S=128, B=3, seed=17, device=DEV)
+    eng = case["eng"]
+    eng.keep_image = False
+    eng.set_lr(0.0, 0.0)
+    eng.set_schedule(torch.arange(3).reshape(1, 3).int())
+    out = {}
+    for sil_only in (False, True):
+        eng.sil_only_raster = sil_only
+        eng.s["face_c"].fill_(-7)
+        for graph in (False, True):
+            for _ in range(2):
+                eng.step(None, True, False, use_graph=graph)
+            torch.cuda.synchronize()
+            out[(sil_only, graph)] = (eng.s["alpha"].clone(), eng.g_buf.double().clone(), eng.loss_vec[:9].double().clone())
+        # sparse outputs: only super-tiles that hold a face are written — with face ids the covered pixels carry ids, without none is touched
+        assert (eng.s["face_c"] != -7).any().item() == (not sil_only)
+    for graph in (False, True):
+        a0, g0, l0 = out[(False, graph)]
+        a1, g1, l1 = out[(True, graph)]
+        assert torch.equal(a0, a1)
+        assert ((l0 - l1).abs() <= 1e-6 * l0.abs() + 1e-12).all() and l0[0] > 0
+        assert rel(g1, g0) < 1e-5, rel(g1, g0)
+
+
 def test_light_view_tile_flags_cover_the_shadow_map_gradient():
     """harp_shade_args.g_zl_tiles: when the shader backward is done, every 16x16 light-view tile that holds a non-zero entry of the
     shadow-map gradient image is flagged (the depth backward reads flagged tiles only); when the depth backward is done, image and flags
