@@ -528,7 +528,7 @@ __device__ __forceinline__ void shade_bwd_tile(ShadeSmem& sm, unsigned vblock, c
 
     STAMP(8);
     // ---- texture + normal-map gradients: 4 bilinear corners x 6 channels into the direct-mapped fixed-point table
-    if (!(dbg & 1)) {
+    if (!(dbg & 1) && (A.g_tex != nullptr || (A.nmap != nullptr && A.g_nmap != nullptr))) {      // (both maps frozen — known_appearance fits: no texel phase)
       const bool do_t = A.g_tex != nullptr, do_n = (A.nmap != nullptr) && (A.g_nmap != nullptr);
       const float ma = wave_max_u(fmaxf(fabsf(g_tex.x), fmaxf(fabsf(g_tex.y), fabsf(g_tex.z))));
       const float mm = wave_max_u(fmaxf(fabsf(g_m_keep.x), fmaxf(fabsf(g_m_keep.y), fabsf(g_m_keep.z))));

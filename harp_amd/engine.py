@@ -362,6 +362,11 @@ class FitEngine:
             setattr(a, k, _lib.ptr(t))
         if getattr(self, "_lean_now", False):            # appearance-only stage: no geometry gradients out of the shader backward
             a.g_verts = a.g_vnormals = a.g_ndc = None
+        # maps kept out of the optimiser (known_appearance, optimize_sequence.py:264-289): their gradients are not formed at all
+        if "texture" in self.frozen:
+            a.g_tex = None
+        if "normal_map" in self.frozen:
+            a.g_nmap = None
         # light-view tiles that receive a shadow-tap gradient are flagged for the depth backward (which clears what it consumes)
         a.g_zl_tiles = _lib.ptr(s["zl_tiles"]) if (self.self_shadow and self.consume_gzl and self.zl_tile_flags) else None
         return a
@@ -472,8 +477,10 @@ class FitEngine:
                     self._ck(L.harp_normalize3_pack(p(self.params["texture"]), p(self.params["normal_map"]), nt, p(s["nmap_n"]),
                                                     p(self.texnm) if self.packed_texels else None, ST()), "normalize3_pack")
                     self._ck(L.harp_texture_terms(p(self.params["texture"]), p(self.params["normal_map"]), p(self.uv_mask), p(self.dist_albedo),
-                                                  p(self.dist_normal), self.Ht, self.Wt, 0.2, wp(7), lp(7), p(self.grads["texture"]), wp(8), lp(8),
-                                                  p(self.grads["normal_map"]), p(self.params["verts_disps"]) if disp_reg else None, V, wp(2), lp(2),
+                                                  p(self.dist_normal), self.Ht, self.Wt, 0.2, wp(7), lp(7),
+                                                  None if "texture" in self.frozen else p(self.grads["texture"]), wp(8), lp(8),      # (frozen maps: loss values only)
+                                                  None if "normal_map" in self.frozen else p(self.grads["normal_map"]),
+                                                  p(self.params["verts_disps"]) if disp_reg else None, V, wp(2), lp(2),
                                                   p(self.grads["verts_disps"]), p(self.draw_counter) if (draw and pro and not fold) else None, ST()),
                              "texture_terms")
                     disp_reg = False
@@ -635,12 +642,14 @@ class FitEngine:
                 # the normal-map chain rule (and, for N > 1, the early all-reduce of the map gradients, which overlaps with the mesh /
                 # hand-layer backward) only feeds the optimiser: with `tail_side` it leaves the critical path for the second stream, which
                 # is idle once the silhouette backward is done (the join in front of the mesh-chain backward already exists)
+                nm_frozen = "normal_map" in self.frozen
                 def maps_tail():
-                    self._ck(L.harp_normalize3_bwd(p(self.params["normal_map"]), p(s["g_nmap_n"]), self.Ht * self.Wt, p(self.grads["normal_map"]), ST()),
-                             "normalize3_bwd")
+                    if not nm_frozen:
+                        self._ck(L.harp_normalize3_bwd(p(self.params["normal_map"]), p(s["g_nmap_n"]), self.Ht * self.Wt, p(self.grads["normal_map"]), ST()),
+                                 "normalize3_bwd")
                     self._allreduce_maps_early()
                 # the chain rule of the normal map rides in the depth backward's launch when both exist (harp_depth_nmap_bwd)
-                nmap_in_depth = self.fused_terms and self.self_shadow and self.consume_gzl and not (self.tail_side and self.overlap)
+                nmap_in_depth = self.fused_terms and self.self_shadow and self.consume_gzl and not (self.tail_side and self.overlap) and not nm_frozen
                 if nmap_in_depth:
                     self._ck(L.harp_depth_nmap_bwd(p(s["face_l"]), p(s["ws_l"]), p(tp.faces), p(s["g_zl"]), B, V, F, S, p(s["g_ndc_l"]),
                                                    p(self.params["normal_map"]), p(s["g_nmap_n"]), self.Ht * self.Wt, p(self.grads["normal_map"]),

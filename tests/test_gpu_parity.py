@@ -1270,6 +1270,34 @@ def test_geometry_only_stage_without_face_ids_and_with_the_silhouette_backward_i
         assert rel(g1, g0) < 1e-5, rel(g1, g0)
 
 
+def test_frozen_maps_form_no_gradients_and_change_nothing_else():
+    """known_appearance keeps texture and normal map out of the optimiser (optimize_sequence.py:264-289): the shader backward then runs
+    without its texel phase, the texture regularisers without their gradient scatter, the normal-map chain rule is left out — the losses
+    and every other gradient are what they are with the maps optimised."""
+    from tests._scene import make_fit_case
+    case = make_fit_case("hand", T=3, S=128, B=3, seed=19, device=DEV)
+    eng = case["eng"]
+    eng.keep_image = False
+    eng.auto_draw = False
+    eng.draw_texture_offsets()
+    eng.set_stage(True, True)
+    eng.fid.copy_(torch.arange(3, dtype=torch.int32)); eng.tfid.copy_(torch.arange(3, dtype=torch.int32))
+    out = {}
+    for frozen in ((), ("texture", "normal_map")):
+        eng.frozen = frozen
+        eng.forward_backward(True, True)
+        torch.cuda.synchronize()
+        out[frozen] = (eng.g_buf.double().clone(), eng.loss_vec[:9].double().clone())
+    eng.frozen = ()
+    (g0, l0), (g1, l1) = out[()], out[("texture", "normal_map")]
+    assert ((l0 - l1).abs() <= 1e-6 * l0.abs() + 1e-12).all(), (l0, l1)
+    for k in ("pose", "cam", "verts_disps", "shape", "light_positions", "amb_ratio"):
+        a, b = eng.arena.view(g1, k), eng.arena.view(g0, k)
+        assert b.abs().max().item() > 0 and rel(a, b) < 1e-5, (k, rel(a, b))
+    for k in ("texture", "normal_map"):
+        assert eng.arena.view(g1, k).abs().max().item() == 0.0 and eng.arena.view(g0, k).abs().max().item() > 0.0, k
+
+
 def test_light_view_tile_flags_cover_the_shadow_map_gradient():
     """harp_shade_args.g_zl_tiles: when the shader backward is done, every 16x16 light-view tile that holds a non-zero entry of the
     shadow-map gradient image is flagged (the depth backward reads flagged tiles only); when the depth backward is done, image and flags
