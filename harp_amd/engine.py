@@ -958,7 +958,7 @@ class FitEngine:
 
     def step(self, fid, coarse=True, app=True, use_graph=True, tfid=None):
         """One optimisation step on the frames `fid` (global frame ids = rows of the parameter tables, length <= batch_size; a shorter —
-        last, partial — batch runs eagerly, optimize_sequence.py:396-399).  fid=None: the next row of the schedule given to
+        last, partial — batch, optimize_sequence.py:396-399, replays a graph captured for its size).  fid=None: the next row of the schedule given to
         `set_schedule`.  tfid: rows of the resident targets these frames compare against (default fid - target_offset, i.e. targets
         stored in frame order); a dataset that holds a subset / another order of the frames passes its own item indices."""
         scheduled = fid is None
@@ -989,7 +989,8 @@ class FitEngine:
         fb = (lambda: (self._schedule_next(), fb0())) if (scheduled and not fold) else fb0
         dist_on = self._dist_on()
         graph_ok = (not dist_on) or self.comm is not None or self.graph_collectives
-        if not use_graph or n != self.B or not graph_ok or (app and self.perceptual is not None and not self.graph_perceptual):
+        # (a shorter — last, partial — batch of an epoch gets a graph of its own: the batch size is part of the key)
+        if not use_graph or not graph_ok or (app and self.perceptual is not None and not self.graph_perceptual):
             fb()
             self.allreduce()
             self.adam(coarse, app, tick=False)
@@ -998,7 +999,7 @@ class FitEngine:
             return
         # every switch the enqueued launch sequence depends on is part of the key: flipping one re-captures instead of replaying a
         # graph recorded for another configuration
-        gkey = (coarse, app, scheduled, self.keep_image, self.fused_loss, self.self_shadow, tuple(self.frozen), self.overlap, self.early_terms,
+        gkey = (coarse, app, scheduled, n, self.keep_image, self.fused_loss, self.self_shadow, tuple(self.frozen), self.overlap, self.early_terms,
                 self.packed_texels, self.fused_keep, self.mesh_third, self.graph_order, fold, self.fused_terms, self.zl_tile_flags, self.accumulate_loss, self.lean_app_stage, self.sil_only_raster, self.auto_draw, self.mesh_terms_first, self.camera_first, self.tail_side, self.fused_bwd, self.fused_chain, self.fused_front, self.fused_back, self.consume_gzl, self.keep_depth, dist_on, self.overlap_allreduce,
                 self.comm is not None, self.perceptual is not None and app)
         g = self._graphs.get(gkey)

@@ -178,7 +178,7 @@ def optimize_hand_sequence(configs, input_params, images_dataset, val_params, va
                 if item.numel() == eng.B and device_schedule:
                     eng.step(None, coarse, app)
                 else:
-                    eng.step(rt.fid[item], coarse, app, tfid=item)                     # the last, partial batch runs eagerly (:396-399)
+                    eng.step(rt.fid[item], coarse, app, tfid=item)                     # the last, partial batch (:396-399): explicit rows, a graph of its own size
             nb = len(items)
             # one sync per epoch; N > 1: the mean over ranks (image terms are means over a rank's frames, regularisers are identical),
             # the same float on every rank

@@ -571,6 +571,28 @@ def test_device_schedule_matches_explicit_batches(sc):
                   sc["focal"], 2, device=DEV).step(None)
 
 
+def test_partial_batch_replays_a_graph_of_its_own_size(sc):
+    """the last, shorter batch of an epoch (optimize_sequence.py:396-399) is captured like a full one (batch size in the graph key):
+    replayed steps == eager steps"""
+    from harp_amd.engine import FitEngine
+    tg = sc["targets"]
+
+    def run(graph):
+        eng = FitEngine(sc["model_np"], sc["topo_np"], sc["tpl"]["verts_uvs"], sc["tpl"]["faces_uvs"], sc["uv_mask"].float(), sc["seq"], sc["S"],
+                        sc["focal"], 3, device=DEV, seed=3)
+        eng.set_targets(tg["y_true"], tg["y_sil"], tg["y_sil_col"])
+        for fid in ([0, 1, 2], [2, 1], [1, 2, 0], [0, 2]):
+            eng.step(torch.tensor(fid), True, True, use_graph=graph)
+        torch.cuda.synchronize()
+        return eng
+    a, b = run(True), run(False)
+    assert len(a._graphs) == 2 and not b._graphs
+    for k in ("pose", "cam", "verts_disps", "shape", "light_positions"):
+        assert (a.params[k] - b.params[k]).abs().max().item() < 2e-3, k
+    la, lb = a.loss_vec[:9].double(), b.loss_vec[:9].double()
+    assert ((la - lb).abs() <= 1e-3 * lb.abs() + 1e-9).all(), (la, lb)
+
+
 @pytest.mark.parametrize("fold", [True, False])
 def test_device_schedule_with_target_rows_and_in_place_update(sc, fold):
     """set_schedule(rows, tschedule=...): the resident targets are stored in REVERSED frame order and the schedule carries their rows, in the
