@@ -245,6 +245,30 @@ __device__ __forceinline__ void shade_bwd_tile(ShadeSmem& sm, unsigned vblock, c
     g.v = uv0y * b0 + uv1y * b1 + uv2y * b2;
     g.bs = bil_setup(g.u, g.v, A.Wt, A.Ht);
     bs = g.bs;
+    // the 9 shadow-map taps only depend on the surface point: requested here, next to the texel fetch, instead of behind it (one
+    // dependent round trip less in the wave's chain: step -2 us, same-box A/B x3)
+    float zt[9];
+    const float half = 0.5f * (float)S;
+    if (A.zl) {
+      const float* R = A.light_R + 9 * b;
+      const float* T = A.light_T + 3 * b;
+      g.q = mk(g.p.x * R[0] + g.p.y * R[3] + g.p.z * R[6] + T[0], g.p.x * R[1] + g.p.y * R[4] + g.p.z * R[7] + T[1],
+               g.p.x * R[2] + g.p.y * R[5] + g.p.z * R[8] + T[2]);
+      const float rqz = rcp(g.q.z), rhalf = rcp(half);
+      const float xn = (A.focal * g.q.x * rqz - A.ppx + half) * rhalf, yn = (A.focal * g.q.y * rqz - A.ppy + half) * rhalf;
+      const float xs = half - half * xn, ys = half - half * yn;
+      g.ix = (int)rintf(fminf(fmaxf(xs, -1.0e6f), 1.0e6f));     // torch .round().long(): half-to-even
+      g.iy = (int)rintf(fminf(fmaxf(ys, -1.0e6f), 1.0e6f));
+      const float* zlb = A.zl + (size_t)b * S * S;
+      int k = 0;
+#pragma unroll
+      for (int ii = -1; ii <= 1; ++ii)
+#pragma unroll
+        for (int jj = -1; jj <= 1; ++jj, ++k) {
+          const int yy = min(max(g.iy + ii, 0), S - 1), xx = min(max(g.ix + jj, 0), S - 1);
+          zt[k] = *at32(zlb, (unsigned)(yy * S + xx));
+        }
+    }
 #ifdef SHADE_STAMPS
     asm volatile("s_waitcnt vmcnt(0)");
 #endif
@@ -282,29 +306,11 @@ __device__ __forceinline__ void shade_bwd_tile(ShadeSmem& sm, unsigned vblock, c
     // shadow (renderer_helper.py:379-408)
     g.vis = 1.f;
     float sg[9];
-    const float half = 0.5f * (float)S;
     if (A.zl) {
-      const float* R = A.light_R + 9 * b;
-      const float* T = A.light_T + 3 * b;
-      g.q = mk(g.p.x * R[0] + g.p.y * R[3] + g.p.z * R[6] + T[0], g.p.x * R[1] + g.p.y * R[4] + g.p.z * R[7] + T[1],
-               g.p.x * R[2] + g.p.y * R[5] + g.p.z * R[8] + T[2]);
-      const float rqz = rcp(g.q.z), rhalf = rcp(half);
-      const float xn = (A.focal * g.q.x * rqz - A.ppx + half) * rhalf, yn = (A.focal * g.q.y * rqz - A.ppy + half) * rhalf;
-      const float xs = half - half * xn, ys = half - half * yn;
-      g.ix = (int)rintf(fminf(fmaxf(xs, -1.0e6f), 1.0e6f));     // torch .round().long(): half-to-even
-      g.iy = (int)rintf(fminf(fmaxf(ys, -1.0e6f), 1.0e6f));
       const float aa = g.q.z - 0.008f;
-      const float* zlb = A.zl + (size_t)b * S * S;
       float acc = 0.f;
-      int k = 0;
 #pragma unroll
-      for (int ii = -1; ii <= 1; ++ii)
-#pragma unroll
-        for (int jj = -1; jj <= 1; ++jj, ++k) {
-          const int yy = min(max(g.iy + ii, 0), S - 1), xx = min(max(g.ix + jj, 0), S - 1);
-          sg[k] = sigmoidf((*at32(zlb, (unsigned)(yy * S + xx)) - aa) * 1000.0f);
-          acc += sg[k];
-        }
+      for (int k = 0; k < 9; ++k) { sg[k] = sigmoidf((zt[k] - aa) * 1000.0f); acc += sg[k]; }
       g.vis = acc * (1.0f / 9.0f);
     }
 #ifdef SHADE_STAMPS
