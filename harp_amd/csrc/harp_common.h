@@ -241,3 +241,10 @@ __device__ __forceinline__ void normalize3_bwd_texel(const float* __restrict__ x
     gx[3 * i] += g0 * 1e12f; gx[3 * i + 1] += g1 * 1e12f; gx[3 * i + 2] += g2 * 1e12f;
   }
 }
+
+// F.normalize(x, dim=-1) of one texel (eps 1e-12; utils/visualize.py:99) with the sum of squares spelled as fused multiply-adds, so that
+// every translation unit that normalises the normal map (losses.hip, shade.hip) produces the same bits
+__device__ __forceinline__ void normalize3_texel(float a, float b, float c, float& x, float& y, float& z) {
+  const float inv = 1.0f / fmaxf(sqrtf(__fmaf_rn(a, a, __fmaf_rn(b, b, c * c))), 1e-12f);
+  x = a * inv; y = b * inv; z = c * inv;
+}

@@ -337,9 +337,7 @@ __global__ void __launch_bounds__(256) texture_terms_kernel(const TexTerms A) {
 __global__ void normalize3_fwd_kernel(const float* __restrict__ x, int n, float* __restrict__ y) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const float a = x[3 * i], b = x[3 * i + 1], c = x[3 * i + 2];
-  const float inv = 1.0f / fmaxf(sqrtf(a * a + b * b + c * c), 1e-12f);
-  y[3 * i] = a * inv; y[3 * i + 1] = b * inv; y[3 * i + 2] = c * inv;
+  normalize3_texel(x[3 * i], x[3 * i + 1], x[3 * i + 2], y[3 * i], y[3 * i + 1], y[3 * i + 2]);
 }
 __global__ void normalize3_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gy, int n, float* __restrict__ gx) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;

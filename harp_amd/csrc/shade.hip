@@ -603,9 +603,8 @@ __global__ void normalize_pack_kernel(const float* __restrict__ tex, const float
                                       float4* __restrict__ out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const float a = nmap_raw[3 * i], b = nmap_raw[3 * i + 1], c = nmap_raw[3 * i + 2];
-  const float inv = 1.0f / fmaxf(sqrtf(a * a + b * b + c * c), 1e-12f);
-  const float n0 = a * inv, n1 = b * inv, n2 = c * inv;
+  float n0, n1, n2;
+  normalize3_texel(nmap_raw[3 * i], nmap_raw[3 * i + 1], nmap_raw[3 * i + 2], n0, n1, n2);
   nmap_n[3 * i] = n0; nmap_n[3 * i + 1] = n1; nmap_n[3 * i + 2] = n2;
   if (out) {
     out[2 * i] = make_float4(tex[3 * i], tex[3 * i + 1], tex[3 * i + 2], n0);

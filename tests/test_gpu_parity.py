@@ -1354,6 +1354,83 @@ def test_light_view_tile_flags_cover_the_shadow_map_gradient():
     assert eng.s["g_zl"].abs().max().item() == 0.0 and eng.s["zl_tiles"].max().item() == 0
 
 
+def test_fused_small_launches_equal_their_building_blocks():
+    """harp_normalize3_pack, harp_texture_terms and harp_mesh_kps_terms through the C ABI against the stand-alone calls they fuse
+    (harp_normalize3_fwd + harp_pack_texels; harp_texture_smooth_reg x 2 + harp_close_to_z_reg + harp_sum_squares; harp_mesh_regularizers
+    + harp_kps_loss) on random data: bit-exact where no atomics are involved, to the order of the float atomics otherwise."""
+    from harp_amd import _lib, synth
+    L, p, st = _lib.lib(), _lib.ptr, _lib.stream
+    g = torch.Generator().manual_seed(5)
+    H = W = 80
+    n = H * W
+    tex = torch.rand(n, 3, generator=g).to(DEV)
+    nm = (torch.randn(n, 3, generator=g) * 0.3 + torch.tensor([0.0, 0.0, 1.0])).to(DEV)
+    nm[7] = 0.0                                                      # (the eps branch of F.normalize)
+    # ---- normalise + pack
+    y1, pk1 = torch.empty(n, 3, device=DEV), torch.empty(n, 8, device=DEV)
+    y2, pk2 = torch.empty(n, 3, device=DEV), torch.empty(n, 8, device=DEV)
+    _lib.check(L.harp_normalize3_fwd(p(nm), n, p(y1), st()), "normalize3")
+    _lib.check(L.harp_pack_texels(p(tex), p(y1), n, p(pk1), st()), "pack")
+    _lib.check(L.harp_normalize3_pack(p(tex), p(nm), n, p(y2), p(pk2), st()), "normalize3_pack")
+    torch.cuda.synchronize()
+    assert torch.equal(y1, y2) and torch.equal(pk1, pk2)
+    # ---- parameter-only regularisers
+    mask = (torch.rand(n, generator=g) > 0.3).float().to(DEV)
+    da = torch.randint(-2, 3, (n, 2), generator=g, dtype=torch.int32).to(DEV)
+    dn = torch.randint(-4, 5, (n, 2), generator=g, dtype=torch.int32).to(DEV)
+    disp = (torch.randn(500, generator=g) * 1e-3).to(DEV)
+    w = torch.tensor([0.5, 0.1, 2.0], device=DEV)
+    wa, wn, wd = (w[i:i + 1] for i in range(3))
+    la, lb = torch.zeros(3, device=DEV), torch.zeros(3, device=DEV)
+    ga = [torch.zeros(n, 3, device=DEV), torch.zeros(n, 3, device=DEV), torch.zeros(500, device=DEV)]
+    gb = [torch.zeros(n, 3, device=DEV), torch.zeros(n, 3, device=DEV), torch.zeros(500, device=DEV)]
+    _lib.check(L.harp_texture_smooth_reg(p(tex), p(da), p(mask), H, W, p(wa), p(la), p(ga[0]), st()), "albedo")
+    _lib.check(L.harp_close_to_z_reg(p(nm), H, W, 0.2, p(wn), p(la) + 4, p(ga[1]), st()), "close_z")
+    _lib.check(L.harp_texture_smooth_reg(p(nm), p(dn), p(mask), H, W, p(wn), p(la) + 4, p(ga[1]), st()), "normal_smooth")
+    _lib.check(L.harp_sum_squares(p(disp), 500, p(wd), p(la) + 8, p(ga[2]), st()), "disp")
+    cnt = torch.tensor([3], dtype=torch.int32, device=DEV)
+    _lib.check(L.harp_texture_terms(p(tex), p(nm), p(mask), p(da), p(dn), H, W, 0.2, p(wa), p(lb), p(gb[0]), p(wn), p(lb) + 4, p(gb[1]), p(disp), 500,
+                                    p(wd), p(lb) + 8, p(gb[2]), p(cnt), st()), "texture_terms")
+    torch.cuda.synchronize()
+    assert cnt.item() == 4
+    assert ((la - lb).abs() <= 1e-6 * la.abs()).all() and (la > 0).all(), (la, lb)
+    for a, b2 in zip(ga, gb):
+        assert a.abs().max().item() > 0 and rel(b2.double(), a.double()) < 1e-5
+    # loss values only (frozen maps): no gradient is touched
+    lc, gz = torch.zeros(3, device=DEV), torch.zeros(n, 3, device=DEV)
+    _lib.check(L.harp_texture_terms(p(tex), p(nm), p(mask), p(da), p(dn), H, W, 0.2, p(wa), p(lc), None, p(wn), p(lc) + 4, None, None, 0, None, None, None,
+                                    None, st()), "texture_terms")
+    torch.cuda.synchronize()
+    assert ((la[:2] - lc[:2]).abs() <= 1e-6 * la[:2].abs()).all() and lc[2].item() == 0.0
+    # ---- key-point + mesh terms
+    tpl = synth.load_template("hand")
+    topo = synth.build_topology(tpl["faces0"], 778)
+    tv = {k: torch.as_tensor(np.asarray(v)).to(DEV) for k, v in topo.items() if k in ("nbr_off", "nbr_idx", "nc_pairs", "vp_off", "vp_idx")}
+    B, V = 3, int(tv["nbr_off"].shape[0]) - 1
+    E, P = int(tv["nbr_idx"].shape[0]) // 2, int(tv["nc_pairs"].shape[0])
+    verts = (torch.randn(B, V, 3, generator=g) * 0.05).to(DEV)
+    ref = (torch.randn(V, 3, generator=g) * 0.05).to(DEV)
+    gt = (torch.randn(5, 21, 3, generator=g) * 50).to(DEV)
+    fid = torch.tensor([4, 0, 2], dtype=torch.int32, device=DEV)
+    pred = (torch.randn(B, 21, 3, generator=g) * 0.05).to(DEV)
+    wm, wk = torch.tensor([4.0, 0.1, 0.2], device=DEV), torch.tensor([10.0], device=DEV)
+    out = []
+    for fused in (False, True):
+        lm, lk = torch.zeros(3, device=DEV), torch.zeros(1, device=DEV)
+        gv, gp = torch.zeros(B, V, 3, device=DEV), torch.zeros(B, 21, 3, device=DEV)
+        if fused:
+            _lib.check(L.harp_mesh_kps_terms(p(verts), p(ref), p(tv["nbr_off"]), p(tv["nbr_idx"]), p(tv["nc_pairs"]), p(tv["vp_off"]), p(tv["vp_idx"]), B, V, P, E,
+                                             p(wm), p(lm), p(gv), p(gt), p(fid), p(pred), 21, p(wk), p(lk), p(gp), st()), "mesh_kps")
+        else:
+            _lib.check(L.harp_mesh_regularizers(p(verts), p(ref), p(tv["nbr_off"]), p(tv["nbr_idx"]), p(tv["nc_pairs"]), p(tv["vp_off"]), p(tv["vp_idx"]), B, V, P,
+                                                E, p(wm), p(lm), p(gv), st()), "mesh")
+            _lib.check(L.harp_kps_loss(p(gt), p(fid), p(pred), B, 21, p(wk), p(lk), p(gp), st()), "kps")
+        torch.cuda.synchronize()
+        out.append((lm, lk, gv, gp))
+    assert ((out[0][0] - out[1][0]).abs() <= 1e-6 * out[0][0].abs()).all() and torch.equal(out[0][1], out[1][1]) and torch.equal(out[0][3], out[1][3])
+    assert rel(out[1][2].double(), out[0][2].double()) < 1e-5 and out[0][2].abs().max().item() > 0
+
+
 def test_step_prologue_equals_fill_tick_and_draw():
     """harp_step_prologue against torch's fill, harp_adam_tick and harp_draw_texture_offsets — with a slab that starts and ends off a
     16-byte boundary, and with parts left out"""
