@@ -217,7 +217,16 @@ int harp_hand_front_fwd(const harp_hand_front* h, hipStream_t stream) {
     return HARP_ERR_ARG;
   if ((h->step.schedule && (!h->step.sched_row || h->step.n_rows <= 0)) || (h->step.clear_mesh_grads && (!a.g_vd || !a.g_joints_m)))
     return HARP_ERR_ARG;
-  const size_t lds = (size_t)(a.V0 + a.E0) * 3 * sizeof(float);          // <= 48 KB (harp_mesh_chain_max_vertices)
+  // The kernel needs V*12 B (<= 48 KB) of dynamic LDS and asks for (almost) the whole CU's 160 KB: a workgroup of it is a frame's latency
+  // chain, and while it runs the parameter-only regularisers start on the second stream — a kernel of 1 500 small workgroups with a few
+  // bytes of LDS each, which can then not land on this CU and take issue slots / L1 from the chain (-3 us / step, same-box A/B x3;
+  // forcing 128 VGPRs — no co-resident wave at all — was bimodal: DESIGN.md 6.4).  HARP_FRONT_LDS=<bytes> overrides (0: only what is needed).
+  const size_t need = (size_t)(a.V0 + a.E0) * 3 * sizeof(float);
+  size_t lds = 159000;
+  if (const char* e = getenv("HARP_FRONT_LDS")) lds = (size_t)atoi(e);
+  lds = lds < need ? need : lds;
+  if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)hand_front_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return HARP_ERR_ARG;
   hipLaunchKernelGGL(hand_front_kernel, dim3(a.B), dim3(kChainThreads), lds, stream, *h);
   HARP_CHECK_LAUNCH();
   return HARP_OK;
