@@ -492,13 +492,16 @@ int harp_draw_texture_offsets(unsigned seed, int* counter_dev, int H, int W, flo
   return HARP_OK;
 }
 
+static size_t side_lds() { const char* e = getenv("HARP_SIDE_LDS"); return e ? (size_t)atoi(e) : 512; }
+
 int harp_step_prologue(float* zero, size_t n_zero, harp_adam_hyper* hyper, int n_hyper, unsigned seed, const int* draw_counter, int H, int W,
                        float std, int32_t* dist, float std2, int32_t* dist2, hipStream_t stream) {
   if ((n_zero && !zero) || (n_hyper && !hyper) || n_hyper < 0 || n_hyper > 64 || (dist && (!draw_counter || H <= 0 || W <= 0)) || (dist2 && !dist))
     return HARP_ERR_ARG;
   const size_t work = max(n_zero / 4, dist ? (size_t)H * W : (size_t)0);
   const int blocks = (int)max((size_t)1, min((size_t)2048, (work + 255) / 256));
-  hipLaunchKernelGGL(step_prologue_kernel, dim3(blocks), dim3(256), 0, stream, n_zero ? zero : nullptr, n_zero, hyper, n_hyper, seed,
+  // (512 B of dynamic LDS it does not use: a workgroup with LDS cannot land on a CU whose LDS hand_front has claimed, hand_front.hip)
+  hipLaunchKernelGGL(step_prologue_kernel, dim3(blocks), dim3(256), side_lds(), stream, n_zero ? zero : nullptr, n_zero, hyper, n_hyper, seed,
                      draw_counter, dist ? H * W : 0, std, dist, std2, dist2);
   HARP_CHECK_LAUNCH();
   return HARP_OK;

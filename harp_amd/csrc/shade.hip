@@ -810,7 +810,8 @@ int harp_depth_nmap_bwd(const int32_t* face_id, const void* ws, const int32_t* f
 
 int harp_normalize3_pack(const float* tex, const float* nmap_raw, int n_texels, float* nmap_n, float* packed, hipStream_t stream) {
   if (!nmap_raw || !nmap_n || n_texels <= 0 || (packed && !tex)) return HARP_ERR_ARG;
-  hipLaunchKernelGGL(normalize_pack_kernel, dim3((n_texels + 255) / 256), dim3(256), 0, stream, tex, nmap_raw, n_texels, nmap_n, (float4*)packed);
+  const char* e = getenv("HARP_SIDE_LDS");           // (see harp_step_prologue: keeps this kernel off the CUs that run hand_front)
+  hipLaunchKernelGGL(normalize_pack_kernel, dim3((n_texels + 255) / 256), dim3(256), e ? (size_t)atoi(e) : 512, stream, tex, nmap_raw, n_texels, nmap_n, (float4*)packed);
   HARP_CHECK_LAUNCH();
   return HARP_OK;
 }
