@@ -450,7 +450,7 @@ class FitEngine:
             pro = fold or (fill_side and self.fused_terms)
             draw = app and shared_terms and self.auto_draw
             if pro:
-                zero = self.gs_zero[:-16] if fill_side else None
+                zero = self.gs_zero[:-64] if fill_side else None
                 hy, nh = (None, 0)
                 if tick and (coarse or app):
                     hy, nh = (self.hyper.data_ptr(), 2) if (coarse and app) else (self.hyper.data_ptr() + (0 if coarse else 1) * self._hyper_stride, 1)
@@ -461,7 +461,7 @@ class FitEngine:
                     self.gs_mesh.zero_()
             else:
                 if fill_side:
-                    self.gs_zero[:-16].zero_()               # everything but the loss vector (last 16 floats of the slab)
+                    self.gs_zero[:-64].zero_()               # everything but the loss vector (the slab's last segment: 16 floats padded to the arena's 64-float granule — a clear that reached into the padding's front would wipe what the other streams have already added)
                     if not mesh_on_third:
                         self.gs_mesh.zero_()
                 if tick:

@@ -571,6 +571,41 @@ def test_device_schedule_matches_explicit_batches(sc):
                   sc["focal"], 2, device=DEV).step(None)
 
 
+@pytest.mark.parametrize("kw", [dict(self_shadow=False), dict(share_light_position=False), dict(self_shadow=False, share_light_position=False)])
+@pytest.mark.parametrize("stage", [(True, True), (False, True), (True, False)])
+def test_folded_fused_step_in_the_other_engine_configurations(kw, stage):
+    """The folded step and the fused small launches (`fold_step`, `fused_terms`, lean appearance stage, silhouette-only raster) with the
+    Phong renderer instead of the shadow renderer and / or per-frame lights, in all three stages: against the same engine with every one of
+    those switches off — the same losses, the same gradients of the optimised groups, the same optimiser state after each step."""
+    from tests._scene import make_fit_case
+    cases = [make_fit_case("hand", T=4, S=128, B=2, seed=23, device=DEV, **kw) for _ in range(2)]
+    new, old = (c["eng"] for c in cases)
+    coarse, app = stage
+    for e in (new, old):
+        e.keep_image = False
+        e.accumulate_loss = True
+        e.set_schedule(torch.tensor([[0, 1], [2, 3], [3, 0]]).int())
+    old.fold_step = old.fused_terms = old.sil_only_raster = False
+    new.lean_app_stage = True
+    span = new.opt_span if (coarse and app) else (new.coarse_span if coarse else new.app_span)
+    for graph in (False, True):
+        for _ in range(3):
+            for e in (new, old):
+                e.step(None, coarse, app, use_graph=graph)
+            torch.cuda.synchronize()
+            assert torch.equal(new.fid, old.fid) and torch.equal(new.hyper, old.hyper) and new.draw_counter.item() == old.draw_counter.item()
+            ln, lo = new.loss_vec[:9].double(), old.loss_vec[:9].double()
+            assert ((ln - lo).abs() <= 1e-5 * lo.abs() + 1e-9).all(), (kw, stage, ln, lo)
+            assert abs(new.loss_total.item() - old.loss_total.item()) <= 1e-4 * abs(old.loss_total.item()) + 1e-9
+            o, n = span
+            gn, go = new.g_buf[o:o + n].double(), old.g_buf[o:o + n].double()
+            assert go.abs().max().item() > 0 and rel(gn, go) < 1e-4, (kw, stage, rel(gn, go))
+            d = (new.p_buf - old.p_buf).abs()
+            assert d.mean().item() < 1e-6 and (d > 1e-3).float().mean().item() < 1e-4, (kw, stage, d.mean().item(), d.max().item())
+            for k in ("p_buf", "m_buf", "v_buf"):
+                new.__dict__[k].copy_(old.__dict__[k])
+
+
 def test_partial_batch_replays_a_graph_of_its_own_size(sc):
     """the last, shorter batch of an epoch (optimize_sequence.py:396-399) is captured like a full one (batch size in the graph key):
     replayed steps == eager steps"""
