@@ -571,18 +571,23 @@ def test_device_schedule_matches_explicit_batches(sc):
                   sc["focal"], 2, device=DEV).step(None)
 
 
-@pytest.mark.parametrize("kw", [dict(self_shadow=False), dict(share_light_position=False), dict(self_shadow=False, share_light_position=False)])
+@pytest.mark.parametrize("kw", [dict(self_shadow=False), dict(share_light_position=False), dict(self_shadow=False, share_light_position=False),
+                                dict(kind="arm"), dict(kind="arm", self_shadow=False), dict(keep_image=True),
+                                dict(frozen=("verts_disps", "shape", "texture", "normal_map"))])
 @pytest.mark.parametrize("stage", [(True, True), (False, True), (True, False)])
 def test_folded_fused_step_in_the_other_engine_configurations(kw, stage):
     """The folded step and the fused small launches (`fold_step`, `fused_terms`, lean appearance stage, silhouette-only raster) with the
     Phong renderer instead of the shadow renderer and / or per-frame lights, in all three stages: against the same engine with every one of
     those switches off — the same losses, the same gradients of the optimised groups, the same optimiser state after each step."""
     from tests._scene import make_fit_case
-    cases = [make_fit_case("hand", T=4, S=128, B=2, seed=23, device=DEV, **kw) for _ in range(2)]
+    kw = dict(kw)
+    kind, keep, frozen = kw.pop("kind", "hand"), kw.pop("keep_image", False), kw.pop("frozen", ())
+    cases = [make_fit_case(kind, T=4, S=128, B=2, seed=23, device=DEV, **kw) for _ in range(2)]
     new, old = (c["eng"] for c in cases)
     coarse, app = stage
     for e in (new, old):
-        e.keep_image = False
+        e.keep_image = keep
+        e.frozen = frozen                      # (known_appearance: optimize_sequence.py:264-289)
         e.accumulate_loss = True
         e.set_schedule(torch.tensor([[0, 1], [2, 3], [3, 0]]).int())
     old.fold_step = old.fused_terms = old.sil_only_raster = False
@@ -600,6 +605,8 @@ def test_folded_fused_step_in_the_other_engine_configurations(kw, stage):
             o, n = span
             gn, go = new.g_buf[o:o + n].double(), old.g_buf[o:o + n].double()
             assert go.abs().max().item() > 0 and rel(gn, go) < 1e-4, (kw, stage, rel(gn, go))
+            if keep and app:
+                assert (new.s["rgb"] - old.s["rgb"]).abs().max().item() < 1e-5
             d = (new.p_buf - old.p_buf).abs()
             assert d.mean().item() < 1e-6 and (d > 1e-3).float().mean().item() < 1e-4, (kw, stage, d.mean().item(), d.max().item())
             for k in ("p_buf", "m_buf", "v_buf"):
