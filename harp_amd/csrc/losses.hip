@@ -595,7 +595,14 @@ int harp_texture_terms(const float* tex, const float* nmap, const float* mask, c
   A.g_tex = g_tex; A.g_nmap = g_nmap; A.g_disp = g_disp; A.bump = draw_counter_bump;
   A.nb_smooth = min((H * W + 255) / 256, 512);
   A.nb_disp = disp ? min((n_disp + 255) / 256, 64) : 0;
-  hipLaunchKernelGGL(texture_terms_kernel, dim3(2 * A.nb_smooth + H + A.nb_disp), dim3(256), 0, stream, A);
+  // ONE workgroup per CU (100 KB of dynamic LDS the kernel does not use; HARP_TEXTERMS_LDS=<bytes> overrides, 0 = none): the kernel is bound
+  // by its ~5 M scattered memory-side atomics, which four waves per CU keep as busy as thirty-two do (34 -> 37 us) — but with every CU full
+  // of its waves the frames' latency chain that runs next to it (hand_front) took 75 us instead of 57: step -13 us, same-box A/B x4.
+  size_t pad = 100 * 1024;
+  if (const char* e = getenv("HARP_TEXTERMS_LDS")) pad = (size_t)atoi(e);
+  if (pad > 60 * 1024 && hipFuncSetAttribute((const void*)texture_terms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad) != hipSuccess)
+    return HARP_ERR_ARG;
+  hipLaunchKernelGGL(texture_terms_kernel, dim3(2 * A.nb_smooth + H + A.nb_disp), dim3(256), pad, stream, A);
   HARP_CHECK_LAUNCH();
   return HARP_OK;
 }
