@@ -172,7 +172,7 @@ class FitEngine:
         self.force_allreduce = False     # run the N > 1 code path on a single rank (tests, bench HARP_FORCE_DIST)
         self.fused_loss = True           # loss-only mode: photometric L1 formed inside the shader backward (no forward shading launch)
         self.graph_order = True
-        self.mesh_third = True           # key-point / mesh regularisers on a third stream (their own graph branch) instead of in front of the light view: 0.755 vs 0.766 ms / step (a fourth branch for the parameter-only terms: 0.803 vs 0.753)
+        self.mesh_third = False          # key-point / mesh regularisers on a third stream (their own graph branch) instead of in front of the light view.  Round 3: 0.755 vs 0.766 ms / step with the third stream (three launches incl. their clear).  Round 4, with ONE launch for the terms, the clear inside hand_front and the texture regularisers throttled: 0.6665 vs 0.6695 without it (the shader backward joins one stream instead of two; the light view has the slack), C5 1.740 vs 1.752 — off
         self.keep_depth = True           # light-view depth map kept across steps (harp_rasterize_fwd_keep): empty super-tiles are filled with -1 once, not every step (25 MB)
         self.consume_gzl = True          # the depth backward clears the shadow-map gradient entries it consumes: no per-step clear of that image (33.5 MB at B = 32, 512^2)
         self.fused_keep = True           # keep_image with the fused loss: the shader backward also writes y_pred (no forward shading launch either)

@@ -1172,7 +1172,7 @@ def test_light_camera_incl_look_at_replacement_branch():
             assert err < (2e-4 if b == 0 else 1e-3), (b, name, err, got.cpu(), ref)
 
 
-@pytest.mark.parametrize("switches", [dict(graph_order=False), dict(mesh_third=False), dict(camera_first=False), dict(overlap=False),
+@pytest.mark.parametrize("switches", [dict(graph_order=False), dict(mesh_third=True), dict(mesh_third=True, fold_step=False), dict(mesh_third=True, graph_order=False), dict(camera_first=False), dict(overlap=False),
                                       dict(graph_order=False, mesh_third=False), dict(mesh_third=False, camera_first=False),
                                       dict(graph_order=False, mesh_third=False, camera_first=False), dict(early_terms=False),
                                       dict(mesh_terms_first=False, mesh_third=False), dict(tail_side=True), dict(consume_gzl=False), dict(keep_depth=False),
