@@ -557,10 +557,17 @@ static int mesh_terms_launch(const float* verts, const float* ref_verts, const i
   const size_t lds = (size_t)V * 3 * sizeof(float);
   // 512 threads per workgroup: a workgroup stages the whole frame (V * 12 B) whatever its size — 7 stagings per (frame, term) instead of the
   // 13 of 256-thread workgroups (40 -> 30 us, and 9 us off the step: the kernel runs next to the camera-view set-up); 1024 threads: 41 us
-  if (lds <= 60 * 1024)
-    hipLaunchKernelGGL((mesh_reg_kernel<true, 512>), dim3((V + 511) / 512, B, nz), dim3(512), lds, stream, verts, ref_verts, nbr_off, nbr_idx, nc_pairs,
+  if (lds <= 60 * 1024) {
+    // TWO workgroups per CU instead of four (80 KB of dynamic LDS asked for, V * 12 B used; HARP_MESHREG_LDS=<bytes> overrides): the kernel
+    // runs next to the camera view's set-up, which it slows down more than the halved residency slows the kernel itself — neutral at
+    // 512^2 (0.666 vs 0.667 ms / step), C5 1.736 -> 1.720; one per CU loses (1.81)
+    size_t ask = max(lds, (size_t)80000);
+    if (const char* e = getenv("HARP_MESHREG_LDS")) ask = max(lds, (size_t)atoi(e));
+    if (ask > 64 * 1024 && hipFuncSetAttribute((const void*)mesh_reg_kernel<true, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ask) != hipSuccess)
+      return HARP_ERR_ARG;
+    hipLaunchKernelGGL((mesh_reg_kernel<true, 512>), dim3((V + 511) / 512, B, nz), dim3(512), ask, stream, verts, ref_verts, nbr_off, nbr_idx, nc_pairs,
                        vp_off, vp_idx, B, V, P, E, w, loss, g_verts, K);
-  else
+  } else
     hipLaunchKernelGGL(mesh_reg_kernel<false>, dim3((V + 255) / 256, B, nz), dim3(256), 0, stream, verts, ref_verts, nbr_off, nbr_idx, nc_pairs,
                        vp_off, vp_idx, B, V, P, E, w, loss, g_verts, K);
   HARP_CHECK_LAUNCH();
