@@ -558,10 +558,10 @@ static int mesh_terms_launch(const float* verts, const float* ref_verts, const i
   // 512 threads per workgroup: a workgroup stages the whole frame (V * 12 B) whatever its size — 7 stagings per (frame, term) instead of the
   // 13 of 256-thread workgroups (40 -> 30 us, and 9 us off the step: the kernel runs next to the camera-view set-up); 1024 threads: 41 us
   if (lds <= 60 * 1024) {
-    // TWO workgroups per CU instead of four (80 KB of dynamic LDS asked for, V * 12 B used; HARP_MESHREG_LDS=<bytes> overrides): the kernel
-    // runs next to the camera view's set-up, which it slows down more than the halved residency slows the kernel itself — neutral at
-    // 512^2 (0.666 vs 0.667 ms / step), C5 1.736 -> 1.720; one per CU loses (1.81)
-    size_t ask = max(lds, (size_t)80000);
+    // HARP_MESHREG_LDS=<bytes>: ask for more dynamic LDS than the V * 12 B used, i.e. fewer resident workgroups per CU.  80000 (two per CU
+    // instead of four) is worth 16 us at 1024^2 on the arm (C5 1.736 -> 1.720: the kernel runs next to the camera view's set-up, which is
+    // four times longer there) and costs 4 us at 512^2 (0.670 vs 0.666 in bench.py, three pairs) — off by default.
+    size_t ask = lds;
     if (const char* e = getenv("HARP_MESHREG_LDS")) ask = max(lds, (size_t)atoi(e));
     if (ask > 64 * 1024 && hipFuncSetAttribute((const void*)mesh_reg_kernel<true, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ask) != hipSuccess)
       return HARP_ERR_ARG;
