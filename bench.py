@@ -315,35 +315,42 @@ _VGG_CONVS = ((3, 64, 512), (64, 64, 512), (64, 128, 256), (128, 128, 256), (128
 
 def perceptual_rate(device, weights, steps=6, warmup=2):
     """The same step with the reference's default VGG feature term on (optimize_sequence.py:404-405, 419, 546-547):
-    torch / MIOpen fp32 convolutions and their autograd, captured into the step's hipGraph next to the HIP launches.  Target features
-    are cached in HBM (the targets do not change during a fit), so a step is one VGG forward + one backward-data pass over the B
-    rendered images.  weights: "random" (seeded filters: the timing does not depend on the values) or the path of a torchvision vgg16
-    state dict.  The convolution rate is priced against the dense fp32 MFMA peak (157.3 TFLOP/s, MI355X_MICROARCH.md)."""
+    the ten 3x3 convolutions, their data gradients and the ReLU / max-pool / L1 glue as the HIP kernels of csrc/conv.hip, captured into
+    the step's hipGraph with every other launch.  Target features are cached in HBM (the targets do not change during a fit), so a step is
+    one VGG forward + one backward-data pass over the B rendered images.  Both arithmetic modes are timed: float32 MFMA
+    (v_mfma_f32_32x32x2_f32, priced against its 157.3 TFLOP/s peak) and the three-term bf16 split (3 v_mfma_f32_32x32x16_bf16 per product
+    block, priced against the 2.5 PFLOP/s dense bf16 peak at 3x the flop count).  weights: "random" (seeded filters: the timing does not
+    depend on the values) or the path of a torchvision vgg16 state dict."""
     from harp_amd.model.vgg import Vgg16Features
-    e = build_engine(0, 1, device, T=B_PER_GPU, img=S, B=B_PER_GPU)[0]
-    e.keep_image = False
-    t0 = time.perf_counter()
-    e.set_perceptual(Vgg16Features(layers_weights=[1, 1 / 16, 1 / 8, 1 / 4, 1], weights=weights))
-    torch.cuda.synchronize()
-    t_set = time.perf_counter() - t0
-    e.set_schedule(torch.arange(B_PER_GPU).reshape(1, -1).to(torch.int32))
-    for _ in range(warmup):
-        e.step(None, True, True)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        e.step(None, True, True)
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / steps
     fwd = sum(2.0 * 9 * ci * co * h * h for ci, co, h in _VGG_CONVS) * B_PER_GPU
     flop = 2.0 * fwd                                   # forward + backward-data (the filters are frozen: no weight gradients)
-    res = {"frames_per_s": B_PER_GPU / dt, "ms_per_step": dt * 1e3, "frames_per_step": B_PER_GPU, "steps": steps,
-           "filters": "random (seeded)" if weights == "random" else os.path.basename(str(weights)), "in_hipgraph": bool(e._graphs),
-           "conv_tflop_per_step": flop / 1e12, "conv_tflops": flop / dt / 1e12, "fp32_mfma_peak_tflops": 157.3,
-           "frac_of_fp32_mfma_peak": flop / dt / 157.3e12, "set_up_s(MIOpen search + target features)": t_set,
-           "vgg_loss": e.losses().get("vgg")}
-    del e
-    torch.cuda.empty_cache()
+    vgg = Vgg16Features(layers_weights=[1, 1 / 16, 1 / 8, 1 / 4, 1], weights=weights)
+    res = {"frames_per_step": B_PER_GPU, "steps": steps, "conv_tflop_per_step": flop / 1e12,
+           "filters": "random (seeded)" if weights == "random" else os.path.basename(str(weights))}
+    for name, prec, peak, mult in (("f32_mfma", 0, 157.3e12, 1.0), ("bf16x3_split", 1, 2.5e15, 3.0)):
+        e = build_engine(0, 1, device, T=B_PER_GPU, img=S, B=B_PER_GPU)[0]
+        e.keep_image = False
+        t0 = time.perf_counter()
+        e.set_perceptual(vgg, precision=prec)
+        torch.cuda.synchronize()
+        t_set = time.perf_counter() - t0
+        e.set_schedule(torch.arange(B_PER_GPU).reshape(1, -1).to(torch.int32))
+        for _ in range(warmup):
+            e.step(None, True, True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            e.step(None, True, True)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        res[name] = {"frames_per_s": B_PER_GPU / dt, "ms_per_step": dt * 1e3, "in_hipgraph": bool(e._graphs),
+                     "conv_tflops": flop / dt / 1e12, "roofline": {"bound": "mfma", "achieved": mult * flop / dt / 1e12, "peak": peak / 1e12,
+                                                                    "unit": "TFLOP/s", "frac": mult * flop / dt / peak},
+                     "set_up_s(filter packing + target features)": t_set, "vgg_loss": e.losses().get("vgg")}
+        del e
+        torch.cuda.empty_cache()
+    res["frames_per_s"] = res["f32_mfma"]["frames_per_s"]
+    res["ms_per_step"] = res["f32_mfma"]["ms_per_step"]
     return res
 
 

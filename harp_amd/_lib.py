@@ -198,3 +198,34 @@ class HandFront(ctypes.Structure):
 
 SIGNATURES["harp_hand_front_fwd"] = (_i, [ctypes.POINTER(HandFront), _vp])
 SIGNATURES["harp_hand_back_bwd"] = (_i, [ctypes.POINTER(HandFront), _vp, _vp, _vp])
+
+
+class Conv3x3Args(ctypes.Structure):
+    """mirror of `harp_conv3x3_args` (include/harp_hip.h)"""
+    _fields_ = ([(n, _vp) for n in ("in_", "filters", "bias", "out", "pooled", "target", "target_row", "g_tap", "loss", "gate")] +
+                [(n, _i) for n in ("N", "H", "W", "Cin", "Cout", "precision", "epilogue", "in_channels")] + [("tap_scale", _f)])
+
+
+SIGNATURES.update({
+    "harp_conv3x3_filter_bytes": (_sz, [_i, _i]),
+    "harp_conv3x3_pack_filters": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
+    "harp_conv3x3": (_i, [ctypes.POINTER(Conv3x3Args), _vp]),
+})
+
+
+class Vgg16(ctypes.Structure):
+    """mirror of `harp_vgg16` (include/harp_hip.h)"""
+    _fields_ = [("filters", _vp * 10), ("filters_t", _vp * 10), ("bias", _vp * 10), ("w0t", _vp), ("layer_w", _f * 5), ("precision", _i)]
+
+
+class Vgg16TermArgs(ctypes.Structure):
+    """mirror of `harp_vgg16_term_args` (include/harp_hip.h)"""
+    _fields_ = [("rgb", _vp), ("y_true", _vp), ("mask", _vp), ("rows", _vp), ("target", _vp * 4), ("target_by_row", _i), ("covered", _vp),
+                ("g_rgb", _vp), ("weight", _f), ("loss", _vp), ("N", _i), ("S", _i), ("ws", _vp)]
+
+
+SIGNATURES.update({
+    "harp_vgg16_ws_bytes": (_sz, [_i, _i, _i]),
+    "harp_vgg16_features": (_i, [ctypes.POINTER(Vgg16), _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "harp_vgg16_term": (_i, [ctypes.POINTER(Vgg16), ctypes.POINTER(Vgg16TermArgs), _vp]),
+})

@@ -1,0 +1,584 @@
+// The perceptual term of the appearance stage on the matrix cores: the ten 3x3 / pad 1 / stride 1 convolutions of
+// VGG16 features[0:23] (reference: model/vgg.py:10-56, built at optimize_sequence.py:405, used at :546-547 with weight 1.0, :419), their
+// data gradients (the filters are frozen: requires_grad=False, model/vgg.py:34-36 — no weight gradient exists), and everything between
+// them (bias, ReLU, 2x2 max pool, the L1 against the target frames' features, ReLU / pool backward) fused into the epilogues.
+//
+// Activations are NHWC float32 in HBM.  One workgroup (4 waves) owns a 16x16-pixel x 64-channel output tile and walks the input channels
+// in chunks of 16: the (16+2)^2 x 16 input patch and the 9 x 16 x 64 filter slab of the chunk are staged in LDS once and every one of the
+// 9 taps reads its shifted window out of the same patch (implicit GEMM: M = pixels, N = output channels, K = 9 x Cin).  Each wave holds a
+// 16x4-pixel x 64-channel block of the tile as 2 x 2 accumulators of a 32x32 MFMA.  The 32 pixels of an MFMA row block are eight 2x2
+// squares (4 across, 2 down) numbered so that the four accumulator registers r = 4q..4q+3 of a lane are one 2x2 square: ReLU + max pool
+// (and its backward, the arg-max routing) need no cross-lane traffic.
+//
+// Two arithmetic modes (harp_conv3x3_args.precision):
+//   0  v_mfma_f32_32x32x2_f32: float32 in, float32 accumulate — bitwise a float32 fma chain (MI355X_MICROARCH.md), 157 TFLOP/s peak.
+//   1  three-term bf16 split on v_mfma_f32_32x32x16_bf16: x = hi + lo with hi = bf16(x), lo = bf16(x - hi); a.b ~ hi.hi + hi.lo + lo.hi
+//      (the dropped lo.lo is 2^-18 relative), float32 accumulate: ~16 mantissa bits per product (the reference's stack — torch 1.11 + cuDNN,
+//      requirements.txt:81 — runs these convolutions with TF32 allowed, 10 bits), 3/16 of the float32 MFMA time.  The split of the
+//      activations happens while the patch is staged; the filters are split once (harp_conv3x3_pack_filters).
+#include "harp_common.h"
+#include "harp_hip.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kCT = 16;                   // output tile: 16 x 16 pixels
+constexpr int kCK = 16;                   // input channels per staged chunk
+constexpr int kCN = 64;                   // output channels per workgroup
+constexpr int kPatch = kCT + 2;           // 18: tile + 1-pixel halo
+// LDS patch: 4 planes of [18 rows][24 pixels][16 B].  float32 mode: plane q = channels 4q..4q+3 of the chunk; bf16 mode: planes 0/1 = hi of
+// channels 0-7 / 8-15, planes 2/3 = lo.  A lane's A fragment is ONE 16-byte read at (its pixel + tap offset) of the plane of its k half
+// (lanes 0-31 / 32-63).  Row pitch 24 pixels = 96 banks = 32 mod 64: the 16 lanes the LDS serves per cycle (ds_read_b128 lane groups)
+// touch two rows x four 2-pixel squares whose 16-B slots fall on distinct banks for every tap (checked in tools/dev/conv_banks.py).
+constexpr int kRow = 24;
+constexpr int kPlane = kPatch * kRow + 2; // +2 float4: consecutive planes 8 banks apart, so the staging stores of one pixel's 4 quads do not collide
+constexpr int kInF4 = 4 * kPlane;
+constexpr int kWF4 = 9 * 4 * kCN;         // filter slab of one (64 output channels, 16 input channels) pair: [tap][plane][co][16 B] = 36 864 B
+constexpr int kLdsBytes = (kInF4 + kWF4) * 16;
+constexpr int kUnits = (kPatch * kPatch * 4 + 255) / 256;   // 16-byte staging units per thread (6; the last one is mostly idle)
+
+enum { EPI_RELU = 0, EPI_RELU_TAP = 1, EPI_GATE = 2, EPI_UNPOOL = 3 };
+
+__device__ __forceinline__ float sgn(float d) { return (float)((d > 0.f) - (d < 0.f)); }
+
+// ---- filter packing ---------------------------------------------------------------------------------------------------------------
+// w (Cout_src, Cin_src, 3, 3) in torch's layout -> slabs [Cout/64][Cin/16] of kWF4 float4 each, zero-padded to the multiples.
+// transpose != 0: the filters of the DATA GRADIENT, a convolution of the output gradient with w'[ci][co][ky][kx] = w[co][ci][2-ky][2-kx].
+__global__ void pack_filters_kernel(const float* __restrict__ w, int Cout_src, int Cin_src, int Cout, int Cin, int transpose, int precision,
+                                    float* __restrict__ packed) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t total = (size_t)Cout * Cin * 9;
+  if (i >= total) return;
+  // one thread per (slab, tap, co in block, channel in chunk)
+  const int c = i % kCK, co_l = (i / kCK) % kCN, tap = (i / (kCK * kCN)) % 9;
+  const size_t slab = i / (kCK * kCN * 9);
+  const int nchunk = Cin / kCK;
+  const int cb = slab / nchunk, cc = slab % nchunk;
+  const int co = cb * kCN + co_l, ci = cc * kCK + c;
+  float v = 0.f;
+  if (!transpose) {
+    if (co < Cout_src && ci < Cin_src) v = w[((size_t)co * Cin_src + ci) * 9 + tap];
+  } else {
+    if (ci < Cout_src && co < Cin_src) v = w[((size_t)ci * Cin_src + co) * 9 + (8 - tap)];
+  }
+  if (precision == 0) {
+    packed[slab * (kWF4 * 4) + ((size_t)(tap * 4 + (c >> 2)) * kCN + co_l) * 4 + (c & 3)] = v;
+  } else {
+    const __bf16 hi = (__bf16)v;
+    const __bf16 lo = (__bf16)(v - (float)hi);
+    __bf16* p = (__bf16*)packed + slab * (kWF4 * 8);
+    p[((size_t)(tap * 4 + (c >> 3)) * kCN + co_l) * 8 + (c & 7)] = hi;
+    p[((size_t)(tap * 4 + 2 + (c >> 3)) * kCN + co_l) * 8 + (c & 7)] = lo;
+  }
+}
+
+// ---- the convolution ----------------------------------------------------------------------------------------------------------------
+template <int PREC, int EPI>
+__global__ __launch_bounds__(256, 2) void conv3x3_kernel(const harp_conv3x3_args a, const int tiles_x, const int tiles_y) {
+  extern __shared__ float4 smem[];          // ONE LDS object (a second one makes hipcc drain vmcnt before every ds_read, cdna_hip_programming.md §5)
+  float4* s_in = smem;
+  float4* s_w = smem + kInF4;
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6, half = lane >> 5, m = lane & 31;
+
+  const int ncb = a.Cout / kCN, nchunk = a.Cin / kCK;
+  int id = blockIdx.x;
+  const int cb = id % ncb; id /= ncb;
+  const int tx = id % tiles_x; id /= tiles_x;
+  const int ty = id % tiles_y;
+  const int n = id / tiles_y;
+  const int x0 = tx * kCT, y0 = ty * kCT;
+  const int H = a.H, W = a.W;
+  const int Cin = a.in_channels > 0 ? a.in_channels : a.Cin;     // channels per pixel in memory (the rest of a.Cin reads as zero)
+  const float* __restrict__ in_n = a.in + (size_t)n * H * W * Cin;
+  const float4* __restrict__ wslab = (const float4*)a.filters + (size_t)cb * nchunk * kWF4;
+
+  // staging units of this thread: unit u = (patch pixel u >> 2, channel quad u & 3): four consecutive lanes fetch one pixel's 64 bytes
+  int goff[kUnits], lidx[kUnits];
+#pragma unroll
+  for (int j = 0; j < kUnits; ++j) {
+    const int u = j * 256 + t, pix = u >> 2, q = u & 3;
+    goff[j] = -1; lidx[j] = -1;
+    if (pix < kPatch * kPatch) {
+      const int py = pix / kPatch, px = pix - py * kPatch;
+      const int gy = y0 + py - 1, gx = x0 + px - 1;
+      if (PREC == 0) lidx[j] = q * kPlane + py * kRow + px;                       // float4 index
+      else lidx[j] = (((q >> 1) * kPlane + py * kRow + px) << 1) | (q & 1);      // 8-byte index of the hi half; lo is 2 planes further
+      if (gy >= 0 && gy < H && gx >= 0 && gx < W) goff[j] = (gy * W + gx) * Cin + 4 * q;
+    }
+  }
+  float4 rin[kUnits], rw[9];
+  // (out-of-image units read the image's first bytes and are zeroed afterwards: a select instead of a branch around every load)
+  auto fetch = [&](int cc) {
+#pragma unroll
+    for (int j = 0; j < kUnits; ++j) {
+      const bool ok = goff[j] >= 0 && cc * kCK + 4 * ((j * 256 + t) & 3) < Cin;
+      const float4 v = *(const float4*)(in_n + (ok ? goff[j] + cc * kCK : 0));
+      rin[j] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int j = 0; j < 9; ++j) rw[j] = wslab[(size_t)cc * kWF4 + j * 256 + t];
+  };
+  auto stage = [&]() {
+#pragma unroll
+    for (int j = 0; j < kUnits; ++j) {
+      if (lidx[j] < 0) continue;
+      if (PREC == 0) {
+        s_in[lidx[j]] = rin[j];
+      } else {
+        const float4 v = rin[j];
+        bf16x4 hi = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+        bf16x4 lo = {(__bf16)(v.x - (float)hi[0]), (__bf16)(v.y - (float)hi[1]), (__bf16)(v.z - (float)hi[2]), (__bf16)(v.w - (float)hi[3])};
+        uint2* s8 = (uint2*)s_in;
+        s8[lidx[j]] = __builtin_bit_cast(uint2, hi);
+        s8[lidx[j] + 4 * kPlane] = __builtin_bit_cast(uint2, lo);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 9; ++j) s_w[j * 256 + t] = rw[j];
+  };
+
+  // this lane's pixel in each of the wave's two 8x4 row blocks: m = 4 * square + (dy, dx); squares 4 across, 2 down
+  const int ly = 4 * wv + 2 * (m >> 4) + ((m >> 1) & 1);
+  const int lx = 2 * ((m >> 2) & 3) + (m & 1);
+  const int pixA = ly * kRow + lx;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  fetch(0);
+  for (int cc = 0; cc < nchunk; ++cc) {
+    __syncthreads();                      // every wave is done with the previous chunk's patch and slab
+    stage();
+    __syncthreads();
+    if (cc + 1 < nchunk) fetch(cc + 1);   // in flight under the chunk's MFMAs
+    // Software pipeline over the chunk's steps (float32: 18 = 9 taps x 2 k groups of 8 channels; bf16: 9 taps of 16 channels): the
+    // fragments of step s + 1 are read from LDS before the MFMAs of step s issue, so one wave alone covers its LDS latency (the compiler's
+    // own schedule read each step's fragments right in front of its MFMAs: MFMA pipe 78 % / 37 % busy, profiles/r05_a_pmc_sq_conv_*).
+    constexpr int kSteps = PREC == 0 ? 18 : 9;
+    constexpr int kFrag = PREC == 0 ? 4 : 8;
+    float4 fr[2][kFrag];
+    auto read_frags = [&](float4* f, int step) {
+      if (PREC == 0) {
+        const int tap = step >> 1, g = step & 1;
+        const int plane = 2 * g + half, toff = (tap / 3) * kRow + (tap % 3);
+        f[0] = s_in[plane * kPlane + pixA + toff]; f[1] = s_in[plane * kPlane + pixA + toff + 8];
+        f[2] = s_w[(tap * 4 + plane) * kCN + m]; f[3] = s_w[(tap * 4 + plane) * kCN + 32 + m];
+      } else {
+        const int tap = step, toff = (tap / 3) * kRow + (tap % 3);
+        f[0] = s_in[half * kPlane + pixA + toff]; f[1] = s_in[half * kPlane + pixA + toff + 8];                       // A hi
+        f[2] = s_in[(2 + half) * kPlane + pixA + toff]; f[3] = s_in[(2 + half) * kPlane + pixA + toff + 8];           // A lo
+        f[4] = s_w[(tap * 4 + half) * kCN + m]; f[5] = s_w[(tap * 4 + half) * kCN + 32 + m];                          // B hi
+        f[6] = s_w[(tap * 4 + 2 + half) * kCN + m]; f[7] = s_w[(tap * 4 + 2 + half) * kCN + 32 + m];                  // B lo
+      }
+    };
+    read_frags(fr[0], 0);
+#pragma unroll
+    for (int step = 0; step < kSteps; ++step) {
+      float4* f = fr[step & 1];
+      if (step + 1 < kSteps) read_frags(fr[(step + 1) & 1], step + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      if (PREC == 0) {
+        const float a0[4] = {f[0].x, f[0].y, f[0].z, f[0].w}, a1[4] = {f[1].x, f[1].y, f[1].z, f[1].w};
+        const float b0[4] = {f[2].x, f[2].y, f[2].z, f[2].w}, b1[4] = {f[3].x, f[3].y, f[3].z, f[3].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], b0[e], acc[0][0], 0, 0, 0);
+          acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], b1[e], acc[0][1], 0, 0, 0);
+          acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], b0[e], acc[1][0], 0, 0, 0);
+          acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], b1[e], acc[1][1], 0, 0, 0);
+        }
+      } else {
+        const bf16x8 Ah0 = __builtin_bit_cast(bf16x8, f[0]), Ah1 = __builtin_bit_cast(bf16x8, f[1]);
+        const bf16x8 Al0 = __builtin_bit_cast(bf16x8, f[2]), Al1 = __builtin_bit_cast(bf16x8, f[3]);
+        const bf16x8 Bh0 = __builtin_bit_cast(bf16x8, f[4]), Bh1 = __builtin_bit_cast(bf16x8, f[5]);
+        const bf16x8 Bl0 = __builtin_bit_cast(bf16x8, f[6]), Bl1 = __builtin_bit_cast(bf16x8, f[7]);
+        // the two small terms first, the leading one last
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al0, Bh0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al0, Bh1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al1, Bh0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al1, Bh1, acc[1][1], 0, 0, 0);
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah0, Bl0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah0, Bl1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah1, Bl0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah1, Bl1, acc[1][1], 0, 0, 0);
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah0, Bh0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah0, Bh1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah1, Bh0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah1, Bh1, acc[1][1], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+
+  // ---- epilogue.  Accumulator register r of lane (half, m) in row block i / column block j: output channel co = 64 cb + 32 j + m;
+  // pixel = square 2 (r >> 2) + half of the row block (4 across, 2 down), corner (dy, dx) = ((r >> 1) & 1, r & 1).
+  const int Cout = a.Cout;
+  float lsum = 0.f;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int co = cb * kCN + 32 * j + m;
+    const float bias = (EPI <= EPI_RELU_TAP && a.bias) ? a.bias[co] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int sq = 2 * q + half;
+        const int gy = y0 + 4 * wv + 2 * (sq >> 2), gx = x0 + 8 * i + 2 * (sq & 3);     // top-left pixel of the 2x2 square (even, even)
+        if (gy >= H || gx >= W) continue;
+        if (EPI == EPI_RELU || EPI == EPI_RELU_TAP) {
+          float v[4];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) v[c] = fmaxf(acc[i][j][4 * q + c] + bias, 0.f);
+          const size_t row = (EPI == EPI_RELU_TAP && a.target_row) ? (size_t)a.target_row[n] : (size_t)n;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const int yy = gy + (c >> 1), xx = gx + (c & 1);
+            if (yy >= H || xx >= W) continue;
+            const size_t o = ((size_t)yy * W + xx) * Cout + co;
+            if (a.out) a.out[(size_t)n * H * W * Cout + o] = v[c];
+            if (EPI == EPI_RELU_TAP) {
+              const float d = v[c] - a.target[row * H * W * Cout + o];
+              lsum += fabsf(d);
+              a.g_tap[(size_t)n * H * W * Cout + o] = v[c] > 0.f ? a.tap_scale * sgn(d) : 0.f;
+            }
+          }
+          if (a.pooled)   // torch.nn.MaxPool2d(2, 2) (model/vgg.py slices 2-4 open with it): H, W even here (checked on the host)
+            a.pooled[(((size_t)n * (H >> 1) + (gy >> 1)) * (W >> 1) + (gx >> 1)) * Cout + co] = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+        } else if (EPI == EPI_GATE) {
+          // ReLU backward: the gradient passes where the forward activation was positive (threshold_backward)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const int yy = gy + (c >> 1), xx = gx + (c & 1);
+            if (yy >= H || xx >= W) continue;
+            const size_t o = (((size_t)n * H + yy) * W + xx) * Cout + co;
+            a.out[o] = a.gate[o] > 0.f ? acc[i][j][4 * q + c] : 0.f;
+          }
+        } else {
+          // max-pool backward + ReLU backward + the tap's own L1 gradient: this convolution's pixels are the POOLED pixels; each routes its
+          // gradient to the first maximum of its 2x2 window in row-major order (max_pool2d's arg-max), if that activation was positive.
+          // a.out (N, 2H, 2W, Cout) holds the tap gradient on entry; every element belongs to exactly one window: no atomics.
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const int yy = gy + (c >> 1), xx = gx + (c & 1);
+            if (yy >= H || xx >= W) continue;
+            const size_t o00 = (((size_t)n * 2 * H + 2 * yy) * 2 * W + 2 * xx) * Cout + co;
+            const size_t dx = Cout, dy = (size_t)2 * W * Cout;
+            const float g00 = a.gate[o00], g01 = a.gate[o00 + dx], g10 = a.gate[o00 + dy], g11 = a.gate[o00 + dy + dx];
+            float best = g00; size_t ob = o00;
+            if (g01 > best) { best = g01; ob = o00 + dx; }
+            if (g10 > best) { best = g10; ob = o00 + dy; }
+            if (g11 > best) { best = g11; ob = o00 + dy + dx; }
+            if (best > 0.f) a.out[ob] += acc[i][j][4 * q + c];
+          }
+        }
+      }
+    }
+  }
+  if (EPI == EPI_RELU_TAP) {
+    __syncthreads();                       // the patch is dead: its first floats carry the block sum (no second LDS object, see above)
+    const float s = block_sum_256(lsum, (float*)smem);
+    if (t == 0 && s != 0.f) atomicAdd(a.loss, (double)s * (double)a.tap_scale);
+  }
+}
+
+template <int PREC, int EPI>
+int launch_conv(const harp_conv3x3_args& a, hipStream_t stream) {
+  static bool ready = false;               // per instantiation: raise the dynamic-LDS limit once, not per launch (and never inside a capture)
+  auto kern = conv3x3_kernel<PREC, EPI>;
+  if (!ready) {
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes) != hipSuccess) return HARP_ERR_LAUNCH;
+    ready = true;
+  }
+  const int tiles_x = (a.W + kCT - 1) / kCT, tiles_y = (a.H + kCT - 1) / kCT;
+  const size_t blocks = (size_t)tiles_x * tiles_y * a.N * (a.Cout / kCN);
+  if (blocks == 0 || blocks > 0x7fffffffu) return HARP_ERR_ARG;
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), kLdsBytes, stream, a, tiles_x, tiles_y);
+  HARP_CHECK_LAUNCH();
+  return HARP_OK;
+}
+
+template <int PREC>
+int launch_conv_prec(const harp_conv3x3_args& a, hipStream_t stream) {
+  switch (a.epilogue) {
+    case EPI_RELU: return launch_conv<PREC, EPI_RELU>(a, stream);
+    case EPI_RELU_TAP: return launch_conv<PREC, EPI_RELU_TAP>(a, stream);
+    case EPI_GATE: return launch_conv<PREC, EPI_GATE>(a, stream);
+    case EPI_UNPOOL: return launch_conv<PREC, EPI_UNPOOL>(a, stream);
+  }
+  return HARP_ERR_ARG;
+}
+
+
+// ---- the two ends of the stack: 3 image channels, vector ALU ------------------------------------------------------------------------
+// x0 = image * mask (optimize_sequence.py:546-547: vgg(y_pred * mask) / vgg(y_true * mask)), written as 4 channels per pixel (r, g, b, 0);
+// with y_true given, also the term's first row (model/vgg.py:41: the flattened input itself): *loss += scale0 * sum |x0 - y_true * mask|.
+__global__ __launch_bounds__(256) void vgg_prep_kernel(const float* __restrict__ image, const int32_t* __restrict__ image_rows,
+                                                       const float* __restrict__ mask, const int32_t* __restrict__ mask_rows,
+                                                       const float* __restrict__ y_true, int S, float scale0, float4* __restrict__ x0,
+                                                       double* __restrict__ loss) {
+  __shared__ float red[4];
+  const int n = blockIdx.y;
+  const size_t ir = image_rows ? (size_t)image_rows[n] : (size_t)n, mr = mask_rows ? (size_t)mask_rows[n] : (size_t)n;
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  float l = 0.f;
+  if (p < S * S) {
+    const float m = mask[mr * S * S + p];
+    const float* px = image + (ir * S * S + p) * 3;
+    const float r = px[0] * m, g = px[1] * m, b = px[2] * m;
+    x0[(size_t)n * S * S + p] = make_float4(r, g, b, 0.f);
+    if (y_true) {
+      const float* t = y_true + (mr * S * S + p) * 3;
+      l = fabsf(r - t[0] * m) + fabsf(g - t[1] * m) + fabsf(b - t[2] * m);
+    }
+  }
+  if (y_true) {
+    const float s = block_sum_256(l, red);
+    if (threadIdx.x == 0 && s != 0.f) atomicAdd(loss, (double)s * (double)scale0);
+  }
+}
+
+// The data gradient of the first convolution (64 -> 3 channels) and the end of the chain:
+//   g_x0 = conv(G, w0^T mirrored) + scale0 * sign(x0 - y_true * mask);  d term / d rgb = mask * g_x0;
+//   g_rgb = covered ? g_rgb + weight * (d term / d rgb) : 0     (the photometric gradient buffer is only defined at covered pixels)
+// One pixel per thread, 16x16-pixel tiles; the 64 channels of G pass through LDS in four 18x18x16 patches; the filter taps are
+// wave-uniform (scalar loads from w0t (9,3,64), w0t[t][c][co] = w0[co][c][8 - t]).  *loss_out = the term's value (the double accumulator is complete when this kernel starts).
+constexpr int kGRow = 20;                                   // LDS row pitch (float4) of the gradient patch
+__global__ __launch_bounds__(256) void vgg_grad_image_kernel(const float* __restrict__ G, const float* __restrict__ w0t, const float* __restrict__ rgb,
+                                                             const float* __restrict__ y_true, const float* __restrict__ mask,
+                                                             const int32_t* __restrict__ rows, const int32_t* __restrict__ covered, int S, float scale0,
+                                                             float weight, float* __restrict__ g_rgb, const double* __restrict__ loss_acc,
+                                                             float* __restrict__ loss_out) {
+  __shared__ float4 patch[4 * kPatch * kGRow];
+  const int t = threadIdx.x, tx = t & 15, ty = t >> 4;
+  const int n = blockIdx.z, x0 = blockIdx.x * kCT, y0 = blockIdx.y * kCT;
+  if (loss_out && t == 0 && blockIdx.x == 0 && blockIdx.y == 0 && n == 0) loss_out[0] = (float)loss_acc[0];
+  const float* __restrict__ Gn = G + (size_t)n * S * S * 64;
+  float o0 = 0.f, o1 = 0.f, o2 = 0.f;
+  for (int cc = 0; cc < 4; ++cc) {
+    __syncthreads();
+    for (int u = t; u < kPatch * kPatch * 4; u += 256) {
+      const int pix = u >> 2, q = u & 3, py = pix / kPatch, px = pix - py * kPatch;
+      const int gy = y0 + py - 1, gx = x0 + px - 1;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (gy >= 0 && gy < S && gx >= 0 && gx < S) v = *(const float4*)(Gn + ((size_t)gy * S + gx) * 64 + cc * 16 + 4 * q);
+      patch[(q * kPatch + py) * kGRow + px] = v;
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int tap = 0; tap < 9; ++tap) {
+      // output channel c, input pixel (y + ky - 1, x + kx - 1), channel co of G: weight w0[co][c][2 - ky][2 - kx] = w0t[tap][c][co]
+      // (wave-uniform: 48 scalar loads per tap and chunk; the tap loop stays rolled so that they are not all hoisted and spilled)
+      const int ky = tap / 3, kx = tap - 3 * ky;
+      const float* __restrict__ w = w0t + tap * 192 + cc * 16;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 g = patch[(q * kPatch + ty + ky) * kGRow + tx + kx];
+        const float gv[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          o0 = fmaf(gv[e], w[4 * q + e], o0);
+          o1 = fmaf(gv[e], w[64 + 4 * q + e], o1);
+          o2 = fmaf(gv[e], w[128 + 4 * q + e], o2);
+        }
+      }
+    }
+  }
+  const int gx = x0 + tx, gy = y0 + ty;
+  if (gx >= S || gy >= S) return;
+  const size_t p = (size_t)gy * S + gx, o = ((size_t)n * S * S + p) * 3;
+  if (covered && covered[(size_t)n * S * S + p] < 0) {
+    g_rgb[o] = 0.f; g_rgb[o + 1] = 0.f; g_rgb[o + 2] = 0.f;
+    return;
+  }
+  const size_t r = rows ? (size_t)rows[n] : (size_t)n;
+  const float m = mask[r * S * S + p];
+  const float* yt = y_true + (r * S * S + p) * 3;
+  const float d0 = (rgb[o] - yt[0]) * m, d1 = (rgb[o + 1] - yt[1]) * m, d2 = (rgb[o + 2] - yt[2]) * m;
+  g_rgb[o] += weight * m * (o0 + scale0 * sgn(d0));
+  g_rgb[o + 1] += weight * m * (o1 + scale0 * sgn(d1));
+  g_rgb[o + 2] += weight * m * (o2 + scale0 * sgn(d2));
+}
+
+// ---- workspace of the whole term ------------------------------------------------------------------------------------------------------
+// VGG16 features[0:23]: convolution k -> (Cin, Cout, image side divisor)
+constexpr int kVggCin[10] = {3, 64, 64, 128, 128, 256, 256, 256, 512, 512};
+constexpr int kVggCout[10] = {64, 64, 128, 128, 256, 256, 256, 512, 512, 512};
+constexpr int kVggDiv[10] = {1, 1, 2, 2, 4, 4, 4, 8, 8, 8};
+constexpr int kVggTap[4] = {1, 3, 6, 9};                     // relu1_2, relu2_2, relu3_3, relu4_3 (model/vgg.py:42-49)
+
+struct VggWs {
+  float4* x0;
+  float* act[10];
+  float* pool[3];
+  float* g_tap[4];
+  float* gbuf[2];
+  double* loss;
+  size_t bytes;
+};
+inline VggWs vgg_ws_split(void* ws, int N, int S, int with_gradient) {
+  VggWs w;
+  char* p = (char*)ws;
+  auto take = [&](size_t floats) { char* r = p; p += (floats * 4 + 255) / 256 * 256; return (float*)r; };
+  const size_t NS2 = (size_t)N * S * S;
+  w.loss = (double*)take(64);
+  w.x0 = (float4*)take(NS2 * 4);
+  for (int k = 0; k < 10; ++k) w.act[k] = take(NS2 / (kVggDiv[k] * kVggDiv[k]) * kVggCout[k]);
+  for (int k = 0; k < 3; ++k) w.pool[k] = take(NS2 / (4 << (2 * k)) * kVggCout[kVggTap[k]]);
+  for (int k = 0; k < 4; ++k) w.g_tap[k] = with_gradient ? take(NS2 / (kVggDiv[kVggTap[k]] * kVggDiv[kVggTap[k]]) * kVggCout[kVggTap[k]]) : nullptr;
+  for (int k = 0; k < 2; ++k) w.gbuf[k] = with_gradient ? take(NS2 * 64) : nullptr;
+  w.bytes = (size_t)(p - (char*)ws);
+  return w;
+}
+
+// forward pass of the stack over x0; tap layers write to tap_out[k] (or their workspace slot) and, with target != NULL, take the L1 epilogue
+int vgg_forward(const harp_vgg16* net, const VggWs& w, int N, int S, float* const tap_out[4], const float* const target[4],
+                const int32_t* target_row, const float scale[5], hipStream_t stream) {
+  const float* in = (const float*)w.x0;
+  int tap = 0;
+  for (int k = 0; k < 10; ++k) {
+    harp_conv3x3_args a = {};
+    const bool is_tap = (tap < 4 && k == kVggTap[tap]);
+    const int s = S / kVggDiv[k];
+    a.in = in; a.filters = net->filters[k]; a.bias = net->bias[k];
+    a.N = N; a.H = s; a.W = s; a.Cin = (kVggCin[k] + kCK - 1) / kCK * kCK; a.Cout = kVggCout[k];
+    a.in_channels = k == 0 ? 4 : 0;
+    a.precision = net->precision;
+    a.out = (is_tap && tap_out && tap_out[tap]) ? tap_out[tap] : w.act[k];
+    a.epilogue = HARP_CONV_RELU;
+    if (is_tap) {
+      if (tap < 3) a.pooled = w.pool[tap];
+      if (target) {
+        a.epilogue = HARP_CONV_RELU_TAP;
+        a.target = target[tap]; a.target_row = target_row; a.tap_scale = scale[tap + 1]; a.g_tap = w.g_tap[tap]; a.loss = w.loss;
+      }
+    }
+    const int rc = harp_conv3x3(&a, stream);
+    if (rc != HARP_OK) return rc;
+    in = (is_tap && tap < 3) ? w.pool[tap] : a.out;
+    if (is_tap) ++tap;
+  }
+  return HARP_OK;
+}
+
+void vgg_scales(const harp_vgg16* net, int N, int S, float scale[5]) {
+  // L1Loss (mean) over the concatenated rows (model/vgg.py:51-55): n = N * (3 S^2 + 64 S^2 + 128 (S/2)^2 + 256 (S/4)^2 + 512 (S/8)^2)
+  const double S2 = (double)S * S;
+  const double n = (double)N * (3 * S2 + 64 * S2 + 128 * S2 / 4 + 256 * S2 / 16 + 512 * S2 / 64);
+  for (int k = 0; k < 5; ++k) scale[k] = (float)(fabs((double)net->layer_w[k]) / n);
+}
+
+bool vgg_net_ok(const harp_vgg16* net, bool gradient) {
+  if (!net || (net->precision != 0 && net->precision != 1)) return false;
+  for (int k = 0; k < 10; ++k) {
+    if (!net->filters[k] || !net->bias[k]) return false;
+    if (gradient && k > 0 && !net->filters_t[k]) return false;
+  }
+  return !gradient || net->w0t;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t harp_conv3x3_filter_bytes(int Cout, int Cin) {
+  const size_t co = (size_t)(Cout + kCN - 1) / kCN, ci = (size_t)(Cin + kCK - 1) / kCK;
+  return co * ci * kWF4 * 16;
+}
+
+int harp_conv3x3_pack_filters(const float* w, int Cout, int Cin, int transpose, int precision, void* packed, hipStream_t stream) {
+  if (!w || !packed || Cout <= 0 || Cin <= 0 || (precision != 0 && precision != 1)) return HARP_ERR_ARG;
+  const int co_src = Cout, ci_src = Cin;
+  const int out_c = transpose ? Cin : Cout, in_c = transpose ? Cout : Cin;          // channels of the packed convolution
+  const int Cout_p = (out_c + kCN - 1) / kCN * kCN, Cin_p = (in_c + kCK - 1) / kCK * kCK;
+  const size_t total = (size_t)Cout_p * Cin_p * 9;
+  hipLaunchKernelGGL(pack_filters_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, w, co_src, ci_src, Cout_p, Cin_p, transpose,
+                     precision, (float*)packed);
+  HARP_CHECK_LAUNCH();
+  return HARP_OK;
+}
+
+int harp_conv3x3(const harp_conv3x3_args* a, hipStream_t stream) {
+  if (!a || !a->in || !a->filters || a->N <= 0 || a->H <= 0 || a->W <= 0 || a->Cin <= 0 || a->Cout <= 0) return HARP_ERR_ARG;
+  if (a->Cin % kCK || a->Cout % kCN) return HARP_ERR_ARG;
+  if ((size_t)a->H * a->W * a->Cin > 0x7fffffffu) return HARP_ERR_ARG;               // 32-bit offsets inside one image
+  if (a->in_channels < 0 || a->in_channels > a->Cin || (a->in_channels & 3)) return HARP_ERR_ARG;
+  switch (a->epilogue) {
+    case EPI_RELU: if (!a->out && !a->pooled) return HARP_ERR_ARG; break;
+    case EPI_RELU_TAP: if (!a->target || !a->g_tap || !a->loss) return HARP_ERR_ARG; break;
+    case EPI_GATE: case EPI_UNPOOL: if (!a->out || !a->gate) return HARP_ERR_ARG; break;
+    default: return HARP_ERR_ARG;
+  }
+  if (a->pooled && ((a->H | a->W) & 1)) return HARP_ERR_ARG;
+  if (a->precision == 0) return launch_conv_prec<0>(*a, stream);
+  if (a->precision == 1) return launch_conv_prec<1>(*a, stream);
+  return HARP_ERR_ARG;
+}
+
+size_t harp_vgg16_ws_bytes(int N, int S, int with_gradient) {
+  if (N <= 0 || S <= 0 || (S & 7)) return 0;
+  return vgg_ws_split(nullptr, N, S, with_gradient).bytes;
+}
+
+int harp_vgg16_features(const harp_vgg16* net, const float* image, const float* mask, const int32_t* rows, int N, int S, void* ws, float* f1,
+                        float* f2, float* f3, float* f4, hipStream_t stream) {
+  if (!vgg_net_ok(net, false) || !image || !mask || !ws || N <= 0 || S <= 0 || (S & 7) || !f1 || !f2 || !f3 || !f4) return HARP_ERR_ARG;
+  const VggWs w = vgg_ws_split(ws, N, S, 0);
+  hipLaunchKernelGGL(vgg_prep_kernel, dim3((S * S + 255) / 256, N), dim3(256), 0, stream, image, rows, mask, rows, (const float*)nullptr, S, 0.f, w.x0,
+                     w.loss);
+  HARP_CHECK_LAUNCH();
+  float* const taps[4] = {f1, f2, f3, f4};
+  return vgg_forward(net, w, N, S, taps, nullptr, nullptr, nullptr, stream);
+}
+
+int harp_vgg16_term(const harp_vgg16* net, const harp_vgg16_term_args* t, hipStream_t stream) {
+  if (!vgg_net_ok(net, true) || !t || !t->rgb || !t->y_true || !t->mask || !t->g_rgb || !t->ws || t->N <= 0 || t->S <= 0 || (t->S & 7))
+    return HARP_ERR_ARG;
+  for (int k = 0; k < 4; ++k)
+    if (!t->target[k]) return HARP_ERR_ARG;
+  const int N = t->N, S = t->S;
+  const VggWs w = vgg_ws_split(t->ws, N, S, 1);
+  float scale[5];
+  vgg_scales(net, N, S, scale);
+  if (hipMemsetAsync(w.loss, 0, sizeof(double), stream) != hipSuccess) return HARP_ERR_LAUNCH;
+  hipLaunchKernelGGL(vgg_prep_kernel, dim3((S * S + 255) / 256, N), dim3(256), 0, stream, t->rgb, (const int32_t*)nullptr, t->mask, t->rows, t->y_true, S,
+                     scale[0], w.x0, w.loss);
+  HARP_CHECK_LAUNCH();
+  int rc = vgg_forward(net, w, N, S, nullptr, t->target, t->target_by_row ? t->rows : nullptr, scale, stream);
+  if (rc != HARP_OK) return rc;
+  // backward: data gradients only.  G(relu4_3) = its tap gradient; then convolution by convolution towards the image
+  const float* g = w.g_tap[3];
+  int flip = 0;
+  for (int k = 9; k >= 1; --k) {
+    harp_conv3x3_args a = {};
+    const int s = S / kVggDiv[k];
+    a.in = g; a.filters = net->filters_t[k];
+    a.N = N; a.H = s; a.W = s; a.Cin = kVggCout[k]; a.Cout = kVggCin[k];
+    a.precision = net->precision;
+    int tap = -1;
+    for (int j = 0; j < 3; ++j)
+      if (kVggTap[j] == k - 1) tap = j;                 // the layer below is a tap layer followed by the pool: route through it
+    if (tap >= 0) {
+      a.epilogue = HARP_CONV_UNPOOL; a.out = w.g_tap[tap]; a.gate = w.act[k - 1];
+    } else {
+      a.epilogue = HARP_CONV_GATE; a.out = w.gbuf[flip]; a.gate = w.act[k - 1];
+      flip ^= 1;
+    }
+    rc = harp_conv3x3(&a, stream);
+    if (rc != HARP_OK) return rc;
+    g = a.out;
+  }
+  hipLaunchKernelGGL(vgg_grad_image_kernel, dim3((S + kCT - 1) / kCT, (S + kCT - 1) / kCT, N), dim3(256), 0, stream, g, net->w0t, t->rgb, t->y_true,
+                     t->mask, t->rows, t->covered, S, scale[0], t->weight, t->g_rgb, w.loss, t->loss);
+  HARP_CHECK_LAUNCH();
+  return HARP_OK;
+}
+
+}  // extern "C"

@@ -129,7 +129,9 @@ __device__ __forceinline__ void raster_tile(RasterSmem<MODE>& sm, unsigned vbloc
     if (MODE == 2 || sub != 0) return;
     // depth pass of a caller that keeps ONE depth map across calls (st_state, harp_rasterize_fwd_keep): a super-tile that was empty — and
     // therefore filled with -1 — the last time as well is left alone; 3/4 of the map are such super-tiles (25 MB of writes per step)
-    if (MODE == 0 && sparse && st_state && st_state[b * nst_of(nsx) + st] == 1) return;
+    // (decided once per workgroup, behind a barrier: thread 0 stores the state below, and a wave that read it after that store would leave
+    // without clearing its quarter of the super-tile)
+    if (MODE == 0 && sparse && st_state && __syncthreads_or(st_state[b * nst_of(nsx) + st] == 1)) return;
     if (MODE == 1 && sparse && l1_target && l1_bg_sums) {
       // nothing to write, and the loss of an un-rendered super-tile against a static target is a constant: one table look-up
       if (threadIdx.x == 0) {

@@ -269,7 +269,7 @@ class FitEngine:
         m = self.y_sil_col.unsqueeze(-1)
         self.bg_photo = tile_sums((bg * m - self.y_true * m).abs().sum(-1))
         if getattr(self, "perceptual", None) is not None:                            # cached target features belong to the old targets
-            self.set_perceptual(self.perceptual, self.perceptual_weight, autocast=self._vgg_autocast)
+            self.set_perceptual(self._vgg_module, self.perceptual_weight, precision=self._vgg_precision)
 
     # ------------------------------------------------------------------------------------------------
     def _ck(self, rc, what):
@@ -709,64 +709,48 @@ class FitEngine:
                                         p(s["g_colors"]) if app else None, ST()), "frame_setup_bwd")
 
     # ---- optional perceptual term (optimize_sequence.py:405, 546-547) -------------------------------
-    def set_perceptual(self, vgg, weight=1.0, cache_bytes=64 << 30, autocast=None):
+    def set_perceptual(self, vgg, weight=1.0, cache_bytes=64 << 30, precision=0):
         """Add `weight * L1(vgg(y_pred * mask), vgg(y_true * mask))` to the appearance stage.  `vgg`: harp_amd.model.vgg.Vgg16Features
-        (None removes the term).  The convolutions are torch / MIOpen library calls with autograd; they are captured into the
-        step's hipGraph together with the HIP launches (`graph_perceptual = False` falls back to eager steps).  The target features do not change during a fit: when they fit `cache_bytes` for all resident frames
-        (123 floats per pixel, 126 MB per 512x512 frame — 256 frames are 32 GB of the 288 GB) they are computed once and kept in
-        HBM, which removes one of the step's two VGG forward passes.  autocast: e.g. torch.bfloat16 to run the convolutions on the
-        bf16 MFMA path (default None = fp32 like the reference)."""
-        self.perceptual = None if vgg is None else vgg.to(self.dev).eval()
-        # the torch / MIOpen part (convolutions, autograd) is captured into the step's hipGraph like the HIP launches: the capture runs
-        # after a warm-up pass, so MIOpen's solver search is done and every tensor comes from the graph's private pool
+        (the filters; None removes the term).  The ten convolutions, their data gradients and everything between them run on the HIP
+        kernels of csrc/conv.hip (harp_vgg16_term: 21 launches, captured into the step's hipGraph like every other launch).  precision:
+        0 = float32 MFMA (a float32 fma chain, what the parity tests anchor on), 1 = three-term bf16 split with float32 accumulation
+        (~16 mantissa bits per product; the reference's own stack runs these convolutions in TF32).  The target features do not change
+        during a fit: when they fit `cache_bytes` for all resident frames (123 floats per pixel, 126 MB per 512x512 frame — 256 frames
+        are 32 GB of the 288 GB) they are computed once and kept in HBM; otherwise every step recomputes them for its B frames."""
+        from .model.vgg_hip import Vgg16Hip, tap_shapes
+        self._vgg_module = vgg
+        self._vgg_precision = int(precision)
+        self.perceptual = None if vgg is None else Vgg16Hip(vgg, self.dev, precision)
         self.graph_perceptual = True
         self.perceptual_weight = float(weight)
-        self._vgg_autocast = autocast
         self._vgg_cache = None
+        self._vgg_step_feats = None
         self._graphs = {}
         if vgg is None or self.y_true is None:
             return
         T, S = self.y_true.shape[0], self.S
-        per_frame = 4 * (S * S * 64 + (S // 2) ** 2 * 128 + (S // 4) ** 2 * 256 + (S // 8) ** 2 * 512)
+        shapes = tap_shapes(S)
+        per_frame = 4 * sum(h * w * c for h, w, c in shapes)
         if T * per_frame <= cache_bytes:
-            chunks = []
+            self._vgg_cache = [torch.empty((T,) + shp, device=self.dev) for shp in shapes]
             for t0 in range(0, T, self.B):
-                idx = torch.arange(t0, min(T, t0 + self.B), device=self.dev)
-                chunks.append(self._vgg_target_features(idx, skip_input=True))
-            self._vgg_cache = [torch.cat([c[i] for c in chunks]) for i in range(4)]
-
-    def _vgg_run(self, x, skip_input=False):
-        if self._vgg_autocast is not None:
-            with torch.autocast("cuda", dtype=self._vgg_autocast):
-                f = self.perceptual.features(x, skip_input=skip_input, weighted=False)
-            return [t.float() for t in f]
-        return self.perceptual.features(x, skip_input=skip_input, weighted=False)
-
-    def _vgg_target_features(self, idx, skip_input=False):
-        with torch.no_grad():
-            m = self.y_sil_col[idx].unsqueeze(-1)
-            return self._vgg_run((self.y_true[idx] * m).permute(0, 3, 1, 2), skip_input=skip_input)
+                rows = torch.arange(t0, min(T, t0 + self.B), device=self.dev, dtype=torch.int32)
+                self.perceptual.features(self.y_true, self.y_sil_col, rows, out=[c[t0:t0 + rows.shape[0]] for c in self._vgg_cache])
+        else:
+            self._vgg_step_feats = [torch.empty((self.B,) + shp, device=self.dev) for shp in shapes]
 
     def _perceptual_term(self, B, ltfid, lloss):
-        """torch autograd through the VGG stack for d(term)/d(y_pred); the result joins the photometric gradient the shader backward
-        consumes (that buffer is only defined at covered pixels — the fused L1 writes nothing elsewhere — hence the where)."""
+        """the term's value into slot 9 of the loss vector; its gradient joins the photometric gradient the shader backward consumes (that
+        buffer is only defined at covered pixels — the fused L1 writes nothing elsewhere — hence the `covered` argument)"""
         s = self.s
-        idx = ltfid[:B].long()
-        m = self.y_sil_col[idx].unsqueeze(-1)
-        leaf = s["rgb"][:B].detach().requires_grad_(True)
-        with torch.enable_grad():
-            fp = self._vgg_run((leaf * m).permute(0, 3, 1, 2))
-            if self._vgg_cache is not None:
-                ft = [(self.y_true[idx] * m).permute(0, 3, 1, 2).flatten(start_dim=1)] + [c[idx] for c in self._vgg_cache]
-            else:
-                ft = self._vgg_target_features(idx)
-            n = sum(f.shape[1] for f in fp) * B
-            # == L1Loss over the concatenated weighted rows: |w a - w b| = |w| |a - b|, so the layer weights scale the partial sums
-            loss = sum(abs(w) * (a - b).abs().sum() for w, a, b in zip(self.perceptual.layers_weights, fp, ft)) / n
-            (g,) = torch.autograd.grad(loss, leaf)
-        lloss[9:10].copy_(loss.detach().reshape(1))
-        covered = (s["face_c"][:B] >= 0).unsqueeze(-1)
-        s["g_rgb"][:B] = torch.where(covered, s["g_rgb"][:B] + self.perceptual_weight * g, torch.zeros((), device=self.dev))
+        rows = ltfid[:B]
+        if self._vgg_cache is not None:
+            target, by_row = self._vgg_cache, 1
+        else:
+            target, by_row = [f[:B] for f in self._vgg_step_feats], 0
+            self.perceptual.features(self.y_true, self.y_sil_col, rows, out=target)
+        self.perceptual.term(s["rgb"][:B], self.y_true, self.y_sil_col, rows, target, by_row, s["g_rgb"][:B], lloss[9:10], weight=self.perceptual_weight,
+                             covered=s["face_c"][:B])
 
     def _extra_stream(self, name):
         lane = self._lane

@@ -464,6 +464,85 @@ int harp_schedule_next(const int32_t* schedule, int n_rows, int B, int target_of
 int harp_schedule_next_rows(const int32_t* schedule, const int32_t* tschedule, int n_rows, int B, int target_offset, int32_t* counter,
                             int32_t* fid, int32_t* tfid, float* zero, int n_zero, hipStream_t stream);
 
+/* ---- perceptual term: 3x3 convolutions on the matrix cores ----------------------------------------------------------------------------
+ * replaces the torch.nn.Conv2d / ReLU / MaxPool2d stack of model/vgg.py:10-56 (torchvision vgg16.features[0:23]; built at
+ * optimize_sequence.py:405, evaluated on y_pred * mask and y_true * mask at :546-547, weight 1.0 at :419) and its autograd: F.conv2d
+ * (cuDNN in the reference), threshold_backward, max_pool2d_with_indices_backward, L1Loss.  The filters are frozen (requires_grad=False,
+ * model/vgg.py:34-36): only data gradients exist.
+ * Activations are NHWC float32.  harp_conv3x3 is one 3x3 / pad 1 / stride 1 convolution (Cin % 16 == 0, Cout % 64 == 0; pad the
+ * channels with zeros otherwise) with one of four fused epilogues:
+ *   HARP_CONV_RELU      out = relu(conv + bias); pooled (optional, H and W even) = max_pool2d(out, 2, 2); out may be NULL when pooled is not
+ *   HARP_CONV_RELU_TAP  the same, plus the tap's share of L1Loss(features(pred), features(target)): *loss (+=, double) tap_scale * sum|out - target|,
+ *                       g_tap = tap_scale * sign(out - target) * [out > 0]  (d loss / d conv, ReLU backward applied);
+ *                       target (T,H,W,Cout) row target_row[n] (NULL: row n)
+ *   HARP_CONV_GATE      data gradient through the ReLU in front of this convolution's input: out = conv * [gate > 0], gate (N,H,W,Cout)
+ *   HARP_CONV_UNPOOL    data gradient through max pool + ReLU: the convolution runs at the pooled size (H,W); out and gate are (N,2H,2W,Cout);
+ *                       out (+=) the result routed to the first maximum of each 2x2 window of gate where that maximum is positive
+ * precision 0: v_mfma_f32_32x32x2_f32 (float32 fma chain); 1: three-term bf16 split, float32 accumulate (~16 mantissa bits per product).
+ * filters: harp_conv3x3_pack_filters output for the same precision (transpose = 1 packs the data-gradient filters of a forward (Cout,Cin,3,3)
+ * weight: channels swap roles, taps are mirrored). */
+#define HARP_CONV_RELU 0
+#define HARP_CONV_RELU_TAP 1
+#define HARP_CONV_GATE 2
+#define HARP_CONV_UNPOOL 3
+typedef struct harp_conv3x3_args {
+  const float* in;            /* (N,H,W,Cin) */
+  const void* filters;        /* harp_conv3x3_filter_bytes(Cout,Cin) bytes */
+  const float* bias;          /* (Cout) or NULL */
+  float* out;
+  float* pooled;              /* (N,H/2,W/2,Cout) or NULL */
+  const float* target;
+  const int32_t* target_row;
+  float* g_tap;
+  double* loss;
+  const float* gate;
+  int N, H, W, Cin, Cout;
+  int precision, epilogue;
+  int in_channels;            /* channels per pixel of `in` in memory (multiple of 4, <= Cin; the rest reads as zero); 0 = Cin */
+  float tap_scale;
+} harp_conv3x3_args;
+size_t harp_conv3x3_filter_bytes(int Cout, int Cin);
+int harp_conv3x3_pack_filters(const float* w, int Cout, int Cin, int transpose, int precision, void* packed, hipStream_t stream);
+int harp_conv3x3(const harp_conv3x3_args* a, hipStream_t stream);
+
+/* The whole term (optimize_sequence.py:546-547): loss = L1Loss(vgg(y_pred * mask), vgg(y_true * mask)) with vgg = model/vgg.py's
+ * Vgg16Features (rows: the image itself, relu1_2, relu2_2, relu3_3, relu4_3, scaled by layers_weights, :51-55), and d loss / d y_pred.
+ * harp_vgg16: the ten convolutions in the order of torchvision vgg16.features[0:23] (0, 2, 5, 7, 10, 12, 14, 17, 19, 21): filters[k] /
+ * filters_t[k] = harp_conv3x3_pack_filters(w_k, transpose = 0 / 1) for `precision` (the first layer's 3 input channels padded to 16;
+ * filters_t[0] unused), bias[k], w0t (9,3,64) = the first layer's data-gradient filters for the vector-ALU kernel that ends the
+ * backward pass: w0t[t][c][co] = w0[co][c][8 - t] with w0 the (64,3,3,3) weight, taps flattened.
+ * ws: harp_vgg16_ws_bytes(N,S,with_gradient) bytes (S % 8 == 0), zero-filled once by the caller before the first use.
+ * harp_vgg16_features: tap activations of image[rows[n]] * mask[rows[n]] (rows NULL: n) -> f1 (N,S,S,64), f2 (N,S/2,S/2,128),
+ *   f3 (N,S/4,S/4,256), f4 (N,S/8,S/8,512), NHWC — the caller's cache of the target frames' features (they do not change during a fit).
+ * harp_vgg16_term: forward over rgb * mask[rows[n]] with the L1 against target[k] fused into the tap layers, backward to the image:
+ *   *loss = the term (unweighted);  g_rgb (N,S,S,3) = covered < 0 ? 0 : g_rgb + weight * d loss / d rgb   (covered NULL: everywhere). */
+typedef struct harp_vgg16 {
+  const void* filters[10];
+  const void* filters_t[10];
+  const float* bias[10];
+  const float* w0t;
+  float layer_w[5];
+  int precision;
+} harp_vgg16;
+typedef struct harp_vgg16_term_args {
+  const float* rgb;            /* (N,S,S,3) rendered images */
+  const float* y_true;         /* (T,S,S,3) */
+  const float* mask;           /* (T,S,S) */
+  const int32_t* rows;         /* (N,) target row of each image; NULL: n */
+  const float* target[4];      /* tap features of y_true * mask, layouts of harp_vgg16_features */
+  int target_by_row;           /* 1: target[k] holds T rows indexed through `rows`; 0: N rows in batch order */
+  const int32_t* covered;      /* (N,S,S) nearest-face ids (< 0: no face) or NULL */
+  float* g_rgb;
+  float weight;
+  float* loss;
+  int N, S;
+  void* ws;
+} harp_vgg16_term_args;
+size_t harp_vgg16_ws_bytes(int N, int S, int with_gradient);
+int harp_vgg16_features(const harp_vgg16* net, const float* image, const float* mask, const int32_t* rows, int N, int S, void* ws,
+                        float* f1, float* f2, float* f3, float* f4, hipStream_t stream);
+int harp_vgg16_term(const harp_vgg16* net, const harp_vgg16_term_args* t, hipStream_t stream);
+
 /* ---- data-parallel exchange (RCCL over xGMI) -------------------------------------------------------------------------
  * New capability: the reference is single-device.  Frames of a sequence are sharded over the GPUs of a node; between
  * `sum_loss.backward()` and `opt_coarse.step() / opt_app.step()` (optimize_sequence.py:567-573) every rank sums the flat fp32

@@ -1,0 +1,182 @@
+"""GPU: the matrix-core 3x3 convolution of the perceptual term (csrc/conv.hip through the C ABI) against torch's float64 convolution and
+its autograd on the CPU — forward with fused bias / ReLU / max pool / L1 tap, and the two data-gradient epilogues (ReLU gate, max-pool
+routing).  Both arithmetic modes: float32 MFMA (bound 5e-6 of the output scale: a float32 fma chain in another order) and the three-term bf16
+split (bound 3e-5: 2^-16 per product)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+TOL = {0: 5e-6, 1: 3e-5}
+
+
+def _nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def _nchw(x):
+    return x.permute(0, 3, 1, 2).contiguous()
+
+
+def _case(Cin, Cout, H, W, N=2, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(N, Cin, H, W, generator=g, dtype=torch.float64)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g, dtype=torch.float64) * (2.0 / (9 * Cin)) ** 0.5
+    b = torch.randn(Cout, generator=g, dtype=torch.float64) * 0.1
+    return x, w, b
+
+
+def _err(got, want):
+    return ((got.double().cpu() - want).abs().max() / want.abs().max()).item()
+
+
+SHAPES = [(16, 64, 32, 32), (64, 64, 40, 24), (64, 128, 32, 32), (128, 256, 16, 16), (256, 512, 16, 16), (512, 512, 8, 8)]
+
+
+@pytest.mark.parametrize("precision", [0, 1])
+@pytest.mark.parametrize("shape", SHAPES)
+def test_forward_relu_pool(shape, precision):
+    from harp_amd.model import conv_hip as C
+    Cin, Cout, H, W = shape
+    x, w, b = _case(*shape)
+    want = F.relu(F.conv2d(x, w, b, padding=1))
+    xd, wd, bd = _nhwc(x).float().to(DEV), w.float().to(DEV), b.float().to(DEV)
+    filt = C.pack_filters(wd, precision)
+    out = torch.full((x.shape[0], H, W, Cout), float("nan"), device=DEV)
+    pooled = torch.full((x.shape[0], H // 2, W // 2, Cout), float("nan"), device=DEV)
+    C.conv3x3(xd, filt, Cout, bias=bd, epilogue=C.RELU, precision=precision, out=out, pooled=pooled)
+    torch.cuda.synchronize()
+    assert _err(_nchw(out), want) < TOL[precision]
+    assert _err(_nchw(pooled), F.max_pool2d(want, 2, 2)) < TOL[precision]
+    # pooled only (the full-size activation is not written)
+    pooled2 = torch.empty_like(pooled)
+    C.conv3x3(xd, filt, Cout, bias=bd, epilogue=C.RELU, precision=precision, out=None, pooled=pooled2)
+    assert torch.equal(pooled2, pooled)
+
+
+@pytest.mark.parametrize("precision", [0, 1])
+def test_tap_epilogue_loss_and_gradient(precision):
+    from harp_amd.model import conv_hip as C
+    Cin, Cout, H, W = 64, 128, 32, 32
+    x, w, b = _case(Cin, Cout, H, W, N=3)
+    g = torch.Generator().manual_seed(9)
+    T = 5
+    target = torch.relu(torch.randn(T, Cout, H, W, generator=g, dtype=torch.float64))
+    rows = torch.tensor([4, 0, 2])
+    conv = F.conv2d(x, w, b, padding=1).requires_grad_(True)
+    act = F.relu(conv)
+    scale = 0.37
+    loss = scale * (act - target[rows]).abs().sum()
+    (g_conv,) = torch.autograd.grad(loss, conv)
+    xd = _nhwc(x).float().to(DEV)
+    filt = C.pack_filters(w.float().to(DEV), precision)
+    out = torch.empty(3, H, W, Cout, device=DEV)
+    pooled = torch.empty(3, H // 2, W // 2, Cout, device=DEV)
+    g_tap = torch.empty_like(out)
+    acc = torch.zeros(1, dtype=torch.float64, device=DEV)
+    C.conv3x3(xd, filt, Cout, bias=b.float().to(DEV), epilogue=C.RELU_TAP, precision=precision, out=out, pooled=pooled,
+              target=_nhwc(target).float().to(DEV), target_row=rows.int().to(DEV), tap_scale=scale, g_tap=g_tap, loss=acc)
+    torch.cuda.synchronize()
+    assert _err(_nchw(out), act.detach()) < TOL[precision]
+    assert abs(acc.item() - loss.item()) < 10 * TOL[precision] * loss.item()
+    # the sign of a feature difference at rounding level is not decided: compare where |difference| is clear of the arithmetic's error
+    diff = (act.detach() - target[rows]).abs()
+    unclear = ((diff < 1e-3) & (diff > 0)) | (conv.detach().abs() < 1e-3)
+    d = (_nchw(g_tap).double().cpu() - g_conv)[~unclear]
+    assert unclear.float().mean() < 0.01 and d.abs().max().item() < 1e-6 * scale
+
+
+@pytest.mark.parametrize("precision", [0, 1])
+@pytest.mark.parametrize("shape", [(64, 64, 40, 24), (128, 64, 32, 32), (512, 256, 16, 16)])
+def test_data_gradient_through_relu(shape, precision):
+    """d/d(conv_a) of conv_b(relu(conv_a)): g_a = conv(g_b, w_b^T mirrored) * [relu(conv_a) > 0]"""
+    from harp_amd.model import conv_hip as C
+    Cout_b, Cin_b, H, W = shape            # conv_b: Cin_b -> Cout_b; the gradient convolution runs Cout_b -> Cin_b
+    g = torch.Generator().manual_seed(3)
+    a = torch.randn(2, Cin_b, H, W, generator=g, dtype=torch.float64).requires_grad_(True)
+    w = torch.randn(Cout_b, Cin_b, 3, 3, generator=g, dtype=torch.float64) * (2.0 / (9 * Cin_b)) ** 0.5
+    g_b = torch.randn(2, Cout_b, H, W, generator=g, dtype=torch.float64)
+    act = F.relu(a)
+    (want,) = torch.autograd.grad(F.conv2d(act, w, None, padding=1), a, g_b)
+    filt = C.pack_filters(w.float().to(DEV), precision, transpose=True)
+    out = torch.full((2, H, W, Cin_b), float("nan"), device=DEV)
+    C.conv3x3(_nhwc(g_b).float().to(DEV), filt, Cin_b, epilogue=C.GATE, precision=precision, out=out, gate=_nhwc(act.detach()).float().to(DEV))
+    torch.cuda.synchronize()
+    assert _err(_nchw(out), want) < TOL[precision]
+
+
+@pytest.mark.parametrize("precision", [0, 1])
+def test_data_gradient_through_max_pool(precision):
+    """tap layer -> pool -> conv_b: the gradient arriving at the tap's convolution = its own L1 gradient + conv_b's data gradient routed
+    through max_pool2d's arg-max and the ReLU (ties between equal maxima: the first in row-major order, as torch)"""
+    from harp_amd.model import conv_hip as C
+    Cin_b, Cout_b, H, W = 64, 128, 16, 24          # pooled size; the tap activation is (2H, 2W)
+    g = torch.Generator().manual_seed(4)
+    pre = torch.randn(2, Cin_b, 2 * H, 2 * W, generator=g, dtype=torch.float64)
+    pre = (pre * 2).round() / 2                      # many exact ties and many zeros: the routing rules are exercised
+    pre.requires_grad_(True)
+    w = torch.randn(Cout_b, Cin_b, 3, 3, generator=g, dtype=torch.float64) * (2.0 / (9 * Cin_b)) ** 0.5
+    g_b = torch.randn(2, Cout_b, H, W, generator=g, dtype=torch.float64)
+    g_own = torch.randn(2, Cin_b, 2 * H, 2 * W, generator=g, dtype=torch.float64)
+    act = F.relu(pre)
+    (want,) = torch.autograd.grad(F.conv2d(F.max_pool2d(act, 2, 2), w, None, padding=1), pre, g_b)
+    want = want + g_own
+    filt = C.pack_filters(w.float().to(DEV), precision, transpose=True)
+    out = _nhwc(g_own).float().to(DEV)
+    C.conv3x3(_nhwc(g_b).float().to(DEV), filt, Cin_b, epilogue=C.UNPOOL, precision=precision, out=out, gate=_nhwc(act.detach()).float().to(DEV))
+    torch.cuda.synchronize()
+    assert _err(_nchw(out), want) < TOL[precision]
+
+
+def test_bad_arguments_are_refused():
+    from harp_amd import _lib
+    from harp_amd.model import conv_hip as C
+    x = torch.zeros(1, 8, 8, 24, device=DEV)         # 24 input channels: not a multiple of 16
+    f = torch.zeros(_lib.lib().harp_conv3x3_filter_bytes(64, 24), dtype=torch.uint8, device=DEV)
+    with pytest.raises(RuntimeError, match="harp_conv3x3"):
+        C.conv3x3(x, f, 64, out=torch.zeros(1, 8, 8, 64, device=DEV))
+
+
+@pytest.mark.parametrize("precision", [0, 1])
+def test_whole_term_against_torch_autograd(precision):
+    """harp_vgg16_features / harp_vgg16_term against the torch module (harp_amd/model/vgg.py == reference model/vgg.py) in float64 on the
+    CPU: tap features, the term's value and d term / d rgb, with cached (all target frames, indexed by row) and per-step target features"""
+    from harp_amd.model.vgg import Vgg16Features
+    from harp_amd.model.vgg_hip import Vgg16Hip
+    S, N, T = 64, 2, 3
+    LW = [1, 1 / 16, 1 / 8, 1 / 4, 1]
+    vgg = Vgg16Features(layers_weights=LW, weights="random", seed=1)
+    g = torch.Generator().manual_seed(11)
+    rgb = torch.rand(N, S, S, 3, generator=g, dtype=torch.float64).requires_grad_(True)
+    y_true = torch.rand(T, S, S, 3, generator=g, dtype=torch.float64)
+    mask = (torch.rand(T, S, S, generator=g, dtype=torch.float64) > 0.3).double()
+    mask[:, ::7] *= 0.5                                              # (fractional values: eroded / resized masks)
+    rows = torch.tensor([2, 0])
+    vgg64 = Vgg16Features(layers_weights=LW, weights=vgg.state_dict()).double()
+    m = mask[rows].unsqueeze(-1)
+    fp = vgg64((rgb * m).permute(0, 3, 1, 2))
+    ft = vgg64((y_true[rows] * m).permute(0, 3, 1, 2))
+    want = F.l1_loss(fp, ft)
+    (g_want,) = torch.autograd.grad(want, rgb)
+
+    hip = Vgg16Hip(vgg, DEV, precision)
+    rgb_d, yt_d, mask_d, rows_d = (t.detach().float().to(DEV).contiguous() for t in (rgb, y_true, mask, rows))
+    rows_d = rows.int().to(DEV)
+    feats = hip.features(yt_d, mask_d)                               # all T frames: the cache
+    ref_feats = vgg64.features((y_true * mask.unsqueeze(-1)).permute(0, 3, 1, 2), skip_input=True, weighted=False)
+    for f, r, shp in zip(feats, ref_feats, ((64, S, S), (128, S // 2, S // 2), (256, S // 4, S // 4), (512, S // 8, S // 8))):
+        assert _err(_nchw(f), r.detach().reshape(T, *shp)) < 4 * TOL[precision]
+    covered = torch.randint(-1, 5, (N, S, S), generator=g).int()
+    g0 = torch.randn(N, S, S, 3, generator=g)
+    expect = torch.where((covered >= 0).unsqueeze(-1), g0.double() + 0.7 * g_want, torch.zeros((), dtype=torch.float64))
+    for by_row in (1, 0):
+        target = feats if by_row else hip.features(yt_d, mask_d, rows_d)
+        g_rgb = g0.to(DEV).contiguous()
+        loss = torch.zeros(1, device=DEV)
+        hip.term(rgb_d, yt_d, mask_d, rows_d, target, by_row, g_rgb, loss, weight=0.7, covered=covered.to(DEV))
+        torch.cuda.synchronize()
+        assert abs(loss.item() - want.item()) < 2e-5 * want.item(), (loss.item(), want.item())
+        rel = ((g_rgb.double().cpu() - expect).norm() / expect.norm()).item()
+        print(f"[whole VGG term, precision {precision}, cached={by_row}] loss {loss.item():.6f} vs {want.item():.6f}, gradient rel-L2 {rel:.1e}")
+        assert rel < (2e-3, 4e-3)[precision], rel

@@ -1,5 +1,5 @@
 """Cost of the optional perceptual term at the bench configuration (B=32, 512^2): ms/step of the full stage with the term off /
-on (fp32, cached target features) / on (fp32, uncached) / on (bf16 autocast, cached).  Random filters (timing only)."""
+on (float32 MFMA, cached target features) / on (float32, uncached) / on (bf16 split, cached / uncached).  Random filters (timing only)."""
 import sys, time
 import torch
 sys.path.insert(0, ".")
@@ -23,11 +23,8 @@ eng, _ = bench.build_engine(0, 1, torch.device("cuda:0"), T=T)
 eng.set_schedule(torch.arange(T).reshape(-1, eng.B))
 print("term off            %8.2f ms/step" % time_steps(eng, 20), flush=True)
 vgg = Vgg16Features(layers_weights=[1, 1 / 16, 1 / 8, 1 / 4, 1], weights="random")
-CL = len(sys.argv) > 2 and sys.argv[2] == "cl"
-if CL:
-    vgg = vgg.to(memory_format=torch.channels_last)
-for name, kw in (("fp32 cached", dict()), ("fp32 uncached", dict(cache_bytes=0)), ("bf16 cached", dict(autocast=torch.bfloat16)),
-                 ("bf16 uncached", dict(autocast=torch.bfloat16, cache_bytes=0))):
+for name, kw in (("f32 cached", dict()), ("f32 uncached", dict(cache_bytes=0)), ("bf16x3 cached", dict(precision=1)),
+                 ("bf16x3 uncached", dict(precision=1, cache_bytes=0))):
     t0 = time.perf_counter()
     eng.set_perceptual(vgg, **kw)
     torch.cuda.synchronize()
