@@ -40,6 +40,16 @@ constexpr int kWF4 = 9 * 4 * kCN;         // filter slab of one (64 output chann
 constexpr int kLdsBytes = (kInF4 + kWF4) * 16;
 constexpr int kUnits = (kPatch * kPatch * 4 + 255) / 256;   // 16-byte staging units per thread (6; the last one is mostly idle)
 
+// experiment switches (tools/dev/build_variant.sh): CONV_PIPE 0 = the compiler's own placement of the fragment reads, 1 = reads of step s + 1
+// issued before the MFMAs of step s, pinned by sched_barrier, 2 = the same without the pins.  Measured on one box, 256 -> 256 channels at
+// 128^2 x 8 images (profiles/r05_conv_variants.txt): float32 94.5 / 93.9 / 93.3 TFLOP/s, bf16 split 203 / 196 / 202 — the explicit pipeline
+// buys nothing; neither does removing the staging or the global fetch altogether (94.6 / 207): the loop is bound by MFMA issue.
+#ifndef CONV_PIPE
+#define CONV_PIPE 0
+#endif
+#ifndef CONV_WAVES
+#define CONV_WAVES 2                      // waves per SIMD the register budget is sized for (2 workgroups per CU)
+#endif
 enum { EPI_RELU = 0, EPI_RELU_TAP = 1, EPI_GATE = 2, EPI_UNPOOL = 3 };
 
 __device__ __forceinline__ float sgn(float d) { return (float)((d > 0.f) - (d < 0.f)); }
@@ -77,7 +87,7 @@ __global__ void pack_filters_kernel(const float* __restrict__ w, int Cout_src, i
 
 // ---- the convolution ----------------------------------------------------------------------------------------------------------------
 template <int PREC, int EPI>
-__global__ __launch_bounds__(256, 2) void conv3x3_kernel(const harp_conv3x3_args a, const int tiles_x, const int tiles_y) {
+__global__ __launch_bounds__(256, CONV_WAVES) void conv3x3_kernel(const harp_conv3x3_args a, const int tiles_x, const int tiles_y) {
   extern __shared__ float4 smem[];          // ONE LDS object (a second one makes hipcc drain vmcnt before every ds_read, cdna_hip_programming.md §5)
   float4* s_in = smem;
   float4* s_w = smem + kInF4;
@@ -179,12 +189,21 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const harp_conv3x3_args
         f[6] = s_w[(tap * 4 + 2 + half) * kCN + m]; f[7] = s_w[(tap * 4 + 2 + half) * kCN + 32 + m];                  // B lo
       }
     };
+#if CONV_PIPE
     read_frags(fr[0], 0);
+#endif
 #pragma unroll
     for (int step = 0; step < kSteps; ++step) {
+#if CONV_PIPE
       float4* f = fr[step & 1];
       if (step + 1 < kSteps) read_frags(fr[(step + 1) & 1], step + 1);
+#else
+      float4* f = fr[0];
+      read_frags(f, step);
+#endif
+#if CONV_PIPE == 1
       __builtin_amdgcn_sched_barrier(0);
+#endif
       if (PREC == 0) {
         const float a0[4] = {f[0].x, f[0].y, f[0].z, f[0].w}, a1[4] = {f[1].x, f[1].y, f[1].z, f[1].w};
         const float b0[4] = {f[2].x, f[2].y, f[2].z, f[2].w}, b1[4] = {f[3].x, f[3].y, f[3].z, f[3].w};
@@ -214,7 +233,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const harp_conv3x3_args
         acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah1, Bh0, acc[1][0], 0, 0, 0);
         acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah1, Bh1, acc[1][1], 0, 0, 0);
       }
+#if CONV_PIPE == 1
       __builtin_amdgcn_sched_barrier(0);
+#endif
     }
   }
 
@@ -300,7 +321,13 @@ int launch_conv(const harp_conv3x3_args& a, hipStream_t stream) {
   const int tiles_x = (a.W + kCT - 1) / kCT, tiles_y = (a.H + kCT - 1) / kCT;
   const size_t blocks = (size_t)tiles_x * tiles_y * a.N * (a.Cout / kCN);
   if (blocks == 0 || blocks > 0x7fffffffu) return HARP_ERR_ARG;
+#ifdef CONV_LDS_PAD
+  static bool padded = (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes + CONV_LDS_PAD), true);
+  (void)padded;
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), kLdsBytes + CONV_LDS_PAD, stream, a, tiles_x, tiles_y);
+#else
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), kLdsBytes, stream, a, tiles_x, tiles_y);
+#endif
   HARP_CHECK_LAUNCH();
   return HARP_OK;
 }

@@ -244,6 +244,34 @@ class FitEngine:
                     loss_vec=torch.zeros(16, dtype=torch.float32, device=dev), w_vec=torch.zeros(16, dtype=torch.float32, device=dev),
                     stream=None, side=None)
 
+    # `consume_gzl` / `keep_depth` carry invariants ACROSS steps (g_zl is all-zero between steps because its consumer clears it; zl_state
+    # says which super-tiles of the kept light depth map are all -1).  A step with the switch off breaks the invariant (g_zl stays dirty, the
+    # plain rasteriser fills super-tiles the state calls empty), so a flip re-establishes it before the next step.
+    def _get_consume_gzl(self):
+        return self._consume_gzl
+
+    def _set_consume_gzl(self, v):
+        if getattr(self, "_consume_gzl", bool(v)) != bool(v):
+            self._shadow_state_stale = True
+        self._consume_gzl = bool(v)
+
+    def _get_keep_depth(self):
+        return self._keep_depth
+
+    def _set_keep_depth(self, v):
+        if getattr(self, "_keep_depth", bool(v)) != bool(v):
+            self._shadow_state_stale = True
+        self._keep_depth = bool(v)
+
+    consume_gzl = property(_get_consume_gzl, _set_consume_gzl)
+    keep_depth = property(_get_keep_depth, _set_keep_depth)
+
+    def _reset_shadow_state(self):
+        for lane in (self._main,):
+            for k in ("g_zl", "zl_tiles", "zl_state"):
+                lane["s"][k].zero_()
+        self._shadow_state_stale = False
+
     def _activate(self, lane):
         """point the step code at one lane's buffers (host-side bookkeeping only)"""
         self.s, self.gs_zero, self.gs_mesh, self.gs_zero_late, self._lane = lane["s"], lane["gs_zero"], lane["gs_mesh"], lane["gs_zero_late"], lane
@@ -381,6 +409,8 @@ class FitEngine:
         in self.g_buf, loss terms in loss_vec[:9] (unweighted, order LOSS_NAMES).  shared_terms=False skips everything that does not
         depend on the frames (gradient-arena zeroing, offset draw, normal-map normalisation, displacement / texture regularisers)."""
         lane = self._lane
+        if getattr(self, "_shadow_state_stale", False) and not torch.cuda.is_current_stream_capturing():
+            self._reset_shadow_state()
         B = lane["B"] if B is None else int(B)
         lfid, ltfid, lloss = lane["fid"], lane["tfid"], lane["loss_vec"]
         # sched: take the next row of the device schedule INSIDE this step's launches (step() passes it when _can_fold()): hand_front fetches

@@ -7,7 +7,8 @@ import torch
 
 def load_obj_uvs(path):
     """(verts_uvs (Nt,2) float32, faces_uvs (F,3) int64) of a triangulated OBJ: the `vt` lines and the second index of every `f` corner
-    — what pytorch3d.io.load_obj returns as properties.verts_uvs and faces.textures_idx"""
+    — what pytorch3d.io.load_obj returns as properties.verts_uvs and faces.textures_idx.  Like load_obj: negative (relative) indices
+    count back from the `vt` lines read so far, and a face whose corners carry no texture index ('f v' / 'f v//vn') gets -1."""
     vt, ft = [], []
     with open(path) as f:
         for line in f:
@@ -19,8 +20,20 @@ def load_obj_uvs(path):
             elif p[0] == "f":
                 if len(p) != 4:
                     raise ValueError(f"{path}: only triangulated OBJ templates are supported")
-                ft.append([int(q.split("/")[1]) - 1 for q in p[1:4]])
-    return torch.tensor(np.asarray(vt, np.float32)), torch.tensor(np.asarray(ft, np.int64))
+                row = []
+                for q in p[1:4]:
+                    parts = q.split("/")
+                    if len(parts) < 2 or parts[1] == "":
+                        row.append(-1)
+                        continue
+                    i = int(parts[1])
+                    if i == 0 or i > len(vt) or -i > len(vt):
+                        raise ValueError(f"{path}: texture index {i} out of range in {line.strip()!r}")
+                    row.append(i - 1 if i > 0 else len(vt) + i)
+                if -1 in row:
+                    row = [-1, -1, -1]
+                ft.append(row)
+    return torch.tensor(np.asarray(vt, np.float32).reshape(-1, 2)), torch.tensor(np.asarray(ft, np.int64).reshape(-1, 3))
 
 
 def load_hand_model(config_dict):

@@ -1218,6 +1218,13 @@ def test_schedule_switches_give_the_default_schedules_result(switches):
     finally:
         for k, v in defaults.items():
             setattr(eng, k, v)
+    # ... and the way BACK: the switched-off steps broke the cross-step invariants of consume_gzl / keep_depth (g_zl left dirty, light-view
+    # super-tiles filled behind zl_state's back); flipping the switch re-establishes them, so the default schedule gives its result again
+    for graph in (False, True):
+        g, l = run(graph)
+        assert rel(g, ref[graph][0]) < 1e-5, ("back to the defaults", switches, graph, rel(g, ref[graph][0]))
+        assert ((l - ref[graph][1]).abs() <= 1e-5 * ref[graph][1].abs() + 1e-9).all(), ("back to the defaults", switches, graph)
+    assert eng.s["g_zl"].abs().max().item() == 0.0
 
 
 def test_folded_step_bookkeeping_equals_the_separate_kernels():
