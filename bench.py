@@ -325,13 +325,14 @@ def perceptual_rate(device, weights, steps=6, warmup=2):
     fwd = sum(2.0 * 9 * ci * co * h * h for ci, co, h in _VGG_CONVS) * B_PER_GPU
     flop = 2.0 * fwd                                   # forward + backward-data (the filters are frozen: no weight gradients)
     vgg = Vgg16Features(layers_weights=[1, 1 / 16, 1 / 8, 1 / 4, 1], weights=weights)
-    res = {"frames_per_step": B_PER_GPU, "steps": steps, "conv_tflop_per_step": flop / 1e12,
+    res = {"frames_per_step": B_PER_GPU, "steps": steps, "conv_tflop_per_step_full_images": flop / 1e12,
            "filters": "random (seeded)" if weights == "random" else os.path.basename(str(weights))}
-    for name, prec, peak, mult in (("f32_mfma", 0, 157.3e12, 1.0), ("bf16x3_split", 1, 2.5e15, 3.0)):
+    for name, prec, peak, mult, bounded in (("f32_mfma", 0, 157.3e12, 1.0, True), ("bf16x3_split", 1, 2.5e15, 3.0, True),
+                                            ("f32_mfma_full_images", 0, 157.3e12, 1.0, False)):
         e = build_engine(0, 1, device, T=B_PER_GPU, img=S, B=B_PER_GPU)[0]
         e.keep_image = False
         t0 = time.perf_counter()
-        e.set_perceptual(vgg, precision=prec)
+        e.set_perceptual(vgg, precision=prec, bounded=bounded)
         torch.cuda.synchronize()
         t_set = time.perf_counter() - t0
         e.set_schedule(torch.arange(B_PER_GPU).reshape(1, -1).to(torch.int32))
@@ -343,9 +344,16 @@ def perceptual_rate(device, weights, steps=6, warmup=2):
             e.step(None, True, True)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / steps
+        # bounded mode: the stack runs in the 16x16 tiles the mask's support reaches (harp_amd/model/vgg_hip.active_tiles): executed flop =
+        # per-level flop x the level's share of active tiles over the batch's frames
+        done, tiles = flop, None
+        if e._vgg_bound is not None:
+            tiles = [float(b[2].float().sum()) / (b[0].shape[0] * b[0].shape[1]) for b in e._vgg_bound]
+            done = 2.0 * B_PER_GPU * sum(2.0 * 9 * ci * co * h * h * tiles[{512: 0, 256: 1, 128: 2, 64: 3}[h * 512 // S]] for ci, co, h in _VGG_CONVS)
         res[name] = {"frames_per_s": B_PER_GPU / dt, "ms_per_step": dt * 1e3, "in_hipgraph": bool(e._graphs),
-                     "conv_tflops": flop / dt / 1e12, "roofline": {"bound": "mfma", "achieved": mult * flop / dt / 1e12, "peak": peak / 1e12,
-                                                                    "unit": "TFLOP/s", "frac": mult * flop / dt / peak},
+                     "active_tile_share_per_level": tiles, "conv_tflop_executed": done / 1e12,
+                     "roofline": {"bound": "mfma", "achieved": mult * done / dt / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s",
+                                  "frac": mult * done / dt / peak},
                      "set_up_s(filter packing + target features)": t_set, "vgg_loss": e.losses().get("vgg")}
         del e
         torch.cuda.empty_cache()

@@ -203,7 +203,9 @@ SIGNATURES["harp_hand_back_bwd"] = (_i, [ctypes.POINTER(HandFront), _vp, _vp, _v
 class Conv3x3Args(ctypes.Structure):
     """mirror of `harp_conv3x3_args` (include/harp_hip.h)"""
     _fields_ = ([(n, _vp) for n in ("in_", "filters", "bias", "out", "pooled", "target", "target_row", "g_tap", "loss", "gate")] +
-                [(n, _i) for n in ("N", "H", "W", "Cin", "Cout", "precision", "epilogue", "in_channels")] + [("tap_scale", _f)])
+                [(n, _i) for n in ("N", "H", "W", "Cin", "Cout", "precision", "epilogue", "in_channels")] + [("tap_scale", _f)] +
+                [("tile_list", _vp), ("tile_count", _vp), ("max_tiles", _i), ("in_valid_shift", _i), ("in_valid", _vp), ("in_alt", _vp),
+                 ("out_valid", _vp)])
 
 
 SIGNATURES.update({
@@ -221,11 +223,12 @@ class Vgg16(ctypes.Structure):
 class Vgg16TermArgs(ctypes.Structure):
     """mirror of `harp_vgg16_term_args` (include/harp_hip.h)"""
     _fields_ = [("rgb", _vp), ("y_true", _vp), ("mask", _vp), ("rows", _vp), ("target", _vp * 4), ("target_by_row", _i), ("covered", _vp),
-                ("g_rgb", _vp), ("weight", _f), ("loss", _vp), ("N", _i), ("S", _i), ("ws", _vp)]
+                ("g_rgb", _vp), ("weight", _f), ("loss", _vp), ("N", _i), ("S", _i), ("ws", _vp), ("target_in", _vp * 10), ("tiles", _vp * 4),
+                ("tile_list", _vp * 4), ("tile_count", _vp * 4), ("max_tiles", _i * 4)]
 
 
 SIGNATURES.update({
     "harp_vgg16_ws_bytes": (_sz, [_i, _i, _i]),
-    "harp_vgg16_features": (_i, [ctypes.POINTER(Vgg16), _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "harp_vgg16_features": (_i, [ctypes.POINTER(Vgg16), _vp, _vp, _vp, _i, _i, _vp, ctypes.POINTER(_vp), _vp]),
     "harp_vgg16_term": (_i, [ctypes.POINTER(Vgg16), ctypes.POINTER(Vgg16TermArgs), _vp]),
 })

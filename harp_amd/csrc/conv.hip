@@ -47,6 +47,9 @@ constexpr int kUnits = (kPatch * kPatch * 4 + 255) / 256;   // 16-byte staging u
 #ifndef CONV_PIPE
 #define CONV_PIPE 0
 #endif
+#ifndef CONV_PRIO
+#define CONV_PRIO 0
+#endif
 #ifndef CONV_WAVES
 #define CONV_WAVES 2                      // waves per SIMD the register budget is sized for (2 workgroups per CU)
 #endif
@@ -96,17 +99,47 @@ __global__ __launch_bounds__(256, CONV_WAVES) void conv3x3_kernel(const harp_con
   const int ncb = a.Cout / kCN, nchunk = a.Cin / kCK;
   int id = blockIdx.x;
   const int cb = id % ncb; id /= ncb;
-  const int tx = id % tiles_x; id /= tiles_x;
-  const int ty = id % tiles_y;
-  const int n = id / tiles_y;
+  int tx, ty, n;
+  if (a.tile_list) {
+    // bounded mode: slot i of image n's frame; frames hold different numbers of tiles, the grid is sized for the largest
+    const int i = id % a.max_tiles;
+    n = id / a.max_tiles;
+    const int r = a.target_row ? a.target_row[n] : n;
+    if (i >= a.tile_count[r]) return;
+    const int tile = a.tile_list[(size_t)r * a.max_tiles + i];
+    ty = tile / tiles_x; tx = tile - ty * tiles_x;
+  } else {
+    tx = id % tiles_x; id /= tiles_x;
+    ty = id % tiles_y;
+    n = id / tiles_y;
+  }
+  const size_t row = a.target_row ? (size_t)a.target_row[n] : (size_t)n;
   const int x0 = tx * kCT, y0 = ty * kCT;
   const int H = a.H, W = a.W;
   const int Cin = a.in_channels > 0 ? a.in_channels : a.Cin;     // channels per pixel in memory (the rest of a.Cin reads as zero)
   const float* __restrict__ in_n = a.in + (size_t)n * H * W * Cin;
+  const float* __restrict__ alt_n = a.in_alt ? a.in_alt + row * H * W * Cin : nullptr;
   const float4* __restrict__ wslab = (const float4*)a.filters + (size_t)cb * nchunk * kWF4;
+
+  // bounded mode: which cells (8 << shift input pixels square) under the patch hold values of THIS pass; the patch spans at most 4 x 4 cells.
+  // Wave-uniform: 16 scalar loads, one bit each.
+  unsigned cellmask = 0xffffu;
+  const int csh = 3 + a.in_valid_shift;
+  const int cy0 = max(y0 - 1, 0) >> csh, cx0 = max(x0 - 1, 0) >> csh;
+  if (a.in_valid) {
+    const int pitch = (W + (1 << csh) - 1) >> csh, rows_c = (H + (1 << csh) - 1) >> csh;
+    const int32_t* __restrict__ v = a.in_valid + row * pitch * rows_c;
+    cellmask = 0;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      const int cy = cy0 + (c >> 2), cx = cx0 + (c & 3);
+      if (cy < rows_c && cx < pitch && v[cy * pitch + cx]) cellmask |= 1u << c;
+    }
+  }
 
   // staging units of this thread: unit u = (patch pixel u >> 2, channel quad u & 3): four consecutive lanes fetch one pixel's 64 bytes
   int goff[kUnits], lidx[kUnits];
+  unsigned use_alt = 0;                    // bit j: unit j lies in a cell this pass did not write -> read in_alt (or zero)
 #pragma unroll
   for (int j = 0; j < kUnits; ++j) {
     const int u = j * 256 + t, pix = u >> 2, q = u & 3;
@@ -116,7 +149,14 @@ __global__ __launch_bounds__(256, CONV_WAVES) void conv3x3_kernel(const harp_con
       const int gy = y0 + py - 1, gx = x0 + px - 1;
       if (PREC == 0) lidx[j] = q * kPlane + py * kRow + px;                       // float4 index
       else lidx[j] = (((q >> 1) * kPlane + py * kRow + px) << 1) | (q & 1);      // 8-byte index of the hi half; lo is 2 planes further
-      if (gy >= 0 && gy < H && gx >= 0 && gx < W) goff[j] = (gy * W + gx) * Cin + 4 * q;
+      if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+        goff[j] = (gy * W + gx) * Cin + 4 * q;
+        const int c = (((gy >> csh) - cy0) << 2) | ((gx >> csh) - cx0);
+        if (!((cellmask >> c) & 1u)) {
+          if (alt_n) use_alt |= 1u << j;
+          else goff[j] = -1;
+        }
+      }
     }
   }
   float4 rin[kUnits], rw[9];
@@ -125,7 +165,8 @@ __global__ __launch_bounds__(256, CONV_WAVES) void conv3x3_kernel(const harp_con
 #pragma unroll
     for (int j = 0; j < kUnits; ++j) {
       const bool ok = goff[j] >= 0 && cc * kCK + 4 * ((j * 256 + t) & 3) < Cin;
-      const float4 v = *(const float4*)(in_n + (ok ? goff[j] + cc * kCK : 0));
+      const float* __restrict__ src = ((use_alt >> j) & 1u) ? alt_n : in_n;
+      const float4 v = *(const float4*)(src + (ok ? goff[j] + cc * kCK : 0));
       rin[j] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
@@ -163,6 +204,11 @@ __global__ __launch_bounds__(256, CONV_WAVES) void conv3x3_kernel(const harp_con
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+#if CONV_PRIO == 1
+  // the two waves that share a SIMD (one of each resident workgroup) get different static priorities, by the parity of their hardware wave
+  // slot: with equal priorities the matrix pipe serves them alternately, so both run out of fragments and wait for the LDS at the same time
+  if (__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 1) __builtin_amdgcn_s_setprio(1);
+#endif
   fetch(0);
   for (int cc = 0; cc < nchunk; ++cc) {
     __syncthreads();                      // every wave is done with the previous chunk's patch and slab
@@ -176,6 +222,10 @@ __global__ __launch_bounds__(256, CONV_WAVES) void conv3x3_kernel(const harp_con
     constexpr int kFrag = PREC == 0 ? 4 : 8;
     float4 fr[2][kFrag];
     auto read_frags = [&](float4* f, int step) {
+#ifdef CONV_LINEAR_LDS      // timing experiment only (wrong results): every fragment read lane-linear, as in tools/dev/micro/mfma_rate.hip
+      for (int i = 0; i < kFrag; ++i) f[i] = smem[((step * kFrag + i) * 64 + lane) & 2047];
+      return;
+#endif
       if (PREC == 0) {
         const int tap = step >> 1, g = step & 1;
         const int plane = 2 * g + half, toff = (tap / 3) * kRow + (tap % 3);
@@ -192,7 +242,11 @@ __global__ __launch_bounds__(256, CONV_WAVES) void conv3x3_kernel(const harp_con
 #if CONV_PIPE
     read_frags(fr[0], 0);
 #endif
+#ifdef CONV_ROLL
+#pragma unroll CONV_ROLL
+#else
 #pragma unroll
+#endif
     for (int step = 0; step < kSteps; ++step) {
 #if CONV_PIPE
       float4* f = fr[step & 1];
@@ -203,6 +257,9 @@ __global__ __launch_bounds__(256, CONV_WAVES) void conv3x3_kernel(const harp_con
 #endif
 #if CONV_PIPE == 1
       __builtin_amdgcn_sched_barrier(0);
+#endif
+#if CONV_PRIO == 2
+      __builtin_amdgcn_s_setprio(1);
 #endif
       if (PREC == 0) {
         const float a0[4] = {f[0].x, f[0].y, f[0].z, f[0].w}, a1[4] = {f[1].x, f[1].y, f[1].z, f[1].w};
@@ -233,6 +290,9 @@ __global__ __launch_bounds__(256, CONV_WAVES) void conv3x3_kernel(const harp_con
         acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah1, Bh0, acc[1][0], 0, 0, 0);
         acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah1, Bh1, acc[1][1], 0, 0, 0);
       }
+#if CONV_PRIO == 2
+      __builtin_amdgcn_s_setprio(0);
+#endif
 #if CONV_PIPE == 1
       __builtin_amdgcn_sched_barrier(0);
 #endif
@@ -258,7 +318,6 @@ __global__ __launch_bounds__(256, CONV_WAVES) void conv3x3_kernel(const harp_con
           float v[4];
 #pragma unroll
           for (int c = 0; c < 4; ++c) v[c] = fmaxf(acc[i][j][4 * q + c] + bias, 0.f);
-          const size_t row = (EPI == EPI_RELU_TAP && a.target_row) ? (size_t)a.target_row[n] : (size_t)n;
 #pragma unroll
           for (int c = 0; c < 4; ++c) {
             const int yy = gy + (c >> 1), xx = gx + (c & 1);
@@ -297,6 +356,8 @@ __global__ __launch_bounds__(256, CONV_WAVES) void conv3x3_kernel(const harp_con
             if (g01 > best) { best = g01; ob = o00 + dx; }
             if (g10 > best) { best = g10; ob = o00 + dy; }
             if (g11 > best) { best = g11; ob = o00 + dy + dx; }
+            // (bounded mode: windows in output tiles this pass does not own are left alone — nothing downstream reads them)
+            if (a.out_valid && !a.out_valid[row * (((2 * W + 15) >> 4) * ((2 * H + 15) >> 4)) + (yy >> 3) * ((2 * W + 15) >> 4) + (xx >> 3)]) continue;
             if (best > 0.f) a.out[ob] += acc[i][j][4 * q + c];
           }
         }
@@ -319,7 +380,7 @@ int launch_conv(const harp_conv3x3_args& a, hipStream_t stream) {
     ready = true;
   }
   const int tiles_x = (a.W + kCT - 1) / kCT, tiles_y = (a.H + kCT - 1) / kCT;
-  const size_t blocks = (size_t)tiles_x * tiles_y * a.N * (a.Cout / kCN);
+  const size_t blocks = (a.tile_list ? (size_t)a.max_tiles : (size_t)tiles_x * tiles_y) * a.N * (a.Cout / kCN);
   if (blocks == 0 || blocks > 0x7fffffffu) return HARP_ERR_ARG;
 #ifdef CONV_LDS_PAD
   static bool padded = (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes + CONV_LDS_PAD), true);
@@ -382,20 +443,25 @@ __global__ __launch_bounds__(256) void vgg_grad_image_kernel(const float* __rest
                                                              const float* __restrict__ y_true, const float* __restrict__ mask,
                                                              const int32_t* __restrict__ rows, const int32_t* __restrict__ covered, int S, float scale0,
                                                              float weight, float* __restrict__ g_rgb, const double* __restrict__ loss_acc,
-                                                             float* __restrict__ loss_out) {
+                                                             float* __restrict__ loss_out, const int32_t* __restrict__ tiles) {
   __shared__ float4 patch[4 * kPatch * kGRow];
   const int t = threadIdx.x, tx = t & 15, ty = t >> 4;
   const int n = blockIdx.z, x0 = blockIdx.x * kCT, y0 = blockIdx.y * kCT;
   if (loss_out && t == 0 && blockIdx.x == 0 && blockIdx.y == 0 && n == 0) loss_out[0] = (float)loss_acc[0];
   const float* __restrict__ Gn = G + (size_t)n * S * S * 64;
+  // bounded mode: G exists in the frame's active 16x16 tiles only (zero elsewhere); a tile that is not active has no gradient from the stack
+  const int ntx = (S + kCT - 1) / kCT;
+  const int32_t* __restrict__ act = tiles ? tiles + (size_t)(rows ? rows[n] : n) * ntx * ntx : nullptr;
+  const bool active = !act || act[blockIdx.y * ntx + blockIdx.x];
   float o0 = 0.f, o1 = 0.f, o2 = 0.f;
-  for (int cc = 0; cc < 4; ++cc) {
+  for (int cc = 0; cc < (active ? 4 : 0); ++cc) {
     __syncthreads();
     for (int u = t; u < kPatch * kPatch * 4; u += 256) {
       const int pix = u >> 2, q = u & 3, py = pix / kPatch, px = pix - py * kPatch;
       const int gy = y0 + py - 1, gx = x0 + px - 1;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (gy >= 0 && gy < S && gx >= 0 && gx < S) v = *(const float4*)(Gn + ((size_t)gy * S + gx) * 64 + cc * 16 + 4 * q);
+      if (gy >= 0 && gy < S && gx >= 0 && gx < S && (!act || act[(gy >> 4) * ntx + (gx >> 4)]))
+        v = *(const float4*)(Gn + ((size_t)gy * S + gx) * 64 + cc * 16 + 4 * q);
       patch[(q * kPatch + py) * kGRow + px] = v;
     }
     __syncthreads();
@@ -465,31 +531,54 @@ inline VggWs vgg_ws_split(void* ws, int N, int S, int with_gradient) {
   return w;
 }
 
-// forward pass of the stack over x0; tap layers write to tap_out[k] (or their workspace slot) and, with target != NULL, take the L1 epilogue
-int vgg_forward(const harp_vgg16* net, const VggWs& w, int N, int S, float* const tap_out[4], const float* const target[4],
-                const int32_t* target_row, const float scale[5], hipStream_t stream) {
+// bounded mode of the term (harp_vgg16_term_args.tiles[0] != NULL): per resolution level L = 0..3 (image side S >> L) the 16x16 tiles of
+// every target frame in which the rendered image's activations can differ from the target frame's (the mask's support grown by the
+// receptive field).  Outside them pred == target exactly, the L1 and its gradient vanish, and a convolution that needs an input pixel
+// from there reads the TARGET frame's cached activation (forward) or zero (backward).
+struct VggBound {
+  const int32_t* tiles[4]; const int32_t* list[4]; const int32_t* count[4]; int max_tiles[4];
+  const float* target_in[10];
+  const int32_t* rows;
+};
+inline int vgg_level(int k) { return kVggDiv[k] == 1 ? 0 : kVggDiv[k] == 2 ? 1 : kVggDiv[k] == 4 ? 2 : 3; }
+
+// forward pass of the stack over x0; out[k] (k < 10: convolution k's activation, 10..12: the three pooled maps) or the workspace slot;
+// with target != NULL the tap layers take the L1 epilogue
+int vgg_forward(const harp_vgg16* net, const VggWs& w, int N, int S, float* const* out, const float* const target[4],
+                const int32_t* target_row, const float scale[5], const VggBound* bd, hipStream_t stream) {
   const float* in = (const float*)w.x0;
   int tap = 0;
   for (int k = 0; k < 10; ++k) {
     harp_conv3x3_args a = {};
     const bool is_tap = (tap < 4 && k == kVggTap[tap]);
-    const int s = S / kVggDiv[k];
+    const int s = S / kVggDiv[k], lv = vgg_level(k);
     a.in = in; a.filters = net->filters[k]; a.bias = net->bias[k];
     a.N = N; a.H = s; a.W = s; a.Cin = (kVggCin[k] + kCK - 1) / kCK * kCK; a.Cout = kVggCout[k];
     a.in_channels = k == 0 ? 4 : 0;
     a.precision = net->precision;
-    a.out = (is_tap && tap_out && tap_out[tap]) ? tap_out[tap] : w.act[k];
+    a.out = (out && out[k]) ? out[k] : w.act[k];
     a.epilogue = HARP_CONV_RELU;
+    float* pooled = nullptr;
     if (is_tap) {
-      if (tap < 3) a.pooled = w.pool[tap];
+      if (tap < 3) pooled = a.pooled = (out && out[10 + tap]) ? out[10 + tap] : w.pool[tap];
       if (target) {
         a.epilogue = HARP_CONV_RELU_TAP;
-        a.target = target[tap]; a.target_row = target_row; a.tap_scale = scale[tap + 1]; a.g_tap = w.g_tap[tap]; a.loss = w.loss;
+        a.target = target[tap]; a.tap_scale = scale[tap + 1]; a.g_tap = w.g_tap[tap]; a.loss = w.loss;
+      }
+    }
+    a.target_row = target_row;
+    if (bd) {
+      a.target_row = bd->rows;
+      a.tile_list = bd->list[lv]; a.tile_count = bd->count[lv]; a.max_tiles = bd->max_tiles[lv];
+      if (k > 0) {                                  // (x0 is written everywhere)
+        const bool behind_pool = (k == 2 || k == 4 || k == 7);
+        a.in_valid = bd->tiles[behind_pool ? lv - 1 : lv]; a.in_valid_shift = behind_pool ? 0 : 1;
+        a.in_alt = bd->target_in[k];
       }
     }
     const int rc = harp_conv3x3(&a, stream);
     if (rc != HARP_OK) return rc;
-    in = (is_tap && tap < 3) ? w.pool[tap] : a.out;
+    in = pooled ? pooled : a.out;
     if (is_tap) ++tap;
   }
   return HARP_OK;
@@ -544,6 +633,8 @@ int harp_conv3x3(const harp_conv3x3_args* a, hipStream_t stream) {
     default: return HARP_ERR_ARG;
   }
   if (a->pooled && ((a->H | a->W) & 1)) return HARP_ERR_ARG;
+  if (a->tile_list && (!a->tile_count || a->max_tiles <= 0)) return HARP_ERR_ARG;
+  if (a->in_valid_shift < 0 || a->in_valid_shift > 1) return HARP_ERR_ARG;
   if (a->precision == 0) return launch_conv_prec<0>(*a, stream);
   if (a->precision == 1) return launch_conv_prec<1>(*a, stream);
   return HARP_ERR_ARG;
@@ -554,15 +645,16 @@ size_t harp_vgg16_ws_bytes(int N, int S, int with_gradient) {
   return vgg_ws_split(nullptr, N, S, with_gradient).bytes;
 }
 
-int harp_vgg16_features(const harp_vgg16* net, const float* image, const float* mask, const int32_t* rows, int N, int S, void* ws, float* f1,
-                        float* f2, float* f3, float* f4, hipStream_t stream) {
-  if (!vgg_net_ok(net, false) || !image || !mask || !ws || N <= 0 || S <= 0 || (S & 7) || !f1 || !f2 || !f3 || !f4) return HARP_ERR_ARG;
+int harp_vgg16_features(const harp_vgg16* net, const float* image, const float* mask, const int32_t* rows, int N, int S, void* ws,
+                        float* const* out, hipStream_t stream) {
+  if (!vgg_net_ok(net, false) || !image || !mask || !ws || N <= 0 || S <= 0 || (S & 7) || !out) return HARP_ERR_ARG;
+  for (int k = 0; k < 4; ++k)
+    if (!out[kVggTap[k]]) return HARP_ERR_ARG;
   const VggWs w = vgg_ws_split(ws, N, S, 0);
   hipLaunchKernelGGL(vgg_prep_kernel, dim3((S * S + 255) / 256, N), dim3(256), 0, stream, image, rows, mask, rows, (const float*)nullptr, S, 0.f, w.x0,
                      w.loss);
   HARP_CHECK_LAUNCH();
-  float* const taps[4] = {f1, f2, f3, f4};
-  return vgg_forward(net, w, N, S, taps, nullptr, nullptr, nullptr, stream);
+  return vgg_forward(net, w, N, S, out, nullptr, nullptr, nullptr, nullptr, stream);
 }
 
 int harp_vgg16_term(const harp_vgg16* net, const harp_vgg16_term_args* t, hipStream_t stream) {
@@ -578,14 +670,28 @@ int harp_vgg16_term(const harp_vgg16* net, const harp_vgg16_term_args* t, hipStr
   hipLaunchKernelGGL(vgg_prep_kernel, dim3((S * S + 255) / 256, N), dim3(256), 0, stream, t->rgb, (const int32_t*)nullptr, t->mask, t->rows, t->y_true, S,
                      scale[0], w.x0, w.loss);
   HARP_CHECK_LAUNCH();
-  int rc = vgg_forward(net, w, N, S, nullptr, t->target, t->target_by_row ? t->rows : nullptr, scale, stream);
+  VggBound bd = {};
+  const bool bounded = t->tiles[0] != nullptr;
+  if (bounded) {
+    if (!t->target_by_row || !t->rows) return HARP_ERR_ARG;
+    for (int l = 0; l < 4; ++l) {
+      if (!t->tiles[l] || !t->tile_list[l] || !t->tile_count[l] || t->max_tiles[l] <= 0) return HARP_ERR_ARG;
+      bd.tiles[l] = t->tiles[l]; bd.list[l] = t->tile_list[l]; bd.count[l] = t->tile_count[l]; bd.max_tiles[l] = t->max_tiles[l];
+    }
+    for (int k = 1; k < 10; ++k) {
+      if (!t->target_in[k]) return HARP_ERR_ARG;
+      bd.target_in[k] = t->target_in[k];
+    }
+    bd.rows = t->rows;
+  }
+  int rc = vgg_forward(net, w, N, S, nullptr, t->target, t->target_by_row ? t->rows : nullptr, scale, bounded ? &bd : nullptr, stream);
   if (rc != HARP_OK) return rc;
   // backward: data gradients only.  G(relu4_3) = its tap gradient; then convolution by convolution towards the image
   const float* g = w.g_tap[3];
   int flip = 0;
   for (int k = 9; k >= 1; --k) {
     harp_conv3x3_args a = {};
-    const int s = S / kVggDiv[k];
+    const int s = S / kVggDiv[k], lv = vgg_level(k);
     a.in = g; a.filters = net->filters_t[k];
     a.N = N; a.H = s; a.W = s; a.Cin = kVggCout[k]; a.Cout = kVggCin[k];
     a.precision = net->precision;
@@ -598,12 +704,19 @@ int harp_vgg16_term(const harp_vgg16* net, const harp_vgg16_term_args* t, hipStr
       a.epilogue = HARP_CONV_GATE; a.out = w.gbuf[flip]; a.gate = w.act[k - 1];
       flip ^= 1;
     }
+    if (bounded) {       // the gradient lives in the level's active tiles and is zero elsewhere
+      a.target_row = bd.rows;
+      a.tile_list = bd.list[lv]; a.tile_count = bd.count[lv]; a.max_tiles = bd.max_tiles[lv];
+      a.in_valid = bd.tiles[lv]; a.in_valid_shift = 1;
+      if (tap >= 0) a.out_valid = bd.tiles[lv - 1];
+    }
     rc = harp_conv3x3(&a, stream);
     if (rc != HARP_OK) return rc;
     g = a.out;
   }
   hipLaunchKernelGGL(vgg_grad_image_kernel, dim3((S + kCT - 1) / kCT, (S + kCT - 1) / kCT, N), dim3(256), 0, stream, g, net->w0t, t->rgb, t->y_true,
-                     t->mask, t->rows, t->covered, S, scale[0], t->weight, t->g_rgb, w.loss, t->loss);
+                     t->mask, t->rows, t->covered, S, scale[0], t->weight, t->g_rgb, w.loss, t->loss,
+                     bounded ? bd.tiles[0] : (const int32_t*)nullptr);
   HARP_CHECK_LAUNCH();
   return HARP_OK;
 }

@@ -297,7 +297,7 @@ class FitEngine:
         m = self.y_sil_col.unsqueeze(-1)
         self.bg_photo = tile_sums((bg * m - self.y_true * m).abs().sum(-1))
         if getattr(self, "perceptual", None) is not None:                            # cached target features belong to the old targets
-            self.set_perceptual(self._vgg_module, self.perceptual_weight, precision=self._vgg_precision)
+            self.set_perceptual(self._vgg_module, self.perceptual_weight, precision=self._vgg_precision, bounded=self._vgg_bounded)
 
     # ------------------------------------------------------------------------------------------------
     def _ck(self, rc, what):
@@ -739,35 +739,47 @@ class FitEngine:
                                         p(s["g_colors"]) if app else None, ST()), "frame_setup_bwd")
 
     # ---- optional perceptual term (optimize_sequence.py:405, 546-547) -------------------------------
-    def set_perceptual(self, vgg, weight=1.0, cache_bytes=64 << 30, precision=0):
+    def set_perceptual(self, vgg, weight=1.0, cache_bytes=128 << 30, precision=0, bounded=True):
         """Add `weight * L1(vgg(y_pred * mask), vgg(y_true * mask))` to the appearance stage.  `vgg`: harp_amd.model.vgg.Vgg16Features
         (the filters; None removes the term).  The ten convolutions, their data gradients and everything between them run on the HIP
         kernels of csrc/conv.hip (harp_vgg16_term: 21 launches, captured into the step's hipGraph like every other launch).  precision:
         0 = float32 MFMA (a float32 fma chain, what the parity tests anchor on), 1 = three-term bf16 split with float32 accumulation
-        (~16 mantissa bits per product; the reference's own stack runs these convolutions in TF32).  The target features do not change
-        during a fit: when they fit `cache_bytes` for all resident frames (123 floats per pixel, 126 MB per 512x512 frame — 256 frames
-        are 32 GB of the 288 GB) they are computed once and kept in HBM; otherwise every step recomputes them for its B frames."""
-        from .model.vgg_hip import Vgg16Hip, tap_shapes
+        (~16 mantissa bits per product; the reference's own stack runs these convolutions in TF32).
+        The target frames' features do not change during a fit; what is kept in HBM depends on `cache_bytes`:
+          * ALL 13 activation maps of every resident frame (300 floats per pixel, 307 MB per 512x512 frame — 256 frames are 79 GB of the
+            288 GB) -> `bounded` mode: y_pred * mask and y_true * mask are identical outside the mask's support, so the stack runs only in
+            the 16x16 tiles the support reaches through the receptive field and reads the cached target activations next to them
+            (same loss and gradient; csrc/conv.hip, model/vgg_hip.active_tiles);
+          * else the four tap maps (126 MB per frame): one full forward + backward over the B rendered images per step;
+          * else nothing: every step also recomputes the target features of its B frames."""
+        from .model.vgg_hip import Vgg16Hip, activation_shapes, active_tiles, tap_shapes
         self._vgg_module = vgg
         self._vgg_precision = int(precision)
+        self._vgg_bounded = bool(bounded)
         self.perceptual = None if vgg is None else Vgg16Hip(vgg, self.dev, precision)
         self.graph_perceptual = True
         self.perceptual_weight = float(weight)
         self._vgg_cache = None
+        self._vgg_bound = None
         self._vgg_step_feats = None
         self._graphs = {}
         if vgg is None or self.y_true is None:
             return
         T, S = self.y_true.shape[0], self.S
-        shapes = tap_shapes(S)
-        per_frame = 4 * sum(h * w * c for h, w, c in shapes)
-        if T * per_frame <= cache_bytes:
-            self._vgg_cache = [torch.empty((T,) + shp, device=self.dev) for shp in shapes]
-            for t0 in range(0, T, self.B):
-                rows = torch.arange(t0, min(T, t0 + self.B), device=self.dev, dtype=torch.int32)
-                self.perceptual.features(self.y_true, self.y_sil_col, rows, out=[c[t0:t0 + rows.shape[0]] for c in self._vgg_cache])
+        full = 4 * sum(h * w * c for h, w, c in activation_shapes(S))
+        taps = 4 * sum(h * w * c for h, w, c in tap_shapes(S))
+        if bounded and T * full <= cache_bytes:
+            shapes, all_slots = activation_shapes(S), True
+            self._vgg_bound = active_tiles(self.y_sil_col)
+        elif T * taps <= cache_bytes:
+            shapes, all_slots = tap_shapes(S), False
         else:
-            self._vgg_step_feats = [torch.empty((self.B,) + shp, device=self.dev) for shp in shapes]
+            self._vgg_step_feats = [torch.empty((self.B,) + shp, device=self.dev) for shp in tap_shapes(S)]
+            return
+        self._vgg_cache = [torch.empty((T,) + shp, device=self.dev) for shp in shapes]
+        for t0 in range(0, T, self.B):
+            rows = torch.arange(t0, min(T, t0 + self.B), device=self.dev, dtype=torch.int32)
+            self.perceptual.features(self.y_true, self.y_sil_col, rows, out=[c[t0:t0 + rows.shape[0]] for c in self._vgg_cache], all_slots=all_slots)
 
     def _perceptual_term(self, B, ltfid, lloss):
         """the term's value into slot 9 of the loss vector; its gradient joins the photometric gradient the shader backward consumes (that
@@ -780,7 +792,7 @@ class FitEngine:
             target, by_row = [f[:B] for f in self._vgg_step_feats], 0
             self.perceptual.features(self.y_true, self.y_sil_col, rows, out=target)
         self.perceptual.term(s["rgb"][:B], self.y_true, self.y_sil_col, rows, target, by_row, s["g_rgb"][:B], lloss[9:10], weight=self.perceptual_weight,
-                             covered=s["face_c"][:B])
+                             covered=s["face_c"][:B], bound=self._vgg_bound)
 
     def _extra_stream(self, name):
         lane = self._lane

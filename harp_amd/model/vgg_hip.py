@@ -19,6 +19,40 @@ def tap_shapes(S):
     return [(S, S, 64), (S // 2, S // 2, 128), (S // 4, S // 4, 256), (S // 8, S // 8, 512)]
 
 
+_DIV = (1, 1, 2, 2, 4, 4, 4, 8, 8, 8)
+_COUT = (64, 64, 128, 128, 256, 256, 256, 512, 512, 512)
+TAPS = (1, 3, 6, 9)                           # slots of relu1_2, relu2_2, relu3_3, relu4_3 in the 13-slot activation list
+# slot of the activation convolution k reads (k = 1..9): relu(conv k-1), or the pooled map behind a tap layer (slots 10..12)
+INPUT_SLOT = {1: 0, 2: 10, 3: 2, 4: 11, 5: 4, 6: 5, 7: 12, 8: 7, 9: 8}
+
+
+def activation_shapes(S):
+    """(H, W, C) of the 13 activation slots of harp_vgg16_features: relu(conv 0..9), then the three pooled maps"""
+    return [(S // d, S // d, c) for d, c in zip(_DIV, _COUT)] + [(S // 2, S // 2, 64), (S // 4, S // 4, 128), (S // 8, S // 8, 256)]
+
+
+def active_tiles(mask):
+    """The 16x16 tiles of each resolution level (side S >> L, L = 0..3) in which activations of image * mask can differ between two images
+    sharing `mask` (T,S,S): the support of the mask grown by the receptive field of the level's last convolution — two 3x3 convolutions at
+    levels 0 and 1, three at levels 2 and 3, a 2x2 max pool between levels (model/vgg.py:26-33).  Returns per level: tiles (T, nt*nt) int32
+    0/1, tile_list (T, max) int32, tile_count (T) int32, max."""
+    F = torch.nn.functional
+    d = (mask > 0).float()[:, None]
+    out = []
+    for level, grow in enumerate((2, 2, 3, 3)):
+        if level:
+            d = F.max_pool2d(d, 2, 2)
+        d = F.max_pool2d(d, 2 * grow + 1, 1, grow)
+        t = F.max_pool2d(d, 16, 16, ceil_mode=True)[:, 0] > 0          # (T, nt, nt)
+        T, nt = t.shape[0], t.shape[1]
+        flat = t.reshape(T, nt * nt)
+        count = flat.sum(1).int()
+        mx = max(int(count.max()), 1)
+        order = torch.argsort((~flat).int(), dim=1, stable=True)[:, :mx].int()      # active tiles first, in raster order
+        out.append((flat.int().contiguous(), order.contiguous(), count.contiguous(), mx))
+    return out
+
+
 class Vgg16Hip:
     def __init__(self, module, device, precision=conv_hip.F32):
         self.dev = torch.device(device)
@@ -54,29 +88,47 @@ class Vgg16Hip:
             self._ws[key] = torch.zeros(n, dtype=torch.uint8, device=self.dev)
         return self._ws[key]
 
-    def features(self, image, mask, rows=None, N=None, out=None):
-        """tap activations of image[rows] * mask[rows] (image (T,S,S,3), mask (T,S,S); rows int32 (N,) or None = the first N): list of
-        four NHWC tensors (written into `out` when given)"""
+    def features(self, image, mask, rows=None, N=None, out=None, all_slots=False):
+        """activations of image[rows] * mask[rows] (image (T,S,S,3), mask (T,S,S); rows int32 (N,) or None = the first N), NHWC.
+        Default: the list of the four taps (written into `out` when given).  all_slots: `out` / the result is the 13-slot list of
+        activation_shapes() (None entries are not kept)."""
         S = image.shape[1]
         N = int(rows.shape[0]) if rows is not None else (image.shape[0] if N is None else N)
-        if out is None:
-            out = [torch.empty((N,) + s, device=self.dev) for s in tap_shapes(S)]
+        if all_slots:
+            if out is None:
+                out = [torch.empty((N,) + s, device=self.dev) for s in activation_shapes(S)]
+            slots = list(out)
+        else:
+            if out is None:
+                out = [torch.empty((N,) + s, device=self.dev) for s in tap_shapes(S)]
+            slots = [None] * 13
+            for k, o in zip(TAPS, out):
+                slots[k] = o
+        arr = (ctypes.c_void_p * 13)(*[_lib.ptr(o) for o in slots])
         ws = self.workspace(N, S, False)
-        rc = _lib.lib().harp_vgg16_features(ctypes.byref(self.net), _lib.ptr(image), _lib.ptr(mask), _lib.ptr(rows), N, S, _lib.ptr(ws),
-                                            *[_lib.ptr(o) for o in out], _lib.stream())
+        rc = _lib.lib().harp_vgg16_features(ctypes.byref(self.net), _lib.ptr(image), _lib.ptr(mask), _lib.ptr(rows), N, S, _lib.ptr(ws), arr,
+                                            _lib.stream())
         _lib.check(rc, "harp_vgg16_features")
         return out
 
-    def term(self, rgb, y_true, mask, rows, target, target_by_row, g_rgb, loss, weight=1.0, covered=None):
-        """enqueue the whole term: *loss (a float32 HIP scalar / 1-element view) = the term, g_rgb updated in place (include/harp_hip.h)"""
+    def term(self, rgb, y_true, mask, rows, target, target_by_row, g_rgb, loss, weight=1.0, covered=None, bound=None):
+        """enqueue the whole term: *loss (a float32 HIP scalar / 1-element view) = the term, g_rgb updated in place (include/harp_hip.h).
+        target: the four tap tensors, or — with bound = active_tiles(mask) — the 13-slot cache of ALL activations of the target frames
+        (bounded mode: the stack runs only where the rendered image can differ from its target frame)"""
         N, S = rgb.shape[0], rgb.shape[1]
         t = _lib.Vgg16TermArgs()
         t.rgb, t.y_true, t.mask, t.rows = _lib.ptr(rgb), _lib.ptr(y_true), _lib.ptr(mask), _lib.ptr(rows)
+        taps = [target[k] for k in TAPS] if len(target) == 13 else list(target)
         for k in range(4):
-            t.target[k] = _lib.ptr(target[k])
+            t.target[k] = _lib.ptr(taps[k])
+        if bound is not None:
+            for k, slot in INPUT_SLOT.items():
+                t.target_in[k] = _lib.ptr(target[slot])
+            for lv, (tiles, order, count, mx) in enumerate(bound):
+                t.tiles[lv], t.tile_list[lv], t.tile_count[lv], t.max_tiles[lv] = _lib.ptr(tiles), _lib.ptr(order), _lib.ptr(count), mx
         t.target_by_row, t.covered, t.g_rgb, t.weight, t.loss = int(target_by_row), _lib.ptr(covered), _lib.ptr(g_rgb), float(weight), _lib.ptr(loss)
         t.N, t.S, t.ws = N, S, _lib.ptr(self.workspace(N, S, True))
         _lib.check(_lib.lib().harp_vgg16_term(ctypes.byref(self.net), ctypes.byref(t), _lib.stream()), "harp_vgg16_term")
 
 
-__all__ = ["Vgg16Hip", "tap_shapes", "feature_length"]
+__all__ = ["Vgg16Hip", "tap_shapes", "activation_shapes", "active_tiles", "feature_length"]

@@ -500,6 +500,16 @@ typedef struct harp_conv3x3_args {
   int precision, epilogue;
   int in_channels;            /* channels per pixel of `in` in memory (multiple of 4, <= Cin; the rest reads as zero); 0 = Cin */
   float tap_scale;
+  /* bounded mode (all NULL / 0 = every tile): image n belongs to frame row r = target_row[n]; only the 16x16 output tiles of that frame's
+   * list are computed, and input pixels in cells this pass did not write are taken from in_alt (the same activation of another pass,
+   * e.g. the target frame's, rows through target_row) or read as zero */
+  const int32_t* tile_list;   /* (T, max_tiles): ty * ceil(W/16) + tx */
+  const int32_t* tile_count;  /* (T) */
+  int max_tiles;
+  int in_valid_shift;         /* cells of in_valid are (8 << shift) input pixels square: 1 = the producer's 16x16 tiles, 0 = tiles of a 2x finer producer behind a pool */
+  const int32_t* in_valid;    /* (T, ceil(H/cell) * ceil(W/cell)) 0/1 */
+  const float* in_alt;        /* (T,H,W,in_channels) or NULL: zero */
+  const int32_t* out_valid;   /* HARP_CONV_UNPOOL: (T, ceil(2H/16) * ceil(2W/16)) 0/1 over the 16x16 tiles of `out`; windows elsewhere are skipped */
 } harp_conv3x3_args;
 size_t harp_conv3x3_filter_bytes(int Cout, int Cin);
 int harp_conv3x3_pack_filters(const float* w, int Cout, int Cin, int transpose, int precision, void* packed, hipStream_t stream);
@@ -512,8 +522,17 @@ int harp_conv3x3(const harp_conv3x3_args* a, hipStream_t stream);
  * filters_t[0] unused), bias[k], w0t (9,3,64) = the first layer's data-gradient filters for the vector-ALU kernel that ends the
  * backward pass: w0t[t][c][co] = w0[co][c][8 - t] with w0 the (64,3,3,3) weight, taps flattened.
  * ws: harp_vgg16_ws_bytes(N,S,with_gradient) bytes (S % 8 == 0), zero-filled once by the caller before the first use.
- * harp_vgg16_features: tap activations of image[rows[n]] * mask[rows[n]] (rows NULL: n) -> f1 (N,S,S,64), f2 (N,S/2,S/2,128),
- *   f3 (N,S/4,S/4,256), f4 (N,S/8,S/8,512), NHWC — the caller's cache of the target frames' features (they do not change during a fit).
+ * harp_vgg16_features: activations of image[rows[n]] * mask[rows[n]] (rows NULL: n), NHWC, into the caller's arrays — its cache of the
+ *   target frames' features (they do not change during a fit): out[k], k = 0..9 = relu(convolution k) (N, S/d_k, S/d_k, Cout_k) with
+ *   d = 1,1,2,2,4,4,4,8,8,8; out[10..12] = the three pooled maps (N,S/2,S/2,64), (N,S/4,S/4,128), (N,S/8,S/8,256).  The four taps
+ *   out[1], out[3], out[6], out[9] (relu1_2 ... relu4_3) are required, the others may be NULL (kept in ws only).
+ * Bounded mode of harp_vgg16_term (tiles[0] != NULL; needs target_by_row and the cache of ALL activations): the stack runs only in the
+ *   16x16 tiles of each resolution level (L = 0..3, side S >> L) where the rendered image's activations can differ from the target
+ *   frame's — tiles[L] (T, ceil(S_L/16)^2) 0/1 per frame, tile_list[L] (T, max_tiles[L]) their indices, tile_count[L] (T): the support
+ *   of mask grown by the receptive field (the caller's set-up, harp_amd/model/vgg_hip.py).  Elsewhere pred == target exactly: the L1
+ *   and its gradient vanish, and inputs needed from there are read from target_in[k] = the target frame's input activation of
+ *   convolution k (k = 1..9: out[0], out[10], out[2], out[11], out[4], out[5], out[12], out[7], out[8] of harp_vgg16_features).  Same
+ *   loss and gradient as the full pass, bit for bit in the tiles it computes.
  * harp_vgg16_term: forward over rgb * mask[rows[n]] with the L1 against target[k] fused into the tap layers, backward to the image:
  *   *loss = the term (unweighted);  g_rgb (N,S,S,3) = covered < 0 ? 0 : g_rgb + weight * d loss / d rgb   (covered NULL: everywhere). */
 typedef struct harp_vgg16 {
@@ -537,10 +556,15 @@ typedef struct harp_vgg16_term_args {
   float* loss;
   int N, S;
   void* ws;
+  const float* target_in[10];
+  const int32_t* tiles[4];
+  const int32_t* tile_list[4];
+  const int32_t* tile_count[4];
+  int max_tiles[4];
 } harp_vgg16_term_args;
 size_t harp_vgg16_ws_bytes(int N, int S, int with_gradient);
 int harp_vgg16_features(const harp_vgg16* net, const float* image, const float* mask, const int32_t* rows, int N, int S, void* ws,
-                        float* f1, float* f2, float* f3, float* f4, hipStream_t stream);
+                        float* const* out, hipStream_t stream);
 int harp_vgg16_term(const harp_vgg16* net, const harp_vgg16_term_args* t, hipStream_t stream);
 
 /* ---- data-parallel exchange (RCCL over xGMI) -------------------------------------------------------------------------

@@ -23,12 +23,15 @@ eng, _ = bench.build_engine(0, 1, torch.device("cuda:0"), T=T)
 eng.set_schedule(torch.arange(T).reshape(-1, eng.B))
 print("term off            %8.2f ms/step" % time_steps(eng, 20), flush=True)
 vgg = Vgg16Features(layers_weights=[1, 1 / 16, 1 / 8, 1 / 4, 1], weights="random")
-for name, kw in (("f32 cached", dict()), ("f32 uncached", dict(cache_bytes=0)), ("bf16x3 cached", dict(precision=1)),
-                 ("bf16x3 uncached", dict(precision=1, cache_bytes=0))):
+for name, kw in (("f32 bounded", dict()), ("f32 full, taps cached", dict(bounded=False)), ("f32 uncached", dict(cache_bytes=0)),
+                 ("bf16x3 bounded", dict(precision=1)), ("bf16x3 full, taps cached", dict(precision=1, bounded=False))):
     t0 = time.perf_counter()
     eng.set_perceptual(vgg, **kw)
     torch.cuda.synchronize()
     t_set = time.perf_counter() - t0
     ms = time_steps(eng)
-    print("%-19s %8.2f ms/step  (set_perceptual %.2f s, peak mem %.1f GB, vgg loss %.5f)" %
+    if eng._vgg_bound is not None:
+        frac = [float(b[2].float().sum()) / (b[0].shape[0] * b[0].shape[1]) for b in eng._vgg_bound]
+        name += " (tiles %s)" % "/".join("%.2f" % f for f in frac)
+    print("%-26s %8.2f ms/step  (set_perceptual %.2f s, peak mem %.1f GB, vgg loss %.5f)" %
           (name, ms, t_set, torch.cuda.max_memory_allocated() / 2**30, eng.losses()["vgg"]), flush=True)
