@@ -38,7 +38,7 @@ def scene_f64(sc, targets):
     return model, {k: v.double() for k, v in targets.items()}
 
 
-# Fraction of the covered pixels the ambiguous-pixel mask removed, per test case, as MEASURED on MI355X (round 3; every caller prints
+# Fraction of the covered pixels the ambiguous-pixel mask removed, per test case, as MEASURED on MI355X (rounds 3 and 5; every caller prints
 # its value).  A case fails when its fraction exceeds 1.5 x the recorded one: the mask may not quietly grow to hide kernel errors.
 # Every masked comparison has an UNMASKED companion with a looser gradient bound (tests/test_gpu_baseline.py), so what the mask
 # removes is bounded, not ignored.
@@ -46,12 +46,12 @@ AMBIGUOUS_FRACTION = {
     "api_loop_body_128": 0.0535,
     "app_only_hand_256_b2": 0.0618,
     "c2_hand_128_b18": 0.0436,
-    "c2_hand_512_b18": 0.0600,          # placeholder until measured (round 5): same mesh / size as the two neighbours
+    "c2_hand_512_b18": 0.0466,
     "c2c3_hand_512_b2": 0.0602,
     "c3_hand_512_b32": 0.0515,
     "c5_arm_1024_b1": 0.0262,
     "c5_arm_1024_b32": 0.0311,
-    "c5_arm_1024_b8": 0.0311,           # placeholder until measured (round 5)
+    "c5_arm_1024_b8": 0.0266,
     "parity_arm_128": 0.0245,
     "parity_empty_supertiles_256": 0.0421,
     "parity_full_step_128": 0.0841,
