@@ -257,6 +257,40 @@ def profiled_traffic():
             shutil.rmtree(d, ignore_errors=True)
 
 
+# measured VALU issue rate of a wave64 instruction with >= 2 waves per SIMD (profiles/r04_valu_issue_micro.txt): 2.5 cycles
+VALU_ISSUE_CYCLES = 2.5
+SIMDS, CLOCK_HZ = 1024, 2.4e9
+ATOMIC_RATE = 330e9        # memory-side float atomics per second, consecutive addresses (tools/dev/micro/glb_atomics)
+
+
+def profiled_issue():
+    """VALU wave-instructions per launch of every kernel from one PMC pass over this command (SQ_INSTS_VALU; counters only with
+    --kernel-trace, 3 eager steps): the counter's rows of one dispatch (one per shader-engine slice) are summed, the last launches of every
+    kernel averaged -> {kernel name: wave-instructions per launch}, or None."""
+    import shutil
+    import sqlite3
+    import tempfile
+    tail = ["--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-extras", "--no-roofline", "--no-graph"]
+    d = tempfile.mkdtemp(prefix="harp_pmc_valu_", dir="/tmp")
+    try:
+        db = _child(tail, ["--kernel-trace", "--pmc", "SQ_INSTS_VALU"], d)
+        if db is None:
+            return None
+        cur = sqlite3.connect(db).cursor()
+        cols = [r[1] for r in cur.execute("pragma table_info(pmc_events)")]
+        name = [c for c in cols if c in ("name", "kernel_name")][0]
+        val = "value" if "value" in cols else "counter_value"
+        per = {}
+        for n, disp, v in cur.execute(f"select {name}, dispatch_id, sum({val}) from pmc_events group by {name}, dispatch_id order by dispatch_id"):
+            per.setdefault(n, []).append(float(v))
+        return {n: float(np.mean(v[-3:])) for n, v in per.items()}
+    except Exception as e:                                       # noqa: BLE001
+        print(f"[bench] SQ_INSTS_VALU pass unusable: {type(e).__name__}: {e}", file=sys.stderr)
+        return None
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
 def _graph_rate(e, steps, warmup, coarse=True, app=True):
     """frames/s of graph-replayed scheduled steps of engine `e` (single GPU, outside the timed region of the headline)"""
     B, T = e.B, e.T
@@ -707,6 +741,23 @@ def main():
             if tjson.get(k):
                 e["frac_of_measured_traffic"] = tjson[k] / (timing[k] * 1e-3) / 1e9 / HBM_PEAK_GBS
             per_kernel[k] = e
+        # the roof that binds: none of these kernels is near the HBM roof (traffic <= the algorithmic bytes at 5 - 12 % of peak).  issue_frac =
+        # VALU wave-instructions per launch (SQ_INSTS_VALU, one PMC child) x the measured 2.5 cycles per instruction / (1024 SIMDs x 2.4 GHz x
+        # the kernel's duration): the share of the chip's vector issue slots the launch fills; atomic_frac (shader backward) = its ~17 M
+        # memory-side float atomics (11.8 M texel + 4 M vertex + 2.3 M shadow-window, per B = 32 launch) at the measured 330 G / s
+        valu = None if (args.no_profile or child or prof is None) else profiled_issue()
+        if valu:
+            for k, subs in _GROUP_KERNELS.items():
+                main = subs[0]                                    # the group's big kernel (set-up kernels are small and shared by both views)
+                hit = [v for n, v in valu.items() if main in n]
+                if hit and k in per_kernel:
+                    wi = max(hit)
+                    per_kernel[k]["valu_wave_instructions"] = wi
+                    per_kernel[k]["issue_frac"] = wi * VALU_ISSUE_CYCLES / (SIMDS * CLOCK_HZ * timing[k] * 1e-3)
+        if "harp_shade_bwd" in per_kernel:
+            n_at = 17.0e6 * eng.B / 32.0
+            per_kernel["harp_shade_bwd"]["memory_atomics_model"] = n_at
+            per_kernel["harp_shade_bwd"]["atomic_frac"] = n_at / ATOMIC_RATE / (timing["harp_shade_bwd"] * 1e-3)
         step_s = dt / args.steps
         step_bytes = a_frame * eng.B + a_step
         # loss-only mode writes no y_pred and reads no gradient image back: 2 * S^2 * 12 B per frame less than §8(d)'s A_frame
@@ -719,7 +770,11 @@ def main():
                            "kernel_ms": timing, "per_kernel": per_kernel, "step_algorithmic_bytes": step_bytes,
                            "step_frac_of_hbm_roofline": step_bytes / step_s / 1e9 / HBM_PEAK_GBS,
                            "step_algorithmic_bytes_loss_only_mode": step_bytes_lean,
-                           "step_frac_of_hbm_roofline_loss_only_bytes": step_bytes_lean / step_s / 1e9 / HBM_PEAK_GBS}
+                           "step_frac_of_hbm_roofline_loss_only_bytes": step_bytes_lean / step_s / 1e9 / HBM_PEAK_GBS,
+                           "issue_frac": per_kernel[dom].get("issue_frac"), "atomic_frac": per_kernel[dom].get("atomic_frac"),
+                           "binding_roof": ("not HBM: the kernel moves <= its algorithmic bytes at `frac` of the HBM peak; `issue_frac` of the chip's VALU issue "
+                                            "slots (2.5 cycles per wave64 instruction, measured) and `atomic_frac` of the memory-side atomic rate are filled "
+                                            "— the remainder is latency between tile-round barriers / LDS-table phases at 4 waves per SIMD (DESIGN.md 6)")}
         if prof:
             short = lambda n: n.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
             out["roofline"]["kernels_in_graph_us"] = {short(n): round(a, 2) for n, (a, c) in sorted(prof.items(), key=lambda kv: -kv[1][0] * kv[1][1])
@@ -733,6 +788,13 @@ def main():
         out["roofline"]["step_frac_of_hbm_roofline_keep_image"] = step_bytes / (ki["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS
         if not args.no_extras:
             out["extras"] = extra_rates(eng, device, vgg_weights=None if args.vgg_weights == "none" else args.vgg_weights)
+            # capture-to-capture spread of the headline step (hipGraph re-draws its stream assignment at every capture: 2 - 3 %): 5 fresh
+            # captures x 200 replays; gains below this band are not gains
+            caps = []
+            for _ in range(5):
+                eng._graphs = {}
+                caps.append(_graph_rate(eng, 200, 10)["ms_per_step"])
+            out["extras"]["headline_step_ms_over_5_captures"] = {"min": min(caps), "median": float(np.median(caps)), "max": max(caps), "replays_each": 200}
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
     if rank == 0:
