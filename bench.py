@@ -521,7 +521,9 @@ def main():
         if force_dist and "MASTER_ADDR" not in os.environ:
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
         with _StdoutToStderr():
-            dist.init_process_group(backend, **({"device_id": device} if backend == "nccl" else {}))
+            import datetime
+            dist.init_process_group(backend, timeout=datetime.timedelta(seconds=int(os.environ.get("HARP_DIST_TIMEOUT_S", "300"))),
+                                    **({"device_id": device} if backend == "nccl" else {}))
             dist.barrier()                               # communicator creation happens at the first collective
             torch.cuda.synchronize()
     eng, focal = build_engine(rank, world, device)
@@ -532,38 +534,14 @@ def main():
     if (world > 1 or force_dist) and backend == "nccl" and not shared_gpu and os.environ.get("HARP_NO_RCCL_COMM") != "1":
         # production N > 1 path: RCCL called directly through the C ABI on the step's own streams (harp_allreduce_flat), so the
         # collective is a node of the same hipGraph as the kernels; torch.distributed only carries the 128-byte communicator id
-        from harp_amd.dist import RcclComm
-        # never exercised on more than one rank in the build environment (1-GPU boxes only): if the communicator cannot be built on ANY
-        # rank, every rank falls back to torch.distributed's all-reduce with eager steps, and the line says so ("collective").
-        # BEST EFFORT: the agreement below needs every rank to reach it.  What can fail on ONE rank without the others blocking inside a
-        # collective is checked first and agreed on (pre-flight: the C-ABI library resolves RCCL's symbols — dlopen + dlsym, no
-        # communication); a rank that dies INSIDE ncclCommInitRank or inside a captured all-reduce still hangs its peers until the
-        # launcher's timeout — that is RCCL's own failure mode, not something a fallback on top of it can repair.
-        pre = 1
-        try:
-            RcclComm.unique_id()                                # dlopen(librccl) + symbol resolution + ncclGetUniqueId: local, no peers involved
-        except Exception as e:                                  # noqa: BLE001
-            print(f"[bench] rank {rank}: RCCL pre-flight failed ({type(e).__name__}: {e})", file=sys.stderr)
-            pre = 0
-        if world > 1:
-            flag = torch.tensor([pre], device=device, dtype=torch.int32)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            pre = int(flag.item())
-        try:
-            if not pre:
-                raise RuntimeError("RCCL pre-flight failed on some rank")
-            with _StdoutToStderr():
-                comm = RcclComm.from_process_group(device) if world > 1 else RcclComm.single()
-            ok = 1
-        except Exception as e:                                # noqa: BLE001 (any failure takes the fallback, it is reported below)
-            print(f"[bench] rank {rank}: RCCL communicator through the C ABI failed ({type(e).__name__}: {e}); torch.distributed fallback", file=sys.stderr)
-            comm, ok = None, 0
-        if world > 1:
-            flag = torch.tensor([ok], device=device, dtype=torch.int32)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            if int(flag.item()) == 0 and comm is not None:
-                comm.destroy()
-                comm = None
+        from harp_amd.dist import negotiate_comm
+        # never exercised on more than one rank in the build environment (1-GPU boxes only).  harp_amd.dist.negotiate_comm: a LOCAL pre-flight
+        # (dlopen + dlsym of RCCL, ncclGetUniqueId — no peer involved) agreed over the process group, then the communicator, agreed again: if
+        # ANY rank cannot have it, every rank falls back to torch.distributed's all-reduce with eager steps and the line says so
+        # ("collective").  BEST EFFORT: a rank that dies INSIDE ncclCommInitRank or inside a captured all-reduce still hangs its peers until
+        # the process group's timeout — RCCL's own failure mode.  HARP_RCCL_DEBUG=1 forces the eager fallback.
+        with _StdoutToStderr():
+            comm = negotiate_comm(device)
         if comm is not None:
             eng.set_comm(comm)
     Tl = eng.T // world

@@ -87,6 +87,58 @@ def allreduce_flat(bucket, comm=None):
     return bucket
 
 
+def agree(ok, device=None):
+    """True only when EVERY rank of the default group passed True (an all-reduce MIN of one int): the way ranks decide together whether to
+    take a path that one of them may not be able to take (a rank that went on alone would meet its peers in different collectives)"""
+    rank, world = dist_env()
+    if world == 1:
+        return bool(ok)
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32)
+    if dist.get_backend() == "nccl":
+        flag = flag.to(device if device is not None else torch.device("cuda", torch.cuda.current_device()))
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    return bool(int(flag.item()))
+
+
+def negotiate_comm(device=None, preflight=None, create=None, log=None):
+    """The RcclComm of the default process group, or None on EVERY rank when any rank cannot have it.
+      1. HARP_RCCL_DEBUG=1: no communicator at all — the caller's steps run eagerly with torch.distributed's all-reduce between the
+         backward pass and Adam, outside any hipGraph (the documented way to take RCCL-in-a-graph out of the picture on a new node).
+      2. pre-flight, LOCAL (no peer involved, cannot hang): the C-ABI library resolves RCCL (dlopen + dlsym) and ncclGetUniqueId works;
+         the ranks agree on the outcome (`agree`) BEFORE anybody enters ncclCommInitRank.
+      3. communicator creation (collective: rank 0's 128-byte id over the process group, then ncclCommInitRank); the ranks agree again and
+         a rank that did get one destroys it when a peer did not.
+    A rank that dies INSIDE ncclCommInitRank or a captured all-reduce still blocks its peers until the process group's timeout
+    (init_process_group(timeout=...)) — RCCL's own failure mode.  preflight / create: injectable for the CPU tests."""
+    import os
+    import sys
+    say = log or (lambda m: print(m, file=sys.stderr))
+    rank, world = dist_env()
+    if os.environ.get("HARP_RCCL_DEBUG") == "1":
+        say(f"[harp_amd.dist] rank {rank}: HARP_RCCL_DEBUG=1 — no RCCL communicator; torch.distributed all-reduce, eager steps")
+        return None
+    ok = True
+    try:
+        (preflight or RcclComm.unique_id)()
+    except Exception as e:                                       # noqa: BLE001
+        say(f"[harp_amd.dist] rank {rank}: RCCL pre-flight failed ({type(e).__name__}: {e})")
+        ok = False
+    if not agree(ok, device):
+        say(f"[harp_amd.dist] rank {rank}: RCCL pre-flight failed on some rank — every rank falls back to torch.distributed's all-reduce")
+        return None
+    comm = None
+    try:
+        comm = (create or (lambda: RcclComm.from_process_group(device) if world > 1 else RcclComm.single()))()
+    except Exception as e:                                       # noqa: BLE001
+        say(f"[harp_amd.dist] rank {rank}: RCCL communicator through the C ABI failed ({type(e).__name__}: {e})")
+    if not agree(comm is not None, device):
+        if comm is not None:
+            comm.destroy()
+        say(f"[harp_amd.dist] rank {rank}: no RCCL communicator on some rank — every rank falls back to torch.distributed's all-reduce")
+        return None
+    return comm
+
+
 class RcclComm:
     """RCCL communicator owned by the C-ABI library (harp_comm_* / harp_allreduce_flat in include/harp_hip.h)."""
 

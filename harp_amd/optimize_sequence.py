@@ -132,8 +132,11 @@ def optimize_hand_sequence(configs, input_params, images_dataset, val_params, va
         if not (tdist.is_available() and tdist.is_initialized()):
             raise RuntimeError("world_size > 1 needs an initialised torch.distributed process group (torch.distributed.run)")
         if tdist.get_backend() == "nccl":                                # one device per rank: RCCL straight from the step's hipGraph
-            comm = hdist.RcclComm.from_process_group(torch.device(device))
-            eng.set_comm(comm)
+            # pre-flight + agreement over the process group: either every rank gets the communicator or none does (then the steps run
+            # eagerly with torch.distributed's all-reduce); HARP_RCCL_DEBUG=1 forces that fallback (harp_amd.dist.negotiate_comm)
+            comm = hdist.negotiate_comm(torch.device(device))
+            if comm is not None:
+                eng.set_comm(comm)
     # perceptual term (:404-405, :546-547): needs the pretrained VGG16 filters, which cannot be downloaded here — pass a ready module
     # (`vgg=`) or the path of torchvision's vgg16 state dict (configs["vgg_weights"]); without either the term is left out
     if vgg is None and configs.get("vgg_weights"):
@@ -237,10 +240,12 @@ def main(argv=None):
     device = "cuda:0" if shared else f"cuda:{local}"
     torch.cuda.set_device(device)
     if world > 1:
+        import datetime
+        timeout = datetime.timedelta(seconds=int(os.environ.get("HARP_DIST_TIMEOUT_S", "600")))     # a dead peer ends the job instead of hanging it
         if shared:
-            tdist.init_process_group("gloo")
+            tdist.init_process_group("gloo", timeout=timeout)
         else:
-            tdist.init_process_group("nccl", device_id=torch.device(device))
+            tdist.init_process_group("nccl", device_id=torch.device(device), timeout=timeout)
     configs["device"] = device
     hand_layer, VERTS_UVS, FACES_UVS, VERTS_COLOR = hand_model_utils.load_hand_model(configs)
     mano_params, images_dataset, val_mano_params, val_images_dataset = load_multiple_sequences(

@@ -148,3 +148,66 @@ def test_fit_entry_point_rejects_uneven_shards():
             optimize_hand_sequence(cfg, {"pose": torch.zeros(8, 45)}, ds, None, None, None, **kw)
     with pytest.raises(NotImplementedError):
         optimize_hand_sequence({"model_type": "nimble"}, {}, ds, None, None, None)
+
+
+class _FakeComm:
+    def __init__(self):
+        self.destroyed = False
+
+    def destroy(self):
+        self.destroyed = True
+
+
+def _negotiate_worker(rank, world, port, out):
+    """three rounds of harp_amd.dist.negotiate_comm with injected pre-flight / creation outcomes"""
+    from harp_amd.dist import negotiate_comm
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    res, log = [], []
+
+    def fail():
+        raise OSError("librccl.so: cannot open shared object file")
+    # 1. the pre-flight fails on rank 1 only: NO rank may enter the (collective) creation
+    created = []
+    c = negotiate_comm(preflight=(fail if rank == 1 else (lambda: None)), create=lambda: created.append(1) or _FakeComm(), log=log.append)
+    res.append((c is None, len(created)))
+    # 2. pre-flight fine everywhere, creation fails on rank 0 only: rank 1 gives its communicator back
+    mine = []
+    def create():
+        if rank == 0:
+            raise RuntimeError("ncclCommInitRank: unhandled system error")
+        mine.append(_FakeComm())
+        return mine[0]
+    c = negotiate_comm(preflight=lambda: None, create=create, log=log.append)
+    res.append((c is None, [m.destroyed for m in mine]))
+    # 3. everything fine: every rank keeps its communicator
+    c = negotiate_comm(preflight=lambda: None, create=_FakeComm, log=log.append)
+    res.append((isinstance(c, _FakeComm) and not c.destroyed,))
+    # 4. HARP_RCCL_DEBUG=1: no communicator, nothing attempted
+    os.environ["HARP_RCCL_DEBUG"] = "1"
+    c = negotiate_comm(preflight=fail, create=fail, log=log.append)
+    res.append((c is None,))
+    out.put((rank, res, len(log)))
+    dist.destroy_process_group()
+
+
+def test_ranks_fall_back_together_when_one_cannot_have_rccl():
+    """harp_amd.dist.negotiate_comm (used by optimize_hand_sequence and bench.py): a rank whose RCCL pre-flight or communicator creation
+    fails takes EVERY rank to the torch.distributed fallback — nobody is left alone inside ncclCommInitRank or a captured all-reduce"""
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_negotiate_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict()
+    for _ in range(2):
+        rank, res, nlog = out.get(timeout=120)
+        got[rank] = res
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got[0][0] == (True, 0) and got[1][0] == (True, 0)                       # pre-flight failed on rank 1: nobody created anything
+    assert got[0][1] == (True, []) and got[1][1] == (True, [True])                  # rank 1's communicator was destroyed again
+    assert got[0][2] == (True,) and got[1][2] == (True,)
+    assert got[0][3] == (True,) and got[1][3] == (True,)

@@ -234,3 +234,38 @@ def test_bounded_term_equals_the_full_pass(precision):
     hip.term(rgb_d[:1], yt_d, mask_d, torch.tensor([2], dtype=torch.int32, device=DEV), cache, 1, g_rgb, loss, weight=1.0, bound=bound)
     torch.cuda.synchronize()
     assert loss.item() == 0.0 and (g_rgb == 1.0).all()
+
+
+def test_filters_from_a_torchvision_state_dict_file(tmp_path):
+    """`--vgg-weights <file>` / configs["vgg_weights"] end to end: a state dict in torchvision's vgg16 layout ("features.N.weight", plus
+    the classifier entries the term does not use) on disk -> Vgg16Features(weights=path) -> packed for the matrix cores -> the HIP term.
+    HARP_VGG16_WEIGHTS=<vgg16-397923af.pth> runs the same check on the real pretrained filters when the file exists (there is no
+    network in the build image, so by default the file is a seeded stand-in of the same layout)."""
+    import os
+    from harp_amd.model.vgg import Vgg16Features
+    from harp_amd.model.vgg_hip import Vgg16Hip
+    path = os.environ.get("HARP_VGG16_WEIGHTS")
+    if not (path and os.path.exists(path)):
+        src = Vgg16Features(weights="random", seed=7)
+        tv = {f"features.{k.split('.')[1]}.{k.split('.')[2]}": v for k, v in src.state_dict().items()}
+        tv["features.24.weight"], tv["classifier.0.weight"] = torch.zeros(512, 512, 3, 3), torch.zeros(8, 8)
+        path = str(tmp_path / "vgg16_layout.pth")
+        torch.save(tv, path)
+    vgg = Vgg16Features(layers_weights=[1, 1 / 16, 1 / 8, 1 / 4, 1], weights=path)
+    S, N = 64, 2
+    g = torch.Generator().manual_seed(2)
+    rgb = torch.rand(N, S, S, 3, generator=g, dtype=torch.float64).requires_grad_(True)
+    y_true = torch.rand(N, S, S, 3, generator=g, dtype=torch.float64)
+    mask = (torch.rand(N, S, S, generator=g) > 0.4).double()
+    vgg64 = Vgg16Features(layers_weights=vgg.layers_weights, weights=vgg.state_dict()).double()
+    m = mask.unsqueeze(-1)
+    want = F.l1_loss(vgg64((rgb * m).permute(0, 3, 1, 2)), vgg64((y_true * m).permute(0, 3, 1, 2)))
+    (g_want,) = torch.autograd.grad(want, rgb)
+    hip = Vgg16Hip(vgg, DEV, 0)
+    rgb_d, yt_d, mask_d = (t.detach().float().to(DEV).contiguous() for t in (rgb, y_true, mask))
+    rows = torch.arange(N, dtype=torch.int32, device=DEV)
+    g_rgb, loss = torch.zeros(N, S, S, 3, device=DEV), torch.zeros(1, device=DEV)
+    hip.term(rgb_d, yt_d, mask_d, rows, hip.features(yt_d, mask_d), 1, g_rgb, loss)
+    torch.cuda.synchronize()
+    rel = ((g_rgb.double().cpu() - g_want).norm() / g_want.norm()).item()
+    assert abs(loss.item() - want.item()) < 2e-5 * want.item() and rel < 2e-3, (loss.item(), want.item(), rel)
