@@ -47,6 +47,9 @@ constexpr int kUnits = (kPatch * kPatch * 4 + 255) / 256;   // 16-byte staging u
 #ifndef CONV_PIPE
 #define CONV_PIPE 0
 #endif
+#ifndef CONV_ORDER
+#define CONV_ORDER 0                      // order of a step's MFMAs over the four accumulators: 0 round-robin, 1 two at a time, 2 one at a time
+#endif
 #ifndef CONV_PRIO
 #define CONV_PRIO 0
 #endif
@@ -159,27 +162,32 @@ __global__ __launch_bounds__(256, CONV_WAVES) void conv3x3_kernel(const harp_con
       }
     }
   }
-  float4 rin[kUnits], rw[9];
-  // (out-of-image units read the image's first bytes and are zeroed afterwards: a select instead of a branch around every load)
+  // (named registers, not an array: hipcc left a 9 x float4 array in SCRATCH — 160 B per lane, every chunk's filter fetch waited for right
+  //  behind its loads to be stored there — although every index is a compile-time constant after unrolling)
+  float4 rin[kUnits], rw0, rw1, rw2, rw3, rw4, rw5, rw6, rw7, rw8;
+#define HARP_RW_EACH(X) X(0, rw0) X(1, rw1) X(2, rw2) X(3, rw3) X(4, rw4) X(5, rw5) X(6, rw6) X(7, rw7) X(8, rw8)
+  // (out-of-image units read the image's first bytes and are zeroed when they are STAGED: a select instead of a branch around every load, and
+  //  placed behind the chunk's MFMAs — a select right behind the load made the wave wait for the fetch before it started the chunk's MFMAs:
+  //  120 instead of 98 TFLOP/s float32, 365 instead of 208 bf16 split without it, profiles/r05_conv_variants.txt)
+  auto unit_ok = [&](int j, int cc) { return goff[j] >= 0 && cc * kCK + 4 * ((j * 256 + t) & 3) < Cin; };
   auto fetch = [&](int cc) {
 #pragma unroll
     for (int j = 0; j < kUnits; ++j) {
-      const bool ok = goff[j] >= 0 && cc * kCK + 4 * ((j * 256 + t) & 3) < Cin;
       const float* __restrict__ src = ((use_alt >> j) & 1u) ? alt_n : in_n;
-      const float4 v = *(const float4*)(src + (ok ? goff[j] + cc * kCK : 0));
-      rin[j] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+      rin[j] = *(const float4*)(src + (unit_ok(j, cc) ? goff[j] + cc * kCK : 0));
     }
-#pragma unroll
-    for (int j = 0; j < 9; ++j) rw[j] = wslab[(size_t)cc * kWF4 + j * 256 + t];
+#define HARP_RW_LOAD(j, r) r = wslab[(size_t)cc * kWF4 + j * 256 + t];
+    HARP_RW_EACH(HARP_RW_LOAD)
+#undef HARP_RW_LOAD
   };
-  auto stage = [&]() {
+  auto stage = [&](int cc) {
 #pragma unroll
     for (int j = 0; j < kUnits; ++j) {
       if (lidx[j] < 0) continue;
+      const float4 v = unit_ok(j, cc) ? rin[j] : make_float4(0.f, 0.f, 0.f, 0.f);
       if (PREC == 0) {
-        s_in[lidx[j]] = rin[j];
+        s_in[lidx[j]] = v;
       } else {
-        const float4 v = rin[j];
         bf16x4 hi = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
         bf16x4 lo = {(__bf16)(v.x - (float)hi[0]), (__bf16)(v.y - (float)hi[1]), (__bf16)(v.z - (float)hi[2]), (__bf16)(v.w - (float)hi[3])};
         uint2* s8 = (uint2*)s_in;
@@ -187,8 +195,9 @@ __global__ __launch_bounds__(256, CONV_WAVES) void conv3x3_kernel(const harp_con
         s8[lidx[j] + 4 * kPlane] = __builtin_bit_cast(uint2, lo);
       }
     }
-#pragma unroll
-    for (int j = 0; j < 9; ++j) s_w[j * 256 + t] = rw[j];
+#define HARP_RW_STORE(j, r) s_w[j * 256 + t] = r;
+    HARP_RW_EACH(HARP_RW_STORE)
+#undef HARP_RW_STORE
   };
 
   // this lane's pixel in each of the wave's two 8x4 row blocks: m = 4 * square + (dy, dx); squares 4 across, 2 down
@@ -211,10 +220,18 @@ __global__ __launch_bounds__(256, CONV_WAVES) void conv3x3_kernel(const harp_con
 #endif
   fetch(0);
   for (int cc = 0; cc < nchunk; ++cc) {
+#ifdef CONV_NOSTAGE                          // timing experiments only (wrong results): stage / fetch the first chunk only
+    if (cc == 0) {
+#endif
     __syncthreads();                      // every wave is done with the previous chunk's patch and slab
-    stage();
+    stage(cc);
     __syncthreads();
+#ifdef CONV_NOSTAGE
+    }
+#endif
+#ifndef CONV_NOFETCH
     if (cc + 1 < nchunk) fetch(cc + 1);   // in flight under the chunk's MFMAs
+#endif
     // Software pipeline over the chunk's steps (float32: 18 = 9 taps x 2 k groups of 8 channels; bf16: 9 taps of 16 channels): the
     // fragments of step s + 1 are read from LDS before the MFMAs of step s issue, so one wave alone covers its LDS latency (the compiler's
     // own schedule read each step's fragments right in front of its MFMAs: MFMA pipe 78 % / 37 % busy, profiles/r05_a_pmc_sq_conv_*).
@@ -264,6 +281,7 @@ __global__ __launch_bounds__(256, CONV_WAVES) void conv3x3_kernel(const harp_con
       if (PREC == 0) {
         const float a0[4] = {f[0].x, f[0].y, f[0].z, f[0].w}, a1[4] = {f[1].x, f[1].y, f[1].z, f[1].w};
         const float b0[4] = {f[2].x, f[2].y, f[2].z, f[2].w}, b1[4] = {f[3].x, f[3].y, f[3].z, f[3].w};
+#if CONV_ORDER == 0
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], b0[e], acc[0][0], 0, 0, 0);
@@ -271,12 +289,34 @@ __global__ __launch_bounds__(256, CONV_WAVES) void conv3x3_kernel(const harp_con
           acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], b0[e], acc[1][0], 0, 0, 0);
           acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], b1[e], acc[1][1], 0, 0, 0);
         }
+#elif CONV_ORDER == 1      // two accumulators at a time
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], b0[e], acc[0][0], 0, 0, 0);
+          acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], b1[e], acc[0][1], 0, 0, 0);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], b0[e], acc[1][0], 0, 0, 0);
+          acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], b1[e], acc[1][1], 0, 0, 0);
+        }
+#else                      // one accumulator at a time (dependent chains of 4)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], b0[e], acc[0][0], 0, 0, 0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], b1[e], acc[0][1], 0, 0, 0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], b0[e], acc[1][0], 0, 0, 0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], b1[e], acc[1][1], 0, 0, 0);
+#endif
       } else {
         const bf16x8 Ah0 = __builtin_bit_cast(bf16x8, f[0]), Ah1 = __builtin_bit_cast(bf16x8, f[1]);
         const bf16x8 Al0 = __builtin_bit_cast(bf16x8, f[2]), Al1 = __builtin_bit_cast(bf16x8, f[3]);
         const bf16x8 Bh0 = __builtin_bit_cast(bf16x8, f[4]), Bh1 = __builtin_bit_cast(bf16x8, f[5]);
         const bf16x8 Bl0 = __builtin_bit_cast(bf16x8, f[6]), Bl1 = __builtin_bit_cast(bf16x8, f[7]);
         // the two small terms first, the leading one last
+#if CONV_ORDER == 0
         acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al0, Bh0, acc[0][0], 0, 0, 0);
         acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al0, Bh1, acc[0][1], 0, 0, 0);
         acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al1, Bh0, acc[1][0], 0, 0, 0);
@@ -289,6 +329,33 @@ __global__ __launch_bounds__(256, CONV_WAVES) void conv3x3_kernel(const harp_con
         acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah0, Bh1, acc[0][1], 0, 0, 0);
         acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah1, Bh0, acc[1][0], 0, 0, 0);
         acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah1, Bh1, acc[1][1], 0, 0, 0);
+#elif CONV_ORDER == 1
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al0, Bh0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al0, Bh1, acc[0][1], 0, 0, 0);
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah0, Bl0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah0, Bl1, acc[0][1], 0, 0, 0);
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah0, Bh0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah0, Bh1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al1, Bh0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al1, Bh1, acc[1][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah1, Bl0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah1, Bl1, acc[1][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah1, Bh0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah1, Bh1, acc[1][1], 0, 0, 0);
+#else
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al0, Bh0, acc[0][0], 0, 0, 0);
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah0, Bl0, acc[0][0], 0, 0, 0);
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah0, Bh0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al0, Bh1, acc[0][1], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah0, Bl1, acc[0][1], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah0, Bh1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al1, Bh0, acc[1][0], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah1, Bl0, acc[1][0], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah1, Bh0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al1, Bh1, acc[1][1], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah1, Bl1, acc[1][1], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah1, Bh1, acc[1][1], 0, 0, 0);
+#endif
       }
 #if CONV_PRIO == 2
       __builtin_amdgcn_s_setprio(0);
