@@ -68,3 +68,39 @@ def test_no_silent_random_fallback():
         pass
     with pytest.raises(RuntimeError):
         Vgg16Features()
+
+
+def test_active_tiles_cover_every_feature_difference():
+    """the premise of the perceptual term's bounded mode (harp_amd/model/vgg_hip.active_tiles, csrc/conv.hip): vgg(a * mask) and vgg(b * mask)
+    can differ only inside the 16x16 tiles the mask's support reaches through the receptive field — at EVERY one of the ten convolutions, not
+    only at the four taps (checked with the torch module on the CPU; levels = image side S, S/2, S/4, S/8)"""
+    from harp_amd.model.vgg import Vgg16Features
+    from harp_amd.model.vgg_hip import active_tiles
+    S = 96
+    g = torch.Generator().manual_seed(0)
+    vgg = Vgg16Features(weights="random", seed=4).double()
+    mask = torch.zeros(2, S, S, dtype=torch.float64)
+    mask[0, 40:43, 50:52] = 1.0                       # a few pixels
+    mask[1, 0:20, 70:96] = (torch.rand(20, 26, generator=g) > 0.5).double()
+    a, b = torch.rand(2, S, S, 3, generator=g, dtype=torch.float64), torch.rand(2, S, S, 3, generator=g, dtype=torch.float64)
+    xa, xb = (a * mask[..., None]).permute(0, 3, 1, 2), (b * mask[..., None]).permute(0, 3, 1, 2)
+    bound = active_tiles(mask)
+    level, ha, hb, checked = 0, xa, xb, 0
+    with torch.no_grad():
+        for n in range(1, 5):
+            for layer in getattr(vgg, f"slice{n}"):
+                ha, hb = layer(ha), layer(hb)
+                if isinstance(layer, torch.nn.MaxPool2d):
+                    level += 1
+                if not isinstance(layer, torch.nn.ReLU):
+                    continue
+                tiles, order, count, mx = bound[level]
+                nt = (ha.shape[-1] + 15) // 16
+                differs = (ha != hb).any(1)                                    # (2, s, s)
+                per_tile = torch.nn.functional.max_pool2d(differs.float()[:, None], 16, 16, ceil_mode=True)[:, 0].reshape(2, nt * nt) > 0
+                assert not (per_tile & (tiles == 0)).any(), (n, level)
+                assert per_tile.any()
+                checked += 1
+                for f in range(2):                                             # the lists hold exactly the flagged tiles, in raster order
+                    assert order[f, :count[f]].tolist() == torch.nonzero(tiles[f]).flatten().tolist()
+    assert checked == 10 and bound[0][2][0] < 36                               # (frame 0: a few of the 36 level-0 tiles)
