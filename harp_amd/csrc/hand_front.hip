@@ -222,11 +222,8 @@ int harp_hand_front_fwd(const harp_hand_front* h, hipStream_t stream) {
   // bytes of LDS each, which can then not land on this CU and take issue slots / L1 from the chain (-3 us / step, same-box A/B x3;
   // forcing 128 VGPRs — no co-resident wave at all — was bimodal: DESIGN.md 6.4).  HARP_FRONT_LDS=<bytes> overrides (0: only what is needed).
   const size_t need = (size_t)(a.V0 + a.E0) * 3 * sizeof(float);
-  size_t lds = 159744;                                                   // 160 KB - the kernel's static LDS rounded up to 4 KB: nothing is left
-  if (const char* e = getenv("HARP_FRONT_LDS")) lds = (size_t)atoi(e);
-  lds = lds < need ? need : lds;
-  if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)hand_front_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-    return HARP_ERR_ARG;
+  static size_t fence = 0;                                              // 160 KB - the kernel's static LDS: nothing is left on the CU
+  const size_t lds = harp_lds_fence((const void*)hand_front_kernel, "HARP_FRONT_LDS", 159744, need, &fence);
   hipLaunchKernelGGL(hand_front_kernel, dim3(a.B), dim3(kChainThreads), lds, stream, *h);
   HARP_CHECK_LAUNCH();
   return HARP_OK;

@@ -13,6 +13,30 @@
     if (e__ != hipSuccess) return HARP_ERR_LAUNCH + (int)e__; \
   } while (0)
 
+// Dynamic-LDS "fence" size of a kernel that asks for more LDS than it uses in order to keep other workgroups off its CU (hand_front,
+// texture_terms): decided ONCE per process and kernel — `want` (or the environment override `env`, bytes; 0 = none) clamped to what the device
+// and the kernel's static LDS leave, never below `need`; if the attribute cannot be raised the launch just uses `need` (the fence is an
+// optimisation, not an argument error).  Call with the first launch's `need`; later launches with a larger `need` get max(need, cached).
+#include <stdlib.h>
+inline size_t harp_lds_fence(const void* kernel, const char* env, size_t want, size_t need, size_t* cache) {
+  if (*cache == 0) {
+    size_t ask = want;
+    if (const char* e = getenv(env)) ask = (size_t)atoi(e);
+    int dev = 0, max_lds = 64 * 1024;
+    hipFuncAttributes fa;
+    size_t stat = 0;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&max_lds, hipDeviceAttributeMaxSharedMemoryPerBlock, dev);
+    if (hipFuncGetAttributes(&fa, kernel) == hipSuccess) stat = fa.sharedSizeBytes;
+    const size_t room = (size_t)max_lds > stat ? (size_t)max_lds - stat : 0;
+    if (ask > room) ask = room;
+    if (ask > 48 * 1024 && hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ask) != hipSuccess) ask = 0;
+    (void)hipGetLastError();
+    *cache = ask + 1;                 // (+1: 0 means "not decided yet")
+  }
+  const size_t fence = *cache - 1;
+  return fence > need ? fence : need;
+}
+
 constexpr float kEps = 1e-8f;      // PyTorch3D kEpsilon
 constexpr int kWave = 64;          // gfx950 wavefront
 

@@ -605,10 +605,8 @@ int harp_texture_terms(const float* tex, const float* nmap, const float* mask, c
   // ONE workgroup per CU (100 KB of dynamic LDS the kernel does not use; HARP_TEXTERMS_LDS=<bytes> overrides, 0 = none): the kernel is bound
   // by its ~5 M scattered memory-side atomics, which four waves per CU keep as busy as thirty-two do (34 -> 37 us) — but with every CU full
   // of its waves the frames' latency chain that runs next to it (hand_front) took 75 us instead of 57: step -13 us, same-box A/B x4.
-  size_t pad = 100 * 1024;
-  if (const char* e = getenv("HARP_TEXTERMS_LDS")) pad = (size_t)atoi(e);
-  if (pad > 60 * 1024 && hipFuncSetAttribute((const void*)texture_terms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad) != hipSuccess)
-    return HARP_ERR_ARG;
+  static size_t fence = 0;
+  const size_t pad = harp_lds_fence((const void*)texture_terms_kernel, "HARP_TEXTERMS_LDS", 100 * 1024, 0, &fence);
   hipLaunchKernelGGL(texture_terms_kernel, dim3(2 * A.nb_smooth + H + A.nb_disp), dim3(256), pad, stream, A);
   HARP_CHECK_LAUNCH();
   return HARP_OK;

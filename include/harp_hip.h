@@ -243,8 +243,10 @@ size_t harp_lbs_tree_ws_floats(const harp_tree_model* m, int B);
 /* verts (B,NV,3) mm, joints (B,n_joints_out,3) mm */
 int harp_lbs_tree_fwd(const harp_tree_model* m, const float* in_pose, const float* betas, const float* transl, int B, float* ws,
                       float* verts, float* joints, hipStream_t stream);
-/* ws: the workspace harp_lbs_tree_fwd filled for the same inputs (it also clears the accumulators this call adds to; the call leaves
- * them cleared again, so it may be repeated on one forward pass) */
+/* ws: the workspace harp_lbs_tree_fwd filled for the same inputs AND THE SAME B (the layout of ws is a function of B).  The forward call
+ * clears the accumulators this call adds to, and this call leaves them cleared again: it may be repeated on one forward pass, and a
+ * workspace may be reused for another batch size by running harp_lbs_tree_fwd at that size first.  Calling it on a workspace whose last
+ * forward ran at another B, or that the caller filled itself, accumulates into whatever those bytes hold. */
 int harp_lbs_tree_bwd(const harp_tree_model* m, const float* in_pose, const float* betas, const float* transl, int B, float* ws,
                       float* g_verts, const float* g_joints, float* g_in_pose, float* g_betas, float* g_transl, hipStream_t stream);
 

@@ -374,6 +374,47 @@ def test_smplx_arm_lbs_vs_oracle():
     assert vm.shape == (B, 778, 3) and jm.shape == (B, 21, 3)
 
 
+
+def test_tree_lbs_workspace_reused_across_batch_sizes():
+    """raw C ABI: harp_lbs_tree_fwd / _bwd on ONE workspace at B = 5, then at B = 3 (the workspace layout is a function of B; the forward
+    call clears the accumulators the backward adds to, the backward leaves them cleared): same gradients as on fresh workspaces"""
+    import ctypes
+    from harp_amd import _lib, synth
+    from harp_amd.hand_models_harp.body_models import SMPLXARM
+    m = synth.make_smplx_arm_model(seed=0)
+    corr = np.load("harp_amd/assets/arm_corr.npz")
+    dm = SMPLXARM(m, m["faces"], corr["mano_vert_from_arm"], device=DEV).device_model
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(1)
+    nin = dm.struct.n_pose_in
+
+    def run(B, ws):
+        gg = torch.Generator().manual_seed(10 + B)
+        pose = (torch.randn(B, nin, 3, generator=gg) * 0.3).to(DEV)
+        betas, transl = (torch.randn(B, dm.struct.NB, generator=gg) * 0.5).to(DEV), (torch.randn(B, 3, generator=gg) * 0.02).to(DEV)     # (NB = betas + expression)
+        verts = torch.empty(B, dm.NV, 3, device=DEV)
+        joints = torch.empty(B, dm.struct.n_joints_out, 3, device=DEV)
+        _lib.check(L.harp_lbs_tree_fwd(ctypes.byref(dm.struct), _lib.ptr(pose), _lib.ptr(betas), _lib.ptr(transl), B, _lib.ptr(ws), _lib.ptr(verts),
+                                       _lib.ptr(joints), _lib.stream()), "fwd")
+        gv, gj = torch.randn(B, dm.NV, 3, generator=gg).to(DEV), torch.randn(B, dm.struct.n_joints_out, 3, generator=gg).to(DEV)
+        out = []
+        for _ in range(2):                                           # (twice on one forward pass)
+            g_pose, g_betas, g_tr = torch.zeros_like(pose), torch.empty_like(betas), torch.empty_like(transl)
+            _lib.check(L.harp_lbs_tree_bwd(ctypes.byref(dm.struct), _lib.ptr(pose), _lib.ptr(betas), _lib.ptr(transl), B, _lib.ptr(ws),
+                                           _lib.ptr(gv.clone()), _lib.ptr(gj), _lib.ptr(g_pose), _lib.ptr(g_betas), _lib.ptr(g_tr), _lib.stream()), "bwd")
+            out.append((g_pose.clone(), g_betas.clone(), g_tr.clone()))
+        torch.cuda.synchronize()
+        return out
+    big = L.harp_lbs_tree_ws_floats(ctypes.byref(dm.struct), 5)
+    shared = torch.empty(big, device=DEV)
+    got = {B: run(B, shared) for B in (5, 3, 5)}
+    for B in (5, 3):
+        fresh = run(B, torch.empty(L.harp_lbs_tree_ws_floats(ctypes.byref(dm.struct), B), device=DEV))
+        for rep in got[B]:
+            for a, b in zip(rep, fresh[0]):
+                assert rel(a, b) < 1e-5, (B, rel(a, b))
+
+
 def test_full_step_smplx_arm():
     """use_arm=True path of the engine (SMPL-X right-arm LBS, 4083-vertex arm mesh, 22 joints, wrist_pose/rot optimised when
     opt_arm_pose) vs the oracle."""
