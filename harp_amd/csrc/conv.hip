@@ -103,21 +103,25 @@ __global__ __launch_bounds__(256, CONV_WAVES) void conv3x3_kernel(const harp_con
   int id = blockIdx.x;
   const int cb = id % ncb; id /= ncb;
   int tx, ty, n;
+  int x0, y0;
   if (a.tile_list) {
-    // bounded mode: slot i of image n's frame; frames hold different numbers of tiles, the grid is sized for the largest
+    // bounded mode: slot i of image n's frame; frames hold different numbers of tiles, the grid is sized for the largest.  The frame's tile
+    // grid may be shifted by an (even) origin so that its tiles hug the frame's active region: tile (ty, tx) covers pixels [16 ty - oy, +16)
     const int i = id % a.max_tiles;
     n = id / a.max_tiles;
     const int r = a.target_row ? a.target_row[n] : n;
     if (i >= a.tile_count[r]) return;
     const int tile = a.tile_list[(size_t)r * a.max_tiles + i];
-    ty = tile / tiles_x; tx = tile - ty * tiles_x;
+    ty = tile / a.tile_pitch; tx = tile - ty * a.tile_pitch;
+    y0 = ty * kCT - (a.tile_origin ? a.tile_origin[2 * r] : 0);
+    x0 = tx * kCT - (a.tile_origin ? a.tile_origin[2 * r + 1] : 0);
   } else {
     tx = id % tiles_x; id /= tiles_x;
     ty = id % tiles_y;
     n = id / tiles_y;
+    x0 = tx * kCT; y0 = ty * kCT;
   }
   const size_t row = a.target_row ? (size_t)a.target_row[n] : (size_t)n;
-  const int x0 = tx * kCT, y0 = ty * kCT;
   const int H = a.H, W = a.W;
   const int Cin = a.in_channels > 0 ? a.in_channels : a.Cin;     // channels per pixel in memory (the rest of a.Cin reads as zero)
   const float* __restrict__ in_n = a.in + (size_t)n * H * W * Cin;
@@ -128,15 +132,18 @@ __global__ __launch_bounds__(256, CONV_WAVES) void conv3x3_kernel(const harp_con
   // Wave-uniform: 16 scalar loads, one bit each.
   unsigned cellmask = 0xffffu;
   const int csh = 3 + a.in_valid_shift;
-  const int cy0 = max(y0 - 1, 0) >> csh, cx0 = max(x0 - 1, 0) >> csh;
+  // origin of the producer's tile grid in INPUT pixels (a producer behind a pool runs at twice the resolution: its even origin halves)
+  const int poy = a.in_valid_origin ? a.in_valid_origin[2 * row] >> (1 - a.in_valid_shift) : 0;
+  const int pox = a.in_valid_origin ? a.in_valid_origin[2 * row + 1] >> (1 - a.in_valid_shift) : 0;
+  const int cy0 = (max(y0 - 1, 0) + poy) >> csh, cx0 = (max(x0 - 1, 0) + pox) >> csh;
   if (a.in_valid) {
-    const int pitch = (W + (1 << csh) - 1) >> csh, rows_c = (H + (1 << csh) - 1) >> csh;
-    const int32_t* __restrict__ v = a.in_valid + row * pitch * rows_c;
+    const int pitch = a.in_valid_pitch;
+    const int32_t* __restrict__ v = a.in_valid + row * pitch * pitch;
     cellmask = 0;
 #pragma unroll
     for (int c = 0; c < 16; ++c) {
       const int cy = cy0 + (c >> 2), cx = cx0 + (c & 3);
-      if (cy < rows_c && cx < pitch && v[cy * pitch + cx]) cellmask |= 1u << c;
+      if (cy < pitch && cx < pitch && v[cy * pitch + cx]) cellmask |= 1u << c;
     }
   }
 
@@ -154,7 +161,7 @@ __global__ __launch_bounds__(256, CONV_WAVES) void conv3x3_kernel(const harp_con
       else lidx[j] = (((q >> 1) * kPlane + py * kRow + px) << 1) | (q & 1);      // 8-byte index of the hi half; lo is 2 planes further
       if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
         goff[j] = (gy * W + gx) * Cin + 4 * q;
-        const int c = (((gy >> csh) - cy0) << 2) | ((gx >> csh) - cx0);
+        const int c = ((((gy + poy) >> csh) - cy0) << 2) | (((gx + pox) >> csh) - cx0);
         if (!((cellmask >> c) & 1u)) {
           if (alt_n) use_alt |= 1u << j;
           else goff[j] = -1;
@@ -380,7 +387,7 @@ __global__ __launch_bounds__(256, CONV_WAVES) void conv3x3_kernel(const harp_con
       for (int q = 0; q < 4; ++q) {
         const int sq = 2 * q + half;
         const int gy = y0 + 4 * wv + 2 * (sq >> 2), gx = x0 + 8 * i + 2 * (sq & 3);     // top-left pixel of the 2x2 square (even, even)
-        if (gy >= H || gx >= W) continue;
+        if (gy >= H || gx >= W || gy < 0 || gx < 0) continue;                          // (a shifted tile grid reaches beyond the image on all sides)
         if (EPI == EPI_RELU || EPI == EPI_RELU_TAP) {
           float v[4];
 #pragma unroll
@@ -424,7 +431,8 @@ __global__ __launch_bounds__(256, CONV_WAVES) void conv3x3_kernel(const harp_con
             if (g10 > best) { best = g10; ob = o00 + dy; }
             if (g11 > best) { best = g11; ob = o00 + dy + dx; }
             // (bounded mode: windows in output tiles this pass does not own are left alone — nothing downstream reads them)
-            if (a.out_valid && !a.out_valid[row * (((2 * W + 15) >> 4) * ((2 * H + 15) >> 4)) + (yy >> 3) * ((2 * W + 15) >> 4) + (xx >> 3)]) continue;
+            if (a.out_valid && !a.out_valid[(row * a.out_valid_pitch + ((2 * yy + (a.out_valid_origin ? a.out_valid_origin[2 * row] : 0)) >> 4)) * a.out_valid_pitch +
+                                            ((2 * xx + (a.out_valid_origin ? a.out_valid_origin[2 * row + 1] : 0)) >> 4)]) continue;
             if (best > 0.f) a.out[ob] += acc[i][j][4 * q + c];
           }
         }
@@ -510,16 +518,21 @@ __global__ __launch_bounds__(256) void vgg_grad_image_kernel(const float* __rest
                                                              const float* __restrict__ y_true, const float* __restrict__ mask,
                                                              const int32_t* __restrict__ rows, const int32_t* __restrict__ covered, int S, float scale0,
                                                              float weight, float* __restrict__ g_rgb, const double* __restrict__ loss_acc,
-                                                             float* __restrict__ loss_out, const int32_t* __restrict__ tiles) {
+                                                             float* __restrict__ loss_out, const int32_t* __restrict__ tiles,
+                                                             const int32_t* __restrict__ origin, int pitch) {
   __shared__ float4 patch[4 * kPatch * kGRow];
   const int t = threadIdx.x, tx = t & 15, ty = t >> 4;
   const int n = blockIdx.z, x0 = blockIdx.x * kCT, y0 = blockIdx.y * kCT;
   if (loss_out && t == 0 && blockIdx.x == 0 && blockIdx.y == 0 && n == 0) loss_out[0] = (float)loss_acc[0];
   const float* __restrict__ Gn = G + (size_t)n * S * S * 64;
   // bounded mode: G exists in the frame's active 16x16 tiles only (zero elsewhere); a tile that is not active has no gradient from the stack
-  const int ntx = (S + kCT - 1) / kCT;
-  const int32_t* __restrict__ act = tiles ? tiles + (size_t)(rows ? rows[n] : n) * ntx * ntx : nullptr;
-  const bool active = !act || act[blockIdx.y * ntx + blockIdx.x];
+  const size_t fr = rows ? (size_t)rows[n] : (size_t)n;
+  const int32_t* __restrict__ act = tiles ? tiles + fr * pitch * pitch : nullptr;
+  const int oy = (tiles && origin) ? origin[2 * fr] : 0, ox = (tiles && origin) ? origin[2 * fr + 1] : 0;
+  auto in_active = [&](int gy, int gx) { return !act || act[((gy + oy) >> 4) * pitch + ((gx + ox) >> 4)] != 0; };
+  // (this kernel's blocks sit on the fixed 16x16 grid; the frame's active tiles may be shifted: a block overlaps at most four of them)
+  const int yb = min(y0 + kCT - 1, S - 1), xb = min(x0 + kCT - 1, S - 1);
+  const bool active = in_active(y0, x0) || in_active(y0, xb) || in_active(yb, x0) || in_active(yb, xb);
   float o0 = 0.f, o1 = 0.f, o2 = 0.f;
   for (int cc = 0; cc < (active ? 4 : 0); ++cc) {
     __syncthreads();
@@ -527,7 +540,7 @@ __global__ __launch_bounds__(256) void vgg_grad_image_kernel(const float* __rest
       const int pix = u >> 2, q = u & 3, py = pix / kPatch, px = pix - py * kPatch;
       const int gy = y0 + py - 1, gx = x0 + px - 1;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (gy >= 0 && gy < S && gx >= 0 && gx < S && (!act || act[(gy >> 4) * ntx + (gx >> 4)]))
+      if (gy >= 0 && gy < S && gx >= 0 && gx < S && in_active(gy, gx))
         v = *(const float4*)(Gn + ((size_t)gy * S + gx) * 64 + cc * 16 + 4 * q);
       patch[(q * kPatch + py) * kGRow + px] = v;
     }
@@ -603,7 +616,7 @@ inline VggWs vgg_ws_split(void* ws, int N, int S, int with_gradient) {
 // receptive field).  Outside them pred == target exactly, the L1 and its gradient vanish, and a convolution that needs an input pixel
 // from there reads the TARGET frame's cached activation (forward) or zero (backward).
 struct VggBound {
-  const int32_t* tiles[4]; const int32_t* list[4]; const int32_t* count[4]; int max_tiles[4];
+  const int32_t* tiles[4]; const int32_t* list[4]; const int32_t* count[4]; const int32_t* origin[4]; int max_tiles[4]; int pitch[4];
   const float* target_in[10];
   const int32_t* rows;
 };
@@ -637,9 +650,11 @@ int vgg_forward(const harp_vgg16* net, const VggWs& w, int N, int S, float* cons
     if (bd) {
       a.target_row = bd->rows;
       a.tile_list = bd->list[lv]; a.tile_count = bd->count[lv]; a.max_tiles = bd->max_tiles[lv];
+      a.tile_origin = bd->origin[lv]; a.tile_pitch = bd->pitch[lv];
       if (k > 0) {                                  // (x0 is written everywhere)
         const bool behind_pool = (k == 2 || k == 4 || k == 7);
-        a.in_valid = bd->tiles[behind_pool ? lv - 1 : lv]; a.in_valid_shift = behind_pool ? 0 : 1;
+        const int pl = behind_pool ? lv - 1 : lv;
+        a.in_valid = bd->tiles[pl]; a.in_valid_origin = bd->origin[pl]; a.in_valid_pitch = bd->pitch[pl]; a.in_valid_shift = behind_pool ? 0 : 1;
         a.in_alt = bd->target_in[k];
       }
     }
@@ -700,7 +715,8 @@ int harp_conv3x3(const harp_conv3x3_args* a, hipStream_t stream) {
     default: return HARP_ERR_ARG;
   }
   if (a->pooled && ((a->H | a->W) & 1)) return HARP_ERR_ARG;
-  if (a->tile_list && (!a->tile_count || a->max_tiles <= 0)) return HARP_ERR_ARG;
+  if (a->tile_list && (!a->tile_count || a->max_tiles <= 0 || a->tile_pitch <= 0)) return HARP_ERR_ARG;
+  if ((a->in_valid && a->in_valid_pitch <= 0) || (a->out_valid && a->out_valid_pitch <= 0)) return HARP_ERR_ARG;
   if (a->in_valid_shift < 0 || a->in_valid_shift > 1) return HARP_ERR_ARG;
   if (a->precision == 0) return launch_conv_prec<0>(*a, stream);
   if (a->precision == 1) return launch_conv_prec<1>(*a, stream);
@@ -742,8 +758,9 @@ int harp_vgg16_term(const harp_vgg16* net, const harp_vgg16_term_args* t, hipStr
   if (bounded) {
     if (!t->target_by_row || !t->rows) return HARP_ERR_ARG;
     for (int l = 0; l < 4; ++l) {
-      if (!t->tiles[l] || !t->tile_list[l] || !t->tile_count[l] || t->max_tiles[l] <= 0) return HARP_ERR_ARG;
+      if (!t->tiles[l] || !t->tile_list[l] || !t->tile_count[l] || !t->tile_origin[l] || t->max_tiles[l] <= 0 || t->tile_pitch[l] <= 0) return HARP_ERR_ARG;
       bd.tiles[l] = t->tiles[l]; bd.list[l] = t->tile_list[l]; bd.count[l] = t->tile_count[l]; bd.max_tiles[l] = t->max_tiles[l];
+      bd.origin[l] = t->tile_origin[l]; bd.pitch[l] = t->tile_pitch[l];
     }
     for (int k = 1; k < 10; ++k) {
       if (!t->target_in[k]) return HARP_ERR_ARG;
@@ -774,8 +791,9 @@ int harp_vgg16_term(const harp_vgg16* net, const harp_vgg16_term_args* t, hipStr
     if (bounded) {       // the gradient lives in the level's active tiles and is zero elsewhere
       a.target_row = bd.rows;
       a.tile_list = bd.list[lv]; a.tile_count = bd.count[lv]; a.max_tiles = bd.max_tiles[lv];
-      a.in_valid = bd.tiles[lv]; a.in_valid_shift = 1;
-      if (tap >= 0) a.out_valid = bd.tiles[lv - 1];
+      a.tile_origin = bd.origin[lv]; a.tile_pitch = bd.pitch[lv];
+      a.in_valid = bd.tiles[lv]; a.in_valid_origin = bd.origin[lv]; a.in_valid_pitch = bd.pitch[lv]; a.in_valid_shift = 1;
+      if (tap >= 0) { a.out_valid = bd.tiles[lv - 1]; a.out_valid_origin = bd.origin[lv - 1]; a.out_valid_pitch = bd.pitch[lv - 1]; }
     }
     rc = harp_conv3x3(&a, stream);
     if (rc != HARP_OK) return rc;
@@ -783,7 +801,7 @@ int harp_vgg16_term(const harp_vgg16* net, const harp_vgg16_term_args* t, hipStr
   }
   hipLaunchKernelGGL(vgg_grad_image_kernel, dim3((S + kCT - 1) / kCT, (S + kCT - 1) / kCT, N), dim3(256), 0, stream, g, net->w0t, t->rgb, t->y_true,
                      t->mask, t->rows, t->covered, S, scale[0], t->weight, t->g_rgb, w.loss, t->loss,
-                     bounded ? bd.tiles[0] : (const int32_t*)nullptr);
+                     bounded ? bd.tiles[0] : (const int32_t*)nullptr, bounded ? bd.origin[0] : (const int32_t*)nullptr, bounded ? bd.pitch[0] : 0);
   HARP_CHECK_LAUNCH();
   return HARP_OK;
 }

@@ -31,11 +31,14 @@ def activation_shapes(S):
     return [(S // d, S // d, c) for d, c in zip(_DIV, _COUT)] + [(S // 2, S // 2, 64), (S // 4, S // 4, 128), (S // 8, S // 8, 256)]
 
 
-def active_tiles(mask):
+def active_tiles(mask, shift_grid=True):
     """The 16x16 tiles of each resolution level (side S >> L, L = 0..3) in which activations of image * mask can differ between two images
     sharing `mask` (T,S,S): the support of the mask grown by the receptive field of the level's last convolution — two 3x3 convolutions at
-    levels 0 and 1, three at levels 2 and 3, a 2x2 max pool between levels (model/vgg.py:26-33).  Returns per level: tiles (T, nt*nt) int32
-    0/1, tile_list (T, max) int32, tile_count (T) int32, max."""
+    levels 0 and 1, three at levels 2 and 3, a 2x2 max pool between levels (model/vgg.py:26-33).  shift_grid: every frame's tile grid is
+    shifted by the EVEN origin (oy, ox) in [0, 14]^2 that needs the fewest tiles (tile (ty, tx) = pixels [16 ty - oy, +16) x [16 tx - ox, +16):
+    the tiles hug the region instead of straddling it — at S/8 = 64 a hand spans 3 tiles instead of 4 per axis).
+    Returns per level: tiles (T, G*G) int32 0/1 with G = ceil(S_L / 16) + 1, tile_list (T, max) int32 (ty * G + tx, raster order), tile_count (T)
+    int32, max, origin (T,2) int32, G."""
     F = torch.nn.functional
     d = (mask > 0).float()[:, None]
     out = []
@@ -43,13 +46,26 @@ def active_tiles(mask):
         if level:
             d = F.max_pool2d(d, 2, 2)
         d = F.max_pool2d(d, 2 * grow + 1, 1, grow)
-        t = F.max_pool2d(d, 16, 16, ceil_mode=True)[:, 0] > 0          # (T, nt, nt)
-        T, nt = t.shape[0], t.shape[1]
-        flat = t.reshape(T, nt * nt)
+        T, s = d.shape[0], d.shape[-1]
+        G = (s + 15) // 16 + 1
+        d2 = F.max_pool2d(d, 2, 2, ceil_mode=True)                         # even origins: work on 2x2 blocks, tiles of 8 blocks
+        best_n = torch.full((T,), 1 << 30, dtype=torch.int64, device=d.device)
+        best_t = torch.zeros(T, G, G, dtype=torch.bool, device=d.device)
+        best_o = torch.zeros(T, 2, dtype=torch.int32, device=d.device)
+        for oy in (range(8) if shift_grid else (0,)):
+            for ox in (range(8) if shift_grid else (0,)):
+                p = F.pad(d2, (ox, 8 * G - ox - d2.shape[-1], oy, 8 * G - oy - d2.shape[-2]))
+                t = F.max_pool2d(p, 8, 8)[:, 0] > 0                         # (T, G, G)
+                n = t.reshape(T, -1).sum(1)
+                better = n < best_n
+                best_n = torch.where(better, n, best_n)
+                best_t = torch.where(better[:, None, None], t, best_t)
+                best_o = torch.where(better[:, None], torch.tensor([2 * oy, 2 * ox], dtype=torch.int32, device=d.device)[None], best_o)
+        flat = best_t.reshape(T, G * G)
         count = flat.sum(1).int()
         mx = max(int(count.max()), 1)
         order = torch.argsort((~flat).int(), dim=1, stable=True)[:, :mx].int()      # active tiles first, in raster order
-        out.append((flat.int().contiguous(), order.contiguous(), count.contiguous(), mx))
+        out.append((flat.int().contiguous(), order.contiguous(), count.contiguous(), mx, best_o.contiguous(), G))
     return out
 
 
@@ -124,8 +140,9 @@ class Vgg16Hip:
         if bound is not None:
             for k, slot in INPUT_SLOT.items():
                 t.target_in[k] = _lib.ptr(target[slot])
-            for lv, (tiles, order, count, mx) in enumerate(bound):
+            for lv, (tiles, order, count, mx, origin, pitch) in enumerate(bound):
                 t.tiles[lv], t.tile_list[lv], t.tile_count[lv], t.max_tiles[lv] = _lib.ptr(tiles), _lib.ptr(order), _lib.ptr(count), mx
+                t.tile_origin[lv], t.tile_pitch[lv] = _lib.ptr(origin), pitch
         t.target_by_row, t.covered, t.g_rgb, t.weight, t.loss = int(target_by_row), _lib.ptr(covered), _lib.ptr(g_rgb), float(weight), _lib.ptr(loss)
         t.N, t.S, t.ws = N, S, _lib.ptr(self.workspace(N, S, True))
         _lib.check(_lib.lib().harp_vgg16_term(ctypes.byref(self.net), ctypes.byref(t), _lib.stream()), "harp_vgg16_term")

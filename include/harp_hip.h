@@ -505,13 +505,20 @@ typedef struct harp_conv3x3_args {
   /* bounded mode (all NULL / 0 = every tile): image n belongs to frame row r = target_row[n]; only the 16x16 output tiles of that frame's
    * list are computed, and input pixels in cells this pass did not write are taken from in_alt (the same activation of another pass,
    * e.g. the target frame's, rows through target_row) or read as zero */
-  const int32_t* tile_list;   /* (T, max_tiles): ty * ceil(W/16) + tx */
+  const int32_t* tile_list;   /* (T, max_tiles): ty * tile_pitch + tx in the frame's tile grid */
   const int32_t* tile_count;  /* (T) */
   int max_tiles;
   int in_valid_shift;         /* cells of in_valid are (8 << shift) input pixels square: 1 = the producer's 16x16 tiles, 0 = tiles of a 2x finer producer behind a pool */
-  const int32_t* in_valid;    /* (T, ceil(H/cell) * ceil(W/cell)) 0/1 */
+  const int32_t* in_valid;    /* (T, in_valid_pitch^2) 0/1 over the PRODUCER's tile grid */
   const float* in_alt;        /* (T,H,W,in_channels) or NULL: zero */
-  const int32_t* out_valid;   /* HARP_CONV_UNPOOL: (T, ceil(2H/16) * ceil(2W/16)) 0/1 over the 16x16 tiles of `out`; windows elsewhere are skipped */
+  const int32_t* out_valid;   /* HARP_CONV_UNPOOL: (T, out_valid_pitch^2) 0/1 over the tile grid of `out` (twice this convolution's resolution); windows elsewhere are skipped */
+  /* a frame's tile grid may be shifted so that its tiles hug the active region: tile (ty, tx) covers pixels [16 ty - oy, 16 ty - oy + 16) x
+   * [16 tx - ox, ...), origin (oy, ox) EVEN (2x2 pool windows stay inside a tile), per frame, in the pixels of the grid's own resolution;
+   * NULL = (0, 0).  pitch = tiles per row (and rows) of the grid's bitmap */
+  const int32_t* tile_origin;       /* (T,2) of the grid tile_list indexes */
+  const int32_t* in_valid_origin;   /* (T,2) of the producer's grid */
+  const int32_t* out_valid_origin;  /* (T,2) of `out`'s grid */
+  int tile_pitch, in_valid_pitch, out_valid_pitch;
 } harp_conv3x3_args;
 size_t harp_conv3x3_filter_bytes(int Cout, int Cin);
 int harp_conv3x3_pack_filters(const float* w, int Cout, int Cin, int transpose, int precision, void* packed, hipStream_t stream);
@@ -530,7 +537,8 @@ int harp_conv3x3(const harp_conv3x3_args* a, hipStream_t stream);
  *   out[1], out[3], out[6], out[9] (relu1_2 ... relu4_3) are required, the others may be NULL (kept in ws only).
  * Bounded mode of harp_vgg16_term (tiles[0] != NULL; needs target_by_row and the cache of ALL activations): the stack runs only in the
  *   16x16 tiles of each resolution level (L = 0..3, side S >> L) where the rendered image's activations can differ from the target
- *   frame's — tiles[L] (T, ceil(S_L/16)^2) 0/1 per frame, tile_list[L] (T, max_tiles[L]) their indices, tile_count[L] (T): the support
+ *   frame's — tiles[L] (T, tile_pitch[L]^2) 0/1 per frame over a tile grid shifted by the frame's tile_origin[L] (so that the tiles hug the
+ *   active region), tile_list[L] (T, max_tiles[L]) their indices, tile_count[L] (T): the support
  *   of mask grown by the receptive field (the caller's set-up, harp_amd/model/vgg_hip.py).  Elsewhere pred == target exactly: the L1
  *   and its gradient vanish, and inputs needed from there are read from target_in[k] = the target frame's input activation of
  *   convolution k (k = 1..9: out[0], out[10], out[2], out[11], out[4], out[5], out[12], out[7], out[8] of harp_vgg16_features).  Same
@@ -563,6 +571,8 @@ typedef struct harp_vgg16_term_args {
   const int32_t* tile_list[4];
   const int32_t* tile_count[4];
   int max_tiles[4];
+  const int32_t* tile_origin[4];   /* (T,2) even (oy, ox) per frame and level: tile (ty, tx) covers pixels [16 ty - oy, +16) x [16 tx - ox, +16) */
+  int tile_pitch[4];               /* tiles per row (= rows) of tiles[L]; tile_list[L] entries are ty * pitch + tx */
 } harp_vgg16_term_args;
 size_t harp_vgg16_ws_bytes(int N, int S, int with_gradient);
 int harp_vgg16_features(const harp_vgg16* net, const float* image, const float* mask, const int32_t* rows, int N, int S, void* ws,

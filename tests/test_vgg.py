@@ -94,13 +94,18 @@ def test_active_tiles_cover_every_feature_difference():
                     level += 1
                 if not isinstance(layer, torch.nn.ReLU):
                     continue
-                tiles, order, count, mx = bound[level]
-                nt = (ha.shape[-1] + 15) // 16
+                tiles, order, count, mx, origin, G = bound[level]
                 differs = (ha != hb).any(1)                                    # (2, s, s)
-                per_tile = torch.nn.functional.max_pool2d(differs.float()[:, None], 16, 16, ceil_mode=True)[:, 0].reshape(2, nt * nt) > 0
-                assert not (per_tile & (tiles == 0)).any(), (n, level)
-                assert per_tile.any()
-                checked += 1
-                for f in range(2):                                             # the lists hold exactly the flagged tiles, in raster order
+                assert differs.any()
+                for f in range(2):
+                    ys, xs = torch.nonzero(differs[f], as_tuple=True)
+                    cell = ((ys + origin[f, 0]) // 16) * G + (xs + origin[f, 1]) // 16          # tile (ty, tx) covers [16 ty - oy, +16) x [16 tx - ox, +16)
+                    assert tiles[f][cell].all(), (n, level, f)
+                    assert origin[f, 0] % 2 == 0 and origin[f, 1] % 2 == 0 and 0 <= origin[f].min() and origin[f].max() <= 14
+                    # the lists hold exactly the flagged tiles, in raster order
                     assert order[f, :count[f]].tolist() == torch.nonzero(tiles[f]).flatten().tolist()
-    assert checked == 10 and bound[0][2][0] < 36                               # (frame 0: a few of the 36 level-0 tiles)
+                checked += 1
+    assert checked == 10 and bound[0][2][0] <= 4                               # (frame 0: a few pixels -> at most 2 x 2 level-0 tiles)
+    # the shifted grid never needs more tiles than the aligned one
+    for (a, b) in zip(bound, active_tiles(mask, shift_grid=False)):
+        assert (a[2] <= b[2]).all() and (b[4] == 0).all()
