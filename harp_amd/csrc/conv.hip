@@ -517,13 +517,18 @@ constexpr int kGRow = 20;                                   // LDS row pitch (fl
 __global__ __launch_bounds__(256) void vgg_grad_image_kernel(const float* __restrict__ G, const float* __restrict__ w0t, const float* __restrict__ rgb,
                                                              const float* __restrict__ y_true, const float* __restrict__ mask,
                                                              const int32_t* __restrict__ rows, const int32_t* __restrict__ covered, int S, float scale0,
-                                                             float weight, float* __restrict__ g_rgb, const double* __restrict__ loss_acc,
+                                                             float weight, float* __restrict__ g_rgb, double* __restrict__ loss_acc,
                                                              float* __restrict__ loss_out, const int32_t* __restrict__ tiles,
                                                              const int32_t* __restrict__ origin, int pitch) {
   __shared__ float4 patch[4 * kPatch * kGRow];
   const int t = threadIdx.x, tx = t & 15, ty = t >> 4;
   const int n = blockIdx.z, x0 = blockIdx.x * kCT, y0 = blockIdx.y * kCT;
-  if (loss_out && t == 0 && blockIdx.x == 0 && blockIdx.y == 0 && n == 0) loss_out[0] = (float)loss_acc[0];
+  // (the accumulator is complete: every forward launch is behind this one on the stream.  It is handed back ZERO for the next call — the
+  //  workspace starts zero-filled —, so the term needs no clear of its own: a captured hipMemsetAsync did not re-execute on replay, App. A)
+  if (t == 0 && blockIdx.x == 0 && blockIdx.y == 0 && n == 0) {
+    if (loss_out) loss_out[0] = (float)loss_acc[0];
+    loss_acc[0] = 0.0;
+  }
   const float* __restrict__ Gn = G + (size_t)n * S * S * 64;
   // bounded mode: G exists in the frame's active 16x16 tiles only (zero elsewhere); a tile that is not active has no gradient from the stack
   const size_t fr = rows ? (size_t)rows[n] : (size_t)n;
@@ -749,7 +754,6 @@ int harp_vgg16_term(const harp_vgg16* net, const harp_vgg16_term_args* t, hipStr
   const VggWs w = vgg_ws_split(t->ws, N, S, 1);
   float scale[5];
   vgg_scales(net, N, S, scale);
-  if (hipMemsetAsync(w.loss, 0, sizeof(double), stream) != hipSuccess) return HARP_ERR_LAUNCH;
   hipLaunchKernelGGL(vgg_prep_kernel, dim3((S * S + 255) / 256, N), dim3(256), 0, stream, t->rgb, (const int32_t*)nullptr, t->mask, t->rows, t->y_true, S,
                      scale[0], w.x0, w.loss);
   HARP_CHECK_LAUNCH();

@@ -143,7 +143,10 @@ def optimize_hand_sequence(configs, input_params, images_dataset, val_params, va
         from .model.vgg import Vgg16Features
         vgg = Vgg16Features(layers_weights=[1, 1 / 16, 1 / 8, 1 / 4, 1], weights=configs["vgg_weights"])
     if vgg is not None:
-        eng.set_perceptual(vgg, weight=1.0)
+        # configs["vgg_precision"]: 0 (default) float32 MFMA — a float32 fma chain like the reference's fp32 convolutions; 1 three-term bf16
+        # split (2.5x faster, ~16 mantissa bits per product; the reference's own stack allows TF32 here).  configs["vgg_cache_bytes"]: HBM the
+        # cached target activations may take (default 128 GB: 307 MB per 512x512 frame for the bounded mode, FitEngine.set_perceptual)
+        eng.set_perceptual(vgg, weight=1.0, precision=int(configs.get("vgg_precision", 0)), cache_bytes=int(configs.get("vgg_cache_bytes", 128 << 30)))
     eng.keep_image = False                                           # the fused L1 consumes y_pred in the shader; nothing reads the image back
     eng.accumulate_loss = True
     eng.lean_app_stage = True                                        # the appearance-only stage steps opt_app alone (:264-310, :567-573): no geometry gradients are formed for it
