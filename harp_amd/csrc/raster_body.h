@@ -86,7 +86,7 @@ struct RasterSmem {
   // face scan: staged faces ordered by the number of 4x4 blocks their bbox covers in this tile (counting sort, descending), so that the
   // four 16-lane groups of a wave walk faces of (nearly) equal length; faces whose bbox holds no pixel centre drop out
   unsigned char perm[MODE <= 1 ? kStage : 1];
-  int hist[MODE <= 1 ? 20 : 1];
+  int hist[MODE <= 1 ? 36 : 1];
   // MODE 1, soft silhouette: sat = some face covers the pixel deeper than the sigmoid's float32 range (alpha = 1 exactly);
   // prodl = running product of (1 - p) over the other faces within the blur radius, in ascending face order; cand = pixels not (yet) saturated
   int sat[MODE == 1 ? 256 : 1];
@@ -368,7 +368,13 @@ __device__ __forceinline__ void raster_tile(RasterSmem<MODE>& sm, unsigned vbloc
       //      4x4 blocks; the nearest face of a pixel is a 64-bit LDS min over (depth bits, face id) — the same (pixel, face) pairs,
       //      the same depth expression and the same tie-break (lower id) as the strip walk below, where every face of a strip's hit
       //      list was classified by all 64 lanes of the strip (~8 % of them inside its bbox).
-      const int grp = threadIdx.x >> 4, gl = threadIdx.x & 15, lx = gl & 3, ly = gl >> 2;
+      // RASTER_BH: rows of a scan block (4: a 16-lane group per face, 4x4 blocks; 2: an 8-lane group per face, 4x2 blocks — twice the faces per
+      // wave instruction and less of a small bbox's last block wasted; same (pixel, face) pairs and arithmetic either way)
+#ifndef RASTER_BH
+#define RASTER_BH 4
+#endif
+      constexpr int kBH = RASTER_BH, kGrp = 4 * kBH, kGroups = 256 / kGrp, kMaxNb = 4 * (16 / kBH);
+      const int grp = threadIdx.x / kGrp, gl = threadIdx.x % kGrp, lx = gl & 3, ly = gl >> 2;
       const float hs = 0.5f * (float)S;
       // ---- order the staged faces by block count (descending): thread = staged face
       int nscan = nl;
@@ -378,22 +384,22 @@ __device__ __forceinline__ void raster_tile(RasterSmem<MODE>& sm, unsigned vbloc
           const float4 q = s_bb[threadIdx.x];
           const int x0 = max((int)ceilf((1.0f - q.y) * hs - 0.501f), tx0), x1 = min(min((int)floorf((1.0f - q.x) * hs - 0.499f), tx0 + kTile - 1), S - 1);
           const int y0 = max((int)ceilf((1.0f - q.w) * hs - 0.501f), ty0), y1 = min(min((int)floorf((1.0f - q.z) * hs - 0.499f), ty0 + kTile - 1), S - 1);
-          if (x0 <= x1 && y0 <= y1) nb = (((x1 - x0) >> 2) + 1) * (((y1 - y0) >> 2) + 1);      // 1 .. 16
+          if (x0 <= x1 && y0 <= y1) nb = (((x1 - x0) >> 2) + 1) * (((y1 - y0) / kBH) + 1);      // 1 .. kMaxNb
         }
-        if (threadIdx.x < 20) sm.hist[threadIdx.x] = 0;
+        if (threadIdx.x < 36) sm.hist[threadIdx.x] = 0;
         __syncthreads();
         int rank = 0;
-        if (nb > 0) rank = atomicAdd(&sm.hist[16 - nb], 1);
+        if (nb > 0) rank = atomicAdd(&sm.hist[kMaxNb - nb], 1);
         __syncthreads();
         int base_b = 0;
-        for (int i = 0; i < 16 - nb; ++i) base_b += sm.hist[i];
+        for (int i = 0; i < kMaxNb - nb; ++i) base_b += sm.hist[i];
         if (nb > 0) sm.perm[base_b + rank] = (unsigned char)threadIdx.x;
         int tot = 0;
-        for (int i = 0; i < 16; ++i) tot += sm.hist[i];
+        for (int i = 0; i < kMaxNb; ++i) tot += sm.hist[i];
         nscan = tot;
         __syncthreads();
       }
-      for (int k0 = 0; k0 < nscan; k0 += 16) {
+      for (int k0 = 0; k0 < nscan; k0 += kGroups) {
         const int ks = k0 + grp;
         const bool valid = ks < nscan;
         const int kk = valid ? (int)sm.perm[ks] : 0;
@@ -448,7 +454,7 @@ __device__ __forceinline__ void raster_tile(RasterSmem<MODE>& sm, unsigned vbloc
               }
             }
             bx += 4;
-            if (bx > x1) { bx = x0; by += 4; }
+            if (bx > x1) { bx = x0; by += kBH; }
             more = by <= y1;
           }
         }
