@@ -269,3 +269,42 @@ def test_filters_from_a_torchvision_state_dict_file(tmp_path):
     torch.cuda.synchronize()
     rel = ((g_rgb.double().cpu() - g_want).norm() / g_want.norm()).item()
     assert abs(loss.item() - want.item()) < 2e-5 * want.item() and rel < 2e-3, (loss.item(), want.item(), rel)
+
+
+@pytest.mark.parametrize("precision", [0, 1])
+def test_hip_features_reproduce_the_reference_modules_golden_rows(golden_dir, precision):
+    """the HIP convolution stack against rows written by the REFERENCE's own model/vgg.py (tests/golden/vgg_ref.npz, see
+    tests/golden/make_golden_vgg.py): the four taps harp_vgg16_features returns are the reference row's segments (flattened NCHW, scaled by
+    layers_weights), and harp_vgg16_term's loss between two images is torch.nn.L1Loss of the reference's two rows (optimize_sequence.py:546-547)"""
+    import os
+    import sys
+    import numpy as np
+    from harp_amd.model.vgg import Vgg16Features
+    from harp_amd.model.vgg_hip import Vgg16Hip
+    sys.path.insert(0, golden_dir)
+    from vgg_filters import state_dict_torchvision_layout
+    ref = np.load(os.path.join(golden_dir, "vgg_ref.npz"))
+    x = torch.from_numpy(ref["x"])                                   # (2,3,16,16)
+    N, S = x.shape[0], x.shape[-1]
+    LW = [float(v) for v in ref["layers_weights_fit"]]
+    vgg = Vgg16Features(layers_weights=LW, weights=state_dict_torchvision_layout())
+    hip = Vgg16Hip(vgg, DEV, precision)
+    img = x.permute(0, 2, 3, 1).contiguous().to(DEV)                 # NHWC
+    ones = torch.ones(N, S, S, device=DEV)
+    taps = hip.features(img, ones)
+    row = torch.from_numpy(ref["y_fit"]).double()
+    off = 3 * S * S
+    assert torch.allclose(row[:, :off], LW[0] * x.flatten(1).double())
+    for f, w in zip(taps, LW[1:]):
+        seg = w * _nchw(f).flatten(1).double().cpu()
+        want = row[:, off:off + seg.shape[1]]
+        assert ((seg - want).abs().max() / want.abs().max()).item() < 4 * TOL[precision]
+        off += seg.shape[1]
+    assert off == row.shape[1]
+    # the term: image 0 against image 1 as its target (mask of ones)
+    want = (row[0] - row[1]).abs().mean().item()
+    g_rgb, loss = torch.zeros(1, S, S, 3, device=DEV), torch.zeros(1, device=DEV)
+    rows = torch.tensor([1], dtype=torch.int32, device=DEV)
+    hip.term(img[:1].contiguous(), img, ones, rows, taps, 1, g_rgb, loss)
+    torch.cuda.synchronize()
+    assert abs(loss.item() - want) < 2e-5 * want, (loss.item(), want)

@@ -109,3 +109,29 @@ def test_active_tiles_cover_every_feature_difference():
     # the shifted grid never needs more tiles than the aligned one
     for (a, b) in zip(bound, active_tiles(mask, shift_grid=False)):
         assert (a[2] <= b[2]).all() and (b[4] == 0).all()
+
+
+def test_module_reproduces_the_reference_modules_golden_rows(golden_dir):
+    """tests/golden/vgg_ref.npz was written by the REFERENCE's own model/vgg.py (imported from /root/reference by
+    tests/golden/make_golden_vgg.py, with only the absent `torchvision.models.vgg16` constructor stubbed by the published layer sequence +
+    seeded filters): this package's Vgg16Features, fed the same filters in torchvision's state-dict layout, returns the same rows — slices,
+    taps, default and explicit layers_weights, concatenation order, state-dict keys."""
+    import os
+    import sys
+    import numpy as np
+    from harp_amd.model.vgg import Vgg16Features
+    sys.path.insert(0, golden_dir)
+    from vgg_filters import state_dict_torchvision_layout
+    ref = np.load(os.path.join(golden_dir, "vgg_ref.npz"))
+    x = torch.from_numpy(ref["x"])
+    sd = state_dict_torchvision_layout()
+    with torch.no_grad():
+        for key, lw in (("y_default", None), ("y_fit", list(ref["layers_weights_fit"]))):
+            m = Vgg16Features(layers_weights=lw, weights=sd)
+            y = m(x)
+            assert y.shape == ref[key].shape
+            assert torch.allclose(y, torch.from_numpy(ref[key]), rtol=0, atol=2e-6), (key, (y - torch.from_numpy(ref[key])).abs().max())
+            if lw is None:
+                assert np.allclose(m.layers_weights, ref["layers_weights_default"])
+    assert sorted(m.state_dict().keys()) == list(ref["state_dict_keys"])
+    assert all(not p.requires_grad for p in m.parameters())
