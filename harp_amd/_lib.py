@@ -200,6 +200,17 @@ SIGNATURES["harp_hand_front_fwd"] = (_i, [ctypes.POINTER(HandFront), _vp])
 SIGNATURES["harp_hand_back_bwd"] = (_i, [ctypes.POINTER(HandFront), _vp, _vp, _vp])
 
 
+class ArmFront(ctypes.Structure):
+    """mirror of `harp_arm_front` (include/harp_hip.h)"""
+    _fields_ = ([("chain", MeshChain), ("tree", TreeModel), ("tables", FrameTables), ("fid", _vp)] +
+                [(n, _vp) for n in ("pose_in", "betas", "trans_b", "cam_R", "cam_T", "light_pos", "colors", "lbs_ws", "weights_T")] +
+                [("self_shadow", _i), ("step", StepFrame)])
+
+
+SIGNATURES["harp_arm_front_fwd"] = (_i, [ctypes.POINTER(ArmFront), _vp])
+SIGNATURES["harp_arm_back_bwd"] = (_i, [ctypes.POINTER(ArmFront), _vp, _vp, _vp, _vp])
+
+
 class Conv3x3Args(ctypes.Structure):
     """mirror of `harp_conv3x3_args` (include/harp_hip.h)"""
     _fields_ = ([(n, _vp) for n in ("in_", "filters", "bias", "out", "pooled", "target", "target_row", "g_tap", "loss", "gate")] +

@@ -7,116 +7,18 @@
 // (I + sin K + (1-cos) K^2, angle = |r + 1e-8|), arbitrary parents[] (parents[j] < j), an input->joint map (only the root, the
 // right wrist and the 15 right-hand joints are driven), recentring on one chain joint, and output joints that are either chain
 // joints or mesh vertices (finger tips).
-#include "harp_common.h"
-#include "harp_hip.h"
+#include "lbs_tree_body.h"
 
 namespace {
 
-constexpr int MAXJ = 64;          // joints
-constexpr int MAXB = 32;          // shape coefficients
+using namespace lt;
 
-// smplx.lbs.batch_rodrigues
-__device__ __forceinline__ void rod_fwd(const float r[3], float R[9]) {
-  const float e0 = r[0] + 1e-8f, e1 = r[1] + 1e-8f, e2 = r[2] + 1e-8f;
-  const float th = sqrtf(e0 * e0 + e1 * e1 + e2 * e2);
-  const float dx = r[0] / th, dy = r[1] / th, dz = r[2] / th;
-  const float s = sinf(th), c = 1.0f - cosf(th);
-  // K = [[0,-dz,dy],[dz,0,-dx],[-dy,dx,0]];  K^2 = d d^T - |d|^2 I
-  const float n2 = dx * dx + dy * dy + dz * dz;
-  R[0] = 1.f + c * (dx * dx - n2); R[1] = -s * dz + c * dx * dy;    R[2] = s * dy + c * dx * dz;
-  R[3] = s * dz + c * dx * dy;     R[4] = 1.f + c * (dy * dy - n2); R[5] = -s * dx + c * dy * dz;
-  R[6] = -s * dy + c * dx * dz;    R[7] = s * dx + c * dy * dz;     R[8] = 1.f + c * (dz * dz - n2);
-}
-
-__device__ __forceinline__ void rod_bwd(const float r[3], const float g[9], float gr[3]) {
-  const float e[3] = {r[0] + 1e-8f, r[1] + 1e-8f, r[2] + 1e-8f};
-  const float th = sqrtf(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]);
-  const float d[3] = {r[0] / th, r[1] / th, r[2] / th};
-  const float s = sinf(th), cs = cosf(th), c = 1.0f - cs;
-  const float n2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
-  const float K[9] = {0.f, -d[2], d[1], d[2], 0.f, -d[0], -d[1], d[0], 0.f};
-  float K2[9];
-  for (int i = 0; i < 3; ++i)
-    for (int j = 0; j < 3; ++j) K2[i * 3 + j] = d[i] * d[j] - (i == j ? n2 : 0.f);
-  float g_th = 0.f;
-  for (int k = 0; k < 9; ++k) g_th += g[k] * (cs * K[k] + s * K2[k]);
-  // R = I + s K + c K K:  g_K = s G + c (G K^T + K^T G)
-  float gK[9];
-  for (int i = 0; i < 3; ++i)
-    for (int j = 0; j < 3; ++j) {
-      float a = 0.f;
-      for (int m = 0; m < 3; ++m) a += g[i * 3 + m] * K[j * 3 + m] + K[m * 3 + i] * g[m * 3 + j];
-      gK[i * 3 + j] = s * g[i * 3 + j] + c * a;
-    }
-  const float gd[3] = {gK[7] - gK[5], gK[2] - gK[6], gK[3] - gK[1]};
-  g_th -= (d[0] * gd[0] + d[1] * gd[1] + d[2] * gd[2]) / th;
-  for (int k = 0; k < 3; ++k) gr[k] = gd[k] / th + g_th * e[k] / th;
-}
-
-// one wave per frame.  in_pose (B, n_in, 3); writes pose_map (B,NP), A (B,NJ,12), G (B,NJ,12), Jrest (B,NJ,3), Rloc (B,NJ,9)
+// one wave per frame.  in_pose (B, n_in, 3); writes pose_map (B,NP), A (B,NJ,12), G (B,NJ,12), Jrest (B,NJ,3), Rloc (B,NJ,9)  (lbs_tree_body.h)
 __global__ void __launch_bounds__(64) tree_joints_kernel(const harp_tree_model M, const float* __restrict__ in_pose,
-                                                         const float* __restrict__ betas, float* __restrict__ pose_map,
-                                                         float* __restrict__ A, float* __restrict__ G, float* __restrict__ Jrest,
-                                                         float* __restrict__ Rloc, float* __restrict__ z_pm, float* __restrict__ z_Gt) {
-  __shared__ float sR[MAXJ][9], sJ[MAXJ][3], sG[MAXJ][12];
-  const int b = blockIdx.x, l = threadIdx.x, NJ = M.NJ, NB = M.NB, NP = (NJ - 1) * 9;
-  // the backward pass accumulates into g_pm / g_Gt with atomics: cleared here, off the backward tail (the chain backward clears what it
-  // consumes, so a second backward call on the same workspace starts from zero as well)
-  for (int k = l; k < NP; k += 64) z_pm[(size_t)b * NP + k] = 0.f;
-  for (int k = l; k < NJ * 3; k += 64) z_Gt[(size_t)b * NJ * 3 + k] = 0.f;
-  for (int j = l; j < NJ; j += 64) {
-    float aa[3];
-    const int src = M.pose_src[j];
-    for (int c = 0; c < 3; ++c) aa[c] = M.pose_mean[3 * j + c] + (src >= 0 ? in_pose[((size_t)b * M.n_pose_in + src) * 3 + c] : 0.f);
-    float R[9];
-    rod_fwd(aa, R);
-    for (int k = 0; k < 9; ++k) { sR[j][k] = R[k]; Rloc[((size_t)b * NJ + j) * 9 + k] = R[k]; }
-    if (j > 0)
-      for (int k = 0; k < 9; ++k) pose_map[(size_t)b * NP + (j - 1) * 9 + k] = R[k] - ((k == 0 || k == 4 || k == 8) ? 1.f : 0.f);
-  }
-  for (int i = l; i < NJ * 3; i += 64) {
-    float acc = M.J_template[i];
-    for (int k = 0; k < NB; ++k) acc += M.J_dirs[i * NB + k] * betas[b * NB + k];
-    sJ[i / 3][i % 3] = acc;
-    Jrest[(size_t)b * NJ * 3 + i] = acc;
-  }
-  __syncthreads();
-  // batch_rigid_transform: chain[i] = chain[parent] @ [R_i | J_i - J_parent].  Level-parallel: lane j waits until its parent's depth has
-  // been processed (the SMPL-X right-arm tree is 11 levels deep, 55 joints: 11 steps instead of 55 serial products on one lane)
-  {
-    const int j = l;
-    int depth = 0;
-    if (j < NJ) for (int q = M.parents[j]; q >= 0; q = M.parents[q]) ++depth;
-    int maxd = depth;
-#pragma unroll
-    for (int o2 = 32; o2 > 0; o2 >>= 1) maxd = max(maxd, __shfl_xor(maxd, o2, 64));
-    if (j == 0) {
-      for (int k = 0; k < 9; ++k) sG[0][(k / 3) * 4 + (k % 3)] = sR[0][k];
-      for (int r = 0; r < 3; ++r) sG[0][r * 4 + 3] = sJ[0][r];
-    }
-    for (int d = 1; d <= maxd; ++d) {
-      __syncthreads();                    // (one wave: orders the LDS traffic of the previous level)
-      if (j < NJ && depth == d) {
-        const int p = M.parents[j];
-        const float rel[3] = {sJ[j][0] - sJ[p][0], sJ[j][1] - sJ[p][1], sJ[j][2] - sJ[p][2]};
-        for (int r = 0; r < 3; ++r) {
-          for (int c = 0; c < 3; ++c)
-            sG[j][r * 4 + c] = sG[p][r * 4] * sR[j][c] + sG[p][r * 4 + 1] * sR[j][3 + c] + sG[p][r * 4 + 2] * sR[j][6 + c];
-          sG[j][r * 4 + 3] = sG[p][r * 4] * rel[0] + sG[p][r * 4 + 1] * rel[1] + sG[p][r * 4 + 2] * rel[2] + sG[p][r * 4 + 3];
-        }
-      }
-    }
-  }
-  __syncthreads();
-  for (int j = l; j < NJ; j += 64) {
-    float* Ao = A + ((size_t)b * NJ + j) * 12;
-    float* Go = G + ((size_t)b * NJ + j) * 12;
-    for (int r = 0; r < 3; ++r) {
-      for (int c = 0; c < 3; ++c) { Ao[r * 4 + c] = sG[j][r * 4 + c]; Go[r * 4 + c] = sG[j][r * 4 + c]; }
-      Go[r * 4 + 3] = sG[j][r * 4 + 3];
-      Ao[r * 4 + 3] = sG[j][r * 4 + 3] - (sG[j][r * 4] * sJ[j][0] + sG[j][r * 4 + 1] * sJ[j][1] + sG[j][r * 4 + 2] * sJ[j][2]);
-    }
-  }
+                                                         const float* __restrict__ betas, const TreeWs W) {
+  __shared__ JointsLds S;
+  const int b = blockIdx.x;
+  joints_body<64>(M, in_pose + (size_t)b * M.n_pose_in * 3, betas + b * M.NB, b, W, S);
 }
 
 // ---- dense contractions on the matrix cores ------------------------------------------------------------------------------------
@@ -124,7 +26,7 @@ __global__ void __launch_bounds__(64) tree_joints_kernel(const harp_tree_model M
 // A[l & 15][l >> 4], B[l >> 4][l & 15] and D[(l >> 4) * 4 + r][l & 15], r = 0..3.  These are the contractions BASELINE.json's
 // north_star reserves MFMA for; on the SMPL-X arm (C5) their VALU forms were 17 % of the step (profiles/r02_c5_kernel_stats.txt:
 // tree_skin 111 + 119 us, tree_gA 65 us, tree_gpm 63 us of 2.73 ms; tools/dev/micro/mfma_poseblend.hip: 39 -> 10 us for the blend).
-typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int kBatch = 8;      // MFMA steps whose operand loads are in flight together
 
 // v_posed(b, m) = v_template[m] + sum_k pose_map(b,k) posedirs_T[k][m] + sum_k betas(b,k) shapedirs_T[k][m]      (smplx.lbs, Appendix A.13)
 // workgroup = 16 frames x 16 columns of NV*3, its 4 waves split the K = NP + NB reduction, LDS sum, one store.
@@ -139,17 +41,25 @@ __global__ void __launch_bounds__(256) tree_blend_mfma_kernel(const harp_tree_mo
   const bool row_ok = row < B;
   const int steps = (K + 3) / 4, per = (steps + 3) / 4;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  for (int st = w * per; st < min(steps, (w + 1) * per); ++st) {
-    const int k = 4 * st + (lane >> 4);
-    float a = 0.f, bv = 0.f;
-    if (k < NP) {
-      if (row_ok) a = pose_map[(size_t)row * NP + k];
-      if (col_ok) bv = M.posedirs_T[(size_t)k * NV3 + col];
-    } else if (k < K) {
-      if (row_ok) a = betas[row * NB + (k - NP)];
-      if (col_ok) bv = M.shapedirs_T[(size_t)(k - NP) * NV3 + col];
+  // kBatch steps' operands are requested together (clamped addresses, zeroed by select): the loop used to be load -> s_waitcnt vmcnt(0) ->
+  // MFMA, one memory round trip per step — 31 in a row per wave, 41 us for a contraction that takes 10 (the blend-shape rows do not stay in L2
+  // from one step to the next).  Padding steps multiply zeros: the accumulation order of the real ones is unchanged.
+  const int colc = min(col, NV3 - 1), rowc = min(row, B - 1);
+  const int s_lo = w * per, s_hi = min(steps, (w + 1) * per);
+  for (int st0 = s_lo; st0 < s_hi; st0 += kBatch) {
+    float a[kBatch], bv[kBatch];
+#pragma unroll
+    for (int u = 0; u < kBatch; ++u) {
+      const int k = 4 * (st0 + u) + (lane >> 4), kc = min(k, K - 1);
+      const float* pa = (kc < NP) ? pose_map + (size_t)rowc * NP + kc : betas + rowc * NB + (kc - NP);
+      const float* pb = (kc < NP) ? M.posedirs_T + (size_t)kc * NV3 + colc : M.shapedirs_T + (size_t)(kc - NP) * NV3 + colc;
+      a[u] = *pa; bv[u] = *pb;
     }
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv, acc, 0, 0, 0);
+#pragma unroll
+    for (int u = 0; u < kBatch; ++u) {
+      const bool ok = (st0 + u < s_hi) && (4 * (st0 + u) + (lane >> 4) < K);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32((ok && row_ok) ? a[u] : 0.f, (ok && col_ok) ? bv[u] : 0.f, acc, 0, 0, 0);
+    }
   }
   s_acc[w][lane] = acc;
   __syncthreads();
@@ -269,14 +179,23 @@ __global__ void __launch_bounds__(256) tree_gA_mfma_kernel(const harp_tree_model
   const float* gb = g_verts + (size_t)b * NV * 3;
   const float* pb = vp + (size_t)b * NV * 3;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  for (int st = w * per; st < min(steps, (w + 1) * per); ++st) {
-    const int v = 4 * st + (lane >> 4);
-    float a = 0.f, bv = 0.f;
-    if (v < NV) {
-      if (ja < NJ) a = M.weights[(size_t)v * NJ + ja];
-      if (cb < 12) bv = gb[3 * v + (cb >> 2)] * 1000.0f * (((cb & 3) < 3) ? pb[3 * v + (cb & 3)] : 1.0f);
+  const int jac = min(ja, NJ - 1), cbc = min(cb, 11);
+  const int s_lo = w * per, s_hi = min(steps, (w + 1) * per);
+  for (int st0 = s_lo; st0 < s_hi; st0 += kBatch) {          // operands of kBatch steps in flight together (see tree_blend_mfma_kernel)
+    float a[kBatch], g[kBatch], q[kBatch];
+#pragma unroll
+    for (int u = 0; u < kBatch; ++u) {
+      const int vc = min(4 * (st0 + u) + (lane >> 4), NV - 1);
+      a[u] = M.weights[(size_t)vc * NJ + jac];
+      g[u] = gb[3 * vc + (cbc >> 2)];
+      q[u] = pb[3 * vc + min(cbc & 3, 2)];
     }
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv, acc, 0, 0, 0);
+#pragma unroll
+    for (int u = 0; u < kBatch; ++u) {
+      const bool ok = (st0 + u < s_hi) && (4 * (st0 + u) + (lane >> 4) < NV);
+      const float bv = g[u] * 1000.0f * (((cb & 3) < 3) ? q[u] : 1.0f);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32((ok && ja < NJ) ? a[u] : 0.f, (ok && cb < 12) ? bv : 0.f, acc, 0, 0, 0);
+    }
   }
   s_acc[w][lane] = acc;
   __syncthreads();
@@ -304,15 +223,20 @@ __global__ void __launch_bounds__(256) tree_gpm_mfma_kernel(const harp_tree_mode
   const int steps = (NV3 + 3) / 4, per_wg = (steps + kSplitP - 1) / kSplitP, per = (per_wg + 3) / 4;
   const int s_lo = blockIdx.z * per_wg + w * per, s_hi = min(min(steps, (int)(blockIdx.z + 1) * per_wg), s_lo + per);
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  for (int st = s_lo; st < s_hi; ++st) {
-    const int i = 4 * st + (lane >> 4);
-    float a = 0.f, bv = 0.f;
-    if (i < NV3) {
-      if (row < B) a = g_vp[(size_t)row * NV3 + i];
-      if (col < NP) bv = M.posedirs[(size_t)i * NP + col];
-      else if (col < K) bv = M.shapedirs_T[(size_t)(col - NP) * NV3 + i];
+  const int rowc = min(row, B - 1), colc = min(col, K - 1);
+  for (int st0 = s_lo; st0 < s_hi; st0 += kBatch) {          // operands of kBatch steps in flight together (see tree_blend_mfma_kernel)
+    float a[kBatch], bv[kBatch];
+#pragma unroll
+    for (int u = 0; u < kBatch; ++u) {
+      const int ic = min(4 * (st0 + u) + (lane >> 4), NV3 - 1);
+      const float* pb = (colc < NP) ? M.posedirs + (size_t)ic * NP + colc : M.shapedirs_T + (size_t)(colc - NP) * NV3 + ic;
+      a[u] = g_vp[(size_t)rowc * NV3 + ic]; bv[u] = *pb;
     }
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv, acc, 0, 0, 0);
+#pragma unroll
+    for (int u = 0; u < kBatch; ++u) {
+      const bool ok = (st0 + u < s_hi) && (4 * (st0 + u) + (lane >> 4) < NV3);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32((ok && row < B) ? a[u] : 0.f, (ok && col < K) ? bv[u] : 0.f, acc, 0, 0, 0);
+    }
   }
   s_acc[w][lane] = acc;
   __syncthreads();
@@ -329,97 +253,35 @@ __global__ void __launch_bounds__(256) tree_gpm_mfma_kernel(const harp_tree_mode
   }
 }
 
-// one wave per frame: chain + Rodrigues backward
-__global__ void __launch_bounds__(64) tree_chain_bwd_kernel(const harp_tree_model M, const float* __restrict__ in_pose,
-                                                            const float* __restrict__ Rloc, const float* __restrict__ G,
-                                                            const float* __restrict__ Jrest, const float* __restrict__ g_A,
-                                                            float* __restrict__ g_pm, float* __restrict__ g_Gt,
+// one wave per frame: chain + Rodrigues backward (lbs_tree_body.h)
+__global__ void __launch_bounds__(64) tree_chain_bwd_kernel(const harp_tree_model M, const float* __restrict__ in_pose, const TreeWs W,
                                                             float* __restrict__ g_in_pose, float* __restrict__ g_beta_b) {
-  __shared__ float gRG[MAXJ][9], gtG[MAXJ][3], gRl[MAXJ][9], gJ[MAXJ][3];
-  const int b = blockIdx.x, l = threadIdx.x, NJ = M.NJ, NB = M.NB, NP = (NJ - 1) * 9;
-  const float* Gb = G + (size_t)b * NJ * 12;
-  const float* Rb = Rloc + (size_t)b * NJ * 9;
-  const float* Jb = Jrest + (size_t)b * NJ * 3;
-  for (int j = l; j < NJ; j += 64) {
-    const float* ga = g_A + ((size_t)b * NJ + j) * 12;
-    for (int r = 0; r < 3; ++r) {
-      const float gt = ga[r * 4 + 3];
-      for (int c = 0; c < 3; ++c) gRG[j][r * 3 + c] = ga[r * 4 + c] - gt * Jb[j * 3 + c];
-      gtG[j][r] = gt + g_Gt[((size_t)b * NJ + j) * 3 + r];
-      g_Gt[((size_t)b * NJ + j) * 3 + r] = 0.f;          // consumed: the two accumulators are all-zero again for the next backward call
-    }
-    for (int c = 0; c < 3; ++c) {
-      float acc = 0.f;
-      for (int r = 0; r < 3; ++r) acc -= Gb[j * 12 + r * 4 + c] * ga[r * 4 + 3];
-      gJ[j][c] = acc;
-    }
-    for (int k = 0; k < 9; ++k) {
-      gRl[j][k] = (j > 0) ? g_pm[(size_t)b * NP + (j - 1) * 9 + k] : 0.f;
-      if (j > 0) g_pm[(size_t)b * NP + (j - 1) * 9 + k] = 0.f;
-    }
-  }
-  __syncthreads();
-  // chain backward, level-parallel from the leaves up: lane j (depth d) is final once every deeper level has been folded into it;
-  // siblings add into their common parent with LDS atomics (a few dozen per frame)
-  {
-    const int j = l;
-    int depth = 0;
-    if (j < NJ) for (int q = M.parents[j]; q >= 0; q = M.parents[q]) ++depth;
-    int maxd = depth;
-#pragma unroll
-    for (int o2 = 32; o2 > 0; o2 >>= 1) maxd = max(maxd, __shfl_xor(maxd, o2, 64));
-    for (int d = maxd; d >= 1; --d) {
-      __syncthreads();
-      if (j < NJ && depth == d) {
-        const int p = M.parents[j];
-        const float rel[3] = {Jb[j * 3] - Jb[p * 3], Jb[j * 3 + 1] - Jb[p * 3 + 1], Jb[j * 3 + 2] - Jb[p * 3 + 2]};
-        float gl[3];
-        for (int c = 0; c < 3; ++c) gl[c] = Gb[p * 12 + c] * gtG[j][0] + Gb[p * 12 + 4 + c] * gtG[j][1] + Gb[p * 12 + 8 + c] * gtG[j][2];
-        for (int r = 0; r < 3; ++r)
-          for (int c = 0; c < 3; ++c) {
-            gRl[j][r * 3 + c] += Gb[p * 12 + r] * gRG[j][c] + Gb[p * 12 + 4 + r] * gRG[j][3 + c] + Gb[p * 12 + 8 + r] * gRG[j][6 + c];
-            atomicAdd(&gRG[p][r * 3 + c], gRG[j][r * 3] * Rb[j * 9 + c * 3] + gRG[j][r * 3 + 1] * Rb[j * 9 + c * 3 + 1] +
-                                              gRG[j][r * 3 + 2] * Rb[j * 9 + c * 3 + 2] + gtG[j][r] * rel[c]);
-          }
-        for (int c = 0; c < 3; ++c) { atomicAdd(&gtG[p][c], gtG[j][c]); atomicAdd(&gJ[p][c], -gl[c]); gJ[j][c] += gl[c]; }
-      }
-    }
-    __syncthreads();
-    if (j == 0) {
-      for (int k = 0; k < 9; ++k) gRl[0][k] += gRG[0][k];
-      for (int c = 0; c < 3; ++c) gJ[0][c] += gtG[0][c];
-    }
-  }
-  __syncthreads();
-  for (int j = l; j < NJ; j += 64) {
-    const int src = M.pose_src[j];
-    if (src < 0) continue;
-    float aa[3], gaa[3];
-    for (int c = 0; c < 3; ++c) aa[c] = M.pose_mean[3 * j + c] + in_pose[((size_t)b * M.n_pose_in + src) * 3 + c];
-    rod_bwd(aa, gRl[j], gaa);
-    for (int c = 0; c < 3; ++c) g_in_pose[((size_t)b * M.n_pose_in + src) * 3 + c] = gaa[c];
-  }
-  for (int k = l; k < NB; k += 64) {
-    float acc = g_beta_b[b * NB + k];
-    for (int i = 0; i < NJ * 3; ++i) acc += M.J_dirs[i * NB + k] * gJ[i / 3][i % 3];
-    g_beta_b[b * NB + k] = acc;
-  }
+  __shared__ ChainBwdLds S;
+  const int b = blockIdx.x;
+  chain_bwd_body<false>(M, in_pose + (size_t)b * M.n_pose_in * 3, b, W, g_in_pose + (size_t)b * M.n_pose_in * 3, g_beta_b + b * M.NB, S, nullptr, 0);
 }
 
-
-struct TreeWs { float *pm, *A, *G, *Jrest, *Rloc, *vp, *g_vp, *g_A, *g_pm, *g_Gt; };
-TreeWs tree_ws(const harp_tree_model* m, float* ws, int B) {
-  const size_t NJ = m->NJ, NV = m->NV, NP = (NJ - 1) * 9;
-  TreeWs w; float* p = ws;
-  w.pm = p; p += B * NP; w.A = p; p += B * NJ * 12; w.G = p; p += B * NJ * 12; w.Jrest = p; p += B * NJ * 3; w.Rloc = p; p += B * NJ * 9;
-  w.vp = p; p += B * NV * 3; w.g_vp = p; p += B * NV * 3;
-  w.g_A = p; p += B * NJ * 12; w.g_pm = p; p += B * NP; w.g_Gt = p;     // g_pm | g_Gt adjacent (zeroed together)
-  return w;
-}
 
 size_t skin_smem(const harp_tree_model* m) { return sizeof(float) * ((size_t)kSkinV * m->NJ + (size_t)kSkinF * (m->NJ * 12 + 3)); }
 
 }  // namespace
+
+// launchers shared with the fused arm front / back (arm_front.hip): the contractions that stay spread over the chip
+int harp_detail_tree_blend(const harp_tree_model& m, float* ws, const float* betas, int B, hipStream_t stream) {
+  const TreeWs w = tree_ws(&m, ws, B);
+  hipLaunchKernelGGL(tree_blend_mfma_kernel, dim3((m.NV * 3 + 15) / 16, (B + 15) / 16), dim3(256), 0, stream, m, w.pm, betas, B, w.vp);
+  HARP_CHECK_LAUNCH();
+  return HARP_OK;
+}
+
+int harp_detail_tree_gA_gpm(const harp_tree_model& m, float* ws, const float* g_verts, float* g_betas, int B, hipStream_t stream) {
+  const TreeWs w = tree_ws(&m, ws, B);
+  hipLaunchKernelGGL(tree_gA_mfma_kernel, dim3((m.NJ + 15) / 16, B), dim3(256), 0, stream, m, g_verts, w.vp, w.g_A);
+  const int ncol = (m.NJ - 1) * 9 + m.NB;
+  hipLaunchKernelGGL(tree_gpm_mfma_kernel, dim3((ncol + 15) / 16, (B + 15) / 16, kSplitP), dim3(256), 0, stream, m, w.g_vp, B, w.g_pm, g_betas);
+  HARP_CHECK_LAUNCH();
+  return HARP_OK;
+}
 
 extern "C" {
 
@@ -432,7 +294,7 @@ int harp_lbs_tree_fwd(const harp_tree_model* m, const float* in_pose, const floa
                       float* verts, float* joints, hipStream_t stream) {
   if (!m || !in_pose || !betas || !transl || !ws || !verts || !joints || B <= 0 || m->NJ > MAXJ || m->NB > MAXB) return HARP_ERR_ARG;
   const TreeWs w = tree_ws(m, ws, B);
-  hipLaunchKernelGGL(tree_joints_kernel, dim3(B), dim3(64), 0, stream, *m, in_pose, betas, w.pm, w.A, w.G, w.Jrest, w.Rloc, w.g_pm, w.g_Gt);
+  hipLaunchKernelGGL(tree_joints_kernel, dim3(B), dim3(64), 0, stream, *m, in_pose, betas, w);
   hipLaunchKernelGGL(tree_blend_mfma_kernel, dim3((m->NV * 3 + 15) / 16, (B + 15) / 16), dim3(256), 0, stream, *m, w.pm, betas, B, w.vp);
   hipLaunchKernelGGL(tree_skin_kernel<false>, dim3((m->NV + kSkinV - 1) / kSkinV, (B + kSkinF - 1) / kSkinF), dim3(256), skin_smem(m), stream, *m,
                      transl, w.vp, w.A, w.G, B, verts, nullptr, nullptr);
@@ -456,8 +318,7 @@ int harp_lbs_tree_bwd(const harp_tree_model* m, const float* in_pose, const floa
   hipLaunchKernelGGL(tree_gA_mfma_kernel, dim3((m->NJ + 15) / 16, B), dim3(256), 0, stream, *m, g_verts, w.vp, w.g_A);
   const int ncol = (m->NJ - 1) * 9 + m->NB;
   hipLaunchKernelGGL(tree_gpm_mfma_kernel, dim3((ncol + 15) / 16, (B + 15) / 16, kSplitP), dim3(256), 0, stream, *m, w.g_vp, B, w.g_pm, g_betas);
-  hipLaunchKernelGGL(tree_chain_bwd_kernel, dim3(B), dim3(64), 0, stream, *m, in_pose, w.Rloc, w.G, w.Jrest, w.g_A, w.g_pm, w.g_Gt, g_in_pose,
-                     g_betas);
+  hipLaunchKernelGGL(tree_chain_bwd_kernel, dim3(B), dim3(64), 0, stream, *m, in_pose, w, g_in_pose, g_betas);
   HARP_CHECK_LAUNCH();
   return HARP_OK;
 }

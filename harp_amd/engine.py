@@ -159,7 +159,10 @@ class FitEngine:
         # per-frame fused mesh chain (csrc/chain.hip): 22 launches -> 2; needs the frame's mesh to fit its LDS staging
         self.fused_chain = self.topo.V <= _lib.lib().harp_mesh_chain_max_vertices()
         # MANO path: frame set-up + hand layer + mesh chain + rasteriser set-up of both views as ONE launch (csrc/hand_front.hip)
-        self.fused_front = self.fused_chain and not self.use_arm and self.n_joints == 21
+        # SMPL-X arm path: the same as three + four launches around the shared MFMA contractions (csrc/arm_front.hip)
+        self.fused_front = self.fused_chain and (self.n_joints == 21 or self.use_arm)
+        if self.use_arm:
+            self._weights_T = self.dm.weights.t().contiguous()                       # (NJ, NV): one coalesced row per joint for the per-frame kernels
         self.fused_back = True           # ... and the backward tail as three launches instead of six (csrc/hand_back.hip)
         # ---- switches (all on in production; tools/dev and bench.py flip some of them to measure their effect)
         self.overlap = True              # second HIP stream (light view, silhouette backward, parameter-only terms); False: one stream
@@ -335,13 +338,30 @@ class FitEngine:
         h.self_shadow = int(self.self_shadow)
         return h
 
+    def _arm_struct(self, fid, B, shadow, has_normal_grad, step=None):
+        """harp_arm_front over the active lane's scratch (SMPL-X arm path): csrc/arm_front.hip"""
+        s, p = self.s, _lib.ptr
+        h = _lib.ArmFront()
+        if step is not None:
+            h.step = step
+        h.chain, h.tree, h.tables = self._chain_struct(B, shadow, has_normal_grad), self.dm.struct, self.tables
+        for k, t in (("fid", fid), ("pose_in", s["pose48"]), ("betas", s["betas"]), ("trans_b", s["trans_b"]), ("cam_R", s["cam_R"]),
+                     ("cam_T", s["cam_T"]), ("light_pos", s["light_pos"]), ("colors", s["colors"]), ("lbs_ws", s["lbs_ws"]),
+                     ("weights_T", self._weights_T)):
+            setattr(h, k, p(t))
+        h.self_shadow = int(self.self_shadow)
+        return h
+
     def _mesh_forward(self, fid, B, shadow=False, front=False, step=None):
         """frame_setup .. normals (and, fused, both projections + the light camera): fills the scratch geometry for the B frames in
         `fid` (int32 device tensor).  Returns True when the fused chain ran (projections / light camera already done).  front=True
         allows the one-launch form of the whole front (MANO path, csrc/hand_front.hip)."""
         L, s, p, st, tp = _lib.lib(), self.s, _lib.ptr, _lib.stream(), self.topo
         if front and self.fused_front and self.fused_chain:
-            self._ck(L.harp_hand_front_fwd(ctypes.byref(self._hand_struct(fid, B, shadow, False, step)), st), "hand_front_fwd")
+            if self.use_arm:
+                self._ck(L.harp_arm_front_fwd(ctypes.byref(self._arm_struct(fid, B, shadow, False, step)), st), "arm_front_fwd")
+            else:
+                self._ck(L.harp_hand_front_fwd(ctypes.byref(self._hand_struct(fid, B, shadow, False, step)), st), "hand_front_fwd")
             return True
         if step is not None:
             raise RuntimeError("a folded step needs the one-launch front (fused_front)")
@@ -710,8 +730,12 @@ class FitEngine:
             wait_s(cur, side)                       # silhouette_bwd -> g_ndc_c (normal-map chain rule with tail_side)
         if fused and self.fused_front and self.fused_back:
             # the whole backward tail — mesh chain, hand layer, scatter into the parameter tables' gradient rows — as three launches
-            self._ck(L.harp_hand_back_bwd(ctypes.byref(self._hand_struct(lfid, B, shadow, app, frame)), p(s["g_colors"]) if app else None,
-                                          p(s["g_betas"]), ST()), "hand_back_bwd")
+            if self.use_arm:
+                self._ck(L.harp_arm_back_bwd(ctypes.byref(self._arm_struct(lfid, B, shadow, app, frame)), p(s["g_colors"]) if app else None,
+                                             p(s["g_pose48"]), p(s["g_betas"]), ST()), "arm_back_bwd")
+            else:
+                self._ck(L.harp_hand_back_bwd(ctypes.byref(self._hand_struct(lfid, B, shadow, app, frame)), p(s["g_colors"]) if app else None,
+                                              p(s["g_betas"]), ST()), "hand_back_bwd")
             return
         if fold:
             raise RuntimeError("a folded step needs the fused backward tail (fused_back)")

@@ -454,6 +454,35 @@ int harp_hand_front_fwd(const harp_hand_front* h, hipStream_t stream);
  * amb_ratio).  g_colors: 9 floats (dL/d colours) or NULL; g_betas_scratch: B*10 floats of scratch. */
 int harp_hand_back_bwd(const harp_hand_front* h, const float* g_colors, float* g_betas_scratch, hipStream_t stream);
 
+/* ---- fused per-frame front / back of a fitting step, SMPL-X arm path (csrc/arm_front.hip) ---------------------------------
+ * replaces, for configs["use_arm"], what harp_hand_front_fwd / harp_hand_back_bwd replace for the MANO hand: the row gathers
+ * params[...][fid] (utils/visualize.py:26-27, 37-40), SMPLXARM.forward(..., return_type='mano_w_arm') (hand_models_harp/
+ * body_models.py:2163-2390) and prepare_mesh (utils/visualize.py:45-64) with both projections and the light camera
+ * (renderer_helper.py:344, 353, 454-468) — and their autograd down to the gradient rows of the parameter tables.
+ * Front = THREE launches: harp_frame_setup_fwd + joint chain per frame | the blend-shape contraction of all frames on the matrix
+ * cores | skinning + output joints + harp_mesh_chain_fwd per frame.  Back = FOUR: harp_mesh_chain_bwd + joint split + recentring
+ * + skinning backward + trans / cam / light / ambient scatter per frame | the two vertex reductions (MFMA) | the kinematic chain
+ * backward with the rot / wrist_pose / pose / shape scatter.  Same arithmetic as harp_frame_setup_* + harp_lbs_tree_* +
+ * harp_mesh_chain_*; `step` as in harp_hand_front.  tables.wrist_pose must be set (rows [rot, wrist_pose, pose] = 51 floats),
+ * tables.n_betas_out = tree.NB, chain.V0 = tree.NV, chain.NJ = tree.n_joints_out; chain.verts_mm / joints_mm are OUTPUTS;
+ * chain.cam_R / cam_T / light_pos must alias cam_R / cam_T / light_pos below. */
+typedef struct harp_arm_front {
+  harp_mesh_chain chain;
+  harp_tree_model tree;
+  harp_frame_tables tables;
+  const int32_t* fid;        /* (B,) frame of each batch row */
+  float *pose_in, *betas, *trans_b, *cam_R, *cam_T, *light_pos, *colors;   /* as harp_frame_setup_fwd: (B,51) (B,NB) (B,3) (B,9) (B,3) (B,3) (9) */
+  float* lbs_ws;             /* harp_lbs_tree_ws_floats(&tree, B) floats, shared by the front and the back of one step */
+  const float* weights_T;    /* (NJ, NV): tree.weights transposed (the per-frame kernels read one coalesced row per joint) */
+  int self_shadow;           /* colours from amb_ratio (shadow renderer) or the fixed Phong lights */
+  harp_step_frame step;      /* optional prologue / epilogue of a fitting step (zero-initialised: none) */
+} harp_arm_front;
+int harp_arm_front_fwd(const harp_arm_front* h, hipStream_t stream);
+/* `h` as passed to harp_arm_front_fwd of the same step, with the chain's gradient inputs filled in (see harp_hand_back_bwd); gradients
+ * are ADDED to the rows tables.g_* (pose, rot, wrist_pose, trans, cam, shape and — when g_colors is given — light_positions, amb_ratio).
+ * g_pose_scratch: B*51 floats (holds dL/d pose rows afterwards), g_betas_scratch: B*NB floats. */
+int harp_arm_back_bwd(const harp_arm_front* h, const float* g_colors, float* g_pose_scratch, float* g_betas_scratch, hipStream_t stream);
+
 int harp_light_setup_fwd(const float* centroid, const float* light_pos, int B, float* light_R, float* light_T, hipStream_t stream);
 int harp_light_setup_bwd(const float* centroid, const float* light_pos, const float* g_light_R, const float* g_light_T, int B, int V,
                          float* g_light_pos, float* g_centroid, float* g_verts, hipStream_t stream);

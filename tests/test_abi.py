@@ -32,17 +32,19 @@ def test_struct_layouts_match_c(tmp_path):
     import subprocess
     from harp_amd import _lib
     src = tmp_path / "layout.c"
-    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "harp_hip.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n",'
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "harp_hip.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n",'
                    'sizeof(harp_shade_args), offsetof(harp_shade_args, B), offsetof(harp_shade_args, rgb), sizeof(harp_mano_model),'
                    'sizeof(harp_frame_tables), sizeof(harp_adam_hyper), offsetof(harp_frame_tables, share_light), sizeof(harp_mesh_chain),'
-                   'sizeof(harp_hand_front), offsetof(harp_hand_front, step), sizeof(harp_step_frame), offsetof(harp_step_frame, draw_counter));'
+                   'sizeof(harp_hand_front), offsetof(harp_hand_front, step), sizeof(harp_step_frame), offsetof(harp_step_frame, draw_counter),'
+                   'sizeof(harp_tree_model), sizeof(harp_arm_front), offsetof(harp_arm_front, weights_T), offsetof(harp_arm_front, step));'
                    'return 0;}\n')
     exe = tmp_path / "layout"
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
     got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
     want = [ctypes.sizeof(_lib.ShadeArgs), _lib.ShadeArgs.B.offset, _lib.ShadeArgs.rgb.offset, ctypes.sizeof(_lib.ManoModel),
             ctypes.sizeof(_lib.FrameTables), 32, _lib.FrameTables.share_light.offset, ctypes.sizeof(_lib.MeshChain),
-            ctypes.sizeof(_lib.HandFront), _lib.HandFront.step.offset, ctypes.sizeof(_lib.StepFrame), _lib.StepFrame.draw_counter.offset]
+            ctypes.sizeof(_lib.HandFront), _lib.HandFront.step.offset, ctypes.sizeof(_lib.StepFrame), _lib.StepFrame.draw_counter.offset,
+            ctypes.sizeof(_lib.TreeModel), ctypes.sizeof(_lib.ArmFront), _lib.ArmFront.weights_T.offset, _lib.ArmFront.step.offset]
     assert got == want, (got, want)
 
 

@@ -1609,3 +1609,68 @@ def test_kept_light_depth_map_equals_a_freshly_filled_one():
         st = a.s["zl_state"].view(2, -1)
         empties.append(st.sum(1).tolist())
     assert len({tuple(e) for e in empties}) > 1, empties            # the set of empty super-tiles did change between passes
+
+
+@pytest.mark.parametrize("coarse,app", [(True, True), (True, False), (False, True)])
+def test_fused_arm_front_and_back_match_building_blocks(coarse, app):
+    """harp_arm_front_fwd / harp_arm_back_bwd (csrc/arm_front.hip: the SMPL-X arm step's per-frame front and back as 3 + 4 launches around
+    the shared MFMA contractions) against harp_frame_setup_fwd + harp_lbs_tree_fwd + harp_mesh_chain_fwd and harp_mesh_chain_bwd +
+    harp_lbs_tree_bwd + harp_frame_setup_bwd: the gathered rows and the skinned vertices bit-exact (same summation order), the mesh chain's
+    outputs to float32 rounding, every block of the gradient arena to float32 summation order; with a frame repeated inside the batch and a
+    partial batch."""
+    from harp_amd import synth
+    from harp_amd.engine import FitEngine
+    torch.manual_seed(0)
+    tpl = synth.load_template("arm")
+    topo_np = synth.build_topology(tpl["faces0"], 1026)
+    m = synth.make_smplx_arm_model(tpl, seed=0)
+    T, S, B = 3, 128, 3
+    focal = 1000.0 * S / 224.0
+    g = torch.Generator().manual_seed(1)
+    c = m["v_template"].mean(0)
+    seq = dict(pose=torch.randn(T, 45, generator=g) * 0.15, rot=torch.randn(T, 3, generator=g) * 0.2, trans=torch.randn(T, 3, generator=g) * 0.01,
+               shape=torch.randn(T, 10, generator=g) * 0.3,
+               cam=torch.tensor([[2 * focal / (S * 1.6), -float(c[0]), -float(c[1])]]).repeat(T, 1) + torch.randn(T, 3, generator=g) * 0.005)
+    seq["joints"] = torch.randn(T, 21, 3, generator=g) * 0.05
+    uv_mask = torch.from_numpy(tpl["uv_mask"]).float() / 255
+    eng = FitEngine(m, topo_np, tpl["verts_uvs"], tpl["faces_uvs"], uv_mask, seq, S, focal, B, device=DEV, use_arm=True, opt_arm_pose=True)
+    with torch.no_grad():
+        eng.params["wrist_pose"].copy_(torch.randn(T, 3, generator=g) * 0.2)
+        eng.params["verts_disps"].copy_(torch.randn(4083, 1, generator=g) * 0.001)
+        eng.params["texture"].copy_(torch.rand(1, 512, 512, 3, generator=g) * 0.5 + 0.3)
+    eng.compute_reference_mesh()
+    eng.set_targets(torch.rand(T, S, S, 3, generator=g), (torch.rand(T, S, S, generator=g) > 0.5).float(), (torch.rand(T, S, S, generator=g) > 0.4).float())
+    assert eng.fused_front and eng.fused_chain and eng.fused_back and eng.use_arm
+    eng.auto_draw = False; eng.draw_texture_offsets(); eng.set_stage(coarse, app)
+    keys = ("pose48", "betas", "trans_b", "cam_R", "cam_T", "light_pos", "colors", "verts_mm", "joints_mm", "joints_m", "vs", "vd", "n1", "n2", "ndc_c")
+    for frames in ([2, 0, 1], [1, 1, 0], [2, 0]):
+        fid = torch.tensor(frames, dtype=torch.int32, device=DEV)
+        n = len(frames)
+        eng.fid[:n].copy_(fid); eng.tfid[:n].copy_(fid)
+        out = {}
+        for fused in (False, True):
+            eng.fused_front = fused
+            for k in keys:
+                eng.s[k][:n].fill_(7.0)                  # every output must be (re)written by the path under test
+            eng.forward_backward(coarse, app, B=n)
+            torch.cuda.synchronize()
+            out[fused] = ({k: eng.s[k][:n].clone() if k != "colors" else eng.s[k].clone() for k in keys}, eng.g_buf.clone().cpu().double(),
+                          eng.loss_vec.clone().cpu())
+        eng.fused_front = True
+        for k in keys[:9]:                               # gathers, skinning (ascending joints, zero weights skipped) and the output joints: same expressions
+            assert torch.equal(out[True][0][k], out[False][0][k]), (frames, k)
+        for k in keys[9:]:
+            a, b = out[True][0][k], out[False][0][k]
+            if k in ("n1", "n2"):
+                assert (a - b).abs().mean().item() < 5e-6 and (a - b).abs().max().item() < 2e-3, k
+            else:
+                assert (a - b).abs().max().item() <= 2e-6 * max(1.0, b.abs().max().item()), (frames, k)
+        assert rel(out[True][2], out[False][2]) < 1e-6
+        for k in ("pose", "cam", "verts_disps", "shape", "rot", "wrist_pose", "trans", "light_positions", "amb_ratio", "texture", "normal_map"):
+            o, mm = eng.arena.offsets[k][0], eng.arena.offsets[k][1]
+            a, b = out[True][1][o:o + mm], out[False][1][o:o + mm]
+            tol = 5e-2 if k == "amb_ratio" else (5e-4 if k in ("texture", "normal_map", "verts_disps") else 5e-5)
+            if b.abs().max() > 0:
+                assert rel(a, b) < tol, (frames, k, rel(a, b))
+            else:
+                assert a.abs().max() == 0, (frames, k)
