@@ -164,6 +164,9 @@ class MeshChain(ctypes.Structure):
 SIGNATURES["harp_mesh_chain_max_vertices"] = (_i, [])
 SIGNATURES["harp_mesh_chain_fwd"] = (_i, [ctypes.POINTER(MeshChain), _vp])
 SIGNATURES["harp_mesh_chain_bwd"] = (_i, [ctypes.POINTER(MeshChain), _vp])
+SIGNATURES["harp_mesh_chain_wide_ws_floats"] = (_sz, [_i, _i])
+SIGNATURES["harp_mesh_chain_bwd_wide"] = (_i, [ctypes.POINTER(MeshChain), _vp, _vp])
+SIGNATURES["harp_mesh_chain_fwd_wide"] = (_i, [ctypes.POINTER(MeshChain), _i, _vp, _vp])
 SIGNATURES["harp_draw_texture_offsets"] = (_i, [ctypes.c_uint, _vp, _i, _i, _f, _vp, _f, _vp, _vp])
 SIGNATURES["harp_rasterize_fwd_keep"] = (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp])
 SIGNATURES["harp_rasterize_l1_fwd"] = (_i, [_vp, _vp, _i, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp])
@@ -197,7 +200,9 @@ class HandFront(ctypes.Structure):
 
 
 SIGNATURES["harp_hand_front_fwd"] = (_i, [ctypes.POINTER(HandFront), _vp])
+SIGNATURES["harp_hand_front_wide_fwd"] = (_i, [ctypes.POINTER(HandFront), _vp, _vp])
 SIGNATURES["harp_hand_back_bwd"] = (_i, [ctypes.POINTER(HandFront), _vp, _vp, _vp])
+SIGNATURES["harp_hand_back_wide_bwd"] = (_i, [ctypes.POINTER(HandFront), _vp, _vp, _vp, _vp])
 
 
 class ArmFront(ctypes.Structure):
@@ -209,6 +214,8 @@ class ArmFront(ctypes.Structure):
 
 SIGNATURES["harp_arm_front_fwd"] = (_i, [ctypes.POINTER(ArmFront), _vp])
 SIGNATURES["harp_arm_back_bwd"] = (_i, [ctypes.POINTER(ArmFront), _vp, _vp, _vp, _vp])
+SIGNATURES["harp_arm_front_wide_fwd"] = (_i, [ctypes.POINTER(ArmFront), _vp, _vp])
+SIGNATURES["harp_arm_back_wide_bwd"] = (_i, [ctypes.POINTER(ArmFront), _vp, _vp, _vp, _vp, _vp])
 
 
 class Conv3x3Args(ctypes.Structure):

@@ -22,6 +22,8 @@
 
 int harp_detail_tree_blend(const harp_tree_model& m, float* ws, const float* betas, int B, hipStream_t stream);
 int harp_detail_tree_gA_gpm(const harp_tree_model& m, float* ws, const float* g_verts, float* g_betas, int B, hipStream_t stream);
+int harp_detail_chain_wide_tail(const harp_mesh_chain& a, int clear_grads, float* part_ws, hipStream_t stream);
+int harp_detail_chain_wide_bwd(const harp_mesh_chain& a, float* part_ws, const float** G_out, hipStream_t stream);
 
 namespace {
 
@@ -252,6 +254,157 @@ __global__ void __launch_bounds__(kChainThreads) arm_back_kernel(const harp_arm_
   }
 }
 
+// ---- wide forms (csrc/chain_wide.hip): skinning / skinning backward on kChainParts workgroups per frame (a contiguous quarter of the NV
+//      vertices each), around the wide mesh chain.  kArmWide threads >= ceil(NV / kChainParts) (checked by the launchers).
+constexpr int kArmWide = 320;
+
+__global__ void __launch_bounds__(kArmWide) arm_skin_wide_kernel(const harp_arm_front H) {
+  __shared__ float s_A[MAXJ * 12], s_ctr[3], s_tr[3];
+  __shared__ int s_jsrc[64];
+  const harp_mesh_chain& A = H.chain;
+  const harp_tree_model& M = H.tree;
+  const int b = blockIdx.x / cb::kChainParts, part = blockIdx.x % cb::kChainParts, tid = threadIdx.x, B = A.B;
+  const int NJ = M.NJ, NV = M.NV, no = M.n_joints_out, per = (NV + cb::kChainParts - 1) / cb::kChainParts;
+  const TreeWs W = tree_ws(&M, H.lbs_ws, B);
+  for (int i = tid; i < NJ * 12; i += kArmWide) s_A[i] = W.A[(size_t)b * NJ * 12 + i];
+  if (tid < 3) {
+    s_ctr[tid] = (M.center_joint >= 0) ? W.G[((size_t)b * NJ + M.center_joint) * 12 + tid * 4 + 3] : 0.f;
+    s_tr[tid] = H.trans_b[b * 3 + tid];
+  } else if (tid >= 64 && tid < 64 + no) {
+    s_jsrc[tid - 64] = M.joint_src[tid - 64];
+  }
+  __syncthreads();
+  const int v = part * per + tid;
+  if (tid < per && v < NV) {
+    const float* p = W.vp + ((size_t)b * NV + v) * 3;
+    const float p0 = p[0], p1 = p[1], p2 = p[2];
+    float Tm[12];
+    skin_transform(H.weights_T, s_A, NJ, NV, v, Tm);
+    float* vo = (float*)A.verts_mm + ((size_t)b * NV + v) * 3;
+    float mm[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const float o = Tm[r * 4] * p0 + Tm[r * 4 + 1] * p1 + Tm[r * 4 + 2] * p2 + Tm[r * 4 + 3];
+      mm[r] = (o - s_ctr[r] + s_tr[r]) * 1000.0f;
+      vo[r] = mm[r];
+    }
+    for (int k = 0; k < no; ++k)              // vertex joints (finger tips): written by the vertex's owner
+      if (s_jsrc[k] == -v - 1)
+        for (int r = 0; r < 3; ++r) ((float*)A.joints_mm)[((size_t)b * no + k) * 3 + r] = mm[r];
+  }
+  if (part == 0 && tid >= 256 && tid < 256 + no) {           // chain joints (tree_joints_out_kernel)
+    const int k = tid - 256, src = s_jsrc[k];
+    if (src >= 0)
+      for (int c = 0; c < 3; ++c)
+        ((float*)A.joints_mm)[((size_t)b * no + k) * 3 + c] = (W.G[((size_t)b * NJ + src) * 12 + c * 4 + 3] - s_ctr[c] + s_tr[c]) * 1000.0f;
+  }
+}
+
+// G: dL/d(subdivided vertices) left by the wide mesh-chain backward.  SubdivideMeshes backward, joint split, recentring / translation sums
+// (partial, joined with atomics: g_Gt of the frame is all-zero on entry), skinning backward; part 0: table scatter + step epilogue.
+__global__ void __launch_bounds__(kArmWide) arm_back_wide_kernel(const harp_arm_front H, const float* __restrict__ G,
+                                                                 const float* __restrict__ g_colors, float* __restrict__ g_betas) {
+  __shared__ float s_A[MAXJ * 12], s_gGt[MAXJ * 3], s_red[kArmWide / 64][3], s_tot[3];
+  __shared__ int s_jsrc[64];
+  const harp_mesh_chain& A = H.chain;
+  const harp_tree_model& M = H.tree;
+  const harp_frame_tables& T = H.tables;
+  const int b = blockIdx.x / cb::kChainParts, part = blockIdx.x % cb::kChainParts, tid = threadIdx.x, B = A.B;
+  const bool lead = part == 0;
+  const int NJ = M.NJ, NV = M.NV, NB = M.NB, no = M.n_joints_out, per = (NV + cb::kChainParts - 1) / cb::kChainParts;
+  const int V = A.V0 + A.E0;
+  const TreeWs W = tree_ws(&M, H.lbs_ws, B);
+  for (int i = tid; i < NJ * 12; i += kArmWide) s_A[i] = W.A[(size_t)b * NJ * 12 + i];
+  if (tid < NJ * 3) s_gGt[tid] = 0.f;
+  if (lead && tid >= 256 && tid < 256 + NB) g_betas[b * NB + tid - 256] = 0.f;      // (the shape gradient is accumulated with atomics by the next launch)
+  if (tid >= 64 && tid < 64 + no) s_jsrc[tid - 64] = M.joint_src[tid - 64];
+  __syncthreads();
+  // ---- joint gradients (tree_joints_bwd_kernel): chain joints -> g_Gt [metres] (part 0), vertex joints -> their vertices (by the owner, below)
+  if (lead && tid < no * 3) {
+    const int k = tid / 3, c = tid % 3, src = s_jsrc[k];
+    if (src >= 0) atomicAdd(&s_gGt[src * 3 + c], A.g_joints_m[(size_t)b * no * 3 + tid] * 1e-3f * 1000.0f);
+  }
+  __syncthreads();
+  float a3[3] = {0.f, 0.f, 0.f};
+  const int v = part * per + tid;
+  if (tid < per && v < NV) {
+    const cb::V3 g0 = cb::subdivide_bwd_vertex(G + (size_t)b * V * 3, A.sub_off, A.sub_idx, v);
+    float g[3] = {g0.x, g0.y, g0.z};
+    for (int k = 0; k < no; ++k)
+      if (s_jsrc[k] == -v - 1)
+        for (int r = 0; r < 3; ++r) g[r] += A.g_joints_m[((size_t)b * no + k) * 3 + r] * 1e-3f;      // (= g_joints_mm)
+    float* gv0 = A.g_v0 + ((size_t)b * NV + v) * 3;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) { gv0[r] = g[r]; g[r] *= 1000.0f; a3[r] = g[r]; }
+    float Tm[12];
+    skin_transform(H.weights_T, s_A, NJ, NV, v, Tm);
+    float* gvp = W.g_vp + ((size_t)b * NV + v) * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) gvp[c] = Tm[c] * g[0] + Tm[4 + c] * g[1] + Tm[8 + c] * g[2];
+  }
+  if (lead && tid >= 256 && tid < 256 + NJ)
+    for (int c = 0; c < 3; ++c) a3[c] += s_gGt[(tid - 256) * 3 + c];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float sw = wave_sum_u(a3[c]);
+    if ((tid & 63) == 0) s_red[tid >> 6][c] = sw;
+  }
+  __syncthreads();
+  if (tid < 3) {
+    float sum = 0.f;
+    for (int w = 0; w < kArmWide / 64; ++w) sum += s_red[w][tid];
+    s_tot[tid] = sum;
+  }
+  __syncthreads();
+  // g_Gt rows of the frame: chain-joint gradients (part 0) and -(this part's share of the translation sum) on the centre joint
+  float* gGt = W.g_Gt + (size_t)b * NJ * 3;
+  if (lead && tid < NJ * 3 && s_gGt[tid] != 0.f) atomicAdd(gGt + tid, s_gGt[tid]);
+  if (tid >= 64 && tid < 67 && M.center_joint >= 0) atomicAdd(gGt + M.center_joint * 3 + tid - 64, -s_tot[tid - 64]);
+  // ---- scatter into the gradient rows of the parameter tables (frame_setup_bwd_kernel's trans / cam / light part)
+  const int f = H.fid[b];
+  if (tid < 3) {
+    const int k = tid;
+    if (T.g_trans) atomicAdd(T.g_trans + f * 3 + k, s_tot[k]);
+    if (T.g_cam && lead) {
+      if (k == 0) {
+        const float c0 = T.cam[f * 3];
+        const float den = (float)A.S * c0 + 1e-9f;
+        atomicAdd(T.g_cam + f * 3, A.g_cam_T[b * 3 + 2] * (-2.0f * A.focal * (float)A.S / (den * den)));
+      } else {
+        atomicAdd(T.g_cam + f * 3 + k, -A.g_cam_T[b * 3 + (k - 1)]);
+      }
+    }
+    if (lead && g_colors && A.g_light_pos && T.g_light_positions) {
+      const int lf = T.share_light ? 0 : f;
+      atomicAdd(T.g_light_positions + lf * 3 + k, A.g_light_pos[b * 3 + k]);
+    }
+  } else if (tid == 128 && lead && b == 0 && H.self_shadow && g_colors && T.g_amb_ratio) {
+    const float amb = 1.0f / (1.0f + expf(-T.amb_ratio[0]));
+    const float g_amb = (g_colors[0] + g_colors[1] + g_colors[2]) - (g_colors[3] + g_colors[4] + g_colors[5]);
+    atomicAdd(T.g_amb_ratio, g_amb * amb * (1.0f - amb));
+  }
+  if (b == 0 && lead) {                             // step epilogue (harp_step_frame), as in arm_back_kernel
+    const harp_step_frame& E = H.step;
+    if ((tid >> 6) == 3) {                          // wave 3 (lanes 192 .. 255), whole: the wave sum below needs every lane
+      const int k = tid - 192;
+      const bool on = E.loss && k < E.n_loss;
+      const float vv = on ? E.loss[k] : 0.f;
+      if (on) {
+        if (E.loss_out) E.loss_out[k] = vv;
+        E.loss[k] = 0.f;
+      }
+      if (E.loss_w && E.loss_total) {
+        const float tot = wave_sum_u(on ? E.loss_w[k] * vv : 0.f);
+        if (k == 0) E.loss_total[0] += tot;
+      }
+    } else if (tid == 256 && E.schedule) {
+      E.sched_row[0] = (int)((unsigned)E.sched_row[0] % (unsigned)E.n_rows) + 1;
+    } else if (tid == 257 && E.draw_counter) {
+      E.draw_counter[0] += 1;
+    }
+  }
+}
+
 // one wave per frame: chain + Rodrigues backward, adding rot / wrist_pose / pose / shape straight to their rows (lbs_tree_body.h)
 __global__ void __launch_bounds__(64) arm_chain_bwd_kernel(const harp_arm_front H, float* __restrict__ g_pose_in, float* __restrict__ g_betas) {
   __shared__ ChainBwdLds S;
@@ -308,6 +461,53 @@ int harp_arm_back_bwd(const harp_arm_front* h, const float* g_colors, float* g_p
   HARP_CHECK_LAUNCH();
   if (a->light_only) return HARP_OK;           // no arm-layer backward: nothing of it reaches the appearance optimiser's parameters
   const int rc = harp_detail_tree_gA_gpm(h->tree, h->lbs_ws, a->g_v0, g_betas_scratch, a->B, stream);
+  if (rc != HARP_OK) return rc;
+  hipLaunchKernelGGL(arm_chain_bwd_kernel, dim3(a->B), dim3(64), 0, stream, *h, g_pose_scratch, g_betas_scratch);
+  HARP_CHECK_LAUNCH();
+  return HARP_OK;
+}
+
+// Wide forms: the per-frame kernels on four workgroups per frame around the wide mesh chain (csrc/chain_wide.hip).  Front: joint chain |
+// blend (MFMA) | skinning + output joints | chain A | chain B.  Back: chain backward A, B, C | SubdivideMeshes backward + joint split + skinning
+// backward + scatter | gA, gpm (MFMA) | kinematic chain backward.  part_ws: harp_mesh_chain_wide_ws_floats(B, V0 + E0).
+static bool arm_wide_ok(const harp_arm_front* h) {
+  const int V = h->chain.V0 + h->chain.E0;
+  return (h->tree.NV + cb::kChainParts - 1) / cb::kChainParts <= kArmWide && (V + cb::kChainParts - 1) / cb::kChainParts <= kChainThreads &&
+         h->tree.NJ <= 64 && h->tree.n_joints_out <= 64 && h->tree.NB <= 64;
+}
+
+int harp_arm_front_wide_fwd(const harp_arm_front* h, float* part_ws, hipStream_t stream) {
+  if (!arm_ok(h) || !part_ws || !arm_wide_ok(h) || (h->chain.V0 + h->chain.E0) * 12 > 64 * 1024) return HARP_ERR_ARG;
+  const harp_mesh_chain& a = h->chain;
+  if (!a.verts_mm || !a.joints_mm || !a.joints_m || !a.vs || !a.n1 || !a.il1 || !a.vd || !a.n2 || !a.il2 || !a.ndc_c || !a.cam_R || !a.cam_T ||
+      (a.shadow && (!a.centroid || !a.light_R || !a.light_T || !a.ndc_l || !a.light_pos)) || (h->step.clear_mesh_grads && (!a.g_vd || !a.g_joints_m)))
+    return HARP_ERR_ARG;
+  hipLaunchKernelGGL(arm_front_kernel, dim3(a.B), dim3(kFrontThreads), 0, stream, *h);
+  const int rc = harp_detail_tree_blend(h->tree, h->lbs_ws, h->betas, a.B, stream);
+  if (rc != HARP_OK) return rc;
+  hipLaunchKernelGGL(arm_skin_wide_kernel, dim3(a.B * cb::kChainParts), dim3(kArmWide), 0, stream, *h);
+  HARP_CHECK_LAUNCH();
+  return harp_detail_chain_wide_tail(a, h->step.clear_mesh_grads, part_ws, stream);
+}
+
+int harp_arm_back_wide_bwd(const harp_arm_front* h, const float* g_colors, float* g_pose_scratch, float* g_betas_scratch, float* part_ws,
+                           hipStream_t stream) {
+  if (!h || !part_ws) return HARP_ERR_ARG;
+  if (h->chain.light_only) return harp_arm_back_bwd(h, g_colors, g_pose_scratch, g_betas_scratch, stream);
+  if (!arm_ok(h) || !g_pose_scratch || !g_betas_scratch || !arm_wide_ok(h) || (h->chain.V0 + h->chain.E0) * 24 > 160 * 1024 - 256) return HARP_ERR_ARG;
+  const harp_mesh_chain* a = &h->chain;
+  if (!a->sub_off || !a->sub_idx || !a->vd || !a->vs || !a->n1 || !a->il1 || !a->cam_R || !a->cam_T || !a->g_vd || !a->g_ndc_c ||
+      !a->g_joints_m || !a->g_joints_mm || !a->g_v0 || !a->g_cam_T || !a->g_disp || (a->has_normal_grad && (!a->n2 || !a->il2 || !a->g_n2)) ||
+      (a->shadow && (!a->light_pos || !a->centroid || !a->light_R || !a->light_T || !a->g_ndc_l || !a->g_light_R || !a->g_light_T ||
+                     !a->g_light_pos)))
+    return HARP_ERR_ARG;
+  if (h->step.loss && (h->step.n_loss < 0 || h->step.n_loss > 64)) return HARP_ERR_ARG;
+  const float* G = nullptr;
+  int rc = harp_detail_chain_wide_bwd(*a, part_ws, &G, stream);
+  if (rc != HARP_OK) return rc;
+  hipLaunchKernelGGL(arm_back_wide_kernel, dim3(a->B * cb::kChainParts), dim3(kArmWide), 0, stream, *h, G, g_colors, g_betas_scratch);
+  HARP_CHECK_LAUNCH();
+  rc = harp_detail_tree_gA_gpm(h->tree, h->lbs_ws, a->g_v0, g_betas_scratch, a->B, stream);
   if (rc != HARP_OK) return rc;
   hipLaunchKernelGGL(arm_chain_bwd_kernel, dim3(a->B), dim3(64), 0, stream, *h, g_pose_scratch, g_betas_scratch);
   HARP_CHECK_LAUNCH();

@@ -8,6 +8,7 @@ namespace cb {
 
 constexpr int kChainThreads = 1024;
 constexpr int kMaxPerThread = 4;          // vertices per thread held in registers between stages => V <= 4096
+constexpr int kChainParts = 4;            // workgroups per frame of the wide forms (chain_wide.hip, hand_front.hip)
 
 struct V3 { float x, y, z; };
 __device__ __forceinline__ V3 mk(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
@@ -255,6 +256,13 @@ __device__ __forceinline__ V3 normals_bwd_gather(const float* p, const float* gN
 }
 __device__ __forceinline__ V3 normal_len_bwd(V3 n, float il, V3 g) { return (il == 0.f) ? g * 1e6f : (g - n * dot(n, g)) * il; }
 
+// SubdivideMeshes backward + millimetres for base vertex i: 1e-3 (g[i] + 0.5 sum_children g[child]); g: the frame's (V,3) rows (global or LDS)
+__device__ __forceinline__ V3 subdivide_bwd_vertex(const float* g, const int32_t* __restrict__ sub_off, const int32_t* __restrict__ sub_idx, int i) {
+  V3 ch = mk(0.f, 0.f, 0.f);
+  for (int k = sub_off[i]; k < sub_off[i + 1]; ++k) ch = ch + ld(g + 3 * sub_idx[k]);
+  return (ld(g + 3 * i) + ch * 0.5f) * 1e-3f;
+}
+
 // Backward chain of frame b by one 1024-thread workgroup.  s_mem: 9*V floats of LDS [positions V*3 | gN V*3 | g V*3].
 __device__ __forceinline__ void mesh_chain_bwd_body(const harp_mesh_chain& A, float* s_mem, int b) {
   __shared__ float s_red12[16 * 12], s_tot[12];
@@ -382,11 +390,7 @@ __device__ __forceinline__ void mesh_chain_bwd_body(const harp_mesh_chain& A, fl
   __syncthreads();
   // ---- SubdivideMeshes backward + millimetres: g_v0[i] = 1e-3 (g[i] + 0.5 sum_children g[child])
   float* gv0 = A.g_v0 + (size_t)b * V0 * 3;
-  for (int i = tid; i < V0; i += kChainThreads) {
-    V3 ch = mk(0.f, 0.f, 0.f);
-    for (int k = A.sub_off[i]; k < A.sub_off[i + 1]; ++k) ch = ch + ld(s_g + 3 * A.sub_idx[k]);
-    st(gv0 + 3 * i, (ld(s_g + 3 * i) + ch * 0.5f) * 1e-3f);
-  }
+  for (int i = tid; i < V0; i += kChainThreads) st(gv0 + 3 * i, subdivide_bwd_vertex(s_g, A.sub_off, A.sub_idx, i));
 }
 
 }  // namespace cb

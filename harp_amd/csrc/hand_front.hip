@@ -201,7 +201,168 @@ __global__ void __launch_bounds__(kChainThreads) hand_front_kernel(const harp_ha
   cb::mesh_chain_fwd_body(A, s_p, b, true, s_cam, s_cam + 9, s_lpos);
 }
 
+// ---- wide form: the hand layer of a frame on kChainParts workgroups (a contiguous quarter of the 778 vertices each: the 1.35 MB of
+//      blend-shape rows of a frame go through FOUR CUs' L1 instead of one), followed by the wide mesh chain (chain_wide.hip).  Every
+//      workgroup gathers the frame's rows and runs the 16-joint chain (same arithmetic, a few hundred flops); part 0 writes the shared rows.
+constexpr int kWideThreads = 256;
+__global__ void __launch_bounds__(kWideThreads) hand_front_wide_kernel(const harp_hand_front H) {
+  __shared__ float s_pose[48], s_beta[NB], s_tr[3], s_pm[NP], s_A[NJ * 12];
+  __shared__ float sR[NJ][9], sJ[NJ][3], sG[NJ][12], s_j16[NJ][3];
+  const harp_mesh_chain& A = H.chain;
+  const harp_mano_model& M = H.mano;
+  const harp_frame_tables& T = H.tables;
+  const int b = blockIdx.x / cb::kChainParts, part = blockIdx.x % cb::kChainParts, tid = threadIdx.x, B = A.B;
+  const bool lead = part == 0;
+  constexpr int kPer = (NV + cb::kChainParts - 1) / cb::kChainParts;
+  static_assert(kPer <= kWideThreads, "one vertex per thread");
+  int f;
+  if (H.step.schedule) {
+    const int row = (int)((unsigned)H.step.sched_row[0] % (unsigned)H.step.n_rows);     // bumped by hand_back_kernel, a later launch
+    f = H.step.schedule[(size_t)row * B + b];
+    if (tid == 0 && lead) {
+      const_cast<int32_t*>(H.fid)[b] = f;
+      if (H.step.tfid_out) H.step.tfid_out[b] = H.step.tschedule ? H.step.tschedule[(size_t)row * B + b] : f - H.step.target_offset;
+    }
+  } else {
+    f = H.fid[b];
+  }
+  // ---- frame set-up (glue.hip: frame_setup_fwd_kernel)
+  if (tid < 48) {
+    const float p = (tid < 3) ? T.rot[f * 3 + tid] : T.pose[f * 45 + tid - 3];
+    s_pose[tid] = p;
+    if (lead) H.pose48[b * 48 + tid] = p;
+  } else if (tid >= 64 && tid < 64 + NB) {
+    const int k = tid - 64;
+    const float v = T.shape[k];
+    s_beta[k] = v;
+    if (lead) H.betas[b * NB + k] = v;
+  } else if (tid >= 128 && tid < 131) {
+    const int k = tid - 128;
+    const float v = T.trans[f * 3 + k];
+    s_tr[k] = v;
+    if (lead) {
+      H.trans_b[b * 3 + k] = v;
+      const int lf = T.share_light ? 0 : f;
+      H.light_pos[b * 3 + k] = T.light_positions[lf * 3 + k];
+    }
+  } else if (tid == 192 && lead) {
+    const float c0 = T.cam[f * 3], c1 = T.cam[f * 3 + 1], c2 = T.cam[f * 3 + 2];
+    const float ct[3] = {-c1, -c2, 2.0f * A.focal / ((float)A.S * c0 + 1e-9f)};
+    const float R[9] = {-1.f, 0.f, 0.f, 0.f, -1.f, 0.f, 0.f, 0.f, 1.f};
+    for (int k = 0; k < 9; ++k) H.cam_R[b * 9 + k] = R[k];
+    for (int k = 0; k < 3; ++k) H.cam_T[b * 3 + k] = ct[k];
+  } else if (tid == 193 && lead && b == 0) {
+    if (H.self_shadow) {
+      const float amb = 1.0f / (1.0f + expf(-T.amb_ratio[0]));            // nn.Sigmoid()(params['amb_ratio'])
+      for (int c = 0; c < 3; ++c) { H.colors[c] = amb; H.colors[3 + c] = 1.0f - amb; H.colors[6 + c] = 0.f; }
+    } else {
+      for (int c = 0; c < 3; ++c) { H.colors[c] = 0.5f; H.colors[3 + c] = 0.4f; H.colors[6 + c] = 0.1f; }   // renderer_helper.py:70-73
+    }
+  }
+  __syncthreads();
+  // ---- hand layer, joints (lbs.hip: lbs_joints_kernel); workspace rows are kept for the backward pass (written by part 0)
+  const LbsWs Wl = lbs_ws(H.lbs_ws, B);
+  if (tid < NJ) {
+    float aa[3];
+    for (int c = 0; c < 3; ++c) {
+      const float p = s_pose[3 * tid + c];
+      aa[c] = (tid == 0) ? p : (M.hands_mean[3 * (tid - 1) + c] + p);       // manolayer.py:139-143
+    }
+    float R[9];
+    rodrigues_fwd(aa, R);
+    for (int k = 0; k < 9; ++k) { sR[tid][k] = R[k]; if (lead) Wl.Rloc[(b * NJ + tid) * 9 + k] = R[k]; }
+    if (tid > 0)
+      for (int k = 0; k < 9; ++k) {
+        const float v = R[k] - ((k == 0 || k == 4 || k == 8) ? 1.f : 0.f);
+        s_pm[(tid - 1) * 9 + k] = v;
+        if (lead) Wl.pm[b * NP + (tid - 1) * 9 + k] = v;
+      }
+  } else if (tid >= 64 && tid < 64 + NJ * 3) {
+    const int l = tid - 64;
+    float acc = M.J_template[l];
+    for (int k = 0; k < NB; ++k) acc += M.J_dirs[l * NB + k] * s_beta[k];
+    sJ[l / 3][l % 3] = acc;
+    if (lead) Wl.Jrest[b * NJ * 3 + l] = acc;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    for (int k = 0; k < 9; ++k) sG[0][(k / 3) * 4 + (k % 3)] = sR[0][k];
+    for (int r = 0; r < 3; ++r) sG[0][r * 4 + 3] = sJ[0][r];
+  }
+  __syncthreads();
+  if (tid < 5) {                          // kinematic chain: one finger per lane
+    for (int lev = 0; lev < 3; ++lev) {
+      const int j = 3 * tid + 1 + lev, p = parent_of(j);
+      const float rel[3] = {sJ[j][0] - sJ[p][0], sJ[j][1] - sJ[p][1], sJ[j][2] - sJ[p][2]};
+      for (int r = 0; r < 3; ++r) {
+        for (int c = 0; c < 3; ++c)
+          sG[j][r * 4 + c] = sG[p][r * 4] * sR[j][c] + sG[p][r * 4 + 1] * sR[j][3 + c] + sG[p][r * 4 + 2] * sR[j][6 + c];
+        sG[j][r * 4 + 3] = sG[p][r * 4] * rel[0] + sG[p][r * 4 + 1] * rel[1] + sG[p][r * 4 + 2] * rel[2] + sG[p][r * 4 + 3];
+      }
+    }
+  }
+  __syncthreads();
+  if (tid < NJ) {
+    float* Ao = Wl.A + (b * NJ + tid) * 12;
+    float* Go = Wl.G + (b * NJ + tid) * 12;
+    for (int r = 0; r < 3; ++r) {
+      const float t3 = sG[tid][r * 4 + 3] - (sG[tid][r * 4] * sJ[tid][0] + sG[tid][r * 4 + 1] * sJ[tid][1] + sG[tid][r * 4 + 2] * sJ[tid][2]);  // :241-247
+      for (int c = 0; c < 3; ++c) { const float g = sG[tid][r * 4 + c]; s_A[tid * 12 + r * 4 + c] = g; if (lead) { Ao[r * 4 + c] = g; Go[r * 4 + c] = g; } }
+      s_A[tid * 12 + r * 4 + 3] = t3;
+      s_j16[tid][r] = sG[tid][r * 4 + 3];
+      if (lead) { Go[r * 4 + 3] = sG[tid][r * 4 + 3]; Ao[r * 4 + 3] = t3; Wl.j16[(b * NJ + tid) * 3 + r] = sG[tid][r * 4 + 3]; }
+    }
+  }
+  __syncthreads();
+  // ---- blend shapes + skinning (lbs.hip: lbs_skin_kernel), one lane per vertex of this part's quarter
+  const int v = part * kPer + tid;
+  if (tid < kPer && v < NV) {
+    const float4* wr = (const float4*)(M.weights + (size_t)v * NJ);
+    const float4 w4s[4] = {wr[0], wr[1], wr[2], wr[3]};        // issued ahead of the blend-shape rows
+    float q0 = M.v_template[3 * v], q1 = M.v_template[3 * v + 1], q2 = M.v_template[3 * v + 2];
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+      const float* r = M.shapedirs_T + (size_t)k * NV * 3 + 3 * v;
+      const float c = s_beta[k];
+      q0 += r[0] * c; q1 += r[1] * c; q2 += r[2] * c;
+    }
+#pragma unroll 15
+    for (int k = 0; k < NP; ++k) {
+      const float* r = M.posedirs_T + (size_t)k * NV * 3 + 3 * v;
+      const float c = s_pm[k];
+      q0 += r[0] * c; q1 += r[1] * c; q2 += r[2] * c;
+    }
+    float* vpo = Wl.vposed + ((size_t)b * NV + v) * 3;
+    vpo[0] = q0; vpo[1] = q1; vpo[2] = q2;
+    float Tm[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) Tm[k] = 0.f;
+#pragma unroll
+    for (int j4 = 0; j4 < NJ / 4; ++j4) {
+      const float4 w4 = w4s[j4];
+      const float wj[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int k = 0; k < 12; ++k) Tm[k] += wj[u] * s_A[(j4 * 4 + u) * 12 + k];
+    }
+    float o[3];
+    for (int r = 0; r < 3; ++r) o[r] = (Tm[r * 4] * q0 + Tm[r * 4 + 1] * q1 + Tm[r * 4 + 2] * q2 + Tm[r * 4 + 3] + s_tr[r]) * 1000.0f;
+    float* vo = (float*)A.verts_mm + ((size_t)b * NV + v) * 3;
+    for (int r = 0; r < 3; ++r) vo[r] = o[r];
+    for (int k = 0; k < 5; ++k)
+      if (v == c_tips[k])                  // finger-tip joints (c_reorder: tip k is output joint 4 (k + 1)), millimetres; metres by the chain
+        for (int r = 0; r < 3; ++r) ((float*)A.joints_mm)[(size_t)b * 63 + 12 * (k + 1) + r] = o[r];
+  }
+  if (lead && tid >= 192 && tid < 192 + 63) {                  // chain joints (lbs_joints_out_kernel)
+    const int t = tid - 192, k = t / 3, c = t % 3, src = c_reorder[k];
+    if (src < NJ) ((float*)A.joints_mm)[(size_t)b * 63 + t] = (s_j16[src][c] + s_tr[c]) * 1000.0f;
+  }
+}
+
 }  // namespace
+
+int harp_detail_chain_wide_tail(const harp_mesh_chain& a, int clear_grads, float* part_ws, hipStream_t stream);
 
 extern "C" {
 
@@ -227,6 +388,26 @@ int harp_hand_front_fwd(const harp_hand_front* h, hipStream_t stream) {
   hipLaunchKernelGGL(hand_front_kernel, dim3(a.B), dim3(kChainThreads), lds, stream, *h);
   HARP_CHECK_LAUNCH();
   return HARP_OK;
+}
+
+// The same front on kChainParts workgroups per frame: hand layer (hand_front_wide_kernel) + the wide mesh chain (chain_wide.hip), three
+// launches.  part_ws: harp_mesh_chain_wide_ws_floats(B) floats.
+int harp_hand_front_wide_fwd(const harp_hand_front* h, float* part_ws, hipStream_t stream) {
+  if (!h || !part_ws) return HARP_ERR_ARG;
+  const harp_mesh_chain& a = h->chain;
+  if (!a.edges0 || !a.vf_off || !a.vf_tri || !a.disp || a.B <= 0 || a.V0 != NV || a.E0 < 0 || a.NJ != 21 ||
+      (a.V0 + a.E0 + cb::kChainParts - 1) / cb::kChainParts > kChainThreads || (a.V0 + a.E0) * 12 > 64 * 1024 || !a.verts_mm || !a.joints_mm ||
+      !a.joints_m || !a.vs || !a.n1 || !a.il1 || !a.vd || !a.n2 || !a.il2 || !a.ndc_c ||
+      (a.shadow && (!a.centroid || !a.light_R || !a.light_T || !a.ndc_l)))
+    return HARP_ERR_ARG;
+  if (!h->fid || !h->pose48 || !h->betas || !h->trans_b || !h->cam_R || !h->cam_T || !h->light_pos || !h->colors || !h->lbs_ws ||
+      h->tables.wrist_pose)
+    return HARP_ERR_ARG;
+  if ((h->step.schedule && (!h->step.sched_row || h->step.n_rows <= 0)) || (h->step.clear_mesh_grads && (!a.g_vd || !a.g_joints_m)))
+    return HARP_ERR_ARG;
+  hipLaunchKernelGGL(hand_front_wide_kernel, dim3(a.B * cb::kChainParts), dim3(kWideThreads), 0, stream, *h);
+  HARP_CHECK_LAUNCH();
+  return harp_detail_chain_wide_tail(a, h->step.clear_mesh_grads, part_ws, stream);
 }
 
 }  // extern "C"

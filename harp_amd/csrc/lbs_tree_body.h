@@ -251,19 +251,34 @@ __device__ __forceinline__ void chain_bwd_body(const harp_tree_model& M, const f
       }
     }
   }
-  for (int k = l; k < NB; k += 64) {
-    float acc = g_beta_row[k];
-    const double* gJf = &gJ[0][0];
-    for (int i0 = 0; i0 < NJ * 3; i0 += 8) {           // 8 rows in flight (one load per trip was NJ*3 = 165 dependent round trips); same order
-      float d[8];
+  // shape gradient through the joint regression: g_beta[k] += sum_i J_dirs[i][k] gJ[i] over the NJ*3 = 165 rows.  Lanes = (coefficient k,
+  // one of 64 / NB chunks of the rows), 28 rows in flight: two or three round trips instead of 165 (one load per trip) or 21 (8 per trip)
+  {
+    const int nch = max(1, 64 / NB), rows = NJ * 3, rper = (rows + nch - 1) / nch;
+    const int k = l % NB, ch = l / NB;
+    float part = 0.f;
+    if (NB <= 64 && ch < nch) {
+      const double* gJf = &gJ[0][0];
+      const int r0 = ch * rper, r1 = min(rows, r0 + rper);
+      for (int i0 = r0; i0 < r1; i0 += 28) {
+        float d[28];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) d[u] = M.J_dirs[min(i0 + u, NJ * 3 - 1) * NB + k];
+        for (int u = 0; u < 28; ++u) d[u] = M.J_dirs[min(i0 + u, rows - 1) * NB + k];
 #pragma unroll
-      for (int u = 0; u < 8; ++u)
-        if (i0 + u < NJ * 3) acc += d[u] * (float)gJf[i0 + u];
+        for (int u = 0; u < 28; ++u)
+          if (i0 + u < r1) part += d[u] * (float)gJf[i0 + u];
+      }
     }
-    g_beta_row[k] = acc;
-    if (SCATTER && k < 10 && tables->g_shape) atomicAdd(tables->g_shape + k, acc);
+    __syncthreads();                                   // gRl is dead: its first 64 floats carry the partial sums
+    float* s_part = &gRl[0][0];
+    s_part[l] = part;
+    __syncthreads();
+    if (l < NB) {
+      float acc = g_beta_row[l];
+      for (int c = 0; c < nch; ++c) acc += s_part[c * NB + l];
+      g_beta_row[l] = acc;
+      if (SCATTER && l < 10 && tables->g_shape) atomicAdd(tables->g_shape + l, acc);
+    }
   }
 }
 

@@ -164,6 +164,10 @@ class FitEngine:
         if self.use_arm:
             self._weights_T = self.dm.weights.t().contiguous()                       # (NJ, NV): one coalesced row per joint for the per-frame kernels
         self.fused_back = True           # ... and the backward tail as three launches instead of six (csrc/hand_back.hip)
+        # the front on FOUR workgroups per frame (csrc/chain_wide.hip, hand_front_wide_kernel): a quarter of the vertices per workgroup, one
+        # pass per stage, kernel boundaries where the parts meet — three launches of 4 B workgroups instead of one of B
+        self.wide_front = self.fused_front and (self.topo.V + 3) // 4 <= 1024
+        self.wide_back = self.wide_front     # ... and the tail: mesh-chain backward + per-vertex hand-layer backward on four workgroups per frame
         # ---- switches (all on in production; tools/dev and bench.py flip some of them to measure their effect)
         self.overlap = True              # second HIP stream (light view, silhouette backward, parameter-only terms); False: one stream
         self.early_terms = True          # parameter-only terms / mesh regularisers scheduled on the second stream
@@ -216,6 +220,7 @@ class FitEngine:
         V0, NJo = self.topo.V0, self.n_joints
         s["lbs_ws"] = f(L.harp_lbs_tree_ws_floats(ctypes.byref(self.dm.struct), B) if self.use_arm else L.harp_lbs_mano_ws_floats(B))
         s["verts_mm"], s["joints_mm"], s["joints_m"] = f(B, V0, 3), f(B, NJo, 3), f(B, NJo, 3)
+        s["chain_parts"] = f(L.harp_mesh_chain_wide_ws_floats(B, V))
         s["vs"], s["n1"], s["il1"], s["vd"], s["n2"], s["il2"] = f(B, V, 3), f(B, V, 3), f(B, V), f(B, V, 3), f(B, V, 3), f(B, V)
         s["ndc_c"], s["ndc_l"], s["centroid"], s["light_R"], s["light_T"] = f(B, V, 3), f(B, V, 3), f(B, 3), f(B, 9), f(B, 3)
         s["ws_c"] = ops.rasterize_workspace(B, self.topo.F, S, dev)
@@ -358,8 +363,14 @@ class FitEngine:
         allows the one-launch form of the whole front (MANO path, csrc/hand_front.hip)."""
         L, s, p, st, tp = _lib.lib(), self.s, _lib.ptr, _lib.stream(), self.topo
         if front and self.fused_front and self.fused_chain:
-            if self.use_arm:
+            if self.use_arm and self.wide_front:
+                self._ck(L.harp_arm_front_wide_fwd(ctypes.byref(self._arm_struct(fid, B, shadow, False, step)), p(s["chain_parts"]), st),
+                         "arm_front_wide_fwd")
+            elif self.use_arm:
                 self._ck(L.harp_arm_front_fwd(ctypes.byref(self._arm_struct(fid, B, shadow, False, step)), st), "arm_front_fwd")
+            elif self.wide_front:
+                self._ck(L.harp_hand_front_wide_fwd(ctypes.byref(self._hand_struct(fid, B, shadow, False, step)), p(s["chain_parts"]), st),
+                         "hand_front_wide_fwd")
             else:
                 self._ck(L.harp_hand_front_fwd(ctypes.byref(self._hand_struct(fid, B, shadow, False, step)), st), "hand_front_fwd")
             return True
@@ -730,9 +741,15 @@ class FitEngine:
             wait_s(cur, side)                       # silhouette_bwd -> g_ndc_c (normal-map chain rule with tail_side)
         if fused and self.fused_front and self.fused_back:
             # the whole backward tail — mesh chain, hand layer, scatter into the parameter tables' gradient rows — as three launches
-            if self.use_arm:
+            if self.use_arm and self.wide_back:
+                self._ck(L.harp_arm_back_wide_bwd(ctypes.byref(self._arm_struct(lfid, B, shadow, app, frame)), p(s["g_colors"]) if app else None,
+                                                  p(s["g_pose48"]), p(s["g_betas"]), p(s["chain_parts"]), ST()), "arm_back_wide_bwd")
+            elif self.use_arm:
                 self._ck(L.harp_arm_back_bwd(ctypes.byref(self._arm_struct(lfid, B, shadow, app, frame)), p(s["g_colors"]) if app else None,
                                              p(s["g_pose48"]), p(s["g_betas"]), ST()), "arm_back_bwd")
+            elif self.wide_back:
+                self._ck(L.harp_hand_back_wide_bwd(ctypes.byref(self._hand_struct(lfid, B, shadow, app, frame)), p(s["g_colors"]) if app else None,
+                                                   p(s["g_betas"]), p(s["chain_parts"]), ST()), "hand_back_wide_bwd")
             else:
                 self._ck(L.harp_hand_back_bwd(ctypes.byref(self._hand_struct(lfid, B, shadow, app, frame)), p(s["g_colors"]) if app else None,
                                               p(s["g_betas"]), ST()), "hand_back_bwd")
@@ -1050,7 +1067,7 @@ class FitEngine:
         # every switch the enqueued launch sequence depends on is part of the key: flipping one re-captures instead of replaying a
         # graph recorded for another configuration
         gkey = (coarse, app, scheduled, n, self.keep_image, self.fused_loss, self.self_shadow, tuple(self.frozen), self.overlap, self.early_terms,
-                self.packed_texels, self.fused_keep, self.mesh_third, self.graph_order, fold, self.fused_terms, self.zl_tile_flags, self.accumulate_loss, self.lean_app_stage, self.sil_only_raster, self.auto_draw, self.mesh_terms_first, self.camera_first, self.tail_side, self.fused_bwd, self.fused_chain, self.fused_front, self.fused_back, self.consume_gzl, self.keep_depth, dist_on, self.overlap_allreduce,
+                self.packed_texels, self.fused_keep, self.mesh_third, self.graph_order, fold, self.fused_terms, self.zl_tile_flags, self.accumulate_loss, self.lean_app_stage, self.sil_only_raster, self.auto_draw, self.mesh_terms_first, self.camera_first, self.tail_side, self.fused_bwd, self.fused_chain, self.fused_front, self.wide_front, self.wide_back, self.fused_back, self.consume_gzl, self.keep_depth, dist_on, self.overlap_allreduce,
                 self.comm is not None, self.perceptual is not None and app)
         g = self._graphs.get(gkey)
         if g is None:

@@ -310,6 +310,17 @@ typedef struct harp_mesh_chain {
 int harp_mesh_chain_max_vertices(void);
 int harp_mesh_chain_fwd(const harp_mesh_chain* a, hipStream_t stream);
 int harp_mesh_chain_bwd(const harp_mesh_chain* a, hipStream_t stream);
+/* The same forward chain on FOUR workgroups per frame (csrc/chain_wide.hip): each owns a contiguous quarter of the vertices (one per thread),
+ * stages the whole frame's positions in LDS, and the two points where a part needs the others' results (displaced neighbours, centroid) are
+ * kernel boundaries — two launches of 4 B workgroups instead of one of B.  Same outputs as harp_mesh_chain_fwd (the centroid is the sum of
+ * four partial sums).  clear_grads != 0: a->g_vd / a->g_joints_m are zeroed (harp_step_frame.clear_mesh_grads).
+ * part_ws: harp_mesh_chain_wide_ws_floats(B, V0 + E0) floats of scratch (shared with harp_mesh_chain_bwd_wide).  (V0 + E0) / 4 <= 1024 and (V0 + E0) * 12 B <= 64 KB. */
+size_t harp_mesh_chain_wide_ws_floats(int B, int V);
+int harp_mesh_chain_fwd_wide(const harp_mesh_chain* a, int clear_grads, float* part_ws, hipStream_t stream);
+/* harp_mesh_chain_bwd on four workgroups per frame: projections backward + normal-length backward | normal gather + displacement |
+ * normal gather | SubdivideMeshes backward — four launches, the same outputs (camera sums are sums of four partial sums).  Not for
+ * a->light_only (HARP_ERR_ARG: that variant is one small pass of harp_mesh_chain_bwd).  (V0 + E0) * 24 B of LDS per workgroup. */
+int harp_mesh_chain_bwd_wide(const harp_mesh_chain* a, float* part_ws, hipStream_t stream);
 
 /* ---- losses, texture helpers, optimiser ---------------------------------------------------------------------------
  * Every loss call accumulates (+=) its value into `loss` and, if `w` (device pointer to the weight(s) = d total/d term)
@@ -445,6 +456,10 @@ typedef struct harp_hand_front {
   harp_step_frame step;      /* optional prologue / epilogue of a fitting step (zero-initialised: none) */
 } harp_hand_front;
 int harp_hand_front_fwd(const harp_hand_front* h, hipStream_t stream);
+/* harp_hand_front_fwd on four workgroups per frame: the hand layer with a quarter of the 778 vertices per workgroup (every workgroup
+ * gathers the rows and runs the 16-joint chain; the frame's 1.35 MB of blend-shape rows go through four CUs' L1) + harp_mesh_chain_fwd_wide:
+ * THREE launches of 4 B workgroups.  Same outputs, same `step` semantics.  part_ws as for harp_mesh_chain_fwd_wide. */
+int harp_hand_front_wide_fwd(const harp_hand_front* h, float* part_ws, hipStream_t stream);
 /* The counterpart for the backward tail of a step (csrc/hand_back.hip): harp_mesh_chain_bwd + harp_lbs_mano_bwd + harp_frame_setup_bwd
  * (autograd of utils/visualize.py:16-88 / manopth/manolayer.py:108-296 down to the rows params[...][fid]) as THREE launches instead of
  * six: mesh chain + joint split + per-vertex skinning backward + trans / cam / light scatter per frame, the two vertex reductions, the
@@ -453,6 +468,10 @@ int harp_hand_front_fwd(const harp_hand_front* h, hipStream_t stream);
  * the rows tables.g_* (pose, rot, trans, cam, shape and — when g_colors is given, i.e. an appearance stage ran — light_positions,
  * amb_ratio).  g_colors: 9 floats (dL/d colours) or NULL; g_betas_scratch: B*10 floats of scratch. */
 int harp_hand_back_bwd(const harp_hand_front* h, const float* g_colors, float* g_betas_scratch, hipStream_t stream);
+/* harp_hand_back_bwd with the mesh-chain backward (harp_mesh_chain_bwd_wide's first three launches) and the per-vertex hand-layer backward on
+ * four workgroups per frame: SIX launches of mostly 4 B workgroups instead of three of B.  Same results to float32 summation order;
+ * chain.light_only is forwarded to harp_hand_back_bwd.  part_ws as for harp_mesh_chain_fwd_wide. */
+int harp_hand_back_wide_bwd(const harp_hand_front* h, const float* g_colors, float* g_betas_scratch, float* part_ws, hipStream_t stream);
 
 /* ---- fused per-frame front / back of a fitting step, SMPL-X arm path (csrc/arm_front.hip) ---------------------------------
  * replaces, for configs["use_arm"], what harp_hand_front_fwd / harp_hand_back_bwd replace for the MANO hand: the row gathers
@@ -482,6 +501,12 @@ int harp_arm_front_fwd(const harp_arm_front* h, hipStream_t stream);
  * are ADDED to the rows tables.g_* (pose, rot, wrist_pose, trans, cam, shape and — when g_colors is given — light_positions, amb_ratio).
  * g_pose_scratch: B*51 floats (holds dL/d pose rows afterwards), g_betas_scratch: B*NB floats. */
 int harp_arm_back_bwd(const harp_arm_front* h, const float* g_colors, float* g_pose_scratch, float* g_betas_scratch, hipStream_t stream);
+/* The same front / back with the per-frame work on FOUR workgroups per frame around harp_mesh_chain_fwd_wide / _bwd_wide
+ * (a quarter of the vertices per workgroup; 5 + 7 launches).  part_ws: harp_mesh_chain_wide_ws_floats(B, V0 + E0) floats.
+ * chain.light_only is forwarded to harp_arm_back_bwd. */
+int harp_arm_front_wide_fwd(const harp_arm_front* h, float* part_ws, hipStream_t stream);
+int harp_arm_back_wide_bwd(const harp_arm_front* h, const float* g_colors, float* g_pose_scratch, float* g_betas_scratch, float* part_ws,
+                           hipStream_t stream);
 
 int harp_light_setup_fwd(const float* centroid, const float* light_pos, int B, float* light_R, float* light_T, hipStream_t stream);
 int harp_light_setup_bwd(const float* centroid, const float* light_pos, const float* g_light_R, const float* g_light_T, int B, int V,

@@ -757,11 +757,13 @@ def test_fused_mesh_chain_matches_building_blocks(sc, coarse, app):
             assert rel(g1[o:o + n], g0[o:o + n]) < 5e-4, k       # atomics order + the conditioning of the silhouette-rim gradient
 
 
+@pytest.mark.parametrize("wide", [False, True])
 @pytest.mark.parametrize("coarse,app", [(True, True), (True, False)])
-def test_fused_front_matches_building_blocks(sc, coarse, app):
-    """harp_hand_front_fwd (frame set-up + MANO layer + mesh chain in one launch, csrc/hand_front.hip) against harp_frame_setup_fwd +
-    harp_lbs_mano_fwd + harp_mesh_chain_fwd: same gathered rows (bit-exact), same geometry and LBS workspace to fp32 rounding (the
-    blend-shape sums run in a different order), same losses and gradients."""
+def test_fused_front_matches_building_blocks(sc, coarse, app, wide):
+    """harp_hand_front_fwd (frame set-up + MANO layer + mesh chain in one launch, csrc/hand_front.hip) — and harp_hand_front_wide_fwd, the
+    same front on four workgroups per frame (three launches, csrc/chain_wide.hip) — against harp_frame_setup_fwd + harp_lbs_mano_fwd +
+    harp_mesh_chain_fwd: same gathered rows (bit-exact), same geometry and LBS workspace to fp32 rounding (the blend-shape sums run in a
+    different order), same losses and gradients."""
     from harp_amd.engine import FitEngine
     tg = sc["targets"]
     eng = FitEngine(sc["model_np"], sc["topo_np"], sc["tpl"]["verts_uvs"], sc["tpl"]["faces_uvs"], sc["uv_mask"].float(), sc["seq"], sc["S"],
@@ -774,9 +776,10 @@ def test_fused_front_matches_building_blocks(sc, coarse, app):
     fid = torch.tensor([2, 0, 1], dtype=torch.int32, device=DEV)
     eng.fid.copy_(fid); eng.tfid.copy_(fid)
     eng.auto_draw = False; eng.draw_texture_offsets(); eng.set_stage(coarse, app)
-    assert eng.fused_front and eng.fused_chain
+    assert eng.fused_front and eng.fused_chain and eng.wide_front
+    eng.wide_front = wide
     keys = ("pose48", "betas", "trans_b", "cam_R", "cam_T", "light_pos", "colors", "verts_mm", "joints_mm", "joints_m", "vs", "vd", "n1", "n2",
-            "ndc_c", "lbs_ws")
+            "ndc_c", "ndc_l", "centroid", "light_R", "light_T", "il1", "il2", "lbs_ws")
     out = {}
     for fused in (False, True):
         eng.fused_front = fused
@@ -791,6 +794,11 @@ def test_fused_front_matches_building_blocks(sc, coarse, app):
     ws_f = _lib.lib().harp_lbs_mano_ws_floats(3)
     for k in keys[7:]:
         a, b = out[True][0][k], out[False][0][k]
+        if k in ("ndc_l", "centroid", "light_R", "light_T") and not app:
+            continue                                     # (light view: appearance stages only)
+        if k in ("il1", "il2"):                          # 1 / |N|, |N| ~ 1e-6 m^2: relative
+            assert ((a - b).abs() / b.abs().clamp_min(1.0)).max().item() < 2e-3, k
+            continue
         if k == "lbs_ws":                                # forward rows only (pose map .. G, posed vertices); the rest is backward scratch
             fwd = 3 * (135 + 192 + 48 + 48 + 144 + 192)
             a, b = torch.cat([a[:fwd], a[ws_f - 3 * 2334:ws_f]]), torch.cat([b[:fwd], b[ws_f - 3 * 2334:ws_f]])
@@ -805,9 +813,12 @@ def test_fused_front_matches_building_blocks(sc, coarse, app):
             assert rel(g1[o:o + n], g0[o:o + n]) < 1e-3, k       # soft-rim conditioning: 1e-7 vertex moves flip a handful of pixels
 
 
+@pytest.mark.parametrize("wide", [False, True])
 @pytest.mark.parametrize("coarse,app", [(True, True), (True, False), (False, True)])
-def test_fused_back_matches_building_blocks(sc, coarse, app):
-    """harp_hand_back_bwd (csrc/hand_back.hip: mesh chain backward + joint split + skinning backward + trans / cam / light scatter in one
+def test_fused_back_matches_building_blocks(sc, coarse, app, wide):
+    """(wide: harp_hand_back_wide_bwd — the same tail with the mesh-chain backward and the per-vertex hand-layer backward on four workgroups
+    per frame, csrc/chain_wide.hip, six launches)
+    harp_hand_back_bwd (csrc/hand_back.hip: mesh chain backward + joint split + skinning backward + trans / cam / light scatter in one
     launch per frame, the vertex reductions, the kinematic-chain backward with the pose / rot / shape scatter: three launches) against
     harp_mesh_chain_bwd + harp_lbs_mano_bwd + harp_frame_setup_bwd (six) on the SAME image-space gradients: every block of the gradient
     arena agrees to float32 summation order; with a frame repeated inside the batch (legal: rows are summed) and a partial batch."""
@@ -822,7 +833,8 @@ def test_fused_back_matches_building_blocks(sc, coarse, app):
         eng.params["pose"].add_((torch.randn(eng.params["pose"].shape, generator=g) * 0.05).to(DEV))
         eng.params["shape"].add_((torch.randn(10, generator=g) * 0.3).to(DEV))
         eng.params["trans"].copy_((torch.randn(3, 3, generator=g) * 0.01).to(DEV))
-    assert eng.fused_front and eng.fused_chain and eng.fused_back
+    assert eng.fused_front and eng.fused_chain and eng.fused_back and eng.wide_back
+    eng.wide_back = wide
     eng.auto_draw = False; eng.draw_texture_offsets(); eng.set_stage(coarse, app)
     for frames in ([2, 0, 1], [1, 1, 0], [2, 0]):
         fid = torch.tensor(frames, dtype=torch.int32, device=DEV)
@@ -1611,8 +1623,9 @@ def test_kept_light_depth_map_equals_a_freshly_filled_one():
     assert len({tuple(e) for e in empties}) > 1, empties            # the set of empty super-tiles did change between passes
 
 
+@pytest.mark.parametrize("wide", [False, True])
 @pytest.mark.parametrize("coarse,app", [(True, True), (True, False), (False, True)])
-def test_fused_arm_front_and_back_match_building_blocks(coarse, app):
+def test_fused_arm_front_and_back_match_building_blocks(coarse, app, wide):
     """harp_arm_front_fwd / harp_arm_back_bwd (csrc/arm_front.hip: the SMPL-X arm step's per-frame front and back as 3 + 4 launches around
     the shared MFMA contractions) against harp_frame_setup_fwd + harp_lbs_tree_fwd + harp_mesh_chain_fwd and harp_mesh_chain_bwd +
     harp_lbs_tree_bwd + harp_frame_setup_bwd: the gathered rows and the skinned vertices bit-exact (same summation order), the mesh chain's
@@ -1640,7 +1653,8 @@ def test_fused_arm_front_and_back_match_building_blocks(coarse, app):
         eng.params["texture"].copy_(torch.rand(1, 512, 512, 3, generator=g) * 0.5 + 0.3)
     eng.compute_reference_mesh()
     eng.set_targets(torch.rand(T, S, S, 3, generator=g), (torch.rand(T, S, S, generator=g) > 0.5).float(), (torch.rand(T, S, S, generator=g) > 0.4).float())
-    assert eng.fused_front and eng.fused_chain and eng.fused_back and eng.use_arm
+    assert eng.fused_front and eng.fused_chain and eng.fused_back and eng.use_arm and eng.wide_front and eng.wide_back
+    eng.wide_front = eng.wide_back = wide            # (wide: four workgroups per frame around csrc/chain_wide.hip)
     eng.auto_draw = False; eng.draw_texture_offsets(); eng.set_stage(coarse, app)
     keys = ("pose48", "betas", "trans_b", "cam_R", "cam_T", "light_pos", "colors", "verts_mm", "joints_mm", "joints_m", "vs", "vd", "n1", "n2", "ndc_c")
     for frames in ([2, 0, 1], [1, 1, 0], [2, 0]):
