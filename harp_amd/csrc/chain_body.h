@@ -129,6 +129,49 @@ __device__ __forceinline__ V3 vertex_normal(const float* p, const int4* __restri
   return N * inv;
 }
 
+// The same in two halves for kernels that can ask for the (static) incident-face table BEFORE the positions are in LDS (chain_wide.hip):
+// TriPre = the vertex's CSR range + its first kPre entries.
+struct TriPre { int ks, n; int4 t[kPre]; };
+__device__ __forceinline__ TriPre tri_fetch(const int4* __restrict__ vf_tri, const int32_t* __restrict__ vf_off, int i) {
+  TriPre r;
+  r.ks = vf_off[i]; r.n = vf_off[i + 1] - r.ks;
+#pragma unroll
+  for (int q = 0; q < kPre; ++q) r.t[q] = vf_tri[r.ks + min(q, r.n - 1)];
+  return r;
+}
+__device__ __forceinline__ V3 vertex_normal_pre(const float* p, const int4* __restrict__ vf_tri, const TriPre& r, float& inv_out) {
+  V3 N = mk(0.f, 0.f, 0.f);
+#pragma unroll
+  for (int q = 0; q < kPre; ++q) {
+    if (q < r.n) {
+      const V3 p0 = ld(p + 3 * r.t[q].x), p1 = ld(p + 3 * r.t[q].y), p2 = ld(p + 3 * r.t[q].z);
+      N = N + cross(p2 - p1, p0 - p1);
+    }
+  }
+  for (int k = r.ks + kPre; k < r.ks + r.n; ++k) {
+    const int4 u = vf_tri[k];
+    const V3 p0 = ld(p + 3 * u.x), p1 = ld(p + 3 * u.y), p2 = ld(p + 3 * u.z);
+    N = N + cross(p2 - p1, p0 - p1);
+  }
+  const float len = sqrtf(dot(N, N));
+  const float inv = 1.0f / fmaxf(len, 1e-6f);
+  inv_out = (len > 1e-6f) ? inv : 0.f;
+  return N * inv;
+}
+
+// n floats global -> LDS by the whole workgroup, kU loads per thread in flight (a plain copy loop waits for every load before its LDS store)
+template <int kU, int T>
+__device__ __forceinline__ void stage_rows(float* dst, const float* __restrict__ src, int n, float scale) {
+  for (int k0 = threadIdx.x; k0 < n; k0 += kU * T) {
+    float v[kU];
+#pragma unroll
+    for (int u = 0; u < kU; ++u) v[u] = src[min(k0 + u * T, n - 1)];
+#pragma unroll
+    for (int u = 0; u < kU; ++u)
+      if (k0 + u * T < n) dst[k0 + u * T] = v[u] * scale;
+  }
+}
+
 __device__ __forceinline__ V3 project(V3 p, const float* r, const float* T, float focal, float pp, float half) {
   const float X = p.x * r[0] + p.y * r[3] + p.z * r[6] + T[0];
   const float Y = p.x * r[1] + p.y * r[4] + p.z * r[7] + T[1];
@@ -252,6 +295,14 @@ __device__ __forceinline__ V3 normals_bwd_gather(const float* p, const float* gN
   for (int q = 0; q < kPre; ++q)
     if (q < n) acc = acc + nb_term(p, gN, t[q]);
   for (int k = ks + kPre; k < ks + n; ++k) acc = acc + nb_term(p, gN, vf_tri[k]);
+  return acc;
+}
+__device__ __forceinline__ V3 normals_bwd_gather_pre(const float* p, const float* gN, const int4* __restrict__ vf_tri, const TriPre& r) {
+  V3 acc = mk(0.f, 0.f, 0.f);
+#pragma unroll
+  for (int q = 0; q < kPre; ++q)
+    if (q < r.n) acc = acc + nb_term(p, gN, r.t[q]);
+  for (int k = r.ks + kPre; k < r.ks + r.n; ++k) acc = acc + nb_term(p, gN, vf_tri[k]);
   return acc;
 }
 __device__ __forceinline__ V3 normal_len_bwd(V3 n, float il, V3 g) { return (il == 0.f) ? g * 1e6f : (g - n * dot(n, g)) * il; }

@@ -31,8 +31,18 @@ __global__ void __launch_bounds__(kChainThreads) chain_wide_a_kernel(const harp_
   const int V0 = A.V0, V = A.V0 + A.E0, per = part_size(V);
   const int i = part * per + tid;
   const bool own = tid < per && i < V;
-  const float* src = A.verts_mm + (size_t)b * V0 * 3;
-  for (int k = tid; k < V0 * 3; k += kChainThreads) s_p[k] = src[k] * 1e-3f;
+  // the static tables this thread will need (its edges, its vertex's incident faces) are requested first: they arrive while the positions are staged
+  const int iv = own ? i : 0;
+  const TriPre tp = tri_fetch((const int4*)A.vf_tri, A.vf_off, iv);
+  constexpr int kEdgeIter = 3;                 // edges per thread held ahead (E0 <= 3 * 1024: 2315 hand, 3057 arm; the rest in the loop below)
+  int ea[kEdgeIter], ec[kEdgeIter];
+#pragma unroll
+  for (int u = 0; u < kEdgeIter; ++u) {
+    const int e = min(tid + u * kChainThreads, max(A.E0 - 1, 0));
+    ea[u] = A.E0 > 0 ? A.edges0[2 * e] : 0; ec[u] = A.E0 > 0 ? A.edges0[2 * e + 1] : 0;
+  }
+  const float dsp = A.disp[iv];
+  stage_rows<3, kChainThreads>(s_p, A.verts_mm + (size_t)b * V0 * 3, V0 * 3, 1e-3f);
   if (part == 0 && tid < A.NJ * 3) A.joints_m[(size_t)b * A.NJ * 3 + tid] = A.joints_mm[(size_t)b * A.NJ * 3 + tid] * 1e-3f;
   if (clear_grads) {                           // the two gradient segments the key-point / mesh terms accumulate into (they start after B)
     float* gv = const_cast<float*>(A.g_vd) + (size_t)b * V * 3;
@@ -41,7 +51,12 @@ __global__ void __launch_bounds__(kChainThreads) chain_wide_a_kernel(const harp_
     if (part == 0 && tid < A.NJ * 3) const_cast<float*>(A.g_joints_m)[(size_t)b * A.NJ * 3 + tid] = 0.f;
   }
   __syncthreads();
-  for (int e = tid; e < A.E0; e += kChainThreads) {
+#pragma unroll
+  for (int u = 0; u < kEdgeIter; ++u) {
+    const int e = tid + u * kChainThreads;
+    if (e < A.E0) st(s_p + 3 * (V0 + e), (ld(s_p + 3 * ea[u]) + ld(s_p + 3 * ec[u])) * 0.5f);
+  }
+  for (int e = tid + kEdgeIter * kChainThreads; e < A.E0; e += kChainThreads) {
     const int a = A.edges0[2 * e], c = A.edges0[2 * e + 1];
     st(s_p + 3 * (V0 + e), (ld(s_p + 3 * a) + ld(s_p + 3 * c)) * 0.5f);
   }
@@ -52,10 +67,10 @@ __global__ void __launch_bounds__(kChainThreads) chain_wide_a_kernel(const harp_
     const V3 p = ld(s_p + 3 * i);
     st(A.vs + o * 3, p);
     float inv;
-    const V3 n = vertex_normal(s_p, (const int4*)A.vf_tri, A.vf_off, i, inv);
+    const V3 n = vertex_normal_pre(s_p, (const int4*)A.vf_tri, tp, inv);
     st(A.n1 + o * 3, n);
     A.il1[o] = inv;
-    const V3 vd = p + n * A.disp[i];
+    const V3 vd = p + n * dsp;
     st(A.vd + o * 3, vd);
     csum = vd;
   }
@@ -73,8 +88,8 @@ __global__ void __launch_bounds__(kChainThreads) chain_wide_b_kernel(const harp_
   const int i = part * per + tid;
   const bool own = tid < per && i < V;
   const float half = 0.5f * (float)A.S;
-  const float* src = A.vd + (size_t)b * V * 3;
-  for (int k = tid; k < V * 3; k += kChainThreads) s_p[k] = src[k];
+  const TriPre tp = tri_fetch((const int4*)A.vf_tri, A.vf_off, own ? i : 0);
+  stage_rows<6, kChainThreads>(s_p, A.vd + (size_t)b * V * 3, V * 3, 1.0f);
   if (A.shadow && tid == 0) {
     float cs[3] = {0.f, 0.f, 0.f};
     for (int q = 0; q < kParts; ++q)
@@ -95,7 +110,7 @@ __global__ void __launch_bounds__(kChainThreads) chain_wide_b_kernel(const harp_
   if (own) {
     const size_t o = (size_t)b * V + i;
     float inv;
-    const V3 n = vertex_normal(s_p, (const int4*)A.vf_tri, A.vf_off, i, inv);
+    const V3 n = vertex_normal_pre(s_p, (const int4*)A.vf_tri, tp, inv);
     st(A.n2 + o * 3, n);
     A.il2[o] = inv;
     const V3 vd = ld(s_p + 3 * i);
@@ -155,8 +170,15 @@ __global__ void __launch_bounds__(kChainThreads) chain_wide_bwd_b_kernel(const h
   const size_t fo = (size_t)b * V * 3;
   float* s_p = s_mem;
   float* s_gN = s_mem + (size_t)V * 3;
-  if (A.has_normal_grad)
-    for (int k = tid; k < V * 3; k += kChainThreads) { s_p[k] = A.vd[fo + k]; s_gN[k] = W.gNa[fo + k]; }
+  const TriPre tp = tri_fetch((const int4*)A.vf_tri, A.vf_off, (own && A.has_normal_grad) ? i : 0);
+  // (this vertex's own rows too: in flight while the frame is staged)
+  const int iv = own ? i : 0;
+  const V3 g_in = ld(W.G + fo + 3 * iv), n1v = ld(A.n1 + fo + 3 * iv);
+  const float il1v = A.il1[(size_t)b * V + iv], dv = A.disp[iv];
+  if (A.has_normal_grad) {
+    stage_rows<5, kChainThreads>(s_p, A.vd + fo, V * 3, 1.0f);
+    stage_rows<5, kChainThreads>(s_gN, W.gNa + fo, V * 3, 1.0f);
+  }
   if (tid == 0) {
     float tot[15];
     for (int k = 0; k < 15; ++k) {
@@ -186,13 +208,13 @@ __global__ void __launch_bounds__(kChainThreads) chain_wide_bwd_b_kernel(const h
   }
   __syncthreads();
   if (own) {
-    V3 g = ld(W.G + fo + 3 * i) + mk(s_gc[0], s_gc[1], s_gc[2]);
-    if (A.has_normal_grad) g = g + normals_bwd_gather(s_p, s_gN, (const int4*)A.vf_tri, A.vf_off, i);
+    V3 g = g_in + mk(s_gc[0], s_gc[1], s_gc[2]);
+    if (A.has_normal_grad) g = g + normals_bwd_gather_pre(s_p, s_gN, (const int4*)A.vf_tri, tp);
     // displacement vd = vs + n1 * d: g_n1 = g_vd * d, g_d += g_vd . n1 (summed over frames by atomics)
-    const V3 n = ld(A.n1 + fo + 3 * i);
-    const float d = A.disp[i];
+    const V3 n = n1v;
+    const float d = dv;
     atomicAdd(A.g_disp + i, dot(g, n));
-    st(W.gNb + fo + 3 * i, normal_len_bwd(n, A.il1[(size_t)b * V + i], g * d));
+    st(W.gNb + fo + 3 * i, normal_len_bwd(n, il1v, g * d));
     st(W.G + fo + 3 * i, g);
   }
 }
@@ -206,9 +228,14 @@ __global__ void __launch_bounds__(kChainThreads) chain_wide_bwd_c_kernel(const h
   const size_t fo = (size_t)b * V * 3;
   float* s_p = s_mem;
   float* s_gN = s_mem + (size_t)V * 3;
-  for (int k = tid; k < V * 3; k += kChainThreads) { s_p[k] = A.vs[fo + k]; s_gN[k] = W.gNb[fo + k]; }
+  const bool own = tid < per && i < V;
+  const TriPre tp = tri_fetch((const int4*)A.vf_tri, A.vf_off, own ? i : 0);
+  V3 g = mk(0.f, 0.f, 0.f);
+  if (own) g = ld(W.G + fo + 3 * i);
+  stage_rows<5, kChainThreads>(s_p, A.vs + fo, V * 3, 1.0f);
+  stage_rows<5, kChainThreads>(s_gN, W.gNb + fo, V * 3, 1.0f);
   __syncthreads();
-  if (tid < per && i < V) st(W.G + fo + 3 * i, ld(W.G + fo + 3 * i) + normals_bwd_gather(s_p, s_gN, (const int4*)A.vf_tri, A.vf_off, i));
+  if (own) st(W.G + fo + 3 * i, g + normals_bwd_gather_pre(s_p, s_gN, (const int4*)A.vf_tri, tp));
 }
 
 // SubdivideMeshes backward + millimetres: g_v0[i] = 1e-3 (g[i] + 0.5 sum_children g[child])

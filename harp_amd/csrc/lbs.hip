@@ -227,24 +227,38 @@ __global__ void __launch_bounds__(64) lbs_chain_bwd_kernel(const harp_mano_model
     }
     for (int k = 0; k < 9; ++k) gRl[l][k] = (l > 0) ? g_pm[b * NP + (l - 1) * 9 + k] : 0.f;
   }
-  __syncthreads();
   // leaves -> root, one finger per lane; the root accumulators are touched by 5 lanes -> LDS float atomics
+  // a finger's share of the forward state (parent rotations, local rotations, offsets of its three joints) is fetched ahead of the barrier
+  // by the lane that walks the finger — fetched inside the walk, every level paid a memory round trip
+  float Gp3[3][9], Rj3[3][9], rel3[3][3];
   if (l < 5) {
+#pragma unroll
+    for (int lev = 0; lev < 3; ++lev) {
+      const int j = 3 * l + 1 + lev, p = parent_of(j);
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { Gp3[lev][r * 3 + c] = Gb[p * 12 + r * 4 + c]; Rj3[lev][r * 3 + c] = Rb[j * 9 + r * 3 + c]; }
+        rel3[lev][r] = Jb[j * 3 + r] - Jb[p * 3 + r];
+      }
+    }
+  }
+  __syncthreads();
+  if (l < 5) {
+#pragma unroll
     for (int lev = 2; lev >= 0; --lev) {
       const int j = 3 * l + 1 + lev, p = parent_of(j);
-      const float rel[3] = {Jb[j * 3] - Jb[p * 3], Jb[j * 3 + 1] - Jb[p * 3 + 1], Jb[j * 3 + 2] - Jb[p * 3 + 2]};
+      const float* Gp = Gp3[lev];
+      const float* Rj = Rj3[lev];
+      const float* rel = rel3[lev];
       float gl[3];
-      for (int c = 0; c < 3; ++c) {
-        gl[c] = Gb[p * 12 + 0 * 4 + c] * gtG[j][0] + Gb[p * 12 + 1 * 4 + c] * gtG[j][1] + Gb[p * 12 + 2 * 4 + c] * gtG[j][2];
-      }
+      for (int c = 0; c < 3; ++c) gl[c] = Gp[c] * gtG[j][0] + Gp[3 + c] * gtG[j][1] + Gp[6 + c] * gtG[j][2];
       for (int r = 0; r < 3; ++r)
         for (int c = 0; c < 3; ++c) {
           // g_Rloc_j = RG_p^T g_RG_j
-          gRl[j][r * 3 + c] += Gb[p * 12 + 0 * 4 + r] * gRG[j][0 * 3 + c] + Gb[p * 12 + 1 * 4 + r] * gRG[j][1 * 3 + c] +
-                               Gb[p * 12 + 2 * 4 + r] * gRG[j][2 * 3 + c];
+          gRl[j][r * 3 + c] += Gp[r] * gRG[j][c] + Gp[3 + r] * gRG[j][3 + c] + Gp[6 + r] * gRG[j][6 + c];
           // g_RG_p += g_RG_j R_j^T + g_tG_j (x) rel
-          const float add = gRG[j][r * 3] * Rb[j * 9 + c * 3] + gRG[j][r * 3 + 1] * Rb[j * 9 + c * 3 + 1] +
-                            gRG[j][r * 3 + 2] * Rb[j * 9 + c * 3 + 2] + gtG[j][r] * rel[c];
+          const float add = gRG[j][r * 3] * Rj[c * 3] + gRG[j][r * 3 + 1] * Rj[c * 3 + 1] + gRG[j][r * 3 + 2] * Rj[c * 3 + 2] + gtG[j][r] * rel[c];
           if (p == 0) atomicAdd(&gRG[0][r * 3 + c], add); else gRG[p][r * 3 + c] += add;
         }
       for (int c = 0; c < 3; ++c) {
@@ -295,24 +309,46 @@ __global__ void __launch_bounds__(192) lbs_gA_gpm_kernel(const harp_mano_model M
     const int j = threadIdx.x / 12, k = threadIdx.x % 12;
     const int per = (NV + kChunksA - 1) / kChunksA, v0 = blockIdx.y * per, v1 = min(NV, v0 + per);
     float acc = 0.f;
-#pragma unroll 4
-    for (int v = v0; v < v1; ++v) acc += weights[v * NJ + j] * Mo[((size_t)b * NV + v) * 12 + k];
+    // (explicit batches: `#pragma unroll 4` left 12 dependent round trips per lane for the 49 vertices of a chunk, and its remainder loop
+    //  one load per trip; 17 operand pairs in flight = 3 trips, same summation order)
+    constexpr int kU = 17;
+    for (int va = v0; va < v1; va += kU) {
+      float w[kU], m[kU];
+#pragma unroll
+      for (int u = 0; u < kU; ++u) { const int vc = min(va + u, v1 - 1); w[u] = weights[vc * NJ + j]; m[u] = Mo[((size_t)b * NV + vc) * 12 + k]; }
+#pragma unroll
+      for (int u = 0; u < kU; ++u)
+        if (va + u < v1) acc += w[u] * m[u];
+    }
     atomicAdd(&g_A[(b * NJ + j) * 12 + k], acc);
     return;
   }
   const int k = threadIdx.x, cy = blockIdx.y - kChunksA;
   const int per = (NV * 3 + kChunksP - 1) / kChunksP, i0 = cy * per, i1 = min(NV * 3, i0 + per);
   const float* g = g_vp + (size_t)b * NV * 3;
+  constexpr int kUp = 19;                  // 37 rows per chunk: two batches
   if (k < NP) {
     float acc = 0.f;
-#pragma unroll 8
-    for (int i = i0; i < i1; ++i) acc += M.posedirs[i * NP + k] * g[i];
+    for (int ia = i0; ia < i1; ia += kUp) {
+      float d[kUp], gg[kUp];
+#pragma unroll
+      for (int u = 0; u < kUp; ++u) { const int ic = min(ia + u, i1 - 1); d[u] = M.posedirs[ic * NP + k]; gg[u] = g[ic]; }
+#pragma unroll
+      for (int u = 0; u < kUp; ++u)
+        if (ia + u < i1) acc += d[u] * gg[u];
+    }
     atomicAdd(&g_pm[b * NP + k], acc);
   } else if (k < NP + NB) {
     const int kk = k - NP;
     float acc = 0.f;
-#pragma unroll 8
-    for (int i = i0; i < i1; ++i) acc += M.shapedirs_T[kk * NV * 3 + i] * g[i];
+    for (int ia = i0; ia < i1; ia += kUp) {
+      float d[kUp], gg[kUp];
+#pragma unroll
+      for (int u = 0; u < kUp; ++u) { const int ic = min(ia + u, i1 - 1); d[u] = M.shapedirs_T[kk * NV * 3 + ic]; gg[u] = g[ic]; }
+#pragma unroll
+      for (int u = 0; u < kUp; ++u)
+        if (ia + u < i1) acc += d[u] * gg[u];
+    }
     atomicAdd(&g_beta_b[b * NB + kk], acc);
   }
 }
