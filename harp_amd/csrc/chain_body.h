@@ -8,7 +8,10 @@ namespace cb {
 
 constexpr int kChainThreads = 1024;
 constexpr int kMaxPerThread = 4;          // vertices per thread held in registers between stages => V <= 4096
-constexpr int kChainParts = 4;            // workgroups per frame of the wide forms (chain_wide.hip, hand_front.hip)
+#ifndef HARP_CHAIN_PARTS
+#define HARP_CHAIN_PARTS 4
+#endif
+constexpr int kChainParts = HARP_CHAIN_PARTS;            // workgroups per frame of the wide forms (chain_wide.hip, hand_front.hip)
 
 struct V3 { float x, y, z; };
 __device__ __forceinline__ V3 mk(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }

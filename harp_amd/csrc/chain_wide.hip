@@ -250,9 +250,13 @@ __global__ void __launch_bounds__(256) chain_wide_bwd_d_kernel(const harp_mesh_c
 }  // namespace
 
 int harp_detail_chain_wide_tail(const harp_mesh_chain& a, int clear_grads, float* part_ws, hipStream_t stream) {
-  const size_t lds = (size_t)(a.V0 + a.E0) * 3 * sizeof(float);
-  hipLaunchKernelGGL(chain_wide_a_kernel, dim3(a.B * kParts), dim3(kChainThreads), lds, stream, a, part_ws, clear_grads);
-  hipLaunchKernelGGL(chain_wide_b_kernel, dim3(a.B * kParts), dim3(kChainThreads), lds, stream, a, part_ws);
+  const size_t need = (size_t)(a.V0 + a.E0) * 3 * sizeof(float);
+  // HARP_WIDE_LDS=<bytes>: LDS fence of the two forward kernels (0 = what they need; see harp_lds_fence / hand_front.hip)
+  static size_t fa = 0, fb = 0;
+  const size_t la = harp_lds_fence((const void*)chain_wide_a_kernel, "HARP_WIDE_LDS", 0, need, &fa);
+  const size_t lb = harp_lds_fence((const void*)chain_wide_b_kernel, "HARP_WIDE_LDS", 0, need, &fb);
+  hipLaunchKernelGGL(chain_wide_a_kernel, dim3(a.B * kParts), dim3(kChainThreads), la, stream, a, part_ws, clear_grads);
+  hipLaunchKernelGGL(chain_wide_b_kernel, dim3(a.B * kParts), dim3(kChainThreads), lb, stream, a, part_ws);
   HARP_CHECK_LAUNCH();
   return HARP_OK;
 }

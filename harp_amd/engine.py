@@ -166,8 +166,13 @@ class FitEngine:
         self.fused_back = True           # ... and the backward tail as three launches instead of six (csrc/hand_back.hip)
         # the front on FOUR workgroups per frame (csrc/chain_wide.hip, hand_front_wide_kernel): a quarter of the vertices per workgroup, one
         # pass per stage, kernel boundaries where the parts meet — three launches of 4 B workgroups instead of one of B
-        self.wide_front = self.fused_front and (self.topo.V + 3) // 4 <= 1024
-        self.wide_back = self.wide_front     # ... and the tail: mesh-chain backward + per-vertex hand-layer backward on four workgroups per frame
+        # Measured (tools/dev/bench_ab.sh, fresh processes = the burst regime bench.py reports; tools/dev/gpu_wide_ab.py, sustained): the wide TAIL
+        # wins everywhere (hand -13 ... -16 us / step, arm -25); the wide FRONT wins on the arm (-10 ... -35 us) and in sustained runs of the hand
+        # path (-17 us), but LOSES on the hand path in a fresh process (+12 ... +20 us: three dependent nodes instead of one in front of a
+        # 0.65-ms step whose second stream is the longer branch of the fork) — off there.
+        wide_ok = self.fused_front and (self.topo.V + 3) // 4 <= 1024
+        self.wide_front = wide_ok and self.use_arm
+        self.wide_back = wide_ok             # the tail: mesh-chain backward + per-vertex hand / arm layer backward on four workgroups per frame
         # ---- switches (all on in production; tools/dev and bench.py flip some of them to measure their effect)
         self.overlap = True              # second HIP stream (light view, silhouette backward, parameter-only terms); False: one stream
         self.early_terms = True          # parameter-only terms / mesh regularisers scheduled on the second stream
@@ -184,6 +189,7 @@ class FitEngine:
         self.consume_gzl = True          # the depth backward clears the shadow-map gradient entries it consumes: no per-step clear of that image (33.5 MB at B = 32, 512^2)
         self.fused_keep = True           # keep_image with the fused loss: the shader backward also writes y_pred (no forward shading launch either)
         self.keep_image = True           # shader forward writes the rendered image s["rgb"] (False: loss + gradient only)
+        self.late_texture_terms = False  # texture regularisers behind the light view on the second stream (see forward_backward)
         self.mesh_terms_first = True     # key-point term + mesh regularisers run before the light raster (under the raster set-up) instead of after it
         self.fused_bwd = False           # shading + silhouette backward in ONE launch (harp_shade_sil_bwd): correct, measured SLOWER (1.05 vs 0.93 ms: the rasteriser tiles inherit 168 VGPRs / 3 waves per SIMD)
         self.tail_side = False           # normal-map chain rule (+ early all-reduce) on the second stream: measured SLOWER (0.960 vs 0.948 ms: the extra cross-stream edge costs more than the 5-us kernel it moves)
@@ -206,6 +212,13 @@ class FitEngine:
         self._loss_cleared = False
         self.perceptual = None           # optional VGG feature term of the appearance stage (set_perceptual)
         self.graph_perceptual = True
+        # HARP_ENG="switch=0,other=1": schedule switches of this engine from the environment (A/B runs of bench.py and the tools; the
+        # switches are all result-neutral, tests/test_gpu_parity.py::test_schedule_switches_give_the_default_schedules_result)
+        for kv in filter(None, os.environ.get("HARP_ENG", "").split(",")):
+            k, v = kv.split("=")
+            if not hasattr(self, k):
+                raise ValueError(f"HARP_ENG: no engine switch {k!r}")
+            setattr(self, k, type(getattr(self, k))(int(v)))
         self.compute_reference_mesh()
 
     # ------------------------------------------------------------------------------------------------
@@ -505,6 +518,7 @@ class FitEngine:
         off = self.disabled_terms
         # ---- terms that depend on the parameters only (normal-map normalisation, texture regularisers, displacement regulariser) go
         #      first on the second stream: they run under the LBS / mesh chain, which is a string of small latency-bound launches
+        deferred = []
         def param_terms():
             # slab clear + Adam tick + offset draw as ONE launch (harp_step_prologue); the draw counter is advanced at the end of the step by
             # hand_back (folded step) or by the launch that consumes the offsets (harp_texture_terms)
@@ -537,13 +551,21 @@ class FitEngine:
                 if self.fused_terms:
                     self._ck(L.harp_normalize3_pack(p(self.params["texture"]), p(self.params["normal_map"]), nt, p(s["nmap_n"]),
                                                     p(self.texnm) if self.packed_texels else None, ST()), "normalize3_pack")
-                    self._ck(L.harp_texture_terms(p(self.params["texture"]), p(self.params["normal_map"]), p(self.uv_mask), p(self.dist_albedo),
-                                                  p(self.dist_normal), self.Ht, self.Wt, 0.2, wp(7), lp(7),
-                                                  None if "texture" in self.frozen else p(self.grads["texture"]), wp(8), lp(8),      # (frozen maps: loss values only)
-                                                  None if "normal_map" in self.frozen else p(self.grads["normal_map"]),
-                                                  p(self.params["verts_disps"]) if disp_reg else None, V, wp(2), lp(2),
-                                                  p(self.grads["verts_disps"]), p(self.draw_counter) if (draw and pro and not fold) else None, ST()),
-                             "texture_terms")
+                    dr = disp_reg
+                    def tex_terms():
+                        self._ck(L.harp_texture_terms(p(self.params["texture"]), p(self.params["normal_map"]), p(self.uv_mask), p(self.dist_albedo),
+                                                      p(self.dist_normal), self.Ht, self.Wt, 0.2, wp(7), lp(7),
+                                                      None if "texture" in self.frozen else p(self.grads["texture"]), wp(8), lp(8),      # (frozen maps: loss values only)
+                                                      None if "normal_map" in self.frozen else p(self.grads["normal_map"]),
+                                                      p(self.params["verts_disps"]) if dr else None, V, wp(2), lp(2),
+                                                      p(self.grads["verts_disps"]), p(self.draw_counter) if (draw and pro and not fold) else None, ST()),
+                                 "texture_terms")
+                    # `late_texture_terms`: the (atomics-bound, 40 us) regularisers are enqueued on the second stream BEHIND the light view
+                    # instead of in front of it — the light view then starts at the fork, not when the regularisers are done
+                    if self.late_texture_terms and self.overlap and self.early_terms and shadow:
+                        deferred.append(tex_terms)
+                    else:
+                        tex_terms()
                     disp_reg = False
                 else:
                     self._ck(L.harp_normalize3_fwd(p(self.params["normal_map"]), nt, p(s["nmap_n"]), ST()), "normalize3")
@@ -619,6 +641,9 @@ class FitEngine:
                                  "raster_light")
                 if sched_early and not self.mesh_terms_first and not mesh_on_third:
                     mesh_terms()
+                for fn in deferred:
+                    fn()
+                deferred.clear()
             if go:
                 third_branch()
 
@@ -1067,7 +1092,7 @@ class FitEngine:
         # every switch the enqueued launch sequence depends on is part of the key: flipping one re-captures instead of replaying a
         # graph recorded for another configuration
         gkey = (coarse, app, scheduled, n, self.keep_image, self.fused_loss, self.self_shadow, tuple(self.frozen), self.overlap, self.early_terms,
-                self.packed_texels, self.fused_keep, self.mesh_third, self.graph_order, fold, self.fused_terms, self.zl_tile_flags, self.accumulate_loss, self.lean_app_stage, self.sil_only_raster, self.auto_draw, self.mesh_terms_first, self.camera_first, self.tail_side, self.fused_bwd, self.fused_chain, self.fused_front, self.wide_front, self.wide_back, self.fused_back, self.consume_gzl, self.keep_depth, dist_on, self.overlap_allreduce,
+                self.packed_texels, self.fused_keep, self.mesh_third, self.graph_order, fold, self.fused_terms, self.zl_tile_flags, self.accumulate_loss, self.lean_app_stage, self.sil_only_raster, self.auto_draw, self.late_texture_terms, self.mesh_terms_first, self.camera_first, self.tail_side, self.fused_bwd, self.fused_chain, self.fused_front, self.wide_front, self.wide_back, self.fused_back, self.consume_gzl, self.keep_depth, dist_on, self.overlap_allreduce,
                 self.comm is not None, self.perceptual is not None and app)
         g = self._graphs.get(gkey)
         if g is None:

@@ -776,7 +776,7 @@ def test_fused_front_matches_building_blocks(sc, coarse, app, wide):
     fid = torch.tensor([2, 0, 1], dtype=torch.int32, device=DEV)
     eng.fid.copy_(fid); eng.tfid.copy_(fid)
     eng.auto_draw = False; eng.draw_texture_offsets(); eng.set_stage(coarse, app)
-    assert eng.fused_front and eng.fused_chain and eng.wide_front
+    assert eng.fused_front and eng.fused_chain and eng.wide_back
     eng.wide_front = wide
     keys = ("pose48", "betas", "trans_b", "cam_R", "cam_T", "light_pos", "colors", "verts_mm", "joints_mm", "joints_m", "vs", "vd", "n1", "n2",
             "ndc_c", "ndc_l", "centroid", "light_R", "light_T", "il1", "il2", "lbs_ws")
