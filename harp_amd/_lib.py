@@ -168,6 +168,7 @@ SIGNATURES["harp_mesh_chain_wide_ws_floats"] = (_sz, [_i, _i])
 SIGNATURES["harp_mesh_chain_bwd_wide"] = (_i, [ctypes.POINTER(MeshChain), _vp, _vp])
 SIGNATURES["harp_mesh_chain_fwd_wide"] = (_i, [ctypes.POINTER(MeshChain), _i, _vp, _vp])
 SIGNATURES["harp_draw_texture_offsets"] = (_i, [ctypes.c_uint, _vp, _i, _i, _f, _vp, _f, _vp, _vp])
+SIGNATURES["harp_raster_setup_pair"] = (_i, [_vp, _f, _vp, _vp, _f, _vp, _vp, _i, _i, _i, _i, _vp])
 SIGNATURES["harp_rasterize_fwd_keep"] = (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp])
 SIGNATURES["harp_rasterize_l1_fwd"] = (_i, [_vp, _vp, _i, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp])
 

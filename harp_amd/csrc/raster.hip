@@ -26,9 +26,9 @@ using rb::Tri;
 // test of the binning pass is separable in x and y: nsx + nsx ballots per wave give the column masks and the row masks, lane l then forms
 // the word of super-tile l as (column mask) & (row mask).  Same comparison, same floats as rb::bin_super_tile -> identical lists.
 template <bool BITS>
-__global__ void __launch_bounds__(256) face_setup_kernel(const float* __restrict__ ndc, const int32_t* __restrict__ faces,
-                                                         int V, int F, float r, FaceRec* __restrict__ recs,
-                                                         float4* __restrict__ bbs, int S, int nsx, unsigned long long* __restrict__ bits, int W64) {
+__device__ __forceinline__ void face_setup_body(const float* __restrict__ ndc, const int32_t* __restrict__ faces,
+                                                int V, int F, float r, FaceRec* __restrict__ recs,
+                                                float4* __restrict__ bbs, int S, int nsx, unsigned long long* __restrict__ bits, int W64) {
   const int f = blockIdx.x * blockDim.x + threadIdx.x;
   const int b = blockIdx.y;
   float4 bb = make_float4(3.0e38f, -3.0e38f, 3.0e38f, -3.0e38f);
@@ -61,6 +61,23 @@ __global__ void __launch_bounds__(256) face_setup_kernel(const float* __restrict
   }
 }
 
+template <bool BITS>
+__global__ void __launch_bounds__(256) face_setup_kernel(const float* __restrict__ ndc, const int32_t* __restrict__ faces,
+                                                         int V, int F, float r, FaceRec* __restrict__ recs,
+                                                         float4* __restrict__ bbs, int S, int nsx, unsigned long long* __restrict__ bits, int W64) {
+  face_setup_body<BITS>(ndc, faces, V, F, r, recs, bbs, S, nsx, bits, W64);
+}
+
+// Both views of a fitting step in ONE launch each (harp_raster_setup_pair): blockIdx.z selects the view.  The light view's three set-up
+// launches were 61 us of the second stream's chain in front of the light raster (profiles/r05_f_timeline_one_step.txt); as the second half
+// of the camera view's grids they cost the main stream a few microseconds, and the light raster can start when the camera raster does.
+struct SetupView { const float* ndc; float r; RasterWs W; };
+
+__global__ void __launch_bounds__(256) face_setup_pair_kernel(const SetupView a, const SetupView b, const int32_t* __restrict__ faces, int V, int F, int S) {
+  const SetupView& v = blockIdx.z ? b : a;
+  face_setup_body<true>(v.ndc, faces, V, F, v.r, v.W.recs, v.W.bbs, S, v.W.nsx, v.W.bits, v.W.W64);
+}
+
 // One WAVE per (frame, 64x64 super-tile): streams the frame's bboxes 64 at a time, ballot + popcount compaction,
 // no LDS, no barriers; the list comes out in ascending face order (== PyTorch3D's tie-break order).
 // (rounds 1-3; since round 4 only for images above 4096 pixels a side, whose super-tile columns no longer fit the lanes of a wave)
@@ -75,8 +92,8 @@ __global__ void __launch_bounds__(256) bin_faces_kernel(const float4* __restrict
 // Round 4: the lists from the hit bitmaps.  One wave per (frame, super-tile) reads its W64 words (coalesced, ONE round trip for up to
 // 4096 faces instead of the 13 dependent trips of the bbox scan), prefix-sums the popcounts and writes the set bits in ascending order.
 // The scan took 32 us of the 51 us between the end of the hand layer and the first raster workgroup (profiles/r04_a_timeline_one_step.txt).
-__global__ void __launch_bounds__(256) expand_bits_kernel(const unsigned long long* __restrict__ bits, int F, int W64, int nst,
-                                                          int32_t* __restrict__ bins, int32_t* __restrict__ bin_count) {
+__device__ __forceinline__ void expand_bits_body(const unsigned long long* __restrict__ bits, int F, int W64, int nst,
+                                                 int32_t* __restrict__ bins, int32_t* __restrict__ bin_count) {
   const int st = blockIdx.x * 4 + (threadIdx.x >> 6), b = blockIdx.y, lane = threadIdx.x & 63;
   if (st >= nst) return;
   const unsigned long long* src = bits + ((size_t)b * nst + st) * W64;
@@ -108,6 +125,14 @@ __global__ void __launch_bounds__(256) expand_bits_kernel(const unsigned long lo
   }
   if (lane == 0) bin_count[b * nst + st] = total;
 }
+__global__ void __launch_bounds__(256) expand_bits_kernel(const unsigned long long* __restrict__ bits, int F, int W64, int nst,
+                                                          int32_t* __restrict__ bins, int32_t* __restrict__ bin_count) {
+  expand_bits_body(bits, F, W64, nst, bins, bin_count);
+}
+__global__ void __launch_bounds__(256) expand_bits_pair_kernel(const RasterWs a, const RasterWs b, int F) {
+  const RasterWs& W = blockIdx.z ? b : a;
+  expand_bits_body(W.bits, F, W.W64, W.nsx * W.nsx, W.bins, W.cnt);
+}
 
 // (Folding this into the binning pass with a "last workgroup done" ticket was measured: 512 same-address ticket atomics cost ~35 us,
 //  8x the launch they save.)
@@ -115,6 +140,12 @@ __global__ void __launch_bounds__(1024) order_tiles_kernel(const int32_t* __rest
                                                            int32_t* __restrict__ nact) {
   __shared__ int s_hist[33], s_base[33];
   rb::order_tiles(bin_count, total, order, nact, s_hist, s_base);
+}
+
+__global__ void __launch_bounds__(1024) order_tiles_pair_kernel(const RasterWs a, const RasterWs b, int total) {
+  __shared__ int s_hist[33], s_base[33];
+  const RasterWs& W = blockIdx.x ? b : a;
+  rb::order_tiles(W.cnt, total, W.order, W.nact, s_hist, s_base);
 }
 
 #ifndef RASTER_OCC1
@@ -237,7 +268,7 @@ static int rasterize_impl(const float* ndc, const int32_t* faces, int B, int V, 
   FaceRec* recs = W.recs; int32_t *bins = W.bins, *cnt = W.cnt, *order = W.order; float4* bbs = W.bbs;
   const int nsx = W.nsx;
   const float r = (soft & 1) ? sqrtf(blur_radius) : 0.f;
-  raster_setup_any(ndc, faces, B, V, F, S, r, ws, stream);
+  if (!(soft & 4)) raster_setup_any(ndc, faces, B, V, F, S, r, ws, stream);      // (bit 2: the workspace was set up by harp_raster_setup_pair)
   const unsigned lgrid = raster_loop_grid(tile_grid(B, nsx));
   const bool loop = lgrid != 0u;
   const dim3 grid(loop ? lgrid : tile_grid(B, nsx));
@@ -255,6 +286,29 @@ static int rasterize_impl(const float* ndc, const int32_t* faces, int B, int V, 
     else HARP_RASTER_LAUNCH(0, false, recs, bbs, bins, cnt, order, W.nact, B, F, S, nsx, 0.f, 1.f, face_id, zbuf, nullptr, nullptr, nullptr, 0, nullptr, nullptr,
                             nullptr, nullptr, nullptr, nullptr, 0.f, sp, nullptr, st_state);
   }
+  HARP_CHECK_LAUNCH();
+  return HARP_OK;
+}
+
+// The rasteriser set-up (face records with the blur-dilated bbox, super-tile lists, launch order) of TWO views of the same meshes — the
+// camera view and the light view of a fitting step — as three launches instead of six.  The rasteriser calls that follow pass bit 2 (value 4)
+// in `soft` / `sparse`: "the workspace is set up".  blur_radius_x: the soft-silhouette radius of that view's raster pass (0: hard K = 1 pass).
+int harp_raster_setup_pair(const float* ndc_a, float blur_radius_a, void* ws_a, const float* ndc_b, float blur_radius_b, void* ws_b,
+                           const int32_t* faces, int B, int V, int F, int S, hipStream_t stream) {
+  if (!ndc_a || !ndc_b || !ws_a || !ws_b || !faces || B <= 0 || V <= 0 || F <= 0 || S <= 0 || blur_radius_a < 0.f || blur_radius_b < 0.f) return HARP_ERR_ARG;
+  SetupView a, b;
+  a.ndc = ndc_a; a.r = sqrtf(blur_radius_a); a.W = raster_ws_split(ws_a, B, F, S);
+  b.ndc = ndc_b; b.r = sqrtf(blur_radius_b); b.W = raster_ws_split(ws_b, B, F, S);
+  if (a.W.nsx > 64) {                          // (images above 4096 px a side: the bbox-scan binning, one view after the other)
+    raster_setup_any(ndc_a, faces, B, V, F, S, a.r, ws_a, stream);
+    raster_setup_any(ndc_b, faces, B, V, F, S, b.r, ws_b, stream);
+    HARP_CHECK_LAUNCH();
+    return HARP_OK;
+  }
+  const int nst = a.W.nsx * a.W.nsx;
+  hipLaunchKernelGGL(face_setup_pair_kernel, dim3((F + 255) / 256, B, 2), dim3(256), 0, stream, a, b, faces, V, F, S);
+  hipLaunchKernelGGL(expand_bits_pair_kernel, dim3((nst + 3) / 4, B, 2), dim3(256), 0, stream, a.W, b.W, F);
+  hipLaunchKernelGGL(order_tiles_pair_kernel, dim3(2), dim3(1024), 0, stream, a.W, b.W, B * nst);
   HARP_CHECK_LAUNCH();
   return HARP_OK;
 }
@@ -279,8 +333,8 @@ int harp_rasterize_fwd(const float* ndc, const int32_t* faces, int B, int V, int
 int harp_rasterize_fwd_keep(const float* ndc, const int32_t* faces, int B, int V, int F, int S, int sparse, void* ws, int32_t* face_id,
                             float* zbuf, int32_t* st_state, hipStream_t stream) {
   if (!zbuf || !st_state) return HARP_ERR_ARG;
-  return rasterize_impl(ndc, faces, B, V, F, S, sparse ? 2 : 0, 0.f, 1.f, ws, face_id, zbuf, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
-                        nullptr, st_state, stream);
+  return rasterize_impl(ndc, faces, B, V, F, S, ((sparse & 3) ? 2 : 0) | (sparse & 4), 0.f, 1.f, ws, face_id, zbuf, nullptr, nullptr, nullptr, nullptr, nullptr,
+                        nullptr, nullptr, st_state, stream);
 }
 
 // Soft-silhouette backward: g_alpha (B,S,S) -> accumulates (atomicAdd) into g_ndc (B,V,3) (x,y components).

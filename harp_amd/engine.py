@@ -189,6 +189,7 @@ class FitEngine:
         self.consume_gzl = True          # the depth backward clears the shadow-map gradient entries it consumes: no per-step clear of that image (33.5 MB at B = 32, 512^2)
         self.fused_keep = True           # keep_image with the fused loss: the shader backward also writes y_pred (no forward shading launch either)
         self.keep_image = True           # shader forward writes the rendered image s["rgb"] (False: loss + gradient only)
+        self.paired_setup = False        # rasteriser set-up of both views as three launches on the main stream (harp_raster_setup_pair; the light raster no longer waits for three set-up launches of its own on the second stream).  Measured, same box: hand +7 us / step (B = 32), +5 (B = 18), arm +15; together with wide_front -3 ... +5: off (profiles/r05_wide_ab.txt)
         self.late_texture_terms = False  # texture regularisers behind the light view on the second stream (see forward_backward)
         self.mesh_terms_first = True     # key-point term + mesh regularisers run before the light raster (under the raster set-up) instead of after it
         self.fused_bwd = False           # shading + silhouette backward in ONE launch (harp_shade_sil_bwd): correct, measured SLOWER (1.05 vs 0.93 ms: the rasteriser tiles inherit 168 VGPRs / 3 waves per SIMD)
@@ -632,11 +633,13 @@ class FitEngine:
                         self._ck(L.harp_light_setup_fwd(p(s["centroid"]), p(s["light_pos"]), B, p(s["light_R"]), p(s["light_T"]), ST()), "light_setup")
                         self._ck(L.harp_project_fwd(p(s["vd"]), p(s["light_R"]), p(s["light_T"]), B, V, self.focal, S / 2.0, S / 2.0, S, p(s["ndc_l"]), ST()),
                                  "project_l")
+                    if pair_ev is not None:
+                        wait_e(torch.cuda.current_stream(), pair_ev)      # both views' set-up ran on the main stream
                     if self.keep_depth:      # the light depth map lives across steps: super-tiles that stay empty are not filled with -1 again
-                        self._ck(L.harp_rasterize_fwd_keep(p(s["ndc_l"]), p(tp.faces), B, V, F, S, 0 if self.keep_image else 1, p(s["ws_l"]), p(s["face_l"]),
+                        self._ck(L.harp_rasterize_fwd_keep(p(s["ndc_l"]), p(tp.faces), B, V, F, S, (0 if self.keep_image else 1) | pre, p(s["ws_l"]), p(s["face_l"]),
                                                            p(s["zl"]), p(s["zl_state"]), ST()), "raster_light")
                     else:
-                        self._ck(L.harp_rasterize_fwd(p(s["ndc_l"]), p(tp.faces), B, V, F, S, 0 if self.keep_image else 2, 0.0, 1.0, p(s["ws_l"]), p(s["face_l"]),
+                        self._ck(L.harp_rasterize_fwd(p(s["ndc_l"]), p(tp.faces), B, V, F, S, (0 if self.keep_image else 2) | pre, 0.0, 1.0, p(s["ws_l"]), p(s["face_l"]),
                                                       p(s["zl"]), None, ST()),
                                  "raster_light")
                 if sched_early and not self.mesh_terms_first and not mesh_on_third:
@@ -657,11 +660,21 @@ class FitEngine:
             sparse = 0 if (self.keep_image or self.perceptual is not None) else 2
             # (geometry-only stage in the loss-only image mode: nothing reads the camera view's face ids — silhouette only)
             face_c = p(s["face_c"]) if (app or self.keep_image or not self.sil_only_raster) else None
-            self._ck(L.harp_rasterize_l1_fwd(p(s["ndc_c"]), p(tp.faces), B, V, F, S, 1 | sparse, ops.SIL_BLUR, ops.SIL_SIGMA, p(s["ws_c"]), face_c,
+            self._ck(L.harp_rasterize_l1_fwd(p(s["ndc_c"]), p(tp.faces), B, V, F, S, 1 | sparse | pre, ops.SIL_BLUR, ops.SIL_SIGMA, p(s["ws_c"]), face_c,
                                              None, p(s["alpha"]), p(self.y_sil) if coarse else None, p(ltfid), wp(0), lp(0), p(s["g_alpha"]),
                                              p(self.bg_sil) if sparse else None, ST()),
                      "raster_cam")
-        if self.camera_first:
+        # `paired_setup`: the set-up of BOTH views on the main stream, in front of the camera raster
+        pair_ev, pre = None, 0
+        if self.paired_setup and shadow and fused and self.camera_first:
+            fork = cur.record_event()                   # fork point = end of the mesh chain (the key-point / mesh terms need no more)
+            self._ck(L.harp_raster_setup_pair(p(s["ndc_c"]), ops.SIL_BLUR, p(s["ws_c"]), p(s["ndc_l"]), 0.0, p(s["ws_l"]), p(tp.faces), B, V, F, S, ST()),
+                     "raster_setup_pair")
+            pre = 4
+            pair_ev = cur.record_event() if self.overlap else None
+            camera_view()
+            light_view(fork)
+        elif self.camera_first:
             fork = cur.record_event()                   # fork point = end of the mesh chain, before the camera-view launches
             camera_view()
             light_view(fork)
@@ -1094,7 +1107,7 @@ class FitEngine:
         # every switch the enqueued launch sequence depends on is part of the key: flipping one re-captures instead of replaying a
         # graph recorded for another configuration
         gkey = (coarse, app, scheduled, n, self.keep_image, self.fused_loss, self.self_shadow, tuple(self.frozen), self.overlap, self.early_terms,
-                self.packed_texels, self.fused_keep, self.mesh_third, self.graph_order, fold, self.fused_terms, self.zl_tile_flags, self.accumulate_loss, self.lean_app_stage, self.sil_only_raster, self.auto_draw, self.late_texture_terms, self.mesh_terms_first, self.camera_first, self.tail_side, self.fused_bwd, self.fused_chain, self.fused_front, self.wide_front, self.wide_back, self.fused_back, self.consume_gzl, self.keep_depth, dist_on, self.overlap_allreduce,
+                self.packed_texels, self.fused_keep, self.mesh_third, self.graph_order, fold, self.fused_terms, self.zl_tile_flags, self.accumulate_loss, self.lean_app_stage, self.sil_only_raster, self.auto_draw, self.paired_setup, self.late_texture_terms, self.mesh_terms_first, self.camera_first, self.tail_side, self.fused_bwd, self.fused_chain, self.fused_front, self.wide_front, self.wide_back, self.fused_back, self.consume_gzl, self.keep_depth, dist_on, self.overlap_allreduce,
                 self.comm is not None, self.perceptual is not None and app)
         g = self._graphs.get(gkey)
         if g is None:

@@ -34,6 +34,12 @@ typedef struct ihipStream_t* hipStream_t;
 size_t harp_rasterize_ws_bytes(int B, int F, int S);
 int harp_rasterize_fwd(const float* ndc, const int32_t* faces, int B, int V, int F, int S, int soft, float blur_radius,
                        float sigma, void* ws, int32_t* face_id, float* zbuf, float* alpha, hipStream_t stream);
+/* The set-up part of the rasteriser calls below (face records with the blur-dilated bbox, per-super-tile face lists, launch order:
+ * PyTorch3D's coarse rasterisation, renderer/renderer_helper.py:52-58, :344, :353) for TWO views of the same meshes in three launches
+ * instead of six.  A rasteriser call on a workspace prepared here passes bit 2 (value 4) in its `soft` / `sparse` argument and then only
+ * launches its tile pass.  blur_radius_x = the blur_radius of that view's pass (0 for a hard K = 1 pass). */
+int harp_raster_setup_pair(const float* ndc_a, float blur_radius_a, void* ws_a, const float* ndc_b, float blur_radius_b, void* ws_b,
+                           const int32_t* faces, int B, int V, int F, int S, hipStream_t stream);
 /* K = 1 depth pass (the light view, renderer_helper.py:344) into a depth map zbuf that the caller KEEPS between calls.  st_state:
  * B * ceil(S/64)^2 ints, zero before the first call and owned by the library afterwards — which 64x64 super-tiles of zbuf hold -1
  * everywhere.  With sparse != 0 (face ids of super-tiles without a face are not written, as with soft bit 1 of harp_rasterize_fwd) a
