@@ -202,6 +202,7 @@ class HandFront(ctypes.Structure):
 
 SIGNATURES["harp_hand_front_fwd"] = (_i, [ctypes.POINTER(HandFront), _vp])
 SIGNATURES["harp_hand_front_wide_fwd"] = (_i, [ctypes.POINTER(HandFront), _vp, _vp])
+SIGNATURES["harp_hand_front_hybrid_fwd"] = (_i, [ctypes.POINTER(HandFront), _vp])
 SIGNATURES["harp_hand_back_bwd"] = (_i, [ctypes.POINTER(HandFront), _vp, _vp, _vp])
 SIGNATURES["harp_hand_back_wide_bwd"] = (_i, [ctypes.POINTER(HandFront), _vp, _vp, _vp, _vp])
 

@@ -205,7 +205,7 @@ __global__ void __launch_bounds__(kChainThreads) hand_front_kernel(const harp_ha
 //      blend-shape rows of a frame go through FOUR CUs' L1 instead of one), followed by the wide mesh chain (chain_wide.hip).  Every
 //      workgroup gathers the frame's rows and runs the 16-joint chain (same arithmetic, a few hundred flops); part 0 writes the shared rows.
 constexpr int kWideThreads = 256;
-__global__ void __launch_bounds__(kWideThreads) hand_front_wide_kernel(const harp_hand_front H) {
+__global__ void __launch_bounds__(kWideThreads) hand_front_wide_kernel(const harp_hand_front H, const int clear_here) {
   __shared__ float s_pose[48], s_beta[NB], s_tr[3], s_pm[NP], s_A[NJ * 12];
   __shared__ float sR[NJ][9], sJ[NJ][3], sG[NJ][12], s_j16[NJ][3];
   const harp_mesh_chain& A = H.chain;
@@ -330,6 +330,12 @@ __global__ void __launch_bounds__(kWideThreads) hand_front_wide_kernel(const har
   }
   __syncthreads();
   if (warm == 1.2345e-30f) H.colors[9] = warm;      // keeps the warm-up loads alive (never true)
+  if (clear_here && H.step.clear_mesh_grads) {       // (hybrid front: the one-workgroup chain that follows does not clear)
+    const int V = A.V0 + A.E0, per = (V * 3 + cb::kChainParts - 1) / cb::kChainParts;
+    float* gv = const_cast<float*>(A.g_vd) + (size_t)b * V * 3;
+    for (int k = part * per + tid; k < min((part + 1) * per, V * 3); k += kWideThreads) gv[k] = 0.f;
+    if (lead && tid < A.NJ * 3) const_cast<float*>(A.g_joints_m)[(size_t)b * A.NJ * 3 + tid] = 0.f;
+  }
   // ---- blend shapes + skinning (lbs.hip: lbs_skin_kernel), one lane per vertex of this part's quarter
   const int v = part * kPer + tid;
   if (tid < kPer && v < NV) {
@@ -421,9 +427,23 @@ int harp_hand_front_wide_fwd(const harp_hand_front* h, float* part_ws, hipStream
     return HARP_ERR_ARG;
   if ((h->step.schedule && (!h->step.sched_row || h->step.n_rows <= 0)) || (h->step.clear_mesh_grads && (!a.g_vd || !a.g_joints_m)))
     return HARP_ERR_ARG;
-  hipLaunchKernelGGL(hand_front_wide_kernel, dim3(a.B * cb::kChainParts), dim3(kWideThreads), 0, stream, *h);
+  hipLaunchKernelGGL(hand_front_wide_kernel, dim3(a.B * cb::kChainParts), dim3(kWideThreads), 0, stream, *h, 0);
   HARP_CHECK_LAUNCH();
   return harp_detail_chain_wide_tail(a, h->step.clear_mesh_grads, part_ws, stream);
+}
+
+// Hybrid: the hand layer on four workgroups per frame (above), then the mesh chain as ONE workgroup per frame (harp_mesh_chain_fwd): two
+// launches.  Same outputs.
+int harp_hand_front_hybrid_fwd(const harp_hand_front* h, hipStream_t stream) {
+  if (!h) return HARP_ERR_ARG;
+  const harp_mesh_chain& a = h->chain;
+  if (a.B <= 0 || a.V0 != NV || a.E0 < 0 || a.NJ != 21 || !a.verts_mm || !a.joints_mm || !h->fid || !h->pose48 || !h->betas || !h->trans_b ||
+      !h->cam_R || !h->cam_T || !h->light_pos || !h->colors || !h->lbs_ws || h->tables.wrist_pose ||
+      (h->step.schedule && (!h->step.sched_row || h->step.n_rows <= 0)) || (h->step.clear_mesh_grads && (!a.g_vd || !a.g_joints_m)))
+    return HARP_ERR_ARG;
+  hipLaunchKernelGGL(hand_front_wide_kernel, dim3(a.B * cb::kChainParts), dim3(kWideThreads), 0, stream, *h, 1);
+  HARP_CHECK_LAUNCH();
+  return harp_mesh_chain_fwd(&a, stream);
 }
 
 }  // extern "C"

@@ -469,6 +469,9 @@ __device__ __forceinline__ void raster_tile(RasterSmem<MODE>& sm, unsigned vbloc
         const int slot = block_compact(in_img && sm.sat[threadIdx.x] == 0, 0, lds_cnt, ncand);
         if (slot >= 0) sm.cand[slot] = (unsigned char)threadIdx.x;
         __syncthreads();
+#if defined(RASTER_ABLATE) && (RASTER_ABLATE & 512)
+        ncand = 0;                 // ablation (timing only): no soft-silhouette pair walk
+#endif
         if (ncand > 0) {
           unsigned short* wl = sm.pairs + w * 128;
           const int cper = (ncand + 3) >> 2, c_lo = min(ncand, w * cper), c_hi = min(ncand, (w + 1) * cper);

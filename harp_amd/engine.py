@@ -172,6 +172,7 @@ class FitEngine:
         # 0.65-ms step whose second stream is the longer branch of the fork) — off there.
         wide_ok = self.fused_front and (self.topo.V + 3) // 4 <= 1024
         self.wide_front = wide_ok and self.use_arm
+        self.hybrid_front = False            # hand path: hand layer on four workgroups per frame + one-workgroup mesh chain (two launches)
         self.wide_back = wide_ok             # the tail: mesh-chain backward + per-vertex hand / arm layer backward on four workgroups per frame
         # ---- switches (all on in production; tools/dev and bench.py flip some of them to measure their effect)
         self.overlap = True              # second HIP stream (light view, silhouette backward, parameter-only terms); False: one stream
@@ -189,6 +190,7 @@ class FitEngine:
         self.consume_gzl = True          # the depth backward clears the shadow-map gradient entries it consumes: no per-step clear of that image (33.5 MB at B = 32, 512^2)
         self.fused_keep = True           # keep_image with the fused loss: the shader backward also writes y_pred (no forward shading launch either)
         self.keep_image = True           # shader forward writes the rendered image s["rgb"] (False: loss + gradient only)
+        self.sil_late = False            # silhouette backward after the shader backward instead of beside it (measured: see profiles/r05_wide_ab.txt)
         self.paired_setup = False        # rasteriser set-up of both views as three launches on the main stream (harp_raster_setup_pair; the light raster no longer waits for three set-up launches of its own on the second stream).  Measured, same box: hand +7 us / step (B = 32), +5 (B = 18), arm +15; together with wide_front -3 ... +5: off (profiles/r05_wide_ab.txt)
         self.late_texture_terms = False  # texture regularisers behind the light view on the second stream (see forward_backward)
         self.mesh_terms_first = True     # key-point term + mesh regularisers run before the light raster (under the raster set-up) instead of after it
@@ -382,6 +384,8 @@ class FitEngine:
                          "arm_front_wide_fwd")
             elif self.use_arm:
                 self._ck(L.harp_arm_front_fwd(ctypes.byref(self._arm_struct(fid, B, shadow, False, step)), st), "arm_front_fwd")
+            elif self.hybrid_front and not self.wide_front:
+                self._ck(L.harp_hand_front_hybrid_fwd(ctypes.byref(self._hand_struct(fid, B, shadow, False, step)), st), "hand_front_hybrid_fwd")
             elif self.wide_front:
                 self._ck(L.harp_hand_front_wide_fwd(ctypes.byref(self._hand_struct(fid, B, shadow, False, step)), p(s["chain_parts"]), st),
                          "hand_front_wide_fwd")
@@ -736,7 +740,8 @@ class FitEngine:
             else:
                 self._ck(L.harp_shade_bwd(ctypes.byref(a), ST()), "shade_bwd")
             if sil_after is not None:
-                launch_sil(sil_after)
+                # `sil_late`: the silhouette backward BEHIND the shader backward (next to the depth backward) instead of next to it
+                launch_sil(cur.record_event() if self.sil_late else sil_after)
             if shared_terms:
                 # the normal-map chain rule (and, for N > 1, the early all-reduce of the map gradients, which overlaps with the mesh /
                 # hand-layer backward) only feeds the optimiser: with `tail_side` it leaves the critical path for the second stream, which
@@ -1107,7 +1112,7 @@ class FitEngine:
         # every switch the enqueued launch sequence depends on is part of the key: flipping one re-captures instead of replaying a
         # graph recorded for another configuration
         gkey = (coarse, app, scheduled, n, self.keep_image, self.fused_loss, self.self_shadow, tuple(self.frozen), self.overlap, self.early_terms,
-                self.packed_texels, self.fused_keep, self.mesh_third, self.graph_order, fold, self.fused_terms, self.zl_tile_flags, self.accumulate_loss, self.lean_app_stage, self.sil_only_raster, self.auto_draw, self.paired_setup, self.late_texture_terms, self.mesh_terms_first, self.camera_first, self.tail_side, self.fused_bwd, self.fused_chain, self.fused_front, self.wide_front, self.wide_back, self.fused_back, self.consume_gzl, self.keep_depth, dist_on, self.overlap_allreduce,
+                self.packed_texels, self.fused_keep, self.mesh_third, self.graph_order, fold, self.fused_terms, self.zl_tile_flags, self.accumulate_loss, self.lean_app_stage, self.sil_only_raster, self.auto_draw, self.sil_late, self.paired_setup, self.late_texture_terms, self.mesh_terms_first, self.camera_first, self.tail_side, self.fused_bwd, self.fused_chain, self.fused_front, self.wide_front, self.hybrid_front, self.wide_back, self.fused_back, self.consume_gzl, self.keep_depth, dist_on, self.overlap_allreduce,
                 self.comm is not None, self.perceptual is not None and app)
         g = self._graphs.get(gkey)
         if g is None:

@@ -466,6 +466,8 @@ int harp_hand_front_fwd(const harp_hand_front* h, hipStream_t stream);
  * gathers the rows and runs the 16-joint chain; the frame's 1.35 MB of blend-shape rows go through four CUs' L1) + harp_mesh_chain_fwd_wide:
  * THREE launches of 4 B workgroups.  Same outputs, same `step` semantics.  part_ws as for harp_mesh_chain_fwd_wide. */
 int harp_hand_front_wide_fwd(const harp_hand_front* h, float* part_ws, hipStream_t stream);
+/* hybrid: the hand layer on four workgroups per frame, then harp_mesh_chain_fwd (one workgroup per frame): two launches, same outputs */
+int harp_hand_front_hybrid_fwd(const harp_hand_front* h, hipStream_t stream);
 /* The counterpart for the backward tail of a step (csrc/hand_back.hip): harp_mesh_chain_bwd + harp_lbs_mano_bwd + harp_frame_setup_bwd
  * (autograd of utils/visualize.py:16-88 / manopth/manolayer.py:108-296 down to the rows params[...][fid]) as THREE launches instead of
  * six: mesh chain + joint split + per-vertex skinning backward + trans / cam / light scatter per frame, the two vertex reductions, the
