@@ -1688,3 +1688,89 @@ def test_fused_arm_front_and_back_match_building_blocks(coarse, app, wide):
                 assert rel(a, b) < tol, (frames, k, rel(a, b))
             else:
                 assert a.abs().max() == 0, (frames, k)
+
+
+@pytest.mark.parametrize("kind", ["hand", "arm"])
+def test_wide_mesh_chain_raw_abi_equals_the_one_workgroup_chain(sc, kind):
+    """harp_mesh_chain_fwd_wide / harp_mesh_chain_bwd_wide (four workgroups per frame, csrc/chain_wide.hip) through the raw C ABI against
+    harp_mesh_chain_fwd / harp_mesh_chain_bwd on the same inputs: every forward output and every backward output (g_v0, g_joints_mm, g_cam_T,
+    g_light_pos, g_disp) to float32 summation order; with and without the light view / the normal gradient; the hand mesh (3093 vertices)
+    and the arm mesh (4083: 1021 vertices per workgroup, 98 KB of LDS in the backward kernels)."""
+    import ctypes
+    from harp_amd import _lib, synth
+    from harp_amd.engine import FitEngine
+    L = _lib.lib()
+    if kind == "hand":
+        eng = FitEngine(sc["model_np"], sc["topo_np"], sc["tpl"]["verts_uvs"], sc["tpl"]["faces_uvs"], sc["uv_mask"].float(), sc["seq"], sc["S"],
+                        sc["focal"], 3, device=DEV, seed=1)
+    else:
+        tpl = synth.load_template("arm")
+        topo_np = synth.build_topology(tpl["faces0"], 1026)
+        m = synth.make_smplx_arm_model(tpl, seed=0)
+        g0 = torch.Generator().manual_seed(1)
+        T, S = 3, 128
+        focal = 1000.0 * S / 224.0
+        c = m["v_template"].mean(0)
+        seq = dict(pose=torch.randn(T, 45, generator=g0) * 0.15, rot=torch.randn(T, 3, generator=g0) * 0.2, trans=torch.randn(T, 3, generator=g0) * 0.01,
+                   shape=torch.randn(T, 10, generator=g0) * 0.3, joints=torch.randn(T, 21, 3, generator=g0) * 0.05,
+                   cam=torch.tensor([[2 * focal / (S * 1.6), -float(c[0]), -float(c[1])]]).repeat(T, 1))
+        eng = FitEngine(m, topo_np, tpl["verts_uvs"], tpl["faces_uvs"], torch.from_numpy(tpl["uv_mask"]).float() / 255, seq, S, focal, 3, device=DEV,
+                        use_arm=True, opt_arm_pose=True)
+    B, V = 3, eng.topo.V
+    g = torch.Generator().manual_seed(5)
+    with torch.no_grad():
+        eng.params["verts_disps"].copy_((torch.randn(V, 1, generator=g) * 0.001).to(DEV))
+    fid = torch.tensor([2, 0, 1], dtype=torch.int32, device=DEV)
+    eng.fid.copy_(fid)
+    eng.fused_front = False
+    eng._mesh_forward(eng.fid, B, shadow=True)               # frame set-up + hand / arm layer + the one-workgroup chain: fills every input
+    torch.cuda.synchronize()
+    s = eng.s
+    fwd_keys = ("joints_m", "vs", "n1", "il1", "vd", "n2", "il2", "ndc_c", "centroid", "light_R", "light_T", "ndc_l")
+    bwd_keys = ("g_v0", "g_joints_mm", "g_light_pos", "g_cam_T")
+    ws = torch.empty(L.harp_mesh_chain_wide_ws_floats(B, V), dtype=torch.float32, device=DEV)
+    rnd = lambda t, sc_: t.copy_((torch.randn(t.shape, generator=g) * sc_).to(DEV))
+    for shadow, ng in ((True, True), (False, False), (True, False)):
+        out = {}
+        for wide in (False, True):
+            for k in fwd_keys:
+                s[k].fill_(7.0)
+            ch = eng._chain_struct(B, shadow, ng)
+            if wide:
+                _lib.check(L.harp_mesh_chain_fwd_wide(ctypes.byref(ch), 0, _lib.ptr(ws), _lib.stream()), "fwd_wide")
+            else:
+                _lib.check(L.harp_mesh_chain_fwd(ctypes.byref(ch), _lib.stream()), "fwd")
+            torch.cuda.synchronize()
+            f_out = {k: s[k].clone() for k in fwd_keys}
+            # backward on seeded image-space gradients
+            gg = torch.Generator().manual_seed(9)
+            for k, sc_ in (("g_ndc_c", 1e-3), ("g_ndc_l", 1e-3), ("g_n2", 1e-3), ("g_vd", 1e-2), ("g_joints_m", 1e-2), ("g_light_R", 1e-3), ("g_light_T", 1e-3)):
+                s[k].copy_((torch.randn(s[k].shape, generator=gg) * sc_).to(DEV))
+            for k in bwd_keys:
+                s[k].zero_()
+            eng.grads["verts_disps"].zero_()
+            ch = eng._chain_struct(B, shadow, ng)
+            if wide:
+                _lib.check(L.harp_mesh_chain_bwd_wide(ctypes.byref(ch), _lib.ptr(ws), _lib.stream()), "bwd_wide")
+            else:
+                _lib.check(L.harp_mesh_chain_bwd(ctypes.byref(ch), _lib.stream()), "bwd")
+            torch.cuda.synchronize()
+            out[wide] = (f_out, {k: s[k].clone() for k in bwd_keys}, eng.grads["verts_disps"].clone())
+        for k in fwd_keys:
+            if not shadow and k in ("centroid", "light_R", "light_T", "ndc_l"):
+                continue
+            a, b = out[True][0][k], out[False][0][k]
+            if k in ("n1", "n2"):
+                assert (a - b).abs().mean().item() < 5e-6 and (a - b).abs().max().item() < 2e-3, k
+            elif k in ("il1", "il2"):
+                assert ((a - b).abs() / b.abs().clamp_min(1.0)).max().item() < 2e-3, k
+            else:
+                assert (a - b).abs().max().item() <= 2e-6 * max(1.0, b.abs().max().item()), (kind, shadow, k)
+        for k in bwd_keys:
+            if not shadow and k == "g_light_pos":
+                continue
+            assert rel(out[True][1][k].double().cpu(), out[False][1][k].double().cpu()) < 2e-5, (kind, shadow, ng, k)
+        assert rel(out[True][2].double().cpu(), out[False][2].double().cpu()) < 2e-5, (kind, shadow, ng, "g_disp")
+    # light_only is not a wide form
+    ch = eng._chain_struct(B, True, True); ch.light_only = 1
+    assert L.harp_mesh_chain_bwd_wide(ctypes.byref(ch), _lib.ptr(ws), _lib.stream()) == 1
