@@ -978,8 +978,6 @@ class FitEngine:
             self.grads[k].zero_()
         if tick:
             self._adam_tick(coarse, app)
-        for _ in range(int(os.environ.get("HARP_DUMMY_NODES", "0"))):      # measurement only: n dependent no-op nodes in front of Adam (what does a node cost in a replay?)
-            self._ck(L.harp_scale(p(self.s["g_centroid"]), 1.0, 1, p(self.s["g_centroid"]), st), "dummy")
         bufs = (self.p_buf.data_ptr(), self.g_buf.data_ptr(), self.m_buf.data_ptr(), self.v_buf.data_ptr())
         if coarse and app:                               # both groups in one launch
             (o0, n0), (o1, n1) = self.coarse_span, self.app_span

@@ -1234,7 +1234,12 @@ def test_light_camera_incl_look_at_replacement_branch():
                                       dict(mesh_terms_first=False, mesh_third=False), dict(tail_side=True), dict(consume_gzl=False), dict(keep_depth=False),
                                       dict(fold_step=False), dict(fused_terms=False), dict(fold_step=False, fused_terms=False),
                                       dict(fold_step=False, mesh_third=False), dict(fused_terms=False, consume_gzl=False), dict(zl_tile_flags=True),
-                                      dict(fused_terms=False, zl_tile_flags=True)])
+                                      dict(fused_terms=False, zl_tile_flags=True),
+                                      # round 5: four-workgroups-per-frame forms, paired rasteriser set-up, late terms (harp_amd/engine.py)
+                                      dict(wide_front=True), dict(wide_back=False), dict(wide_front=True, wide_back=False), dict(hybrid_front=True),
+                                      dict(paired_setup=True), dict(paired_setup=True, wide_front=True), dict(paired_setup=True, overlap=False),
+                                      dict(late_texture_terms=True), dict(late_texture_terms=True, mesh_terms_first=False), dict(sil_late=True),
+                                      dict(paired_setup=True, keep_depth=False)])
 def test_schedule_switches_give_the_default_schedules_result(switches):
     """The stream / capture-order switches of FitEngine (graph_order, mesh_third, camera_first, overlap, early_terms, mesh_terms_first,
     tail_side) only move launches between streams: losses and the whole gradient arena of every non-default combination must equal the
@@ -1264,13 +1269,17 @@ def test_schedule_switches_give_the_default_schedules_result(switches):
     for k, v in switches.items():
         setattr(eng, k, v)
     try:
+        # (the four-workgroups-per-frame forms also change the ORDER of float sums inside the front / back — vertex positions move by 1e-7,
+        #  which the conditioning of the silhouette-rim gradients amplifies: the bounds of test_fused_front_matches_building_blocks)
+        arith = any(k in switches for k in ("wide_front", "wide_back", "hybrid_front"))
+        tol_g, tol_k = (1e-3, 1e-3) if arith else (1e-5, 1e-4)
         for graph in (False, True):
             g, l = run(graph)
-            assert rel(g, ref[graph][0]) < 1e-5, (switches, graph, rel(g, ref[graph][0]))
+            assert rel(g, ref[graph][0]) < tol_g, (switches, graph, rel(g, ref[graph][0]))
             assert ((l - ref[graph][1]).abs() <= 1e-5 * ref[graph][1].abs() + 1e-9).all(), (switches, graph, l, ref[graph][1])
             for k in ("pose", "cam", "verts_disps", "shape", "light_positions", "texture", "normal_map"):
                 a, b = eng.arena.view(g, k), eng.arena.view(ref[graph][0], k)
-                assert rel(a, b) < 1e-4, (switches, graph, k, rel(a, b))
+                assert rel(a, b) < tol_k, (switches, graph, k, rel(a, b))
     finally:
         for k, v in defaults.items():
             setattr(eng, k, v)
