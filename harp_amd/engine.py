@@ -190,6 +190,7 @@ class FitEngine:
         self.consume_gzl = True          # the depth backward clears the shadow-map gradient entries it consumes: no per-step clear of that image (33.5 MB at B = 32, 512^2)
         self.fused_keep = True           # keep_image with the fused loss: the shader backward also writes y_pred (no forward shading launch either)
         self.keep_image = True           # shader forward writes the rendered image s["rgb"] (False: loss + gradient only)
+        self.mesh_terms_late = False     # key-point / mesh terms on the second stream behind the silhouette backward (beside the shader backward)
         self.sil_late = False            # silhouette backward after the shader backward instead of beside it (measured: see profiles/r05_wide_ab.txt)
         self.paired_setup = False        # rasteriser set-up of both views as three launches on the main stream (harp_raster_setup_pair; the light raster no longer waits for three set-up launches of its own on the second stream).  Measured, same box: hand +7 us / step (B = 32), +5 (B = 18), arm +15; together with wide_front -3 ... +5: off (profiles/r05_wide_ab.txt)
         self.late_texture_terms = False  # texture regularisers behind the light view on the second stream (see forward_backward)
@@ -610,6 +611,8 @@ class FitEngine:
         # ---- the light-view chain (centroid -> light camera -> projection -> K=1 raster) is independent of the camera-view chain:
         #      it runs on the second HIP stream so the two rasterisations overlap (fork / join is captured into the graph); the mesh
         #      regularisers and the key-point term follow it there (the light raster is the shorter of the two)
+        mesh_late = bool(self.mesh_terms_late and sched_early and self.overlap and coarse and app and not mesh_on_third and self.perceptual is None
+                         and not (self.fused_bwd and coarse and app))
         def light_view(fork=None):
             if fork is None:
                 wait_s(side, cur)
@@ -629,7 +632,7 @@ class FitEngine:
             if not go:
                 third_branch()
             with torch.cuda.stream(side):
-                if sched_early and self.mesh_terms_first and not mesh_on_third:
+                if sched_early and self.mesh_terms_first and not mesh_on_third and not mesh_late:
                     mesh_terms()
                 if shadow:
                     if not fused:
@@ -646,7 +649,7 @@ class FitEngine:
                         self._ck(L.harp_rasterize_fwd(p(s["ndc_l"]), p(tp.faces), B, V, F, S, (0 if self.keep_image else 2) | pre, 0.0, 1.0, p(s["ws_l"]), p(s["face_l"]),
                                                       p(s["zl"]), None, ST()),
                                  "raster_light")
-                if sched_early and not self.mesh_terms_first and not mesh_on_third:
+                if sched_early and not self.mesh_terms_first and not mesh_on_third and not mesh_late:
                     mesh_terms()
                 for fn in deferred:
                     fn()
@@ -701,6 +704,8 @@ class FitEngine:
             with torch.cuda.stream(side):
                 self._ck(L.harp_silhouette_bwd(p(tp.faces), B, V, F, S, ops.SIL_BLUR, ops.SIL_SIGMA, p(s["ws_c"]), p(s["alpha"]), p(s["g_alpha"]),
                                                p(s["g_ndc_c"]), ST()), "silhouette_bwd")
+                if mesh_late:
+                    mesh_terms()                # `mesh_terms_late`: beside the (latency-bound) shader backward instead of beside the (VALU-bound) rasterisers
         if coarse and not fuse_bwd:
             if not app and self.overlap:
                 # geometry-only stage: there is no shader backward to run next to — the silhouette backward stays on the critical stream
@@ -1110,7 +1115,7 @@ class FitEngine:
         # every switch the enqueued launch sequence depends on is part of the key: flipping one re-captures instead of replaying a
         # graph recorded for another configuration
         gkey = (coarse, app, scheduled, n, self.keep_image, self.fused_loss, self.self_shadow, tuple(self.frozen), self.overlap, self.early_terms,
-                self.packed_texels, self.fused_keep, self.mesh_third, self.graph_order, fold, self.fused_terms, self.zl_tile_flags, self.accumulate_loss, self.lean_app_stage, self.sil_only_raster, self.auto_draw, self.sil_late, self.paired_setup, self.late_texture_terms, self.mesh_terms_first, self.camera_first, self.tail_side, self.fused_bwd, self.fused_chain, self.fused_front, self.wide_front, self.hybrid_front, self.wide_back, self.fused_back, self.consume_gzl, self.keep_depth, dist_on, self.overlap_allreduce,
+                self.packed_texels, self.fused_keep, self.mesh_third, self.graph_order, fold, self.fused_terms, self.zl_tile_flags, self.accumulate_loss, self.lean_app_stage, self.sil_only_raster, self.auto_draw, self.mesh_terms_late, self.sil_late, self.paired_setup, self.late_texture_terms, self.mesh_terms_first, self.camera_first, self.tail_side, self.fused_bwd, self.fused_chain, self.fused_front, self.wide_front, self.hybrid_front, self.wide_back, self.fused_back, self.consume_gzl, self.keep_depth, dist_on, self.overlap_allreduce,
                 self.comm is not None, self.perceptual is not None and app)
         g = self._graphs.get(gkey)
         if g is None:

@@ -1238,7 +1238,8 @@ def test_light_camera_incl_look_at_replacement_branch():
                                       # round 5: four-workgroups-per-frame forms, paired rasteriser set-up, late terms (harp_amd/engine.py)
                                       dict(wide_front=True), dict(wide_back=False), dict(wide_front=True, wide_back=False), dict(hybrid_front=True),
                                       dict(paired_setup=True), dict(paired_setup=True, wide_front=True), dict(paired_setup=True, overlap=False),
-                                      dict(late_texture_terms=True), dict(late_texture_terms=True, mesh_terms_first=False), dict(sil_late=True),
+                                      dict(late_texture_terms=True), dict(late_texture_terms=True, mesh_terms_first=False), dict(sil_late=True), dict(mesh_terms_late=True),
+                                      dict(mesh_terms_late=True, graph_order=False), dict(mesh_terms_late=True, sil_late=True),
                                       dict(paired_setup=True, keep_depth=False)])
 def test_schedule_switches_give_the_default_schedules_result(switches):
     """The stream / capture-order switches of FitEngine (graph_order, mesh_third, camera_first, overlap, early_terms, mesh_terms_first,
