@@ -326,14 +326,21 @@ LOSS_WEIGHTS = {"silhouette": 7.0, "kps_anchor": 10.0, "vert_disp_reg": 2.0, "no
 
 
 def step_losses(params, fid, model, topo, targets, S, focal, ref_verts, dist_albedo, dist_normal,
-                coarse=True, app=True, self_shadow=True, use_arm=False):
+                coarse=True, app=True, self_shadow=True, use_arm=False, mask_from_render=None):
     """Loop body optimize_sequence.py:446-558 (VGG term excluded: SURVEY §8(f)). Returns (dict, weighted sum,
     aux dict with images)."""
     y_true, y_sil_true, y_sil_col = targets["y_true"][fid], targets["y_sil"][fid], targets["y_sil_col"][fid]
     joints, verts = prepare_mesh(params, fid, model, topo, use_arm=use_arm)
     cam = params["cam"][fid]
     y_sil_pred = render_silhouette(verts, topo["faces"], cam, S, focal)
-    y_pred = render_rgb(verts, topo, params, cam, S, focal, self_shadow=self_shadow)
+    raux = None
+    if mask_from_render is not None:
+        # (tests: the photometric mask of this evaluation is decided from the SAME render — the float32-undecidable pixels the render flags —
+        #  instead of by a second, gradient-free render in front of it: mask_from_render(y_pred, render aux, y_sil_col) -> y_sil_col)
+        y_pred, raux = render_rgb(verts, topo, params, cam, S, focal, self_shadow=self_shadow, return_aux=True, flag_ambiguous=True)
+        y_sil_col = mask_from_render(y_pred.detach(), raux, y_sil_col)
+    else:
+        y_pred = render_rgb(verts, topo, params, cam, S, focal, self_shadow=self_shadow)
     loss = {}
     if coarse:
         loss["silhouette"] = F.l1_loss(y_sil_true, y_sil_pred)                                      # :519
@@ -347,7 +354,7 @@ def step_losses(params, fid, model, topo, targets, S, focal, ref_verts, dist_alb
         loss["albedo"] = albedo_reg(params["texture"], dist_albedo, params["uv_mask"])              # :552
         loss["normal_reg"] = normal_reg(params["normal_map"], dist_normal, params["uv_mask"])       # :553
     total = sum(l * LOSS_WEIGHTS[k] for k, l in loss.items())                                        # :556-558
-    return loss, total, {"y_sil_pred": y_sil_pred, "y_pred": y_pred, "verts": verts, "joints": joints}
+    return loss, total, {"y_sil_pred": y_sil_pred, "y_pred": y_pred, "verts": verts, "joints": joints, "render_aux": raux}
 
 
 # ----------------------------------------------------------------------------------------------

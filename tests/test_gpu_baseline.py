@@ -194,7 +194,8 @@ def _batch_all_gradients(kind, T, S, tag, mask_tag, seed, keeps=(True, False), u
     on the frames, so the batch objective is the average of the T one-frame objectives; it is evaluated frame by frame (K=50 fragments of
     ONE frame at a time) and the gradients accumulate.  Float32-undecidable pixels of all frames are out of the mask (both sides);
     unmasked_tol: afterwards the same comparison with NO pixel removed, at that looser gradient bound (losses rel 1e-4)."""
-    from tests._scene import ambiguous_pixels
+    from oracle import harp_ref as H
+    import torch.nn.functional as F
     B = T
     use_arm = kind == "arm"
     case = make_fit_case(kind, T=T, S=S, B=B, seed=seed, device=DEV)
@@ -202,61 +203,95 @@ def _batch_all_gradients(kind, T, S, tag, mask_tag, seed, keeps=(True, False), u
     P, model, targets = oracle_inputs(case, torch.float64)
     y_col_full = case["targets"]["y_sil_col"].clone()
     y_col = y_col_full.clone()
-    n_amb = n_cov = 0
-    for f in range(T):
-        amb, aux = ambiguous_pixels(P, model, case["topo"], S, case["focal"], [f], targets["y_true"], use_arm=use_arm)
-        y_col[f][amb[0]] = 0.0
-        n_amb += amb.sum().item()
-        n_cov += (aux["pix_to_face"][..., 0] >= 0).sum().item()
-    check_removed(mask_tag, n_amb / max(n_cov, 1))
     fid = torch.arange(T)
     keys = [k for k in ORACLE_KEYS if use_arm or k != "wrist_pose"]
     rows_keys = ("pose", "cam", "rot", "trans") + (("wrist_pose",) if use_arm else ())
-    for masked in (True, False):
-        if not masked and unmasked_tol is None:
-            break
+    passes = (True, False) if unmasked_tol is not None else (True,)
+    eng.auto_draw = False
+    eng.draw_texture_offsets()                           # ONE draw for the oracle and both engine passes
+    # ---- the oracle, ONE render per frame: it flags the float32-undecidable pixels of the frame (tests/_scene.py: ambiguous_pixels — the same
+    #      flags from the same float64 forward pass, which used to be a second render), they leave the photometric mask of this evaluation
+    #      and of the engine's masked pass; the unmasked objective differs from the masked one only in that mask, so its gradient is the
+    #      masked one plus the gradient of  w_photo * (photo(full mask) - photo(masked))  through the same render
+    for k in ORACLE_KEYS:
+        P[k].grad = None
+    rv = case.get(("ref_verts", torch.float64))
+    if rv is None:
+        with torch.no_grad():
+            _, rv = H.prepare_mesh(P, torch.tensor([0]), model, case["topo"], use_arm=use_arm)
+        case[("ref_verts", torch.float64)] = rv
+    loss_sum, delta_grad, photo_full_sum = {}, {k: None for k in keys}, 0.0
+    full64 = y_col_full.double()
+    n_cov, counts = 0, [0]
+    for f in range(T):                                                # .grad accumulates over the T one-frame steps
+        def mask_from_render(y_pred, raux, col, f=f):
+            amb = raux["ambiguous"] | ((y_pred - targets["y_true"][f:f + 1]).abs() < 3e-4).any(-1)      # (+ the kink of the L1 term)
+            amb = amb & (raux["pix_to_face"][..., 0] >= 0)
+            counts[0] += amb.sum().item()
+            y_col[f][amb[0]] = 0.0
+            out = col.clone()
+            out[amb] = 0.0
+            return out
+        loss, total, aux = H.step_losses(P, torch.tensor([f]), model, case["topo"], targets, S, case["focal"], rv, eng.dist_albedo.cpu().long(),
+                                         eng.dist_normal.cpu().long(), coarse=True, app=True, self_shadow=eng.self_shadow, use_arm=use_arm,
+                                         mask_from_render=mask_from_render)
+        n_cov += (aux["render_aux"]["pix_to_face"][..., 0] >= 0).sum().item()
+        total.backward(retain_graph=unmasked_tol is not None)
+        for k, v in loss.items():
+            loss_sum[k] = loss_sum.get(k, 0.0) + v.item()
+        if unmasked_tol is not None:
+            m = full64[f].unsqueeze(0).unsqueeze(-1)
+            photo_full = F.l1_loss(targets["y_true"][f:f + 1] * m, aux["y_pred"] * m)
+            photo_full_sum += photo_full.item()
+            gs = torch.autograd.grad(H.LOSS_WEIGHTS["photo"] * (photo_full - loss["photo"]), [P[k] for k in keys], allow_unused=True)
+            for k, g_ in zip(keys, gs):
+                if g_ is not None:
+                    delta_grad[k] = g_.detach().clone() if delta_grad[k] is None else delta_grad[k] + g_
+        del loss, total, aux
+    check_removed(mask_tag, counts[0] / max(n_cov, 1))
+    # ---- the engine: the masked step and (unmasked_tol) the same step with NO pixel removed
+    got, lvs = {}, {}
+    for masked in passes:
         col = y_col if masked else y_col_full
-        gtol, ltol = (GRAD_TOL, LOSS_TOL) if masked else (unmasked_tol, 1e-4)
         case["targets"]["y_sil_col"] = col
         eng.set_targets(case["targets"]["y_true"], case["targets"]["y_sil"], col)
-        eng.draw_texture_offsets()
-        got, lvs = {}, {}
         for keep in keeps:
             eng.keep_image = keep
-            lvs[keep] = engine_eval(case, fid)
-            got[keep] = {k: eng.grads[k].detach().cpu().double().clone() for k in keys}
+            lvs[masked, keep] = engine_eval(case, fid)
+            got[masked, keep] = {k: eng.grads[k].detach().cpu().double().clone() for k in keys}
             if keep:
                 a, fc, rgb = eng.s["alpha"], eng.s["face_c"], eng.s["rgb"]
                 cov = fc >= 0
                 assert (a >= 0).all() and (a <= 1).all() and (fc >= -1).all() and (fc < eng.topo.F).all()
                 assert 0.02 < cov.float().mean().item() < 0.9 and (a[cov] > 0.49).all() and (rgb[~cov] == 1.0).all()
                 assert torch.isfinite(rgb).all() and torch.isfinite(eng.g_buf).all()
-        for k, v in lvs[keeps[0]].items():
-            assert abs(v - lvs[keeps[-1]][k]) <= LOSS_TOL * abs(v) + 1e-12, (k, v, lvs[keeps[-1]][k])
-        targets["y_sil_col"] = col.double()
-        for k in ORACLE_KEYS:
-            P[k].grad = None
-        loss_sum = {}
-        for f in range(T):                                            # .grad accumulates over the T one-frame steps
-            _, loss, _, _, _ = oracle_step(case, torch.tensor([f]), P=P, model=model, targets=targets)
-            for k, v in loss.items():
-                loss_sum[k] = loss_sum.get(k, 0.0) + v.item()
+        for k, v in lvs[masked, keeps[0]].items():
+            assert abs(v - lvs[masked, keeps[-1]][k]) <= LOSS_TOL * abs(v) + 1e-12, (k, v, lvs[masked, keeps[-1]][k])
+    for masked in passes:
+        gtol, ltol = (GRAD_TOL, LOSS_TOL) if masked else (unmasked_tol, 1e-4)
+        want_loss = dict(loss_sum) if masked else dict(loss_sum, photo=photo_full_sum)
+        want_grad = {}
+        for k in keys:
+            gk = P[k].grad
+            if not masked and delta_grad[k] is not None:
+                gk = delta_grad[k] if gk is None else gk + delta_grad[k]
+            want_grad[k] = gk
         for keep in keeps:
-            for k, v in loss_sum.items():
-                assert abs(lvs[keep][k] - v / T) <= ltol * abs(v / T) + 1e-9, (k, keep, lvs[keep][k], v / T)
+            for k, v in want_loss.items():
+                assert abs(lvs[masked, keep][k] - v / T) <= ltol * abs(v / T) + 1e-9, (k, keep, masked, lvs[masked, keep][k], v / T)
             worst = {}
             for k in keys:
-                if P[k].grad is None or P[k].grad.abs().max() == 0:
-                    assert got[keep][k].abs().max().item() == 0, (k, "expected an exactly zero gradient")
+                if want_grad[k] is None or want_grad[k].abs().max() == 0:
+                    assert got[masked, keep][k].abs().max().item() == 0, (k, "expected an exactly zero gradient")
                     continue
-                worst[k] = rel(got[keep][k], P[k].grad / T)
+                worst[k] = rel(got[masked, keep][k], want_grad[k] / T)
             print(f"[gradient rel-L2 vs fp64 oracle] {tag}, all parameters, {'masked' if masked else 'UNMASKED'}, keep_image={keep}:",
                   {k: f"{v:.1e}" for k, v in worst.items()})
             assert all(v < gtol for v in worst.values()), (keep, masked, worst)
             assert all(k in worst for k in ("pose", "cam", "verts_disps", "shape", "light_positions", "amb_ratio", "texture", "normal_map", "rot", "trans"))
             # per-frame rows frame by frame (a wrong frame index would average out of the whole-table norm above)
             for k in rows_keys:
-                rows = torch.stack([(got[keep][k][f] - P[k].grad[f] / T).norm() / (P[k].grad[f] / T).norm().clamp_min(1e-30) for f in range(T)])
+                rows = torch.stack([(got[masked, keep][k][f] - want_grad[k][f] / T).norm() / (want_grad[k][f] / T).norm().clamp_min(1e-30) for f in range(T)])
                 assert rows.max().item() < 2 * gtol, (k, keep, masked, rows.max().item(), int(rows.argmax()))
 
 
