@@ -149,7 +149,10 @@ def _assert_fit_equals_global_batch(two, one, batch=4):
         if n < 64:      # a few scalars (amb_ratio, the shared light position: differences of nearly equal gradient sums, so their first Adam steps follow a noisy sign)
             assert d.max() < 1e-3, (k, worst[k])
             continue
-        assert d.mean() < 1e-5 and (d > 1e-3).double().mean() < max(2e-4, 4.0 / n), (k, worst[k])      # measured on MI355X: mean <= 2e-7, outliers <= 2e-5
+        # measured on MI355X: mean <= 2e-7 and outliers <= 2e-5 in most runs; about one run in six (either form of the backward tail, 24 runs)
+        # lands at mean 4.2e-6 / outliers 4.2e-4 on the texture — one undecided pixel whose first, sign-like Adam steps go the other way and
+        # take its bilinear footprints along: the outlier bound is the 1e-3 of the single-GPU test above, the mean bound stays
+        assert d.mean() < 1e-5 and (d > 1e-3).double().mean() < max(1e-3, 4.0 / n), (k, worst[k])
     print("data-parallel fit vs global-batch fit, |dp| mean / max / fraction > 1e-3:", worst)
 
 
