@@ -213,6 +213,23 @@ __device__ __forceinline__ float wave_sum_u(float v) {
   HARP_DPP_STEP(dpp_fadd_, __float_as_int, __int_as_float, 0x143, 0xC, false)
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
+// N sums at once, step-major: the N dependent chains of six DPP steps interleave (one after the other, every step waits for the previous
+// one's result: ~150 cycles per sum instead of ~35).  The sums end up in LANE 63 of v[0..N) (no readlane).
+template <int N>
+__device__ __forceinline__ void wave_sum_u_n(float (&v)[N]) {
+#define HARP_DPP_STEP_N(ctrl, rmask)                                                                                         \
+  _Pragma("unroll") for (int k_ = 0; k_ < N; ++k_) {                                                                         \
+    const int self_ = __float_as_int(v[k_]);                                                                                 \
+    v[k_] += __int_as_float(__builtin_amdgcn_update_dpp(0, self_, ctrl, rmask, 0xF, false));                                 \
+  }
+  HARP_DPP_STEP_N(0x111, 0xF)
+  HARP_DPP_STEP_N(0x112, 0xF)
+  HARP_DPP_STEP_N(0x114, 0xF)
+  HARP_DPP_STEP_N(0x118, 0xF)
+  HARP_DPP_STEP_N(0x142, 0xA)
+  HARP_DPP_STEP_N(0x143, 0xC)
+#undef HARP_DPP_STEP_N
+}
 __device__ __forceinline__ float wave_max_u(float v) {
   HARP_DPP_STEP(fmaxf, __float_as_int, __int_as_float, 0x111, 0xF, true)
   HARP_DPP_STEP(fmaxf, __float_as_int, __int_as_float, 0x112, 0xF, true)

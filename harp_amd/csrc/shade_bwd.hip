@@ -437,10 +437,10 @@ __device__ __forceinline__ void shade_bwd_tile(ShadeSmem& sm, unsigned vblock, c
   // ---- per-frame scalars: wave sums -> this wave's LDS partials (the last wave of the tile sends them on, below)
   const bool working = 64 * w < n_tile;          // (wave-uniform) this wave has a share of the tile's active pixels
   if (working) {
+    wave_sum_u_n<kScalars>(racc);            // (all 17 chains interleaved; lane 63 holds the sums)
+    if (lane == 63) {
 #pragma unroll
-    for (int k = 0; k < kScalars; ++k) {
-      const float s = wave_sum_u(racc[k]);
-      if (lane == 0) s_part[w][k] = s;
+      for (int k = 0; k < kScalars; ++k) s_part[w][k] = racc[k];
     }
   } else {
     const float s = wave_sum_u(loss_acc);
