@@ -31,15 +31,23 @@ __device__ __forceinline__ V3 normz_bwd(V3 n, float len, float eps, V3 g) {
 template <int N>
 __device__ __forceinline__ void block_sum_n(const float* v, float* red, float* out) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#ifdef CHAIN_SLOW_SUM
 #pragma unroll
   for (int k = 0; k < N; ++k) {
-#ifdef CHAIN_SLOW_SUM
     const float s = wave_sum(v[k]);
-#else
-    const float s = wave_sum_u(v[k]);     // DPP reduction (~8 cycles a step; the shuffle form goes through ds_bpermute, ~100)
-#endif
     if (lane == 0) red[w * N + k] = s;
   }
+#else
+  // DPP reductions (~8 cycles a step; the shuffle form goes through ds_bpermute, ~100), the N chains interleaved, lane 63 stores the sums
+  float t[N];
+#pragma unroll
+  for (int k = 0; k < N; ++k) t[k] = v[k];
+  wave_sum_u_n<N>(t);
+  if (lane == 63) {
+#pragma unroll
+    for (int k = 0; k < N; ++k) red[w * N + k] = t[k];
+  }
+#endif
   __syncthreads();
   if (threadIdx.x < N) {
     float s = 0.f;
