@@ -3,12 +3,12 @@
 replayable as a hipGraph, with one RCCL all-reduce of the flat gradient arena between backward and Adam.
 
 What the reference does per step with ~600 torch/PyTorch3D kernel launches, >= 8 host syncs and CPU-resident
-parameters, this does with 32 launches (hand mesh; 44 for the SMPL-X arm), no host sync and everything resident:
+parameters, this does with 23 launches (hand mesh; 28 for the SMPL-X arm), no host sync and everything resident:
 
-  schedule -> hand_front (frame set-up, LBS, subdivide, normals + displace, normals, both projections, light camera) ->
+  hand_front (schedule row, frame set-up, LBS, subdivide, normals + displace, normals, both projections, light camera; arm: 5 launches) ->
   raster(cam, K=1 + soft silhouette + its L1) || raster(light, K=1) || parameter / mesh regularisers ->
   shade_bwd (recomputes the colour, forms the photometric L1, writes y_pred when asked) || silhouette_bwd -> depth_bwd ->
-  hand_back (mesh chain + hand layer backward, 3 launches) -> [all-reduce] -> Adam
+  mesh chain + hand / arm layer backward on four workgroups per frame (6 / 7 launches) -> [all-reduce] -> Adam
 
 (the building blocks behind the fused launches — frame_setup, LBS, subdivide, normals, project, centroid, light_setup, shade and
 their backward passes — are separate C-ABI entry points and stay reachable through the `fused_*` switches; tests compare the two).
