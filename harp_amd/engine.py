@@ -173,6 +173,7 @@ class FitEngine:
         wide_ok = self.fused_front and (self.topo.V + 3) // 4 <= 1024
         self.wide_front = wide_ok and self.use_arm
         self.hybrid_front = False            # hand path: hand layer on four workgroups per frame + one-workgroup mesh chain (two launches)
+        self.front_auto = wide_ok and not self.use_arm   # hand path: the form of the front is chosen per stage (see _mesh_forward); False: wide_front / hybrid_front as set
         self.wide_back = wide_ok             # the tail: mesh-chain backward + per-vertex hand / arm layer backward on four workgroups per frame
         # ---- switches (all on in production; tools/dev and bench.py flip some of them to measure their effect)
         self.overlap = True              # second HIP stream (light view, silhouette backward, parameter-only terms); False: one stream
@@ -223,6 +224,8 @@ class FitEngine:
             if not hasattr(self, k):
                 raise ValueError(f"HARP_ENG: no engine switch {k!r}")
             setattr(self, k, type(getattr(self, k))(int(v)))
+            if k in ("wide_front", "hybrid_front"):
+                self.front_auto = False                  # an explicit form is an explicit form
         self.compute_reference_mesh()
 
     # ------------------------------------------------------------------------------------------------
@@ -374,20 +377,27 @@ class FitEngine:
         h.self_shadow = int(self.self_shadow)
         return h
 
-    def _mesh_forward(self, fid, B, shadow=False, front=False, step=None):
+    def _mesh_forward(self, fid, B, shadow=False, front=False, step=None, stage=None):
         """frame_setup .. normals (and, fused, both projections + the light camera): fills the scratch geometry for the B frames in
         `fid` (int32 device tensor).  Returns True when the fused chain ran (projections / light camera already done).  front=True
         allows the one-launch form of the whole front (MANO path, csrc/hand_front.hip)."""
         L, s, p, st, tp = _lib.lib(), self.s, _lib.ptr, _lib.stream(), self.topo
         if front and self.fused_front and self.fused_chain:
-            if self.use_arm and self.wide_front:
+            wide, hybrid = self.wide_front, self.hybrid_front
+            if self.front_auto and not self.use_arm and stage is not None:
+                # hand path, by stage (profiles/r05_wide_ab.txt item 19, fresh processes): a single-stage step (geometry only / appearance
+                # only) has no long second-stream chain in front of the rasterisers, its head is on the critical path -> wide front
+                # (-15 ... -25 us); the combined stage -> hybrid (hand layer wide, mesh chain one workgroup per frame: -5 us; wide: +6)
+                both = bool(stage[0] and stage[1])
+                wide, hybrid = (not both), both
+            if self.use_arm and wide:
                 self._ck(L.harp_arm_front_wide_fwd(ctypes.byref(self._arm_struct(fid, B, shadow, False, step)), p(s["chain_parts"]), st),
                          "arm_front_wide_fwd")
             elif self.use_arm:
                 self._ck(L.harp_arm_front_fwd(ctypes.byref(self._arm_struct(fid, B, shadow, False, step)), st), "arm_front_fwd")
-            elif self.hybrid_front and not self.wide_front:
+            elif hybrid and not wide:
                 self._ck(L.harp_hand_front_hybrid_fwd(ctypes.byref(self._hand_struct(fid, B, shadow, False, step)), st), "hand_front_hybrid_fwd")
-            elif self.wide_front:
+            elif wide:
                 self._ck(L.harp_hand_front_wide_fwd(ctypes.byref(self._hand_struct(fid, B, shadow, False, step)), p(s["chain_parts"]), st),
                          "hand_front_wide_fwd")
             else:
@@ -603,7 +613,7 @@ class FitEngine:
             with torch.cuda.stream(side):
                 param_terms()
         ev0 = cur.record_event() if go else None
-        fused = self._mesh_forward(lfid, B, shadow, front=True, step=frame)      # fused chain: both projections and the light camera are done as well
+        fused = self._mesh_forward(lfid, B, shadow, front=True, step=frame, stage=(coarse, app))      # fused chain: both projections and the light camera are done as well
         if go:
             wait_e(side, ev0)
             with torch.cuda.stream(side):
@@ -1115,7 +1125,7 @@ class FitEngine:
         # every switch the enqueued launch sequence depends on is part of the key: flipping one re-captures instead of replaying a
         # graph recorded for another configuration
         gkey = (coarse, app, scheduled, n, self.keep_image, self.fused_loss, self.self_shadow, tuple(self.frozen), self.overlap, self.early_terms,
-                self.packed_texels, self.fused_keep, self.mesh_third, self.graph_order, fold, self.fused_terms, self.zl_tile_flags, self.accumulate_loss, self.lean_app_stage, self.sil_only_raster, self.auto_draw, self.mesh_terms_late, self.sil_late, self.paired_setup, self.late_texture_terms, self.mesh_terms_first, self.camera_first, self.tail_side, self.fused_bwd, self.fused_chain, self.fused_front, self.wide_front, self.hybrid_front, self.wide_back, self.fused_back, self.consume_gzl, self.keep_depth, dist_on, self.overlap_allreduce,
+                self.packed_texels, self.fused_keep, self.mesh_third, self.graph_order, fold, self.fused_terms, self.zl_tile_flags, self.accumulate_loss, self.lean_app_stage, self.sil_only_raster, self.auto_draw, self.mesh_terms_late, self.sil_late, self.paired_setup, self.late_texture_terms, self.mesh_terms_first, self.camera_first, self.tail_side, self.fused_bwd, self.fused_chain, self.fused_front, self.wide_front, self.hybrid_front, self.front_auto, self.wide_back, self.fused_back, self.consume_gzl, self.keep_depth, dist_on, self.overlap_allreduce,
                 self.comm is not None, self.perceptual is not None and app)
         g = self._graphs.get(gkey)
         if g is None:

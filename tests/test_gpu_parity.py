@@ -757,7 +757,7 @@ def test_fused_mesh_chain_matches_building_blocks(sc, coarse, app):
             assert rel(g1[o:o + n], g0[o:o + n]) < 5e-4, k       # atomics order + the conditioning of the silhouette-rim gradient
 
 
-@pytest.mark.parametrize("wide", [False, True])
+@pytest.mark.parametrize("wide", ["one", "wide", "hybrid"])
 @pytest.mark.parametrize("coarse,app", [(True, True), (True, False)])
 def test_fused_front_matches_building_blocks(sc, coarse, app, wide):
     """harp_hand_front_fwd (frame set-up + MANO layer + mesh chain in one launch, csrc/hand_front.hip) — and harp_hand_front_wide_fwd, the
@@ -776,8 +776,9 @@ def test_fused_front_matches_building_blocks(sc, coarse, app, wide):
     fid = torch.tensor([2, 0, 1], dtype=torch.int32, device=DEV)
     eng.fid.copy_(fid); eng.tfid.copy_(fid)
     eng.auto_draw = False; eng.draw_texture_offsets(); eng.set_stage(coarse, app)
-    assert eng.fused_front and eng.fused_chain and eng.wide_back
-    eng.wide_front = wide
+    assert eng.fused_front and eng.fused_chain and eng.wide_back and eng.front_auto
+    eng.front_auto = False                       # (the form under test, not the per-stage choice)
+    eng.wide_front, eng.hybrid_front = wide == "wide", wide == "hybrid"     # (hybrid: hand layer on four workgroups per frame, mesh chain on one)
     keys = ("pose48", "betas", "trans_b", "cam_R", "cam_T", "light_pos", "colors", "verts_mm", "joints_mm", "joints_m", "vs", "vd", "n1", "n2",
             "ndc_c", "ndc_l", "centroid", "light_R", "light_T", "il1", "il2", "lbs_ws")
     out = {}
@@ -1236,8 +1237,8 @@ def test_light_camera_incl_look_at_replacement_branch():
                                       dict(fold_step=False, mesh_third=False), dict(fused_terms=False, consume_gzl=False), dict(zl_tile_flags=True),
                                       dict(fused_terms=False, zl_tile_flags=True),
                                       # round 5: four-workgroups-per-frame forms, paired rasteriser set-up, late terms (harp_amd/engine.py)
-                                      dict(wide_front=True), dict(wide_back=False), dict(wide_front=True, wide_back=False), dict(hybrid_front=True),
-                                      dict(paired_setup=True), dict(paired_setup=True, wide_front=True), dict(paired_setup=True, overlap=False),
+                                      dict(front_auto=False), dict(front_auto=False, wide_front=True), dict(wide_back=False), dict(front_auto=False, wide_front=True, wide_back=False), dict(front_auto=False, hybrid_front=True),
+                                      dict(paired_setup=True), dict(paired_setup=True, front_auto=False, wide_front=True), dict(paired_setup=True, overlap=False),
                                       dict(late_texture_terms=True), dict(late_texture_terms=True, mesh_terms_first=False), dict(sil_late=True), dict(mesh_terms_late=True),
                                       dict(mesh_terms_late=True, graph_order=False), dict(mesh_terms_late=True, sil_late=True),
                                       dict(paired_setup=True, keep_depth=False)])
@@ -1272,7 +1273,7 @@ def test_schedule_switches_give_the_default_schedules_result(switches):
     try:
         # (the four-workgroups-per-frame forms also change the ORDER of float sums inside the front / back — vertex positions move by 1e-7,
         #  which the conditioning of the silhouette-rim gradients amplifies: the bounds of test_fused_front_matches_building_blocks)
-        arith = any(k in switches for k in ("wide_front", "wide_back", "hybrid_front"))
+        arith = any(k in switches for k in ("wide_front", "wide_back", "hybrid_front", "front_auto"))
         tol_g, tol_k = (1e-3, 1e-3) if arith else (1e-5, 1e-4)
         for graph in (False, True):
             g, l = run(graph)
