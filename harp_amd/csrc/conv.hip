@@ -754,9 +754,8 @@ int harp_vgg16_term(const harp_vgg16* net, const harp_vgg16_term_args* t, hipStr
   const VggWs w = vgg_ws_split(t->ws, N, S, 1);
   float scale[5];
   vgg_scales(net, N, S, scale);
-  hipLaunchKernelGGL(vgg_prep_kernel, dim3((S * S + 255) / 256, N), dim3(256), 0, stream, t->rgb, (const int32_t*)nullptr, t->mask, t->rows, t->y_true, S,
-                     scale[0], w.x0, w.loss);
-  HARP_CHECK_LAUNCH();
+  // every argument is checked before the first launch: vgg_prep_kernel adds into the workspace's loss accumulator, which only the LAST
+  // launch of the term hands back zeroed — an error return between the two would leave it dirty for the next call
   VggBound bd = {};
   const bool bounded = t->tiles[0] != nullptr;
   if (bounded) {
@@ -772,6 +771,9 @@ int harp_vgg16_term(const harp_vgg16* net, const harp_vgg16_term_args* t, hipStr
     }
     bd.rows = t->rows;
   }
+  hipLaunchKernelGGL(vgg_prep_kernel, dim3((S * S + 255) / 256, N), dim3(256), 0, stream, t->rgb, (const int32_t*)nullptr, t->mask, t->rows, t->y_true, S,
+                     scale[0], w.x0, w.loss);
+  HARP_CHECK_LAUNCH();
   int rc = vgg_forward(net, w, N, S, nullptr, t->target, t->target_by_row ? t->rows : nullptr, scale, bounded ? &bd : nullptr, stream);
   if (rc != HARP_OK) return rc;
   // backward: data gradients only.  G(relu4_3) = its tap gradient; then convolution by convolution towards the image

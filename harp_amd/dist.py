@@ -114,17 +114,22 @@ def negotiate_comm(device=None, preflight=None, create=None, log=None):
     import sys
     say = log or (lambda m: print(m, file=sys.stderr))
     rank, world = dist_env()
-    if os.environ.get("HARP_RCCL_DEBUG") == "1":
+    # the debug switch is folded into the FIRST agreement instead of returning in front of it: a variable set on some ranks only would
+    # otherwise leave those ranks out of the collectives their peers enter (every rank takes the same number of them, whatever it holds)
+    debug = os.environ.get("HARP_RCCL_DEBUG") == "1"
+    ok = not debug
+    if debug:
         say(f"[harp_amd.dist] rank {rank}: HARP_RCCL_DEBUG=1 — no RCCL communicator; torch.distributed all-reduce, eager steps")
-        return None
-    ok = True
-    try:
-        (preflight or RcclComm.unique_id)()
-    except Exception as e:                                       # noqa: BLE001
-        say(f"[harp_amd.dist] rank {rank}: RCCL pre-flight failed ({type(e).__name__}: {e})")
-        ok = False
+    else:
+        try:
+            (preflight or RcclComm.unique_id)()
+        except Exception as e:                                       # noqa: BLE001
+            say(f"[harp_amd.dist] rank {rank}: RCCL pre-flight failed ({type(e).__name__}: {e})")
+            ok = False
     if not agree(ok, device):
-        say(f"[harp_amd.dist] rank {rank}: RCCL pre-flight failed on some rank — every rank falls back to torch.distributed's all-reduce")
+        if not debug:
+            say(f"[harp_amd.dist] rank {rank}: RCCL pre-flight failed (or HARP_RCCL_DEBUG=1) on some rank — every rank falls back to "
+                "torch.distributed's all-reduce")
         return None
     comm = None
     try:
@@ -174,8 +179,16 @@ class RcclComm:
         rank, world = dist.get_rank(), dist.get_world_size()
         if device is not None:
             torch.cuda.set_device(device)
-        box = [cls.unique_id() if rank == 0 else None]
+        # rank 0 broadcasts a failure marker instead of raising in front of the broadcast its peers are waiting in
+        box = [None]
+        if rank == 0:
+            try:
+                box = [cls.unique_id()]
+            except Exception as e:                                   # noqa: BLE001
+                box = [("error", f"{type(e).__name__}: {e}")]
         dist.broadcast_object_list(box, src=0)
+        if not isinstance(box[0], (bytes, bytearray)):
+            raise RuntimeError(f"RcclComm.from_process_group: rank 0 could not draw the communicator id ({box[0]})")
         return cls(rank, world, box[0])
 
     @classmethod

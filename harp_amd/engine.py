@@ -325,7 +325,8 @@ class FitEngine:
         m = self.y_sil_col.unsqueeze(-1)
         self.bg_photo = tile_sums((bg * m - self.y_true * m).abs().sum(-1))
         if getattr(self, "perceptual", None) is not None:                            # cached target features belong to the old targets
-            self.set_perceptual(self._vgg_module, self.perceptual_weight, precision=self._vgg_precision, bounded=self._vgg_bounded)
+            self.set_perceptual(self._vgg_module, self.perceptual_weight, cache_bytes=self._vgg_cache_bytes, precision=self._vgg_precision,
+                                bounded=self._vgg_bounded)
 
     # ------------------------------------------------------------------------------------------------
     def _ck(self, rc, what):
@@ -853,6 +854,7 @@ class FitEngine:
           * else nothing: every step also recomputes the target features of its B frames."""
         from .model.vgg_hip import Vgg16Hip, activation_shapes, active_tiles, tap_shapes
         self._vgg_module = vgg
+        self._vgg_cache_bytes = int(cache_bytes)         # the caller's budget (set_targets re-invokes with it)
         self._vgg_precision = int(precision)
         self._vgg_bounded = bool(bounded)
         self.perceptual = None if vgg is None else Vgg16Hip(vgg, self.dev, precision)
@@ -867,15 +869,28 @@ class FitEngine:
         T, S = self.y_true.shape[0], self.S
         full = 4 * sum(h * w * c for h, w, c in activation_shapes(S))
         taps = 4 * sum(h * w * c for h, w, c in tap_shapes(S))
-        if bounded and T * full <= cache_bytes:
-            shapes, all_slots = activation_shapes(S), True
-            self._vgg_bound = active_tiles(self.y_sil_col)
-        elif T * taps <= cache_bytes:
-            shapes, all_slots = tap_shapes(S), False
-        else:
+        # the budget is the caller's figure, but never more than 80 % of what the device has free right now (a smaller device, or several
+        # ranks sharing one: each would otherwise take the full default); a tier whose allocation fails anyway falls through to the next
+        torch.cuda.synchronize(self.dev)
+        budget = min(int(cache_bytes), int(0.8 * torch.cuda.mem_get_info(self.dev)[0]))
+        tiers = []
+        if bounded and T * full <= budget:
+            tiers.append((activation_shapes(S), True))
+        if T * taps <= budget:
+            tiers.append((tap_shapes(S), False))
+        for shapes, all_slots in tiers:
+            try:
+                self._vgg_cache = [torch.empty((T,) + shp, device=self.dev) for shp in shapes]
+            except torch.OutOfMemoryError:
+                self._vgg_cache = None
+                torch.cuda.empty_cache()
+                continue
+            if all_slots:
+                self._vgg_bound = active_tiles(self.y_sil_col)
+            break
+        if self._vgg_cache is None:
             self._vgg_step_feats = [torch.empty((self.B,) + shp, device=self.dev) for shp in tap_shapes(S)]
             return
-        self._vgg_cache = [torch.empty((T,) + shp, device=self.dev) for shp in shapes]
         for t0 in range(0, T, self.B):
             rows = torch.arange(t0, min(T, t0 + self.B), device=self.dev, dtype=torch.int32)
             self.perceptual.features(self.y_true, self.y_sil_col, rows, out=[c[t0:t0 + rows.shape[0]] for c in self._vgg_cache], all_slots=all_slots)
@@ -1105,6 +1120,10 @@ class FitEngine:
             # (a device-resident batch costs no host sync at all)
             self.fid[:n].copy_(fid.to(torch.int32).to(self.dev), non_blocking=True)
             self.tfid[:n].copy_(t.to(torch.int32).to(self.dev), non_blocking=True)
+        # a flipped consume_gzl / keep_depth left g_zl / zl_state in the other mode's state: a cached graph replays without passing through
+        # forward_backward, so the invariant is re-established here, in front of the graph lookup
+        if getattr(self, "_shadow_state_stale", False):
+            self._reset_shadow_state()
         key = (coarse, app)
         if self._stage != key:
             self.set_stage(coarse, app)

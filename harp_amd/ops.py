@@ -99,6 +99,13 @@ class DeviceTopology:
         self.verts_uvs = torch.as_tensor(verts_uvs, dtype=torch.float32).reshape(-1, 2).contiguous().to(device)
         self.faces_uvs = i32(faces_uvs).reshape(-1, 3)
         self.device = device
+        self._check_uvs()
+
+    def _check_uvs(self):
+        # the shader kernels read verts_uvs[faces_uvs] without a bounds check
+        lo, hi = int(self.faces_uvs.min()), int(self.faces_uvs.max())
+        if lo < 0 or hi >= self.verts_uvs.shape[0]:
+            raise ValueError(f"faces_uvs must index verts_uvs ({self.verts_uvs.shape[0]} rows): found indices in [{lo}, {hi}]")
 
     def set_uvs(self, verts_uvs, faces_uvs):
         """(re)bind the UV tables (TexturesUV(faces_uvs=, verts_uvs=), utils/visualize.py:84-87); accepts the reference's (1,VT,2)/(1,F,3)"""
@@ -106,6 +113,7 @@ class DeviceTopology:
         if getattr(self, "_uv_key", None) != key:
             self.verts_uvs = torch.as_tensor(verts_uvs, dtype=torch.float32).reshape(-1, 2).contiguous().to(self.device)
             self.faces_uvs = torch.as_tensor(faces_uvs).to(torch.int32).reshape(-1, 3).contiguous().to(self.device)
+            self._check_uvs()
             self._uv_key = key
 
 

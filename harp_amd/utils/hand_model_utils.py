@@ -7,9 +7,10 @@ import torch
 
 def load_obj_uvs(path):
     """(verts_uvs (Nt,2) float32, faces_uvs (F,3) int64) of a triangulated OBJ: the `vt` lines and the second index of every `f` corner
-    — what pytorch3d.io.load_obj returns as properties.verts_uvs and faces.textures_idx.  Like load_obj: negative (relative) indices
-    count back from the `vt` lines read so far, and a face whose corners carry no texture index ('f v' / 'f v//vn') gets -1."""
-    vt, ft = [], []
+    — what pytorch3d.io.load_obj returns as properties.verts_uvs and faces.textures_idx.  Like load_obj: negative (relative) indices are
+    resolved against the FINAL number of `vt` lines (after the whole file is read — an OBJ that interleaves `vt` and `f` lines therefore
+    reads the same as through load_obj), and a face whose corners carry no texture index ('f v' / 'f v//vn') gets -1."""
+    vt, ft, where = [], [], []
     with open(path) as f:
         for line in f:
             p = line.split()
@@ -23,17 +24,19 @@ def load_obj_uvs(path):
                 row = []
                 for q in p[1:4]:
                     parts = q.split("/")
-                    if len(parts) < 2 or parts[1] == "":
-                        row.append(-1)
-                        continue
-                    i = int(parts[1])
-                    if i == 0 or i > len(vt) or -i > len(vt):
-                        raise ValueError(f"{path}: texture index {i} out of range in {line.strip()!r}")
-                    row.append(i - 1 if i > 0 else len(vt) + i)
-                if -1 in row:
-                    row = [-1, -1, -1]
+                    row.append(int(parts[1]) if (len(parts) >= 2 and parts[1] != "") else None)
                 ft.append(row)
-    return torch.tensor(np.asarray(vt, np.float32).reshape(-1, 2)), torch.tensor(np.asarray(ft, np.int64).reshape(-1, 3))
+                where.append(line.strip())
+    n, out = len(vt), []
+    for row, line in zip(ft, where):
+        if None in row:
+            out.append([-1, -1, -1])
+            continue
+        for i in row:
+            if i == 0 or i > n or -i > n:
+                raise ValueError(f"{path}: texture index {i} out of range in {line!r}")
+        out.append([i - 1 if i > 0 else n + i for i in row])
+    return torch.tensor(np.asarray(vt, np.float32).reshape(-1, 2)), torch.tensor(np.asarray(out, np.int64).reshape(-1, 3))
 
 
 def load_hand_model(config_dict):
@@ -42,6 +45,8 @@ def load_hand_model(config_dict):
     if config_dict["model_type"] != "harp":
         raise NotImplementedError("model_type 'html' / 'nimble' are out of scope (SURVEY.md §2)")
     verts_uvs, faces_uvs = load_obj_uvs(config_dict["MANO_TEMPLATE"])
+    if (faces_uvs < 0).any():                # the shaders index verts_uvs[faces_uvs] on the device: a face without UVs cannot be textured
+        raise ValueError(f"{config_dict['MANO_TEMPLATE']}: {int((faces_uvs < 0).any(1).sum())} faces carry no texture indices")
     VERTS_COLOR = None
     if config_dict["use_arm"]:
         from ..hand_models_harp import body_models

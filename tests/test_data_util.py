@@ -133,7 +133,10 @@ def test_load_obj_uvs_reads_what_pytorch3d_load_obj_returns(tmp_path):
     import pytest
     with pytest.raises(ValueError):
         load_obj_uvs(str(tmp_path / "q.obj"))
-    # relative (negative) texture indices count back from the vt lines read so far; corners without a texture index give -1 (load_obj)
+    # relative (negative) texture indices count back from the END of the vt list (as load_obj resolves them: also when vt and f lines
+    # interleave); corners without a texture index give -1
+    (tmp_path / "i.obj").write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nvt 0 0\nvt 1 0\nf 1/-3 2/-2 3/-1\nvt 0 1\n")
+    assert load_obj_uvs(str(tmp_path / "i.obj"))[1].tolist() == [[0, 1, 2]]
     (tmp_path / "r.obj").write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nvt 0 0\nvt 1 0\nvt 0 1\nf 1/-3 2/-2 3/-1\nf 1//1 2//1 3//1\nf 1 2 3\n")
     uv, f = load_obj_uvs(str(tmp_path / "r.obj"))
     assert f.tolist() == [[0, 1, 2], [-1, -1, -1], [-1, -1, -1]]

@@ -187,6 +187,12 @@ def _negotiate_worker(rank, world, port, out):
     os.environ["HARP_RCCL_DEBUG"] = "1"
     c = negotiate_comm(preflight=fail, create=fail, log=log.append)
     res.append((c is None,))
+    # 5. the variable set on ONE rank only: both ranks still take the same collectives (no hang) and fall back together
+    if rank == 1:
+        del os.environ["HARP_RCCL_DEBUG"]
+    made = []
+    c = negotiate_comm(preflight=lambda: None, create=lambda: made.append(1) or _FakeComm(), log=log.append)
+    res.append((c is None, len(made)))
     out.put((rank, res, len(log)))
     dist.destroy_process_group()
 
@@ -211,3 +217,4 @@ def test_ranks_fall_back_together_when_one_cannot_have_rccl():
     assert got[0][1] == (True, []) and got[1][1] == (True, [True])                  # rank 1's communicator was destroyed again
     assert got[0][2] == (True,) and got[1][2] == (True,)
     assert got[0][3] == (True,) and got[1][3] == (True,)
+    assert got[0][4] == (True, 0) and got[1][4] == (True, 0)                       # HARP_RCCL_DEBUG on rank 0 only: nobody created anything

@@ -1292,6 +1292,17 @@ def test_schedule_switches_give_the_default_schedules_result(switches):
         assert rel(g, ref[graph][0]) < 1e-5, ("back to the defaults", switches, graph, rel(g, ref[graph][0]))
         assert ((l - ref[graph][1]).abs() <= 1e-5 * ref[graph][1].abs() + 1e-9).all(), ("back to the defaults", switches, graph)
     assert eng.s["g_zl"].abs().max().item() == 0.0
+    # ... and through CACHED graphs only (a replay does not pass through forward_backward: step() itself has to notice the flip)
+    flips = {k: v for k, v in switches.items() if k in ("consume_gzl", "keep_depth")}
+    if flips:
+        for k, v in flips.items():
+            setattr(eng, k, v)
+        run(True)
+        for k in flips:
+            setattr(eng, k, defaults[k])
+        g, l = run(True)
+        assert rel(g, ref[True][0]) < 1e-5, ("back to the defaults by graph replays only", switches, rel(g, ref[True][0]))
+        assert eng.s["g_zl"].abs().max().item() == 0.0
 
 
 def test_folded_step_bookkeeping_equals_the_separate_kernels():
