@@ -62,7 +62,8 @@ class ShadeArgs(ctypes.Structure):
                 [(n, _f) for n in ("focal", "ppx", "ppy")] + [("bg", _f * 3)] +
                 [(n, _vp) for n in ("rgb", "g_rgb", "g_tex", "g_nmap", "g_verts", "g_vnormals", "g_ndc", "g_zl", "g_light_pos",
                                     "g_colors", "g_light_R", "g_light_T")] + [("debug_skip", _i)] +
-                [(n, _vp) for n in ("l1_target", "l1_mask", "l1_fid", "l1_w", "l1_loss", "l1_grad")] + [("l1_inv", _f), ("texnm", _vp), ("l1_bg_sums", _vp), ("g_zl_tiles", _vp)])
+                [(n, _vp) for n in ("l1_target", "l1_mask", "l1_fid", "l1_w", "l1_loss", "l1_grad")] + [("l1_inv", _f), ("texnm", _vp), ("l1_bg_sums", _vp), ("g_zl_tiles", _vp),
+                 ("trec", _vp), ("trec_cnt", _vp), ("trec_cap", _i), ("trec_acc_tex", _vp), ("trec_acc_nmap", _vp)])
 
 
 SIGNATURES.update({
@@ -70,6 +71,9 @@ SIGNATURES.update({
     "harp_depth_bwd_consume": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "harp_shade_fwd": (_i, [ctypes.POINTER(ShadeArgs), _vp]),
     "harp_shade_bwd": (_i, [ctypes.POINTER(ShadeArgs), _vp]),
+    "harp_texel_bins": (_i, [_i, _i]),
+    "harp_texel_reduce": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "harp_texel_finish": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "harp_pack_texels": (_i, [_vp, _vp, _i, _vp, _vp]),
     "harp_normalize3_pack": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
     "harp_depth_nmap_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp]),

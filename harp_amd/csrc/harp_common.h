@@ -271,16 +271,19 @@ __device__ __forceinline__ void merge_same_face(float* v, int fk, bool& alive, i
 }
 
 // chain rule of F.normalize(x, dim=-1) (eps 1e-12) for texel i: gx[i] += d normalize / dx ^T gy[i]   (utils/visualize.py:99)
-__device__ __forceinline__ void normalize3_bwd_texel(const float* __restrict__ x, const float* __restrict__ gy, float* __restrict__ gx, size_t i) {
+__device__ __forceinline__ void normalize3_bwd_vals(const float* __restrict__ x, float g0, float g1, float g2, float* __restrict__ gx, size_t i) {
   const float a = x[3 * i], b = x[3 * i + 1], c = x[3 * i + 2];
   const float l = sqrtf(a * a + b * b + c * c);
-  const float g0 = gy[3 * i], g1 = gy[3 * i + 1], g2 = gy[3 * i + 2];
   if (l > 1e-12f) {
     const float inv = 1.0f / l, na = a * inv, nb = b * inv, nc = c * inv, d = na * g0 + nb * g1 + nc * g2;
     gx[3 * i] += (g0 - na * d) * inv; gx[3 * i + 1] += (g1 - nb * d) * inv; gx[3 * i + 2] += (g2 - nc * d) * inv;
   } else {
     gx[3 * i] += g0 * 1e12f; gx[3 * i + 1] += g1 * 1e12f; gx[3 * i + 2] += g2 * 1e12f;
   }
+}
+
+__device__ __forceinline__ void normalize3_bwd_texel(const float* __restrict__ x, const float* __restrict__ gy, float* __restrict__ gx, size_t i) {
+  normalize3_bwd_vals(x, gy[3 * i], gy[3 * i + 1], gy[3 * i + 2], gx, i);
 }
 
 // F.normalize(x, dim=-1) of one texel (eps 1e-12; utils/visualize.py:99) with the sum of squares spelled as fused multiply-adds, so that

@@ -270,6 +270,149 @@ __global__ void __launch_bounds__(256) tex_smooth_kernel(const float* __restrict
   tex_smooth_body(blockIdx.x, gridDim.x, t, dist, mask, H, W, w, loss, g, red);
 }
 
+// The same term by TILE OWNERS (the form the fused launch below runs): a workgroup owns a 32x32-texel tile and forms the complete
+// gradient of its texels — the own part k sgn(t[p] - t[j(p)]) and what every source s with j(s) = p hands over, -k_s sgn(t[s] - t[p]) —
+// in registers, then adds it to g with ONE row-contiguous memory atomic per texel and channel, and only where the UV mask is set.  The
+// stand-alone form above scatters two memory atomics per texel and channel to random addresses (3 M per step at 21 G/s: the kernel at the
+// head of the step's second stream was bound by exactly that).  How a target finds its sources: the offsets are int(N(0, 1 | 2)), so all
+// but ~1e-5 of the sources lie within 8 texels of their target; the workgroup stages texels and mask of its tile + an 8-texel halo in LDS,
+// walks the staged sources, and every source whose (clamped) target lies in the tile appends itself to the target's list in LDS (4 slots,
+// ds_add_rtn_u32; mean occupancy 1).  The rest keep today's path: a source whose target is further than the halo reaches (decided by the
+// source's own tile, which alone knows it) or whose target's list is full adds its three values to the target with memory atomics.
+constexpr int kST = 32, kSH = 8, kSR = kST + 2 * kSH, kSL = 4;
+constexpr int kSE = (kSR * kSR + 255) / 256;       // staged texels per thread (9)
+struct SmoothTileSmem {
+  float t[kSR * kSR * 3];
+  float m[kSR * kSR];
+  int cnt[kST * kST];
+  int tj[kST * kST];                               // (clamped) target of the tile's own texels, row << 16 | column
+  unsigned short list[kST * kST][kSL];
+  float red[4];
+};
+__device__ __forceinline__ void tex_smooth_tile_body(int tile, const float* __restrict__ t, const int32_t* __restrict__ dist, const float* __restrict__ mask,
+                                                     int H, int W, const float* __restrict__ w, float* __restrict__ loss, float* __restrict__ g,
+                                                     SmoothTileSmem& S) {
+  const int ntc = (W + kST - 1) / kST;
+  const int tr = tile / ntc, tc = tile - tr * ntc;
+  const int r0 = tr * kST - kSH, c0 = tc * kST - kSH;          // origin of the staged region (may lie outside the image)
+  // every thread owns kSE fixed texels of the staged region; its loads are issued together (three round trips per workgroup in all:
+  // mask | texels + offsets | — rarely — a target outside the region)
+  int gi[kSE];
+  float mv[kSE];
+  // ---- mask of tile + halo; a region without a single masked texel has no loss and no gradient (3/5 of the tiles of the hand atlas)
+  float mmax = 0.f;
+#pragma unroll
+  for (int e = 0; e < kSE; ++e) {
+    const int i = threadIdx.x + 256 * e;
+    const int rr = r0 + i / kSR, cc = c0 + i % kSR;
+    const bool in = i < kSR * kSR && rr >= 0 && rr < H && cc >= 0 && cc < W;
+    gi[e] = in ? rr * W + cc : -1;
+    mv[e] = in ? (mask ? mask[gi[e]] : 1.f) : 0.f;
+  }
+#pragma unroll
+  for (int e = 0; e < kSE; ++e) {
+    const int i = threadIdx.x + 256 * e;
+    if (i < kSR * kSR) S.m[i] = mv[e];
+    mmax = fmaxf(mmax, fabsf(mv[e]));
+  }
+  for (int i = threadIdx.x; i < kST * kST; i += 256) S.cnt[i] = 0;
+  if (__syncthreads_or(mmax != 0.f) == 0) return;
+  float tx[kSE][3];
+  int dr[kSE], dc[kSE];
+#pragma unroll
+  for (int e = 0; e < kSE; ++e) {
+    const bool in = gi[e] >= 0;
+    const float* q = t + (size_t)(in ? gi[e] : 0) * 3;
+    tx[e][0] = in ? q[0] : 0.f; tx[e][1] = in ? q[1] : 0.f; tx[e][2] = in ? q[2] : 0.f;
+    const bool on = in && mv[e] != 0.f;                  // (a source outside the mask: no loss, nothing handed over — its offsets are not needed)
+    const int2 d2 = on ? *reinterpret_cast<const int2*>(dist + 2 * (size_t)gi[e]) : make_int2(0, 0);
+    dr[e] = d2.x; dc[e] = d2.y;
+  }
+#pragma unroll
+  for (int e = 0; e < kSE; ++e) {
+    const int i = threadIdx.x + 256 * e;
+    if (i < kSR * kSR) { S.t[3 * i] = tx[e][0]; S.t[3 * i + 1] = tx[e][1]; S.t[3 * i + 2] = tx[e][2]; }
+  }
+  __syncthreads();
+  const float kk = (w ? w[0] : 0.f) / (3.0f * (float)(H * W));
+  const bool grad = w != nullptr && g != nullptr;
+  // texel (rr, cc) of the image: from the staged region if it lies there, else from memory
+  auto fetch = [&](int rr, int cc, float* o) {
+    const int lr = rr - r0, lc = cc - c0;
+    if (lr >= 0 && lr < kSR && lc >= 0 && lc < kSR) { const float* q = &S.t[3 * (lr * kSR + lc)]; o[0] = q[0]; o[1] = q[1]; o[2] = q[2]; }
+    else { const float* q = t + (size_t)(rr * W + cc) * 3; o[0] = q[0]; o[1] = q[1]; o[2] = q[2]; }
+  };
+  // ---- sources: every staged texel inside the mask
+  float acc = 0.f;
+#pragma unroll
+  for (int e = 0; e < kSE; ++e) {
+    const float ms = mv[e];
+    if (gi[e] < 0 || ms == 0.f) continue;
+    const int i = threadIdx.x + 256 * e;
+    const int lr = i / kSR, lc = i % kSR, rr = r0 + lr, cc = c0 + lc;
+    const bool own = lr >= kSH && lr < kSH + kST && lc >= kSH && lc < kSH + kST;
+    const int jr = min(max(rr + dr[e], 0), H - 1), jc = min(max(cc + dc[e], 0), W - 1);
+    const int ttr = jr / kST, ttc = jc / kST;          // the target's tile
+    const bool mine = ttr == tr && ttc == tc;
+    float tj[3];
+    if (own || !mine) fetch(jr, jc, tj);               // (a halo source that targets this tile is read by the target, below)
+    if (own) {
+      acc += (fabsf(tx[e][0] - tj[0]) + fabsf(tx[e][1] - tj[1]) + fabsf(tx[e][2] - tj[2])) / 3.0f * ms;
+      S.tj[(lr - kSH) * kST + lc - kSH] = (jr << 16) | jc;
+    }
+    if (!grad) continue;
+    // does the target's owner see this source?  (its staged region: the target tile + halo)
+    const bool reach = rr >= ttr * kST - kSH && rr < ttr * kST + kST + kSH && cc >= ttc * kST - kSH && cc < ttc * kST + kST + kSH;
+    bool direct = own && !reach;                       // an outlier draw: only the source's own tile knows about it
+    if (mine) {
+      const int tl = (jr - tr * kST) * kST + (jc - tc * kST);
+      const int slot = atomicAdd(&S.cnt[tl], 1);
+      if (slot < kSL) S.list[tl][slot] = (unsigned short)i;
+      else { direct = true; fetch(jr, jc, tj); }       // the target's list is full
+    }
+    if (direct) {
+      const float k = kk * ms;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float d = tx[e][c] - tj[c];
+        if (d != 0.f) atomicAdd(g + 3 * (size_t)(jr * W + jc) + c, -k * sgn(d));
+      }
+    }
+  }
+  __syncthreads();
+  // ---- targets: the tile's texels
+  if (grad) {
+#pragma unroll
+    for (int e = 0; e < kST * kST / 256; ++e) {
+      const int q = threadIdx.x + 256 * e;
+      const int pr = q / kST, pc = q % kST, rr = tr * kST + pr, cc = tc * kST + pc;
+      if (rr >= H || cc >= W) continue;
+      const int i = (pr + kSH) * kSR + pc + kSH;
+      const float tp[3] = {S.t[3 * i], S.t[3 * i + 1], S.t[3 * i + 2]};
+      float tot[3] = {0.f, 0.f, 0.f};
+      const float kp = kk * S.m[i];
+      if (kp != 0.f) {
+        const int pj = S.tj[q];
+        float tj[3];
+        fetch(pj >> 16, pj & 0xffff, tj);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { const float d = tp[c] - tj[c]; if (d != 0.f) tot[c] += kp * sgn(d); }
+      }
+      const int n = min(S.cnt[q], kSL);
+      for (int u = 0; u < n; ++u) {
+        const int si = S.list[q][u];
+        const float ks = kk * S.m[si];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { const float d = S.t[3 * si + c] - tp[c]; if (d != 0.f) tot[c] -= ks * sgn(d); }
+      }
+#pragma unroll
+      for (int c = 0; c < 3; ++c) if (tot[c] != 0.f) atomicAdd(g + 3 * (size_t)(rr * W + cc) + c, tot[c]);
+    }
+  }
+  const float s = block_sum_256(acc, S.red);
+  if (threadIdx.x == 0 && s != 0.f) atomicAdd(loss, s / (float)(H * W));
+}
+
 // close_to_z_reg (loss/texture_reg.py:40-45) as the reference computes it: L2 norm over the WIDTH axis of
 // (nm - (0,0,1)) for every (row, channel), /3, mean over rows x channels. One block per row.
 // ATOMIC: the gradient is added with atomics (the fused launch below runs this term next to the smoothness term, which scatters into
@@ -318,16 +461,20 @@ struct TexTerms {
   float *g_tex, *g_nmap, *g_disp;
   int nb_smooth, nb_disp;
   int* bump;                           // optional: the draw counter the offsets were drawn for (advanced here: the offsets are consumed)
+  int dbg;                             // HARP_TT_DBG (timing experiments only, results WRONG): 1 no smoothness tiles, 2 no close-to-z rows
 };
 __global__ void __launch_bounds__(256) texture_terms_kernel(const TexTerms A) {
-  __shared__ float red[4];
+  __shared__ SmoothTileSmem tile;
   __shared__ float s_norm[3];
+  float* red = tile.red;
   int bid = blockIdx.x;
   if (A.bump && bid == 0 && threadIdx.x == 0) A.bump[0] += 1;      // (harp_step_prologue, an earlier launch, drew with the old value)
-  if (bid < A.nb_smooth) { tex_smooth_body(bid, A.nb_smooth, A.tex, A.dist_a, A.mask, A.H, A.W, A.w_a, A.l_a, A.g_tex, red); return; }
+  if (bid < 2 * A.nb_smooth && (A.dbg & 1)) return;
+  if (bid < A.nb_smooth) { tex_smooth_tile_body(bid, A.tex, A.dist_a, A.mask, A.H, A.W, A.w_a, A.l_a, A.g_tex, tile); return; }
   bid -= A.nb_smooth;
-  if (bid < A.nb_smooth) { tex_smooth_body(bid, A.nb_smooth, A.nmap, A.dist_n, A.mask, A.H, A.W, A.w_n, A.l_n, A.g_nmap, red); return; }
+  if (bid < A.nb_smooth) { tex_smooth_tile_body(bid, A.nmap, A.dist_n, A.mask, A.H, A.W, A.w_n, A.l_n, A.g_nmap, tile); return; }
   bid -= A.nb_smooth;
+  if (bid < A.H && (A.dbg & 2)) return;
   if (bid < A.H) { close_to_z_body<true>(bid, A.nmap, A.H, A.W, A.w_n, A.z_scale, A.l_n, A.g_nmap, red, s_norm); return; }
   bid -= A.H;
   if (A.disp) sumsq_body(bid, A.nb_disp, A.disp, A.n_disp, A.w_d, A.l_d, A.g_disp, red);
@@ -600,8 +747,10 @@ int harp_texture_terms(const float* tex, const float* nmap, const float* mask, c
   A.H = H; A.W = W; A.n_disp = n_disp; A.z_scale = z_scale;
   A.w_a = w_albedo; A.w_n = w_normal; A.w_d = w_disp; A.l_a = loss_albedo; A.l_n = loss_normal; A.l_d = loss_disp;
   A.g_tex = g_tex; A.g_nmap = g_nmap; A.g_disp = g_disp; A.bump = draw_counter_bump;
-  A.nb_smooth = min((H * W + 255) / 256, 512);
+  A.nb_smooth = ((H + kST - 1) / kST) * ((W + kST - 1) / kST);          // one workgroup per 32x32-texel tile and map
   A.nb_disp = disp ? min((n_disp + 255) / 256, 64) : 0;
+  static const int dbg = [] { const char* e = getenv("HARP_TT_DBG"); return e ? atoi(e) : 0; }();
+  A.dbg = dbg;
   // ONE workgroup per CU (100 KB of dynamic LDS the kernel does not use; HARP_TEXTERMS_LDS=<bytes> overrides, 0 = none): the kernel is bound
   // by its ~5 M scattered memory-side atomics, which four waves per CU keep as busy as thirty-two do (34 -> 37 us) — but with every CU full
   // of its waves the frames' latency chain that runs next to it (hand_front) took 75 us instead of 57: step -13 us, same-box A/B x4.

@@ -741,6 +741,8 @@ int harp_shade_bwd(const harp_shade_args* a, hipStream_t stream) {
   } else {
     b.l1_target = nullptr;          // a caller that hands over the gradient image gets the plain backward pass
   }
+  // texel-gradient records (production kernel only): the list counters and a capacity come with the record buffer
+  if (b.trec && (!b.trec_cnt || b.trec_cap <= 0 || (b.trec_cap & 3) || (b.g_tex && !b.trec_acc_tex) || (b.nmap && b.g_nmap && !b.trec_acc_nmap) || (b.debug_skip & 0xff) || b.Wt > 65535 || b.Ht > 65535)) return HARP_ERR_ARG;
   const RasterWs W = raster_ws_split((void*)a->recs, a->B, a->F, a->S);
   // production: the wave-autonomous kernel of shade_bwd.hip; debug_skip != 0 selects the first, barrier-synchronised version below
   // (bit 6 alone = that kernel unmodified, for A/B timing; bits 0-5 = its ablation switches)

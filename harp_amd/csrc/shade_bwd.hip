@@ -65,9 +65,11 @@ constexpr int kVSlots = 32;                               // vertex table
 constexpr int kZW = 16, kZH = 16;                         // shadow-tap window (light-view pixels)
 constexpr int kScalars = 17;                              // 0-8 colours, 9-11 light_pos, 12-14 light_R[:,2], 15 light_T.z, 16 loss
 
+// REC = the texel gradients leave as RECORDS (harp_shade_args.trec): no texel table — 3.4 KB of LDS per wave instead of 9.6
+template <bool REC>
 struct alignas(16) WaveLds {
-  int tkey[kTSlots];
-  int tval[6][kTSlots];        // fixed point; 0-2 albedo, 3-5 normal map
+  int tkey[REC ? 4 : kTSlots];
+  int tval[6][REC ? 4 : kTSlots];        // fixed point; 0-2 albedo, 3-5 normal map
   int vkey[kVSlots];
   double vval[9][kVSlots];     // 0-2 g_verts, 3-5 g_vnormals, 6-8 g_ndc
   int zwin[kZW * kZH];         // fixed point
@@ -81,21 +83,22 @@ __device__ __forceinline__ void fixed_scale(float m, float& s, float& inv) {
   inv = __int_as_float((127 - 24 + e) << 23);
 }
 
+template <bool REC>
 struct ShadeSmem {
-  WaveLds w[4];
+  WaveLds<REC> w[4];
   float part[4][20];
   int ticket;
   int cnt[4];
   int list[256];          // compacted active pixels of the tile: face id | (pixel in tile) << 24
 };
 #ifndef SHADE_SKIP_LDS_ASSERT
-static_assert(sizeof(ShadeSmem) <= (160 / SHADE_BWD_OCC) * 1024, "LDS budget per workgroup");
+static_assert(sizeof(ShadeSmem<false>) <= (160 / SHADE_BWD_OCC) * 1024, "LDS budget per workgroup");
 #endif
 
 // one 16x16 tile of the shading backward; `vblock` = index in the 1-D heaviest-first tile grid
 // IMG: the fused-loss pass also writes the colour it recomputes (a template flag: the loss-only kernel must not pay for the branch — 9 % measured)
-template <bool IMG>
-__device__ __forceinline__ void shade_bwd_tile(ShadeSmem& sm, unsigned vblock, const harp_shade_args& A, const int32_t* __restrict__ order,
+template <bool IMG, bool REC>
+__device__ __forceinline__ void shade_bwd_tile(ShadeSmem<REC>& sm, unsigned vblock, const harp_shade_args& A, const int32_t* __restrict__ order,
                                                const int32_t* __restrict__ nact, int nsx) {
   auto& s_w = sm.w; auto& s_part = sm.part; int& s_ticket = sm.ticket; auto& s_cnt = sm.cnt; auto& s_list = sm.list;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -138,7 +141,7 @@ __device__ __forceinline__ void shade_bwd_tile(ShadeSmem& sm, unsigned vblock, c
     return;
   }
   const int tfid = !fused ? 0 : (A.B <= 64 ? __builtin_amdgcn_readlane(tf_all, b) : A.l1_fid[b]);
-  WaveLds& L = s_w[w];
+  WaveLds<REC>& L = s_w[w];
   if (threadIdx.x == 0) s_ticket = 0;
 
   // ---- own 16x4 strip: face id, mask -> active flag (coalesced rows)
@@ -183,8 +186,8 @@ __device__ __forceinline__ void shade_bwd_tile(ShadeSmem& sm, unsigned vblock, c
   if (64 * w < n_tile) {                     // only waves that got a share of the tile's active pixels clear their tables
     // (16-B stores over the whole 9.5-KB block, then the two key arrays: 14 LDS instructions instead of 43)
     int4* L4 = reinterpret_cast<int4*>(&L);
-    for (int i = lane; i < (int)(sizeof(WaveLds) / 16); i += 64) L4[i] = make_int4(0, 0, 0, 0);
-    for (int i = lane; i < kTSlots; i += 64) L.tkey[i] = -1;
+    for (int i = lane; i < (int)(sizeof(WaveLds<REC>) / 16); i += 64) L4[i] = make_int4(0, 0, 0, 0);
+    if constexpr (!REC) for (int i = lane; i < kTSlots; i += 64) L.tkey[i] = -1;
     if (lane < kVSlots) L.vkey[lane] = -1;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   }
@@ -220,6 +223,9 @@ __device__ __forceinline__ void shade_bwd_tile(ShadeSmem& sm, unsigned vblock, c
   for (int c = 0; c < 9; ++c) zd[c] = 0.f;
 
   bool dead = false;      // IMG mode: covered pixel outside the L1 mask — its colour is written, it stays out of the table phases
+  // REC: the lane's slot in its UV tile's record list = (count returned to the group's leader lane) + rank in the group
+  int rbase = 0, rwho = 0;
+  const bool rec_on = REC && (A.g_tex != nullptr || (A.nmap != nullptr && A.g_nmap != nullptr));
   if (act) {
     const float px = pix_to_ndc(xi, S), py = pix_to_ndc(yi, S);
     const float* col = A.colors;               // amb(3) diff(3) spec(3)
@@ -277,6 +283,24 @@ __device__ __forceinline__ void shade_bwd_tile(ShadeSmem& sm, unsigned vblock, c
     const bool packed = A.texnm != nullptr && A.nmap != nullptr;
     if (packed) bil_sample2((const float4*)A.texnm, g.bs, A.Wt, A.Ht, g.texel, g.m, &tdx, &tdy, &mdx, &mdy);
     else g.texel = bil_sample(A.tex, g.bs, A.Wt, A.Ht, &tdx, &tdy);
+    if constexpr (REC) {
+      // a slot in the record list of the 32x32-texel UV tile the footprint starts in: ONE returning atomic per distinct tile of the wave
+      // (1.8 on average: screen neighbours are UV neighbours), issued behind the texel fetch and not waited for until the record is written
+      if (rec_on) {
+        const bool emit = !(IMG && fused && l1_m == 0.f);
+        const int rbin = (g.bs.y0 >> 5) * ((A.Wt + 31) >> 5) + (g.bs.x0 >> 5);
+        unsigned long long todo = __ballot(emit ? 1 : 0);
+        while (todo) {
+          const int l = __builtin_ctzll(todo);
+          const int bb = __builtin_amdgcn_readlane(rbin, l);
+          const bool mine = emit && rbin == bb;
+          const unsigned long long m = __ballot(mine ? 1 : 0);
+          if (mine) rwho = l | ((int)__popcll(m & ((1ull << lane) - 1ull)) << 8);
+          if (lane == l) rbase = atomicAdd(A.trec_cnt + 16 * bb, (int)__popcll(m));
+          todo &= ~m;
+        }
+      }
+    }
     // normal map (pbr_materials.py:58-124): n' = normalize(-u m.x - v m.y + n m.z)
     V3 nfin = g.n;
     if (A.nmap) {
@@ -533,6 +557,27 @@ __device__ __forceinline__ void shade_bwd_tile(ShadeSmem& sm, unsigned vblock, c
     }
 
     STAMP(8);
+    if constexpr (REC) {
+      // ---- texture + normal-map gradients leave as one 36-byte record per pixel (planes of 4 bytes: consecutive slots of a tile's list
+      //      are consecutive addresses); harp_texel_reduce adds the footprints up, tile by tile
+      if (rec_on && !(dbg & 1)) {
+        const int pos = __shfl(rbase, rwho & 63, 64) + (rwho >> 8);
+        if (act) {
+          if (pos < A.trec_cap) {
+            const int rbin = (bs.y0 >> 5) * ((A.Wt + 31) >> 5) + (bs.x0 >> 5);
+            const size_t cap = (size_t)A.trec_cap;
+            float* r = A.trec + (size_t)rbin * 9 * cap + (size_t)pos;
+            r[0] = __int_as_float(bs.x0 | (bs.y0 << 16));
+            r[cap] = bs.wx; r[2 * cap] = bs.wy;
+            r[3 * cap] = g_tex.x; r[4 * cap] = g_tex.y; r[5 * cap] = g_tex.z;
+            r[6 * cap] = g_m_keep.x; r[7 * cap] = g_m_keep.y; r[8 * cap] = g_m_keep.z;
+          } else {                                   // the tile's list is full: straight into the reduce's double maps
+            if (A.g_tex) bil_scatter_d(A.trec_acc_tex, bs, A.Wt, A.Ht, g_tex);
+            if (A.nmap && A.g_nmap) bil_scatter_d(A.trec_acc_nmap, bs, A.Wt, A.Ht, g_m_keep);
+          }
+        }
+      }
+    } else
     // ---- texture + normal-map gradients: 4 bilinear corners x 6 channels into the direct-mapped fixed-point table
     if (!(dbg & 1) && (A.g_tex != nullptr || (A.nmap != nullptr && A.g_nmap != nullptr))) {      // (both maps frozen — known_appearance fits: no texel phase)
       const bool do_t = A.g_tex != nullptr, do_n = (A.nmap != nullptr) && (A.g_nmap != nullptr);
@@ -679,11 +724,14 @@ __device__ __forceinline__ void shade_bwd_tile(ShadeSmem& sm, unsigned vblock, c
   }
 }
 
-template <bool IMG>
-__global__ void __launch_bounds__(256, SHADE_BWD_OCC) shade_bwd_wave_kernel(const harp_shade_args A, const int32_t* __restrict__ order,
-                                                                            const int32_t* __restrict__ nact, int nsx) {
-  __shared__ ShadeSmem sm;
-  shade_bwd_tile<IMG>(sm, blockIdx.x, A, order, nact, nsx);
+#ifndef SHADE_REC_OCC
+#define SHADE_REC_OCC 4
+#endif
+template <bool IMG, bool REC>
+__global__ void __launch_bounds__(256, REC ? SHADE_REC_OCC : SHADE_BWD_OCC) shade_bwd_wave_kernel(const harp_shade_args A, const int32_t* __restrict__ order,
+                                                                                                  const int32_t* __restrict__ nact, int nsx) {
+  __shared__ ShadeSmem<REC> sm;
+  shade_bwd_tile<IMG, REC>(sm, blockIdx.x, A, order, nact, nsx);
 }
 
 // FUSED BACKWARD LAUNCH: the shading backward and the silhouette backward (csrc/raster_body.h, MODE 2) as ONE grid.  As two kernels on
@@ -697,7 +745,7 @@ struct SilBwdArgs {
   const float* alpha; const float* g_alpha; float* g_ndc; int F; float blur, sigma;
 };
 union FusedSmem {
-  ShadeSmem sh;
+  ShadeSmem<false> sh;
   rb::RasterSmem<2> rs;
   __device__ FusedSmem() {}
 };
@@ -711,7 +759,7 @@ __global__ void __launch_bounds__(256, FUSED_BWD_OCC) fused_bwd_kernel(const har
   const unsigned g = blockIdx.x >> 4, r = blockIdx.x & 15;
   const unsigned v = g * 8 + (r & 7);
   if (r < 8) {
-    shade_bwd_tile<false>(sm.sh, v, A, order, nact, nsx);
+    shade_bwd_tile<false, false>(sm.sh, v, A, order, nact, nsx);
   } else {
     rb::raster_tile<2>(sm.rs, v, R.recs, R.bbs, R.bins, R.cnt, order, nact, A.B, R.F, A.S, nsx, R.blur, R.sigma, nullptr, nullptr, (float*)R.alpha,
                        R.g_alpha, R.faces, A.V, R.g_ndc, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0, nullptr);
@@ -737,8 +785,12 @@ int harp_detail_shade_bwd_wave(const harp_shade_args& a, const int32_t* order, c
   // HARP_SHADE_LDS_PAD=<bytes> (timing experiments only) adds dynamic LDS to the launch to LOWER the number of resident workgroups:
   // how the kernel's time scales with occupancy (round 3: t = 0.134 + 0.454 / n ms for n workgroups per CU)
   static const unsigned pad = [] { const char* e = getenv("HARP_SHADE_LDS_PAD"); return e ? (unsigned)atoi(e) : 0u; }();
-  if (a.g_rgb == nullptr && a.rgb != nullptr) hipLaunchKernelGGL(shade_bwd_wave_kernel<true>, dim3(grid), dim3(256), pad, stream, a, order, nact, nsx);
-  else hipLaunchKernelGGL(shade_bwd_wave_kernel<false>, dim3(grid), dim3(256), pad, stream, a, order, nact, nsx);
+  const bool img = a.g_rgb == nullptr && a.rgb != nullptr;
+  if (a.trec != nullptr) {
+    if (img) hipLaunchKernelGGL((shade_bwd_wave_kernel<true, true>), dim3(grid), dim3(256), pad, stream, a, order, nact, nsx);
+    else hipLaunchKernelGGL((shade_bwd_wave_kernel<false, true>), dim3(grid), dim3(256), pad, stream, a, order, nact, nsx);
+  } else if (img) hipLaunchKernelGGL((shade_bwd_wave_kernel<true, false>), dim3(grid), dim3(256), pad, stream, a, order, nact, nsx);
+  else hipLaunchKernelGGL((shade_bwd_wave_kernel<false, false>), dim3(grid), dim3(256), pad, stream, a, order, nact, nsx);
   HARP_CHECK_LAUNCH();
   return HARP_OK;
 }

@@ -158,6 +158,20 @@ __device__ __forceinline__ void bil_scatter(float* g, const Bil& s, int W, int H
   }
 }
 
+// the same into a double map (the accumulators of harp_texel_reduce)
+__device__ __forceinline__ void bil_scatter_d(double* g, const Bil& s, int W, int H, V3 v) {
+  const float ax = 1.f - s.wx, ay = 1.f - s.wy;
+  const float w[4] = {ax * ay, s.wx * ay, ax * s.wy, s.wx * s.wy};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int x = s.x0 + (k & 1), y = s.y0 + (k >> 1);
+    if (x < W && y < H && w[k] != 0.f) {
+      double* p = g + ((size_t)y * W + x) * 3;
+      atomicAdd(p, (double)(v.x * w[k])); atomicAdd(p + 1, (double)(v.y * w[k])); atomicAdd(p + 2, (double)(v.z * w[k]));
+    }
+  }
+}
+
 // shadow test sigmoid: fast exp + reciprocal (rel. error < 1e-6 where it is not saturated; image tolerance 1e-4)
 __device__ __forceinline__ float sigmoidf(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 

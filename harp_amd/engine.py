@@ -204,6 +204,14 @@ class FitEngine:
         # the depth backward walks <= 2 tiles, it costs what it saves (0.704 vs 0.701 ms / step); at 1024^2 (8 tiles per workgroup) it wins
         # (1.777 vs 1.788 ms / step on the arm) — on from 1024 px.
         self.zl_tile_flags = self.S >= 1024
+        # the shader backward hands the texture / normal-map gradients on as one record per shaded pixel, binned by 32x32-texel UV tile, and
+        # harp_texel_reduce (csrc/texel_reduce.hip) adds them up on a branch of its own that joins in front of Adam — beside the mesh / hand
+        # backward tail instead of inside the shader backward (its LDS texel table, flush and ~12 M memory atomics per launch are gone)
+        self.texel_records = _lib.lib().harp_texel_bins(self.Ht, self.Wt) <= 1024 and world_size == 1      # (N > 1: the table form — the map gradients are final ~60 us earlier, which is what their early all-reduce overlaps with; switchable)
+        self.trec_cap_div = 32           # capacity of a tile's record list = B * S * S / this (>= 65536): 3.5x the fullest list of the bench scenes; a full list falls back to memory atomics
+        self.trec_cap_min = 65536
+        self._trec = self._tacc = None
+        self._maps_pending = None
         self.lean_app_stage = False      # appearance-only stage without the geometry gradients nothing reads (set by optimize_hand_sequence; off by default: g_buf then holds what autograd would)
         self._lean_now = False
         self.sil_only_raster = True      # geometry-only steps without a kept image: the camera raster forms no nearest-face ids (harp_rasterize_l1_fwd with face_id == NULL)
@@ -458,7 +466,31 @@ class FitEngine:
             a.g_nmap = None
         # light-view tiles that receive a shadow-tap gradient are flagged for the depth backward (which clears what it consumes)
         a.g_zl_tiles = _lib.ptr(s["zl_tiles"]) if (self.self_shadow and self.consume_gzl and self.zl_tile_flags) else None
+        if self._records_on():
+            rec, cnt, cap = self._texel_record_buffers()
+            a.trec, a.trec_cnt, a.trec_cap = _lib.ptr(rec), _lib.ptr(cnt), cap
+            a.trec_acc_tex, a.trec_acc_nmap = _lib.ptr(self._tacc[0]), _lib.ptr(self._tacc[1])
         return a
+
+    def _records_on(self):
+        return bool(self.texel_records and not ("texture" in self.frozen and "normal_map" in self.frozen))
+
+    def _texel_record_buffers(self):
+        if self._trec is None:
+            nb = _lib.lib().harp_texel_bins(self.Ht, self.Wt)
+            cap = max(int(self.trec_cap_min), self.B * self.S * self.S // max(1, int(self.trec_cap_div)))
+            self._trec = (torch.empty(nb * 9 * cap, dtype=torch.float32, device=self.dev),
+                          torch.zeros(nb * 16 + 16, dtype=torch.int32, device=self.dev), cap)
+        if self._tacc is None:                           # double accumulators of the two maps: all-zero between steps (harp_texel_finish clears what it consumes)
+            self._tacc = torch.zeros(2, self.Ht * self.Wt * 3, dtype=torch.float64, device=self.dev)
+        return self._trec
+
+    def _join_maps(self):
+        """the texel reduce (+ normal-map chain rule) runs on a branch of its own behind the shader backward: whoever reads the map
+        gradients next (all-reduce, Adam) joins it first"""
+        st, self._maps_pending = self._maps_pending, None
+        if st is not None:
+            torch.cuda.current_stream().wait_stream(st)
 
     def _can_fold(self):
         """the step's book-keeping rides in hand_front / hand_back / harp_step_prologue (`fold_step`) when those launches exist"""
@@ -706,6 +738,7 @@ class FitEngine:
         fuse_bwd = self.fused_bwd and coarse and app and self.perceptual is None
         side_used = False
         sil_after = None
+        marks = {}
         def launch_sil(ev=None):
             # the silhouette backward only needs g_alpha and the camera-view workspace: it overlaps with shading on the side stream
             if ev is None:
@@ -717,6 +750,7 @@ class FitEngine:
                                                p(s["g_ndc_c"]), ST()), "silhouette_bwd")
                 if mesh_late:
                     mesh_terms()                # `mesh_terms_late`: beside the (latency-bound) shader backward instead of beside the (VALU-bound) rasterisers
+                marks["sil"] = None if one else side.record_event()
         if coarse and not fuse_bwd:
             if not app and self.overlap:
                 # geometry-only stage: there is no shader backward to run next to — the silhouette backward stays on the critical stream
@@ -734,6 +768,8 @@ class FitEngine:
             mesh_terms()
         if app:
             a = self._shade_struct(B, app)
+            if fuse_bwd or not shared_terms:
+                a.trec = None                           # (the one-launch backward pair hosts the table form of the shader tile; the reduce is a shared term)
             # the photometric L1 term and its gradient are fused into the shader (no separate pass over the image)
             a.l1_target, a.l1_mask, a.l1_fid = p(self.y_true), p(self.y_sil_col), p(ltfid)
             a.l1_w, a.l1_loss, a.l1_grad = wp(6), lp(6), p(s["g_rgb"])
@@ -769,8 +805,22 @@ class FitEngine:
                                  "normalize3_bwd")
                     self._allreduce_maps_early()
                 # the chain rule of the normal map rides in the depth backward's launch when both exist (harp_depth_nmap_bwd)
-                nmap_in_depth = self.fused_terms and self.self_shadow and self.consume_gzl and not (self.tail_side and self.overlap) and not nm_frozen
-                if nmap_in_depth:
+                records = self._records_on() and not fuse_bwd
+                def maps_branch():
+                    rec, cnt, cap = self._texel_record_buffers()
+                    at, an = (None if "texture" in self.frozen else p(self._tacc[0])), (None if nm_frozen else p(self._tacc[1]))
+                    self._ck(L.harp_texel_reduce(p(rec), p(cnt), cap, self.Ht, self.Wt, at, an, ST()), "texel_reduce")
+                    # float(exact sum) -> gradient arena, the normal map's through the chain rule of its normalisation
+                    self._ck(L.harp_texel_finish(at, p(self.grads["texture"]), an, p(self.grads["normal_map"]), p(self.params["normal_map"]),
+                                                 self.Ht * self.Wt, ST()), "texel_finish")
+                    self._allreduce_maps_early()
+                nmap_in_depth = self.fused_terms and self.self_shadow and self.consume_gzl and not (self.tail_side and self.overlap) and not nm_frozen and not records
+                ev_shade = cur.record_event() if (records and self.overlap) else None
+                if records and not self.overlap:
+                    maps_branch()
+                elif records:
+                    pass                                # (captured BEHIND the depth backward, below: the critical path keeps the shader's stream)
+                elif nmap_in_depth:
                     self._ck(L.harp_depth_nmap_bwd(p(s["face_l"]), p(s["ws_l"]), p(tp.faces), p(s["g_zl"]), B, V, F, S, p(s["g_ndc_l"]),
                                                    p(self.params["normal_map"]), p(s["g_nmap_n"]), self.Ht * self.Wt, p(self.grads["normal_map"]),
                                                    p(s["zl_tiles"]) if self.zl_tile_flags else None, ST()), "depth_nmap_bwd")
@@ -782,7 +832,7 @@ class FitEngine:
                 else:
                     maps_tail()
             else:
-                nmap_in_depth = False
+                nmap_in_depth, ev_shade = False, None
             if self.self_shadow:
                 if not nmap_in_depth:
                     if self.consume_gzl and self.zl_tile_flags:
@@ -796,7 +846,17 @@ class FitEngine:
                                                 p(s["g_light_R"]), p(s["g_light_T"]), ST()), "project_bwd_l")
                     self._ck(L.harp_light_setup_bwd(p(s["centroid"]), p(s["light_pos"]), p(s["g_light_R"]), p(s["g_light_T"]), B, V, p(s["g_light_pos"]),
                                                     p(s["g_centroid"]), p(s["g_vd"]), ST()), "light_setup_bwd")
-        if side_used or (self.tail_side and self.overlap and app):
+        if app and ev_shade is not None:
+            # the texel reduce + normal-map chain rule follow the silhouette backward on the second stream (no further graph branch: a third
+            # one made the replay run the silhouette backward BEHIND it); the mesh-chain backward then joins the silhouette backward's end
+            # only, and Adam (`_join_maps`) the stream
+            if side_used and marks.get("sil") is not None:
+                wait_e(cur, marks["sil"])
+            wait_e(side, ev_shade)
+            with torch.cuda.stream(side):
+                maps_branch()
+            self._maps_pending = side
+        elif side_used or (self.tail_side and self.overlap and app):
             wait_s(cur, side)                       # silhouette_bwd -> g_ndc_c (normal-map chain rule with tail_side)
         if fused and self.fused_front and self.fused_back:
             # the whole backward tail — mesh chain, hand layer, scatter into the parameter tables' gradient rows — as three launches
@@ -972,6 +1032,7 @@ class FitEngine:
         self._early_from = o
 
     def allreduce(self):
+        self._join_maps()
         if not self._dist_on():
             return
         from .dist import allreduce_flat
@@ -1001,6 +1062,7 @@ class FitEngine:
             self._ck(L.harp_adam_tick(self.hyper.data_ptr() + (0 if coarse else 1) * self._hyper_stride, 1, st), "adam_tick")
 
     def adam(self, coarse=True, app=True, tick=True):
+        self._join_maps()
         L, p, st = _lib.lib(), _lib.ptr, _lib.stream()
         # parameters outside the reference's optimiser groups (known_appearance: shape / displacement / texture / normal map,
         # optimize_sequence.py:264-289) keep a zero gradient: with m = v = 0 the dense Adam update of such an element is exactly 0
@@ -1144,7 +1206,7 @@ class FitEngine:
         # every switch the enqueued launch sequence depends on is part of the key: flipping one re-captures instead of replaying a
         # graph recorded for another configuration
         gkey = (coarse, app, scheduled, n, self.keep_image, self.fused_loss, self.self_shadow, tuple(self.frozen), self.overlap, self.early_terms,
-                self.packed_texels, self.fused_keep, self.mesh_third, self.graph_order, fold, self.fused_terms, self.zl_tile_flags, self.accumulate_loss, self.lean_app_stage, self.sil_only_raster, self.auto_draw, self.mesh_terms_late, self.sil_late, self.paired_setup, self.late_texture_terms, self.mesh_terms_first, self.camera_first, self.tail_side, self.fused_bwd, self.fused_chain, self.fused_front, self.wide_front, self.hybrid_front, self.front_auto, self.wide_back, self.fused_back, self.consume_gzl, self.keep_depth, dist_on, self.overlap_allreduce,
+                self.packed_texels, self.fused_keep, self.mesh_third, self.graph_order, fold, self.fused_terms, self.zl_tile_flags, self.accumulate_loss, self.lean_app_stage, self.sil_only_raster, self.auto_draw, self.mesh_terms_late, self.sil_late, self.paired_setup, self.late_texture_terms, self.mesh_terms_first, self.camera_first, self.tail_side, self.fused_bwd, self.fused_chain, self.fused_front, self.wide_front, self.hybrid_front, self.front_auto, self.wide_back, self.fused_back, self.consume_gzl, self.keep_depth, self.texel_records, dist_on, self.overlap_allreduce,
                 self.comm is not None, self.perceptual is not None and app)
         g = self._graphs.get(gkey)
         if g is None:

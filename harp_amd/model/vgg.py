@@ -14,10 +14,13 @@ this package, so the 10 convolutions are declared here (same layer indices -> sa
     Vgg16Features(weights="random")                                                       # tests only: seeded random filters
 
 With `weights=None` the module tries torchvision (as the reference does) and raises if it is absent: there is no silent
-random-weight fallback.  Parity of this term against the reference is UNPINNED: neither torchvision nor the pretrained file exist
-in the build image, only the architecture / concatenation / weighting can be checked (tests/test_vgg.py).
+random-weight fallback.  What is pinned: the module structure, row layout and weighting against rows written by the imported reference
+module (tests/golden/vgg_ref.npz, tests/golden/make_golden_vgg.py); what is not: torchvision's PRETRAINED filters (absent here).
 
-The convolutions themselves run through torch (MIOpen); they are GEMM-shaped library work, not part of the hand-written HIP path.
+On a HIP tensor `forward` runs the ten convolutions, the pools and — under autograd — their data gradients on this repo's matrix-core
+kernels (csrc/conv.hip through `model/vgg_hip.py:Vgg16Rows`), so the reference loop body's `l1_loss(vgg(a), vgg(b))`
+(optimize_sequence.py:546-547) lands on them; `FitEngine.set_perceptual` runs the same kernels as one fused 21-launch term
+(harp_vgg16_term).  A CPU tensor goes through the torch layers declared here: that path exists for the CPU tests of the layout.
 """
 import torch
 
@@ -100,5 +103,18 @@ class Vgg16Features(torch.nn.Module):
             feats.append(scale(h.flatten(start_dim=1), w[n]))
         return feats
 
+    hip_precision = 0                # 0: float32 MFMA (parity anchor), 1: three-term bf16 split (model/conv_hip.py)
+
+    def _hip(self, device):
+        from .vgg_hip import Vgg16Hip
+        key = (str(device), int(self.hip_precision))
+        cache = self.__dict__.setdefault("_hip_cache", {})
+        if key not in cache:
+            cache[key] = Vgg16Hip(self, device, self.hip_precision)
+        return cache[key]
+
     def forward(self, x):
+        if x.is_cuda:
+            from .vgg_hip import Vgg16Rows
+            return Vgg16Rows.apply(x, self._hip(x.device))
         return torch.cat(self.features(x), 1)

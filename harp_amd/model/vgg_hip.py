@@ -78,12 +78,16 @@ class Vgg16Hip:
         slice_of = {ix: n for n, (lo, hi) in enumerate(_SLICES, start=1) for ix in range(lo, hi)}
         self._keep = []                          # device tensors the C struct points into
         net = _lib.Vgg16()
+        self.packed = []                         # per convolution: (filters, data-gradient filters, bias) — what the module-level call runs on
         for k, ix in enumerate(_ORDER):
             w = sd[f"slice{slice_of[ix]}.{ix}.weight"].detach().to(self.dev).float().contiguous()
             b = sd[f"slice{slice_of[ix]}.{ix}.bias"].detach().to(self.dev).float().contiguous()
             f = conv_hip.pack_filters(w, self.precision)
             ft = conv_hip.pack_filters(w, self.precision, transpose=True) if k > 0 else None
             self._keep += [w, b, f, ft]
+            self.packed.append((f, ft, b))
+            if k == 0:
+                self._w0 = w
             net.filters[k], net.filters_t[k], net.bias[k] = _lib.ptr(f), _lib.ptr(ft), _lib.ptr(b)
             if k == 0:      # (64,3,3,3) -> (9,3,64) with the taps mirrored: the layout the last backward kernel reads with scalar loads
                 w0t = w.reshape(64, 3, 9).flip(2).permute(2, 1, 0).contiguous()
@@ -148,4 +152,74 @@ class Vgg16Hip:
         _lib.check(_lib.lib().harp_vgg16_term(ctypes.byref(self.net), ctypes.byref(t), _lib.stream()), "harp_vgg16_term")
 
 
-__all__ = ["Vgg16Hip", "tap_shapes", "activation_shapes", "active_tiles", "feature_length"]
+    def first_layer_gradient_filters(self):
+        """data-gradient filters of the first convolution for harp_conv3x3 (64 -> 3 channels, padded to 64): the whole-term entry point has a
+        vector-ALU kernel for this layer (w0t); the module-level call runs it as one more matrix-core convolution"""
+        if getattr(self, "_ft0", None) is None:
+            self._ft0 = conv_hip.pack_filters(self._w0, self.precision, transpose=True)
+        return self._ft0
+
+
+class Vgg16Rows(torch.autograd.Function):
+    """`Vgg16Features.forward` on a HIP tensor (model/vgg.py:38-56 of the reference): x (N,3,H,W) -> one row per image — the flattened
+    input and the flattened relu1_2 / relu2_2 / relu3_3 / relu4_3 maps (NCHW order), scaled by layers_weights — with the ten convolutions
+    on csrc/conv.hip (harp_conv3x3, RELU epilogue with the fused 2x2 pool) and, backward, their data gradients (GATE / UNPOOL epilogues:
+    ReLU mask and arg-max routing fused; the filters are frozen, model/vgg.py:34-36).  The reference loop body's
+    `l1_loss(vgg(a), vgg(b))` (optimize_sequence.py:546-547) thereby lands on this repo's kernels, not on a library."""
+
+    POOL_BELOW = (2, 4, 7)                    # convolutions that read the 2x2-pooled map of the layer below
+
+    @staticmethod
+    def forward(ctx, x, hip):
+        if x.dim() != 4 or x.shape[1] != 3 or x.shape[2] % 8 or x.shape[3] % 8:
+            raise ValueError(f"Vgg16Features on HIP: input must be (N,3,H,W) with H, W multiples of 8, got {tuple(x.shape)}")
+        C = conv_hip
+        N, _, H, W = x.shape
+        x = x.float()
+        img = torch.zeros(N, H, W, 16, device=x.device)                      # NHWC, 3 -> 16 channels (the kernels walk 16 at a time)
+        img[..., :3] = x.permute(0, 2, 3, 1)
+        acts, h = [], img
+        for k in range(10):
+            d, co = _DIV[k], _COUT[k]
+            out = torch.empty(N, H // d, W // d, co, device=x.device)
+            pool = torch.empty(N, H // (2 * d), W // (2 * d), co, device=x.device) if (k + 1) in Vgg16Rows.POOL_BELOW else None
+            f, _, b = hip.packed[k]
+            C.conv3x3(h, f, co, bias=b, epilogue=C.RELU, precision=hip.precision, out=out, pooled=pool)
+            acts.append(out)
+            h = pool if pool is not None else out
+        lw = hip.layers_weights
+        row = torch.cat([lw[0] * x.flatten(1)] + [lw[i + 1] * acts[k].permute(0, 3, 1, 2).flatten(1) for i, k in enumerate(TAPS)], 1)
+        ctx.hip, ctx.acts, ctx.shape = hip, acts, (N, H, W)
+        return row
+
+    @staticmethod
+    def backward(ctx, g_row):
+        C, hip, acts = conv_hip, ctx.hip, ctx.acts
+        N, H, W = ctx.shape
+        lw = hip.layers_weights
+        g_row = g_row.float()
+        off = 3 * H * W
+        g_x = lw[0] * g_row[:, :off].reshape(N, 3, H, W)
+        g_tap = {}
+        for i, k in enumerate(TAPS):                                            # d / d relu(conv k), gated by the ReLU, NHWC
+            n, hk, wk, ck = acts[k].shape
+            seg = g_row[:, off:off + hk * wk * ck].reshape(n, ck, hk, wk).permute(0, 2, 3, 1)
+            g_tap[k] = (lw[i + 1] * seg * (acts[k] > 0)).contiguous()
+            off += hk * wk * ck
+        G = g_tap[9]
+        for k in range(9, 0, -1):
+            _, ft, _ = hip.packed[k]
+            below = acts[k - 1]
+            if k in Vgg16Rows.POOL_BELOW:      # through the pool into the tap layer below: added to that tap's own gradient
+                out = g_tap[k - 1]
+                C.conv3x3(G, ft, below.shape[-1], epilogue=C.UNPOOL, precision=hip.precision, out=out, gate=below)
+            else:
+                out = torch.empty_like(below)
+                C.conv3x3(G, ft, below.shape[-1], epilogue=C.GATE, precision=hip.precision, out=out, gate=below)
+            G = out
+        out = torch.empty(N, H, W, 64, device=G.device)
+        C.conv3x3(G, hip.first_layer_gradient_filters(), 64, epilogue=C.GATE, precision=hip.precision, out=out, gate=torch.ones_like(out))
+        return g_x + out[..., :3].permute(0, 3, 1, 2), None
+
+
+__all__ = ["Vgg16Hip", "Vgg16Rows", "tap_shapes", "activation_shapes", "active_tiles", "feature_length"]

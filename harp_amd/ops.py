@@ -268,6 +268,27 @@ def _shade_args(face_id, ws, topo, verts, vnormals, tex, nmap, light_pos, colors
     return a
 
 
+# the shader backward's texel gradients as records + harp_texel_reduce (include/harp_hip.h: harp_shade_args.trec) instead of the in-kernel
+# scatter; False: the table form.  Same gradients either way (tests/test_gpu_parity.py::test_texel_records_match_the_table_form).
+TEXEL_RECORDS = True
+_trec_cache = {}
+
+
+def texel_record_buffers(device, Ht, Wt, cap):
+    """(records, counters, cap, double accumulators of both maps) for harp_shade_args.trec / trec_cnt / trec_cap and harp_texel_reduce /
+    harp_texel_finish; None when the map has more tiles than the reduce handles"""
+    nb = _lib.lib().harp_texel_bins(int(Ht), int(Wt))
+    if nb > 1024:
+        return None
+    key = (str(device), int(Ht), int(Wt), int(cap))
+    if key not in _trec_cache:
+        _trec_cache.clear()
+        _trec_cache[key] = (torch.empty(nb * 9 * int(cap), dtype=torch.float32, device=device),
+                            torch.zeros(nb * 16 + 16, dtype=torch.int32, device=device), int(cap),
+                            torch.zeros(2, int(Ht) * int(Wt) * 3, dtype=torch.float64, device=device))
+    return _trec_cache[key]
+
+
 class _Shade(torch.autograd.Function):
     @staticmethod
     def forward(ctx, ndc, verts, vnormals, tex, nmap, light_pos, colors, zl, light_R, light_T, face_id, ws, topo, S, focal, pp, bg):
@@ -301,8 +322,16 @@ class _Shade(torch.autograd.Function):
         for k, t in (("g_rgb", g_rgb), ("g_tex", g_tex), ("g_nmap", g_nmap), ("g_verts", g_verts), ("g_vnormals", g_vn), ("g_ndc", g_ndc),
                      ("g_zl", g_zl), ("g_light_pos", g_lp), ("g_colors", g_col), ("g_light_R", g_lR), ("g_light_T", g_lT)):
             setattr(a, k, _lib.ptr(t))
-        _lib.check(_lib.lib().harp_shade_bwd(a, _lib.stream()), "harp_shade_bwd")
         B = verts.shape[0]
+        bufs = texel_record_buffers(verts.device, a.Ht, a.Wt, max(4096, B * S * S // 8)) if TEXEL_RECORDS else None
+        if bufs is not None:
+            a.trec, a.trec_cnt, a.trec_cap = _lib.ptr(bufs[0]), _lib.ptr(bufs[1]), bufs[2]
+            a.trec_acc_tex, a.trec_acc_nmap = _lib.ptr(bufs[3][0]), _lib.ptr(bufs[3][1])
+        _lib.check(_lib.lib().harp_shade_bwd(a, _lib.stream()), "harp_shade_bwd")
+        if bufs is not None:
+            at, an = _lib.ptr(bufs[3][0]), (_lib.ptr(bufs[3][1]) if g_nmap is not None else None)
+            _lib.check(_lib.lib().harp_texel_reduce(_lib.ptr(bufs[0]), _lib.ptr(bufs[1]), bufs[2], a.Ht, a.Wt, at, an, _lib.stream()), "harp_texel_reduce")
+            _lib.check(_lib.lib().harp_texel_finish(at, _lib.ptr(g_tex), an, _lib.ptr(g_nmap), None, a.Ht * a.Wt, _lib.stream()), "harp_texel_finish")
         return (g_ndc, g_verts, g_vn, g_tex, g_nmap, g_lp, g_col, g_zl, g_lR.view(B, 3, 3) if g_lR is not None else None, g_lT,
                 None, None, None, None, None, None, None)
 

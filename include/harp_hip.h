@@ -164,7 +164,36 @@ typedef struct harp_shade_args {
    * is set to 1.  harp_depth_bwd_tiles / harp_depth_nmap_bwd read them to leave out the tiles without a gradient (about half of the
    * tiles they would otherwise read) and clear the ones they consume. */
   unsigned char* g_zl_tiles;
+  /* optional (harp_shade_bwd, production kernel): texel-gradient RECORDS.  With trec != NULL the pass does not scatter the bilinear
+   * footprints of g_tex / g_nmap (the backward of TexturesUV.sample_textures, renderer/pbr_materials.py:82-124) itself: every shaded
+   * pixel appends ONE 36-byte record (texel x0 | y0 << 16, the two bilinear fractions, g_albedo[3], g_nmap[3]) to the list of the
+   * 32x32-texel UV tile its top-left texel lies in, and harp_texel_reduce (below) adds the lists up tile by tile in LDS into the double
+   * maps trec_acc_tex / trec_acc_nmap, which harp_texel_finish turns into g_tex / g_nmap.  harp_shade_bwd itself leaves g_tex / g_nmap
+   * untouched (they still say WHICH maps take a gradient: NULL = frozen); a record that does not fit its list is added to the double maps
+   * with memory atomics straight away.
+   *   trec      (harp_texel_bins(Ht, Wt), 9, trec_cap) floats, plane k of bin b at ((b * 9 + k) * trec_cap); 16-byte aligned, trec_cap a
+   *             multiple of 4
+   *   trec_cnt  harp_texel_bins(Ht, Wt) * 16 + 16 int32: the record count of bin b at [16 b] (one counter per 64-byte line), ALL ZERO on
+   *             entry; harp_texel_reduce hands them back zeroed */
+  float* trec;
+  int32_t* trec_cnt;
+  int trec_cap;
+  double* trec_acc_tex;    /* (Ht,Wt,3) doubles, the accumulators harp_texel_reduce adds into (required with trec unless the map is frozen) */
+  double* trec_acc_nmap;
 } harp_shade_args;
+/* number of 32x32-texel UV tiles (record bins) of an (Ht, Wt) map */
+int harp_texel_bins(int Ht, int Wt);
+/* second half of the texel gradient (see harp_shade_args.trec): acc_tex / acc_nmap (Ht,Wt,3) DOUBLE += the bilinear footprints of the
+ * records the harp_shade_bwd call(s) since the last reduce appended.  One workgroup per chunk of 2048 records of a bin: a (33 x 33 texel) x
+ * 6 channel 64-bit fixed-point accumulator in LDS (the extra row / column takes the footprints of the tile's last row / column; sums
+ * exact and independent of the order of the records), added to the double maps with row-contiguous memory atomics — the gradient a texel
+ * ends up with is float(exact sum) however the frames were batched.  Either map pointer may be NULL (frozen map).  The counters are
+ * all-zero again when the call has run. */
+int harp_texel_reduce(const float* trec, int32_t* trec_cnt, int trec_cap, int Ht, int Wt, double* acc_tex, double* acc_nmap, hipStream_t stream);
+/* third and last part: g_tex (n_texels,3) += float(acc_tex), g_nmap += float(acc_nmap) — with nmap_raw != NULL through the chain rule of
+ * F.normalize(nmap_raw, dim=-1) (utils/visualize.py:99; harp_normalize3_bwd's arithmetic: acc_nmap is then the gradient of the NORMALISED
+ * map, g_nmap that of the raw one) — and both accumulators are all-zero again.  A NULL accumulator skips that map. */
+int harp_texel_finish(double* acc_tex, float* g_tex, double* acc_nmap, float* g_nmap, const float* nmap_raw, int n_texels, hipStream_t stream);
 /* interleaves albedo (Ht*Wt,3) and the normalised normal map (Ht*Wt,3) into out (Ht*Wt,8): [r g b nx | ny nz 0 0], 16-B aligned */
 int harp_pack_texels(const float* tex, const float* nmap, int n_texels, float* out, hipStream_t stream);
 /* harp_normalize3_fwd(nmap_raw) -> nmap_n and harp_pack_texels(tex, nmap_n) -> packed (may be NULL) in ONE launch */

@@ -308,3 +308,110 @@ def test_hip_features_reproduce_the_reference_modules_golden_rows(golden_dir, pr
     hip.term(img[:1].contiguous(), img, ones, rows, taps, 1, g_rgb, loss)
     torch.cuda.synchronize()
     assert abs(loss.item() - want) < 2e-5 * want, (loss.item(), want)
+
+
+def _ref_filters_module(golden_dir, LW):
+    import sys
+    from harp_amd.model.vgg import Vgg16Features
+    sys.path.insert(0, golden_dir)
+    from vgg_filters import state_dict_torchvision_layout
+    return Vgg16Features(layers_weights=LW, weights=state_dict_torchvision_layout())
+
+
+@pytest.mark.parametrize("precision", [0, 1])
+def test_module_call_on_hip_reproduces_the_reference_rows_64x48(golden_dir, precision):
+    """`Vgg16Features.forward` on a HIP tensor (model/vgg_hip.py:Vgg16Rows, the ten convolutions on csrc/conv.hip) against rows the
+    REFERENCE's module wrote for a 64 x 48 input (tests/golden/make_golden_vgg.py): non-square, 4 x 3 tiles of 16 x 16 at full resolution,
+    seams between tiles at every level, one ragged 8 x 6 tile at the last.  The fixture keeps every 5th element of each row, the absolute
+    sum of each of its five segments and the L1 distance of the two rows; and `l1_loss(vgg(a), vgg(b))` (optimize_sequence.py:546-547,
+    verbatim) gives the reference's number."""
+    import os
+    import numpy as np
+    ref = np.load(os.path.join(golden_dir, "vgg_ref.npz"))
+    LW = [float(v) for v in ref["layers_weights_fit"]]
+    vgg = _ref_filters_module(golden_dir, LW)
+    vgg.hip_precision = precision
+    x = torch.from_numpy(ref["x_64x48"]).to(DEV)
+    with torch.no_grad():
+        row = vgg(x)
+    torch.cuda.synchronize()
+    seg = [int(v) for v in ref["y_64x48_segments"]]
+    assert row.shape == (2, seg[-1])
+    got, want = row[:, ::5].double().cpu(), torch.from_numpy(ref["y_64x48_every5th"]).double()
+    idx = torch.arange(0, seg[-1], 5)
+    for i in range(5):
+        sel = (idx >= seg[i]) & (idx < seg[i + 1])
+        scale = want[:, sel].abs().max()
+        assert ((got[:, sel] - want[:, sel]).abs().max() / scale).item() < 4 * TOL[precision], i
+        sums = row[:, seg[i]:seg[i + 1]].double().abs().sum(1).cpu()
+        assert torch.allclose(sums, torch.from_numpy(ref["y_64x48_segment_abs_sums"][:, i]), rtol=2e-5), i
+    l1_loss = torch.nn.L1Loss()
+    with torch.no_grad():
+        loss = l1_loss(vgg(x[:1]), vgg(x[1:]))
+    assert abs(loss.item() - float(ref["y_64x48_l1"])) < 2e-5 * float(ref["y_64x48_l1"])
+
+
+@pytest.mark.parametrize("precision", [0, 1])
+def test_module_call_backward_on_hip_against_torch_float64(golden_dir, precision):
+    """autograd through `Vgg16Features.forward` on HIP tensors (GATE / UNPOOL data-gradient convolutions of csrc/conv.hip) against torch's
+    float64 autograd through the same module on the CPU: a LINEAR functional of the row (no sign noise), 64 x 48, then the loop's own
+    `l1_loss(vgg(pred * mask), vgg(true * mask))` on the reference-written masked pair of tests/golden/vgg_ref.npz — loss and gradient
+    against the numbers the imported reference module and its autograd produced."""
+    import os
+    import numpy as np
+    from harp_amd.model.vgg import Vgg16Features
+    ref = np.load(os.path.join(golden_dir, "vgg_ref.npz"))
+    LW = [float(v) for v in ref["layers_weights_fit"]]
+    vgg = _ref_filters_module(golden_dir, LW)
+    vgg.hip_precision = precision
+    vgg64 = Vgg16Features(layers_weights=LW, weights=vgg.state_dict()).double()
+    g = torch.Generator().manual_seed(9)
+    x = torch.from_numpy(ref["x_64x48"]).double().requires_grad_(True)
+    R = torch.randn(2, vgg64(x.detach()).shape[1], generator=g, dtype=torch.float64)
+    (want,) = torch.autograd.grad((vgg64(x) * R).sum(), x)
+    xd = x.detach().float().to(DEV).requires_grad_(True)
+    (got,) = torch.autograd.grad((vgg(xd) * R.float().to(DEV)).sum(), xd)
+    torch.cuda.synchronize()
+    rel = ((got.double().cpu() - want).norm() / want.norm()).item()
+    # (bf16 split: activations within 1e-5 of zero change side, and with them the ReLU gates of the data gradient — 6e-3 measured, the same
+    #  effect as in the whole-term tests; the float32 mode is the parity anchor)
+    assert rel < (2e-6, 2e-2)[precision], rel
+    # the loop body's two lines on the masked pair (reference numbers)
+    l1_loss = torch.nn.L1Loss()
+    y_pred = torch.from_numpy(ref["pair_pred"]).to(DEV).requires_grad_(True)
+    y_true = torch.from_numpy(ref["pair_true"]).to(DEV)
+    y_sil_true_col = torch.from_numpy(ref["pair_mask"]).to(DEV)[None]
+    loss = l1_loss(vgg((y_pred * y_sil_true_col.unsqueeze(-1)).permute(0, 3, 1, 2)),
+                   vgg((y_true * y_sil_true_col.unsqueeze(-1)).permute(0, 3, 1, 2)))
+    loss.backward()
+    torch.cuda.synchronize()
+    g_want = torch.from_numpy(ref["pair_grad"]).double()
+    rel = ((y_pred.grad.double().cpu() - g_want).norm() / g_want.norm()).item()
+    print(f"[module call, precision {precision}] loss {loss.item():.8f} vs reference {float(ref['pair_loss']):.8f}, gradient rel-L2 {rel:.1e}")
+    assert abs(loss.item() - float(ref["pair_loss"])) < 2e-5 * float(ref["pair_loss"]) and rel < (2e-3, 6e-2)[precision]
+
+
+@pytest.mark.parametrize("shift", [True, False])
+@pytest.mark.parametrize("precision", [0, 1])
+def test_whole_term_full_and_bounded_against_the_reference_pair(golden_dir, precision, shift):
+    """harp_vgg16_term — full pass, bounded mode, bounded mode with the shifted tile grids — on the masked 64 x 64 pair whose loss and
+    image gradient the imported reference module (model/vgg.py) and torch autograd wrote into tests/golden/vgg_ref.npz."""
+    import os
+    import numpy as np
+    from harp_amd.model.vgg_hip import Vgg16Hip, active_tiles
+    ref = np.load(os.path.join(golden_dir, "vgg_ref.npz"))
+    LW = [float(v) for v in ref["layers_weights_fit"]]
+    hip = Vgg16Hip(_ref_filters_module(golden_dir, LW), DEV, precision)
+    rgb, y_true, mask = (torch.from_numpy(ref[k]).to(DEV).contiguous() for k in ("pair_pred", "pair_true", "pair_mask"))
+    mask = mask[None].contiguous()
+    rows = torch.zeros(1, dtype=torch.int32, device=DEV)
+    cache = hip.features(y_true, mask, all_slots=True)
+    bound = active_tiles(mask, shift_grid=shift)
+    assert bound[0][2].item() < 16                                   # the blob leaves full-resolution tiles out
+    g_want = torch.from_numpy(ref["pair_grad"]).double()
+    for bd in (None, bound):
+        g_rgb, loss = torch.zeros_like(rgb), torch.zeros(1, device=DEV)
+        hip.term(rgb, y_true, mask, rows, cache, 1, g_rgb, loss, weight=1.0, bound=bd)
+        torch.cuda.synchronize()
+        rel = ((g_rgb.double().cpu() - g_want).norm() / g_want.norm()).item()
+        assert abs(loss.item() - float(ref["pair_loss"])) < 2e-5 * float(ref["pair_loss"]) and rel < (2e-3, 6e-2)[precision], (bd is None, loss.item(), rel)

@@ -1241,7 +1241,9 @@ def test_light_camera_incl_look_at_replacement_branch():
                                       dict(paired_setup=True), dict(paired_setup=True, front_auto=False, wide_front=True), dict(paired_setup=True, overlap=False),
                                       dict(late_texture_terms=True), dict(late_texture_terms=True, mesh_terms_first=False), dict(sil_late=True), dict(mesh_terms_late=True),
                                       dict(mesh_terms_late=True, graph_order=False), dict(mesh_terms_late=True, sil_late=True),
-                                      dict(paired_setup=True, keep_depth=False)])
+                                      dict(paired_setup=True, keep_depth=False),
+                                      # round 6: texel gradients as records + harp_texel_reduce on a branch of its own (default) vs the in-kernel table form
+                                      dict(texel_records=False), dict(texel_records=False, tail_side=True), dict(texel_records=False, fused_terms=False), dict(tail_side=True, fused_terms=False)])
 def test_schedule_switches_give_the_default_schedules_result(switches):
     """The stream / capture-order switches of FitEngine (graph_order, mesh_third, camera_first, overlap, early_terms, mesh_terms_first,
     tail_side) only move launches between streams: losses and the whole gradient arena of every non-default combination must equal the
@@ -1796,3 +1798,83 @@ def test_wide_mesh_chain_raw_abi_equals_the_one_workgroup_chain(sc, kind):
     # light_only is not a wide form
     ch = eng._chain_struct(B, True, True); ch.light_only = 1
     assert L.harp_mesh_chain_bwd_wide(ctypes.byref(ch), _lib.ptr(ws), _lib.stream()) == 1
+
+
+@pytest.mark.parametrize("stage", [(True, True, False), (False, True, False), (False, True, True)])
+@pytest.mark.parametrize("cap", [1 << 16, 48])
+def test_texel_records_match_the_table_form(sc, cap, stage):
+    """harp_shade_args.trec: one record per shaded pixel + harp_texel_reduce instead of the shader backward's own texel scatter (the
+    backward of TexturesUV.sample_textures, renderer/pbr_materials.py:82-124).  Same texture / normal-map gradient as the table form
+    (float-atomic order apart), every other gradient untouched, counters handed back zeroed; a list that is full (cap = 48: nearly every
+    record of this scene) falls back to memory atomics and changes nothing."""
+    from tests._scene import make_fit_case
+    case = make_fit_case("hand", T=3, S=128, B=3, seed=5, device=DEV)
+    eng = case["eng"]
+    eng.keep_image = False
+    eng.auto_draw = False
+    eng.draw_texture_offsets()
+    eng.set_lr(0.0, 0.0)
+    eng.set_schedule(torch.arange(3).reshape(1, 3).int())
+    coarse, app, eng.lean_app_stage = stage
+
+    def run(graph):
+        for _ in range(3 if graph else 1):
+            eng.step(None, coarse, app, use_graph=graph)
+        torch.cuda.synchronize()
+        return eng.g_buf.double().clone(), eng.loss_vec[:9].double().clone()
+    eng.texel_records = False
+    ref = {g: run(g) for g in (False, True)}
+    eng.texel_records, eng.trec_cap_min, eng.trec_cap_div, eng._trec = True, cap, 1 << 30, None
+    for graph in (False, True):
+        g, l = run(graph)
+        assert eng._trec[2] == cap
+        assert int(eng._trec[1].abs().max().item()) == 0, "harp_texel_reduce hands the list counters back zeroed"
+        for k in ("texture", "normal_map"):
+            a, b = eng.arena.view(g, k), eng.arena.view(ref[graph][0], k)
+            assert b.abs().max() > 0 and rel(a, b) < 2e-6, (cap, graph, k, rel(a, b))
+        assert rel(g, ref[graph][0]) < 1e-5, (cap, graph, rel(g, ref[graph][0]))
+        assert ((l - ref[graph][1]).abs() <= 1e-5 * ref[graph][1].abs() + 1e-9).all()
+
+
+def test_texture_terms_by_tile_owners_edge_cases():
+    """harp_texture_terms forms the smoothness gradients by tile owners (csrc/losses.hip: tex_smooth_tile_body; loss/texture_reg.py:5-30,
+    48-66): every path of it against the scattering stand-alone kernel — map sizes that are no multiple of the 32-texel tile, offsets
+    clamped at the map border, outlier draws further than the 8-texel halo (handed on by the source's own tile), many sources on one
+    target (the 4-slot list overflows), a fractional mask, tiles without a masked texel."""
+    from harp_amd import _lib
+    L, p, st = _lib.lib(), _lib.ptr, _lib.stream
+    g = torch.Generator().manual_seed(11)
+    for (H, W) in ((72, 100), (64, 64), (33, 129)):
+        n = H * W
+        tex, nm = torch.rand(n, 3, generator=g).to(DEV), (torch.randn(n, 3, generator=g) * 0.3 + torch.tensor([0., 0., 1.])).to(DEV)
+        mask = torch.rand(n, generator=g)
+        mask[mask < 0.3] = 0.0                                     # fractional where set
+        mask.view(H, W)[:, : W // 3] = 0.0                         # whole tiles outside the mask
+        mask = mask.to(DEV)
+        da = (torch.randn(n, 2, generator=g) * 1.0).to(torch.int32)
+        dn = (torch.randn(n, 2, generator=g) * 2.0).to(torch.int32)
+        far = torch.randperm(n, generator=g)[: n // 50]
+        dn[far] = torch.randint(-40, 41, (far.numel(), 2), generator=g, dtype=torch.int32)     # outliers, many of them clamped at the border
+        # a crowd of sources on ONE target: every texel of a 7x7 patch inside the mask points at the patch centre
+        r0, c0 = H // 2, (2 * W) // 3
+        rr, cc = torch.meshgrid(torch.arange(r0 - 3, r0 + 4), torch.arange(c0 - 3, c0 + 4), indexing="ij")
+        idx = (rr * W + cc).reshape(-1)
+        da[idx, 0], da[idx, 1] = (r0 - rr).reshape(-1).int(), (c0 - cc).reshape(-1).int()
+        mh = mask.clone(); mh[idx.to(DEV)] = 0.75; mask = mh
+        da, dn = da.to(DEV), dn.to(DEV)
+        w = torch.tensor([0.5, 0.1], device=DEV)
+        wa, wn = w[0:1], w[1:2]
+        la, lb = torch.zeros(3, device=DEV), torch.zeros(3, device=DEV)
+        ga = [torch.zeros(n, 3, device=DEV) for _ in range(2)]
+        gb = [torch.zeros(n, 3, device=DEV) for _ in range(2)]
+        _lib.check(L.harp_texture_smooth_reg(p(tex), p(da), p(mask), H, W, p(wa), p(la), p(ga[0]), st()), "albedo")
+        _lib.check(L.harp_close_to_z_reg(p(nm), H, W, 0.2, p(wn), p(la) + 4, p(ga[1]), st()), "close_z")
+        _lib.check(L.harp_texture_smooth_reg(p(nm), p(dn), p(mask), H, W, p(wn), p(la) + 4, p(ga[1]), st()), "normal_smooth")
+        _lib.check(L.harp_texture_terms(p(tex), p(nm), p(mask), p(da), p(dn), H, W, 0.2, p(wa), p(lb), p(gb[0]), p(wn), p(lb) + 4, p(gb[1]), None, 0,
+                                        None, None, None, None, st()), "texture_terms")
+        torch.cuda.synchronize()
+        assert ((la - lb).abs() <= 2e-6 * la.abs()).all() and (la[:2] > 0).all(), (H, W, la, lb)
+        for a, b in zip(ga, gb):
+            assert a.abs().max().item() > 0 and rel(b.double(), a.double()) < 2e-6, (H, W, rel(b.double(), a.double()))
+            # (sums of +-k: the two forms may differ in the order of a few float additions only)
+            assert (a - b).abs().max().item() <= 4e-7 * a.abs().max().item(), (H, W)
