@@ -175,6 +175,7 @@ SIGNATURES["harp_draw_texture_offsets"] = (_i, [ctypes.c_uint, _vp, _i, _i, _f, 
 SIGNATURES["harp_raster_setup_pair"] = (_i, [_vp, _f, _vp, _vp, _f, _vp, _vp, _i, _i, _i, _i, _vp])
 SIGNATURES["harp_rasterize_fwd_keep"] = (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp])
 SIGNATURES["harp_rasterize_l1_fwd"] = (_i, [_vp, _vp, _i, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp])
+SIGNATURES["harp_rasterize_l1_fwd_bwd"] = (_i, [_vp, _vp, _i, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp])
 
 # data-parallel exchange (csrc/comm.hip): RCCL bound at run time, all-reduce enqueued on the caller's stream
 SIGNATURES.update({

@@ -227,18 +227,10 @@ __global__ __launch_bounds__(256, CONV_WAVES) void conv3x3_kernel(const harp_con
 #endif
   fetch(0);
   for (int cc = 0; cc < nchunk; ++cc) {
-#ifdef CONV_NOSTAGE                          // timing experiments only (wrong results): stage / fetch the first chunk only
-    if (cc == 0) {
-#endif
     __syncthreads();                      // every wave is done with the previous chunk's patch and slab
     stage(cc);
     __syncthreads();
-#ifdef CONV_NOSTAGE
-    }
-#endif
-#ifndef CONV_NOFETCH
     if (cc + 1 < nchunk) fetch(cc + 1);   // in flight under the chunk's MFMAs
-#endif
     // Software pipeline over the chunk's steps (float32: 18 = 9 taps x 2 k groups of 8 channels; bf16: 9 taps of 16 channels): the
     // fragments of step s + 1 are read from LDS before the MFMAs of step s issue, so one wave alone covers its LDS latency (the compiler's
     // own schedule read each step's fragments right in front of its MFMAs: MFMA pipe 78 % / 37 % busy, profiles/r05_a_pmc_sq_conv_*).
@@ -246,10 +238,6 @@ __global__ __launch_bounds__(256, CONV_WAVES) void conv3x3_kernel(const harp_con
     constexpr int kFrag = PREC == 0 ? 4 : 8;
     float4 fr[2][kFrag];
     auto read_frags = [&](float4* f, int step) {
-#ifdef CONV_LINEAR_LDS      // timing experiment only (wrong results): every fragment read lane-linear, as in tools/dev/micro/mfma_rate.hip
-      for (int i = 0; i < kFrag; ++i) f[i] = smem[((step * kFrag + i) * 64 + lane) & 2047];
-      return;
-#endif
       if (PREC == 0) {
         const int tap = step >> 1, g = step & 1;
         const int plane = 2 * g + half, toff = (tap / 3) * kRow + (tap % 3);

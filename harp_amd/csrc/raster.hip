@@ -159,7 +159,7 @@ __global__ void __launch_bounds__(1024) order_tiles_pair_kernel(const RasterWs a
 #endif
 constexpr unsigned kRasterGrid = 16384;
 
-template <int MODE, bool LOOP>
+template <int MODE, bool LOOP, bool BWD = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == 2 ? RASTER_OCC2 : (MODE == 0 ? RASTER_OCC0 : RASTER_OCC1), 8))) raster_kernel(const FaceRec* __restrict__ recs, const float4* __restrict__ bbs,
                                                      const int32_t* __restrict__ bins,
                                                      const int32_t* __restrict__ bin_count, const int32_t* __restrict__ order,
@@ -171,9 +171,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE =
                                                      const int32_t* __restrict__ l1_fid, const float* __restrict__ l1_w,
                                                      float* __restrict__ l1_loss, float* __restrict__ l1_grad, float l1_inv, int sparse,
                                                      const float* __restrict__ l1_bg_sums, int32_t* __restrict__ st_state) {
-  __shared__ rb::RasterSmem<MODE> sm;
+  __shared__ rb::RasterSmem<MODE, BWD> sm;
   if constexpr (!LOOP) {
-    rb::raster_tile<MODE>(sm, blockIdx.x, recs, bbs, bins, bin_count, order, nact, B, F, S, nsx, blur, sigma, face_id, zbuf, alpha, g_alpha, faces, V, g_ndc,
+    rb::raster_tile<MODE, BWD>(sm, blockIdx.x, recs, bbs, bins, bin_count, order, nact, B, F, S, nsx, blur, sigma, face_id, zbuf, alpha, g_alpha, faces, V, g_ndc,
                           l1_target, l1_fid, l1_w, l1_loss, l1_grad, l1_inv, sparse, l1_bg_sums, st_state);
     return;
   }
@@ -188,7 +188,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE =
   const unsigned limit = skip_empty ? min(total, (unsigned)(((nact[0] + 7) / 8) * 8 * (kSuper / kTile) * (kSuper / kTile))) : total;
   for (unsigned v = blockIdx.x; v < limit; v += gridDim.x) {
     if (v != blockIdx.x) __syncthreads();                 // LDS of the previous tile
-    rb::raster_tile<MODE>(sm, v, recs, bbs, bins, bin_count, order, nact, B, F, S, nsx, blur, sigma, face_id, zbuf, alpha, g_alpha, faces, V, g_ndc,
+    rb::raster_tile<MODE, BWD>(sm, v, recs, bbs, bins, bin_count, order, nact, B, F, S, nsx, blur, sigma, face_id, zbuf, alpha, g_alpha, faces, V, g_ndc,
                           l1_target, l1_fid, l1_w, l1_loss, l1_grad, l1_inv, sparse, l1_bg_sums, st_state);
   }
   if (bg_table) {
@@ -260,7 +260,7 @@ size_t harp_rasterize_ws_bytes(int B, int F, int S) {
 static int rasterize_impl(const float* ndc, const int32_t* faces, int B, int V, int F, int S, int soft, float blur_radius,
                           float sigma, void* ws, int32_t* face_id, float* zbuf, float* alpha, const float* l1_target,
                           const int32_t* l1_fid, const float* l1_w, float* l1_loss, float* l1_grad, const float* l1_bg_sums,
-                          int32_t* st_state, hipStream_t stream) {
+                          int32_t* st_state, hipStream_t stream, float* g_ndc = nullptr) {
   // face_id == NULL: silhouette only (camera view of a geometry-only step: nothing reads the nearest face) — soft pass, no depth map
   if (!ndc || !faces || !ws || (!face_id && (!(soft & 1) || zbuf)) || B <= 0 || F <= 0 || S <= 0 || ((soft & 1) && !alpha)) return HARP_ERR_ARG;
   if (l1_target && (!(soft & 1) || !l1_fid || !l1_w || !l1_loss || !l1_grad)) return HARP_ERR_ARG;
@@ -275,7 +275,13 @@ static int rasterize_impl(const float* ndc, const int32_t* faces, int B, int V, 
   const float l1_inv = 1.0f / ((float)B * (float)S * (float)S);
   const int sp = (soft & 2) ? 1 : 0;
 #define HARP_RASTER_LAUNCH(MODE, LOOP, ...) hipLaunchKernelGGL((raster_kernel<MODE, LOOP>), grid, dim3(256), 0, stream, __VA_ARGS__)
-  if (soft & 1) {
+  if ((soft & 1) && g_ndc) {
+    // camera view with the silhouette backward of every tile fused in (harp_rasterize_l1_fwd_bwd)
+    if (loop) hipLaunchKernelGGL((raster_kernel<1, true, true>), grid, dim3(256), 0, stream, recs, bbs, bins, cnt, order, W.nact, B, F, S, nsx, blur_radius, sigma, face_id, zbuf,
+                                 alpha, nullptr, faces, V, g_ndc, l1_target, l1_fid, l1_w, l1_loss, l1_grad, l1_inv, sp, l1_bg_sums, nullptr);
+    else hipLaunchKernelGGL((raster_kernel<1, false, true>), grid, dim3(256), 0, stream, recs, bbs, bins, cnt, order, W.nact, B, F, S, nsx, blur_radius, sigma, face_id, zbuf,
+                            alpha, nullptr, faces, V, g_ndc, l1_target, l1_fid, l1_w, l1_loss, l1_grad, l1_inv, sp, l1_bg_sums, nullptr);
+  } else if (soft & 1) {
     if (loop) HARP_RASTER_LAUNCH(1, true, recs, bbs, bins, cnt, order, W.nact, B, F, S, nsx, blur_radius, sigma, face_id, zbuf, alpha, nullptr, nullptr, 0, nullptr,
                                  l1_target, l1_fid, l1_w, l1_loss, l1_grad, l1_inv, sp, l1_bg_sums, nullptr);
     else HARP_RASTER_LAUNCH(1, false, recs, bbs, bins, cnt, order, W.nact, B, F, S, nsx, blur_radius, sigma, face_id, zbuf, alpha, nullptr, nullptr, 0, nullptr,
@@ -319,6 +325,16 @@ int harp_rasterize_l1_fwd(const float* ndc, const int32_t* faces, int B, int V, 
                           hipStream_t stream) {
   return rasterize_impl(ndc, faces, B, V, F, S, soft, blur_radius, sigma, ws, face_id, zbuf, alpha, l1_target, l1_fid, l1_w, l1_loss, l1_grad,
                         l1_bg_sums, nullptr, stream);
+}
+
+// harp_rasterize_l1_fwd with the silhouette backward fused into the same launch: g_ndc (B,V,3) += d (w * L1) / d ndc (x, y components),
+// what harp_silhouette_bwd(alpha, l1_grad) would add — formed tile by tile while the tile's faces are still staged in LDS.
+int harp_rasterize_l1_fwd_bwd(const float* ndc, const int32_t* faces, int B, int V, int F, int S, int soft, float blur_radius,
+                              float sigma, void* ws, int32_t* face_id, float* alpha, const float* l1_target, const int32_t* l1_fid,
+                              const float* l1_w, float* l1_loss, float* l1_grad, const float* l1_bg_sums, float* g_ndc, hipStream_t stream) {
+  if (!g_ndc || !l1_target || !(soft & 1)) return HARP_ERR_ARG;
+  return rasterize_impl(ndc, faces, B, V, F, S, soft, blur_radius, sigma, ws, face_id, nullptr, alpha, l1_target, l1_fid, l1_w, l1_loss, l1_grad,
+                        l1_bg_sums, nullptr, stream, g_ndc);
 }
 
 int harp_rasterize_fwd(const float* ndc, const int32_t* faces, int B, int V, int F, int S, int soft, float blur_radius,

@@ -70,7 +70,8 @@ __device__ __forceinline__ int nst_of(int nsx) { return nsx * nsx; }
 #define RASTER_CAP2 128
 #endif
 template <int MODE> constexpr int stage_cap() { return MODE == 2 ? RASTER_CAP2 : kStage; }
-template <int MODE>
+// BWD (MODE 1 only): the camera-view pass also runs the silhouette backward of its own tile (see the end of raster_tile)
+template <int MODE, bool BWD = false>
 struct RasterSmem {
   static constexpr int kCap = stage_cap<MODE>();
   float4 s_a[kCap], s_b[kCap], s_bb[kCap];
@@ -99,13 +100,25 @@ struct RasterSmem {
   unsigned short pairs[MODE >= 1 ? 512 : 1];      // 4 waves x 128-entry ring of (pixel, staged face) pairs
   // MODE 2: per-staged-face gradient accumulators (x,y of 3 verts).  double: ds_add_f64 is ~20x faster than ds_add_f32 on gfx950
   double s_g[MODE == 2 ? kCap : 1][6];
+  // MODE 1 + BWD: the same accumulators as float (6 KB instead of 12: the forward pass lives on its occupancy) — a few dozen pairs per tile add
+  // into them through an fp32 compare-and-swap loop (11 clk per wave instruction; ds_add_f32 takes 193 on gfx950)
+  float s_gf[(MODE == 1 && BWD) ? kCap : 1][6];
   float red[4];
 };
 
+__device__ __forceinline__ void lds_add_f32(float* p, float v) {
+  unsigned* u = reinterpret_cast<unsigned*>(p);
+  unsigned old = *u, assumed;
+  do {
+    assumed = old;
+    old = atomicCAS(u, assumed, __float_as_uint(__uint_as_float(assumed) + v));
+  } while (old != assumed);
+}
+
 // One 16x16 tile; `vblock` = index in the 1-D heaviest-first tile grid (harp_common.h: tile_decode_v).  A __device__ function so that
 // the silhouette backward (MODE 2) can also run as part of the fused backward launch (shade_bwd.hip), interleaved with the shading tiles.
-template <int MODE>
-__device__ __forceinline__ void raster_tile(RasterSmem<MODE>& sm, unsigned vblock, const FaceRec* __restrict__ recs, const float4* __restrict__ bbs,
+template <int MODE, bool BWD = false>
+__device__ __forceinline__ void raster_tile(RasterSmem<MODE, BWD>& sm, unsigned vblock, const FaceRec* __restrict__ recs, const float4* __restrict__ bbs,
                                                      const int32_t* __restrict__ bins,
                                                      const int32_t* __restrict__ bin_count, const int32_t* __restrict__ order,
                                                      const int32_t* __restrict__ nact, int B, int F, int S, int nsx,
@@ -323,6 +336,7 @@ __device__ __forceinline__ void raster_tile(RasterSmem<MODE>& sm, unsigned vbloc
   // a walk runs when the next chunk would not fit, or at the end of the list — one walk per tile almost always (a tile sees 30 - 100
   // of its super-tile's ~350 faces), instead of one per 256 list entries.
   int staged = 0, skip = 0;                    // skip: hits of the current chunk staged in an earlier round (a chunk with more hits than a round holds)
+  int rounds = 0, last_nl = 0;                 // (BWD: a tile that took ONE round still holds all its faces in LDS when the forward pass is done)
   for (int base = 0; base < n || staged > 0;) {
     bool flush = true;
     if (base < n) {
@@ -357,6 +371,7 @@ __device__ __forceinline__ void raster_tile(RasterSmem<MODE>& sm, unsigned vbloc
     const int nl = staged;
     staged = 0;
     if (nl == 0) continue;
+    ++rounds; last_nl = nl;
     if (MODE == 2) {
 #pragma unroll
       for (int c = 0; c < 6; ++c)
@@ -409,9 +424,6 @@ __device__ __forceinline__ void raster_tile(RasterSmem<MODE>& sm, unsigned vbloc
         const int x0 = max((int)ceilf((1.0f - q.y) * hs - 0.501f), tx0), x1 = min(min((int)floorf((1.0f - q.x) * hs - 0.499f), tx0 + kTile - 1), S - 1);
         const int y0 = max((int)ceilf((1.0f - q.w) * hs - 0.501f), ty0), y1 = min(min((int)floorf((1.0f - q.z) * hs - 0.499f), ty0 + kTile - 1), S - 1);
         bool more = valid && x0 <= x1 && y0 <= y1;
-#if defined(RASTER_ABLATE) && (RASTER_ABLATE & 256)
-        more = false;              // ablation (timing only): per-face prologue up to the pixel range only
-#endif
         if (!__any(more)) continue;
         const Tri t = tri_from(s_a[kk], s_b[kk], make_float4(s_z2[kk], 0.f, 0.f, 0.f));
         const int fid = s_id[kk];
@@ -426,9 +438,6 @@ __device__ __forceinline__ void raster_tile(RasterSmem<MODE>& sm, unsigned vbloc
         while (__any(more)) {
           if (more) {
             const int xs = bx + lx, ys = by + ly;
-#if defined(RASTER_ABLATE) && (RASTER_ABLATE & 128)
-            if (xs == 123456)      // ablation (timing only): face prologue and block loop run, no pixel is tested
-#endif
             if (xs <= x1 && ys <= y1) {
               const float qx = sm.ndc_x[xs - tx0], qy = sm.ndc_y[ys - ty0];
               // (same predicate as !(qx > q.y || qx < q.x || qy > q.w || qy < q.z) for finite operands, as two median-of-three
@@ -469,9 +478,6 @@ __device__ __forceinline__ void raster_tile(RasterSmem<MODE>& sm, unsigned vbloc
         const int slot = block_compact(in_img && sm.sat[threadIdx.x] == 0, 0, lds_cnt, ncand);
         if (slot >= 0) sm.cand[slot] = (unsigned char)threadIdx.x;
         __syncthreads();
-#if defined(RASTER_ABLATE) && (RASTER_ABLATE & 512)
-        ncand = 0;                 // ablation (timing only): no soft-silhouette pair walk
-#endif
         if (ncand > 0) {
           unsigned short* wl = sm.pairs + w * 128;
           const int cper = (ncand + 3) >> 2, c_lo = min(ncand, w * cper), c_hi = min(ncand, (w + 1) * cper);
@@ -664,9 +670,6 @@ __device__ __forceinline__ void raster_tile(RasterSmem<MODE>& sm, unsigned vbloc
       // now queues the staged-face indices it needs (hard: 4 x 8 bit, soft: 8 x 8 bit) and the queues are drained per lane, in
       // ascending face order (same tie-break, same product order => bit-identical results), a handful of iterations per strip.
       unsigned long long m = __ballot(whit);
-#if defined(RASTER_ABLATE) && (RASTER_ABLATE & 1)
-      m = 0;                 // ablation (timing only, -DRASTER_ABLATE=1): no classification -> what staging, culls and epilogue cost
-#endif
       while (m) {
         const int j = g + __ffsll((unsigned long long)m) - 1;
         m &= m - 1;
@@ -688,9 +691,6 @@ __device__ __forceinline__ void raster_tile(RasterSmem<MODE>& sm, unsigned vbloc
         }
         const float e0s = e0 * sg, e1s = e1 * sg, e2s = e2 * sg;
         const bool inside = (e0s > 0.f) && (e1s > 0.f) && (e2s > 0.f);
-#if defined(RASTER_ABLATE) && (RASTER_ABLATE & 4)
-        if (px == 12345.f)     // ablation (timing only, -DRASTER_ABLATE=4): classification runs, nothing is ever queued -> no drains
-#endif
         if (MODE != 2 && inside && inbox) { hq |= (unsigned)j << (8 * hn); ++hn; }
         if (MODE >= 1) {
           bool soft = (MODE == 1) ? (inbox && prod != 0.f) : (inbox && need);
@@ -713,9 +713,6 @@ __device__ __forceinline__ void raster_tile(RasterSmem<MODE>& sm, unsigned vbloc
               const float Bf = blur * 1.00001f;
               if ((e0s < 0.f && e0 * e0 >= Bf * l12) || (e1s < 0.f && e1 * e1 >= Bf * l20) || (e2s < 0.f && e2 * e2 >= Bf * l01)) soft = false;
             }
-#if defined(RASTER_ABLATE) && (RASTER_ABLATE & 4)
-            if (px == 12345.f)
-#endif
             if (soft) { sq |= (unsigned long long)j << (8 * sn); ++sn; }
           }
         }
@@ -766,6 +763,162 @@ __device__ __forceinline__ void raster_tile(RasterSmem<MODE>& sm, unsigned vbloc
   if (MODE == 1 && l1_target) {
     const float sum = block_sum_256(l1_acc, sm.red);
     if (threadIdx.x == 0 && sum != 0.f) atomicAdd(l1_loss, sum * l1_inv);
+  }
+  if constexpr (MODE == 1 && BWD) {
+    // ---- FUSED SILHOUETTE BACKWARD (rasterize_meshes_backward, dists path + sigmoid_alpha_blend's backward; the stand-alone form is MODE 2).
+    //      The pixel's alpha is final, the fused L1 has just formed d loss / d alpha, and the tile's faces are still staged in LDS: the rim
+    //      pixels walk them again right here instead of in a second launch that re-reads alpha and the gradient image and stages the same
+    //      faces through the same list -> bbox -> record chain (~4 000 rim tiles per camera view: 50 us alone, 117 us beside the shader
+    //      backward, which it slowed by 30).  Same pairs, same arithmetic as MODE 2; the per-face sums are float instead of double.
+    //      A tile that needed more than one staging round (> 256 faces: dense, minified meshes) stages its rounds once more.
+    if (g_ndc != nullptr && l1_target != nullptr) {
+      float Pq = 0.f, gq = 0.f;
+      if (in_img) {
+        const float a = 1.0f - prod;
+        const float d = a - l1_target[((size_t)l1_fid[b] * S + yi) * S + xi];
+        Pq = 1.0f - a;                                   // (as the stand-alone pass forms it from the stored alpha)
+        gq = l1_w[0] * l1_inv * ((d > 0.f) - (d < 0.f));
+      }
+      const bool rim = in_img && (Pq != 0.f) && (Pq != 1.0f) && (gq != 0.f);
+      if (__syncthreads_or(rim ? 1 : 0) != 0) {
+        // the pixel's forward state is in registers: its LDS (min keys, saturation flags, running products) becomes the rim-pixel list
+        float* rp_x = reinterpret_cast<float*>(sm.zkey);
+        float* rp_y = rp_x + 256;
+        float* rp_P = reinterpret_cast<float*>(sm.sat);
+        float* rp_g = sm.prodl;
+        int npx;
+        const int slot = block_compact(rim, 0, lds_cnt, npx);
+        if (slot >= 0) { rp_x[slot] = px; rp_y[slot] = py; rp_P[slot] = Pq; rp_g[slot] = gq; }
+        auto bwd_round = [&](int nl) {
+#pragma unroll
+          for (int c = 0; c < 6; ++c) sm.s_gf[threadIdx.x][c] = 0.f;
+          __syncthreads();
+          const int npairs = npx * nl;
+          const float inv_nl = 1.0f / (float)nl;
+          unsigned short* wl = sm.pairs + w * 128;
+          const int per = (npairs + 3) >> 2, i_end = min(npairs, (w + 1) * per);
+          int head = 0, tail = 0;
+          auto process = [&](int nvalid) {
+            if (lane < nvalid) {
+              const int pr = wl[(head + lane) & 127], c = pr >> 8, j = pr & 255;
+              const float qx = rp_x[c], qy = rp_y[c], Pc = rp_P[c], gc = rp_g[c];
+              const Tri t = tri_from(s_a[j], s_b[j], make_float4(0.f, 0.f, 0.f, 0.f));
+              const float e0 = edge_fn(qx, qy, t.x1, t.y1, t.x2, t.y2);
+              const float e1 = edge_fn(qx, qy, t.x2, t.y2, t.x0, t.y0);
+              const float e2 = edge_fn(qx, qy, t.x0, t.y0, t.x1, t.y1);
+              const float area = edge_fn(t.x2, t.y2, t.x0, t.y0, t.x1, t.y1) + kEps;
+              const float sg = (area > 0.f) ? 1.f : ((area < 0.f) ? -1.f : 0.f);
+              const float e0s = e0 * sg, e1s = e1 * sg, e2s = e2 * sg;
+              const bool inside = (e0s > 0.f) && (e1s > 0.f) && (e2s > 0.f);
+              const float l12 = (t.x2 - t.x1) * (t.x2 - t.x1) + (t.y2 - t.y1) * (t.y2 - t.y1);
+              const float l20 = (t.x0 - t.x2) * (t.x0 - t.x2) + (t.y0 - t.y2) * (t.y0 - t.y2);
+              const float l01 = (t.x1 - t.x0) * (t.x1 - t.x0) + (t.y1 - t.y0) * (t.y1 - t.y0);
+              bool soft = true;
+              if (inside) {
+                const float K = 18.0f * sigma;               // saturated: the factor (1 - p) is exactly 0 and so is its gradient
+                if (e0 * e0 > K * l12 && e1 * e1 > K * l20 && e2 * e2 > K * l01) soft = false;
+              } else {
+                const float Bf = blur * 1.00001f;            // beyond the blur radius of a violated edge line
+                if ((e0s < 0.f && e0 * e0 >= Bf * l12) || (e1s < 0.f && e1 * e1 >= Bf * l20) || (e2s < 0.f && e2 * e2 >= Bf * l01)) soft = false;
+              }
+              if (soft) {
+                float ta, tb, tc;
+                const float d01 = seg_dist2(qx, qy, t.x0, t.y0, t.x1, t.y1, ta);
+                const float d02 = seg_dist2(qx, qy, t.x0, t.y0, t.x2, t.y2, tb);
+                const float d12 = seg_dist2(qx, qy, t.x1, t.y1, t.x2, t.y2, tc);
+                const float dist = fminf(d01, fminf(d02, d12));
+                if (inside || dist < blur) {
+                  const float sd = inside ? -dist : dist;
+                  const float p = __builtin_amdgcn_rcpf(1.0f + __expf(sd * inv_sigma));
+                  const float g_sd = gc * (-Pc * p * inv_sigma);          // d alpha / d sd = -P * p / sigma
+                  const float gd = inside ? -g_sd : g_sd;                 // d / d(dist^2)
+                  int ia, ib; float ax, ay, bx, by, tt;                   // PointLineDistanceBackward on the argmin edge (t treated as constant)
+                  if (d01 <= d02 && d01 <= d12) { ia = 0; ib = 1; ax = t.x0; ay = t.y0; bx = t.x1; by = t.y1; tt = ta; }
+                  else if (d02 <= d12)          { ia = 0; ib = 2; ax = t.x0; ay = t.y0; bx = t.x2; by = t.y2; tt = tb; }
+                  else                          { ia = 1; ib = 2; ax = t.x1; ay = t.y1; bx = t.x2; by = t.y2; tt = tc; }
+                  const float hx = ax + tt * (bx - ax), hy = ay + tt * (by - ay);
+                  const float cx = gd * 2.f * (hx - qx), cy = gd * 2.f * (hy - qy);
+                  lds_add_f32(&sm.s_gf[j][2 * ia], (1.f - tt) * cx);
+                  lds_add_f32(&sm.s_gf[j][2 * ia + 1], (1.f - tt) * cy);
+                  lds_add_f32(&sm.s_gf[j][2 * ib], tt * cx);
+                  lds_add_f32(&sm.s_gf[j][2 * ib + 1], tt * cy);
+                }
+              }
+            }
+          };
+          for (int i0 = w * per; i0 < i_end; i0 += 64) {
+            const int i = i0 + lane;
+            bool pass = false;
+            int c = 0, k = 0;
+            if (i < i_end) {
+              c = (int)(((float)i + 0.5f) * inv_nl);
+              k = i - c * nl;
+              if (k < 0) { --c; k += nl; } else if (k >= nl) { ++c; k -= nl; }
+              const float4 q = s_bb[k];
+              const float qx = rp_x[c], qy = rp_y[c];
+              pass = !(qx > q.y || qx < q.x || qy > q.w || qy < q.z);
+            }
+            const unsigned long long m = __ballot(pass);
+            if (pass) wl[(tail + __popcll(m & ((1ull << lane) - 1ull))) & 127] = (unsigned short)((c << 8) | k);
+            tail += __popcll(m);
+            if (tail - head >= 64) { process(64); head += 64; }
+          }
+          if (tail > head) process(tail - head);
+          __syncthreads();
+          if ((int)threadIdx.x < nl) {          // flush: one memory atomic per (staged face, vertex, component) with a gradient
+            const int fid = s_id[threadIdx.x];
+            float* gb = g_ndc + (size_t)b * V * 3;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+              const float gx = sm.s_gf[threadIdx.x][2 * k], gy = sm.s_gf[threadIdx.x][2 * k + 1];
+              if (gx != 0.f || gy != 0.f) {
+                const int v = faces[3 * fid + k];
+                atomicAdd(gb + 3 * v, gx);
+                atomicAdd(gb + 3 * v + 1, gy);
+              }
+            }
+          }
+        };
+        if (rounds == 1) {
+          bwd_round(last_nl);
+        } else {
+          // more than one round: stage the list again, round by round (same filter, same order as the forward loop above)
+          int st2 = 0, sk2 = 0;
+          for (int base = 0; base < n || st2 > 0;) {
+            bool flush = true;
+            __syncthreads();                    // the previous round's flush is done with the staged ids
+            if (base < n) {
+              const int e = base + threadIdx.x;
+              bool hit = false;
+              int id = 0;
+              float4 bb;
+              if (e < n) {
+                id = list[e];
+                bb = bbb[id];
+                hit = !(t_xlo > bb.y || t_xhi < bb.x || t_ylo > bb.w || t_yhi < bb.z);
+              }
+              int cnt;
+              const int posc = block_compact(hit, 0, lds_cnt, cnt);
+              const int rem = cnt - sk2, room = stage_cap<MODE>() - st2;
+              if (rem <= room) {
+                stage_write((posc >= sk2) ? st2 + posc - sk2 : -1, id, bb);
+                st2 += rem; sk2 = 0; base += kStage;
+                flush = base >= n;
+              } else if (st2 == 0) {
+                stage_write((posc >= sk2 && posc < sk2 + room) ? posc - sk2 : -1, id, bb);
+                st2 = room; sk2 += room;
+              }
+            }
+            if (!flush) continue;
+            const int nl2 = st2;
+            st2 = 0;
+            if (nl2 == 0) continue;
+            __syncthreads();
+            bwd_round(nl2);
+          }
+        }
+      }
+    }
   }
 }
 

@@ -746,7 +746,7 @@ struct SilBwdArgs {
 };
 union FusedSmem {
   ShadeSmem<false> sh;
-  rb::RasterSmem<2> rs;
+  rb::RasterSmem<2, false> rs;
   __device__ FusedSmem() {}
 };
 // (its own occupancy target: the rasteriser tiles it hosts want 168 VGPRs; under the shader's 4-waves-per-SIMD cap of 128 they would spill)

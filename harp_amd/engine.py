@@ -212,6 +212,7 @@ class FitEngine:
         self.trec_cap_min = 65536
         self._trec = self._tacc = None
         self._maps_pending = None
+        self.fused_sil_bwd = False       # the silhouette backward inside the camera-view raster launch (harp_rasterize_l1_fwd_bwd) instead of a launch of its own beside the shader backward.  Correct (tests) and measured SLOWER: the shader backward gains 32 us without its neighbour (230 -> 198 in the graph), the camera raster pays 56 (198 -> 254: 94 VGPRs / 26 KB of LDS = 5 waves per SIMD instead of 7, and the rim walk is ~25 us of VALU work wherever it runs): step 0.665 vs 0.638 ms (profiles/r06_ab_record.txt)
         self.lean_app_stage = False      # appearance-only stage without the geometry gradients nothing reads (set by optimize_hand_sequence; off by default: g_buf then holds what autograd would)
         self._lean_now = False
         self.sil_only_raster = True      # geometry-only steps without a kept image: the camera raster forms no nearest-face ids (harp_rasterize_l1_fwd with face_id == NULL)
@@ -565,6 +566,9 @@ class FitEngine:
         sched_early = self.early_terms
         extra = lambda name: self._extra_stream(name) if self.overlap else cur      # further graph branches (hipGraph replays four concurrently here)
         off = self.disabled_terms
+        marks = {}
+        # the silhouette backward inside the camera-view raster launch (its atomics into g_ndc_c need the slab clear in front of them)
+        fsb = bool(self.fused_sil_bwd and coarse and not (self.fused_bwd and app and self.perceptual is None))
         # ---- terms that depend on the parameters only (normal-map normalisation, texture regularisers, displacement regulariser) go
         #      first on the second stream: they run under the LBS / mesh chain, which is a string of small latency-bound launches
         deferred = []
@@ -592,6 +596,8 @@ class FitEngine:
                     self._adam_tick(coarse, app)             # only touches the hyper-parameter block: off the serial tail of the step
             if not self.consume_gzl:
                 self.gs_zero_late.zero_()
+            if fsb and fill_side and not one:
+                marks["zero"] = torch.cuda.current_stream().record_event()      # the slab clear ran on this (the second) stream
             disp_reg = coarse and shared_terms and "vert_disp_reg" not in off
             if app and shared_terms:
                 if draw and not pro:
@@ -654,7 +660,7 @@ class FitEngine:
         # ---- the light-view chain (centroid -> light camera -> projection -> K=1 raster) is independent of the camera-view chain:
         #      it runs on the second HIP stream so the two rasterisations overlap (fork / join is captured into the graph); the mesh
         #      regularisers and the key-point term follow it there (the light raster is the shorter of the two)
-        mesh_late = bool(self.mesh_terms_late and sched_early and self.overlap and coarse and app and not mesh_on_third and self.perceptual is None
+        mesh_late = bool(not fsb and self.mesh_terms_late and sched_early and self.overlap and coarse and app and not mesh_on_third and self.perceptual is None
                          and not (self.fused_bwd and coarse and app))
         def light_view(fork=None):
             if fork is None:
@@ -710,6 +716,13 @@ class FitEngine:
             sparse = 0 if (self.keep_image or self.perceptual is not None) else 2
             # (geometry-only stage in the loss-only image mode: nothing reads the camera view's face ids — silhouette only)
             face_c = p(s["face_c"]) if (app or self.keep_image or not self.sil_only_raster) else None
+            if fsb:
+                if marks.get("zero") is not None:
+                    wait_e(cur, marks["zero"])
+                self._ck(L.harp_rasterize_l1_fwd_bwd(p(s["ndc_c"]), p(tp.faces), B, V, F, S, 1 | sparse | pre, ops.SIL_BLUR, ops.SIL_SIGMA, p(s["ws_c"]), face_c,
+                                                     p(s["alpha"]), p(self.y_sil), p(ltfid), wp(0), lp(0), p(s["g_alpha"]), p(self.bg_sil) if sparse else None,
+                                                     p(s["g_ndc_c"]), ST()), "raster_cam_fwd_bwd")
+                return
             self._ck(L.harp_rasterize_l1_fwd(p(s["ndc_c"]), p(tp.faces), B, V, F, S, 1 | sparse | pre, ops.SIL_BLUR, ops.SIL_SIGMA, p(s["ws_c"]), face_c,
                                              None, p(s["alpha"]), p(self.y_sil) if coarse else None, p(ltfid), wp(0), lp(0), p(s["g_alpha"]),
                                              p(self.bg_sil) if sparse else None, ST()),
@@ -738,7 +751,6 @@ class FitEngine:
         fuse_bwd = self.fused_bwd and coarse and app and self.perceptual is None
         side_used = False
         sil_after = None
-        marks = {}
         def launch_sil(ev=None):
             # the silhouette backward only needs g_alpha and the camera-view workspace: it overlaps with shading on the side stream
             if ev is None:
@@ -751,7 +763,7 @@ class FitEngine:
                 if mesh_late:
                     mesh_terms()                # `mesh_terms_late`: beside the (latency-bound) shader backward instead of beside the (VALU-bound) rasterisers
                 marks["sil"] = None if one else side.record_event()
-        if coarse and not fuse_bwd:
+        if coarse and not fuse_bwd and not fsb:
             if not app and self.overlap:
                 # geometry-only stage: there is no shader backward to run next to — the silhouette backward stays on the critical stream
                 # (two cross-stream edges, ~6 us each, off the step)
@@ -1206,7 +1218,7 @@ class FitEngine:
         # every switch the enqueued launch sequence depends on is part of the key: flipping one re-captures instead of replaying a
         # graph recorded for another configuration
         gkey = (coarse, app, scheduled, n, self.keep_image, self.fused_loss, self.self_shadow, tuple(self.frozen), self.overlap, self.early_terms,
-                self.packed_texels, self.fused_keep, self.mesh_third, self.graph_order, fold, self.fused_terms, self.zl_tile_flags, self.accumulate_loss, self.lean_app_stage, self.sil_only_raster, self.auto_draw, self.mesh_terms_late, self.sil_late, self.paired_setup, self.late_texture_terms, self.mesh_terms_first, self.camera_first, self.tail_side, self.fused_bwd, self.fused_chain, self.fused_front, self.wide_front, self.hybrid_front, self.front_auto, self.wide_back, self.fused_back, self.consume_gzl, self.keep_depth, self.texel_records, dist_on, self.overlap_allreduce,
+                self.packed_texels, self.fused_keep, self.mesh_third, self.graph_order, fold, self.fused_terms, self.zl_tile_flags, self.accumulate_loss, self.lean_app_stage, self.sil_only_raster, self.auto_draw, self.mesh_terms_late, self.sil_late, self.paired_setup, self.late_texture_terms, self.mesh_terms_first, self.camera_first, self.tail_side, self.fused_bwd, self.fused_chain, self.fused_front, self.wide_front, self.hybrid_front, self.front_auto, self.wide_back, self.fused_back, self.consume_gzl, self.keep_depth, self.texel_records, self.fused_sil_bwd, dist_on, self.overlap_allreduce,
                 self.comm is not None, self.perceptual is not None and app)
         g = self._graphs.get(gkey)
         if g is None:

@@ -60,6 +60,13 @@ int harp_rasterize_l1_fwd(const float* ndc, const int32_t* faces, int B, int V, 
                           float sigma, void* ws, int32_t* face_id, float* zbuf, float* alpha, const float* l1_target,
                           const int32_t* l1_fid, const float* l1_w, float* l1_loss, float* l1_grad, const float* l1_bg_sums,
                           hipStream_t stream);
+/* harp_rasterize_l1_fwd (soft & 1, y_sil != NULL) with the silhouette backward fused into the SAME launch (renderer_helper.py:44-58 forward,
+ * rasterize_meshes_backward's dists path + sigmoid_alpha_blend's backward): g_ndc (B,V,3) += d (w * L1(alpha, y_sil)) / d ndc, x and y
+ * components — what harp_silhouette_bwd(alpha, g_alpha) of the same workspace would add.  A tile's rim pixels walk the tile's faces again
+ * while these are still staged in LDS; no second launch re-reads alpha / g_alpha and re-stages the lists.  alpha and g_alpha are still written. */
+int harp_rasterize_l1_fwd_bwd(const float* ndc, const int32_t* faces, int B, int V, int F, int S, int soft, float blur_radius, float sigma,
+                              void* ws, int32_t* face_id, float* alpha, const float* y_sil, const int32_t* fid, const float* w, float* loss,
+                              float* g_alpha, const float* bg_sums, float* g_ndc, hipStream_t stream);
 /* replaces _C.rasterize_meshes_backward (grad_dists path) + sigmoid_alpha_blend backward; g_ndc (B,V,3) (+=) */
 int harp_silhouette_bwd(const int32_t* faces, int B, int V, int F, int S, float blur_radius, float sigma, const void* ws,
                         const float* alpha, const float* g_alpha, float* g_ndc, hipStream_t stream);

@@ -1243,7 +1243,10 @@ def test_light_camera_incl_look_at_replacement_branch():
                                       dict(mesh_terms_late=True, graph_order=False), dict(mesh_terms_late=True, sil_late=True),
                                       dict(paired_setup=True, keep_depth=False),
                                       # round 6: texel gradients as records + harp_texel_reduce on a branch of its own (default) vs the in-kernel table form
-                                      dict(texel_records=False), dict(texel_records=False, tail_side=True), dict(texel_records=False, fused_terms=False), dict(tail_side=True, fused_terms=False)])
+                                      dict(texel_records=False), dict(texel_records=False, tail_side=True), dict(texel_records=False, fused_terms=False), dict(tail_side=True, fused_terms=False),
+                                      # ... and the silhouette backward inside the camera-view raster launch (harp_rasterize_l1_fwd_bwd) vs the stand-alone launch beside the shader backward (default)
+                                      dict(fused_sil_bwd=True), dict(fused_sil_bwd=True, texel_records=False), dict(fused_sil_bwd=True, graph_order=False), dict(fused_sil_bwd=True, overlap=False),
+                                      dict(fused_sil_bwd=True, fold_step=False), dict(fused_sil_bwd=True, mesh_third=True)])
 def test_schedule_switches_give_the_default_schedules_result(switches):
     """The stream / capture-order switches of FitEngine (graph_order, mesh_third, camera_first, overlap, early_terms, mesh_terms_first,
     tail_side) only move launches between streams: losses and the whole gradient arena of every non-default combination must equal the
@@ -1462,19 +1465,26 @@ def test_light_view_tile_flags_cover_the_shadow_map_gradient():
     eng.set_stage(True, True)
     L = _lib.lib()
     seen = {}
-    orig = L.harp_depth_nmap_bwd
+    # (the depth backward of the step: with the normal map's chain rule riding along in the table form of the shader backward, on its own
+    #  when the texel gradients leave as records)
+    names = ("harp_depth_nmap_bwd", "harp_depth_bwd_tiles")
+    orig = {n: getattr(L, n) for n in names}
 
-    def spy(*a):
-        torch.cuda.synchronize()
-        seen["g"], seen["t"] = eng.s["g_zl"].clone(), eng.s["zl_tiles"].clone()
-        return orig(*a)
-    L.harp_depth_nmap_bwd = spy
+    def spy(name):
+        def f(*a):
+            torch.cuda.synchronize()
+            seen["g"], seen["t"] = eng.s["g_zl"].clone(), eng.s["zl_tiles"].clone()
+            return orig[name](*a)
+        return f
+    for n in names:
+        setattr(L, n, spy(n))
     try:
         eng.fid.copy_(torch.arange(3, dtype=torch.int32)); eng.tfid.copy_(torch.arange(3, dtype=torch.int32))
         eng.forward_backward(True, True)
         torch.cuda.synchronize()
     finally:
-        L.harp_depth_nmap_bwd = orig
+        for n in names:
+            setattr(L, n, orig[n])
     S, nt = 128, 8
     nz = (seen["g"].view(3, nt, 16, nt, 16) != 0).any(dim=4).any(dim=2)
     fl = seen["t"].view(3, nt, nt) != 0
@@ -1878,3 +1888,55 @@ def test_texture_terms_by_tile_owners_edge_cases():
             assert a.abs().max().item() > 0 and rel(b.double(), a.double()) < 2e-6, (H, W, rel(b.double(), a.double()))
             # (sums of +-k: the two forms may differ in the order of a few float additions only)
             assert (a - b).abs().max().item() <= 4e-7 * a.abs().max().item(), (H, W)
+
+
+@pytest.mark.parametrize("shrink,loop", [(1.0, 0), (0.25, 0), (0.1, 0), (1.0, 16)])
+def test_silhouette_backward_fused_into_the_raster_launch(sc, shrink, loop, monkeypatch):
+    """harp_rasterize_l1_fwd_bwd (the camera-view raster with every tile's silhouette backward fused in: the rim pixels walk the tile's
+    faces while these are still staged in LDS) against harp_rasterize_l1_fwd + harp_silhouette_bwd on the same workspace: same alpha, loss
+    and gradient image, same d loss / d ndc up to the order of float sums (the fused form accumulates a face's sums in float, the
+    stand-alone one in double).  shrink < 1: the whole hand in a handful of tiles — hundreds to thousands of faces per tile against 256
+    staging slots, i.e. the tiles that stage their rounds a second time for the backward; loop: the striding grid."""
+    from harp_amd import _lib, ops
+    from oracle import harp_ref as H, p3d_like as P
+    if loop:
+        monkeypatch.setenv("HARP_RASTER_LOOP", str(loop))
+    S, focal, topo = 128, sc["focal"] * shrink, sc["topo"]
+    params = dict(pose=sc["seq"]["pose"], rot=sc["seq"]["rot"], trans=sc["seq"]["trans"], shape=sc["seq"]["shape"].mean(0),
+                  verts_disps=torch.zeros(3093, 1))
+    fid = torch.arange(3)
+    with torch.no_grad():
+        _, v = H.prepare_mesh(params, fid, sc["model"], topo)
+        R, T = H.camera_RT(sc["seq"]["cam"][fid], S, sc["focal"])
+        _, ndc = P.world_to_ndc(v, R, T, focal, (S / 2, S / 2), S)
+    B, V, F = 3, ndc.shape[1], topo["faces"].shape[0]
+    ndc_d, faces_d = ndc.float().to(DEV).contiguous(), topo["faces"].int().to(DEV).contiguous()
+    g = torch.Generator().manual_seed(5)
+    y_sil = (torch.rand(4, S, S, generator=g) > 0.5).float().to(DEV)
+    rows = torch.tensor([2, 0, 3], dtype=torch.int32, device=DEV)
+    w = torch.tensor([7.0], device=DEV)
+    L, p, st = _lib.lib(), _lib.ptr, _lib.stream
+    out = {}
+    for fused in (False, True):
+        ws = ops.rasterize_workspace(B, F, S, DEV)
+        face_id = torch.full((B, S, S), -7, dtype=torch.int32, device=DEV)
+        alpha, g_alpha = torch.zeros(B, S, S, device=DEV), torch.zeros(B, S, S, device=DEV)
+        loss, g_ndc = torch.zeros(1, device=DEV), torch.zeros(B, V, 3, device=DEV)
+        if fused:
+            _lib.check(L.harp_rasterize_l1_fwd_bwd(p(ndc_d), p(faces_d), B, V, F, S, 1, ops.SIL_BLUR, ops.SIL_SIGMA, p(ws), p(face_id), p(alpha), p(y_sil), p(rows),
+                                                   p(w), p(loss), p(g_alpha), None, p(g_ndc), st()), "fwd_bwd")
+        else:
+            _lib.check(L.harp_rasterize_l1_fwd(p(ndc_d), p(faces_d), B, V, F, S, 1, ops.SIL_BLUR, ops.SIL_SIGMA, p(ws), p(face_id), None, p(alpha), p(y_sil), p(rows),
+                                               p(w), p(loss), p(g_alpha), None, st()), "fwd")
+            _lib.check(L.harp_silhouette_bwd(p(faces_d), B, V, F, S, ops.SIL_BLUR, ops.SIL_SIGMA, p(ws), p(alpha), p(g_alpha), p(g_ndc), st()), "bwd")
+        torch.cuda.synchronize()
+        out[fused] = (face_id, alpha, g_alpha, loss, g_ndc)
+    for k in range(3):
+        assert torch.equal(out[True][k], out[False][k]), k
+    assert abs(out[True][3].item() - out[False][3].item()) <= 1e-6 * abs(out[False][3].item())
+    ga, gb = out[True][4].double(), out[False][4].double()
+    assert gb.abs().max() > 0 and (ga[..., 2] == 0).all()
+    assert rel(ga, gb) < 2e-6, rel(ga, gb)
+    if shrink < 1.0:
+        tiles = ((out[False][0] >= 0).view(B, S // 16, 16, S // 16, 16).sum((2, 4)) > 0).sum().item()
+        assert B * F / tiles > 256                                   # really more faces per tile than one staging round holds
