@@ -119,7 +119,8 @@ def kernel_roofline(eng, steps, overlap=False):
     L = _lib.lib()
     # (the fitting loop calls the light-view pass and its backward through the variants that keep their images across steps)
     alias = {"harp_rasterize_fwd_keep": "raster_light", "harp_depth_bwd_consume": "harp_depth_bwd", "harp_depth_nmap_bwd": "harp_depth_bwd", "harp_depth_bwd_tiles": "harp_depth_bwd"}
-    names = ["harp_rasterize_fwd", "harp_rasterize_l1_fwd", "harp_shade_fwd", "harp_shade_bwd", "harp_silhouette_bwd", "harp_depth_bwd"] + list(alias)
+    alias.update({"harp_texel_finish": "harp_texel_reduce"})        # (reduce + finish: the second half of the shader backward's texel gradients)
+    names = ["harp_rasterize_fwd", "harp_rasterize_l1_fwd", "harp_shade_fwd", "harp_shade_bwd", "harp_silhouette_bwd", "harp_depth_bwd", "harp_texel_reduce"] + list(alias)
     rec = {n: [] for n in names}
     orig = {}
 
@@ -155,6 +156,8 @@ def kernel_roofline(eng, steps, overlap=False):
     for n in names[2:6]:
         if ms.get(n):
             out[n] = float(np.mean(ms[n]))
+    if ms.get("harp_texel_reduce"):                # two calls per step (reduce, finish): their sum
+        out["harp_texel_reduce"] = float(np.sum(ms["harp_texel_reduce"])) / steps
     return out
 
 
@@ -163,7 +166,8 @@ def kernel_roofline(eng, steps, overlap=False):
 _GROUP_KERNELS = {"raster_cam_fwd(setup+bin+raster)": ("raster_kernel<1,", "face_setup_kernel", "bin_faces_kernel", "expand_bits_kernel", "order_tiles_kernel"),
                   "raster_light_fwd(setup+bin+raster)": ("raster_kernel<0,", "face_setup_kernel", "bin_faces_kernel", "expand_bits_kernel", "order_tiles_kernel"),
                   "harp_shade_fwd": ("shade_kernel<false>",), "harp_shade_bwd": ("shade_bwd_wave_kernel",),
-                  "harp_silhouette_bwd": ("raster_kernel<2,",), "harp_depth_bwd": ("depth_bwd_kernel",)}
+                  "harp_silhouette_bwd": ("raster_kernel<2,",), "harp_depth_bwd": ("depth_bwd_kernel",),
+                  "harp_texel_reduce": ("texel_reduce_kernel", "texel_finish_kernel", "texel_counters_clear_kernel")}
 
 
 def _child(cmd_tail, prof_args, out_dir, timeout=240):
@@ -339,7 +343,35 @@ def extra_rates(eng, device, steps=100, warmup=30, vgg_weights="random"):
     torch.cuda.empty_cache()
     if vgg_weights is not None:
         out["C3_with_perceptual_term"] = perceptual_rate(device, vgg_weights)
+    out["C3_one_rank_allreduce_in_graph"] = one_rank_allreduce_cost(eng, steps, warmup)
     return out
+
+
+def one_rank_allreduce_cost(eng, steps, warmup):
+    """What the N > 1 step adds to the single-GPU step BEFORE any wire time: the headline engine on a 1-rank RCCL communicator — the two
+    captured harp_allreduce_flat nodes (map gradients early on the communication stream, the remainder in front of Adam), their fork / join
+    edges, and the engine in its N > 1 configuration (table form of the shader backward: the map gradients are final ~60 us earlier).
+    DESIGN.md 5 builds its 2 / 4 / 8-GPU expectation on this figure."""
+    try:
+        from harp_amd.dist import RcclComm
+        base = _graph_rate(eng, steps, warmup)
+        keep = (eng.texel_records, eng.force_allreduce)
+        eng.texel_records = False
+        table = _graph_rate(eng, steps, warmup)
+        comm = RcclComm(0, 1, RcclComm.unique_id())
+        eng.force_allreduce = True
+        eng.set_comm(comm)
+        with_comm = _graph_rate(eng, steps, warmup)
+        torch.cuda.synchronize()
+        eng.set_comm(None)
+        comm.destroy()
+        eng.texel_records, eng.force_allreduce = keep
+        eng._graphs = {}
+        return {"ms_per_step_single_gpu_default": base["ms_per_step"], "ms_per_step_table_form_no_collective": table["ms_per_step"],
+                "ms_per_step_with_two_captured_1rank_allreduce_nodes": with_comm["ms_per_step"],
+                "added_us": (with_comm["ms_per_step"] - table["ms_per_step"]) * 1e3, "bucket_bytes": int(eng.opt_span[1]) * 4, "steps": steps}
+    except Exception as e:                                       # noqa: BLE001  (no RCCL on this box: the figure is reported as missing, not guessed)
+        return {"error": f"{type(e).__name__}: {e}"}
 
 
 # VGG16 features[0:23] at 512x512: 3x3 convolutions (Cin, Cout, H) -> 2 * 9 * Cin * Cout * H * H flop each
@@ -687,6 +719,12 @@ def main():
                "harp_shade_bwd": (parts["geom"] + parts["V"] * 36 + S2 * (4 + (12 + 4 if fused else 12) + 4 + 4)) * eng.B + 2 * eng.Ht * eng.Wt * 12,
                "harp_silhouette_bwd": (geom_pos + S2 * 8 + parts["V"] * 12) * eng.B,
                "harp_depth_bwd": (geom_pos + S2 * 8 + parts["V"] * 12) * eng.B}
+        if "harp_texel_reduce" in kt:
+            # the texel records written by the shader backward and read back once (36 B per shaded pixel) + both maps' double accumulators
+            # (read + cleared) and gradient images (read + written) in the finish pass
+            shaded = int(((eng.s["face_c"][:eng.B] >= 0) & (eng.y_sil_col[eng.tfid[:eng.B].long()] != 0)).sum().item())
+            alg["harp_texel_reduce"] = shaded * 36 + 2 * eng.Ht * eng.Wt * 3 * (8 + 4 + 4)
+            alg["harp_shade_bwd"] += shaded * 36 - 2 * eng.Ht * eng.Wt * 12          # (it writes the records instead of the two gradient maps)
         # ... and the bytes the FUSED rasteriser kernels really have to move (barycentrics / distances are never materialised): their
         # `frac` is against THIS figure; the one against §8(d)'s formula is kept as `frac_survey_8d`
         moved = {"raster_cam_fwd(setup+bin+raster)": (geom_pos + S2 * (4 + 4) + S2 * (4 + 4)) * eng.B,     # face id + alpha out; mask in, g_alpha out
@@ -733,7 +771,9 @@ def main():
                     per_kernel[k]["valu_wave_instructions"] = wi
                     per_kernel[k]["issue_frac"] = wi * VALU_ISSUE_CYCLES / (SIMDS * CLOCK_HZ * timing[k] * 1e-3)
         if "harp_shade_bwd" in per_kernel:
-            n_at = 17.0e6 * eng.B / 32.0
+            # (table form: 11.8 M texel + 4 M vertex + 2.3 M shadow-window atomics per B = 32 launch; with texel records the texel part leaves
+            #  the kernel: harp_texel_reduce adds ~1.5 M double atomics of its own)
+            n_at = (6.3e6 if "harp_texel_reduce" in kt else 17.0e6) * eng.B / 32.0
             per_kernel["harp_shade_bwd"]["memory_atomics_model"] = n_at
             per_kernel["harp_shade_bwd"]["atomic_frac"] = n_at / ATOMIC_RATE / (timing["harp_shade_bwd"] * 1e-3)
         step_s = dt / args.steps

@@ -461,7 +461,6 @@ struct TexTerms {
   float *g_tex, *g_nmap, *g_disp;
   int nb_smooth, nb_disp;
   int* bump;                           // optional: the draw counter the offsets were drawn for (advanced here: the offsets are consumed)
-  int dbg;                             // HARP_TT_DBG (timing experiments only, results WRONG): 1 no smoothness tiles, 2 no close-to-z rows
 };
 __global__ void __launch_bounds__(256) texture_terms_kernel(const TexTerms A) {
   __shared__ SmoothTileSmem tile;
@@ -469,12 +468,10 @@ __global__ void __launch_bounds__(256) texture_terms_kernel(const TexTerms A) {
   float* red = tile.red;
   int bid = blockIdx.x;
   if (A.bump && bid == 0 && threadIdx.x == 0) A.bump[0] += 1;      // (harp_step_prologue, an earlier launch, drew with the old value)
-  if (bid < 2 * A.nb_smooth && (A.dbg & 1)) return;
   if (bid < A.nb_smooth) { tex_smooth_tile_body(bid, A.tex, A.dist_a, A.mask, A.H, A.W, A.w_a, A.l_a, A.g_tex, tile); return; }
   bid -= A.nb_smooth;
   if (bid < A.nb_smooth) { tex_smooth_tile_body(bid, A.nmap, A.dist_n, A.mask, A.H, A.W, A.w_n, A.l_n, A.g_nmap, tile); return; }
   bid -= A.nb_smooth;
-  if (bid < A.H && (A.dbg & 2)) return;
   if (bid < A.H) { close_to_z_body<true>(bid, A.nmap, A.H, A.W, A.w_n, A.z_scale, A.l_n, A.g_nmap, red, s_norm); return; }
   bid -= A.H;
   if (A.disp) sumsq_body(bid, A.nb_disp, A.disp, A.n_disp, A.w_d, A.l_d, A.g_disp, red);
@@ -749,8 +746,6 @@ int harp_texture_terms(const float* tex, const float* nmap, const float* mask, c
   A.g_tex = g_tex; A.g_nmap = g_nmap; A.g_disp = g_disp; A.bump = draw_counter_bump;
   A.nb_smooth = ((H + kST - 1) / kST) * ((W + kST - 1) / kST);          // one workgroup per 32x32-texel tile and map
   A.nb_disp = disp ? min((n_disp + 255) / 256, 64) : 0;
-  static const int dbg = [] { const char* e = getenv("HARP_TT_DBG"); return e ? atoi(e) : 0; }();
-  A.dbg = dbg;
   // ONE workgroup per CU (100 KB of dynamic LDS the kernel does not use; HARP_TEXTERMS_LDS=<bytes> overrides, 0 = none): the kernel is bound
   // by its ~5 M scattered memory-side atomics, which four waves per CU keep as busy as thirty-two do (34 -> 37 us) — but with every CU full
   // of its waves the frames' latency chain that runs next to it (hand_front) took 75 us instead of 57: step -13 us, same-box A/B x4.

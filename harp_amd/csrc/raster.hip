@@ -160,7 +160,7 @@ __global__ void __launch_bounds__(1024) order_tiles_pair_kernel(const RasterWs a
 constexpr unsigned kRasterGrid = 16384;
 
 template <int MODE, bool LOOP, bool BWD = false>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == 2 ? RASTER_OCC2 : (MODE == 0 ? RASTER_OCC0 : RASTER_OCC1), 8))) raster_kernel(const FaceRec* __restrict__ recs, const float4* __restrict__ bbs,
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == 2 ? RASTER_OCC2 : (MODE == 0 ? RASTER_OCC0 : (BWD ? 5 : RASTER_OCC1)), 8))) raster_kernel(const FaceRec* __restrict__ recs, const float4* __restrict__ bbs,
                                                      const int32_t* __restrict__ bins,
                                                      const int32_t* __restrict__ bin_count, const int32_t* __restrict__ order,
                                                      const int32_t* __restrict__ nact, int B, int F, int S, int nsx,

@@ -76,11 +76,6 @@ struct RasterSmem {
   static constexpr int kCap = stage_cap<MODE>();
   float4 s_a[kCap], s_b[kCap], s_bb[kCap];
   float s_z2[MODE == 2 ? 1 : kCap];
-#ifndef RASTER_NO_SCAN
-  float4 s_fc[1];
-#else
-  float4 s_fc[MODE == 1 ? kStage : 1];      // (strip walk) per staged face: sign of the area, squared edge lengths l12, l20, l01
-#endif
   int32_t s_id[kCap];
   int lds_cnt[4];
   unsigned long long zkey[MODE <= 1 ? 256 : 1];   // face-scan walk (MODE 0 / 1): per pixel min over (depth bits << 32 | face id)
@@ -129,7 +124,7 @@ __device__ __forceinline__ void raster_tile(RasterSmem<MODE, BWD>& sm, unsigned 
                                                      const int32_t* __restrict__ l1_fid, const float* __restrict__ l1_w,
                                                      float* __restrict__ l1_loss, float* __restrict__ l1_grad, float l1_inv, int sparse,
                                                      const float* __restrict__ l1_bg_sums, int32_t* __restrict__ st_state = nullptr) {
-  auto& s_a = sm.s_a; auto& s_b = sm.s_b; auto& s_bb = sm.s_bb; auto& s_z2 = sm.s_z2; auto& s_fc = sm.s_fc; auto& s_id = sm.s_id;
+  auto& s_a = sm.s_a; auto& s_b = sm.s_b; auto& s_bb = sm.s_bb; auto& s_z2 = sm.s_z2; auto& s_id = sm.s_id;
   auto& s_g = sm.s_g;
   int* lds_cnt = sm.lds_cnt;
 
@@ -201,9 +196,7 @@ __device__ __forceinline__ void raster_tile(RasterSmem<MODE, BWD>& sm, unsigned 
   // tile and wave-strip bounds in NDC (conservative supersets of the per-pixel bbox test)
   const float t_xhi = pix_to_ndc(tx0, S), t_xlo = pix_to_ndc(min(tx0 + kTile, S) - 1, S);
   const float t_yhi = pix_to_ndc(ty0, S), t_ylo = pix_to_ndc(min(ty0 + kTile, S) - 1, S);
-  const float w_yhi = pix_to_ndc(ty0 + w * 4, S), w_ylo = pix_to_ndc(ty0 + w * 4 + 3, S);
 
-  const float strip_r = (MODE == 0) ? 0.f : sqrtf(blur);
   float best_z = 3.0e38f;
   int best_f = -1;
   float prod = 1.0f;
@@ -223,11 +216,7 @@ __device__ __forceinline__ void raster_tile(RasterSmem<MODE, BWD>& sm, unsigned 
     // whole tile saturated / no upstream gradient -> nothing to do
     if (__syncthreads_or(need ? 1 : 0) == 0) return;
   }
-#ifndef RASTER_NO_SCAN
   constexpr bool kPix = (MODE == 2);
-#else
-  constexpr bool kPix = false;
-#endif
   int npx = 0;
   if constexpr (kPix) {
     const int slot = block_compact(need, 0, lds_cnt, npx);
@@ -235,81 +224,7 @@ __device__ __forceinline__ void raster_tile(RasterSmem<MODE, BWD>& sm, unsigned 
   }
 
   const float inv_sigma = 1.0f / sigma;
-  unsigned hq = 0u;
-  unsigned long long sq = 0ull;
-  int hn = 0, sn = 0;
-  // ---- phase 2: every lane pops its own queued faces (LDS gathers with per-lane addresses)
-  auto drain = [&]() {
-    if (MODE != 2) {
-      while (__any(hn > 0)) {
-        if (hn > 0) {
-          const int j = (int)(hq & 0xffu);
-          hq >>= 8; --hn;
-          const Tri t = tri_from(s_a[j], s_b[j], make_float4(s_z2[j], 0.f, 0.f, 0.f));
-          const float e0 = edge_fn(px, py, t.x1, t.y1, t.x2, t.y2);
-          const float e1 = edge_fn(px, py, t.x2, t.y2, t.x0, t.y0);
-          const float e2 = edge_fn(px, py, t.x0, t.y0, t.x1, t.y1);
-          const float area = edge_fn(t.x2, t.y2, t.x0, t.y0, t.x1, t.y1) + kEps;
-          // BarycentricCoordsForward + PerspectiveCorrection with reciprocals (<= 2 ulp from the IEEE-division form)
-          const float ra = __builtin_amdgcn_rcpf(area);
-          const float t0 = (e0 * ra) * t.z1 * t.z2, t1 = t.z0 * (e1 * ra) * t.z2, t2 = t.z0 * t.z1 * (e2 * ra);
-          const float rd = __builtin_amdgcn_rcpf(fmaxf(t0 + t1 + t2, kEps));
-          const float pz = (t0 * rd) * t.z0 + (t1 * rd) * t.z1 + (t2 * rd) * t.z2;
-          if (pz >= 0.f && pz < best_z) { best_z = pz; best_f = s_id[j]; }
-        }
-      }
-    }
-    if (MODE >= 1) {
-      while (__any(sn > 0)) {
-        if (sn > 0) {
-          const int j = (int)(sq & 0xffull);
-          sq >>= 8; --sn;
-          if (MODE == 2 || prod != 0.f) {
-            const Tri t = tri_from(s_a[j], s_b[j], make_float4(0.f, 0.f, 0.f, 0.f));
-            const float e0 = edge_fn(px, py, t.x1, t.y1, t.x2, t.y2);
-            const float e1 = edge_fn(px, py, t.x2, t.y2, t.x0, t.y0);
-            const float e2 = edge_fn(px, py, t.x0, t.y0, t.x1, t.y1);
-            const float area = edge_fn(t.x2, t.y2, t.x0, t.y0, t.x1, t.y1) + kEps;
-            const float sg = (area > 0.f) ? 1.f : ((area < 0.f) ? -1.f : 0.f);
-            const bool inside = (e0 * sg > 0.f) && (e1 * sg > 0.f) && (e2 * sg > 0.f);
-            float ta, tb, tc;
-            const float d01 = seg_dist2(px, py, t.x0, t.y0, t.x1, t.y1, ta);
-            const float d02 = seg_dist2(px, py, t.x0, t.y0, t.x2, t.y2, tb);
-            const float d12 = seg_dist2(px, py, t.x1, t.y1, t.x2, t.y2, tc);
-            const float dist = fminf(d01, fminf(d02, d12));
-            if (inside || dist < blur) {
-              const float sd = inside ? -dist : dist;
-              const float p = __builtin_amdgcn_rcpf(1.0f + __expf(sd * inv_sigma));   // sigmoid(-sd/sigma): fast exp + reciprocal (rel. error ~1e-6 at |x| ~ 18; image tolerance 1e-4)
-              if (MODE == 1) {
-                prod *= (1.0f - p);
-              } else {
-                // d alpha / d sd = -P * p / sigma  (P = prod over all faces)
-                const float g_sd = ga * (-P * p * inv_sigma);
-                const float gd = inside ? -g_sd : g_sd;     // d/d(dist^2)
-                // PointLineDistanceBackward on the argmin edge (t treated as constant)
-                int ia, ib; float ax, ay, bx, by, tt;
-                if (d01 <= d02 && d01 <= d12) { ia = 0; ib = 1; ax = t.x0; ay = t.y0; bx = t.x1; by = t.y1; tt = ta; }
-                else if (d02 <= d12)          { ia = 0; ib = 2; ax = t.x0; ay = t.y0; bx = t.x2; by = t.y2; tt = tb; }
-                else                          { ia = 1; ib = 2; ax = t.x1; ay = t.y1; bx = t.x2; by = t.y2; tt = tc; }
-                const float qx = ax + tt * (bx - ax), qy = ay + tt * (by - ay);
-                const float cx = gd * 2.f * (qx - px), cy = gd * 2.f * (qy - py);
-                atomicAdd(&s_g[j][2 * ia], (double)((1.f - tt) * cx));
-                atomicAdd(&s_g[j][2 * ia + 1], (double)((1.f - tt) * cy));
-                atomicAdd(&s_g[j][2 * ib], (double)(tt * cx));
-                atomicAdd(&s_g[j][2 * ib + 1], (double)(tt * cy));
-              }
-            }
-          }
-        }
-      }
-    }
-  };
-
-#ifndef RASTER_NO_SCAN
   constexpr bool kScan = (MODE <= 1);
-#else
-  constexpr bool kScan = false;
-#endif
   if (kScan) {                                  // (the first barrier of the staging below orders these before their first use)
     sm.zkey[threadIdx.x] = ~0ull;
     if (MODE == 1) { sm.sat[threadIdx.x] = 0; sm.prodl[threadIdx.x] = 1.0f; }
@@ -321,15 +236,6 @@ __device__ __forceinline__ void raster_tile(RasterSmem<MODE, BWD>& sm, unsigned 
       const FaceRec r = rb[id];
       s_a[pos] = r.a; s_b[pos] = r.b; s_bb[pos] = bb; s_id[pos] = id;
       if (MODE != 2) s_z2[pos] = r.c.x;
-      if (MODE == 1 && !kScan) {
-        // constants of the face that every (face, strip) classification below used to recompute on all 64 lanes
-        const Tri t = tri_from(r.a, r.b, make_float4(0.f, 0.f, 0.f, 0.f));
-        const float area = edge_fn(t.x2, t.y2, t.x0, t.y0, t.x1, t.y1) + kEps;
-        s_fc[pos] = make_float4((area > 0.f) ? 1.f : ((area < 0.f) ? -1.f : 0.f),
-                                (t.x2 - t.x1) * (t.x2 - t.x1) + (t.y2 - t.y1) * (t.y2 - t.y1),
-                                (t.x0 - t.x2) * (t.x0 - t.x2) + (t.y0 - t.y2) * (t.y0 - t.y2),
-                                (t.x1 - t.x0) * (t.x1 - t.x0) + (t.y1 - t.y0) * (t.y1 - t.y0));
-      }
     }
   };
   // The super-tile's list is filtered against this 16x16 tile 256 entries at a time and the hits ACCUMULATE in the staging arrays:
@@ -637,89 +543,7 @@ __device__ __forceinline__ void raster_tile(RasterSmem<MODE, BWD>& sm, unsigned 
         if (tail - head >= 64) { process(64); head += 64; }
       }
       if (tail > head) process(tail - head);
-    } else
-    // ---- walk: each wave ballots the staged faces against its 16x4 strip
-    for (int g = 0; g < nl; g += 64) {
-      const int i = g + lane;
-      bool whit = false;
-      if (i < nl) {
-        const float4 q = s_bb[i];
-        whit = !(t_xlo > q.y || t_xhi < q.x || w_ylo > q.w || w_yhi < q.z);
-        if (whit) {
-          // tighter than the bbox: the strip (a rectangle of pixel centres) is rejected when it lies entirely beyond one edge
-          // LINE of the face by more than the blur radius r (edge function = signed line distance * edge length).
-          const float4 fa = s_a[i], fb = s_b[i];
-          const float X0 = fa.x, Y0 = fa.y, X1 = fa.w, Y1 = fb.x, X2 = fb.z, Y2 = fb.w;
-          const float ar = edge_fn(X2, Y2, X0, Y0, X1, Y1) + kEps;
-          const float sgn = (ar > 0.f) ? 1.f : -1.f;
-          const float ex[3] = {X1, X2, X0}, ey[3] = {Y1, Y2, Y0}, fx[3] = {X2, X0, X1}, fy[3] = {Y2, Y0, Y1};
-#pragma unroll
-          for (int k = 0; k < 3; ++k) {
-            // e(p) = (px-ax)(by-ay) - (py-ay)(bx-ax), a = (ex,ey), b = (fx,fy); maximum of sgn*e over the 4 strip corners
-            const float dx = fx[k] - ex[k], dy = fy[k] - ey[k];
-            const float c00 = sgn * ((t_xlo - ex[k]) * dy - (w_ylo - ey[k]) * dx), c10 = sgn * ((t_xhi - ex[k]) * dy - (w_ylo - ey[k]) * dx);
-            const float c01 = sgn * ((t_xlo - ex[k]) * dy - (w_yhi - ey[k]) * dx), c11 = sgn * ((t_xhi - ex[k]) * dy - (w_yhi - ey[k]) * dx);
-            const float emax = fmaxf(fmaxf(c00, c10), fmaxf(c01, c11));
-            const float margin = strip_r * sqrtf(dx * dx + dy * dy) * 1.0001f + 1e-12f;
-            if (emax < -margin) whit = false;
-          }
-        }
-      }
-      // ---- phase 1: classify only.  The expensive parts (depth interpolation of a hit, the three segment distances + exp of a
-      // rim face) used to run for the whole wave whenever ANY lane needed them (~130 VALU instructions per face iteration); each lane
-      // now queues the staged-face indices it needs (hard: 4 x 8 bit, soft: 8 x 8 bit) and the queues are drained per lane, in
-      // ascending face order (same tie-break, same product order => bit-identical results), a handful of iterations per strip.
-      unsigned long long m = __ballot(whit);
-      while (m) {
-        const int j = g + __ffsll((unsigned long long)m) - 1;
-        m &= m - 1;
-        const float4 q = s_bb[j];
-        const bool inbox = in_img && !(px > q.y || px < q.x || py > q.w || py < q.z);
-        if (!__any(inbox && (MODE == 2 ? need : true))) continue;
-        const float4 fa = s_a[j], fb = s_b[j];
-        const Tri t = tri_from(fa, fb, make_float4(0.f, 0.f, 0.f, 0.f));
-        const float e0 = edge_fn(px, py, t.x1, t.y1, t.x2, t.y2);
-        const float e1 = edge_fn(px, py, t.x2, t.y2, t.x0, t.y0);
-        const float e2 = edge_fn(px, py, t.x0, t.y0, t.x1, t.y1);
-        float sg, l12 = 0.f, l20 = 0.f, l01 = 0.f;
-        if (MODE == 1) {
-          const float4 fc = s_fc[j];
-          sg = fc.x; l12 = fc.y; l20 = fc.z; l01 = fc.w;
-        } else {
-          const float area = edge_fn(t.x2, t.y2, t.x0, t.y0, t.x1, t.y1) + kEps;
-          sg = (area > 0.f) ? 1.f : ((area < 0.f) ? -1.f : 0.f);
-        }
-        const float e0s = e0 * sg, e1s = e1 * sg, e2s = e2 * sg;
-        const bool inside = (e0s > 0.f) && (e1s > 0.f) && (e2s > 0.f);
-        if (MODE != 2 && inside && inbox) { hq |= (unsigned)j << (8 * hn); ++hn; }
-        if (MODE >= 1) {
-          bool soft = (MODE == 1) ? (inbox && prod != 0.f) : (inbox && need);
-          if (soft) {
-            if (MODE == 2) {       // (few pairs get here in the backward pass: recomputing beats staging the constants, measured)
-              l12 = (t.x2 - t.x1) * (t.x2 - t.x1) + (t.y2 - t.y1) * (t.y2 - t.y1);
-              l20 = (t.x0 - t.x2) * (t.x0 - t.x2) + (t.y0 - t.y2) * (t.y0 - t.y2);
-              l01 = (t.x1 - t.x0) * (t.x1 - t.x0) + (t.y1 - t.y0) * (t.y1 - t.y0);
-            }
-            if (inside) {
-              // deeper than sqrt(18 sigma) inside every edge LINE (<= segment distance): sigmoid saturates to exactly 1 in
-              // fp32 (exp(-18) < 2^-24), so the factor (1-p) is exactly 0 — same result as the exact path, no div/exp.
-              const float K = 18.0f * sigma;
-              if (e0 * e0 > K * l12 && e1 * e1 > K * l20 && e2 * e2 > K * l01) {
-                if (MODE == 1) prod = 0.f;
-                soft = false;
-              }
-            } else {
-              // outside: the triangle lies beyond the line of any violated edge, so dist >= that line distance
-              const float Bf = blur * 1.00001f;
-              if ((e0s < 0.f && e0 * e0 >= Bf * l12) || (e1s < 0.f && e1 * e1 >= Bf * l20) || (e2s < 0.f && e2 * e2 >= Bf * l01)) soft = false;
-            }
-            if (soft) { sq |= (unsigned long long)j << (8 * sn); ++sn; }
-          }
-        }
-        if (__any(hn == 4 || sn == 8)) drain();
-      }
     }
-    drain();            // staged indices are only valid within this round
     __syncthreads();
     if (MODE == 2 && (int)threadIdx.x < nl) {
       // flush: one global atomic per (staged face, vertex, component) per workgroup

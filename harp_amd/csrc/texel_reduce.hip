@@ -35,7 +35,7 @@ __device__ __forceinline__ long long to_fixed(double x) {
 }
 
 __global__ void __launch_bounds__(kThreads) texel_reduce_kernel(const float* __restrict__ rec, int32_t* __restrict__ cnt, int cap, int nbins, int nbx,
-                                                                int Wt, int Ht, double* __restrict__ g_tex, double* __restrict__ g_nmap, int dbg) {
+                                                                int Wt, int Ht, double* __restrict__ g_tex, double* __restrict__ g_nmap) {
   __shared__ long long acc[2][kAcc * kAcc * 3];   // [map][(ly * 33 + lx) * 3 + channel], 64-bit fixed point (see the scales below)
   __shared__ float wmax[2][kThreads / 64];
   __shared__ int pre[kMaxBins];                // inclusive prefix of the tiles' chunk counts
@@ -81,7 +81,7 @@ __global__ void __launch_bounds__(kThreads) texel_reduce_kernel(const float* __r
       if (i < n) {
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
-          const float4 q = (dbg & 8) ? make_float4(1e-3f * i, 2e-3f, 3e-3f, 4e-3f) : *(const float4*)(r0 + k * capz + i);   // (slots past n: stale, never used)
+          const float4 q = *(const float4*)(r0 + k * capz + i);   // (slots past n: stale, never used)
           rv[0][k] = q.x; rv[1][k] = q.y; rv[2][k] = q.z; rv[3][k] = q.w;
         }
       }
@@ -122,8 +122,8 @@ __global__ void __launch_bounds__(kThreads) texel_reduce_kernel(const float* __r
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           const int cx = x0 + (k & 1), cy = y0 + (k >> 1);
-          if (cx < Wt && cy < Ht && cw[k] != 0.f && !(dbg & 1)) {
-            const int o = (dbg & 16) ? ((t * 3 + k * 811 + j * 97) % (kAcc * kAcc * 3 - 3)) : ((ly + (k >> 1)) * kAcc + lx + (k & 1)) * 3;
+          if (cx < Wt && cy < Ht && cw[k] != 0.f) {
+            const int o = ((ly + (k >> 1)) * kAcc + lx + (k & 1)) * 3;
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
               if (g_tex) atomicAdd((unsigned long long*)&acc[0][o + c], (unsigned long long)to_fixed((double)(rv[j][3 + c] * cw[k]) * s0));
@@ -139,7 +139,7 @@ __global__ void __launch_bounds__(kThreads) texel_reduce_kernel(const float* __r
     for (int i = t; i < kAcc * kAcc * 3; i += kThreads) {
       const int ly = i / (kAcc * 3), q = i - ly * (kAcc * 3);
       const int gx3 = bx * kBin * 3 + q, gy = by * kBin + ly;
-      if (gy < Ht && gx3 < Wt * 3 && !(dbg & 2)) {
+      if (gy < Ht && gx3 < Wt * 3) {
         const size_t o = (size_t)gy * Wt * 3 + gx3;
         const long long a0 = acc[0][i], a1 = acc[1][i];
         if (g_tex && a0 != 0) atomicAdd(g_tex + o, (double)a0 * i0);          // (exact product: |a0| < 2^51, i0 a power of two)
@@ -191,11 +191,9 @@ int harp_texel_reduce(const float* trec, int32_t* trec_cnt, int trec_cap, int Ht
   if (!trec || !trec_cnt || trec_cap <= 0 || (trec_cap & 3) || ((size_t)trec & 15) || nbins <= 0 || nbins > kMaxBins || Wt > 65535 || Ht > 65535) return HARP_ERR_ARG;
   // 512 workgroups of 512 threads, at most TWO per CU (61 KB of LDS each + 12 KB of dynamic LDS it does not use: a third one does not fit): the kernel runs
   // beside the mesh / hand backward tail, whose small launches need wave slots on every CU
-  // HARP_TREC_DBG (timing experiments only, results WRONG): 1 no LDS adds, 2 no flush, 4 counters kept, 8 no record loads, 16 conflict-free LDS addresses
-  static const int dbg = [] { const char* e = getenv("HARP_TREC_DBG"); return e ? atoi(e) : 0; }();
-  hipLaunchKernelGGL(texel_reduce_kernel, dim3(512), dim3(kThreads), 12 * 1024, stream, trec, trec_cnt, trec_cap, nbins, (Wt + kBin - 1) / kBin, Wt, Ht, acc_tex, acc_nmap, dbg);
+  hipLaunchKernelGGL(texel_reduce_kernel, dim3(512), dim3(kThreads), 12 * 1024, stream, trec, trec_cnt, trec_cap, nbins, (Wt + kBin - 1) / kBin, Wt, Ht, acc_tex, acc_nmap);
   // (a "last workgroup clears" ticket was measured first: the 512 same-address returning atomics put ~15 us under every workgroup's record loads)
-  if (!(dbg & 4)) hipLaunchKernelGGL(texel_counters_clear_kernel, dim3(1), dim3(256), 0, stream, trec_cnt, nbins);
+  hipLaunchKernelGGL(texel_counters_clear_kernel, dim3(1), dim3(256), 0, stream, trec_cnt, nbins);
   HARP_CHECK_LAUNCH();
   return HARP_OK;
 }

@@ -894,7 +894,7 @@ def test_rccl_path_on_one_rank(sc):
 
 
 def test_perceptual_term_gradients(sc):
-    """the optional VGG term: engine (HIP shader backward fed by torch/MIOpen VGG autograd) against the oracle's
+    """the optional VGG term: engine (shader forward -> harp_vgg16_term on csrc/conv.hip -> shader backward) against the oracle's
     renderer + functional VGG16 on the CPU, same seeded random filters; all other weights zero so only this term's gradient is seen"""
     from harp_amd.engine import FitEngine
     from harp_amd.model.vgg import Vgg16Features

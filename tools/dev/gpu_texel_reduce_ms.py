@@ -1,5 +1,5 @@
 """harp_texel_reduce alone on the records of one bench step (C3 by default; `arm` = C5's share): ms per launch.  HARP_TREC_DBG selects
-the ablations of csrc/texel_reduce.hip (bit 4 = counters kept is forced here so that every launch sees the same lists)."""
+the ablations of tools/dev/variants/texel_reduce_timing_ablations.patch (build_variant.sh NAME "" texel_reduce <patch>, HARP_LIB_PATH; bit 4 = counters kept is forced here so that every launch sees the same lists — without the patch the first launch consumes them)."""
 import sys, os; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
 os.environ["HARP_TREC_DBG"] = str(int(os.environ.get("HARP_TREC_DBG", "0")) | 4)
 import torch, bench

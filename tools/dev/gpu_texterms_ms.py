@@ -1,4 +1,4 @@
-"""harp_texture_terms alone on the bench engine's maps: ms per launch (HARP_TT_DBG / HARP_TEXTERMS_LDS select ablations / the LDS fence)"""
+"""harp_texture_terms alone on the bench engine's maps: ms per launch (HARP_TEXTERMS_LDS: the LDS fence; HARP_TT_DBG ablations live in tools/dev/variants/texture_terms_timing_ablations.patch)"""
 import sys, os; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
 import torch, bench
 from harp_amd import _lib
