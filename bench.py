@@ -724,7 +724,9 @@ def main():
             # (read + cleared) and gradient images (read + written) in the finish pass
             shaded = int(((eng.s["face_c"][:eng.B] >= 0) & (eng.y_sil_col[eng.tfid[:eng.B].long()] != 0)).sum().item())
             alg["harp_texel_reduce"] = shaded * 36 + 2 * eng.Ht * eng.Wt * 3 * (8 + 4 + 4)
-            alg["harp_shade_bwd"] += shaded * 36 - 2 * eng.Ht * eng.Wt * 12          # (it writes the records instead of the two gradient maps)
+            # (the shader backward's own figure stays SURVEY 8(d)'s — the path's algorithmic bytes; that it now writes 36-byte records instead of
+            #  scattering into the two gradient maps is reported next to it, not folded into `frac`)
+            records_bytes = shaded * 36
         # ... and the bytes the FUSED rasteriser kernels really have to move (barycentrics / distances are never materialised): their
         # `frac` is against THIS figure; the one against §8(d)'s formula is kept as `frac_survey_8d`
         moved = {"raster_cam_fwd(setup+bin+raster)": (geom_pos + S2 * (4 + 4) + S2 * (4 + 4)) * eng.B,     # face id + alpha out; mask in, g_alpha out
@@ -770,6 +772,8 @@ def main():
                     wi = max(hit)
                     per_kernel[k]["valu_wave_instructions"] = wi
                     per_kernel[k]["issue_frac"] = wi * VALU_ISSUE_CYCLES / (SIMDS * CLOCK_HZ * timing[k] * 1e-3)
+        if "harp_shade_bwd" in per_kernel and "harp_texel_reduce" in kt:
+            per_kernel["harp_shade_bwd"]["texel_record_bytes_written"] = records_bytes
         if "harp_shade_bwd" in per_kernel:
             # (table form: 11.8 M texel + 4 M vertex + 2.3 M shadow-window atomics per B = 32 launch; with texel records the texel part leaves
             #  the kernel: harp_texel_reduce adds ~1.5 M double atomics of its own)
@@ -816,7 +820,12 @@ def main():
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
     if rank == 0:
-        print(json.dumps(out))
+        try:                                             # (RCCL prints its version banner through C stdio: keep the JSON line the LAST line of stdout)
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:                                # noqa: BLE001
+            pass
+        print(json.dumps(out), flush=True)
     if comm is not None:
         torch.cuda.synchronize()
         comm.destroy()

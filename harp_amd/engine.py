@@ -3,7 +3,7 @@
 replayable as a hipGraph, with one RCCL all-reduce of the flat gradient arena between backward and Adam.
 
 What the reference does per step with ~600 torch/PyTorch3D kernel launches, >= 8 host syncs and CPU-resident
-parameters, this does with 24 launches (hand mesh; 28 for the SMPL-X arm), no host sync and everything resident:
+parameters, this does with 27 launches (hand mesh, texel records; 24 in the table form; 28 + 3 for the SMPL-X arm), no host sync and everything resident:
 
   hand_front (schedule row, frame set-up, LBS, subdivide, normals + displace, normals, both projections, light camera; arm: 5 launches) ->
   raster(cam, K=1 + soft silhouette + its L1) || raster(light, K=1) || parameter / mesh regularisers ->

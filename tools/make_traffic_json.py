@@ -46,8 +46,9 @@ GROUPS = {
     "raster_light_fwd(raster kernel only)": (("raster_kernel<0,",),),
     "harp_silhouette_bwd": (("raster_kernel<2,",),),
     "harp_depth_bwd": (("depth_bwd_kernel",),),
+    "harp_texel_reduce": (("texel_reduce_kernel",), ("texel_finish_kernel",), ("texel_counters_clear_kernel",)),
 }
-OPTIONAL = {"harp_shade_fwd"}       # not launched in the fitting loop's fused-loss mode
+OPTIONAL = {"harp_shade_fwd", "harp_texel_reduce"}       # not launched in the fitting loop's fused-loss mode / in the table form of the shader backward
 
 
 def main(fetch_db, write_db, cmd):
