@@ -943,6 +943,8 @@ class FitEngine:
         taps = 4 * sum(h * w * c for h, w, c in tap_shapes(S))
         # the budget is the caller's figure, but never more than 80 % of what the device has free right now (a smaller device, or several
         # ranks sharing one: each would otherwise take the full default); a tier whose allocation fails anyway falls through to the next
+        if self._records_on():
+            self._texel_record_buffers()                 # (allocated before the cache is sized against what the device has free)
         torch.cuda.synchronize(self.dev)
         budget = min(int(cache_bytes), int(0.8 * torch.cuda.mem_get_info(self.dev)[0]))
         tiers = []
