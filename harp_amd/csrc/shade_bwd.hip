@@ -724,8 +724,10 @@ __device__ __forceinline__ void shade_bwd_tile(ShadeSmem<REC>& sm, unsigned vblo
   }
 }
 
+// (launch-bounds hint of the record form: 120 VGPRs = 4 waves per SIMD whatever the hint says; with 3 hipcc schedules the same registers a little
+//  better — step -2.5 us in 4 of 4 fresh-process pairs, -5 sustained; 5 = 96 VGPRs + 51 spills: +40 us.  profiles/r06_ab_record.txt item 10)
 #ifndef SHADE_REC_OCC
-#define SHADE_REC_OCC 4
+#define SHADE_REC_OCC 3
 #endif
 template <bool IMG, bool REC>
 __global__ void __launch_bounds__(256, REC ? SHADE_REC_OCC : SHADE_BWD_OCC) shade_bwd_wave_kernel(const harp_shade_args A, const int32_t* __restrict__ order,
