@@ -61,8 +61,17 @@ namespace {
 #define SHADE_BWD_TH 7
 #endif
 constexpr int kTW = 32, kTH = SHADE_BWD_TH, kTSlots = kTW * kTH;     // texel table: (x & 31, y mod kTH)
-constexpr int kVSlots = 32;                               // vertex table
-constexpr int kZW = 16, kZH = 16;                         // shadow-tap window (light-view pixels)
+#ifndef SHADE_VSLOTS_LOG2
+#define SHADE_VSLOTS_LOG2 5
+#endif
+#ifndef SHADE_ZW
+#define SHADE_ZW 16
+#endif
+#ifndef SHADE_ZH
+#define SHADE_ZH 16
+#endif
+constexpr int kVSlots = 1 << SHADE_VSLOTS_LOG2;           // vertex table
+constexpr int kZW = SHADE_ZW, kZH = SHADE_ZH;             // shadow-tap window (light-view pixels)
 constexpr int kScalars = 17;                              // 0-8 colours, 9-11 light_pos, 12-14 light_R[:,2], 15 light_T.z, 16 loss
 
 // REC = the texel gradients leave as RECORDS (harp_shade_args.trec): no texel table — 3.4 KB of LDS per wave instead of 9.6
@@ -188,7 +197,7 @@ __device__ __forceinline__ void shade_bwd_tile(ShadeSmem<REC>& sm, unsigned vblo
     int4* L4 = reinterpret_cast<int4*>(&L);
     for (int i = lane; i < (int)(sizeof(WaveLds<REC>) / 16); i += 64) L4[i] = make_int4(0, 0, 0, 0);
     if constexpr (!REC) for (int i = lane; i < kTSlots; i += 64) L.tkey[i] = -1;
-    if (lane < kVSlots) L.vkey[lane] = -1;
+    for (int i = lane; i < kVSlots; i += 64) L.vkey[i] = -1;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   }
   bool act = 64 * w + lane < n_tile;
@@ -486,7 +495,7 @@ __device__ __forceinline__ void shade_bwd_tile(ShadeSmem<REC>& sm, unsigned vblo
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
         const int v = vidx[k];
-        unsigned h = ((unsigned)v * 2654435761u) >> 27;
+        unsigned h = ((unsigned)v * 2654435761u) >> (32 - SHADE_VSLOTS_LOG2);
         int slot = -1;
         for (int probe = 0; probe < 4; ++probe) {
           const int old = atomicCAS(&L.vkey[h], -1, v);
