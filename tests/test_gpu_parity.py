@@ -1940,3 +1940,46 @@ def test_silhouette_backward_fused_into_the_raster_launch(sc, shrink, loop, monk
     if shrink < 1.0:
         tiles = ((out[False][0] >= 0).view(B, S // 16, 16, S // 16, 16).sum((2, 4)) > 0).sum().item()
         assert B * F / tiles > 256                                   # really more faces per tile than one staging round holds
+
+
+@pytest.mark.parametrize("tex_hw", [(100, 72), (33, 160), (512, 512)])
+def test_shade_backward_records_on_odd_texture_sizes(sc, tex_hw, monkeypatch):
+    """`ops.shade` (the module-level shader of the reference API mirror) backward with the texel gradients as records + harp_texel_reduce +
+    harp_texel_finish against the same call in the table form, on textures that are neither square nor a multiple of the 32-texel UV tile
+    (ragged last tile row / column, one-texel-wide tiles), with a tiny list capacity on top (most records take the overflow path into the
+    double maps): the texture and normal-map gradients agree to float rounding, every other gradient is untouched."""
+    from harp_amd import ops
+    from oracle import harp_ref as H, p3d_like as P
+    S, topo_h = 96, sc["topo"]
+    params = dict(pose=sc["seq"]["pose"], rot=sc["seq"]["rot"], trans=sc["seq"]["trans"], shape=sc["seq"]["shape"].mean(0),
+                  verts_disps=torch.zeros(3093, 1))
+    fid = torch.arange(2)
+    with torch.no_grad():
+        _, v = H.prepare_mesh(params, fid, sc["model"], topo_h)
+        R, T = H.camera_RT(sc["seq"]["cam"][fid], S, sc["focal"])
+        _, ndc = P.world_to_ndc(v, R, T, sc["focal"], (S / 2, S / 2), S)
+    topo = ops.DeviceTopology(sc["topo_np"], sc["tpl"]["verts_uvs"], sc["tpl"]["faces_uvs"], DEV)
+    g = torch.Generator().manual_seed(3)
+    Ht, Wt = tex_hw
+    base = dict(ndc=ndc.float(), verts=v.float(), tex=torch.rand(Ht, Wt, 3, generator=g), nmap=torch.nn.functional.normalize(torch.randn(Ht, Wt, 3, generator=g) * 0.2 + torch.tensor([0., 0., 1.]), dim=-1),
+                light_pos=torch.tensor([[-0.5, -0.5, -0.5]]).repeat(2, 1), colors=torch.tensor([0.4, 0.4, 0.4, 0.6, 0.6, 0.6, 0., 0., 0.]))
+    Rw = torch.rand(2, S, S, 3, generator=g).to(DEV)
+    out = {}
+    for rec, cap in ((False, None), (True, None), (True, 64)):
+        monkeypatch.setattr(ops, "TEXEL_RECORDS", rec)
+        if cap is not None:
+            real = ops.texel_record_buffers
+            monkeypatch.setattr(ops, "texel_record_buffers", lambda dev, h, w, c: real(dev, h, w, cap))
+        t = {k: x.clone().to(DEV).requires_grad_(k != "ndc" or True) for k, x in base.items()}
+        vn = ops.vertex_normals(t["verts"], topo)
+        face_id, _, _, ws = ops.rasterize_fwd(t["ndc"].detach(), topo.faces, S)
+        rgb = ops.shade(t["ndc"], t["verts"], vn, t["tex"], t["nmap"], t["light_pos"], t["colors"], face_id, ws, topo, S, sc["focal"])
+        (rgb * Rw).sum().backward()
+        torch.cuda.synchronize()
+        out[rec, cap] = {k: x.grad.double().clone() for k, x in t.items()}
+    ref = out[False, None]
+    assert ref["tex"].abs().max() > 0 and ref["nmap"].abs().max() > 0
+    for key in ((True, None), (True, 64)):
+        for k, gref in ref.items():
+            tol = 2e-6 if k in ("tex", "nmap") else 1e-5
+            assert rel(out[key][k], gref) < tol, (tex_hw, key, k, rel(out[key][k], gref))
