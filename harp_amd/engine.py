@@ -3,7 +3,7 @@
 replayable as a hipGraph, with one RCCL all-reduce of the flat gradient arena between backward and Adam.
 
 What the reference does per step with ~600 torch/PyTorch3D kernel launches, >= 8 host syncs and CPU-resident
-parameters, this does with 27 launches (hand mesh, texel records; 24 in the table form; 28 + 3 for the SMPL-X arm), no host sync and everything resident:
+parameters, this does with 28 launches (hand mesh, texel records; 24 in the table form; 28 + 4 for the SMPL-X arm), no host sync and everything resident:
 
   hand_front (schedule row, frame set-up, LBS, subdivide, normals + displace, normals, both projections, light camera; arm: 5 launches) ->
   raster(cam, K=1 + soft silhouette + its L1) || raster(light, K=1) || parameter / mesh regularisers ->
@@ -212,6 +212,7 @@ class FitEngine:
         self.trec_cap_min = 65536
         self._trec = self._tacc = None
         self._maps_pending = None
+        self.split_adam = True           # with the texel records: the maps' Adam update on the second stream behind harp_texel_finish, the step's last launch only for the small parameters
         self.fused_sil_bwd = False       # the silhouette backward inside the camera-view raster launch (harp_rasterize_l1_fwd_bwd) instead of a launch of its own beside the shader backward.  Correct (tests) and measured SLOWER: the shader backward gains 32 us without its neighbour (230 -> 198 in the graph), the camera raster pays 56 (198 -> 254: 94 VGPRs / 26 KB of LDS = 5 waves per SIMD instead of 7, and the rim walk is ~25 us of VALU work wherever it runs): step 0.665 vs 0.638 ms (profiles/r06_ab_record.txt)
         self.lean_app_stage = False      # appearance-only stage without the geometry gradients nothing reads (set by optimize_hand_sequence; off by default: g_buf then holds what autograd would)
         self._lean_now = False
@@ -1046,9 +1047,9 @@ class FitEngine:
         self._early_from = o
 
     def allreduce(self):
-        self._join_maps()
         if not self._dist_on():
-            return
+            return                                       # (the maps' branch stays open: adam() joins it — behind the maps' own update, `split_adam`)
+        self._join_maps()
         from .dist import allreduce_flat
         o, n = self.opt_span
         work, self._early_work = self._early_work, None
@@ -1076,6 +1077,24 @@ class FitEngine:
             self._ck(L.harp_adam_tick(self.hyper.data_ptr() + (0 if coarse else 1) * self._hyper_stride, 1, st), "adam_tick")
 
     def adam(self, coarse=True, app=True, tick=True):
+        # the maps are 99.99 % of the optimised elements and their gradients are final on the second stream (texel reduce -> finish) well before
+        # the backward tail ends: their Adam update runs THERE, and the launch that ends the step only carries the ~15 k other parameters
+        # (8 -> 4 us at the very end of the critical path).  Single rank, nothing frozen, hyper-parameters already ticked by the prologue.
+        maps = self._maps_pending
+        if (self.split_adam and maps is not None and app and not tick and not self.frozen and not self._dist_on()):
+            L, h1 = _lib.lib(), self.hyper.data_ptr() + self._hyper_stride
+            bufs = (self.p_buf.data_ptr(), self.g_buf.data_ptr(), self.m_buf.data_ptr(), self.v_buf.data_ptr())
+            om, nm = self.arena.span("texture", "normal_map")
+            with torch.cuda.stream(maps):
+                self._ck(L.harp_adam_apply(*(b + 4 * om for b in bufs), nm, h1, _lib.stream()), "adam_apply(maps)")
+            self._join_maps()
+            osm, nsm = self.arena.span("light_positions", "amb_ratio")
+            if coarse:
+                (o0, n0) = self.coarse_span
+                self._ck(L.harp_adam_apply2(*bufs, o0, n0, osm, nsm, self.hyper.data_ptr(), _lib.stream()), "adam_apply2(small)")
+            else:
+                self._ck(L.harp_adam_apply(*(b + 4 * osm for b in bufs), nsm, h1, _lib.stream()), "adam_apply(small)")
+            return
         self._join_maps()
         L, p, st = _lib.lib(), _lib.ptr, _lib.stream()
         # parameters outside the reference's optimiser groups (known_appearance: shape / displacement / texture / normal map,
@@ -1220,7 +1239,7 @@ class FitEngine:
         # every switch the enqueued launch sequence depends on is part of the key: flipping one re-captures instead of replaying a
         # graph recorded for another configuration
         gkey = (coarse, app, scheduled, n, self.keep_image, self.fused_loss, self.self_shadow, tuple(self.frozen), self.overlap, self.early_terms,
-                self.packed_texels, self.fused_keep, self.mesh_third, self.graph_order, fold, self.fused_terms, self.zl_tile_flags, self.accumulate_loss, self.lean_app_stage, self.sil_only_raster, self.auto_draw, self.mesh_terms_late, self.sil_late, self.paired_setup, self.late_texture_terms, self.mesh_terms_first, self.camera_first, self.tail_side, self.fused_bwd, self.fused_chain, self.fused_front, self.wide_front, self.hybrid_front, self.front_auto, self.wide_back, self.fused_back, self.consume_gzl, self.keep_depth, self.texel_records, self.fused_sil_bwd, dist_on, self.overlap_allreduce,
+                self.packed_texels, self.fused_keep, self.mesh_third, self.graph_order, fold, self.fused_terms, self.zl_tile_flags, self.accumulate_loss, self.lean_app_stage, self.sil_only_raster, self.auto_draw, self.mesh_terms_late, self.sil_late, self.paired_setup, self.late_texture_terms, self.mesh_terms_first, self.camera_first, self.tail_side, self.fused_bwd, self.fused_chain, self.fused_front, self.wide_front, self.hybrid_front, self.front_auto, self.wide_back, self.fused_back, self.consume_gzl, self.keep_depth, self.texel_records, self.fused_sil_bwd, self.split_adam, dist_on, self.overlap_allreduce,
                 self.comm is not None, self.perceptual is not None and app)
         g = self._graphs.get(gkey)
         if g is None:

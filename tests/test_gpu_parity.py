@@ -1246,7 +1246,8 @@ def test_light_camera_incl_look_at_replacement_branch():
                                       dict(texel_records=False), dict(texel_records=False, tail_side=True), dict(texel_records=False, fused_terms=False), dict(tail_side=True, fused_terms=False),
                                       # ... and the silhouette backward inside the camera-view raster launch (harp_rasterize_l1_fwd_bwd) vs the stand-alone launch beside the shader backward (default)
                                       dict(fused_sil_bwd=True), dict(fused_sil_bwd=True, texel_records=False), dict(fused_sil_bwd=True, graph_order=False), dict(fused_sil_bwd=True, overlap=False),
-                                      dict(fused_sil_bwd=True, fold_step=False), dict(fused_sil_bwd=True, mesh_third=True)])
+                                      dict(fused_sil_bwd=True, fold_step=False), dict(fused_sil_bwd=True, mesh_third=True),
+                                      dict(split_adam=False), dict(split_adam=False, texel_records=False)])
 def test_schedule_switches_give_the_default_schedules_result(switches):
     """The stream / capture-order switches of FitEngine (graph_order, mesh_third, camera_first, overlap, early_terms, mesh_terms_first,
     tail_side) only move launches between streams: losses and the whole gradient arena of every non-default combination must equal the

@@ -17,7 +17,9 @@ def main(path, marker="schedule_next", step=None):
     if len(marks) < 3 and marker == "schedule_next":
         # folded steps (FitEngine.fold_step) have no schedule kernel: a step then runs from the kernel after one Adam launch (the last
         # kernel of every step) through the next Adam launch
-        marks = [i + 1 for i, r in enumerate(rows) if "adam_dev" in r[0] and i + 1 < len(rows)]
+        # (with `split_adam` the maps' own adam_dev launch sits inside the step: the step ends with adam_dev2 — or, appearance-only, with the LAST adam_dev)
+        last = "adam_dev2" if any("adam_dev2" in r[0] for r in rows) else "adam_dev"
+        marks = [i + 1 for i, r in enumerate(rows) if last in r[0] and i + 1 < len(rows)]
     if len(marks) < 3:
         print("not enough steps"); return
     lo, hi = (marks[-2], marks[-1]) if step is None else (marks[int(step)], marks[int(step) + 1])
