@@ -30,7 +30,7 @@
 //         of that maximum, i.e. float32-grade.  Flushed row-major, lanes = (texel, channel): consecutive addresses share memory
 //         requests (330 G atomics/s against 21 G/s for random addresses), without the counting sort the hash table needed.
 //       - vertices (position, normal, NDC: 27 values per pixel): lanes on the same face are merged first (DPP butterfly over the
-//         x neighbours of the compacted order), the survivors add into a 32-slot double table.
+//         x neighbours of the compacted order), the survivors add into a 32-slot fixed-point table (round 6; it was double: -3 us).
 //       - shadow-map taps: 16x16 fixed-point window anchored at the wave's smallest tap.
 //       - the 17 per-frame scalars (light colours, light position, light camera, loss): wave reductions -> LDS partials; the LAST
 //         wave of the tile to finish (LDS ticket, no barrier) issues one memory atomic per scalar.
@@ -80,7 +80,14 @@ struct alignas(16) WaveLds {
   int tkey[REC ? 4 : kTSlots];
   int tval[6][REC ? 4 : kTSlots];        // fixed point; 0-2 albedo, 3-5 normal map
   int vkey[kVSlots];
+#ifndef SHADE_VFIXED
+#define SHADE_VFIXED 1
+#endif
+#if SHADE_VFIXED
+  int vval[9][kVSlots];        // 0-2 g_verts, 3-5 g_vnormals, 6-8 g_ndc; 32-bit fixed point, one power-of-two scale per group and wave
+#else
   double vval[9][kVSlots];     // 0-2 g_verts, 3-5 g_vnormals, 6-8 g_ndc
+#endif
   int zwin[kZW * kZH];         // fixed point
 };
 
@@ -482,6 +489,12 @@ __device__ __forceinline__ void shade_bwd_tile(ShadeSmem<REC>& sm, unsigned vblo
   const bool any_act = working && __any(act ? 1 : 0) != 0;
   STAMP(6);
 
+#if SHADE_VFIXED
+  float vinv[3] = {0.f, 0.f, 0.f};        // 1 / scale of the three groups of the vertex table
+#define VVAL_F(x, c) ((float)(x) * vinv[(c) / 3])
+#else
+#define VVAL_F(x, c) ((float)(x))
+#endif
   float* gvb = A.g_verts + (size_t)b * V * 3;
   float* gnb = A.g_vnormals + (size_t)b * V * 3;
   float* gdb = A.g_ndc + (size_t)b * V * 3;
@@ -491,6 +504,22 @@ __device__ __forceinline__ void shade_bwd_tile(ShadeSmem<REC>& sm, unsigned vblo
     //      neighbours in the compacted order), the survivors add into the wave's double table
     bool alive = act;
     merge_same_face<27, SHADE_MERGE_MASK>(vsc, act ? f : -1, alive, lane);
+#if SHADE_VFIXED
+    // fixed-point adds (ds_add_u32: 4.8 clk per wave instruction and 3.6 per further lane on the same address, against 8.7 and 11 for
+    // ds_add_f64 — and neighbouring faces DO share vertices): one scale per gradient group from the wave's largest (merged) contribution, as
+    // for the texel table: |sum| <= 64 lanes x max < 2^30, resolution 2^-23 of that maximum
+    float vm[3] = {0.f, 0.f, 0.f};
+    if (alive) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int c = 0; c < 9; ++c) vm[c / 3] = fmaxf(vm[c / 3], fabsf(vsc[9 * k + c]));
+    }
+    float vs[3], vi[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) { vm[q] = wave_max_u(vm[q]); fixed_scale(vm[q], vs[q], vi[q]); }
+    vinv[0] = vi[0]; vinv[1] = vi[1]; vinv[2] = vi[2];
+#endif
     if (alive) {
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
@@ -504,7 +533,11 @@ __device__ __forceinline__ void shade_bwd_tile(ShadeSmem<REC>& sm, unsigned vblo
         }
         if (slot >= 0) {
 #pragma unroll
+#if SHADE_VFIXED
+          for (int c = 0; c < 9; ++c) atomicAdd(&L.vval[c][slot], __float2int_rn(vsc[9 * k + c] * vs[c / 3]));
+#else
           for (int c = 0; c < 9; ++c) atomicAdd(&L.vval[c][slot], (double)vsc[9 * k + c]);
+#endif
         } else {
 #pragma unroll
           for (int c = 0; c < 3; ++c) {
@@ -678,7 +711,7 @@ __device__ __forceinline__ void shade_bwd_tile(ShadeSmem<REC>& sm, unsigned vblo
 #pragma unroll
       for (int j = 0; j < kQ; ++j) {
         const int i = min(lane + 64 * j, kVSlots * 9 - 1), sl = i / 9, c = i - 9 * sl;
-        vk[j] = L.vkey[sl]; vv[j] = (float)L.vval[c][sl];
+        vk[j] = L.vkey[sl]; vv[j] = VVAL_F(L.vval[c][sl], c);
       }
 #pragma unroll
       for (int j = 0; j < kQ; ++j) {
@@ -694,7 +727,7 @@ __device__ __forceinline__ void shade_bwd_tile(ShadeSmem<REC>& sm, unsigned vblo
       const int sl = i / 9, c = i - 9 * sl;
       const int v = L.vkey[sl];
       if (v < 0) continue;
-      const float val = (float)L.vval[c][sl];
+      const float val = VVAL_F(L.vval[c][sl], c);
       if (val == 0.f) continue;
       float* dst = c < 3 ? gvb : (c < 6 ? gnb : gdb);
       atomicAdd(at32m(dst, 3u * (unsigned)v + (c % 3)), val);
