@@ -763,6 +763,7 @@ int harp_shade_sil_bwd(const harp_shade_args* a, float blur_radius, float sigma,
     b.l1_target = nullptr;
   }
   b.debug_skip = 0;
+  b.trec = nullptr;               // (the one-launch pair hosts the table form of the shader tile: texel gradients go straight into g_tex / g_nmap)
   return harp_detail_fused_bwd(b, a->recs, a->faces, blur_radius, sigma, alpha, g_alpha, stream);
 }
 

@@ -213,7 +213,8 @@ int harp_shade_fwd(const harp_shade_args* a, hipStream_t stream);
 int harp_shade_bwd(const harp_shade_args* a, hipStream_t stream);
 /* harp_shade_bwd(a) and harp_silhouette_bwd(a->faces, ..., ws = a->recs, alpha, g_alpha, g_ndc = a->g_ndc) of the SAME camera-view
  * rasterisation as ONE launch whose workgroups alternate between the two kinds of tile: as separate kernels on two streams they cannot
- * share a CU (registers / LDS), in one grid the rasteriser's waves issue while the shader's wait on memory.  Same results. */
+ * share a CU (registers / LDS), in one grid the rasteriser's waves issue while the shader's wait on memory.  Same results.  (a->trec is
+ * ignored: this launch hosts the table form of the shader tile, the texel gradients go straight into g_tex / g_nmap.) */
 int harp_shade_sil_bwd(const harp_shade_args* a, float blur_radius, float sigma, const float* alpha, const float* g_alpha,
                        hipStream_t stream);
 
