@@ -1984,3 +1984,76 @@ def test_shade_backward_records_on_odd_texture_sizes(sc, tex_hw, monkeypatch):
         for k, gref in ref.items():
             tol = 2e-6 if k in ("tex", "nmap") else 1e-5
             assert rel(out[key][k], gref) < tol, (tex_hw, key, k, rel(out[key][k], gref))
+
+
+@pytest.mark.parametrize("hw", [(72, 100), (512, 512)])
+def test_texel_reduce_and_finish_raw_abi_against_grid_sample_autograd(hw):
+    """harp_texel_reduce + harp_texel_finish through the C ABI on hand-made record lists against torch's float64 autograd through
+    F.grid_sample(bilinear, align_corners=True, padding_mode="border") — the op the reference samples its texture and normal map with
+    (pytorch3d TexturesUV.sample_textures; oracle/p3d_like.py:242-259): records on the last row / column (the corner beyond the map is
+    dropped), exactly-zero fractions, 5 000 records on ONE texel, lists longer than one 2 048-record chunk, a ragged last tile; the
+    normal map's gradient through harp_texel_finish's chain rule of F.normalize (utils/visualize.py:99); counters and accumulators handed
+    back zeroed."""
+    import torch.nn.functional as F
+    from harp_amd import _lib
+    L, p, st = _lib.lib(), _lib.ptr, _lib.stream
+    H, W = hw
+    g = torch.Generator().manual_seed(17)
+    N = 40000
+    x0 = torch.randint(0, W, (N,), generator=g)
+    y0 = torch.randint(0, H, (N,), generator=g)
+    x0[:5000], y0[:5000] = W // 3, H // 2                     # a crowd on one texel
+    x0[5000:5400], y0[5400:5800] = W - 1, H - 1               # last column / last row
+    wx, wy = torch.rand(N, generator=g), torch.rand(N, generator=g)
+    wx[x0 == W - 1] = 0.0                                     # (border padding: the sample position is clamped onto the last texel)
+    wy[y0 == H - 1] = 0.0
+    wx[6000:6200], wy[6200:6400] = 0.0, 0.0                   # exactly-zero fractions inside the map
+    ga, gm = torch.randn(N, 3, generator=g) * 1e-5, torch.randn(N, 3, generator=g) * 3e-4
+    ga[7000:7050] *= 1e4                                      # a few contributions 10 000 x the rest (one chunk, one scale)
+    # ---- expected: autograd through grid_sample on double maps
+    tex = torch.zeros(1, 3, H, W, dtype=torch.float64, requires_grad=True)
+    nraw = (torch.randn(H, W, 3, generator=g, dtype=torch.float64) * 0.3 + torch.tensor([0.0, 0.0, 1.0], dtype=torch.float64)).requires_grad_(True)
+    nmap = F.normalize(nraw, dim=-1).permute(2, 0, 1)[None]
+    grid = torch.stack([2.0 * (x0 + wx.double()) / (W - 1) - 1.0, 2.0 * (y0 + wy.double()) / (H - 1) - 1.0], -1)[None, None]
+    sa = F.grid_sample(tex, grid, mode="bilinear", align_corners=True, padding_mode="border")[0, :, 0].t()
+    sm = F.grid_sample(nmap, grid, mode="bilinear", align_corners=True, padding_mode="border")[0, :, 0].t()
+    ((sa * ga.double()).sum() + (sm * gm.double()).sum()).backward()
+    want_t, want_n = tex.grad[0].permute(1, 2, 0), nraw.grad
+    # ---- the record lists, as the shader backward lays them out
+    nbx = (W + 31) // 32
+    nb = L.harp_texel_bins(H, W)
+    assert nb == nbx * ((H + 31) // 32)
+    cap = 16384
+    bins = (y0 // 32) * nbx + x0 // 32
+    rec = torch.zeros(nb, 9, cap)
+    cnt = torch.zeros(nb * 16 + 16, dtype=torch.int32)
+    key = (x0 | (y0 << 16)).to(torch.int32).view(torch.float32)
+    planes = torch.stack([key, wx, wy, ga[:, 0], ga[:, 1], ga[:, 2], gm[:, 0], gm[:, 1], gm[:, 2]], 0)       # (9, N)
+    for b in range(nb):
+        idx = torch.nonzero(bins == b).flatten()
+        assert idx.numel() <= cap
+        rec[b, :, : idx.numel()] = planes[:, idx]
+        cnt[16 * b] = idx.numel()
+    assert int(cnt.max()) > 2048                                # more than one chunk in the fullest list
+    rec_d, cnt_d = rec.to(DEV).contiguous(), cnt.to(DEV)
+    acc = torch.zeros(2, H * W * 3, dtype=torch.float64, device=DEV)
+    g_tex, g_nm = torch.zeros(H, W, 3, device=DEV), torch.zeros(H, W, 3, device=DEV)
+    nraw_d = nraw.detach().float().to(DEV).contiguous()
+    _lib.check(L.harp_texel_reduce(p(rec_d), p(cnt_d), cap, H, W, p(acc[0]), p(acc[1]), st()), "reduce")
+    torch.cuda.synchronize()
+    assert int(cnt_d.abs().max()) == 0
+    a0 = acc[0].view(H, W, 3).cpu()
+    err = ((a0 - want_t).abs().max() / want_t.abs().max()).item()
+    assert err < 3e-7, err       # exact sums of FLOAT32 products weight x gradient (each 6e-8 from the exact product; the 2^-40 fixed point adds nothing)
+    _lib.check(L.harp_texel_finish(p(acc[0]), p(g_tex), p(acc[1]), p(g_nm), p(nraw_d), H * W, st()), "finish")
+    torch.cuda.synchronize()
+    assert int((acc != 0).sum()) == 0
+    assert rel(g_tex.double().cpu(), want_t) < 2e-7 and rel(g_nm.double().cpu(), want_n) < 2e-6, (rel(g_tex.double().cpu(), want_t), rel(g_nm.double().cpu(), want_n))
+    # frozen maps: a NULL accumulator leaves that map out
+    cnt_d.copy_(cnt.to(DEV))
+    _lib.check(L.harp_texel_reduce(p(rec_d), p(cnt_d), cap, H, W, p(acc[0]), None, st()), "reduce (texture only)")
+    torch.cuda.synchronize()
+    assert int((acc[1] != 0).sum()) == 0 and int((acc[0] != 0).sum()) > 0
+    # bad arguments launch nothing
+    assert L.harp_texel_reduce(p(rec_d), p(cnt_d), cap + 2, H, W, p(acc[0]), p(acc[1]), st()) == 1
+    assert L.harp_texel_reduce(p(rec_d), p(cnt_d), cap, 2048, 2048, p(acc[0]), p(acc[1]), st()) == 1
