@@ -63,7 +63,7 @@ class ShadeArgs(ctypes.Structure):
                 [(n, _vp) for n in ("rgb", "g_rgb", "g_tex", "g_nmap", "g_verts", "g_vnormals", "g_ndc", "g_zl", "g_light_pos",
                                     "g_colors", "g_light_R", "g_light_T")] + [("debug_skip", _i)] +
                 [(n, _vp) for n in ("l1_target", "l1_mask", "l1_fid", "l1_w", "l1_loss", "l1_grad")] + [("l1_inv", _f), ("texnm", _vp), ("l1_bg_sums", _vp), ("g_zl_tiles", _vp),
-                 ("trec", _vp), ("trec_cnt", _vp), ("trec_cap", _i), ("trec_acc_tex", _vp), ("trec_acc_nmap", _vp)])
+                 ("trec", _vp), ("trec_cnt", _vp), ("trec_cap", _i), ("trec_acc_tex", _vp), ("trec_acc_nmap", _vp), ("g_vert9", _vp)])
 
 
 SIGNATURES.update({
@@ -78,6 +78,8 @@ SIGNATURES.update({
     "harp_normalize3_pack": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
     "harp_depth_nmap_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
     "harp_depth_bwd_tiles": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "harp_depth_bwd_riders": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "harp_vert9_unpack": (_i, [_vp, _i, _vp, _vp, _vp, _vp]),
     "harp_subdivide_fwd": (_i, [_vp, _vp, _i, _i, _i, _f, _vp, _vp]),
     "harp_subdivide_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _vp, _vp]),
     "harp_vertex_normals_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),

@@ -621,7 +621,30 @@ __global__ void normalize_pack_kernel(const float* __restrict__ tex, const float
 // NMAP: the launch carries `M.blocks` more workgroups behind the tile workgroups, which apply the chain rule of the normal-map
 // normalisation (losses.hip: normalize3_bwd_kernel) — the other small kernel between the shader backward and the per-frame backward
 // tail; both only need the shader backward's output and neither reads what the other writes.
-struct NmapBwd { const float* x; const float* gy; float* gx; int n; int blocks; };
+struct NmapBwd {
+  const float* x; const float* gy; float* gx; int n; int blocks;
+  // ... and `v9_blocks` more that add the shader backward's interleaved vertex gradients (harp_shade_args.g_vert9: 9 floats per vertex) into
+  // the three per-vertex arrays the mesh-chain backward reads, and clear them
+  float* v9; float* gv; float* gn; float* gd; int nv; int v9_blocks;
+};
+// g9 (nv, 9) = [g_verts(3) | g_vnormals(3) | g_ndc(3)] per vertex -> += into the three (nv,3) arrays, g9 cleared.  Atomic adds: the silhouette
+// backward may still be adding to g_ndc on another stream (consecutive addresses: the coalesced rate)
+__device__ __forceinline__ void vert9_unpack_body(float* __restrict__ g9, float* __restrict__ gv, float* __restrict__ gn, float* __restrict__ gd,
+                                                  int nv, size_t first, size_t stride) {
+  for (size_t i = first; i < (size_t)nv * 9; i += stride) {
+    const float x = g9[i];
+    if (x != 0.f) {
+      const size_t v = i / 9;
+      const int c = (int)(i - 9 * v);
+      float* dst = c < 3 ? gv : (c < 6 ? gn : gd);
+      atomicAdd(dst + 3 * v + (c % 3), x);
+      g9[i] = 0.f;
+    }
+  }
+}
+__global__ void __launch_bounds__(256) vert9_unpack_kernel(float* __restrict__ g9, float* __restrict__ gv, float* __restrict__ gn, float* __restrict__ gd, int nv) {
+  vert9_unpack_body(g9, gv, gn, gd, nv, (size_t)blockIdx.x * 256 + threadIdx.x, (size_t)gridDim.x * 256);
+}
 template <bool CONSUME, bool NMAP = false>
 __global__ void __launch_bounds__(256) depth_bwd_kernel(const int32_t* __restrict__ face_id, const FaceRec* __restrict__ recs,
                                                         const int32_t* __restrict__ faces, float* __restrict__ g_z,
@@ -629,10 +652,14 @@ __global__ void __launch_bounds__(256) depth_bwd_kernel(const int32_t* __restric
                                                         const int32_t* __restrict__ order, const int32_t* __restrict__ nact,
                                                         int B, int nsx, const NmapBwd M, unsigned char* __restrict__ tiles) {
   __shared__ VertexAccum<256, 3> s_acc;
-  const unsigned tile_blocks = NMAP ? gridDim.x - (unsigned)M.blocks : gridDim.x;
+  const unsigned tile_blocks = NMAP ? gridDim.x - (unsigned)M.blocks - (unsigned)M.v9_blocks : gridDim.x;
   if (NMAP && blockIdx.x >= tile_blocks) {
-    for (size_t i = (size_t)(blockIdx.x - tile_blocks) * 256 + threadIdx.x; i < (size_t)M.n; i += (size_t)M.blocks * 256)
-      normalize3_bwd_texel(M.x, M.gy, M.gx, i);
+    const unsigned e = blockIdx.x - tile_blocks;
+    if (e < (unsigned)M.blocks) {
+      for (size_t i = (size_t)e * 256 + threadIdx.x; i < (size_t)M.n; i += (size_t)M.blocks * 256) normalize3_bwd_texel(M.x, M.gy, M.gx, i);
+    } else {
+      vert9_unpack_body(M.v9, M.gv, M.gn, M.gd, M.nv, (size_t)(e - M.blocks) * 256 + threadIdx.x, (size_t)M.v9_blocks * 256);
+    }
     return;
   }
   // capped grid: a workgroup strides over the tiles of the super-tiles that hold faces (launch order).  The full grid is 16 workgroups
@@ -741,6 +768,7 @@ int harp_shade_bwd(const harp_shade_args* a, hipStream_t stream) {
   } else {
     b.l1_target = nullptr;          // a caller that hands over the gradient image gets the plain backward pass
   }
+  if (b.g_vert9 && (!geom || (b.debug_skip & 0xff))) return HARP_ERR_ARG;      // interleaved vertex gradients: production kernel, geometry gradients wanted
   // texel-gradient records (production kernel only): the list counters and a capacity come with the record buffer
   if (b.trec && (!b.trec_cnt || b.trec_cap <= 0 || (b.trec_cap & 3) || (b.g_tex && !b.trec_acc_tex) || (b.nmap && b.g_nmap && !b.trec_acc_nmap) || (b.debug_skip & 0xff) || b.Wt > 65535 || b.Ht > 65535)) return HARP_ERR_ARG;
   const RasterWs W = raster_ws_split((void*)a->recs, a->B, a->F, a->S);
@@ -804,9 +832,33 @@ int harp_depth_nmap_bwd(const int32_t* face_id, const void* ws, const int32_t* f
                         const float* nmap, const float* g_nmap_n, int n_texels, float* g_nmap, unsigned char* g_z_tiles, hipStream_t stream) {
   if (!face_id || !ws || !faces || !g_z || !g_ndc || !nmap || !g_nmap_n || !g_nmap || n_texels <= 0) return HARP_ERR_ARG;
   const RasterWs W = raster_ws_split((void*)ws, B, F, S);
-  const NmapBwd M{nmap, g_nmap_n, g_nmap, n_texels, min((n_texels + 255) / 256, 1024)};
+  const NmapBwd M{nmap, g_nmap_n, g_nmap, n_texels, min((n_texels + 255) / 256, 1024), nullptr, nullptr, nullptr, nullptr, 0, 0};
   hipLaunchKernelGGL((depth_bwd_kernel<true, true>), dim3(min(tile_grid(B, W.nsx), 4096u) + (unsigned)M.blocks), dim3(256), 0, stream, face_id,
                      (const FaceRec*)ws, faces, g_z, V, F, S, g_ndc, (const int32_t*)W.order, (const int32_t*)W.nact, B, W.nsx, M, g_z_tiles);
+  HARP_CHECK_LAUNCH();
+  return HARP_OK;
+}
+
+// harp_depth_bwd_tiles (consume; g_z_tiles optional) with up to two riders in the same launch: the normal map's chain rule (nmap != NULL:
+// harp_depth_nmap_bwd's) and the unpacking of the shader backward's interleaved vertex gradients (g_vert9 != NULL)
+int harp_depth_bwd_riders(const int32_t* face_id, const void* ws, const int32_t* faces, float* g_z, int B, int V, int F, int S, float* g_ndc,
+                          unsigned char* g_z_tiles, const float* nmap, const float* g_nmap_n, int n_texels, float* g_nmap, float* g_vert9,
+                          float* g_verts, float* g_vnormals, float* g_ndc_cam, hipStream_t stream) {
+  if (!face_id || !ws || !faces || !g_z || !g_ndc) return HARP_ERR_ARG;
+  if (nmap && (!g_nmap_n || !g_nmap || n_texels <= 0)) return HARP_ERR_ARG;
+  if (g_vert9 && (!g_verts || !g_vnormals || !g_ndc_cam)) return HARP_ERR_ARG;
+  const RasterWs W = raster_ws_split((void*)ws, B, F, S);
+  NmapBwd M{nmap, g_nmap_n, g_nmap, nmap ? n_texels : 0, nmap ? min((n_texels + 255) / 256, 1024) : 0,
+            g_vert9, g_verts, g_vnormals, g_ndc_cam, g_vert9 ? B * V : 0, g_vert9 ? min((B * V * 9 + 255) / 256, 1024) : 0};
+  hipLaunchKernelGGL((depth_bwd_kernel<true, true>), dim3(min(tile_grid(B, W.nsx), 4096u) + (unsigned)M.blocks + (unsigned)M.v9_blocks), dim3(256), 0, stream,
+                     face_id, (const FaceRec*)ws, faces, g_z, V, F, S, g_ndc, (const int32_t*)W.order, (const int32_t*)W.nact, B, W.nsx, M, g_z_tiles);
+  HARP_CHECK_LAUNCH();
+  return HARP_OK;
+}
+
+int harp_vert9_unpack(float* g_vert9, int n_verts, float* g_verts, float* g_vnormals, float* g_ndc, hipStream_t stream) {
+  if (!g_vert9 || !g_verts || !g_vnormals || !g_ndc || n_verts <= 0) return HARP_ERR_ARG;
+  hipLaunchKernelGGL(vert9_unpack_kernel, dim3(min((n_verts * 9 + 255) / 256, 1024)), dim3(256), 0, stream, g_vert9, g_verts, g_vnormals, g_ndc, n_verts);
   HARP_CHECK_LAUNCH();
   return HARP_OK;
 }

@@ -498,6 +498,7 @@ __device__ __forceinline__ void shade_bwd_tile(ShadeSmem<REC>& sm, unsigned vblo
   float* gvb = A.g_verts + (size_t)b * V * 3;
   float* gnb = A.g_vnormals + (size_t)b * V * 3;
   float* gdb = A.g_ndc + (size_t)b * V * 3;
+  float* g9b = A.g_vert9 ? A.g_vert9 + (size_t)b * V * 9 : nullptr;
   if (any_act) {
     if (!(dbg & 4) && geom) {
     // ---- vertex gradients: lanes on the same face add to the same three vertices: merge them first (xor distances 1, 2, 4 = x
@@ -541,8 +542,13 @@ __device__ __forceinline__ void shade_bwd_tile(ShadeSmem<REC>& sm, unsigned vblo
         } else {
 #pragma unroll
           for (int c = 0; c < 3; ++c) {
-            atomicAdd(at32m(gvb, 3u * (unsigned)v + c), vsc[9 * k + c]); atomicAdd(at32m(gnb, 3u * (unsigned)v + c), vsc[9 * k + 3 + c]);
-            atomicAdd(at32m(gdb, 3u * (unsigned)v + c), vsc[9 * k + 6 + c]);
+            if (g9b) {
+              atomicAdd(at32m(g9b, 9u * (unsigned)v + c), vsc[9 * k + c]); atomicAdd(at32m(g9b, 9u * (unsigned)v + 3 + c), vsc[9 * k + 3 + c]);
+              atomicAdd(at32m(g9b, 9u * (unsigned)v + 6 + c), vsc[9 * k + 6 + c]);
+            } else {
+              atomicAdd(at32m(gvb, 3u * (unsigned)v + c), vsc[9 * k + c]); atomicAdd(at32m(gnb, 3u * (unsigned)v + c), vsc[9 * k + 3 + c]);
+              atomicAdd(at32m(gdb, 3u * (unsigned)v + c), vsc[9 * k + 6 + c]);
+            }
           }
         }
       }
@@ -717,8 +723,12 @@ __device__ __forceinline__ void shade_bwd_tile(ShadeSmem<REC>& sm, unsigned vblo
       for (int j = 0; j < kQ; ++j) {
         const int i = lane + 64 * j, c = i % 9;
         if (i < kVSlots * 9 && vk[j] >= 0 && vv[j] != 0.f) {
-          float* dst = c < 3 ? gvb : (c < 6 ? gnb : gdb);
-          atomicAdd(at32m(dst, 3u * (unsigned)vk[j] + (c % 3)), vv[j]);
+          if (g9b) {
+            atomicAdd(at32m(g9b, 9u * (unsigned)vk[j] + c), vv[j]);          // a slot's 9 values are ONE 36-byte run (harp_shade_args.g_vert9)
+          } else {
+            float* dst = c < 3 ? gvb : (c < 6 ? gnb : gdb);
+            atomicAdd(at32m(dst, 3u * (unsigned)vk[j] + (c % 3)), vv[j]);
+          }
         }
       }
     }
@@ -729,6 +739,7 @@ __device__ __forceinline__ void shade_bwd_tile(ShadeSmem<REC>& sm, unsigned vblo
       if (v < 0) continue;
       const float val = VVAL_F(L.vval[c][sl], c);
       if (val == 0.f) continue;
+      if (g9b) { atomicAdd(at32m(g9b, 9u * (unsigned)v + c), val); continue; }
       float* dst = c < 3 ? gvb : (c < 6 ? gnb : gdb);
       atomicAdd(at32m(dst, 3u * (unsigned)v + (c % 3)), val);
     }

@@ -212,6 +212,7 @@ class FitEngine:
         self.trec_cap_min = 65536
         self._trec = self._tacc = None
         self._maps_pending = None
+        self.vert9 = True                # the shader backward's vertex gradients as ONE interleaved (B,V,9) buffer (a 36-byte run per vertex and wave instead of three 12-byte runs: a third of the memory-atomic lines), unpacked into the three arrays by extra workgroups of the depth backward's launch
         self.split_adam = True           # with the texel records: the maps' Adam update on the second stream behind harp_texel_finish, the step's last launch only for the small parameters
         self.fused_sil_bwd = False       # the silhouette backward inside the camera-view raster launch (harp_rasterize_l1_fwd_bwd) instead of a launch of its own beside the shader backward.  Correct (tests) and measured SLOWER: the shader backward gains 32 us without its neighbour (230 -> 198 in the graph), the camera raster pays 56 (198 -> 254: 94 VGPRs / 26 KB of LDS = 5 waves per SIMD instead of 7, and the rim walk is ~25 us of VALU work wherever it runs): step 0.665 vs 0.638 ms (profiles/r06_ab_record.txt)
         self.lean_app_stage = False      # appearance-only stage without the geometry gradients nothing reads (set by optimize_hand_sequence; off by default: g_buf then holds what autograd would)
@@ -258,6 +259,7 @@ class FitEngine:
         s["face_c"] = torch.empty(B, S, S, dtype=torch.int32, device=dev)
         s["face_l"] = torch.empty(B, S, S, dtype=torch.int32, device=dev)
         s["alpha"], s["zl"], s["rgb"] = f(B, S, S), f(B, S, S), f(B, S, S, 3)
+        s["g_v9"] = torch.zeros(B, V, 9, dtype=torch.float32, device=dev)       # harp_shade_args.g_vert9: all-zero between steps (its unpack clears it)
         s["zl_tiles"] = torch.zeros(B * ((S + 15) // 16) ** 2, dtype=torch.uint8, device=dev)     # harp_shade_args.g_zl_tiles: all-zero between steps
         s["zl_state"] = torch.zeros(B * ((S + 63) // 64) ** 2, dtype=torch.int32, device=dev)     # harp_rasterize_fwd_keep: which super-tiles of zl are all -1
         s["nmap_n"] = self.nmap_n
@@ -459,8 +461,10 @@ class FitEngine:
                      ("g_light_pos", s["g_light_pos"]), ("g_colors", s["g_colors"]),
                      ("g_light_R", s["g_light_R"] if self.self_shadow else None), ("g_light_T", s["g_light_T"] if self.self_shadow else None)):
             setattr(a, k, _lib.ptr(t))
+        if self.vert9:
+            a.g_vert9 = _lib.ptr(s["g_v9"])
         if getattr(self, "_lean_now", False):            # appearance-only stage: no geometry gradients out of the shader backward
-            a.g_verts = a.g_vnormals = a.g_ndc = None
+            a.g_verts = a.g_vnormals = a.g_ndc = a.g_vert9 = None
         # maps kept out of the optimiser (known_appearance, optimize_sequence.py:264-289): their gradients are not formed at all
         if "texture" in self.frozen:
             a.g_tex = None
@@ -828,11 +832,15 @@ class FitEngine:
                                                  self.Ht * self.Wt, ST()), "texel_finish")
                     self._allreduce_maps_early()
                 nmap_in_depth = self.fused_terms and self.self_shadow and self.consume_gzl and not (self.tail_side and self.overlap) and not nm_frozen and not records
+                # (with the interleaved vertex gradients the depth backward is launched below, with its riders)
+                v9_riders = bool(self.vert9 and not self._lean_now and self.self_shadow and self.consume_gzl)
                 ev_shade = cur.record_event() if (records and self.overlap) else None
                 if records and not self.overlap:
                     maps_branch()
                 elif records:
                     pass                                # (captured BEHIND the depth backward, below: the critical path keeps the shader's stream)
+                elif nmap_in_depth and v9_riders:
+                    pass
                 elif nmap_in_depth:
                     self._ck(L.harp_depth_nmap_bwd(p(s["face_l"]), p(s["ws_l"]), p(tp.faces), p(s["g_zl"]), B, V, F, S, p(s["g_ndc_l"]),
                                                    p(self.params["normal_map"]), p(s["g_nmap_n"]), self.Ht * self.Wt, p(self.grads["normal_map"]),
@@ -846,8 +854,22 @@ class FitEngine:
                     maps_tail()
             else:
                 nmap_in_depth, ev_shade = False, None
+            v9 = bool(self.vert9 and not self._lean_now)
+            depth_done = nmap_in_depth
+            if v9 and self.self_shadow and self.consume_gzl:
+                # the depth backward with its riders: the unpacking of the interleaved vertex gradients (and, table form, the normal map's chain rule)
+                self._ck(L.harp_depth_bwd_riders(p(s["face_l"]), p(s["ws_l"]), p(tp.faces), p(s["g_zl"]), B, V, F, S, p(s["g_ndc_l"]),
+                                                 p(s["zl_tiles"]) if self.zl_tile_flags else None,
+                                                 p(self.params["normal_map"]) if nmap_in_depth else None, p(s["g_nmap_n"]) if nmap_in_depth else None,
+                                                 self.Ht * self.Wt, p(self.grads["normal_map"]) if nmap_in_depth else None,
+                                                 p(s["g_v9"]), p(s["g_vd"]), p(s["g_n2"]), p(s["g_ndc_c"]), ST()), "depth_bwd_riders")
+                if nmap_in_depth:
+                    self._allreduce_maps_early()
+                depth_done = True
+            elif v9:
+                self._ck(L.harp_vert9_unpack(p(s["g_v9"]), B * V, p(s["g_vd"]), p(s["g_n2"]), p(s["g_ndc_c"]), ST()), "vert9_unpack")
             if self.self_shadow:
-                if not nmap_in_depth:
+                if not depth_done:
                     if self.consume_gzl and self.zl_tile_flags:
                         self._ck(L.harp_depth_bwd_tiles(p(s["face_l"]), p(s["ws_l"]), p(tp.faces), p(s["g_zl"]), B, V, F, S, p(s["g_ndc_l"]), p(s["zl_tiles"]),
                                                         ST()), "depth_bwd")
@@ -1239,7 +1261,7 @@ class FitEngine:
         # every switch the enqueued launch sequence depends on is part of the key: flipping one re-captures instead of replaying a
         # graph recorded for another configuration
         gkey = (coarse, app, scheduled, n, self.keep_image, self.fused_loss, self.self_shadow, tuple(self.frozen), self.overlap, self.early_terms,
-                self.packed_texels, self.fused_keep, self.mesh_third, self.graph_order, fold, self.fused_terms, self.zl_tile_flags, self.accumulate_loss, self.lean_app_stage, self.sil_only_raster, self.auto_draw, self.mesh_terms_late, self.sil_late, self.paired_setup, self.late_texture_terms, self.mesh_terms_first, self.camera_first, self.tail_side, self.fused_bwd, self.fused_chain, self.fused_front, self.wide_front, self.hybrid_front, self.front_auto, self.wide_back, self.fused_back, self.consume_gzl, self.keep_depth, self.texel_records, self.fused_sil_bwd, self.split_adam, dist_on, self.overlap_allreduce,
+                self.packed_texels, self.fused_keep, self.mesh_third, self.graph_order, fold, self.fused_terms, self.zl_tile_flags, self.accumulate_loss, self.lean_app_stage, self.sil_only_raster, self.auto_draw, self.mesh_terms_late, self.sil_late, self.paired_setup, self.late_texture_terms, self.mesh_terms_first, self.camera_first, self.tail_side, self.fused_bwd, self.fused_chain, self.fused_front, self.wide_front, self.hybrid_front, self.front_auto, self.wide_back, self.fused_back, self.consume_gzl, self.keep_depth, self.texel_records, self.fused_sil_bwd, self.split_adam, self.vert9, dist_on, self.overlap_allreduce,
                 self.comm is not None, self.perceptual is not None and app)
         g = self._graphs.get(gkey)
         if g is None:

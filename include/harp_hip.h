@@ -85,6 +85,14 @@ int harp_depth_nmap_bwd(const int32_t* face_id, const void* ws, const int32_t* f
                         const float* nmap, const float* g_nmap_n, int n_texels, float* g_nmap, unsigned char* g_z_tiles, hipStream_t stream);
 /* harp_depth_bwd_consume restricted to the tiles flagged in g_z_tiles (harp_shade_args.g_zl_tiles of the backward that filled g_z; NULL:
  * every tile); the flags of the tiles visited are cleared */
+/* g_vert9 (n_verts, 9) of harp_shade_args -> g_verts / g_vnormals / g_ndc (n_verts,3 each) +=, g_vert9 all-zero again */
+int harp_vert9_unpack(float* g_vert9, int n_verts, float* g_verts, float* g_vnormals, float* g_ndc, hipStream_t stream);
+/* harp_depth_bwd_tiles (g_z consumed; g_z_tiles optional) with up to two riders in the SAME launch (extra workgroups behind the tile workgroups:
+ * both only need the shader backward's output): nmap != NULL: harp_normalize3_bwd(nmap, g_nmap_n, n_texels, g_nmap); g_vert9 != NULL:
+ * harp_vert9_unpack(g_vert9, B * V, g_verts, g_vnormals, g_ndc_cam). */
+int harp_depth_bwd_riders(const int32_t* face_id, const void* ws, const int32_t* faces, float* g_z, int B, int V, int F, int S, float* g_ndc,
+                          unsigned char* g_z_tiles, const float* nmap, const float* g_nmap_n, int n_texels, float* g_nmap, float* g_vert9,
+                          float* g_verts, float* g_vnormals, float* g_ndc_cam, hipStream_t stream);
 int harp_depth_bwd_tiles(const int32_t* face_id, const void* ws, const int32_t* faces, float* g_z, int B, int V, int F, int S,
                          float* g_ndc, unsigned char* g_z_tiles, hipStream_t stream);
 
@@ -187,6 +195,11 @@ typedef struct harp_shade_args {
   int trec_cap;
   double* trec_acc_tex;    /* (Ht,Wt,3) doubles, the accumulators harp_texel_reduce adds into (required with trec unless the map is frozen) */
   double* trec_acc_nmap;
+  /* optional (harp_shade_bwd, production kernel): (B,V,9) (+=).  The three vertex gradients go HERE instead of into g_verts / g_vnormals /
+   * g_ndc, interleaved per vertex [g_verts(3) | g_vnormals(3) | g_ndc(3)]: a wave's table flush is then one 36-byte run per vertex instead of
+   * three 12-byte runs in three arrays — a third of the memory-atomic lines.  g_verts / g_vnormals / g_ndc must still be non-NULL (they say
+   * that geometry gradients are wanted) and stay untouched; harp_vert9_unpack or harp_depth_bwd_riders adds the buffer into them and clears it. */
+  float* g_vert9;
 } harp_shade_args;
 /* number of 32x32-texel UV tiles (record bins) of an (Ht, Wt) map */
 int harp_texel_bins(int Ht, int Wt);

@@ -1247,7 +1247,10 @@ def test_light_camera_incl_look_at_replacement_branch():
                                       # ... and the silhouette backward inside the camera-view raster launch (harp_rasterize_l1_fwd_bwd) vs the stand-alone launch beside the shader backward (default)
                                       dict(fused_sil_bwd=True), dict(fused_sil_bwd=True, texel_records=False), dict(fused_sil_bwd=True, graph_order=False), dict(fused_sil_bwd=True, overlap=False),
                                       dict(fused_sil_bwd=True, fold_step=False), dict(fused_sil_bwd=True, mesh_third=True),
-                                      dict(split_adam=False), dict(split_adam=False, texel_records=False)])
+                                      dict(split_adam=False), dict(split_adam=False, texel_records=False),
+                                      # the shader backward's vertex gradients as one interleaved buffer unpacked by riders of the depth backward (default) vs three arrays
+                                      dict(vert9=False), dict(vert9=False, texel_records=False), dict(vert9=True, texel_records=False), dict(vert9=True, consume_gzl=False),
+                                      dict(vert9=True, texel_records=False, fused_terms=False), dict(vert9=True, zl_tile_flags=True), dict(vert9=True, fused_bwd=True)])
 def test_schedule_switches_give_the_default_schedules_result(switches):
     """The stream / capture-order switches of FitEngine (graph_order, mesh_third, camera_first, overlap, early_terms, mesh_terms_first,
     tail_side) only move launches between streams: losses and the whole gradient arena of every non-default combination must equal the
@@ -2057,3 +2060,23 @@ def test_texel_reduce_and_finish_raw_abi_against_grid_sample_autograd(hw):
     # bad arguments launch nothing
     assert L.harp_texel_reduce(p(rec_d), p(cnt_d), cap + 2, H, W, p(acc[0]), p(acc[1]), st()) == 1
     assert L.harp_texel_reduce(p(rec_d), p(cnt_d), cap, 2048, 2048, p(acc[0]), p(acc[1]), st()) == 1
+
+
+def test_vert9_unpack_raw_abi():
+    """harp_vert9_unpack: the shader backward's interleaved vertex gradients (harp_shade_args.g_vert9, 9 floats per vertex) added into the three
+    per-vertex arrays and cleared; zeros are neither added nor written."""
+    from harp_amd import _lib
+    L, p, st = _lib.lib(), _lib.ptr, _lib.stream
+    g = torch.Generator().manual_seed(2)
+    n = 3 * 3093
+    g9 = torch.randn(n, 9, generator=g)
+    g9[torch.rand(n, generator=g) < 0.5] = 0.0
+    base = [torch.randn(n, 3, generator=g) for _ in range(3)]
+    g9_d = g9.to(DEV).contiguous()
+    out = [b.to(DEV).contiguous() for b in base]
+    _lib.check(L.harp_vert9_unpack(p(g9_d), n, p(out[0]), p(out[1]), p(out[2]), st()), "vert9_unpack")
+    torch.cuda.synchronize()
+    assert int((g9_d != 0).sum()) == 0
+    for k in range(3):
+        assert torch.equal(out[k].cpu(), base[k] + g9[:, 3 * k:3 * k + 3])
+    assert L.harp_vert9_unpack(None, n, p(out[0]), p(out[1]), p(out[2]), st()) == 1
