@@ -706,7 +706,15 @@ def main():
         timing_source = ("rocprofv3 --kernel-trace child over `python bench.py --steps 40 --warmup 8 --no-cpu-baseline --no-extras --no-roofline`: average "
                          "duration over the 40 timed graph replays (in the graph, next to the other streams' kernels)" if timing is kg else
                          "HIP events around the C-ABI call in an eager two-stream re-run of the steps (no rocprofv3 child: --no-profile, not on PATH, or failed)")
-        dom = max(timing, key=timing.get)            # dominant kernel group of the step by measured time
+        # dominant KERNEL of the step by measured time: a group's own big kernel decides (subs[0]), not the sum with its set-up launches —
+        # the camera-view group (raster + three set-up kernels, 0.232 ms) would otherwise outrank the shader backward (one kernel, 0.227 ms)
+        kmain = {}
+        if prof:
+            for grp, subs in _GROUP_KERNELS.items():
+                hit = [avg for name, (avg, n) in prof.items() if subs[0] in name]
+                if hit and grp in timing:
+                    kmain[grp] = max(hit) / 1e3
+        dom = max(kmain, key=kmain.get) if kmain else max(timing, key=timing.get)
         fused = "harp_shade_fwd" not in kt           # loss-only mode: the photometric L1 is formed inside the shader backward
         geom_pos = parts["V"] * 12 + parts["F"] * 12
         S2 = parts["S2"]

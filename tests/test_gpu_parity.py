@@ -1470,8 +1470,8 @@ def test_light_view_tile_flags_cover_the_shadow_map_gradient():
     L = _lib.lib()
     seen = {}
     # (the depth backward of the step: with the normal map's chain rule riding along in the table form of the shader backward, on its own
-    #  when the texel gradients leave as records)
-    names = ("harp_depth_nmap_bwd", "harp_depth_bwd_tiles")
+    #  when the texel gradients leave as records, with the vertex-gradient unpack riding when that buffer is on)
+    names = ("harp_depth_nmap_bwd", "harp_depth_bwd_tiles", "harp_depth_bwd_riders")
     orig = {n: getattr(L, n) for n in names}
 
     def spy(name):
