@@ -118,7 +118,7 @@ def kernel_roofline(eng, steps, overlap=False):
     from harp_amd import _lib
     L = _lib.lib()
     # (the fitting loop calls the light-view pass and its backward through the variants that keep their images across steps)
-    alias = {"harp_rasterize_fwd_keep": "raster_light", "harp_depth_bwd_consume": "harp_depth_bwd", "harp_depth_nmap_bwd": "harp_depth_bwd", "harp_depth_bwd_tiles": "harp_depth_bwd"}
+    alias = {"harp_rasterize_fwd_keep": "raster_light", "harp_depth_bwd_consume": "harp_depth_bwd", "harp_depth_nmap_bwd": "harp_depth_bwd", "harp_depth_bwd_tiles": "harp_depth_bwd", "harp_depth_bwd_riders": "harp_depth_bwd"}
     alias.update({"harp_texel_finish": "harp_texel_reduce"})        # (reduce + finish: the second half of the shader backward's texel gradients)
     names = ["harp_rasterize_fwd", "harp_rasterize_l1_fwd", "harp_shade_fwd", "harp_shade_bwd", "harp_silhouette_bwd", "harp_depth_bwd", "harp_texel_reduce"] + list(alias)
     rec = {n: [] for n in names}
