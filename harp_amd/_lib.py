@@ -72,7 +72,7 @@ SIGNATURES.update({
     "harp_shade_fwd": (_i, [ctypes.POINTER(ShadeArgs), _vp]),
     "harp_shade_bwd": (_i, [ctypes.POINTER(ShadeArgs), _vp]),
     "harp_texel_bins": (_i, [_i, _i]),
-    "harp_texel_reduce": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "harp_texel_reduce": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp]),
     "harp_texel_finish": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "harp_pack_texels": (_i, [_vp, _vp, _i, _vp, _vp]),
     "harp_normalize3_pack": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),

@@ -186,12 +186,18 @@ extern "C" {
 
 int harp_texel_bins(int Ht, int Wt) { return (Ht <= 0 || Wt <= 0) ? 0 : ((Ht + kBin - 1) / kBin) * ((Wt + kBin - 1) / kBin); }
 
-int harp_texel_reduce(const float* trec, int32_t* trec_cnt, int trec_cap, int Ht, int Wt, double* acc_tex, double* acc_nmap, hipStream_t stream) {
+int harp_texel_reduce(const float* trec, int32_t* trec_cnt, int trec_cap, int Ht, int Wt, double* acc_tex, double* acc_nmap, int expected_records,
+                      hipStream_t stream) {
   const int nbins = harp_texel_bins(Ht, Wt);
   if (!trec || !trec_cnt || trec_cap <= 0 || (trec_cap & 3) || ((size_t)trec & 15) || nbins <= 0 || nbins > kMaxBins || Wt > 65535 || Ht > 65535) return HARP_ERR_ARG;
-  // 512 workgroups of 512 threads, at most TWO per CU (61 KB of LDS each + 12 KB of dynamic LDS it does not use: a third one does not fit): the kernel runs
-  // beside the mesh / hand backward tail, whose small launches need wave slots on every CU
-  hipLaunchKernelGGL(texel_reduce_kernel, dim3(512), dim3(kThreads), 12 * 1024, stream, trec, trec_cnt, trec_cap, nbins, (Wt + kBin - 1) / kBin, Wt, Ht, acc_tex, acc_nmap);
+  // Launch shape.  The kernel runs beside the mesh / hand backward tail, whose workgroups (76 KB of LDS each) must find room on every CU:
+  //   small job (expected_records <= 2 M, or unknown: the C3 step's 1.4 M records are ~680 chunks): 256 workgroups, ONE per CU (61 KB + 21.5 KB of
+  //     dynamic LDS it does not use: a second one does not fit, a chain workgroup does) — chain_wide_bwd_b 21 -> 14 us, step -3.5 us
+  //   large job (C5: 4.9 M records, ~2 600 chunks): 512 workgroups, two per CU (12 KB pad: a third does not fit)
+  const bool small_job = expected_records <= 2000000;
+  const unsigned grid = small_job ? 256u : 512u;
+  const size_t pad = small_job ? 21504 : 12288;
+  hipLaunchKernelGGL(texel_reduce_kernel, dim3(grid), dim3(kThreads), pad, stream, trec, trec_cnt, trec_cap, nbins, (Wt + kBin - 1) / kBin, Wt, Ht, acc_tex, acc_nmap);
   // (a "last workgroup clears" ticket was measured first: the 512 same-address returning atomics put ~15 us under every workgroup's record loads)
   hipLaunchKernelGGL(texel_counters_clear_kernel, dim3(1), dim3(256), 0, stream, trec_cnt, nbins);
   HARP_CHECK_LAUNCH();

@@ -826,7 +826,7 @@ class FitEngine:
                 def maps_branch():
                     rec, cnt, cap = self._texel_record_buffers()
                     at, an = (None if "texture" in self.frozen else p(self._tacc[0])), (None if nm_frozen else p(self._tacc[1]))
-                    self._ck(L.harp_texel_reduce(p(rec), p(cnt), cap, self.Ht, self.Wt, at, an, ST()), "texel_reduce")
+                    self._ck(L.harp_texel_reduce(p(rec), p(cnt), cap, self.Ht, self.Wt, at, an, B * self.S * self.S // 6, ST()), "texel_reduce")
                     # float(exact sum) -> gradient arena, the normal map's through the chain rule of its normalisation
                     self._ck(L.harp_texel_finish(at, p(self.grads["texture"]), an, p(self.grads["normal_map"]), p(self.params["normal_map"]),
                                                  self.Ht * self.Wt, ST()), "texel_finish")

@@ -330,7 +330,7 @@ class _Shade(torch.autograd.Function):
         _lib.check(_lib.lib().harp_shade_bwd(a, _lib.stream()), "harp_shade_bwd")
         if bufs is not None:
             at, an = _lib.ptr(bufs[3][0]), (_lib.ptr(bufs[3][1]) if g_nmap is not None else None)
-            _lib.check(_lib.lib().harp_texel_reduce(_lib.ptr(bufs[0]), _lib.ptr(bufs[1]), bufs[2], a.Ht, a.Wt, at, an, _lib.stream()), "harp_texel_reduce")
+            _lib.check(_lib.lib().harp_texel_reduce(_lib.ptr(bufs[0]), _lib.ptr(bufs[1]), bufs[2], a.Ht, a.Wt, at, an, B * S * S // 6, _lib.stream()), "harp_texel_reduce")
             _lib.check(_lib.lib().harp_texel_finish(at, _lib.ptr(g_tex), an, _lib.ptr(g_nmap), None, a.Ht * a.Wt, _lib.stream()), "harp_texel_finish")
         return (g_ndc, g_verts, g_vn, g_tex, g_nmap, g_lp, g_col, g_zl, g_lR.view(B, 3, 3) if g_lR is not None else None, g_lT,
                 None, None, None, None, None, None, None)

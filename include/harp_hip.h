@@ -208,8 +208,10 @@ int harp_texel_bins(int Ht, int Wt);
  * 6 channel 64-bit fixed-point accumulator in LDS (the extra row / column takes the footprints of the tile's last row / column; sums
  * exact and independent of the order of the records), added to the double maps with row-contiguous memory atomics — the gradient a texel
  * ends up with is float(exact sum) however the frames were batched.  Either map pointer may be NULL (frozen map).  The counters are
- * all-zero again when the call has run. */
-int harp_texel_reduce(const float* trec, int32_t* trec_cnt, int trec_cap, int Ht, int Wt, double* acc_tex, double* acc_nmap, hipStream_t stream);
+ * all-zero again when the call has run.  expected_records: a hint for the launch shape only (<= 2 M or <= 0: one workgroup per CU, which leaves
+ * LDS for the kernels that run beside it; more: two) — e.g. a sixth of B * S * S. */
+int harp_texel_reduce(const float* trec, int32_t* trec_cnt, int trec_cap, int Ht, int Wt, double* acc_tex, double* acc_nmap, int expected_records,
+                      hipStream_t stream);
 /* third and last part: g_tex (n_texels,3) += float(acc_tex), g_nmap += float(acc_nmap) — with nmap_raw != NULL through the chain rule of
  * F.normalize(nmap_raw, dim=-1) (utils/visualize.py:99; harp_normalize3_bwd's arithmetic: acc_nmap is then the gradient of the NORMALISED
  * map, g_nmap that of the raw one) — and both accumulators are all-zero again.  A NULL accumulator skips that map. */

@@ -2042,7 +2042,7 @@ def test_texel_reduce_and_finish_raw_abi_against_grid_sample_autograd(hw):
     acc = torch.zeros(2, H * W * 3, dtype=torch.float64, device=DEV)
     g_tex, g_nm = torch.zeros(H, W, 3, device=DEV), torch.zeros(H, W, 3, device=DEV)
     nraw_d = nraw.detach().float().to(DEV).contiguous()
-    _lib.check(L.harp_texel_reduce(p(rec_d), p(cnt_d), cap, H, W, p(acc[0]), p(acc[1]), st()), "reduce")
+    _lib.check(L.harp_texel_reduce(p(rec_d), p(cnt_d), cap, H, W, p(acc[0]), p(acc[1]), N, st()), "reduce")
     torch.cuda.synchronize()
     assert int(cnt_d.abs().max()) == 0
     a0 = acc[0].view(H, W, 3).cpu()
@@ -2054,12 +2054,12 @@ def test_texel_reduce_and_finish_raw_abi_against_grid_sample_autograd(hw):
     assert rel(g_tex.double().cpu(), want_t) < 2e-7 and rel(g_nm.double().cpu(), want_n) < 2e-6, (rel(g_tex.double().cpu(), want_t), rel(g_nm.double().cpu(), want_n))
     # frozen maps: a NULL accumulator leaves that map out
     cnt_d.copy_(cnt.to(DEV))
-    _lib.check(L.harp_texel_reduce(p(rec_d), p(cnt_d), cap, H, W, p(acc[0]), None, st()), "reduce (texture only)")
+    _lib.check(L.harp_texel_reduce(p(rec_d), p(cnt_d), cap, H, W, p(acc[0]), None, 0, st()), "reduce (texture only)")
     torch.cuda.synchronize()
     assert int((acc[1] != 0).sum()) == 0 and int((acc[0] != 0).sum()) > 0
     # bad arguments launch nothing
-    assert L.harp_texel_reduce(p(rec_d), p(cnt_d), cap + 2, H, W, p(acc[0]), p(acc[1]), st()) == 1
-    assert L.harp_texel_reduce(p(rec_d), p(cnt_d), cap, 2048, 2048, p(acc[0]), p(acc[1]), st()) == 1
+    assert L.harp_texel_reduce(p(rec_d), p(cnt_d), cap + 2, H, W, p(acc[0]), p(acc[1]), N, st()) == 1
+    assert L.harp_texel_reduce(p(rec_d), p(cnt_d), cap, 2048, 2048, p(acc[0]), p(acc[1]), N, st()) == 1
 
 
 def test_vert9_unpack_raw_abi():

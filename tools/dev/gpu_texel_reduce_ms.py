@@ -15,7 +15,7 @@ print("records", int(c.sum()), "bins used", int((c > 0).sum()), "max", int(c.max
 L, p = _lib.lib(), _lib.ptr
 gt, gn = (torch.zeros(eng.Ht * eng.Wt * 3, dtype=torch.float64, device="cuda") for _ in range(2))
 def run(n):
-    for _ in range(n): L.harp_texel_reduce(p(rec), p(cnt), cap, eng.Ht, eng.Wt, p(gt), p(gn), _lib.stream())
+    for _ in range(n): L.harp_texel_reduce(p(rec), p(cnt), cap, eng.Ht, eng.Wt, p(gt), p(gn), int(c.sum()), _lib.stream())
 run(3); torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record(); run(20); e1.record(); torch.cuda.synchronize()
