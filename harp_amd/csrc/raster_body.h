@@ -3,6 +3,7 @@
 #pragma once
 #include "harp_common.h"
 #include "harp_hip.h"
+#include <type_traits>
 
 namespace rb {
 
@@ -79,20 +80,21 @@ struct RasterSmem {
   int32_t s_id[kCap];
   int lds_cnt[4];
   unsigned long long zkey[MODE <= 1 ? 256 : 1];   // face-scan walk (MODE 0 / 1): per pixel min over (depth bits << 32 | face id)
-  // face scan: staged faces ordered by the number of 4x4 blocks their bbox covers in this tile (counting sort, descending), so that the
-  // four 16-lane groups of a wave walk faces of (nearly) equal length; faces whose bbox holds no pixel centre drop out
-  unsigned char perm[MODE <= 1 ? kStage : 1];
-  int hist[MODE <= 1 ? 36 : 1];
+  // dense scan: the staged faces with pixels in this tile, compacted: start slot of each in the tile's (face, pixel) slot sequence (+ the
+  // total behind the last), and staged index | tile-local bbox origin | bbox width - 1
+  int s_pre[MODE <= 1 ? kStage + 1 : 1];
+  unsigned s_fb[MODE == 0 ? kStage : 1];           // (MODE 1: the pair rings' 1 KB, which only the soft pass behind the scan uses)
   // MODE 1, soft silhouette: sat = some face covers the pixel deeper than the sigmoid's float32 range (alpha = 1 exactly);
   // prodl = running product of (1 - p) over the other faces within the blur radius, in ascending face order; cand = pixels not (yet) saturated
-  int sat[MODE == 1 ? 256 : 1];
+  // (bytes; the fused-backward form re-uses the array as 256 floats)
+  typename std::conditional<BWD, int, unsigned char>::type sat[MODE == 1 ? 256 : 1];
   float prodl[MODE == 1 ? 256 : 1];
   unsigned char cand[MODE == 1 ? 256 : 1];
   float ndc_x[kTile], ndc_y[kTile];               // pixel-centre NDC of the tile's columns / rows (pix_to_ndc holds an IEEE division)
   // pixel-centric pair walk (MODE 2): the tile's rim pixels (coordinates, P = 1 - alpha, upstream gradient), compacted, and the
   // (rim pixel, staged face) pairs whose pixel lies in the face's bbox
   float rp_x[MODE == 2 ? 256 : 1], rp_y[MODE == 2 ? 256 : 1], rp_P[MODE == 2 ? 256 : 1], rp_g[MODE == 2 ? 256 : 1];
-  unsigned short pairs[MODE >= 1 ? 512 : 1];      // 4 waves x 128-entry ring of (pixel, staged face) pairs
+  alignas(4) unsigned short pairs[MODE >= 1 ? 512 : 1];      // 4 waves x 128-entry ring of (pixel, staged face) pairs
   // MODE 2: per-staged-face gradient accumulators (x,y of 3 verts).  double: ds_add_f64 is ~20x faster than ds_add_f32 on gfx950
   double s_g[MODE == 2 ? kCap : 1][6];
   // MODE 1 + BWD: the same accumulators as float (6 KB instead of 12: the forward pass lives on its occupancy) — a few dozen pairs per tile add
@@ -289,63 +291,85 @@ __device__ __forceinline__ void raster_tile(RasterSmem<MODE, BWD>& sm, unsigned 
       //      4x4 blocks; the nearest face of a pixel is a 64-bit LDS min over (depth bits, face id) — the same (pixel, face) pairs,
       //      the same depth expression and the same tie-break (lower id) as the strip walk below, where every face of a strip's hit
       //      list was classified by all 64 lanes of the strip (~8 % of them inside its bbox).
-      // RASTER_BH: rows of a scan block (4: a 16-lane group per face, 4x4 blocks; 2: an 8-lane group per face, 4x2 blocks — twice the faces per
-      // wave instruction and less of a small bbox's last block wasted; same (pixel, face) pairs and arithmetic either way)
-#ifndef RASTER_BH
-#define RASTER_BH 4
-#endif
-      constexpr int kBH = RASTER_BH, kGrp = 4 * kBH, kGroups = 256 / kGrp, kMaxNb = 4 * (16 / kBH);
-      const int grp = threadIdx.x / kGrp, gl = threadIdx.x % kGrp, lx = gl & 3, ly = gl >> 2;
+      // DENSE PACKING: the walk visits (staged face, pixel of its bbox clipped to the tile) pairs, one pair per lane, every lane busy: the
+      // pairs are numbered face after face (a prefix sum over the faces' clipped bbox sizes), a wave owns a contiguous quarter of the
+      // numbers and tracks the face its first lane is in; the starts of the next 64 faces sit in one register across the wave, and a lane's
+      // face is the number of those starts at or below its slot.  (The blocked walk spent 3.7 blocks x 16 lanes per (face, tile) for a
+      // bbox of ~25 pixels.)
       const float hs = 0.5f * (float)S;
-      // ---- order the staged faces by block count (descending): thread = staged face
-      int nscan = nl;
+      unsigned* s_fb = (MODE == 1) ? reinterpret_cast<unsigned*>(sm.pairs) : sm.s_fb;
+      int nf, T;
       {
-        int nb = 0;
+        int cnt = 0;
+        unsigned box = 0;
         if ((int)threadIdx.x < nl) {
           const float4 q = s_bb[threadIdx.x];
+          // pixel-centre columns / rows that can lie in the bbox (pixel coordinate of NDC n: (1 - n) S / 2 - 1/2; 1e-3 px of slack,
+          // the exact comparison below decides), clipped to the tile
           const int x0 = max((int)ceilf((1.0f - q.y) * hs - 0.501f), tx0), x1 = min(min((int)floorf((1.0f - q.x) * hs - 0.499f), tx0 + kTile - 1), S - 1);
           const int y0 = max((int)ceilf((1.0f - q.w) * hs - 0.501f), ty0), y1 = min(min((int)floorf((1.0f - q.z) * hs - 0.499f), ty0 + kTile - 1), S - 1);
-          if (x0 <= x1 && y0 <= y1) nb = (((x1 - x0) >> 2) + 1) * (((y1 - y0) / kBH) + 1);      // 1 .. kMaxNb
+          if (x0 <= x1 && y0 <= y1) {
+            cnt = (x1 - x0 + 1) * (y1 - y0 + 1);                                                 // 1 .. 256
+            box = (unsigned)(x0 - tx0) | ((unsigned)(y0 - ty0) << 4) | ((unsigned)(x1 - x0) << 8);
+          }
         }
-        if (threadIdx.x < 36) sm.hist[threadIdx.x] = 0;
+        // block-wide exclusive scan of (pixels | faces-with-pixels << 20)
+        const int own = cnt + ((cnt > 0) << 20);
+        int v = own;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+          const int u = __shfl_up(v, d);
+          if (lane >= d) v += u;
+        }
+        if (lane == 63) lds_cnt[w] = v;
         __syncthreads();
-        int rank = 0;
-        if (nb > 0) rank = atomicAdd(&sm.hist[kMaxNb - nb], 1);
-        __syncthreads();
-        int base_b = 0;
-        for (int i = 0; i < kMaxNb - nb; ++i) base_b += sm.hist[i];
-        if (nb > 0) sm.perm[base_b + rank] = (unsigned char)threadIdx.x;
-        int tot = 0;
-        for (int i = 0; i < kMaxNb; ++i) tot += sm.hist[i];
-        nscan = tot;
+        int off = 0, tot = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { const int c = lds_cnt[i]; tot += c; if (i < w) off += c; }
+        const int excl = v + off - own;
+        nf = tot >> 20; T = tot & 0xfffff;
+        if (cnt > 0) {
+          sm.s_pre[excl >> 20] = excl & 0xfffff;
+          s_fb[excl >> 20] = threadIdx.x | (box << 8);
+        }
+        if (threadIdx.x == 0) sm.s_pre[nf] = T;
         __syncthreads();
       }
-      for (int k0 = 0; k0 < nscan; k0 += kGroups) {
-        const int ks = k0 + grp;
-        const bool valid = ks < nscan;
-        const int kk = valid ? (int)sm.perm[ks] : 0;
-        const float4 q = s_bb[kk];
-        // pixel-centre columns / rows that can lie in the bbox (pixel coordinate of NDC n: (1 - n) S / 2 - 1/2; 1e-3 px of slack,
-        // the exact comparison below decides), clipped to the tile
-        const int x0 = max((int)ceilf((1.0f - q.y) * hs - 0.501f), tx0), x1 = min(min((int)floorf((1.0f - q.x) * hs - 0.499f), tx0 + kTile - 1), S - 1);
-        const int y0 = max((int)ceilf((1.0f - q.w) * hs - 0.501f), ty0), y1 = min(min((int)floorf((1.0f - q.z) * hs - 0.499f), ty0 + kTile - 1), S - 1);
-        bool more = valid && x0 <= x1 && y0 <= y1;
-        if (!__any(more)) continue;
-        const Tri t = tri_from(s_a[kk], s_b[kk], make_float4(s_z2[kk], 0.f, 0.f, 0.f));
-        const int fid = s_id[kk];
-        const float area = edge_fn(t.x2, t.y2, t.x0, t.y0, t.x1, t.y1) + kEps;
-        const float sg = (area > 0.f) ? 1.f : ((area < 0.f) ? -1.f : 0.f);
-        const float ra = __builtin_amdgcn_rcpf(area);
-        const float K18 = 18.0f * sigma;
-        const float l12 = (t.x2 - t.x1) * (t.x2 - t.x1) + (t.y2 - t.y1) * (t.y2 - t.y1);
-        const float l20 = (t.x0 - t.x2) * (t.x0 - t.x2) + (t.y0 - t.y2) * (t.y0 - t.y2);
-        const float l01 = (t.x1 - t.x0) * (t.x1 - t.x0) + (t.y1 - t.y0) * (t.y1 - t.y0);
-        int bx = x0, by = y0;
-        while (__any(more)) {
-          if (more) {
-            const int xs = bx + lx, ys = by + ly;
-            if (xs <= x1 && ys <= y1) {
-              const float qx = sm.ndc_x[xs - tx0], qy = sm.ndc_y[ys - ty0];
+      if (T > 0) {
+        const int per = (((T + 3) >> 2) + 63) & ~63;
+        const int s_lo = w * per, s_end = min(T, s_lo + per);
+        if (s_lo < s_end) {
+          // the face that holds this wave's first slot: the number of starts <= s_lo, minus one
+          int kb = -1;
+#pragma unroll
+          for (int j = 0; j < kStage / 64; ++j) {
+            const int idx = j * 64 + lane;
+            kb += __popcll(__ballot(idx < nf && sm.s_pre[idx] <= s_lo));
+          }
+          int pkb = sm.s_pre[kb];
+          const float K18 = 18.0f * sigma;
+          for (int sb = s_lo; sb < s_end; sb += 64) {
+            const int sl = sb + lane;
+            const int pw = sm.s_pre[min(kb + 1 + lane, nf)];             // lane j: the start of face kb + 1 + j (the total behind the last)
+            int k = kb, pk = pkb;
+            const int lim = min(sb + 64, s_end);
+            for (int j = 0; j < 64; ++j) {
+              const int p = __builtin_amdgcn_readlane(pw, j);
+              if (p >= lim) break;
+              if (sl >= p) { ++k; pk = p; }
+              ++kb; pkb = p;
+            }
+            if (sl < s_end) {
+              const unsigned fb = s_fb[k];
+              const int kk = fb & 255, wd = (int)((fb >> 16) & 15) + 1;
+              const int r = sl - pk;
+              const int ry = (int)(((float)r + 0.5f) * __builtin_amdgcn_rcpf((float)wd));     // r / wd ((r + 1/2) / wd is >= 1/32 from an integer)
+              const int xl = (int)((fb >> 8) & 15) + r - ry * wd, yl = (int)((fb >> 12) & 15) + ry;
+              const float qx = sm.ndc_x[xl], qy = sm.ndc_y[yl];
+              const float4 q = s_bb[kk];
+              const Tri t = tri_from(s_a[kk], s_b[kk], make_float4(s_z2[kk], 0.f, 0.f, 0.f));
+              const float area = edge_fn(t.x2, t.y2, t.x0, t.y0, t.x1, t.y1) + kEps;
+              const float sg = (area > 0.f) ? 1.f : ((area < 0.f) ? -1.f : 0.f);
               // (same predicate as !(qx > q.y || qx < q.x || qy > q.w || qy < q.z) for finite operands, as two median-of-three
               //  instructions + two compares instead of four compares and the mask arithmetic that joins them)
               const bool inbox = __builtin_amdgcn_fmed3f(qx, q.x, q.y) == qx && __builtin_amdgcn_fmed3f(qy, q.z, q.w) == qy;
@@ -354,23 +378,24 @@ __device__ __forceinline__ void raster_tile(RasterSmem<MODE, BWD>& sm, unsigned 
               const float e2 = edge_fn(qx, qy, t.x0, t.y0, t.x1, t.y1);
               if (inbox && (e0 * sg > 0.f) && (e1 * sg > 0.f) && (e2 * sg > 0.f)) {
                 // BarycentricCoordsForward + PerspectiveCorrection with reciprocals (<= 2 ulp from the IEEE-division form)
-                const int pix = (ys - ty0) * kTile + (xs - tx0);
+                const int pix = yl * kTile + xl;
                 if (MODE != 1 || face_id) {        // (camera view without face ids — the geometry-only stage: the silhouette needs no nearest face)
+                  const float ra = __builtin_amdgcn_rcpf(area);
                   const float t0 = (e0 * ra) * t.z1 * t.z2, t1 = t.z0 * (e1 * ra) * t.z2, t2 = t.z0 * t.z1 * (e2 * ra);
                   const float rd = __builtin_amdgcn_rcpf(fmaxf(t0 + t1 + t2, kEps));
                   const float pz = (t0 * rd) * t.z0 + (t1 * rd) * t.z1 + (t2 * rd) * t.z2;
-                  if (pz >= 0.f && pz < 3.0e38f) atomicMin(&sm.zkey[pix], ((unsigned long long)__float_as_uint(pz) << 32) | (unsigned)fid);
+                  if (pz >= 0.f && pz < 3.0e38f) atomicMin(&sm.zkey[pix], ((unsigned long long)__float_as_uint(pz) << 32) | (unsigned)s_id[kk]);
                 }
                 if (MODE == 1) {
                   // deeper than sqrt(18 sigma) inside every edge LINE (<= segment distance): sigmoid saturates to exactly 1 in
                   // fp32 (exp(-18) < 2^-24), so the factor (1-p) is exactly 0 — the pixel's alpha is 1 whatever the other faces do
+                  const float l12 = (t.x2 - t.x1) * (t.x2 - t.x1) + (t.y2 - t.y1) * (t.y2 - t.y1);
+                  const float l20 = (t.x0 - t.x2) * (t.x0 - t.x2) + (t.y0 - t.y2) * (t.y0 - t.y2);
+                  const float l01 = (t.x1 - t.x0) * (t.x1 - t.x0) + (t.y1 - t.y0) * (t.y1 - t.y0);
                   if (e0 * e0 > K18 * l12 && e1 * e1 > K18 * l20 && e2 * e2 > K18 * l01) sm.sat[pix] = 1;
                 }
               }
             }
-            bx += 4;
-            if (bx > x1) { bx = x0; by += kBH; }
-            more = by <= y1;
           }
         }
       }
