@@ -412,8 +412,24 @@ __device__ __forceinline__ void raster_tile(RasterSmem<MODE, BWD>& sm, unsigned 
         if (ncand > 0) {
           unsigned short* wl = sm.pairs + w * 128;
           const int cper = (ncand + 3) >> 2, c_lo = min(ncand, w * cper), c_hi = min(ncand, (w + 1) * cper);
-          const int i_lo = c_lo * nl, i_end = c_hi * nl;
-          const float inv_nl = 1.0f / (float)nl;
+          // the wave's candidates are a band of the tile's rows (the list is in pixel order): only the staged faces whose bbox reaches the band
+          // are paired with them — a wave-local sub-list, in the staged (= ascending face) order, in the scan's dead prefix array
+          unsigned char* sub = reinterpret_cast<unsigned char*>(sm.s_pre) + w * 256;
+          int nlw = 0;
+          if (c_lo < c_hi) {
+            const float ya = sm.ndc_y[sm.cand[c_lo] >> 4], yb = sm.ndc_y[sm.cand[c_hi - 1] >> 4];
+            const float by_lo = fminf(ya, yb), by_hi = fmaxf(ya, yb);
+            for (int k0 = 0; k0 < nl; k0 += 64) {
+              const int k = k0 + lane;
+              bool hit = false;
+              if (k < nl) { const float4 q = s_bb[k]; hit = !(by_lo > q.w || by_hi < q.z); }
+              const unsigned long long m = __ballot(hit);
+              if (hit) sub[nlw + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned char)k;
+              nlw += __popcll(m);
+            }
+          }
+          const int i_end = (c_hi - c_lo) * nlw;
+          const float inv_nl = 1.0f / (float)max(nlw, 1);
           int head = 0, tail = 0;
           auto process = [&](int nvalid) {
             float f = 1.0f;
@@ -467,15 +483,16 @@ __device__ __forceinline__ void raster_tile(RasterSmem<MODE, BWD>& sm, unsigned 
             }
             if (first) sm.prodl[c] = pacc;
           };
-          for (int i0 = i_lo; i0 < i_end; i0 += 64) {
+          for (int i0 = 0; i0 < i_end; i0 += 64) {
             const int i = i0 + lane;
             bool pass = false;
             int c = 0, k = 0;
             if (i < i_end) {
               int ci = (int)(((float)i + 0.5f) * inv_nl);
-              k = i - ci * nl;
-              if (k < 0) { --ci; k += nl; } else if (k >= nl) { ++ci; k -= nl; }
-              c = sm.cand[ci];
+              k = i - ci * nlw;
+              if (k < 0) { --ci; k += nlw; } else if (k >= nlw) { ++ci; k -= nlw; }
+              c = sm.cand[c_lo + ci];
+              k = sub[k];
               const float4 q = s_bb[k];
               const float qx = sm.ndc_x[c & (kTile - 1)], qy = sm.ndc_y[c >> 4];
               pass = !(qx > q.y || qx < q.x || qy > q.w || qy < q.z);
