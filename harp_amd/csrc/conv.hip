@@ -513,7 +513,8 @@ __global__ __launch_bounds__(256) void vgg_grad_image_kernel(const float* __rest
   const int n = blockIdx.z, x0 = blockIdx.x * kCT, y0 = blockIdx.y * kCT;
   // (the accumulator is complete: every forward launch is behind this one on the stream.  It is handed back ZERO for the next call — the
   //  workspace starts zero-filled —, so the term needs no clear of its own: a captured hipMemsetAsync did not re-execute on replay, App. A)
-  if (t == 0 && blockIdx.x == 0 && blockIdx.y == 0 && n == 0) {
+  // (loss_acc == NULL: the term runs as two half batches on two streams and a launch behind their join does this, vgg_loss_finish_kernel)
+  if (loss_acc && t == 0 && blockIdx.x == 0 && blockIdx.y == 0 && n == 0) {
     if (loss_out) loss_out[0] = (float)loss_acc[0];
     loss_acc[0] = 0.0;
   }
@@ -571,6 +572,11 @@ __global__ __launch_bounds__(256) void vgg_grad_image_kernel(const float* __rest
   g_rgb[o] += weight * m * (o0 + scale0 * sgn(d0));
   g_rgb[o + 1] += weight * m * (o1 + scale0 * sgn(d1));
   g_rgb[o + 2] += weight * m * (o2 + scale0 * sgn(d2));
+}
+
+__global__ void vgg_loss_finish_kernel(double* __restrict__ loss_acc, float* __restrict__ loss_out) {
+  if (loss_out) loss_out[0] = (float)loss_acc[0];
+  loss_acc[0] = 0.0;
 }
 
 // ---- workspace of the whole term ------------------------------------------------------------------------------------------------------
@@ -718,7 +724,14 @@ int harp_conv3x3(const harp_conv3x3_args* a, hipStream_t stream) {
 
 size_t harp_vgg16_ws_bytes(int N, int S, int with_gradient) {
   if (N <= 0 || S <= 0 || (S & 7)) return 0;
-  return vgg_ws_split(nullptr, N, S, with_gradient).bytes;
+  // (harp_vgg16_term with side streams lays the workspace out as 2 - 4 parts of the batch, each with its own 256-byte paddings)
+  size_t most = vgg_ws_split(nullptr, N, S, with_gradient).bytes;
+  for (int parts = 2; parts <= 4 && parts <= N; ++parts) {
+    size_t sum = 0;
+    for (int i = 0; i < parts; ++i) sum += vgg_ws_split(nullptr, N / parts + (i < N % parts ? 1 : 0), S, with_gradient).bytes;
+    if (sum > most) most = sum;
+  }
+  return most;
 }
 
 int harp_vgg16_features(const harp_vgg16* net, const float* image, const float* mask, const int32_t* rows, int N, int S, void* ws,
@@ -739,7 +752,6 @@ int harp_vgg16_term(const harp_vgg16* net, const harp_vgg16_term_args* t, hipStr
   for (int k = 0; k < 4; ++k)
     if (!t->target[k]) return HARP_ERR_ARG;
   const int N = t->N, S = t->S;
-  const VggWs w = vgg_ws_split(t->ws, N, S, 1);
   float scale[5];
   vgg_scales(net, N, S, scale);
   // every argument is checked before the first launch: vgg_prep_kernel adds into the workspace's loss accumulator, which only the LAST
@@ -757,45 +769,89 @@ int harp_vgg16_term(const harp_vgg16* net, const harp_vgg16_term_args* t, hipStr
       if (!t->target_in[k]) return HARP_ERR_ARG;
       bd.target_in[k] = t->target_in[k];
     }
-    bd.rows = t->rows;
   }
-  hipLaunchKernelGGL(vgg_prep_kernel, dim3((S * S + 255) / 256, N), dim3(256), 0, stream, t->rgb, (const int32_t*)nullptr, t->mask, t->rows, t->y_true, S,
-                     scale[0], w.x0, w.loss);
-  HARP_CHECK_LAUNCH();
-  int rc = vgg_forward(net, w, N, S, nullptr, t->target, t->target_by_row ? t->rows : nullptr, scale, bounded ? &bd : nullptr, stream);
-  if (rc != HARP_OK) return rc;
-  // backward: data gradients only.  G(relu4_3) = its tap gradient; then convolution by convolution towards the image
-  const float* g = w.g_tap[3];
-  int flip = 0;
-  for (int k = 9; k >= 1; --k) {
-    harp_conv3x3_args a = {};
-    const int s = S / kVggDiv[k], lv = vgg_level(k);
-    a.in = g; a.filters = net->filters_t[k];
-    a.N = N; a.H = s; a.W = s; a.Cin = kVggCout[k]; a.Cout = kVggCin[k];
-    a.precision = net->precision;
-    int tap = -1;
-    for (int j = 0; j < 3; ++j)
-      if (kVggTap[j] == k - 1) tap = j;                 // the layer below is a tap layer followed by the pool: route through it
-    if (tap >= 0) {
-      a.epilogue = HARP_CONV_UNPOOL; a.out = w.g_tap[tap]; a.gate = w.act[k - 1];
-    } else {
-      a.epilogue = HARP_CONV_GATE; a.out = w.gbuf[flip]; a.gate = w.act[k - 1];
-      flip ^= 1;
-    }
-    if (bounded) {       // the gradient lives in the level's active tiles and is zero elsewhere
-      a.target_row = bd.rows;
-      a.tile_list = bd.list[lv]; a.tile_count = bd.count[lv]; a.max_tiles = bd.max_tiles[lv];
-      a.tile_origin = bd.origin[lv]; a.tile_pitch = bd.pitch[lv];
-      a.in_valid = bd.tiles[lv]; a.in_valid_origin = bd.origin[lv]; a.in_valid_pitch = bd.pitch[lv]; a.in_valid_shift = 1;
-      if (tap >= 0) { a.out_valid = bd.tiles[lv - 1]; a.out_valid_origin = bd.origin[lv - 1]; a.out_valid_pitch = bd.pitch[lv - 1]; }
-    }
-    rc = harp_conv3x3(&a, stream);
+  // images [n0, n0 + Nh) of the batch on stream st with workspace w; `finish`: the last launch hands the loss out and its accumulator back zeroed
+  auto run = [&](int n0, int Nh, const VggWs& w, hipStream_t st, bool finish) -> int {
+    const size_t px = (size_t)n0 * S * S;
+    const int32_t* rows = t->rows ? t->rows + n0 : nullptr;
+    VggBound b = bd;
+    b.rows = rows;
+    hipLaunchKernelGGL(vgg_prep_kernel, dim3((S * S + 255) / 256, Nh), dim3(256), 0, st, t->rgb + px * 3, (const int32_t*)nullptr, t->mask, rows, t->y_true, S,
+                       scale[0], w.x0, w.loss);
+    HARP_CHECK_LAUNCH();
+    int rc = vgg_forward(net, w, Nh, S, nullptr, t->target, t->target_by_row ? rows : nullptr, scale, bounded ? &b : nullptr, st);
     if (rc != HARP_OK) return rc;
-    g = a.out;
+    // backward: data gradients only.  G(relu4_3) = its tap gradient; then convolution by convolution towards the image
+    const float* g = w.g_tap[3];
+    int flip = 0;
+    for (int k = 9; k >= 1; --k) {
+      harp_conv3x3_args a = {};
+      const int s = S / kVggDiv[k], lv = vgg_level(k);
+      a.in = g; a.filters = net->filters_t[k];
+      a.N = Nh; a.H = s; a.W = s; a.Cin = kVggCout[k]; a.Cout = kVggCin[k];
+      a.precision = net->precision;
+      int tap = -1;
+      for (int j = 0; j < 3; ++j)
+        if (kVggTap[j] == k - 1) tap = j;                 // the layer below is a tap layer followed by the pool: route through it
+      if (tap >= 0) {
+        a.epilogue = HARP_CONV_UNPOOL; a.out = w.g_tap[tap]; a.gate = w.act[k - 1];
+      } else {
+        a.epilogue = HARP_CONV_GATE; a.out = w.gbuf[flip]; a.gate = w.act[k - 1];
+        flip ^= 1;
+      }
+      if (bounded) {       // the gradient lives in the level's active tiles and is zero elsewhere
+        a.target_row = b.rows;
+        a.tile_list = b.list[lv]; a.tile_count = b.count[lv]; a.max_tiles = b.max_tiles[lv];
+        a.tile_origin = b.origin[lv]; a.tile_pitch = b.pitch[lv];
+        a.in_valid = b.tiles[lv]; a.in_valid_origin = b.origin[lv]; a.in_valid_pitch = b.pitch[lv]; a.in_valid_shift = 1;
+        if (tap >= 0) { a.out_valid = b.tiles[lv - 1]; a.out_valid_origin = b.origin[lv - 1]; a.out_valid_pitch = b.pitch[lv - 1]; }
+      }
+      rc = harp_conv3x3(&a, st);
+      if (rc != HARP_OK) return rc;
+      g = a.out;
+    }
+    hipLaunchKernelGGL(vgg_grad_image_kernel, dim3((S + kCT - 1) / kCT, (S + kCT - 1) / kCT, Nh), dim3(256), 0, st, g, net->w0t, t->rgb + px * 3, t->y_true,
+                       t->mask, rows, t->covered ? t->covered + px : (const int32_t*)nullptr, S, scale[0], t->weight, t->g_rgb + px * 3,
+                       finish ? w.loss : (double*)nullptr, t->loss,
+                       bounded ? b.tiles[0] : (const int32_t*)nullptr, bounded ? b.origin[0] : (const int32_t*)nullptr, bounded ? b.pitch[0] : 0);
+    HARP_CHECK_LAUNCH();
+    return HARP_OK;
+  };
+  // The batch in 2 - 4 parts on as many streams (t->side_streams): the term is a chain of 21 dependent launches of a few rounds of workgroups
+  // each, and every launch ends with a partly filled round (measured: 1.17 ms per frame at 32 frames, 1.26 at 16, 1.47 at 8); the chains fill
+  // each other's tails.  Needs per-frame target rows (the engine's form); the parts share the loss accumulator.
+  int nside = 0;
+  while (nside < 3 && t->side_streams[nside]) ++nside;
+  if (nside > N - 1) nside = N - 1;
+  const bool split = nside > 0 && t->rows != nullptr && t->target_by_row;
+  if (!split) return run(0, N, vgg_ws_split(t->ws, N, S, 1), stream, true);
+  static hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
+  if (!ev_fork) {
+    bool ok = hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) == hipSuccess;
+    for (int i = 0; i < 3; ++i) ok = ok && hipEventCreateWithFlags(&ev_join[i], hipEventDisableTiming) == hipSuccess;
+    if (!ok) { ev_fork = nullptr; return HARP_ERR_LAUNCH; }
   }
-  hipLaunchKernelGGL(vgg_grad_image_kernel, dim3((S + kCT - 1) / kCT, (S + kCT - 1) / kCT, N), dim3(256), 0, stream, g, net->w0t, t->rgb, t->y_true,
-                     t->mask, t->rows, t->covered, S, scale[0], t->weight, t->g_rgb, w.loss, t->loss,
-                     bounded ? bd.tiles[0] : (const int32_t*)nullptr, bounded ? bd.origin[0] : (const int32_t*)nullptr, bounded ? bd.pitch[0] : 0);
+  const int parts = nside + 1;
+  if (hipEventRecord(ev_fork, stream) != hipSuccess) return HARP_ERR_LAUNCH;
+  for (int i = 0; i < nside; ++i)
+    if (hipStreamWaitEvent((hipStream_t)t->side_streams[i], ev_fork, 0) != hipSuccess) return HARP_ERR_LAUNCH;
+  int rc = HARP_OK, n0 = 0;
+  char* wp = (char*)t->ws;
+  double* acc = nullptr;
+  for (int i = 0; i < parts; ++i) {
+    const int Nh = N / parts + (i < N % parts ? 1 : 0);
+    VggWs w = vgg_ws_split(wp, Nh, S, 1);
+    wp += w.bytes;
+    if (i == 0) acc = w.loss;
+    w.loss = acc;
+    if (rc == HARP_OK) rc = run(n0, Nh, w, i == 0 ? stream : (hipStream_t)t->side_streams[i - 1], false);
+    n0 += Nh;
+  }
+  // (joined even after an error: a capture must not end with a stream forked off)
+  for (int i = 0; i < nside; ++i)
+    if (hipEventRecord(ev_join[i], (hipStream_t)t->side_streams[i]) != hipSuccess || hipStreamWaitEvent(stream, ev_join[i], 0) != hipSuccess) return HARP_ERR_LAUNCH;
+  if (rc != HARP_OK) return rc;
+  hipLaunchKernelGGL(vgg_loss_finish_kernel, dim3(1), dim3(1), 0, stream, acc, t->loss);
   HARP_CHECK_LAUNCH();
   return HARP_OK;
 }

@@ -213,6 +213,7 @@ class FitEngine:
         self._trec = self._tacc = None
         self._maps_pending = None
         self.vert9 = True                # the shader backward's vertex gradients as ONE interleaved (B,V,9) buffer (a 36-byte run per vertex and wave instead of three 12-byte runs: a third of the memory-atomic lines), unpacked into the three arrays by extra workgroups of the depth backward's launch
+        self.vgg_streams = 2             # perceptual term: the batch in this many parts on as many streams (harp_vgg16_term_args.side_streams; 1 - 4)
         self.split_adam = True           # with the texel records: the maps' Adam update on the second stream behind harp_texel_finish, the step's last launch only for the small parameters
         self.fused_sil_bwd = False       # the silhouette backward inside the camera-view raster launch (harp_rasterize_l1_fwd_bwd) instead of a launch of its own beside the shader backward.  Correct (tests) and measured SLOWER: the shader backward gains 32 us without its neighbour (230 -> 198 in the graph), the camera raster pays 56 (198 -> 254: 94 VGPRs / 26 KB of LDS = 5 waves per SIMD instead of 7, and the rim walk is ~25 us of VALU work wherever it runs): step 0.665 vs 0.638 ms (profiles/r06_ab_record.txt)
         self.lean_app_stage = False      # appearance-only stage without the geometry gradients nothing reads (set by optimize_hand_sequence; off by default: g_buf then holds what autograd would)
@@ -1002,8 +1003,10 @@ class FitEngine:
         else:
             target, by_row = [f[:B] for f in self._vgg_step_feats], 0
             self.perceptual.features(self.y_true, self.y_sil_col, rows, out=target)
+        # (the batch in parts on as many streams: the term's 21 dependent launches fill each other's last rounds of workgroups)
+        more = [self._extra_stream("vgg%d" % i) for i in range(min(self.vgg_streams, 4, B) - 1)] if (self.overlap and by_row) else []
         self.perceptual.term(s["rgb"][:B], self.y_true, self.y_sil_col, rows, target, by_row, s["g_rgb"][:B], lloss[9:10], weight=self.perceptual_weight,
-                             covered=s["face_c"][:B], bound=self._vgg_bound)
+                             covered=s["face_c"][:B], bound=self._vgg_bound, side_streams=more)
 
     def _extra_stream(self, name):
         lane = self._lane
@@ -1261,7 +1264,7 @@ class FitEngine:
         # every switch the enqueued launch sequence depends on is part of the key: flipping one re-captures instead of replaying a
         # graph recorded for another configuration
         gkey = (coarse, app, scheduled, n, self.keep_image, self.fused_loss, self.self_shadow, tuple(self.frozen), self.overlap, self.early_terms,
-                self.packed_texels, self.fused_keep, self.mesh_third, self.graph_order, fold, self.fused_terms, self.zl_tile_flags, self.accumulate_loss, self.lean_app_stage, self.sil_only_raster, self.auto_draw, self.mesh_terms_late, self.sil_late, self.paired_setup, self.late_texture_terms, self.mesh_terms_first, self.camera_first, self.tail_side, self.fused_bwd, self.fused_chain, self.fused_front, self.wide_front, self.hybrid_front, self.front_auto, self.wide_back, self.fused_back, self.consume_gzl, self.keep_depth, self.texel_records, self.fused_sil_bwd, self.split_adam, self.vert9, dist_on, self.overlap_allreduce,
+                self.packed_texels, self.fused_keep, self.mesh_third, self.graph_order, fold, self.fused_terms, self.zl_tile_flags, self.accumulate_loss, self.lean_app_stage, self.sil_only_raster, self.auto_draw, self.mesh_terms_late, self.sil_late, self.paired_setup, self.late_texture_terms, self.mesh_terms_first, self.camera_first, self.tail_side, self.fused_bwd, self.fused_chain, self.fused_front, self.wide_front, self.hybrid_front, self.front_auto, self.wide_back, self.fused_back, self.consume_gzl, self.keep_depth, self.texel_records, self.fused_sil_bwd, self.split_adam, self.vert9, self.vgg_streams, dist_on, self.overlap_allreduce,
                 self.comm is not None, self.perceptual is not None and app)
         g = self._graphs.get(gkey)
         if g is None:

@@ -131,10 +131,11 @@ class Vgg16Hip:
         _lib.check(rc, "harp_vgg16_features")
         return out
 
-    def term(self, rgb, y_true, mask, rows, target, target_by_row, g_rgb, loss, weight=1.0, covered=None, bound=None):
+    def term(self, rgb, y_true, mask, rows, target, target_by_row, g_rgb, loss, weight=1.0, covered=None, bound=None, side_streams=()):
         """enqueue the whole term: *loss (a float32 HIP scalar / 1-element view) = the term, g_rgb updated in place (include/harp_hip.h).
         target: the four tap tensors, or — with bound = active_tiles(mask) — the 13-slot cache of ALL activations of the target frames
-        (bounded mode: the stack runs only where the rendered image can differ from its target frame)"""
+        (bounded mode: the stack runs only where the rendered image can differ from its target frame).  side_streams: up to three more torch streams
+        for further parts of the batch (forked and joined inside the call)"""
         N, S = rgb.shape[0], rgb.shape[1]
         t = _lib.Vgg16TermArgs()
         t.rgb, t.y_true, t.mask, t.rows = _lib.ptr(rgb), _lib.ptr(y_true), _lib.ptr(mask), _lib.ptr(rows)
@@ -149,6 +150,8 @@ class Vgg16Hip:
                 t.tile_origin[lv], t.tile_pitch[lv] = _lib.ptr(origin), pitch
         t.target_by_row, t.covered, t.g_rgb, t.weight, t.loss = int(target_by_row), _lib.ptr(covered), _lib.ptr(g_rgb), float(weight), _lib.ptr(loss)
         t.N, t.S, t.ws = N, S, _lib.ptr(self.workspace(N, S, True))
+        for i, st in enumerate(list(side_streams)[:3]):          # the batch in len + 1 parts on as many streams (include/harp_hip.h)
+            t.side_streams[i] = st.cuda_stream
         _lib.check(_lib.lib().harp_vgg16_term(ctypes.byref(self.net), ctypes.byref(t), _lib.stream()), "harp_vgg16_term")
 
 

@@ -687,6 +687,10 @@ typedef struct harp_vgg16_term_args {
   int max_tiles[4];
   const int32_t* tile_origin[4];   /* (T,2) even (oy, ox) per frame and level: tile (ty, tx) covers pixels [16 ty - oy, +16) x [16 tx - ox, +16) */
   int tile_pitch[4];               /* tiles per row (= rows) of tiles[L]; tile_list[L] entries are ty * pitch + tx */
+  void* side_streams[3];           /* up to three more hipStream_t (NULL-terminated).  With k of them (and rows, target_by_row) the term runs as k + 1
+                                    * parts of the batch, part i > 0 on side_streams[i - 1], forked from and joined back into `stream` by events
+                                    * (capturable): the chains of 21 dependent launches fill each other's partly filled last rounds of workgroups.
+                                    * Same results. */
 } harp_vgg16_term_args;
 size_t harp_vgg16_ws_bytes(int N, int S, int with_gradient);
 int harp_vgg16_features(const harp_vgg16* net, const float* image, const float* mask, const int32_t* rows, int N, int S, void* ws,

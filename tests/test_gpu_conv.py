@@ -228,6 +228,16 @@ def test_bounded_term_equals_the_full_pass(precision):
         assert abs(res[name][0] - want.item()) < 2e-5 * want.item() and rel < (2e-3, 6e-2)[precision]
     assert abs(res["full"][0] - res["bounded"][0]) < 1e-6 * res["full"][0]
     assert torch.equal(res["full"][1], res["bounded"][1])            # tile by tile the same arithmetic on the same inputs
+    # the batch in parts on 2 - 4 streams (harp_vgg16_term_args.side_streams: uneven parts of the 3 images, more streams than images): the
+    # same gradient bit for bit, the same loss up to the order its double accumulator is added in; twice in a row (the accumulator comes back zero)
+    streams = [torch.cuda.Stream(device=DEV) for _ in range(3)]
+    for bd in (None, bound):
+        for k in (1, 2, 3, 1):
+            g_rgb = torch.zeros(N, S, S, 3, device=DEV)
+            loss = torch.zeros(1, device=DEV)
+            hip.term(rgb_d, yt_d, mask_d, rows_d, cache, 1, g_rgb, loss, weight=1.0, bound=bd, side_streams=streams[:k])
+            torch.cuda.synchronize()
+            assert torch.equal(g_rgb.double().cpu(), res["full"][1]) and abs(loss.item() - res["full"][0]) < 1e-6 * res["full"][0], (bd is None, k, loss.item())
     # an all-empty batch: nothing to compute, zero loss and gradient
     g_rgb = torch.ones(1, S, S, 3, device=DEV)
     loss = torch.ones(1, device=DEV)
