@@ -414,7 +414,7 @@ def perceptual_rate(device, weights, steps=6, warmup=2):
         # per-level flop x the level's share of active tiles over the batch's frames
         done, tiles = flop, None
         if e._vgg_bound is not None:
-            tiles = [float(b[2].float().sum()) / (b[0].shape[0] * ((S >> lv) / 16.0) ** 2) for lv, b in enumerate(e._vgg_bound)]      # share of the image's area
+            tiles = [float(b[2].float().sum()) * b[6] ** 2 / (b[0].shape[0] * float(S >> lv) ** 2) for lv, b in enumerate(e._vgg_bound)]      # share of the image's area
             done = 2.0 * B_PER_GPU * sum(2.0 * 9 * ci * co * h * h * tiles[{512: 0, 256: 1, 128: 2, 64: 3}[h * 512 // S]] for ci, co, h in _VGG_CONVS)
         res[name] = {"frames_per_s": B_PER_GPU / dt, "ms_per_step": dt * 1e3, "in_hipgraph": bool(e._graphs),
                      "active_tile_share_per_level": tiles, "conv_tflop_executed": done / 1e12,

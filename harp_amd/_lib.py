@@ -233,7 +233,7 @@ class Conv3x3Args(ctypes.Structure):
                 [(n, _i) for n in ("N", "H", "W", "Cin", "Cout", "precision", "epilogue", "in_channels")] + [("tap_scale", _f)] +
                 [("tile_list", _vp), ("tile_count", _vp), ("max_tiles", _i), ("in_valid_shift", _i), ("in_valid", _vp), ("in_alt", _vp),
                  ("out_valid", _vp), ("tile_origin", _vp), ("in_valid_origin", _vp), ("out_valid_origin", _vp), ("tile_pitch", _i),
-                 ("in_valid_pitch", _i), ("out_valid_pitch", _i)])
+                 ("in_valid_pitch", _i), ("out_valid_pitch", _i), ("tile_side", _i), ("in_valid_cell", _i), ("out_valid_cell", _i)])
 
 
 SIGNATURES.update({
@@ -252,7 +252,7 @@ class Vgg16TermArgs(ctypes.Structure):
     """mirror of `harp_vgg16_term_args` (include/harp_hip.h)"""
     _fields_ = [("rgb", _vp), ("y_true", _vp), ("mask", _vp), ("rows", _vp), ("target", _vp * 4), ("target_by_row", _i), ("covered", _vp),
                 ("g_rgb", _vp), ("weight", _f), ("loss", _vp), ("N", _i), ("S", _i), ("ws", _vp), ("target_in", _vp * 10), ("tiles", _vp * 4),
-                ("tile_list", _vp * 4), ("tile_count", _vp * 4), ("max_tiles", _i * 4), ("tile_origin", _vp * 4), ("tile_pitch", _i * 4), ("side_streams", _vp * 3)]
+                ("tile_list", _vp * 4), ("tile_count", _vp * 4), ("max_tiles", _i * 4), ("tile_origin", _vp * 4), ("tile_pitch", _i * 4), ("tile_side", _i * 4), ("side_streams", _vp * 3)]
 
 
 SIGNATURES.update({

@@ -39,6 +39,15 @@ constexpr int kInF4 = 4 * kPlane;
 constexpr int kWF4 = 9 * 4 * kCN;         // filter slab of one (64 output channels, 16 input channels) pair: [tap][plane][co][16 B] = 36 864 B
 constexpr int kLdsBytes = (kInF4 + kWF4) * 16;
 constexpr int kUnits = (kPatch * kPatch * 4 + 255) / 256;   // 16-byte staging units per thread (6; the last one is mostly idle)
+// SUB8 form (bounded mode at the coarse levels, harp_conv3x3_args.tile_side == 8): the workgroup's four waves own four INDEPENDENT 8x8-pixel
+// tiles of the frame's list (x 64 channels, the same filter slab); a wave stages its own 10x10 patch and its two MFMA row blocks are the
+// upper and the lower 8x4 half of its tile.  Two waves share a set of planes [10 rows][24 pixels], 12 pixels apart: the same row pitch, hence
+// the same conflict-free fragment reads.
+constexpr int kPatch8 = 10;
+constexpr int kPlane8 = kPatch8 * kRow + 2;
+constexpr int kInF4_8 = 2 * 4 * kPlane8;
+constexpr int kUnits8 = (kPatch8 * kPatch8 * 4 + 63) / 64;   // 16-byte staging units per LANE (7)
+constexpr int kLdsBytes8 = (kInF4_8 + kWF4) * 16;
 
 // experiment switches (tools/dev/build_variant.sh): CONV_PIPE 0 = the compiler's own placement of the fragment reads, 1 = reads of step s + 1
 // issued before the MFMAs of step s, pinned by sched_barrier, 2 = the same without the pins.  Measured on one box, 256 -> 256 channels at
@@ -92,19 +101,33 @@ __global__ void pack_filters_kernel(const float* __restrict__ w, int Cout_src, i
 }
 
 // ---- the convolution ----------------------------------------------------------------------------------------------------------------
-template <int PREC, int EPI>
+template <int PREC, int EPI, bool SUB8 = false>
 __global__ __launch_bounds__(256, CONV_WAVES) void conv3x3_kernel(const harp_conv3x3_args a, const int tiles_x, const int tiles_y) {
   extern __shared__ float4 smem[];          // ONE LDS object (a second one makes hipcc drain vmcnt before every ds_read, cdna_hip_programming.md §5)
   float4* s_in = smem;
-  float4* s_w = smem + kInF4;
+  float4* s_w = smem + (SUB8 ? kInF4_8 : kInF4);
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6, half = lane >> 5, m = lane & 31;
+  constexpr int kT = SUB8 ? 8 : kCT, kP = SUB8 ? kPatch8 : kPatch, kPl = SUB8 ? kPlane8 : kPlane, kU = SUB8 ? kUnits8 : kUnits;
 
   const int ncb = a.Cout / kCN, nchunk = a.Cin / kCK;
   int id = blockIdx.x;
   const int cb = id % ncb; id /= ncb;
   int tx, ty, n;
   int x0, y0;
-  if (a.tile_list) {
+  bool active = true;                       // SUB8: this wave holds a tile of the list (the last group of a frame may not be full)
+  if (SUB8) {
+    const int groups = (a.max_tiles + 3) >> 2;
+    const int i = 4 * (id % groups) + wv;
+    n = id / groups;
+    const int r = a.target_row ? a.target_row[n] : n;
+    const int cnt = a.tile_count[r];
+    if (4 * (id % groups) >= cnt) return;                          // (the whole workgroup)
+    active = i < cnt;
+    const int tile = a.tile_list[(size_t)r * a.max_tiles + (active ? i : 0)];
+    ty = tile / a.tile_pitch; tx = tile - ty * a.tile_pitch;
+    y0 = ty * kT - (a.tile_origin ? a.tile_origin[2 * r] : 0);
+    x0 = tx * kT - (a.tile_origin ? a.tile_origin[2 * r + 1] : 0);
+  } else if (a.tile_list) {
     // bounded mode: slot i of image n's frame; frames hold different numbers of tiles, the grid is sized for the largest.  The frame's tile
     // grid may be shifted by an (even) origin so that its tiles hug the frame's active region: tile (ty, tx) covers pixels [16 ty - oy, +16)
     const int i = id % a.max_tiles;
@@ -131,7 +154,9 @@ __global__ __launch_bounds__(256, CONV_WAVES) void conv3x3_kernel(const harp_con
   // bounded mode: which cells (8 << shift input pixels square) under the patch hold values of THIS pass; the patch spans at most 4 x 4 cells.
   // Wave-uniform: 16 scalar loads, one bit each.
   unsigned cellmask = 0xffffu;
-  const int csh = 3 + a.in_valid_shift;
+  // cells of in_valid: the producer's tiles in INPUT pixels — (8 << in_valid_shift) for a producer on 16-pixel tiles, in_valid_cell
+  // (4, 8 or 16) when given: a producer on 8-pixel tiles, behind a pool (shift 0) half of that
+  const int csh = a.in_valid_cell ? 31 - __builtin_clz(a.in_valid_cell) : 3 + a.in_valid_shift;
   // origin of the producer's tile grid in INPUT pixels (a producer behind a pool runs at twice the resolution: its even origin halves)
   const int poy = a.in_valid_origin ? a.in_valid_origin[2 * row] >> (1 - a.in_valid_shift) : 0;
   const int pox = a.in_valid_origin ? a.in_valid_origin[2 * row + 1] >> (1 - a.in_valid_shift) : 0;
@@ -148,17 +173,19 @@ __global__ __launch_bounds__(256, CONV_WAVES) void conv3x3_kernel(const harp_con
   }
 
   // staging units of this thread: unit u = (patch pixel u >> 2, channel quad u & 3): four consecutive lanes fetch one pixel's 64 bytes
-  int goff[kUnits], lidx[kUnits];
+  // (SUB8: the units of this WAVE's own patch, lane by lane; its planes start at sbase, its columns at 12 * (wv & 1))
+  const int sbase = SUB8 ? (wv >> 1) * 4 * kPlane8 + 12 * (wv & 1) : 0;
+  int goff[kU], lidx[kU];
   unsigned use_alt = 0;                    // bit j: unit j lies in a cell this pass did not write -> read in_alt (or zero)
 #pragma unroll
-  for (int j = 0; j < kUnits; ++j) {
-    const int u = j * 256 + t, pix = u >> 2, q = u & 3;
+  for (int j = 0; j < kU; ++j) {
+    const int u = SUB8 ? j * 64 + lane : j * 256 + t, pix = u >> 2, q = u & 3;
     goff[j] = -1; lidx[j] = -1;
-    if (pix < kPatch * kPatch) {
-      const int py = pix / kPatch, px = pix - py * kPatch;
+    if (pix < kP * kP && active) {
+      const int py = pix / kP, px = pix - py * kP;
       const int gy = y0 + py - 1, gx = x0 + px - 1;
-      if (PREC == 0) lidx[j] = q * kPlane + py * kRow + px;                       // float4 index
-      else lidx[j] = (((q >> 1) * kPlane + py * kRow + px) << 1) | (q & 1);      // 8-byte index of the hi half; lo is 2 planes further
+      if (PREC == 0) lidx[j] = sbase + q * kPl + py * kRow + px;                       // float4 index
+      else lidx[j] = ((sbase + (q >> 1) * kPl + py * kRow + px) << 1) | (q & 1);      // 8-byte index of the hi half; lo is 2 planes further
       if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
         goff[j] = (gy * W + gx) * Cin + 4 * q;
         const int c = ((((gy + poy) >> csh) - cy0) << 2) | (((gx + pox) >> csh) - cx0);
@@ -171,15 +198,15 @@ __global__ __launch_bounds__(256, CONV_WAVES) void conv3x3_kernel(const harp_con
   }
   // (named registers, not an array: hipcc left a 9 x float4 array in SCRATCH — 160 B per lane, every chunk's filter fetch waited for right
   //  behind its loads to be stored there — although every index is a compile-time constant after unrolling)
-  float4 rin[kUnits], rw0, rw1, rw2, rw3, rw4, rw5, rw6, rw7, rw8;
+  float4 rin[kU], rw0, rw1, rw2, rw3, rw4, rw5, rw6, rw7, rw8;
 #define HARP_RW_EACH(X) X(0, rw0) X(1, rw1) X(2, rw2) X(3, rw3) X(4, rw4) X(5, rw5) X(6, rw6) X(7, rw7) X(8, rw8)
   // (out-of-image units read the image's first bytes and are zeroed when they are STAGED: a select instead of a branch around every load, and
   //  placed behind the chunk's MFMAs — a select right behind the load made the wave wait for the fetch before it started the chunk's MFMAs:
   //  120 instead of 98 TFLOP/s float32, 365 instead of 208 bf16 split without it, profiles/r05_conv_variants.txt)
-  auto unit_ok = [&](int j, int cc) { return goff[j] >= 0 && cc * kCK + 4 * ((j * 256 + t) & 3) < Cin; };
+  auto unit_ok = [&](int j, int cc) { return goff[j] >= 0 && cc * kCK + 4 * (t & 3) < Cin; };      // (unit j's channel quad = (j * 256 + t) & 3 = (j * 64 + lane) & 3 = t & 3)
   auto fetch = [&](int cc) {
 #pragma unroll
-    for (int j = 0; j < kUnits; ++j) {
+    for (int j = 0; j < kU; ++j) {
       const float* __restrict__ src = ((use_alt >> j) & 1u) ? alt_n : in_n;
       rin[j] = *(const float4*)(src + (unit_ok(j, cc) ? goff[j] + cc * kCK : 0));
     }
@@ -189,7 +216,7 @@ __global__ __launch_bounds__(256, CONV_WAVES) void conv3x3_kernel(const harp_con
   };
   auto stage = [&](int cc) {
 #pragma unroll
-    for (int j = 0; j < kUnits; ++j) {
+    for (int j = 0; j < kU; ++j) {
       if (lidx[j] < 0) continue;
       const float4 v = unit_ok(j, cc) ? rin[j] : make_float4(0.f, 0.f, 0.f, 0.f);
       if (PREC == 0) {
@@ -199,7 +226,7 @@ __global__ __launch_bounds__(256, CONV_WAVES) void conv3x3_kernel(const harp_con
         bf16x4 lo = {(__bf16)(v.x - (float)hi[0]), (__bf16)(v.y - (float)hi[1]), (__bf16)(v.z - (float)hi[2]), (__bf16)(v.w - (float)hi[3])};
         uint2* s8 = (uint2*)s_in;
         s8[lidx[j]] = __builtin_bit_cast(uint2, hi);
-        s8[lidx[j] + 4 * kPlane] = __builtin_bit_cast(uint2, lo);
+        s8[lidx[j] + 4 * kPl] = __builtin_bit_cast(uint2, lo);
       }
     }
 #define HARP_RW_STORE(j, r) s_w[j * 256 + t] = r;
@@ -208,9 +235,11 @@ __global__ __launch_bounds__(256, CONV_WAVES) void conv3x3_kernel(const harp_con
   };
 
   // this lane's pixel in each of the wave's two 8x4 row blocks: m = 4 * square + (dy, dx); squares 4 across, 2 down
-  const int ly = 4 * wv + 2 * (m >> 4) + ((m >> 1) & 1);
+  // (SUB8: the two row blocks are rows 0-3 and 4-7 of the wave's own 8x8 tile)
+  const int ly = (SUB8 ? 0 : 4 * wv) + 2 * (m >> 4) + ((m >> 1) & 1);
   const int lx = 2 * ((m >> 2) & 3) + (m & 1);
-  const int pixA = ly * kRow + lx;
+  const int pixA = sbase + ly * kRow + lx;
+  constexpr int kBlk1 = SUB8 ? 4 * kRow : 8;          // the second row block: 4 rows down (SUB8) or 8 pixels to the right
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -231,6 +260,7 @@ __global__ __launch_bounds__(256, CONV_WAVES) void conv3x3_kernel(const harp_con
     stage(cc);
     __syncthreads();
     if (cc + 1 < nchunk) fetch(cc + 1);   // in flight under the chunk's MFMAs
+    if (SUB8 && !active) continue;        // (a wave without a tile only helps staging the slab)
     // Software pipeline over the chunk's steps (float32: 18 = 9 taps x 2 k groups of 8 channels; bf16: 9 taps of 16 channels): the
     // fragments of step s + 1 are read from LDS before the MFMAs of step s issue, so one wave alone covers its LDS latency (the compiler's
     // own schedule read each step's fragments right in front of its MFMAs: MFMA pipe 78 % / 37 % busy, profiles/r05_a_pmc_sq_conv_*).
@@ -241,12 +271,12 @@ __global__ __launch_bounds__(256, CONV_WAVES) void conv3x3_kernel(const harp_con
       if (PREC == 0) {
         const int tap = step >> 1, g = step & 1;
         const int plane = 2 * g + half, toff = (tap / 3) * kRow + (tap % 3);
-        f[0] = s_in[plane * kPlane + pixA + toff]; f[1] = s_in[plane * kPlane + pixA + toff + 8];
+        f[0] = s_in[plane * kPl + pixA + toff]; f[1] = s_in[plane * kPl + pixA + toff + kBlk1];
         f[2] = s_w[(tap * 4 + plane) * kCN + m]; f[3] = s_w[(tap * 4 + plane) * kCN + 32 + m];
       } else {
         const int tap = step, toff = (tap / 3) * kRow + (tap % 3);
-        f[0] = s_in[half * kPlane + pixA + toff]; f[1] = s_in[half * kPlane + pixA + toff + 8];                       // A hi
-        f[2] = s_in[(2 + half) * kPlane + pixA + toff]; f[3] = s_in[(2 + half) * kPlane + pixA + toff + 8];           // A lo
+        f[0] = s_in[half * kPl + pixA + toff]; f[1] = s_in[half * kPl + pixA + toff + kBlk1];                       // A hi
+        f[2] = s_in[(2 + half) * kPl + pixA + toff]; f[3] = s_in[(2 + half) * kPl + pixA + toff + kBlk1];           // A lo
         f[4] = s_w[(tap * 4 + half) * kCN + m]; f[5] = s_w[(tap * 4 + half) * kCN + 32 + m];                          // B hi
         f[6] = s_w[(tap * 4 + 2 + half) * kCN + m]; f[7] = s_w[(tap * 4 + 2 + half) * kCN + 32 + m];                  // B lo
       }
@@ -374,8 +404,9 @@ __global__ __launch_bounds__(256, CONV_WAVES) void conv3x3_kernel(const harp_con
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int sq = 2 * q + half;
-        const int gy = y0 + 4 * wv + 2 * (sq >> 2), gx = x0 + 8 * i + 2 * (sq & 3);     // top-left pixel of the 2x2 square (even, even)
-        if (gy >= H || gx >= W || gy < 0 || gx < 0) continue;                          // (a shifted tile grid reaches beyond the image on all sides)
+        // top-left pixel of the 2x2 square (even, even)
+        const int gy = y0 + (SUB8 ? 4 * i : 4 * wv) + 2 * (sq >> 2), gx = x0 + (SUB8 ? 0 : 8 * i) + 2 * (sq & 3);
+        if (gy >= H || gx >= W || gy < 0 || gx < 0 || !active) continue;               // (a shifted tile grid reaches beyond the image on all sides)
         if (EPI == EPI_RELU || EPI == EPI_RELU_TAP) {
           float v[4];
 #pragma unroll
@@ -419,8 +450,9 @@ __global__ __launch_bounds__(256, CONV_WAVES) void conv3x3_kernel(const harp_con
             if (g10 > best) { best = g10; ob = o00 + dy; }
             if (g11 > best) { best = g11; ob = o00 + dy + dx; }
             // (bounded mode: windows in output tiles this pass does not own are left alone — nothing downstream reads them)
-            if (a.out_valid && !a.out_valid[(row * a.out_valid_pitch + ((2 * yy + (a.out_valid_origin ? a.out_valid_origin[2 * row] : 0)) >> 4)) * a.out_valid_pitch +
-                                            ((2 * xx + (a.out_valid_origin ? a.out_valid_origin[2 * row + 1] : 0)) >> 4)]) continue;
+            const int osh = a.out_valid_cell == 8 ? 3 : 4;          // `out`'s tiles: 16 pixels, or 8
+            if (a.out_valid && !a.out_valid[(row * a.out_valid_pitch + ((2 * yy + (a.out_valid_origin ? a.out_valid_origin[2 * row] : 0)) >> osh)) * a.out_valid_pitch +
+                                            ((2 * xx + (a.out_valid_origin ? a.out_valid_origin[2 * row + 1] : 0)) >> osh)]) continue;
             if (best > 0.f) a.out[ob] += acc[i][j][4 * q + c];
           }
         }
@@ -434,23 +466,25 @@ __global__ __launch_bounds__(256, CONV_WAVES) void conv3x3_kernel(const harp_con
   }
 }
 
-template <int PREC, int EPI>
+template <int PREC, int EPI, bool SUB8>
 int launch_conv(const harp_conv3x3_args& a, hipStream_t stream) {
   static bool ready = false;               // per instantiation: raise the dynamic-LDS limit once, not per launch (and never inside a capture)
-  auto kern = conv3x3_kernel<PREC, EPI>;
+  auto kern = conv3x3_kernel<PREC, EPI, SUB8>;
+  constexpr int lds = SUB8 ? kLdsBytes8 : kLdsBytes;
   if (!ready) {
-    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes) != hipSuccess) return HARP_ERR_LAUNCH;
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return HARP_ERR_LAUNCH;
     ready = true;
   }
   const int tiles_x = (a.W + kCT - 1) / kCT, tiles_y = (a.H + kCT - 1) / kCT;
-  const size_t blocks = (a.tile_list ? (size_t)a.max_tiles : (size_t)tiles_x * tiles_y) * a.N * (a.Cout / kCN);
+  // (SUB8: four tiles of the list per workgroup)
+  const size_t blocks = (SUB8 ? (size_t)((a.max_tiles + 3) >> 2) : a.tile_list ? (size_t)a.max_tiles : (size_t)tiles_x * tiles_y) * a.N * (a.Cout / kCN);
   if (blocks == 0 || blocks > 0x7fffffffu) return HARP_ERR_ARG;
 #ifdef CONV_LDS_PAD
-  static bool padded = (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes + CONV_LDS_PAD), true);
+  static bool padded = (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds + CONV_LDS_PAD), true);
   (void)padded;
-  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), kLdsBytes + CONV_LDS_PAD, stream, a, tiles_x, tiles_y);
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds + CONV_LDS_PAD, stream, a, tiles_x, tiles_y);
 #else
-  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), kLdsBytes, stream, a, tiles_x, tiles_y);
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, stream, a, tiles_x, tiles_y);
 #endif
   HARP_CHECK_LAUNCH();
   return HARP_OK;
@@ -458,15 +492,15 @@ int launch_conv(const harp_conv3x3_args& a, hipStream_t stream) {
 
 template <int PREC>
 int launch_conv_prec(const harp_conv3x3_args& a, hipStream_t stream) {
+  const bool sub8 = a.tile_side == 8;
   switch (a.epilogue) {
-    case EPI_RELU: return launch_conv<PREC, EPI_RELU>(a, stream);
-    case EPI_RELU_TAP: return launch_conv<PREC, EPI_RELU_TAP>(a, stream);
-    case EPI_GATE: return launch_conv<PREC, EPI_GATE>(a, stream);
-    case EPI_UNPOOL: return launch_conv<PREC, EPI_UNPOOL>(a, stream);
+    case EPI_RELU: return sub8 ? launch_conv<PREC, EPI_RELU, true>(a, stream) : launch_conv<PREC, EPI_RELU, false>(a, stream);
+    case EPI_RELU_TAP: return sub8 ? launch_conv<PREC, EPI_RELU_TAP, true>(a, stream) : launch_conv<PREC, EPI_RELU_TAP, false>(a, stream);
+    case EPI_GATE: return sub8 ? launch_conv<PREC, EPI_GATE, true>(a, stream) : launch_conv<PREC, EPI_GATE, false>(a, stream);
+    case EPI_UNPOOL: return sub8 ? launch_conv<PREC, EPI_UNPOOL, true>(a, stream) : launch_conv<PREC, EPI_UNPOOL, false>(a, stream);
   }
   return HARP_ERR_ARG;
 }
-
 
 // ---- the two ends of the stack: 3 image channels, vector ALU ------------------------------------------------------------------------
 // x0 = image * mask (optimize_sequence.py:546-547: vgg(y_pred * mask) / vgg(y_true * mask)), written as 4 channels per pixel (r, g, b, 0);
@@ -615,7 +649,7 @@ inline VggWs vgg_ws_split(void* ws, int N, int S, int with_gradient) {
 // receptive field).  Outside them pred == target exactly, the L1 and its gradient vanish, and a convolution that needs an input pixel
 // from there reads the TARGET frame's cached activation (forward) or zero (backward).
 struct VggBound {
-  const int32_t* tiles[4]; const int32_t* list[4]; const int32_t* count[4]; const int32_t* origin[4]; int max_tiles[4]; int pitch[4];
+  const int32_t* tiles[4]; const int32_t* list[4]; const int32_t* count[4]; const int32_t* origin[4]; int max_tiles[4]; int pitch[4]; int side[4];
   const float* target_in[10];
   const int32_t* rows;
 };
@@ -649,11 +683,12 @@ int vgg_forward(const harp_vgg16* net, const VggWs& w, int N, int S, float* cons
     if (bd) {
       a.target_row = bd->rows;
       a.tile_list = bd->list[lv]; a.tile_count = bd->count[lv]; a.max_tiles = bd->max_tiles[lv];
-      a.tile_origin = bd->origin[lv]; a.tile_pitch = bd->pitch[lv];
+      a.tile_origin = bd->origin[lv]; a.tile_pitch = bd->pitch[lv]; a.tile_side = bd->side[lv];
       if (k > 0) {                                  // (x0 is written everywhere)
         const bool behind_pool = (k == 2 || k == 4 || k == 7);
         const int pl = behind_pool ? lv - 1 : lv;
         a.in_valid = bd->tiles[pl]; a.in_valid_origin = bd->origin[pl]; a.in_valid_pitch = bd->pitch[pl]; a.in_valid_shift = behind_pool ? 0 : 1;
+        a.in_valid_cell = behind_pool ? bd->side[pl] / 2 : bd->side[pl];          // the producer's tiles in this convolution's input pixels
         a.in_alt = bd->target_in[k];
       }
     }
@@ -717,6 +752,9 @@ int harp_conv3x3(const harp_conv3x3_args* a, hipStream_t stream) {
   if (a->tile_list && (!a->tile_count || a->max_tiles <= 0 || a->tile_pitch <= 0)) return HARP_ERR_ARG;
   if ((a->in_valid && a->in_valid_pitch <= 0) || (a->out_valid && a->out_valid_pitch <= 0)) return HARP_ERR_ARG;
   if (a->in_valid_shift < 0 || a->in_valid_shift > 1) return HARP_ERR_ARG;
+  if ((a->tile_side != 0 && a->tile_side != 8 && a->tile_side != 16) || (a->tile_side == 8 && !a->tile_list)) return HARP_ERR_ARG;
+  if ((a->in_valid_cell != 0 && a->in_valid_cell != 4 && a->in_valid_cell != 8 && a->in_valid_cell != 16) || (a->in_valid_cell == 4 && a->tile_side != 8) ||
+      (a->out_valid_cell != 0 && a->out_valid_cell != 8 && a->out_valid_cell != 16)) return HARP_ERR_ARG;
   if (a->precision == 0) return launch_conv_prec<0>(*a, stream);
   if (a->precision == 1) return launch_conv_prec<1>(*a, stream);
   return HARP_ERR_ARG;
@@ -764,6 +802,10 @@ int harp_vgg16_term(const harp_vgg16* net, const harp_vgg16_term_args* t, hipStr
       if (!t->tiles[l] || !t->tile_list[l] || !t->tile_count[l] || !t->tile_origin[l] || t->max_tiles[l] <= 0 || t->tile_pitch[l] <= 0) return HARP_ERR_ARG;
       bd.tiles[l] = t->tiles[l]; bd.list[l] = t->tile_list[l]; bd.count[l] = t->tile_count[l]; bd.max_tiles[l] = t->max_tiles[l];
       bd.origin[l] = t->tile_origin[l]; bd.pitch[l] = t->tile_pitch[l];
+      bd.side[l] = t->tile_side[l] ? t->tile_side[l] : 16;
+      // (the image-side kernels sit on the 16-pixel grid; a 16-pixel level behind an 8-pixel one would see validity cells of 4 pixels, of which
+      //  its 18-pixel patch spans more than the four a workgroup looks up)
+      if ((bd.side[l] != 16 && bd.side[l] != 8) || (l == 0 && bd.side[l] != 16) || (l > 0 && bd.side[l] > bd.side[l - 1])) return HARP_ERR_ARG;
     }
     for (int k = 1; k < 10; ++k) {
       if (!t->target_in[k]) return HARP_ERR_ARG;
@@ -802,9 +844,9 @@ int harp_vgg16_term(const harp_vgg16* net, const harp_vgg16_term_args* t, hipStr
       if (bounded) {       // the gradient lives in the level's active tiles and is zero elsewhere
         a.target_row = b.rows;
         a.tile_list = b.list[lv]; a.tile_count = b.count[lv]; a.max_tiles = b.max_tiles[lv];
-        a.tile_origin = b.origin[lv]; a.tile_pitch = b.pitch[lv];
-        a.in_valid = b.tiles[lv]; a.in_valid_origin = b.origin[lv]; a.in_valid_pitch = b.pitch[lv]; a.in_valid_shift = 1;
-        if (tap >= 0) { a.out_valid = b.tiles[lv - 1]; a.out_valid_origin = b.origin[lv - 1]; a.out_valid_pitch = b.pitch[lv - 1]; }
+        a.tile_origin = b.origin[lv]; a.tile_pitch = b.pitch[lv]; a.tile_side = b.side[lv];
+        a.in_valid = b.tiles[lv]; a.in_valid_origin = b.origin[lv]; a.in_valid_pitch = b.pitch[lv]; a.in_valid_shift = 1; a.in_valid_cell = b.side[lv];
+        if (tap >= 0) { a.out_valid = b.tiles[lv - 1]; a.out_valid_origin = b.origin[lv - 1]; a.out_valid_pitch = b.pitch[lv - 1]; a.out_valid_cell = b.side[lv - 1]; }
       }
       rc = harp_conv3x3(&a, st);
       if (rc != HARP_OK) return rc;

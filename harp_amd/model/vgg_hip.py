@@ -31,31 +31,40 @@ def activation_shapes(S):
     return [(S // d, S // d, c) for d, c in zip(_DIV, _COUT)] + [(S // 2, S // 2, 64), (S // 4, S // 4, 128), (S // 8, S // 8, 256)]
 
 
-def active_tiles(mask, shift_grid=True):
-    """The 16x16 tiles of each resolution level (side S >> L, L = 0..3) in which activations of image * mask can differ between two images
+TILE_SIDES = (16, 16, 8, 8)                   # side of a tile of active_tiles() per resolution level
+
+
+def active_tiles(mask, shift_grid=True, tile_sides=TILE_SIDES):
+    """The tiles of each resolution level (side S >> L, L = 0..3) in which activations of image * mask can differ between two images
     sharing `mask` (T,S,S): the support of the mask grown by the receptive field of the level's last convolution — two 3x3 convolutions at
-    levels 0 and 1, three at levels 2 and 3, a 2x2 max pool between levels (model/vgg.py:26-33).  shift_grid: every frame's tile grid is
-    shifted by the EVEN origin (oy, ox) in [0, 14]^2 that needs the fewest tiles (tile (ty, tx) = pixels [16 ty - oy, +16) x [16 tx - ox, +16):
-    the tiles hug the region instead of straddling it — at S/8 = 64 a hand spans 3 tiles instead of 4 per axis).
-    Returns per level: tiles (T, G*G) int32 0/1 with G = ceil(S_L / 16) + 1, tile_list (T, max) int32 (ty * G + tx, raster order), tile_count (T)
-    int32, max, origin (T,2) int32, G."""
+    levels 0 and 1, three at levels 2 and 3, a 2x2 max pool between levels (model/vgg.py:26-33).  Tiles are tile_sides[L] pixels square:
+    16 (one workgroup of csrc/conv.hip) at the fine levels, 8 (one WAVE of a workgroup) at S/4 and S/8, where a hand is a few tiles across
+    and a 16-pixel grid spends its tiles on the rim (level 0 stays at 16: the image-side kernels sit on that grid).  shift_grid: every
+    frame's tile grid is shifted by the EVEN origin (oy, ox) in [0, side - 2]^2 that needs the fewest tiles (tile (ty, tx) = pixels
+    [side ty - oy, +side) x [side tx - ox, +side)): the tiles hug the region instead of straddling it.
+    Returns per level: tiles (T, G*G) int32 0/1 with G = ceil(S_L / side) + 1, tile_list (T, max) int32 (ty * G + tx, raster order),
+    tile_count (T) int32, max, origin (T,2) int32, G, side."""
     F = torch.nn.functional
     d = (mask > 0).float()[:, None]
     out = []
     for level, grow in enumerate((2, 2, 3, 3)):
+        side = int(tile_sides[level])
+        if side not in (8, 16) or (level == 0 and side != 16) or (level and side > int(tile_sides[level - 1])):
+            raise ValueError("active_tiles: tile sides are 8 or 16 pixels, 16 at level 0, and no 16 at a coarser level than an 8")
         if level:
             d = F.max_pool2d(d, 2, 2)
         d = F.max_pool2d(d, 2 * grow + 1, 1, grow)
         T, s = d.shape[0], d.shape[-1]
-        G = (s + 15) // 16 + 1
-        d2 = F.max_pool2d(d, 2, 2, ceil_mode=True)                         # even origins: work on 2x2 blocks, tiles of 8 blocks
+        G = (s + side - 1) // side + 1
+        h = side // 2                                                       # even origins: work on 2x2 blocks, tiles of side / 2 blocks
+        d2 = F.max_pool2d(d, 2, 2, ceil_mode=True)
         best_n = torch.full((T,), 1 << 30, dtype=torch.int64, device=d.device)
         best_t = torch.zeros(T, G, G, dtype=torch.bool, device=d.device)
         best_o = torch.zeros(T, 2, dtype=torch.int32, device=d.device)
-        for oy in (range(8) if shift_grid else (0,)):
-            for ox in (range(8) if shift_grid else (0,)):
-                p = F.pad(d2, (ox, 8 * G - ox - d2.shape[-1], oy, 8 * G - oy - d2.shape[-2]))
-                t = F.max_pool2d(p, 8, 8)[:, 0] > 0                         # (T, G, G)
+        for oy in (range(h) if shift_grid else (0,)):
+            for ox in (range(h) if shift_grid else (0,)):
+                p = F.pad(d2, (ox, h * G - ox - d2.shape[-1], oy, h * G - oy - d2.shape[-2]))
+                t = F.max_pool2d(p, h, h)[:, 0] > 0                         # (T, G, G)
                 n = t.reshape(T, -1).sum(1)
                 better = n < best_n
                 best_n = torch.where(better, n, best_n)
@@ -65,8 +74,13 @@ def active_tiles(mask, shift_grid=True):
         count = flat.sum(1).int()
         mx = max(int(count.max()), 1)
         order = torch.argsort((~flat).int(), dim=1, stable=True)[:, :mx].int()      # active tiles first, in raster order
-        out.append((flat.int().contiguous(), order.contiguous(), count.contiguous(), mx, best_o.contiguous(), G))
+        out.append((flat.int().contiguous(), order.contiguous(), count.contiguous(), mx, best_o.contiguous(), G, side))
     return out
+
+
+def active_share(bound, S):
+    """share of each level's image area inside the active tiles of active_tiles()"""
+    return [float(b[2].float().sum()) * b[6] ** 2 / (b[0].shape[0] * float(S >> lv) ** 2) for lv, b in enumerate(bound)]
 
 
 class Vgg16Hip:
@@ -145,9 +159,9 @@ class Vgg16Hip:
         if bound is not None:
             for k, slot in INPUT_SLOT.items():
                 t.target_in[k] = _lib.ptr(target[slot])
-            for lv, (tiles, order, count, mx, origin, pitch) in enumerate(bound):
+            for lv, (tiles, order, count, mx, origin, pitch, side) in enumerate(bound):
                 t.tiles[lv], t.tile_list[lv], t.tile_count[lv], t.max_tiles[lv] = _lib.ptr(tiles), _lib.ptr(order), _lib.ptr(count), mx
-                t.tile_origin[lv], t.tile_pitch[lv] = _lib.ptr(origin), pitch
+                t.tile_origin[lv], t.tile_pitch[lv], t.tile_side[lv] = _lib.ptr(origin), pitch, side
         t.target_by_row, t.covered, t.g_rgb, t.weight, t.loss = int(target_by_row), _lib.ptr(covered), _lib.ptr(g_rgb), float(weight), _lib.ptr(loss)
         t.N, t.S, t.ws = N, S, _lib.ptr(self.workspace(N, S, True))
         for i, st in enumerate(list(side_streams)[:3]):          # the batch in len + 1 parts on as many streams (include/harp_hip.h)
@@ -225,4 +239,4 @@ class Vgg16Rows(torch.autograd.Function):
         return g_x + out[..., :3].permute(0, 3, 1, 2), None
 
 
-__all__ = ["Vgg16Hip", "Vgg16Rows", "tap_shapes", "activation_shapes", "active_tiles", "feature_length"]
+__all__ = ["Vgg16Hip", "Vgg16Rows", "tap_shapes", "activation_shapes", "active_tiles", "active_share", "TILE_SIDES", "feature_length"]

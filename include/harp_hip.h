@@ -633,6 +633,11 @@ typedef struct harp_conv3x3_args {
   const int32_t* in_valid_origin;   /* (T,2) of the producer's grid */
   const int32_t* out_valid_origin;  /* (T,2) of `out`'s grid */
   int tile_pitch, in_valid_pitch, out_valid_pitch;
+  /* tiles of 8x8 pixels (the coarse levels of the perceptual term, where a hand is a few tiles across): tile_side = 8 — tile_list / tile_origin /
+   * tile_pitch then describe a grid of 8-pixel tiles and a workgroup computes four of them (one per wave); 0 or 16 = the 16x16 form.
+   * in_valid_cell: side of in_valid's cells in INPUT pixels when the producer's tiles are not 16 pixels (4 — only with tile_side 8 —, 8, 16;
+   * 0 = 8 << in_valid_shift; in_valid_shift still says whether the producer sits behind a pool).  out_valid_cell: side of `out`'s tiles (8 or 16; 0 = 16). */
+  int tile_side, in_valid_cell, out_valid_cell;
 } harp_conv3x3_args;
 size_t harp_conv3x3_filter_bytes(int Cout, int Cin);
 int harp_conv3x3_pack_filters(const float* w, int Cout, int Cin, int transpose, int precision, void* packed, hipStream_t stream);
@@ -687,6 +692,7 @@ typedef struct harp_vgg16_term_args {
   int max_tiles[4];
   const int32_t* tile_origin[4];   /* (T,2) even (oy, ox) per frame and level: tile (ty, tx) covers pixels [16 ty - oy, +16) x [16 tx - ox, +16) */
   int tile_pitch[4];               /* tiles per row (= rows) of tiles[L]; tile_list[L] entries are ty * pitch + tx */
+  int tile_side[4];                /* side of level L's tiles in pixels: 16 (0 = 16) or 8; 16 at level 0, and never 16 behind (coarser than) an 8 */
   void* side_streams[3];           /* up to three more hipStream_t (NULL-terminated).  With k of them (and rows, target_by_row) the term runs as k + 1
                                     * parts of the batch, part i > 0 on side_streams[i - 1], forked from and joined back into `stream` by events
                                     * (capturable): the chains of 21 dependent launches fill each other's partly filled last rounds of workgroups.

@@ -72,7 +72,7 @@ def test_no_silent_random_fallback():
 
 def test_active_tiles_cover_every_feature_difference():
     """the premise of the perceptual term's bounded mode (harp_amd/model/vgg_hip.active_tiles, csrc/conv.hip): vgg(a * mask) and vgg(b * mask)
-    can differ only inside the 16x16 tiles the mask's support reaches through the receptive field — at EVERY one of the ten convolutions, not
+    can differ only inside the tiles (16 or 8 pixels a side per level) the mask's support reaches through the receptive field — at EVERY one of the ten convolutions, not
     only at the four taps (checked with the torch module on the CPU; levels = image side S, S/2, S/4, S/8)"""
     from harp_amd.model.vgg import Vgg16Features
     from harp_amd.model.vgg_hip import active_tiles
@@ -84,31 +84,33 @@ def test_active_tiles_cover_every_feature_difference():
     mask[1, 0:20, 70:96] = (torch.rand(20, 26, generator=g) > 0.5).double()
     a, b = torch.rand(2, S, S, 3, generator=g, dtype=torch.float64), torch.rand(2, S, S, 3, generator=g, dtype=torch.float64)
     xa, xb = (a * mask[..., None]).permute(0, 3, 1, 2), (b * mask[..., None]).permute(0, 3, 1, 2)
-    bound = active_tiles(mask)
-    level, ha, hb, checked = 0, xa, xb, 0
-    with torch.no_grad():
-        for n in range(1, 5):
-            for layer in getattr(vgg, f"slice{n}"):
-                ha, hb = layer(ha), layer(hb)
-                if isinstance(layer, torch.nn.MaxPool2d):
-                    level += 1
-                if not isinstance(layer, torch.nn.ReLU):
-                    continue
-                tiles, order, count, mx, origin, G = bound[level]
-                differs = (ha != hb).any(1)                                    # (2, s, s)
-                assert differs.any()
-                for f in range(2):
-                    ys, xs = torch.nonzero(differs[f], as_tuple=True)
-                    cell = ((ys + origin[f, 0]) // 16) * G + (xs + origin[f, 1]) // 16          # tile (ty, tx) covers [16 ty - oy, +16) x [16 tx - ox, +16)
-                    assert tiles[f][cell].all(), (n, level, f)
-                    assert origin[f, 0] % 2 == 0 and origin[f, 1] % 2 == 0 and 0 <= origin[f].min() and origin[f].max() <= 14
-                    # the lists hold exactly the flagged tiles, in raster order
-                    assert order[f, :count[f]].tolist() == torch.nonzero(tiles[f]).flatten().tolist()
-                checked += 1
-    assert checked == 10 and bound[0][2][0] <= 4                               # (frame 0: a few pixels -> at most 2 x 2 level-0 tiles)
-    # the shifted grid never needs more tiles than the aligned one
-    for (a, b) in zip(bound, active_tiles(mask, shift_grid=False)):
-        assert (a[2] <= b[2]).all() and (b[4] == 0).all()
+    for sides in ((16, 16, 8, 8), (16, 16, 16, 16), (16, 8, 8, 8)):
+        bound = active_tiles(mask, tile_sides=sides)
+        level, ha, hb, checked = 0, xa, xb, 0
+        with torch.no_grad():
+            for n in range(1, 5):
+                for layer in getattr(vgg, f"slice{n}"):
+                    ha, hb = layer(ha), layer(hb)
+                    if isinstance(layer, torch.nn.MaxPool2d):
+                        level += 1
+                    if not isinstance(layer, torch.nn.ReLU):
+                        continue
+                    tiles, order, count, mx, origin, G, side = bound[level]
+                    assert side == sides[level]
+                    differs = (ha != hb).any(1)                                    # (2, s, s)
+                    assert differs.any()
+                    for f in range(2):
+                        ys, xs = torch.nonzero(differs[f], as_tuple=True)
+                        cell = ((ys + origin[f, 0]) // side) * G + (xs + origin[f, 1]) // side      # tile (ty, tx) covers [side ty - oy, +side) x [side tx - ox, +side)
+                        assert tiles[f][cell].all(), (n, level, f)
+                        assert origin[f, 0] % 2 == 0 and origin[f, 1] % 2 == 0 and 0 <= origin[f].min() and origin[f].max() <= side - 2
+                        # the lists hold exactly the flagged tiles, in raster order
+                        assert order[f, :count[f]].tolist() == torch.nonzero(tiles[f]).flatten().tolist()
+                    checked += 1
+        assert checked == 10 and bound[0][2][0] <= 4                               # (frame 0: a few pixels -> at most 2 x 2 level-0 tiles)
+        # the shifted grid never needs more tiles than the aligned one
+        for (a, b) in zip(bound, active_tiles(mask, shift_grid=False, tile_sides=sides)):
+            assert (a[2] <= b[2]).all() and (b[4] == 0).all()
 
 
 def test_module_reproduces_the_reference_modules_golden_rows(golden_dir):

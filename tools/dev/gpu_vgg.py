@@ -31,7 +31,7 @@ for name, kw in (("f32 bounded", dict()), ("f32 full, taps cached", dict(bounded
     t_set = time.perf_counter() - t0
     ms = time_steps(eng)
     if eng._vgg_bound is not None:
-        frac = [float(b[2].float().sum()) / (b[0].shape[0] * ((eng.S >> lv) / 16.0) ** 2) for lv, b in enumerate(eng._vgg_bound)]
+        frac = [float(b[2].float().sum()) * b[6] ** 2 / (b[0].shape[0] * float(eng.S >> lv) ** 2) for lv, b in enumerate(eng._vgg_bound)]
         name += " (tiles %s)" % "/".join("%.2f" % f for f in frac)
     print("%-26s %8.2f ms/step  (set_perceptual %.2f s, peak mem %.1f GB, vgg loss %.5f)" %
           (name, ms, t_set, torch.cuda.max_memory_allocated() / 2**30, eng.losses()["vgg"]), flush=True)
