@@ -410,7 +410,7 @@ def perceptual_rate(device, weights, steps=6, warmup=2):
             e.step(None, True, True)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / steps
-        # bounded mode: the stack runs in the 16x16 tiles the mask's support reaches (harp_amd/model/vgg_hip.active_tiles): executed flop =
+        # bounded mode: the stack runs in the tiles (16 px a side, 8 at S/4 and S/8) the mask's support reaches (harp_amd/model/vgg_hip.active_tiles): executed flop =
         # per-level flop x the level's share of active tiles over the batch's frames
         done, tiles = flop, None
         if e._vgg_bound is not None:

@@ -867,7 +867,7 @@ int harp_vgg16_term(const harp_vgg16* net, const harp_vgg16_term_args* t, hipStr
   if (nside > N - 1) nside = N - 1;
   const bool split = nside > 0 && t->rows != nullptr && t->target_by_row;
   if (!split) return run(0, N, vgg_ws_split(t->ws, N, S, 1), stream, true);
-  static hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
+  static thread_local hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};      // (per host thread: one term is enqueued at a time per thread)
   if (!ev_fork) {
     bool ok = hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) == hipSuccess;
     for (int i = 0; i < 3; ++i) ok = ok && hipEventCreateWithFlags(&ev_join[i], hipEventDisableTiming) == hipSuccess;

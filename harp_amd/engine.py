@@ -944,7 +944,7 @@ class FitEngine:
         The target frames' features do not change during a fit; what is kept in HBM depends on `cache_bytes`:
           * ALL 13 activation maps of every resident frame (300 floats per pixel, 307 MB per 512x512 frame — 256 frames are 79 GB of the
             288 GB) -> `bounded` mode: y_pred * mask and y_true * mask are identical outside the mask's support, so the stack runs only in
-            the 16x16 tiles the support reaches through the receptive field and reads the cached target activations next to them
+            the tiles (16 pixels a side, 8 at S/4 and S/8) the support reaches through the receptive field and reads the cached target activations next to them
             (same loss and gradient; csrc/conv.hip, model/vgg_hip.active_tiles);
           * else the four tap maps (126 MB per frame): one full forward + backward over the B rendered images per step;
           * else nothing: every step also recomputes the target features of its B frames."""

@@ -655,7 +655,7 @@ int harp_conv3x3(const harp_conv3x3_args* a, hipStream_t stream);
  *   d = 1,1,2,2,4,4,4,8,8,8; out[10..12] = the three pooled maps (N,S/2,S/2,64), (N,S/4,S/4,128), (N,S/8,S/8,256).  The four taps
  *   out[1], out[3], out[6], out[9] (relu1_2 ... relu4_3) are required, the others may be NULL (kept in ws only).
  * Bounded mode of harp_vgg16_term (tiles[0] != NULL; needs target_by_row and the cache of ALL activations): the stack runs only in the
- *   16x16 tiles of each resolution level (L = 0..3, side S >> L) where the rendered image's activations can differ from the target
+ *   tiles (tile_side[L]: 16 pixels a side, or 8) of each resolution level (L = 0..3, side S >> L) where the rendered image's activations can differ from the target
  *   frame's — tiles[L] (T, tile_pitch[L]^2) 0/1 per frame over a tile grid shifted by the frame's tile_origin[L] (so that the tiles hug the
  *   active region), tile_list[L] (T, max_tiles[L]) their indices, tile_count[L] (T): the support
  *   of mask grown by the receptive field (the caller's set-up, harp_amd/model/vgg_hip.py).  Elsewhere pred == target exactly: the L1
