@@ -31,15 +31,15 @@ def activation_shapes(S):
     return [(S // d, S // d, c) for d, c in zip(_DIV, _COUT)] + [(S // 2, S // 2, 64), (S // 4, S // 4, 128), (S // 8, S // 8, 256)]
 
 
-TILE_SIDES = (16, 16, 8, 8)                   # side of a tile of active_tiles() per resolution level
+TILE_SIDES = (16, 8, 8, 8)                    # side of a tile of active_tiles() per resolution level (S/2 at 8 too: -1.3 % of the term's time)
 
 
 def active_tiles(mask, shift_grid=True, tile_sides=TILE_SIDES):
     """The tiles of each resolution level (side S >> L, L = 0..3) in which activations of image * mask can differ between two images
     sharing `mask` (T,S,S): the support of the mask grown by the receptive field of the level's last convolution — two 3x3 convolutions at
     levels 0 and 1, three at levels 2 and 3, a 2x2 max pool between levels (model/vgg.py:26-33).  Tiles are tile_sides[L] pixels square:
-    16 (one workgroup of csrc/conv.hip) at the fine levels, 8 (one WAVE of a workgroup) at S/4 and S/8, where a hand is a few tiles across
-    and a 16-pixel grid spends its tiles on the rim (level 0 stays at 16: the image-side kernels sit on that grid).  shift_grid: every
+    16 (one workgroup of csrc/conv.hip) at full resolution, 8 (one WAVE of a workgroup) below, where a hand is a few tiles across and a
+    16-pixel grid spends its tiles on the rim (level 0 stays at 16: the image-side kernels sit on that grid).  shift_grid: every
     frame's tile grid is shifted by the EVEN origin (oy, ox) in [0, side - 2]^2 that needs the fewest tiles (tile (ty, tx) = pixels
     [side ty - oy, +side) x [side tx - ox, +side)): the tiles hug the region instead of straddling it.
     Returns per level: tiles (T, G*G) int32 0/1 with G = ceil(S_L / side) + 1, tile_list (T, max) int32 (ty * G + tx, raster order),

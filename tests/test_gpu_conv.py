@@ -184,7 +184,7 @@ def test_whole_term_against_torch_autograd(precision):
 
 @pytest.mark.parametrize("precision", [0, 1])
 def test_bounded_term_equals_the_full_pass(precision):
-    """harp_vgg16_term's bounded mode (the stack runs only in the tiles — 16 pixels a side at S and S/2, 8 at S/4 and S/8 by default — the mask's support reaches through the receptive field, and
+    """harp_vgg16_term's bounded mode (the stack runs only in the tiles — 16 pixels a side at S, 8 below by default — the mask's support reaches through the receptive field, and
     reads the cached TARGET activations next to them) against the full pass on the same inputs: same loss, same gradient — and both against
     torch's float64 autograd.  Masks with a small support (few active tiles at the three finer levels), a support touching the image border,
     and an empty mask."""
@@ -228,9 +228,9 @@ def test_bounded_term_equals_the_full_pass(precision):
         assert abs(res[name][0] - want.item()) < 2e-5 * want.item() and rel < (2e-3, 6e-2)[precision]
     assert abs(res["full"][0] - res["bounded"][0]) < 1e-6 * res["full"][0]
     assert torch.equal(res["full"][1], res["bounded"][1])            # tile by tile the same arithmetic on the same inputs
-    # the other mixes of 16- and 8-pixel tile grids over the levels (the default is 16, 16, 8, 8;  8: four independent tiles per workgroup, one per wave; validity cells of 4, 8 and
+    # the other mixes of 16- and 8-pixel tile grids over the levels (the default is 16, 8, 8, 8;  8: four independent tiles per workgroup, one per wave; validity cells of 4, 8 and
     # 16 input pixels; the un-pool routing into either kind of grid): the same bits as the full pass
-    for sides in ((16, 16, 16, 16), (16, 8, 8, 8), (16, 16, 16, 8)):
+    for sides in ((16, 16, 16, 16), (16, 16, 8, 8), (16, 16, 16, 8)):
         for shift in (True, False):
             bd = active_tiles(mask_d, shift_grid=shift, tile_sides=sides)
             g_rgb = torch.zeros(N, S, S, 3, device=DEV)

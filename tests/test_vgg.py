@@ -84,7 +84,7 @@ def test_active_tiles_cover_every_feature_difference():
     mask[1, 0:20, 70:96] = (torch.rand(20, 26, generator=g) > 0.5).double()
     a, b = torch.rand(2, S, S, 3, generator=g, dtype=torch.float64), torch.rand(2, S, S, 3, generator=g, dtype=torch.float64)
     xa, xb = (a * mask[..., None]).permute(0, 3, 1, 2), (b * mask[..., None]).permute(0, 3, 1, 2)
-    for sides in ((16, 16, 8, 8), (16, 16, 16, 16), (16, 8, 8, 8)):
+    for sides in ((16, 8, 8, 8), (16, 16, 16, 16), (16, 16, 8, 8)):
         bound = active_tiles(mask, tile_sides=sides)
         level, ha, hb, checked = 0, xa, xb, 0
         with torch.no_grad():
