@@ -2052,6 +2052,13 @@ def test_texel_reduce_and_finish_raw_abi_against_grid_sample_autograd(hw):
     torch.cuda.synchronize()
     assert int((acc != 0).sum()) == 0
     assert rel(g_tex.double().cpu(), want_t) < 2e-7 and rel(g_nm.double().cpu(), want_n) < 2e-6, (rel(g_tex.double().cpu(), want_t), rel(g_nm.double().cpu(), want_n))
+    # the launch shape for large jobs (expected_records > 2 M: two workgroups per CU): the same sums
+    cnt_d.copy_(cnt.to(DEV))
+    _lib.check(L.harp_texel_reduce(p(rec_d), p(cnt_d), cap, H, W, p(acc[0]), p(acc[1]), 10_000_000, st()), "reduce (large-job shape)")
+    torch.cuda.synchronize()
+    a1 = acc[0].view(H, W, 3).cpu()
+    assert ((a1 - a0).abs().max() / want_t.abs().max()).item() < 1e-12 and int(cnt_d.abs().max()) == 0      # (exact sums either way; the double maps add them in another order)
+    acc.zero_()
     # frozen maps: a NULL accumulator leaves that map out
     cnt_d.copy_(cnt.to(DEV))
     _lib.check(L.harp_texel_reduce(p(rec_d), p(cnt_d), cap, H, W, p(acc[0]), None, 0, st()), "reduce (texture only)")
