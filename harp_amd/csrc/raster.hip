@@ -8,11 +8,11 @@
 //                   blur-dilated bbox; culled faces get an empty box.
 //   2. bin_faces    one workgroup per (frame, 64x64 super-tile): scan the frame's bboxes (coalesced float4),
 //                   wave-ballot compaction -> ascending face-id list in HBM/L2 (deterministic, no atomics).
-//   3. raster       one workgroup (4 waves) per 16x16 tile, one pixel per lane (wave = 16x4 strip).
-//                   Stages the tile's faces into LDS (SoA float4, broadcast reads), each wave ballots the
-//                   staged faces against its own strip and walks only the hits.  Per pixel, in registers:
-//                   nearest-z face (K=1 semantics, ties -> lower face id like PyTorch3D) and the running
-//                   silhouette product prod_f (1 - sigmoid(-d_f/sigma)).
+//   3. raster       one workgroup (4 waves) per 16x16 tile.  Stages the tile's faces into LDS (SoA float4); the hard pass walks the (staged face,
+//                   bbox pixel) pairs densely packed over the lanes (prefix sum over the clipped bbox sizes) and keeps the nearest face per
+//                   pixel as a 64-bit LDS min over (depth bits, face id) (K=1 semantics, ties -> lower face id like PyTorch3D), flagging the
+//                   pixels a face saturates; the soft pass pairs the remaining pixels with the faces near them and multiplies the silhouette
+//                   product prod_f (1 - sigmoid(-d_f/sigma)) in ascending face order (raster_body.h).
 //   4. sil_bwd      same walk, rim pixels only: dL/dalpha -> dL/d(ndc xy) of the face vertices (atomics).
 #include <stdlib.h>
 #include "raster_body.h"

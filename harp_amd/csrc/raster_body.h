@@ -287,10 +287,8 @@ __device__ __forceinline__ void raster_tile(RasterSmem<MODE, BWD>& sm, unsigned 
     }
     __syncthreads();
     if constexpr (kScan) {
-      // ---- face scan (hard K = 1 pass): a 16-lane group owns one staged face at a time and visits only the pixels of its bbox, as
-      //      4x4 blocks; the nearest face of a pixel is a 64-bit LDS min over (depth bits, face id) — the same (pixel, face) pairs,
-      //      the same depth expression and the same tie-break (lower id) as the strip walk below, where every face of a strip's hit
-      //      list was classified by all 64 lanes of the strip (~8 % of them inside its bbox).
+      // ---- face scan (hard K = 1 pass): the nearest face of a pixel is a 64-bit LDS min over (depth bits, face id) — the depth expression and
+      //      the tie-break (lower id) of PyTorch3D's K = 1 rasterisation.
       // DENSE PACKING: the walk visits (staged face, pixel of its bbox clipped to the tile) pairs, one pair per lane, every lane busy: the
       // pairs are numbered face after face (a prefix sum over the faces' clipped bbox sizes), a wave owns a contiguous quarter of the
       // numbers and tracks the face its first lane is in; the starts of the next 64 faces sit in one register across the wave, and a lane's
