@@ -9,7 +9,7 @@ mkdir -p harp_amd/csrc/variants
 F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -Wno-unused-result -DNDEBUG -I include"
 SRC=${3:-shade}
 PATCH=$4
-EXTRA=""; [ "$SRC" = "shade_bwd" ] && EXTRA="-fno-slp-vectorize"
+EXTRA=""; [ "$SRC" = "shade_bwd" ] && EXTRA="-fno-slp-vectorize -mllvm --amdgpu-sched-strategy=max-memory-clause"
 DIR=harp_amd/csrc
 if [ -n "$PATCH" ]; then
   DIR=$(mktemp -d)/harp_amd/csrc; mkdir -p $DIR; cp harp_amd/csrc/*.hip harp_amd/csrc/*.h $DIR/
