@@ -20,7 +20,9 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-mun
 # (155 -> 122 VGPRs together with the reload of the face data in its backward half: 3 -> 4 waves per SIMD, no scratch)
 # ... and the "max-memory-clause" machine scheduler (loads grouped into clauses ahead of their uses) instead of the default: same registers, same
 # results, step -2.4 us in 8 of 8 pairs of runs (profiles/r06_ab_record.txt 26; "max-ilp": shader backward 0.190 -> 0.214 ms)
-FILE_FLAGS = {"shade_bwd.hip": ["-fno-slp-vectorize", "-mllvm", "--amdgpu-sched-strategy=max-memory-clause"]}
+# conv.hip: the same scheduler, float32 perceptual term 30.53 30.54 30.53 -> 30.10 30.04 30.09 ms (bf16 split unchanged); the other files: no effect
+_MEM_CLAUSE = ["-mllvm", "--amdgpu-sched-strategy=max-memory-clause"]
+FILE_FLAGS = {"shade_bwd.hip": ["-fno-slp-vectorize"] + _MEM_CLAUSE, "conv.hip": _MEM_CLAUSE}
 
 
 def sources():
