@@ -22,7 +22,9 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-mun
 # results, step -2.4 us in 8 of 8 pairs of runs (profiles/r06_ab_record.txt 26; "max-ilp": shader backward 0.190 -> 0.214 ms)
 # conv.hip: the same scheduler, float32 perceptual term 30.53 30.54 30.53 -> 30.10 30.04 30.09 ms (bf16 split unchanged); the other files: no effect
 _MEM_CLAUSE = ["-mllvm", "--amdgpu-sched-strategy=max-memory-clause"]
-FILE_FLAGS = {"shade_bwd.hip": ["-fno-slp-vectorize"] + _MEM_CLAUSE, "conv.hip": _MEM_CLAUSE}
+# raster.hip: without the SLP vectoriser as well — the three tile kernels are VALU-issue-bound and register-tight (camera view 72 VGPRs with 12 B
+# of scratch): light view 58 -> 52 VGPRs, silhouette backward's scratch gone; camera group 0.164 -> 0.160 ms, light 0.086 -> 0.082, step -10 us (4 of 4)
+FILE_FLAGS = {"shade_bwd.hip": ["-fno-slp-vectorize"] + _MEM_CLAUSE, "conv.hip": _MEM_CLAUSE, "raster.hip": ["-fno-slp-vectorize"]}
 
 
 def sources():

@@ -10,6 +10,8 @@ F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -Wno-unused-re
 SRC=${3:-shade}
 PATCH=$4
 EXTRA=""; [ "$SRC" = "shade_bwd" ] && EXTRA="-fno-slp-vectorize -mllvm --amdgpu-sched-strategy=max-memory-clause"
+[ "$SRC" = "raster" ] && EXTRA="-fno-slp-vectorize"
+[ "$SRC" = "conv" ] && EXTRA="-mllvm --amdgpu-sched-strategy=max-memory-clause"
 DIR=harp_amd/csrc
 if [ -n "$PATCH" ]; then
   DIR=$(mktemp -d)/harp_amd/csrc; mkdir -p $DIR; cp harp_amd/csrc/*.hip harp_amd/csrc/*.h $DIR/
