@@ -777,10 +777,12 @@ __device__ __forceinline__ void shade_bwd_tile(ShadeSmem<REC>& sm, unsigned vblo
   }
 }
 
-// (launch-bounds hint of the record form: 120 VGPRs = 4 waves per SIMD whatever the hint says; with 3 hipcc schedules the same registers a little
-//  better — step -2.5 us in 4 of 4 fresh-process pairs, -5 sustained; 5 = 96 VGPRs + 51 spills: +40 us.  profiles/r06_ab_record.txt item 10)
+// (launch-bounds hint of the record form: 120 - 122 VGPRs = 4 waves per SIMD whatever the hint says; with a lower hint hipcc schedules the same
+//  registers a little better — 3 instead of 4: step -2.5 us in 4 of 4 fresh-process pairs under the default scheduler; 2 instead of 3 under the
+//  max-memory-clause scheduler (harp_amd/build.py): -3 us, better in 6 of 8 pairs, 2 ties; 5 = 96 VGPRs + 51 spills: +40 us.
+//  profiles/r06_ab_record.txt items 10, 28)
 #ifndef SHADE_REC_OCC
-#define SHADE_REC_OCC 3
+#define SHADE_REC_OCC 2
 #endif
 template <bool IMG, bool REC>
 __global__ void __launch_bounds__(256, REC ? SHADE_REC_OCC : SHADE_BWD_OCC) shade_bwd_wave_kernel(const harp_shade_args A, const int32_t* __restrict__ order,
